@@ -1,0 +1,256 @@
+/*
+ * kmernator_amd.h -- C-ABI of the MI355X-native k-mer spectrum builder.
+ *
+ * This is the drop-in boundary for ONE path of JGI-Bioinformatics/Kmernator:
+ * the FilterReads / KmerSpectrum k-mer-spectrum build and lookup.  Every entry
+ * point below names the reference interface it replaces (path:line under the
+ * reference checkout).  The reference has no FFI of its own -- the boundary is
+ * a compile-time C++ template API -- so the C++ shim a maintainer adds on the
+ * Kmernator side (a KmerSpectrum<> subclass that calls these functions and
+ * restore()s the returned images into the reference's own map types) is shown
+ * in INTEGRATION.md and shipped as include/kmernator_amd_shim.hpp.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary.
+ *   - every function returns 0 on success or a negative kmr_status; the text
+ *     of the last error of a handle is kmr_last_error(h) (thread-unsafe, like
+ *     the reference's maps, src/Kmer.h:2269 "bucket ownership" model).
+ *   - all in/out buffers are caller owned.  "host" pointers are ordinary
+ *     memory; "dev" pointers are HIP device memory of the handle's device.
+ *   - k is per handle (the reference keeps it in the process-global KmerSizer,
+ *     src/Kmer.h:83-127).
+ *   - packed k-mers use the reference byte layout (TwoBitSequence,
+ *     src/TwoBitSequence.cpp:242-269): 4 bases per byte, first base in bits
+ *     7..6, A=0 C=1 G=2 T=3, kb = ceil(k/4) bytes, pad bits zero.
+ *   - there is NO CPU fallback: if the HIP device or the code object is
+ *     missing every compute entry point fails with KMR_ERR_NO_DEVICE.
+ */
+#ifndef KMERNATOR_AMD_H_
+#define KMERNATOR_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMR_ABI_VERSION 1
+
+typedef enum kmr_status {
+	KMR_OK = 0,
+	KMR_ERR_INVALID_ARG = -1,
+	KMR_ERR_NO_DEVICE = -2,   /* no HIP device / kernel image not loadable */
+	KMR_ERR_HIP = -3,         /* a HIP runtime call failed                  */
+	KMR_ERR_OOM = -4,         /* device or host allocation failed           */
+	KMR_ERR_STATE = -5,       /* call not valid in the handle's state       */
+	KMR_ERR_CAPACITY = -6,    /* a caller supplied buffer is too small      */
+	KMR_ERR_UNSUPPORTED = -7  /* option not built (e.g. solid map)          */
+} kmr_status;
+
+/* Value type families of the reference's maps (src/KmerTrackingData.h).
+ * COUNT_DIR: weak = TrackingDataWithDirection (12 B: u16 count @0, f32
+ *            weightedCount @4, u16 directionBias @8; :491-551), singleton =
+ *            TrackingDataSingleton (1 B; :613-686).   [FilterReads(-P)]
+ * EXT:       weak = ExtensionTrackingData (60 B = the 12 B above + u32
+ *            [Left,Right][A,C,G,T,N,X]; :1027-1074), singleton =
+ *            ExtensionTrackingDataSingleton (5 B; :1078-1126). [MeraculousCounter] */
+typedef enum kmr_value_kind { KMR_VALUE_COUNT_DIR = 0, KMR_VALUE_EXT = 1 } kmr_value_kind;
+
+/* Which of the spectrum's maps (src/KmerSpectrum.h:396-403). */
+typedef enum kmr_map { KMR_MAP_WEAK = 0, KMR_MAP_SINGLETON = 1, KMR_MAP_SOLID = 2 } kmr_map;
+
+/* Replaces the option singletons read on this path:
+ * KmerSizer::set (src/Kmer.h:107), KmerSpectrumOptions (src/KmerSpectrum.h:92-139),
+ * GeneralOptions min-quality-score / fastq-base-quality (src/Options.h:327-331),
+ * ExtensionTracking::setMinQuality (src/KmerTrackingData.h:157-163) and the bucket
+ * sizing of the KmerSpectrum constructor (src/KmerSpectrum.h:414-421, src/Kmer.h:2837,2224). */
+typedef struct kmr_config {
+	uint32_t struct_size;            /* = sizeof(kmr_config), ABI guard                       */
+	uint32_t k;                      /* k-mer length in bases, 1..128                          */
+	uint64_t num_buckets_weak;       /* 0 => derive from estimated_raw_kmers like the ctor     */
+	uint64_t num_buckets_singleton;  /* 0 => derive; both rounded up to a power of two <= 2^26 */
+	uint64_t estimated_raw_kmers;    /* KmerSpectrum::estimateRawKmers() of the caller         */
+	uint32_t value_kind;             /* kmr_value_kind                                         */
+	float    min_weight;             /* --min-kmer-quality (TrackingData::minimumWeight), 0.10 */
+	uint32_t min_quality_score;      /* --min-quality-score, 3 (MeraculousCounter: 2)          */
+	uint32_t fastq_start_char;       /* Phred base of the quals handed in: 33 or 64            */
+	uint32_t ext_min_quality;        /* ExtensionTracking min quality, 20                      */
+	uint32_t separate_singletons;    /* 1 = reference default (hasSingletons)                  */
+	uint32_t kmer_subsample;         /* --kmer-subsample; keep k-mer iff hash % n == 0; 1=all  */
+	int32_t  device;                 /* HIP device ordinal; -1 = current                       */
+	uint32_t rank;                   /* owner partition of this handle ...                     */
+	uint32_t world_size;             /* ... out of world_size (1 = single partition)           */
+	double   estimated_depth;        /* --estimated-depth, 20 (used only to derive buckets)    */
+	double   estimated_error_rate;   /* --estimated-error-rate, 0.35 (ditto)                   */
+	uint32_t kmers_per_bucket;       /* --kmers-per-bucket, 32 (ditto)                         */
+	uint32_t num_parts;              /* --build-partitions: keep k-mers whose                  */
+	uint32_t part_idx;               /*   getDMPThread(kmer,num_parts)==part_idx; 0/1 = all    */
+	uint32_t reserved0;
+	uint64_t max_table_entries;      /* 0 = size from estimated_raw_kmers; else distinct-key
+	                                    capacity of the device table                           */
+} kmr_config;
+
+typedef struct kmr_handle kmr_handle;
+
+/* Counters of KmerSpectrum (src/KmerSpectrum.h:405-409,455-459) and of
+ * TrackingData::discarded (src/KmerTrackingData.h:354-364). */
+typedef struct kmr_stats {
+	uint64_t raw_kmers;        /* every k-mer occurrence offered to append()                  */
+	uint64_t raw_good_kmers;   /* occurrences that passed the weight test                     */
+	uint64_t unique_kmers;     /* distinct k-mers ever seen (weak + singleton)                */
+	uint64_t singleton_kmers;  /* distinct k-mers seen exactly once                           */
+	uint64_t discarded;        /* occurrences with weight <= min_weight                       */
+	uint64_t weak_entries;     /* entries now in the weak map (after finalize: after purge)   */
+	uint64_t singleton_entries;/* entries now in the singleton map                            */
+	uint64_t reads;            /* reads consumed (discarded reads included)                   */
+} kmr_stats;
+
+/* Fill *cfg with the reference defaults listed above (k must still be set). */
+int kmr_config_init(kmr_config *cfg);
+
+/* Create / destroy.  Replaces KmerSpectrum(estimatedRawKmers, separateSingletons)
+ * (src/KmerSpectrum.h:414-421) and DistributedKmerSpectrum(world, ...)
+ * (src/DistributedFunctions.h:126-131); the handle owns all device memory. */
+int  kmr_create(const kmr_config *cfg, kmr_handle **out);
+void kmr_destroy(kmr_handle *h);
+const char *kmr_last_error(const kmr_handle *h);   /* h may be NULL: creation errors */
+
+/* Effective bucket counts after power-of-two rounding (BucketExposedMapLogic::
+ * resizeBuckets, src/Kmer.h:2224-2236). */
+int kmr_num_buckets(const kmr_handle *h, int which_map, uint64_t *out);
+
+/* Feed one batch of reads.  Replaces the per-read body of
+ * KmerSpectrum::_buildKmerSpectrumSerial/_Parallel (src/KmerSpectrum.h:1914-2074)
+ * = KmerReadUtils::buildWeightedKmers (src/KmerReadUtils.h:176-248) + append()
+ * (src/KmerSpectrum.h:1578-1668).  Host buffers:
+ *   bases  : ASCII sequence characters of all reads back to back
+ *   quals  : ASCII qualities, same layout; NULL = reads without quals
+ *            (reference reads, weight 1.0; src/KmerReadUtils.h:195-199)
+ *   offsets: n_reads+1 byte offsets into bases/quals (read r = [off[r],off[r+1]))
+ *   discarded: optional, 1 = Read::isDiscarded() (skipped)
+ * May be called any number of times before kmr_finalize. */
+int kmr_add_reads(kmr_handle *h, const char *bases, const char *quals,
+                  const uint64_t *offsets, uint64_t n_reads,
+                  uint64_t first_global_read_idx, const uint8_t *discarded);
+
+/* Same, but the buffers are already in the handle's device memory (this is
+ * the form bench.py times: inputs resident in HBM).  Asynchronous on the
+ * handle's stream; kmr_sync() waits. */
+int kmr_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals,
+                      const void *dev_offsets, uint64_t n_reads, uint64_t total_bases,
+                      uint64_t first_global_read_idx, const void *dev_discarded);
+int kmr_sync(kmr_handle *h);
+
+/* Post-build steps of buildKmerSpectrumInParts / DistributedKmerSpectrum::
+ * buildKmerSpectrum: purgeMinDepth(min_depth) (src/KmerSpectrum.h:1805-1815,
+ * 1825; src/DistributedFunctions.h:560-569) and optimize() (sorted buckets,
+ * src/Kmer.h:3079-3088).  After this call the maps are immutable and
+ * queryable / exportable. */
+int kmr_finalize(kmr_handle *h, uint32_t min_depth);
+
+int kmr_get_stats(kmr_handle *h, kmr_stats *out);
+
+/* Lookup.  Replaces KmerMap::getElementIfExists(kmer).value().getCount()
+ * (src/Kmer.h:2617-2624; consumer src/ReadSelector.h:924-931) and
+ * KmerSpectrum::getCount(kmer,false) (src/KmerSpectrum.h:701-725): weak count
+ * if present, else 1 if in the singleton map, else 0.  Keys are packed
+ * canonical k-mers, kb bytes each. */
+int kmr_lookup(kmr_handle *h, const uint8_t *packed_kmers, uint64_t n, uint32_t *counts);
+
+/* Fused extract + canonicalise + lookup for whole reads: counts_out gets one
+ * u32 per k-mer position of each read (read r writes out_offsets[r]..+L-k+1).
+ * This is ReadSelector::scoreReadByKmers' inner loop (src/ReadSelector.h:1048-1076). */
+int kmr_lookup_reads(kmr_handle *h, const char *bases, const uint64_t *offsets,
+                     uint64_t n_reads, uint32_t *counts_out, const uint64_t *out_offsets);
+
+/* Export in the reference's on-disk / mmap format so the caller can
+ * WeakMapType::restore(dst) it.  Replaces KmerMapByKmerArrayPair::getSizeToStore /
+ * store(void*) (src/Kmer.h:3143-3159,3181-3191) and KmerSpectrum::storeMmap
+ * (src/KmerSpectrum.h:476-488).  Layout: u64 numBuckets; u64 bucketMask;
+ * u64 offset[numBuckets]; then per bucket {u32 n; u8 keys[n][kb]; V values[n]}
+ * with keys sorted by memcmp. */
+int kmr_image_size(kmr_handle *h, int which_map, uint64_t *bytes);
+int kmr_write_image(kmr_handle *h, int which_map, void *dst, uint64_t capacity);
+
+/* Restore: replaces KmerSpectrum::restoreMmap / KmerMapByKmerArrayPair(const void*)
+ * (src/KmerSpectrum.h:489-518, src/Kmer.h:3124-3135).  The handle must be fresh
+ * (no reads added); it becomes finalized. */
+int kmr_load_image(kmr_handle *h, int which_map, const void *src, uint64_t len);
+
+/* Histogram of weak counts (KmerSpectrum::Histogram, src/KmerSpectrum.h:909-1057):
+ * counts[c] = number of weak entries with count == c for c < n_bins-1, last bin
+ * collects the rest; weights[c] = sum of weightedCount (may be NULL). */
+int kmr_count_histogram(kmr_handle *h, uint64_t *counts, double *weights, uint32_t n_bins);
+
+/* MeraculousDistributedKmerSpectrum::dumpCounts / dumpGraphs
+ * (src/Meraculous.h:107-134): text lines for every weak entry with
+ * count >= min_depth, both orientations.  Appends to the file at 'path'. */
+int kmr_dump_mercount(kmr_handle *h, const char *path, uint32_t min_depth);
+int kmr_dump_mergraph(kmr_handle *h, const char *path, uint32_t min_depth);
+
+/* ---- stateless helpers (bit-identical to the reference functions) -------- */
+
+/* KmerHasher::getHash (src/Kmer.h:207-230) = Lookup3::hashlittle2
+ * (src/lookup3.h:470-641) with pc=0xDEADBEEF, pb=0, result c | b<<32. */
+uint64_t kmr_hash(const uint8_t *key, uint32_t len);
+/* BucketExposedMapLogic::getBucketIdx / getLocalThreadId / getDistributedThreadId
+ * (src/Kmer.h:2329-2333, 2269-2280, 2284-2295). */
+uint64_t kmr_bucket_idx(uint64_t hash, uint64_t num_buckets_pow2);
+uint32_t kmr_local_thread_id(uint64_t hash, uint64_t num_buckets_pow2, uint32_t num_threads);
+uint32_t kmr_distributed_thread_id(uint64_t hash, uint32_t world_size);
+/* TwoBitSequence::compressSequence (src/TwoBitSequence.cpp:242-269); returns
+ * the number of markups (non-ACGT bases), written to markup_pos/markup_char
+ * up to markup_cap. */
+int64_t kmr_compress_sequence(const char *bases, uint64_t len, uint8_t *out,
+                              uint32_t *markup_pos, char *markup_char, uint64_t markup_cap);
+/* Kmer::buildLeastComplement (src/Kmer.h:356-364): writes the canonical form
+ * of a packed k-mer, returns 1 if the input was already the least. */
+int kmr_least_complement(const uint8_t *packed, uint32_t k, uint8_t *out);
+
+/* ---- device-level pieces for one-process-per-GPU owner partitioning ------
+ * These replace the body of DistributedKmerSpectrum::_buildKmerSpectrumMPI
+ * (src/DistributedFunctions.h:340-458): sender side = buildWeightedKmers +
+ * isDiscard + getThreadIds (:418-433) + bufferMessage (:438); the
+ * MPI_Alltoallv (src/MPIBuffer.h:588-600) is done by the caller (RCCL
+ * all-to-all over xGMI via torch.distributed); receiver side =
+ * StoreKmerMessageHeaderProcessor::process -> append (:323-328).
+ *
+ * A record is KMR_RECORD_BYTES(k) bytes: u64 key words (big-endian packed
+ * k-mer, zero padded), f32 signed weight (negative = observed strand was the
+ * reverse complement, as StoreKmerMessageHeader::weight :279), u32 extension
+ * packet (leftBase,rightBase chars, leftQ,rightQ; ExtensionMessagePacket,
+ * src/KmerTrackingData.h:232-288). */
+#define KMR_KEY_WORDS(k) ((((k) + 3u) / 4u + 7u) / 8u)
+#define KMR_RECORD_BYTES(k) (8u * KMR_KEY_WORDS(k) + 8u)
+
+/* Extract all good k-mers of a device-resident read batch and bin them by
+ * owner = kmr_distributed_thread_id(hash, world_size) into world_size
+ * contiguous segments of dev_records.  dev_seg_counts[world_size] (u64, device)
+ * receives the records per owner; segment s starts at record
+ * seg_capacity * s.  Returns KMR_ERR_CAPACITY (after sync) if a segment
+ * overflowed.  Asynchronous on the handle's stream otherwise. */
+int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals,
+                             const void *dev_offsets, uint64_t n_reads, uint64_t total_bases,
+                             uint64_t first_global_read_idx, const void *dev_discarded,
+                             void *dev_records, uint64_t seg_capacity, void *dev_seg_counts);
+/* Insert n records (any owner mix that belongs to this handle) into the table. */
+int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n_records);
+
+/* Raw HIP stream of the handle (hipStream_t) so callers can order their own
+ * work (torch.cuda.ExternalStream) against it. */
+void *kmr_stream(kmr_handle *h);
+
+/* Timing of the dominant kernels measured with HIP events on the handle's
+ * stream (used by bench.py for the roofline object).  which: 0 = build
+ * (extract+insert), 1 = finalize.  Returns accumulated milliseconds and
+ * launch count since the last reset. */
+int kmr_kernel_time(kmr_handle *h, int which, double *ms, uint64_t *launches);
+int kmr_kernel_time_reset(kmr_handle *h);
+
+uint32_t kmr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMERNATOR_AMD_H_ */

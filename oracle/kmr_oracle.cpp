@@ -1,0 +1,941 @@
+/*
+ * kmr_oracle.cpp -- CPU restatement of Kmernator's k-mer-spectrum build.
+ *
+ * TEST INFRASTRUCTURE.  This file is the parity oracle and the "port" CPU
+ * baseline.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it; the product (kmernator_amd/csrc) never links or calls it.
+ *
+ * It restates, function by function, the reference algorithm (all citations
+ * are path:line under the reference checkout):
+ *   a1  TwoBitSequence::compressSequence        src/TwoBitSequence.cpp:242-269
+ *   a2  TwoBitSequence::reverseComplement       src/TwoBitSequence.cpp:395-409
+ *       TwoBitSequence::shiftLeft               src/TwoBitSequence.cpp:418-465
+ *   a3  KmerArrayPair::build                    src/Kmer.h:1323-1375
+ *   a4  Kmer::compare/buildLeastComplement      src/Kmer.h:311-313,356-364
+ *   a5  KmerReadUtils::buildWeightedKmers       src/KmerReadUtils.h:176-248
+ *   a6  Read::initializeQualityToProbability    src/Sequence.cpp:522-540
+ *   a7  KmerHasher::getHash / hashlittle2       src/Kmer.h:207-230, src/lookup3.h:470-641
+ *   a8  getBucketIdx/getLocalThreadId/getDistributedThreadId  src/Kmer.h:2329,2269,2284
+ *   a9  KmerMapByKmerArrayPair / KmerArrayPair  src/Kmer.h:785-1917,2799-3279
+ *   a10 KmerSpectrum::append + track()s         src/KmerSpectrum.h:1578-1668, src/KmerTrackingData.h
+ *   a11 _buildKmerSpectrumSerial/_Parallel      src/KmerSpectrum.h:1914-2074, purgeMinDepth :1805
+ *   a12 store()/restore image                   src/Kmer.h:3143-3191, 960-984
+ *   a13 owner partition of _buildKmerSpectrumMPI src/DistributedFunctions.h:340-458
+ *   a14 dumpCounts/dumpGraphs                   src/Meraculous.h:107-134
+ *
+ * Pinning (tests/test_oracle_*.py): the reference's own golden fixtures
+ * test/phix.mercount.m21 and test/phix.mergraph.m21.D2 (sorted-output equality
+ * after a MeraculousCounter-configured build of test/1000.fastq), the
+ * MedianScore/Trim labels of test/1000-Filtered.fastq (k=31 counts through the
+ * 0.10 weight threshold), the TwoBitSequenceTest/KmerTest known-answer tables
+ * and lookup3's driver5 vectors; the hash is additionally cross-checked against
+ * the reference's own src/lookup3.h compiled into oracle/_ref.
+ *
+ * Differences from the reference that do not change results: buckets keep
+ * keys/values in two std::vectors instead of one malloc block with the
+ * 1.5x/+48 growth rule (src/Kmer.h:795-796,1241); strict IEEE arithmetic (the
+ * reference Release build adds -ffast-math, override.cmake:2).
+ */
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/kmernator_amd.h"
+
+namespace orc {
+
+typedef uint8_t TwoBitEncoding;
+
+static inline uint32_t fastaLengthToTwoBitLength(uint32_t n) { return (n + 3) / 4; }
+
+/* ---------------------------------------------------------------- a1 --- */
+static const uint8_t END_OF_TWO_BIT_SEQUENCE = 254, INVALID_BASE = 255;
+static inline uint8_t compressBase(char base) {          /* TwoBitSequence.cpp:124-147 */
+	switch (base) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': return 3;
+	case '\0': return END_OF_TWO_BIT_SEQUENCE;
+	default: return INVALID_BASE;
+	}
+}
+struct Markup { char base; uint32_t pos; };
+
+/* TwoBitSequence.cpp:242-269 with an explicit length instead of a NUL. */
+static void compressSequence(const char *bases, uint32_t len, TwoBitEncoding *out, std::vector<Markup> *markups) {
+	uint32_t offset = 0;
+	while (offset < len) {
+		TwoBitEncoding c = 0;
+		for (int i = 6; i >= 0 && offset < len; i -= 2) {
+			uint8_t cbase = compressBase(bases[offset]);
+			if (cbase == END_OF_TWO_BIT_SEQUENCE) { len = offset; break; }
+			if (cbase == INVALID_BASE) {
+				char base = bases[offset];
+				if (base == '.') base = 'N';
+				if (markups) markups->push_back(Markup{base, offset});
+				cbase = 0;
+			}
+			offset++;
+			c |= cbase << i;
+		}
+		if (out) *out++ = c;
+	}
+}
+
+/* ---------------------------------------------------------------- a2 --- */
+static TwoBitEncoding reverseComplementTable[256];
+static TwoBitEncoding shiftLeftMatrix[3][65536];
+static bool tablesInit = false;
+static void initTables() {
+	if (tablesInit) return;
+	for (int c = 0; c < 256; c++) {                      /* TwoBitSequence.cpp:168-178 */
+		TwoBitEncoding i = c, complement = ~i;
+		reverseComplementTable[i] = ((complement << 6) & (0x03 << 6)) | ((complement << 2) & (0x03 << 4))
+			| ((complement >> 2) & (0x03 << 2)) | ((complement >> 6) & (0x03 << 0));
+	}
+	for (int s = 1; s <= 3; s++) {                       /* TwoBitSequence.cpp:467-477 */
+		const int shift = 8 - s * 2;
+		for (int i = 0; i < 65536; i++) {
+			unsigned short buffer = i;
+			shiftLeftMatrix[s - 1][buffer] = (TwoBitEncoding)((unsigned short)((buffer >> 8) | (buffer << 8)) >> shift);
+		}
+	}
+	tablesInit = true;
+}
+
+/* TwoBitSequence.cpp:418-465.  hasExtraByte: in[twoBitLength] is readable. */
+static void shiftLeft(const TwoBitEncoding *twoBitIn, TwoBitEncoding *twoBitOut, uint32_t twoBitLength,
+                      unsigned char shiftAmountInBases, bool hasExtraByte = false) {
+	const TwoBitEncoding *in = twoBitIn;
+	TwoBitEncoding *out = twoBitOut;
+	if (shiftAmountInBases == 0) {
+		if (in != out) memmove(out, in, twoBitLength);
+		return;
+	}
+	in += twoBitLength;
+	out += twoBitLength;
+	unsigned short buffer;
+	if (hasExtraByte) { --in; buffer = (unsigned short)(in[0] | (in[1] << 8)); }
+	else { buffer = *(--in); }
+	const TwoBitEncoding *shiftLookup = shiftLeftMatrix[shiftAmountInBases - 1];
+	bool cont = true;
+	while (cont) {
+		TwoBitEncoding byte = shiftLookup[buffer];
+		if (in != twoBitIn) { --in; buffer = (unsigned short)(in[0] | (in[1] << 8)); }
+		else cont = false;
+		*--out = byte;
+	}
+}
+
+/* TwoBitSequence.cpp:395-409 */
+static void reverseComplement(const TwoBitEncoding *in, TwoBitEncoding *out, uint32_t length) {
+	uint32_t twoBitLength = fastaLengthToTwoBitLength(length);
+	TwoBitEncoding *tmpOut = out + twoBitLength;
+	unsigned long bitShift = length & 0x03;
+	while (tmpOut != out) *(--tmpOut) = reverseComplementTable[*(in++)];
+	if (bitShift > 0) shiftLeft(out, out, twoBitLength, (unsigned char)(4 - bitShift));
+}
+
+/* ---------------------------------------------------------------- a7 --- */
+#define ORC_ROT(x, k) (((x) << (k)) | ((x) >> (32 - (k))))
+#define ORC_MIX(a, b, c) { \
+	a -= c; a ^= ORC_ROT(c, 4);  c += b; \
+	b -= a; b ^= ORC_ROT(a, 6);  a += c; \
+	c -= b; c ^= ORC_ROT(b, 8);  b += a; \
+	a -= c; a ^= ORC_ROT(c, 16); c += b; \
+	b -= a; b ^= ORC_ROT(a, 19); a += c; \
+	c -= b; c ^= ORC_ROT(b, 4);  b += a; }
+#define ORC_FINAL(a, b, c) { \
+	c ^= b; c -= ORC_ROT(b, 14); \
+	a ^= c; a -= ORC_ROT(c, 11); \
+	b ^= a; b -= ORC_ROT(a, 25); \
+	c ^= b; c -= ORC_ROT(b, 16); \
+	a ^= c; a -= ORC_ROT(c, 4);  \
+	b ^= a; b -= ORC_ROT(a, 14); \
+	c ^= b; c -= ORC_ROT(b, 24); }
+
+/* lookup3.h:470-641, byte-wise form (the result is alignment independent). */
+static void hashlittle2(const void *key, size_t length, uint32_t *pc, uint32_t *pb) {
+	uint32_t a, b, c;
+	a = b = c = 0xdeadbeef + ((uint32_t)length) + *pc;
+	c += *pb;
+	const uint8_t *k = (const uint8_t *)key;
+	while (length > 12) {
+		a += k[0]; a += ((uint32_t)k[1]) << 8; a += ((uint32_t)k[2]) << 16; a += ((uint32_t)k[3]) << 24;
+		b += k[4]; b += ((uint32_t)k[5]) << 8; b += ((uint32_t)k[6]) << 16; b += ((uint32_t)k[7]) << 24;
+		c += k[8]; c += ((uint32_t)k[9]) << 8; c += ((uint32_t)k[10]) << 16; c += ((uint32_t)k[11]) << 24;
+		ORC_MIX(a, b, c);
+		length -= 12;
+		k += 12;
+	}
+	switch (length) {
+	case 12: c += ((uint32_t)k[11]) << 24; /* fall through */
+	case 11: c += ((uint32_t)k[10]) << 16; /* fall through */
+	case 10: c += ((uint32_t)k[9]) << 8;   /* fall through */
+	case 9:  c += k[8];                    /* fall through */
+	case 8:  b += ((uint32_t)k[7]) << 24;  /* fall through */
+	case 7:  b += ((uint32_t)k[6]) << 16;  /* fall through */
+	case 6:  b += ((uint32_t)k[5]) << 8;   /* fall through */
+	case 5:  b += k[4];                    /* fall through */
+	case 4:  a += ((uint32_t)k[3]) << 24;  /* fall through */
+	case 3:  a += ((uint32_t)k[2]) << 16;  /* fall through */
+	case 2:  a += ((uint32_t)k[1]) << 8;   /* fall through */
+	case 1:  a += k[0]; break;
+	case 0:  *pc = c; *pb = b; return;
+	}
+	ORC_FINAL(a, b, c);
+	*pc = c; *pb = b;
+}
+/* Kmer.h:207-230 */
+static inline uint64_t getHash(const void *ptr, int length) {
+	uint32_t pc = 0xDEADBEEF, pb = 0;
+	hashlittle2(ptr, length, &pc, &pb);
+	return (uint64_t)pc | ((uint64_t)pb << 32);
+}
+
+/* ---------------------------------------------------------------- a8 --- */
+static const int DMP_HASH_SHIFT = 24;
+static const uint64_t DMP_HASH_MASK = 0x7ffff;
+static const uint64_t MAX_KMER_MAP_BUCKETS = 67108864;
+static uint64_t getMinPowerOf2(uint64_t minBucketCount) {  /* Kmer.h:2199-2212 */
+	uint64_t p = minBucketCount;
+	if (p == 0) p = 1;
+	else if ((p & (p - 1)) == 0) {}
+	else { p--; for (size_t i = 1; i < 64; i <<= 1) p |= p >> i; p++; }
+	return p;
+}
+static inline uint64_t resizeBuckets(uint64_t bucketCount) {   /* Kmer.h:2224-2229 */
+	if (bucketCount > MAX_KMER_MAP_BUCKETS) bucketCount = MAX_KMER_MAP_BUCKETS;
+	return getMinPowerOf2(bucketCount);
+}
+static inline int getLocalThreadId(uint64_t hash, uint64_t numBuckets, int numThreads) {  /* Kmer.h:2269-2280 */
+	if (numBuckets > 1 && numThreads > 1) return (int)((hash & (numBuckets - 1)) % numThreads);
+	return 0;
+}
+static inline int getDistributedThreadId(uint64_t hash, int n) {   /* Kmer.h:2284-2295 */
+	if (n > 1) return (int)(((hash >> DMP_HASH_SHIFT) & DMP_HASH_MASK) % n);
+	return 0;
+}
+
+/* ---------------------------------------------------------------- a6 --- */
+static const uint8_t PRINT_REF_QUAL = 33 + 70, REF_QUAL = 127;
+/* Sequence.cpp:522-540.  The reference first rescales every read to
+ * Read::FASTQ_START_CHAR (ReadSet.cpp:324-337, ReadSet.h:694-703) and builds the
+ * table for that base; here quals stay raw and 'startChar' is their base, which
+ * is the same function of the Phred value (table entry for raw char c equals the
+ * reference entry for c - startChar + 33 with FASTQ_START_CHAR = 33). */
+static void initializeQualityToProbability(double P[256], unsigned char minQualityScore, unsigned int startChar) {
+	const int start = 33;
+	for (int raw = 0; raw < 256; raw++) {
+		int i = raw - (int)startChar + start;          /* the char after the reference's rescale */
+		if (i < start + (int)minQualityScore) P[raw] = 0.0;
+		else if (i < PRINT_REF_QUAL) P[raw] = 1.0 - pow(10.0, ((start - i) / 10.0));
+		else P[raw] = 1.0;                               /* for reads with no quality data */
+	}
+}
+
+/* ------------------------------------------------- extension types ----- */
+enum ExtensionType { EA = 0, EC, EG, ET, EN, EX, MAX_EXTENSIONS };
+static inline ExtensionType extFromChar(char c) {       /* KmerTrackingData.h:98-110 */
+	switch (c) {
+	case 'A': case 'a': return EA;
+	case 'C': case 'c': return EC;
+	case 'G': case 'g': return EG;
+	case 'T': case 't': return ET;
+	case 'X': case 'x': return EX;
+	default: return EN;
+	}
+}
+static inline char extToChar(ExtensionType e) { static const char t[] = {'A', 'C', 'G', 'T', 'N', 'X'}; return t[e]; }
+static inline ExtensionType extRevComp(ExtensionType b) { /* :78-91 */
+	if (b == EA) return ET; if (b == EC) return EG; if (b == EG) return EC; if (b == ET) return EA; return b;
+}
+struct Extension {
+	ExtensionType base; uint8_t quality;
+	Extension() : base(MAX_EXTENSIONS), quality(0) {}
+	Extension(char c, unsigned int q) : base(extFromChar(c)), quality((uint8_t)q) {}
+	bool isValid() const { return base < MAX_EXTENSIONS; }
+	bool isBase() const { return base <= ET; }
+	Extension getReverseComplement() const { Extension r = *this; r.base = isValid() ? extRevComp(base) : base; return r; }
+};
+/* ExtensionMessagePacket, KmerTrackingData.h:232-288: chars + qualities. */
+struct ExtPacket {
+	char leftB, rightB; uint8_t leftQ, rightQ;
+	ExtPacket() : leftB('\0'), rightB('\0'), leftQ(0), rightQ(0) {}
+	void set(const Extension &l, const Extension &r) {
+		leftB = l.isValid() ? extToChar(l.base) : '\0'; leftQ = l.quality;
+		rightB = r.isValid() ? extToChar(r.base) : '\0'; rightQ = r.quality;
+	}
+	/* Extension(char,quality): '\0' maps through the default branch to N */
+	Extension getLeft() const { return Extension(leftB, leftQ); }
+	Extension getRight() const { return Extension(rightB, rightQ); }
+};
+
+struct Globals {           /* TrackingData statics, KmerTrackingData.h:395-403 */
+	float minimumWeight;
+	uint8_t extMinQuality;
+	unsigned long discarded;
+};
+
+/* ------------------------------------------------- value types (a10) --- */
+struct TDDir {             /* TrackingDataWithDirection, sizeof 12 */
+	uint16_t count; float weightedCount; uint16_t directionBias;
+	TDDir() : count(0), weightedCount(0.0f), directionBias(0) {}
+};
+struct TDExt : TDDir {     /* ExtensionTrackingData, sizeof 60 */
+	uint32_t ext[2][6];
+	TDExt() { memset(ext, 0, sizeof(ext)); }
+};
+struct SingDir { uint8_t _weight; SingDir() : _weight(0) {} };          /* sizeof 1 */
+#pragma pack(push, 1)
+struct SingExt { uint8_t _weight; ExtPacket pkt; SingExt() : _weight(0) {} };  /* sizeof 5 */
+#pragma pack(pop)
+static_assert(sizeof(TDDir) == 12 && sizeof(TDExt) == 60 && sizeof(SingDir) == 1 && sizeof(SingExt) == 5, "value layouts");
+
+static inline bool isDiscard(Globals &g, float weight) {   /* :354-364 */
+	if (weight > g.minimumWeight) return false;
+#pragma omp atomic
+	g.discarded++;
+	return true;
+}
+/* TrackingData::track :427-448 + TrackingDataWithDirection::track :517-529 */
+static inline bool trackWeak(Globals &g, TDDir &v, double weight, bool forward) {
+	if (isDiscard(g, (float)weight)) return false;
+	if (v.count < 65535) {
+		v.count++;
+		v.weightedCount += weight;            /* float += double, as in the reference */
+		if (forward) v.directionBias++;
+		return true;
+	}
+	return false;
+}
+static inline void trackExtension(Globals &g, uint32_t ext[2][6], const Extension &e, int dir) {  /* :195-201 */
+	if (e.isValid() && (e.quality >= g.extMinQuality || !e.isBase())) ext[dir][e.base]++;
+}
+static inline void trackExtensions(Globals &g, TDDir &, const Extension &, const Extension &) {}
+static inline void trackExtensions(Globals &g, TDExt &v, const Extension &l, const Extension &r) {
+	trackExtension(g, v.ext, l, 0); trackExtension(g, v.ext, r, 1);
+}
+/* TrackingDataSingleton::track :641-649 */
+template <class S> static inline bool trackSingleton(Globals &g, S &s, double weight) {
+	if (isDiscard(g, (float)weight)) return false;
+	s._weight = (unsigned char)((weight * 254.0)) + 1;
+	return true;
+}
+static inline void trackExtensions(Globals &, SingDir &, const Extension &, const Extension &) {}
+static inline void trackExtensions(Globals &, SingExt &s, const Extension &l, const Extension &r) { s.pkt.set(l, r); }
+/* weak = singleton (operator= templates :540-547, :1061-1067, getters :651-659, :1103-1107) */
+static inline void assignFromSingleton(Globals &, TDDir &w, const SingDir &s) {
+	w.count = s._weight == 0 ? 0 : 1;
+	w.weightedCount = (float)(s._weight == 0 ? 0.0 : (s._weight - 1) / 254.0);
+	w.directionBias = 0;
+}
+static inline void assignFromSingleton(Globals &g, TDExt &w, const SingExt &s) {
+	w.count = s._weight == 0 ? 0 : 1;
+	w.weightedCount = (float)(s._weight == 0 ? 0.0 : (s._weight - 1) / 254.0);
+	w.directionBias = 0;
+	memset(w.ext, 0, sizeof(w.ext));
+	trackExtension(g, w.ext, s.pkt.getLeft(), 0);
+	trackExtension(g, w.ext, s.pkt.getRight(), 1);
+}
+
+/* ------------------------------------------------- bucket (a9) --------- */
+template <class V> struct Bucket {                 /* KmerArrayPair<V>, Kmer.h:785-1917 */
+	std::vector<uint8_t> keys;
+	std::vector<V> vals;
+	uint32_t endSorted;
+	Bucket() : endSorted(0) {}
+	uint32_t size() const { return (uint32_t)vals.size(); }
+	const uint8_t *key(uint32_t i, uint32_t kb) const { return keys.data() + (size_t)i * kb; }
+
+	static const uint32_t MAX_INDEX = 0xffffffffu;
+	uint32_t findSorted(const uint8_t *target, uint32_t kb, bool &found, uint32_t start, uint32_t end) const {  /* :1506-1541 */
+		if (end <= start) { found = false; return 0; }
+		uint32_t min = start, max = end;
+		max--;
+		uint32_t mid; int comp;
+		do {
+			mid = (min + max) / 2;
+			comp = memcmp(target, key(mid, kb), kb);
+			if (comp > 0) min = mid + 1;
+			else if (comp < 0) max = mid - 1;
+		} while (comp != 0 && max != MAX_INDEX && min <= max);
+		found = (comp == 0);
+		return mid + (comp > 0 && end > mid ? 1 : 0);
+	}
+	uint32_t findIndex(const uint8_t *target, uint32_t kb) const {   /* :1491-1503 */
+		const uint32_t minSortedToFindSorted = 8;
+		if (endSorted >= minSortedToFindSorted) {
+			bool found; uint32_t idx = findSorted(target, kb, found, 0, endSorted);
+			if (found) return idx;
+		}
+		for (uint32_t i = (endSorted >= minSortedToFindSorted ? endSorted : 0); i < size(); i++)
+			if (memcmp(target, key(i, kb), kb) == 0) return i;
+		return MAX_INDEX;
+	}
+	uint32_t append(const uint8_t *k, uint32_t kb, const V &v) {     /* :1580-1584 */
+		keys.insert(keys.end(), k, k + kb);
+		vals.push_back(v);
+		return size() - 1;
+	}
+	void resort(uint32_t kb) {                                     /* :1713-1743: index sort + full copy */
+		if (endSorted == size()) return;
+		std::vector<uint32_t> idx(size());
+		for (uint32_t i = 0; i < size(); i++) idx[i] = i;
+		const uint8_t *base = keys.data();
+		std::sort(idx.begin(), idx.end(), [=](uint32_t a, uint32_t b) { return memcmp(base + (size_t)a * kb, base + (size_t)b * kb, kb) < 0; });
+		std::vector<uint8_t> nk(keys.size());
+		std::vector<V> nv(vals.size());
+		for (uint32_t i = 0; i < size(); i++) { memcpy(nk.data() + (size_t)i * kb, base + (size_t)idx[i] * kb, kb); nv[i] = vals[idx[i]]; }
+		keys.swap(nk); vals.swap(nv);
+		endSorted = size();
+	}
+	void remove(uint32_t idx, uint32_t kb) {                       /* :1616-1622 */
+		keys.erase(keys.begin() + (size_t)idx * kb, keys.begin() + (size_t)(idx + 1) * kb);
+		vals.erase(vals.begin() + idx);
+		if (endSorted > idx) endSorted--;
+	}
+	void clear() { keys.clear(); vals.clear(); endSorted = 0; }
+};
+
+template <class V> struct Map {                    /* KmerMapByKmerArrayPair<V>, Kmer.h:2799-3279 */
+	std::vector<Bucket<V> > buckets;
+	uint64_t mask;
+	uint32_t kb;
+	void init(uint64_t numBuckets, uint32_t _kb) { uint64_t p = resizeBuckets(numBuckets); buckets.assign(p, Bucket<V>()); mask = p - 1; kb = _kb; }
+	uint64_t numBuckets() const { return buckets.size(); }
+	Bucket<V> &bucketFor(uint64_t hash) { return buckets[hash & mask]; }
+	V *getIfExists(const uint8_t *key, uint64_t hash) {             /* getElementIfExists :2617-2624 */
+		Bucket<V> &b = bucketFor(hash);
+		uint32_t idx = b.findIndex(key, kb);
+		return idx == Bucket<V>::MAX_INDEX ? NULL : &b.vals[idx];
+	}
+	/* insert(), unsorted-map branch :3095-3110.  getNumUnsorted() is
+	 * _endSorted - size() on unsigned (Kmer.h:1699-1702), so any unsorted tail
+	 * satisfies ">= MAX_UNSORTED" and the bucket is re-sorted on every insert. */
+	V *insert(const uint8_t *key, uint64_t hash, const V &v) {
+		Bucket<V> &b = bucketFor(hash);
+		b.append(key, kb, v);
+		if ((uint32_t)(b.endSorted - b.size()) >= 16u) b.resort(kb);
+		uint32_t idx = b.findIndex(key, kb);
+		return &b.vals[idx];
+	}
+	bool remove(const uint8_t *key, uint64_t hash) {                /* :3113-3119 */
+		Bucket<V> &b = bucketFor(hash);
+		uint32_t idx = b.findIndex(key, kb);
+		if (idx == Bucket<V>::MAX_INDEX) return false;
+		b.remove(idx, kb);
+		return true;
+	}
+	uint64_t size() const { uint64_t s = 0; for (size_t i = 0; i < buckets.size(); i++) s += buckets[i].size(); return s; }
+	void resortAll() {
+		long n = (long)buckets.size();
+#pragma omp parallel for
+		for (long i = 0; i < n; i++) buckets[i].resort(kb);
+	}
+	void clearAll() { for (size_t i = 0; i < buckets.size(); i++) buckets[i].clear(); }
+	uint64_t sizeToStore() const { return 8 * (2 + numBuckets()) + numBuckets() * 4 + size() * (kb + sizeof(V)); }  /* :3181-3191 */
+	void store(uint8_t *dst) const {                                /* :3143-3159 + KmerArrayPair::store :960-969 */
+		uint64_t n = numBuckets();
+		uint64_t *numbers = (uint64_t *)dst;
+		numbers[0] = n; numbers[1] = mask;
+		uint64_t offset = 8 * (2 + n);
+		for (uint64_t i = 0; i < n; i++) {
+			numbers[2 + i] = offset;
+			const Bucket<V> &b = buckets[i];
+			uint32_t sz = b.size();
+			memcpy(dst + offset, &sz, 4);
+			memcpy(dst + offset + 4, b.keys.data(), (size_t)sz * kb);
+			memcpy(dst + offset + 4 + (size_t)sz * kb, (const void *)b.vals.data(), (size_t)sz * sizeof(V));
+			offset += 4 + (uint64_t)sz * (kb + sizeof(V));
+		}
+	}
+	bool load(const uint8_t *src, uint64_t len, uint32_t _kb) {     /* copy-restore ctor :3124-3135 */
+		if (len < 16) return false;
+		const uint64_t *numbers = (const uint64_t *)src;
+		uint64_t n = numbers[0];
+		if (n == 0 || (n & (n - 1)) || len < 8 * (2 + n)) return false;
+		kb = _kb; mask = numbers[1]; buckets.assign(n, Bucket<V>());
+		for (uint64_t i = 0; i < n; i++) {
+			uint64_t off = numbers[2 + i];
+			if (off + 4 > len) return false;
+			uint32_t sz; memcpy(&sz, src + off, 4);
+			if (off + 4 + (uint64_t)sz * (kb + sizeof(V)) > len) return false;
+			Bucket<V> &b = buckets[i];
+			b.keys.assign(src + off + 4, src + off + 4 + (size_t)sz * kb);
+			b.vals.resize(sz);
+			memcpy((void *)b.vals.data(), src + off + 4 + (size_t)sz * kb, (size_t)sz * sizeof(V));
+			b.endSorted = sz > 0 ? 1 : 0;                               /* setLastSorted :1003-1014 */
+			for (uint32_t j = 1; j < sz; j++) { if (memcmp(b.key(j - 1, kb), b.key(j, kb), kb) <= 0) b.endSorted++; else break; }
+		}
+		return true;
+	}
+};
+
+/* ------------------------------------------------- weighted k-mers (a3-a5) */
+struct WeightedKmers {
+	std::vector<uint8_t> keys;      /* n * kb, canonical */
+	std::vector<float> weights;     /* signed: + if observed strand is the least */
+	std::vector<ExtPacket> exts;
+	uint32_t n;
+};
+
+struct ReadView { const char *bases; const char *quals; uint32_t len; bool discarded; };
+
+struct KmerBuilder {
+	uint32_t k, kb;
+	double P[256];
+	uint32_t fastqStart;
+	uint8_t extMinQuality;
+	std::vector<uint8_t> twoBit, tmp, rc;
+	std::vector<Markup> markups;
+	std::vector<uint8_t> bools;
+
+	/* KmerArrayPair::build, Kmer.h:1323-1375, on a zero padded copy */
+	void build(const ReadView &r, WeightedKmers &out) {
+		uint32_t length = r.len;
+		out.n = 0;
+		if (length < k) return;
+		uint32_t numKmers = length - k + 1;
+		uint32_t numBytes = fastaLengthToTwoBitLength(length);
+		twoBit.assign(numBytes + kb + 2, 0);
+		markups.clear();
+		compressSequence(r.bases, length, twoBit.data(), &markups);
+		out.n = numKmers;
+		out.keys.resize((size_t)numKmers * kb);
+		bools.resize(numKmers);
+		for (uint32_t bytes = 0; bytes < numBytes; bytes++) {
+			uint32_t i = bytes * 4;
+			const uint8_t *ref = twoBit.data() + bytes;
+			for (int bitShift = 0; bitShift < 4 && i + bitShift < numKmers; bitShift++) {
+				uint8_t *dst = out.keys.data() + (size_t)(i + bitShift) * kb;
+				shiftLeft(ref, dst, kb, (unsigned char)bitShift, bytes < numBytes - 1);
+				uint8_t *lastByte = dst + kb - 1;
+				switch (k & 0x03) { case 1: *lastByte &= 0xc0; break; case 2: *lastByte &= 0xf0; break; case 3: *lastByte &= 0xfc; break; }
+			}
+		}
+		rc.resize(kb);
+		for (uint32_t i = 0; i < numKmers; i++) {              /* buildLeastComplement, Kmer.h:356-364 */
+			uint8_t *km = out.keys.data() + (size_t)i * kb;
+			reverseComplement(km, rc.data(), k);
+			bool isLeast = memcmp(km, rc.data(), kb) <= 0;
+			if (!isLeast) memcpy(km, rc.data(), kb);
+			bools[i] = isLeast;
+		}
+	}
+
+	/* KmerReadUtils::buildWeightedKmers(read, true, true), KmerReadUtils.h:176-248 */
+	void buildWeighted(const ReadView &r, WeightedKmers &out) {
+		out.n = 0;
+		if (r.discarded) return;
+		build(r, out);
+		uint32_t size = out.n;
+		out.weights.resize(size);
+		out.exts.resize(size);
+		if (size == 0) return;
+		const unsigned char *quals = (const unsigned char *)r.quals;
+		bool isRef = (quals == NULL) || (r.len > 0 && quals[0] == REF_QUAL);
+		double weight = 0.0, change = 0.0;
+		size_t markupIdx = 0;
+		Extension left = Extension('X', extMinQuality), right;
+		const char *dec = "ACGT";
+		for (uint32_t i = 0; i < size; i++) {
+			if (isRef) weight = 1.0;
+			else if (i % 1024 == 0 || weight == 0.0) {
+				weight = 1.0;
+				for (uint32_t j = 0; j < k; j++) weight *= P[quals[i + j]];
+			} else {
+				change = P[quals[i + k - 1]] / P[quals[i - 1]];
+				weight *= change;
+			}
+			while (markupIdx < markups.size() && markups[markupIdx].pos < i) markupIdx++;
+			if (markupIdx < markups.size() && markups[markupIdx].pos < i + k) weight = 0.0;
+			out.weights[i] = (float)(bools[i] ? weight : (0.0 - weight));
+			/* getFastaNoMarkup(): bases decoded from the 2-bit form, so a non-ACGT base reads 'A' */
+			uint32_t rightBase = i + k;
+			unsigned rq = isRef ? REF_QUAL : 0, lq = isRef ? REF_QUAL : 0;
+			if (rightBase < r.len) {
+				if (!isRef) rq = quals[rightBase];
+				uint8_t code = (twoBit[rightBase >> 2] >> (6 - 2 * (rightBase & 3))) & 3;
+				right = Extension(dec[code], (rq - fastqStart) & 0xff);
+			} else right = Extension('X', extMinQuality);
+			if (bools[i]) out.exts[i].set(left, right);
+			else out.exts[i].set(right.getReverseComplement(), left.getReverseComplement());
+			if (!isRef) lq = quals[i];
+			uint8_t lcode = (twoBit[i >> 2] >> (6 - 2 * (i & 3))) & 3;
+			left = Extension(dec[lcode], (lq - fastqStart) & 0xff);
+		}
+	}
+};
+
+/* ------------------------------------------------- spectrum (a10,a11) --- */
+struct SpectrumBase {
+	kmr_config cfg;
+	uint32_t k, kb;
+	Globals g;
+	bool hasSingletons, finalized;
+	long rawKmers, rawGoodKmers, uniqueKmers, singletonKmers;
+	uint64_t reads;
+	double P[256];
+	std::string err;
+	virtual ~SpectrumBase() {}
+	virtual void addReads(const char *bases, const char *quals, const uint64_t *offsets, uint64_t n, uint64_t firstIdx, const uint8_t *disc, int threads) = 0;
+	virtual void finalize(uint32_t minDepth) = 0;
+	virtual uint64_t numBuckets(int which) = 0;
+	virtual uint64_t imageSize(int which) = 0;
+	virtual void writeImage(int which, uint8_t *dst) = 0;
+	virtual bool loadImage(int which, const uint8_t *src, uint64_t len) = 0;
+	virtual uint32_t lookup(const uint8_t *key) = 0;
+	virtual uint64_t mapSize(int which) = 0;
+	virtual void dump(FILE *f, uint32_t minDepth, bool graph) = 0;
+	virtual void histogram(uint64_t *counts, double *weights, uint32_t nbins) = 0;
+	virtual uint64_t exportEntries(uint8_t *keys, uint32_t *count, uint32_t *dir, float *weighted, uint32_t *ext, uint64_t cap) = 0;
+};
+
+template <class WV, class SV> struct Spectrum : SpectrumBase {
+	Map<WV> weak;
+	Map<SV> singleton;
+
+	/* KmerSpectrum::append, KmerSpectrum.h:1578-1668 (isSolid = false, no subtractingReference) */
+	inline void append(const uint8_t *least, float weight, const Extension &left, const Extension &right) {
+#pragma omp atomic
+		rawKmers++;
+		bool keepDirection = true;
+		if (weight < 0.0) { keepDirection = false; weight = (float)(0.0 - weight); }
+		if (isDiscard(g, weight)) return;
+#pragma omp atomic
+		rawGoodKmers++;
+		uint64_t hash = getHash(least, kb);
+		WV *w = weak.getIfExists(least, hash);
+		if (w) {
+			trackWeak(g, *w, weight, keepDirection);
+			trackExtensions(g, *w, left, right);
+			return;
+		}
+		SV *s = hasSingletons ? singleton.getIfExists(least, hash) : NULL;
+		if (s) {
+#pragma omp atomic
+			singletonKmers--;
+			SV singleData = *s;
+			WV *we = weak.insert(least, hash, WV());
+			assignFromSingleton(g, *we, singleData);
+			trackWeak(g, *we, weight, keepDirection);
+			trackExtensions(g, *we, left, right);
+			singleton.remove(least, hash);
+		} else {
+#pragma omp atomic
+			uniqueKmers++;
+			if (hasSingletons) {
+#pragma omp atomic
+				singletonKmers++;
+				SV *e = singleton.insert(least, hash, SV());
+				trackSingleton(g, *e, weight);
+				trackExtensions(g, *e, left, right);
+			} else {
+				WV *we = weak.insert(least, hash, WV());
+				trackWeak(g, *we, weight, keepDirection);
+				trackExtensions(g, *we, left, right);
+			}
+		}
+	}
+
+	/* sender-side filters of _buildKmerSpectrumMPI, DistributedFunctions.h:418-433,
+	 * and the part filter of append(KmerWeightedExtensions...), KmerSpectrum.h:1680 */
+	inline bool mine(const uint8_t *key, uint64_t &hash) {
+		hash = getHash(key, kb);
+		if (cfg.kmer_subsample > 1 && hash % cfg.kmer_subsample != 0) return false;
+		if (cfg.world_size > 1 && (uint32_t)getDistributedThreadId(hash, cfg.world_size) != cfg.rank) return false;
+		if (cfg.num_parts > 1 && (uint32_t)getDistributedThreadId(hash, cfg.num_parts) != cfg.part_idx) return false;
+		return true;
+	}
+
+	void initBuilder(KmerBuilder &b) {
+		b.k = k; b.kb = kb; memcpy(b.P, P, sizeof(P)); b.fastqStart = cfg.fastq_start_char; b.extMinQuality = (uint8_t)cfg.ext_min_quality;
+	}
+
+	void addReads(const char *bases, const char *quals, const uint64_t *offsets, uint64_t n, uint64_t firstIdx, const uint8_t *disc, int threads) {
+		reads += n;
+		int numThreads = threads;
+#ifndef _OPENMP
+		numThreads = 1;
+#endif
+		if (numThreads <= 1) {            /* _buildKmerSpectrumSerial, KmerSpectrum.h:1914-1931 */
+			KmerBuilder kb_; initBuilder(kb_);
+			WeightedKmers wk;
+			for (uint64_t r = 0; r < n; r++) {
+				ReadView rv{bases + offsets[r], quals ? quals + offsets[r] : NULL, (uint32_t)(offsets[r + 1] - offsets[r]), disc ? disc[r] != 0 : false};
+				kb_.buildWeighted(rv, wk);
+				for (uint32_t i = 0; i < wk.n; i++) {
+					const uint8_t *key = wk.keys.data() + (size_t)i * kb;
+					uint64_t h; if (!mine(key, h)) continue;
+					append(key, wk.weights[i], wk.exts[i].getLeft(), wk.exts[i].getRight());
+				}
+			}
+			return;
+		}
+#ifdef _OPENMP
+		/* _buildKmerSpectrumParallel, KmerSpectrum.h:1932-2074: T x T routing buffers,
+		 * owner thread = bucketIdx % T, owners replay grouped by producer then read order. */
+		long size = (long)n, batch = 100000;
+		if (size < batch) batch = size / 10 + 1;
+		uint64_t maxLen = 0; for (uint64_t r = 0; r < n; r++) maxLen = std::max<uint64_t>(maxLen, offsets[r + 1] - offsets[r]);
+		long kmersPerRead = (long)maxLen - (long)k + 1; if (kmersPerRead < 1) kmersPerRead = 1;
+		batch = std::min(batch, 128L * 1024 * 1024 / kmersPerRead / (long)kb / numThreads + 1);
+		struct Buf { std::vector<uint8_t> keys; std::vector<float> w; std::vector<ExtPacket> e; };
+		std::vector<std::vector<Buf> > kmerBuffers(numThreads, std::vector<Buf>(numThreads));
+		long batchIdx = 0;
+		uint64_t wnb = weak.numBuckets();
+#pragma omp parallel num_threads(numThreads) shared(batchIdx)
+		{
+			int threadId = omp_get_thread_num();
+			KmerBuilder kb_; initBuilder(kb_);
+			WeightedKmers wk;
+			while (batchIdx < size) {
+				for (int t2 = 0; t2 < numThreads; t2++) { Buf &b = kmerBuffers[threadId][t2]; b.keys.clear(); b.w.clear(); b.e.clear(); }
+				for (long i = 0; i < batch; i += numThreads) {
+					long readIdx = batchIdx + i + threadId;
+					if (readIdx >= size || readIdx >= batchIdx + batch) continue;
+					ReadView rv{bases + offsets[readIdx], quals ? quals + offsets[readIdx] : NULL, (uint32_t)(offsets[readIdx + 1] - offsets[readIdx]), disc ? disc[readIdx] != 0 : false};
+					kb_.buildWeighted(rv, wk);
+					for (uint32_t j = 0; j < wk.n; j++) {
+						const uint8_t *key = wk.keys.data() + (size_t)j * kb;
+						uint64_t h; if (!mine(key, h)) continue;
+						int smp = getLocalThreadId(h, wnb, numThreads);
+						Buf &b = kmerBuffers[threadId][smp];
+						b.keys.insert(b.keys.end(), key, key + kb); b.w.push_back(wk.weights[j]); b.e.push_back(wk.exts[j]);
+					}
+				}
+#pragma omp barrier
+				for (int t = 0; t < numThreads; t++) {
+					Buf &b = kmerBuffers[t][threadId];
+					for (size_t j = 0; j < b.w.size(); j++)
+						append(b.keys.data() + j * kb, b.w[j], b.e[j].getLeft(), b.e[j].getRight());
+				}
+#pragma omp barrier
+#pragma omp single
+				{ batchIdx += batch; }
+			}
+		}
+#endif
+	}
+
+	/* purgeMinDepth, KmerSpectrum.h:1805-1815 (+PurgeUtils :293-337) then optimize() (Kmer.h:3079-3088) */
+	void finalize(uint32_t minDepth) {
+		if (!hasSingletons || minDepth > 2) {
+			if (minDepth != 1) {
+				for (size_t i = 0; i < weak.buckets.size(); i++) {
+					Bucket<WV> &b = weak.buckets[i];
+					Bucket<WV> nb;
+					for (uint32_t j = 0; j < b.size(); j++) if ((long)minDepth <= (long)b.vals[j].count) nb.append(b.key(j, kb), kb, b.vals[j]);
+					if (nb.size() != b.size()) { b = nb; b.endSorted = 0; }
+				}
+			}
+		}
+		if (hasSingletons && minDepth > 1) { singleton.clearAll(); hasSingletons = false; }
+		weak.resortAll();
+		singleton.resortAll();
+		finalized = true;
+	}
+	uint64_t numBuckets(int which) { return which == KMR_MAP_WEAK ? weak.numBuckets() : singleton.numBuckets(); }
+	uint64_t mapSize(int which) { return which == KMR_MAP_WEAK ? weak.size() : singleton.size(); }
+	uint64_t imageSize(int which) { return which == KMR_MAP_WEAK ? weak.sizeToStore() : singleton.sizeToStore(); }
+	void writeImage(int which, uint8_t *dst) {
+		if (which == KMR_MAP_WEAK) { weak.resortAll(); weak.store(dst); } else { singleton.resortAll(); singleton.store(dst); }
+	}
+	bool loadImage(int which, const uint8_t *src, uint64_t len) {
+		bool ok = which == KMR_MAP_WEAK ? weak.load(src, len, kb) : singleton.load(src, len, kb);
+		if (ok && which == KMR_MAP_SINGLETON) hasSingletons = true;
+		finalized = true;
+		return ok;
+	}
+	/* DataPointers::getCount(false), KmerSpectrum.h:642-695 */
+	uint32_t lookup(const uint8_t *key) {
+		uint64_t hash = getHash(key, kb);
+		WV *w = weak.getIfExists(key, hash);
+		if (w) return w->count;
+		if (hasSingletons) { SV *s = singleton.getIfExists(key, hash); if (s) return s->_weight == 0 ? 0 : 1; }
+		return 0;
+	}
+	static void extText(const uint32_t ext[2][6], char *buf) {      /* toTextValues :207-218 */
+		sprintf(buf, "%u %u %u %u %u %u %u %u %u %u %u %u 0", ext[0][0], ext[0][1], ext[0][2], ext[0][3], ext[0][4], ext[0][5],
+		        ext[1][0], ext[1][1], ext[1][2], ext[1][3], ext[1][4], ext[1][5]);
+	}
+	void dumpOne(FILE *f, const uint8_t *key, const TDDir &v, bool graph) { (void)f; (void)key; (void)v; (void)graph; }
+	void dump(FILE *f, uint32_t minDepth, bool graph) {             /* Meraculous.h:107-134 */
+		std::vector<uint8_t> rc(kb);
+		std::string fa(k, 'A'), rfa(k, 'A');
+		const char *dec = "ACGT";
+		for (size_t bi = 0; bi < weak.buckets.size(); bi++) {
+			Bucket<WV> &b = weak.buckets[bi];
+			for (uint32_t j = 0; j < b.size(); j++) {
+				const WV &v = b.vals[j];
+				if ((int)v.count < (int)minDepth) continue;
+				const uint8_t *key = b.key(j, kb);
+				reverseComplement(key, rc.data(), k);
+				for (uint32_t p = 0; p < k; p++) { fa[p] = dec[(key[p >> 2] >> (6 - 2 * (p & 3))) & 3]; rfa[p] = dec[(rc[p >> 2] >> (6 - 2 * (p & 3))) & 3]; }
+				if (!graph) {
+					fprintf(f, "%s\t%lu\n%s\t%lu\n", fa.c_str(), (unsigned long)v.count, rfa.c_str(), (unsigned long)v.count);
+				} else {
+					dumpGraphLine(f, fa, rfa, v);
+				}
+			}
+		}
+	}
+	void dumpGraphLine(FILE *, const std::string &, const std::string &, const TDDir &) {}
+	void dumpGraphLine(FILE *f, const std::string &fa, const std::string &rfa, const TDExt &v) {
+		char buf[256]; extText(v.ext, buf);
+		fprintf(f, "%s\t%s\n", fa.c_str(), buf);
+		uint32_t rev[2][6];                                       /* getReverseComplement :219-226 */
+		for (int i = 0; i < 6; i++) { rev[0][extRevComp((ExtensionType)i)] = v.ext[1][i]; rev[1][extRevComp((ExtensionType)i)] = v.ext[0][i]; }
+		extText(rev, buf);
+		fprintf(f, "%s\t%s\n", rfa.c_str(), buf);
+	}
+	void histogram(uint64_t *counts, double *weights, uint32_t nbins) {
+		for (uint32_t i = 0; i < nbins; i++) { counts[i] = 0; if (weights) weights[i] = 0; }
+		for (size_t bi = 0; bi < weak.buckets.size(); bi++) for (uint32_t j = 0; j < weak.buckets[bi].size(); j++) {
+			const WV &v = weak.buckets[bi].vals[j];
+			uint32_t c = v.count >= nbins ? nbins - 1 : v.count;
+			counts[c]++; if (weights) weights[c] += v.weightedCount;
+		}
+	}
+	static void copyExt(uint32_t *, const TDDir &) {}
+	static void copyExt(uint32_t *dst, const TDExt &v) { memcpy(dst, v.ext, 48); }
+	/* flat dump of the weak map in bucket order, for field-by-field parity tests */
+	uint64_t exportEntries(uint8_t *keys, uint32_t *count, uint32_t *dir, float *weighted, uint32_t *ext, uint64_t cap) {
+		uint64_t n = 0;
+		for (size_t bi = 0; bi < weak.buckets.size(); bi++) for (uint32_t j = 0; j < weak.buckets[bi].size(); j++) {
+			if (n < cap) {
+				const WV &v = weak.buckets[bi].vals[j];
+				memcpy(keys + n * kb, weak.buckets[bi].key(j, kb), kb);
+				count[n] = v.count; dir[n] = v.directionBias; weighted[n] = v.weightedCount;
+				if (ext) copyExt(ext + n * 12, v);
+			}
+			n++;
+		}
+		return n;
+	}
+};
+
+}  // namespace orc
+
+/* ====================================================================== */
+extern "C" {
+
+using namespace orc;
+
+struct orc_handle { SpectrumBase *s; };
+
+int orc_config_init(kmr_config *c) {
+	memset(c, 0, sizeof(*c));
+	c->struct_size = sizeof(*c);
+	c->value_kind = KMR_VALUE_COUNT_DIR; c->min_weight = 0.10f; c->min_quality_score = 3; c->fastq_start_char = 33;
+	c->ext_min_quality = 20; c->separate_singletons = 1; c->kmer_subsample = 1; c->device = -1; c->rank = 0; c->world_size = 1;
+	c->estimated_depth = 20; c->estimated_error_rate = 0.35; c->kmers_per_bucket = 32; c->num_parts = 1; c->part_idx = 0;
+	return 0;
+}
+
+/* bucket sizing of KmerSpectrum(estimatedRawKmers, separateSingletons), KmerSpectrum.h:414-416
+ * via KmerMapByKmerArrayPair(estimatedRawKmers), Kmer.h:2837 */
+void orc_derive_buckets(const kmr_config *c, uint64_t *weak, uint64_t *singleton) {
+	uint64_t w = c->num_buckets_weak, s = c->num_buckets_singleton;
+	if (w == 0) { unsigned long est = (unsigned long)(int)(c->estimated_raw_kmers / c->estimated_depth); w = est / c->kmers_per_bucket + 1; }
+	if (s == 0) { unsigned long est = c->separate_singletons ? (unsigned long)(c->estimated_raw_kmers * c->estimated_error_rate) : 1; s = est / c->kmers_per_bucket + 1; }
+	*weak = resizeBuckets(w); *singleton = resizeBuckets(s);
+}
+
+orc_handle *orc_create(const kmr_config *cfg) {
+	initTables();
+	if (!cfg || cfg->k == 0) return NULL;
+	SpectrumBase *s;
+	uint64_t nw, ns; orc_derive_buckets(cfg, &nw, &ns);
+	uint32_t kb = (cfg->k + 3) / 4;
+	if (cfg->value_kind == KMR_VALUE_EXT) { Spectrum<TDExt, SingExt> *p = new Spectrum<TDExt, SingExt>(); p->weak.init(nw, kb); p->singleton.init(ns, kb); s = p; }
+	else { Spectrum<TDDir, SingDir> *p = new Spectrum<TDDir, SingDir>(); p->weak.init(nw, kb); p->singleton.init(ns, kb); s = p; }
+	s->cfg = *cfg; s->k = cfg->k; s->kb = kb;
+	s->g.minimumWeight = cfg->min_weight; s->g.extMinQuality = (uint8_t)cfg->ext_min_quality; s->g.discarded = 0;
+	s->hasSingletons = cfg->separate_singletons != 0; s->finalized = false;
+	s->rawKmers = s->rawGoodKmers = s->uniqueKmers = s->singletonKmers = 0; s->reads = 0;
+	initializeQualityToProbability(s->P, (unsigned char)cfg->min_quality_score, cfg->fastq_start_char);
+	orc_handle *h = new orc_handle; h->s = s; return h;
+}
+void orc_destroy(orc_handle *h) { if (h) { delete h->s; delete h; } }
+
+int orc_add_reads(orc_handle *h, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n, uint64_t firstIdx, const uint8_t *disc, int threads) {
+	h->s->addReads(bases, quals, offsets, n, firstIdx, disc, threads); return 0;
+}
+int orc_finalize(orc_handle *h, uint32_t minDepth) { h->s->finalize(minDepth); return 0; }
+int orc_get_stats(orc_handle *h, kmr_stats *o) {
+	SpectrumBase *s = h->s;
+	o->raw_kmers = s->rawKmers; o->raw_good_kmers = s->rawGoodKmers; o->unique_kmers = s->uniqueKmers; o->singleton_kmers = s->singletonKmers;
+	o->discarded = s->rawKmers - s->rawGoodKmers; o->weak_entries = s->mapSize(KMR_MAP_WEAK); o->singleton_entries = s->mapSize(KMR_MAP_SINGLETON); o->reads = s->reads;
+	return 0;
+}
+int orc_num_buckets(orc_handle *h, int which, uint64_t *out) { *out = h->s->numBuckets(which); return 0; }
+int orc_lookup(orc_handle *h, const uint8_t *keys, uint64_t n, uint32_t *counts) { for (uint64_t i = 0; i < n; i++) counts[i] = h->s->lookup(keys + i * h->s->kb); return 0; }
+int orc_image_size(orc_handle *h, int which, uint64_t *bytes) { *bytes = h->s->imageSize(which); return 0; }
+int orc_write_image(orc_handle *h, int which, void *dst, uint64_t cap) { if (cap < h->s->imageSize(which)) return KMR_ERR_CAPACITY; h->s->writeImage(which, (uint8_t *)dst); return 0; }
+int orc_load_image(orc_handle *h, int which, const void *src, uint64_t len) { return h->s->loadImage(which, (const uint8_t *)src, len) ? 0 : KMR_ERR_INVALID_ARG; }
+int orc_count_histogram(orc_handle *h, uint64_t *counts, double *weights, uint32_t nbins) { h->s->histogram(counts, weights, nbins); return 0; }
+int orc_dump(orc_handle *h, const char *path, uint32_t minDepth, int graph) {
+	FILE *f = fopen(path, "a"); if (!f) return KMR_ERR_INVALID_ARG; h->s->dump(f, minDepth, graph != 0); fclose(f); return 0;
+}
+uint64_t orc_export_entries(orc_handle *h, uint8_t *keys, uint32_t *count, uint32_t *dir, float *weighted, uint32_t *ext, uint64_t cap) {
+	return h->s->exportEntries(keys, count, dir, weighted, ext, cap);
+}
+void orc_quality_table(unsigned minQ, unsigned startChar, double *P) { initializeQualityToProbability(P, (unsigned char)minQ, startChar); }
+
+/* stateless pieces, for the known-answer tests */
+uint64_t orc_hash(const uint8_t *key, uint32_t len) { return getHash(key, (int)len); }
+void orc_hashlittle2(const void *key, uint64_t len, uint32_t *pc, uint32_t *pb) { hashlittle2(key, (size_t)len, pc, pb); }
+int64_t orc_compress_sequence(const char *bases, uint64_t len, uint8_t *out, uint32_t *mpos, char *mchar, uint64_t mcap) {
+	initTables();
+	std::vector<Markup> m; compressSequence(bases, (uint32_t)len, out, &m);
+	for (size_t i = 0; i < m.size() && i < mcap; i++) { if (mpos) mpos[i] = m[i].pos; if (mchar) mchar[i] = m[i].base; }
+	return (int64_t)m.size();
+}
+void orc_reverse_complement(const uint8_t *in, uint8_t *out, uint32_t length) { initTables(); reverseComplement(in, out, length); }
+void orc_shift_left(const uint8_t *in, uint8_t *out, uint32_t twoBitLength, uint32_t shift, int hasExtra) { initTables(); shiftLeft(in, out, twoBitLength, (unsigned char)shift, hasExtra != 0); }
+int orc_least_complement(const uint8_t *packed, uint32_t k, uint8_t *out) {
+	initTables();
+	uint32_t kb = (k + 3) / 4; reverseComplement(packed, out, k);
+	if (memcmp(packed, out, kb) <= 0) { memcpy(out, packed, kb); return 1; }
+	return 0;
+}
+/* per-read weighted k-mers (a3-a5) for direct comparison with the extract kernel */
+int64_t orc_build_weighted_kmers(const kmr_config *cfg, const char *bases, const char *quals, uint32_t len,
+                                 uint8_t *keys, float *weights, uint8_t *ext4, uint64_t cap) {
+	initTables();
+	KmerBuilder b; b.k = cfg->k; b.kb = (cfg->k + 3) / 4; b.fastqStart = cfg->fastq_start_char; b.extMinQuality = (uint8_t)cfg->ext_min_quality;
+	initializeQualityToProbability(b.P, (unsigned char)cfg->min_quality_score, cfg->fastq_start_char);
+	WeightedKmers wk; ReadView rv{bases, quals, len, false};
+	b.buildWeighted(rv, wk);
+	for (uint32_t i = 0; i < wk.n && i < cap; i++) {
+		memcpy(keys + (size_t)i * b.kb, wk.keys.data() + (size_t)i * b.kb, b.kb);
+		weights[i] = wk.weights[i];
+		if (ext4) { ext4[4 * i] = (uint8_t)wk.exts[i].leftB; ext4[4 * i + 1] = (uint8_t)wk.exts[i].rightB; ext4[4 * i + 2] = wk.exts[i].leftQ; ext4[4 * i + 3] = wk.exts[i].rightQ; }
+	}
+	return wk.n;
+}
+uint64_t orc_bucket_idx(uint64_t hash, uint64_t nb) { return hash & (nb - 1); }
+uint32_t orc_local_thread_id(uint64_t hash, uint64_t nb, uint32_t t) { return (uint32_t)getLocalThreadId(hash, nb, (int)t); }
+uint32_t orc_distributed_thread_id(uint64_t hash, uint32_t n) { return (uint32_t)getDistributedThreadId(hash, (int)n); }
+uint64_t orc_min_power_of_2(uint64_t n) { return getMinPowerOf2(n); }
+int orc_max_threads(void) {
+#ifdef _OPENMP
+	return omp_get_max_threads();
+#else
+	return 1;
+#endif
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+"""Shared test plumbing: ctypes bindings for the oracle (oracle/libkmr_oracle.so)
+and the product C-ABI (kmernator_amd/csrc/libkmernator_amd.so), a FASTQ reader and
+the synthetic read generator described in SURVEY.md section 8(d).
+
+The oracle is test infrastructure: it is loaded here, by __graft_entry__.smoke()
+and by bench.py's cpu_baseline leg only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libkmr_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_lookup3.so")
+PRODUCT_SO = os.path.join(ROOT, "kmernator_amd", "csrc", "libkmernator_amd.so")
+
+KMR_VALUE_COUNT_DIR, KMR_VALUE_EXT = 0, 1
+KMR_MAP_WEAK, KMR_MAP_SINGLETON, KMR_MAP_SOLID = 0, 1, 2
+
+
+class KmrConfig(C.Structure):
+    """Mirror of kmr_config in include/kmernator_amd.h."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("k", C.c_uint32),
+        ("num_buckets_weak", C.c_uint64), ("num_buckets_singleton", C.c_uint64),
+        ("estimated_raw_kmers", C.c_uint64),
+        ("value_kind", C.c_uint32), ("min_weight", C.c_float),
+        ("min_quality_score", C.c_uint32), ("fastq_start_char", C.c_uint32),
+        ("ext_min_quality", C.c_uint32), ("separate_singletons", C.c_uint32),
+        ("kmer_subsample", C.c_uint32), ("device", C.c_int32),
+        ("rank", C.c_uint32), ("world_size", C.c_uint32),
+        ("estimated_depth", C.c_double), ("estimated_error_rate", C.c_double),
+        ("kmers_per_bucket", C.c_uint32), ("num_parts", C.c_uint32),
+        ("part_idx", C.c_uint32), ("reserved0", C.c_uint32),
+        ("max_table_entries", C.c_uint64),
+    ]
+
+
+class KmrStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "raw_kmers", "raw_good_kmers", "unique_kmers", "singleton_kmers",
+        "discarded", "weak_entries", "singleton_entries", "reads")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def default_config(k, **kw):
+    c = KmrConfig()
+    c.struct_size = C.sizeof(KmrConfig)
+    c.k = k
+    c.value_kind = KMR_VALUE_COUNT_DIR
+    c.min_weight = 0.10
+    c.min_quality_score = 3
+    c.fastq_start_char = 33
+    c.ext_min_quality = 20
+    c.separate_singletons = 1
+    c.kmer_subsample = 1
+    c.device = -1
+    c.rank = 0
+    c.world_size = 1
+    c.estimated_depth = 20.0
+    c.estimated_error_rate = 0.35
+    c.kmers_per_bucket = 32
+    c.num_parts = 1
+    c.part_idx = 0
+    for name, v in kw.items():
+        setattr(c, name, v)
+    return c
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+            os.path.join(ORACLE_DIR, "kmr_oracle.cpp")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return ORACLE_SO
+
+
+_oracle = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        lib = C.CDLL(build_oracle())
+        u8p, u32p, u64p, f32p, f64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_uint64, C.c_float, C.c_double))
+        lib.orc_create.restype = C.c_void_p
+        lib.orc_create.argtypes = [C.POINTER(KmrConfig)]
+        lib.orc_destroy.argtypes = [C.c_void_p]
+        lib.orc_add_reads.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, u64p, C.c_uint64, C.c_uint64, u8p, C.c_int]
+        lib.orc_finalize.argtypes = [C.c_void_p, C.c_uint32]
+        lib.orc_get_stats.argtypes = [C.c_void_p, C.POINTER(KmrStats)]
+        lib.orc_num_buckets.argtypes = [C.c_void_p, C.c_int, u64p]
+        lib.orc_lookup.argtypes = [C.c_void_p, u8p, C.c_uint64, u32p]
+        lib.orc_image_size.argtypes = [C.c_void_p, C.c_int, u64p]
+        lib.orc_write_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+        lib.orc_load_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+        lib.orc_count_histogram.argtypes = [C.c_void_p, u64p, f64p, C.c_uint32]
+        lib.orc_dump.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int]
+        lib.orc_export_entries.restype = C.c_uint64
+        lib.orc_export_entries.argtypes = [C.c_void_p, u8p, u32p, u32p, f32p, u32p, C.c_uint64]
+        lib.orc_quality_table.argtypes = [C.c_uint, C.c_uint, f64p]
+        lib.orc_hash.restype = C.c_uint64
+        lib.orc_hash.argtypes = [C.c_char_p, C.c_uint32]
+        lib.orc_hashlittle2.argtypes = [C.c_char_p, C.c_uint64, u32p, u32p]
+        lib.orc_compress_sequence.restype = C.c_int64
+        lib.orc_compress_sequence.argtypes = [C.c_char_p, C.c_uint64, u8p, u32p, C.c_char_p, C.c_uint64]
+        lib.orc_reverse_complement.argtypes = [u8p, u8p, C.c_uint32]
+        lib.orc_shift_left.argtypes = [u8p, u8p, C.c_uint32, C.c_uint32, C.c_int]
+        lib.orc_least_complement.argtypes = [u8p, C.c_uint32, u8p]
+        lib.orc_build_weighted_kmers.restype = C.c_int64
+        lib.orc_build_weighted_kmers.argtypes = [C.POINTER(KmrConfig), C.c_char_p, C.c_char_p, C.c_uint32, u8p, f32p, u8p, C.c_uint64]
+        lib.orc_bucket_idx.restype = C.c_uint64
+        lib.orc_bucket_idx.argtypes = [C.c_uint64, C.c_uint64]
+        lib.orc_local_thread_id.restype = C.c_uint32
+        lib.orc_local_thread_id.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        lib.orc_distributed_thread_id.restype = C.c_uint32
+        lib.orc_distributed_thread_id.argtypes = [C.c_uint64, C.c_uint32]
+        lib.orc_min_power_of_2.restype = C.c_uint64
+        lib.orc_min_power_of_2.argtypes = [C.c_uint64]
+        lib.orc_derive_buckets.argtypes = [C.POINTER(KmrConfig), u64p, u64p]
+        _oracle = lib
+    return _oracle
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class ReadBatch:
+    """Flat read arrays in the layout kmr_add_reads takes."""
+
+    def __init__(self, seqs, quals=None, discarded=None):
+        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+        self.offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=self.offsets[1:])
+        self.bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if len(seqs) else np.zeros(0, np.uint8)
+        self.quals = None
+        if quals is not None:
+            self.quals = np.frombuffer(b"".join(quals), dtype=np.uint8).copy() if len(quals) else np.zeros(0, np.uint8)
+            assert self.quals.size == self.bases.size
+        self.discarded = None if discarded is None else np.asarray(discarded, dtype=np.uint8)
+        self.n = len(seqs)
+
+    @classmethod
+    def from_arrays(cls, bases, quals, offsets):
+        self = cls.__new__(cls)
+        self.bases, self.quals, self.offsets = bases, quals, offsets
+        self.discarded = None
+        self.n = len(offsets) - 1
+        return self
+
+    def slice(self, lo, hi):
+        b0, b1 = int(self.offsets[lo]), int(self.offsets[hi])
+        out = ReadBatch.__new__(ReadBatch)
+        out.offsets = (self.offsets[lo:hi + 1] - self.offsets[lo]).copy()
+        out.bases = self.bases[b0:b1].copy()
+        out.quals = None if self.quals is None else self.quals[b0:b1].copy()
+        out.discarded = None if self.discarded is None else self.discarded[lo:hi].copy()
+        out.n = hi - lo
+        return out
+
+    def seq(self, i):
+        return self.bases[int(self.offsets[i]):int(self.offsets[i + 1])].tobytes()
+
+    def qual(self, i):
+        return self.quals[int(self.offsets[i]):int(self.offsets[i + 1])].tobytes()
+
+
+def read_fastq(path):
+    seqs, quals, names = [], [], []
+    with open(path, "rb") as f:
+        while True:
+            name = f.readline()
+            if not name:
+                break
+            seq = f.readline().rstrip(b"\r\n")
+            f.readline()
+            q = f.readline().rstrip(b"\r\n")
+            names.append(name.rstrip(b"\r\n")[1:])
+            seqs.append(seq)
+            quals.append(q)
+    rb = ReadBatch(seqs, quals)
+    rb.names = names
+    return rb
+
+
+class _SpectrumCommon:
+    """Method set shared by the oracle and the product wrappers so parity tests
+    drive both with the same code."""
+
+    def stats(self):
+        s = KmrStats()
+        self._call("get_stats", self.h, C.byref(s))
+        return s.as_dict()
+
+    def num_buckets(self, which):
+        v = C.c_uint64()
+        self._call("num_buckets", self.h, which, C.byref(v))
+        return v.value
+
+    def finalize(self, min_depth=2):
+        self._call("finalize", self.h, min_depth)
+
+    def lookup(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint8)
+        n = keys.size // self.kb
+        out = np.zeros(n, dtype=np.uint32)
+        if n:
+            self._call("lookup", self.h, _ptr(keys, C.c_uint8), n, _ptr(out, C.c_uint32))
+        return out
+
+    def image(self, which=KMR_MAP_WEAK):
+        sz = C.c_uint64()
+        self._call("image_size", self.h, which, C.byref(sz))
+        buf = np.zeros(sz.value, dtype=np.uint8)
+        self._call("write_image", self.h, which, buf.ctypes.data_as(C.c_void_p), sz.value)
+        return buf
+
+    def load_image(self, which, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self._call("load_image", self.h, which, buf.ctypes.data_as(C.c_void_p), buf.size)
+
+    def histogram(self, nbins=256):
+        counts = np.zeros(nbins, dtype=np.uint64)
+        weights = np.zeros(nbins, dtype=np.float64)
+        self._call("count_histogram", self.h, _ptr(counts, C.c_uint64), _ptr(weights, C.c_double), nbins)
+        return counts, weights
+
+
+class OracleSpectrum(_SpectrumCommon):
+    def __init__(self, cfg):
+        self.lib = oracle_lib()
+        self.cfg = cfg
+        self.k = cfg.k
+        self.kb = (cfg.k + 3) // 4
+        self.h = self.lib.orc_create(C.byref(cfg))
+        assert self.h
+
+    def _call(self, name, *a):
+        rc = getattr(self.lib, "orc_" + name)(*a)
+        if rc != 0:
+            raise RuntimeError("orc_%s -> %d" % (name, rc))
+
+    def add_reads(self, rb, first_idx=0, threads=1):
+        self._call("add_reads", self.h, rb.bases.ctypes.data_as(C.c_char_p),
+                   None if rb.quals is None else rb.quals.ctypes.data_as(C.c_char_p),
+                   _ptr(rb.offsets, C.c_uint64), rb.n, first_idx,
+                   None if rb.discarded is None else _ptr(rb.discarded, C.c_uint8), threads)
+
+    def dump(self, path, min_depth, graph):
+        self._call("dump", self.h, path.encode(), min_depth, 1 if graph else 0)
+
+    def entries(self):
+        n = self.stats()["weak_entries"]
+        keys = np.zeros(n * self.kb, dtype=np.uint8)
+        count = np.zeros(n, dtype=np.uint32)
+        dirb = np.zeros(n, dtype=np.uint32)
+        w = np.zeros(n, dtype=np.float32)
+        ext = np.zeros(n * 12, dtype=np.uint32)
+        got = self.lib.orc_export_entries(self.h, _ptr(keys, C.c_uint8), _ptr(count, C.c_uint32), _ptr(dirb, C.c_uint32),
+                                          _ptr(w, C.c_float), _ptr(ext, C.c_uint32), n)
+        assert got == n
+        return keys.reshape(n, self.kb), count, dirb, w, ext.reshape(n, 12)
+
+    def close(self):
+        if self.h:
+            self.lib.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def oracle_weighted_kmers(cfg, seq, qual):
+    lib = oracle_lib()
+    kb = (cfg.k + 3) // 4
+    n = max(0, len(seq) - cfg.k + 1)
+    keys = np.zeros(max(n, 1) * kb, dtype=np.uint8)
+    w = np.zeros(max(n, 1), dtype=np.float32)
+    ext = np.zeros(max(n, 1) * 4, dtype=np.uint8)
+    got = lib.orc_build_weighted_kmers(C.byref(cfg), seq, qual, len(seq), _ptr(keys, C.c_uint8), _ptr(w, C.c_float),
+                                       _ptr(ext, C.c_uint8), max(n, 1))
+    assert got == n, (got, n)
+    return keys[:n * kb].reshape(n, kb), w[:n], ext[:n * 4].reshape(n, 4)
+
+
+# ---------------------------------------------------------------- synthetic reads
+def synth_reads(n_reads, read_len=150, genome_len=None, seed=1, err=0.01, quality="flat", n_rate=0.0):
+    """Synthetic reads per SURVEY.md 8(d): uniform random genome, uniform start, random
+    strand, per-base substitution with probability err, Phred-33 quals.  quality:
+    'flat' ('I' everywhere) or 'noisy' (Q in {40,30,20,10,2} with probs
+    {.80,.10,.05,.04,.01}, substituted bases forced to Q10).  n_rate adds N bases."""
+    rng = np.random.default_rng(seed)
+    if genome_len is None:
+        genome_len = max(read_len * 2, n_reads * read_len // 30)
+    genome = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
+    starts = rng.integers(0, genome_len - read_len + 1, size=n_reads)
+    idx = starts[:, None] + np.arange(read_len)[None, :]
+    codes = genome[idx]
+    strand = rng.integers(0, 2, size=n_reads).astype(bool)
+    codes[strand] = (3 - codes[strand])[:, ::-1]
+    errs = rng.random(codes.shape) < err
+    shift = rng.integers(1, 4, size=codes.shape, dtype=np.uint8)
+    codes = np.where(errs, (codes + shift) & 3, codes).astype(np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    bases = lut[codes]
+    if quality == "flat":
+        quals = np.full(codes.shape, ord("I"), dtype=np.uint8)
+    else:
+        qv = np.array([40, 30, 20, 10, 2], dtype=np.uint8)
+        pick = rng.choice(5, size=codes.shape, p=[0.80, 0.10, 0.05, 0.04, 0.01])
+        quals = (qv[pick] + 33).astype(np.uint8)
+        quals[errs] = 10 + 33
+    if n_rate > 0:
+        ns = rng.random(codes.shape) < n_rate
+        bases = np.where(ns, ord("N"), bases).astype(np.uint8)
+        quals = np.where(ns, 33 + 2, quals).astype(np.uint8)
+    offsets = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len))
+    return ReadBatch.from_arrays(np.ascontiguousarray(bases.reshape(-1)), np.ascontiguousarray(quals.reshape(-1)), offsets)
+
+
+def parse_image(buf, kb, vsize):
+    """Decode the reference on-disk map layout (src/Kmer.h:3143-3159) into
+    (num_buckets, mask, [(keys[n,kb], values[n,vsize])...])."""
+    hdr = np.frombuffer(buf[:16].tobytes(), dtype=np.uint64)
+    nb, mask = int(hdr[0]), int(hdr[1])
+    offs = np.frombuffer(buf[16:16 + 8 * nb].tobytes(), dtype=np.uint64)
+    buckets = []
+    for i in range(nb):
+        o = int(offs[i])
+        n = int(np.frombuffer(buf[o:o + 4].tobytes(), dtype=np.uint32)[0])
+        keys = buf[o + 4:o + 4 + n * kb].reshape(n, kb)
+        vals = buf[o + 4 + n * kb:o + 4 + n * (kb + vsize)].reshape(n, vsize)
+        buckets.append((keys, vals))
+    return nb, mask, buckets
