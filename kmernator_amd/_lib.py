@@ -1,0 +1,123 @@
+"""ctypes binding of the C-ABI in include/kmernator_amd.h.
+
+The shared library is built in-tree (kmernator_amd/csrc/libkmernator_amd.so) by
+__graft_entry__.build() / `make -C kmernator_amd/csrc`.  There is no fallback: if the
+library is missing, load() raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkmernator_amd.so")
+
+KMR_VALUE_COUNT_DIR, KMR_VALUE_EXT = 0, 1
+KMR_MAP_WEAK, KMR_MAP_SINGLETON, KMR_MAP_SOLID = 0, 1, 2
+
+STATUS = {0: "KMR_OK", -1: "KMR_ERR_INVALID_ARG", -2: "KMR_ERR_NO_DEVICE", -3: "KMR_ERR_HIP", -4: "KMR_ERR_OOM",
+          -5: "KMR_ERR_STATE", -6: "KMR_ERR_CAPACITY", -7: "KMR_ERR_UNSUPPORTED"}
+
+
+class KmrConfig(C.Structure):
+    """kmr_config"""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("k", C.c_uint32),
+        ("num_buckets_weak", C.c_uint64), ("num_buckets_singleton", C.c_uint64),
+        ("estimated_raw_kmers", C.c_uint64),
+        ("value_kind", C.c_uint32), ("min_weight", C.c_float),
+        ("min_quality_score", C.c_uint32), ("fastq_start_char", C.c_uint32),
+        ("ext_min_quality", C.c_uint32), ("separate_singletons", C.c_uint32),
+        ("kmer_subsample", C.c_uint32), ("device", C.c_int32),
+        ("rank", C.c_uint32), ("world_size", C.c_uint32),
+        ("estimated_depth", C.c_double), ("estimated_error_rate", C.c_double),
+        ("kmers_per_bucket", C.c_uint32), ("num_parts", C.c_uint32),
+        ("part_idx", C.c_uint32), ("reserved0", C.c_uint32),
+        ("max_table_entries", C.c_uint64),
+    ]
+
+
+class KmrStats(C.Structure):
+    """kmr_stats"""
+    _fields_ = [(n, C.c_uint64) for n in (
+        "raw_kmers", "raw_good_kmers", "unique_kmers", "singleton_kmers",
+        "discarded", "weak_entries", "singleton_entries", "reads")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+# every symbol include/kmernator_amd.h declares
+EXPORTS = [
+    "kmr_abi_version", "kmr_config_init", "kmr_create", "kmr_destroy", "kmr_last_error", "kmr_num_buckets",
+    "kmr_add_reads", "kmr_add_reads_dev", "kmr_sync", "kmr_finalize", "kmr_get_stats", "kmr_lookup",
+    "kmr_lookup_reads", "kmr_image_size", "kmr_write_image", "kmr_load_image", "kmr_count_histogram",
+    "kmr_dump_mercount", "kmr_dump_mergraph", "kmr_hash", "kmr_bucket_idx", "kmr_local_thread_id",
+    "kmr_distributed_thread_id", "kmr_compress_sequence", "kmr_least_complement", "kmr_extract_by_owner_dev",
+    "kmr_insert_records_dev", "kmr_stream", "kmr_kernel_time", "kmr_kernel_time_reset",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u8p, u32p, u64p, f64p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+    lib.kmr_abi_version.restype = C.c_uint32
+    lib.kmr_config_init.argtypes = [C.POINTER(KmrConfig)]
+    lib.kmr_create.argtypes = [C.POINTER(KmrConfig), C.POINTER(vp)]
+    lib.kmr_destroy.argtypes = [vp]
+    lib.kmr_destroy.restype = None
+    lib.kmr_last_error.argtypes = [vp]
+    lib.kmr_last_error.restype = C.c_char_p
+    lib.kmr_num_buckets.argtypes = [vp, C.c_int, u64p]
+    lib.kmr_add_reads.argtypes = [vp, vp, vp, u64p, C.c_uint64, C.c_uint64, u8p]
+    lib.kmr_add_reads_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    lib.kmr_sync.argtypes = [vp]
+    lib.kmr_finalize.argtypes = [vp, C.c_uint32]
+    lib.kmr_get_stats.argtypes = [vp, C.POINTER(KmrStats)]
+    lib.kmr_lookup.argtypes = [vp, u8p, C.c_uint64, u32p]
+    lib.kmr_lookup_reads.argtypes = [vp, vp, u64p, C.c_uint64, u32p, u64p]
+    lib.kmr_image_size.argtypes = [vp, C.c_int, u64p]
+    lib.kmr_write_image.argtypes = [vp, C.c_int, vp, C.c_uint64]
+    lib.kmr_load_image.argtypes = [vp, C.c_int, vp, C.c_uint64]
+    lib.kmr_count_histogram.argtypes = [vp, u64p, f64p, C.c_uint32]
+    lib.kmr_dump_mercount.argtypes = [vp, C.c_char_p, C.c_uint32]
+    lib.kmr_dump_mergraph.argtypes = [vp, C.c_char_p, C.c_uint32]
+    lib.kmr_hash.restype = C.c_uint64
+    lib.kmr_hash.argtypes = [C.c_char_p, C.c_uint32]
+    lib.kmr_bucket_idx.restype = C.c_uint64
+    lib.kmr_bucket_idx.argtypes = [C.c_uint64, C.c_uint64]
+    lib.kmr_local_thread_id.restype = C.c_uint32
+    lib.kmr_local_thread_id.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+    lib.kmr_distributed_thread_id.restype = C.c_uint32
+    lib.kmr_distributed_thread_id.argtypes = [C.c_uint64, C.c_uint32]
+    lib.kmr_compress_sequence.restype = C.c_int64
+    lib.kmr_compress_sequence.argtypes = [C.c_char_p, C.c_uint64, u8p, u32p, C.c_char_p, C.c_uint64]
+    lib.kmr_least_complement.argtypes = [u8p, C.c_uint32, u8p]
+    lib.kmr_extract_by_owner_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, C.c_uint64, vp]
+    lib.kmr_insert_records_dev.argtypes = [vp, vp, C.c_uint64]
+    lib.kmr_stream.restype = vp
+    lib.kmr_stream.argtypes = [vp]
+    lib.kmr_kernel_time.argtypes = [vp, C.c_int, f64p, u64p]
+    lib.kmr_kernel_time_reset.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def default_config(k, **kw):
+    c = KmrConfig()
+    load().kmr_config_init(C.byref(c))
+    c.k = k
+    for name, v in kw.items():
+        setattr(c, name, v)
+    return c
+
+
+def record_bytes(k):
+    """KMR_RECORD_BYTES(k)"""
+    return 8 * ((((k + 3) // 4) + 7) // 8) + 8

@@ -1,0 +1,789 @@
+/*
+ * kmr_api.hip -- C-ABI of include/kmernator_amd.h on top of the HIP kernels.
+ *
+ * Host logic only: handle life cycle, device memory, launches on the handle's
+ * stream, growth of the device table, finalize (bucket histogram -> scan ->
+ * scatter -> sort -> image) and the stateless helpers.  There is no CPU
+ * fallback: every compute entry point needs a HIP device and fails with
+ * KMR_ERR_NO_DEVICE otherwise.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kmernator_amd.h"
+#include "kmr_kernels.hpp"
+
+using namespace kmr;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevMap {                      /* a finalized map resident in HBM */
+	uint64_t nb = 0, n = 0;
+	uint64_t *start = nullptr;       /* [nb+1] */
+	uint64_t *keys = nullptr;        /* [n][W] */
+	uint32_t *vals = nullptr;        /* weak: [n][vw] */
+	uint8_t *sweight = nullptr;      /* singleton */
+	uint32_t *spkt = nullptr;        /* singleton, EXT */
+	uint8_t *image = nullptr;        /* reference layout, built lazily */
+	uint64_t image_bytes = 0;
+	bool present = false;
+};
+
+}  // namespace
+
+struct kmr_handle {
+	kmr_config cfg;
+	uint32_t k = 0, kb = 0, W = 0;
+	bool ext = false;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	/* device table */
+	void *slots = nullptr;
+	ExtSlot *extslots = nullptr;
+	uint32_t log2cap = 0;
+	uint64_t occupied = 0;           /* exact as of the last sync */
+	uint64_t pending_kmers = 0;      /* upper bound of keys added since */
+	double *dP = nullptr;
+	DevStats *dstats = nullptr;
+	uint32_t *derr = nullptr;
+	uint64_t stream_base = 0, reads = 0;
+	uint64_t nb_weak = 0, nb_sing = 0;
+	bool finalized = false, has_singletons = true;
+	DevMap weak, sing;
+	kmr_stats stats;
+	/* timing */
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	double ms[2] = {0, 0};
+	uint64_t launches[2] = {0, 0};
+	std::vector<std::pair<hipEvent_t, hipEvent_t> > pending_events[2];
+};
+
+namespace {
+
+#define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+	(h)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+	return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+
+int fail(kmr_handle *h, int code, const std::string &msg) { if (h) h->err = msg; else g_create_error = msg; return code; }
+
+uint64_t min_pow2(uint64_t n) {   /* BucketExposedMapLogic::getMinPowerOf2, src/Kmer.h:2199-2212 */
+	uint64_t p = n;
+	if (p == 0) p = 1;
+	else if ((p & (p - 1)) != 0) { p--; for (size_t i = 1; i < 64; i <<= 1) p |= p >> i; p++; }
+	return p;
+}
+uint64_t resize_buckets(uint64_t n) { if (n > 67108864ull) n = 67108864ull; return min_pow2(n); }   /* :2224-2229 */
+
+/* Read::initializeQualityToProbability (src/Sequence.cpp:522-540) as a function of the Phred value;
+ * the reference rescales reads to base 33 first (ReadSet.cpp:324-337) */
+void quality_table(double P[256], unsigned minQ, unsigned startChar) {
+	for (int raw = 0; raw < 256; raw++) {
+		int i = raw - (int)startChar + 33;
+		if (i < 33 + (int)minQ) P[raw] = 0.0;
+		else if (i < 103) P[raw] = 1.0 - pow(10.0, ((33 - i) / 10.0));
+		else P[raw] = 1.0;
+	}
+}
+
+size_t slot_bytes(uint32_t W) {
+	switch (W) { case 1: return sizeof(Slot<1>); case 2: return sizeof(Slot<2>); case 3: return sizeof(Slot<3>); default: return sizeof(Slot<4>); }
+}
+
+DevParams dev_params(kmr_handle *h) {
+	DevParams p;
+	p.k = h->k; p.kb = h->kb; p.min_weight = h->cfg.min_weight; p.fastq_start = h->cfg.fastq_start_char; p.ext_min_q = h->cfg.ext_min_quality;
+	p.subsample = h->cfg.kmer_subsample; p.rank = h->cfg.rank; p.world = h->cfg.world_size; p.num_parts = h->cfg.num_parts; p.part_idx = h->cfg.part_idx;
+	p.P = h->dP; p.stats = h->dstats; p.err = h->derr;
+	return p;
+}
+
+int grid_for(uint64_t n, int block = 256, int maxBlocks = 256 * 16) {
+	uint64_t g = (n + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > (uint64_t)maxBlocks) g = maxBlocks;
+	return (int)g;
+}
+
+template <int W> Table<W> table_of(kmr_handle *h) { Table<W> t; t.slots = (Slot<W> *)h->slots; t.ext = h->extslots; t.log2cap = h->log2cap; return t; }
+
+template <int W> int clear_table(kmr_handle *h, void *slots, ExtSlot *ext, uint32_t log2cap) {
+	hipLaunchKernelGGL(table_clear_kernel<W>, dim3(grid_for(1ull << log2cap)), dim3(256), 0, h->stream, (Slot<W> *)slots, ext, 1ull << log2cap);
+	HIPCHK(h, hipGetLastError());
+	return 0;
+}
+int clear_table_any(kmr_handle *h, void *slots, ExtSlot *ext, uint32_t log2cap) {
+	switch (h->W) { case 1: return clear_table<1>(h, slots, ext, log2cap); case 2: return clear_table<2>(h, slots, ext, log2cap);
+	case 3: return clear_table<3>(h, slots, ext, log2cap); default: return clear_table<4>(h, slots, ext, log2cap); }
+}
+
+int alloc_table(kmr_handle *h, uint32_t log2cap, void **slots, ExtSlot **ext) {
+	*slots = nullptr; *ext = nullptr;
+	HIPCHK(h, hipMalloc(slots, slot_bytes(h->W) << log2cap));
+	if (h->ext) { hipError_t e = hipMalloc((void **)ext, sizeof(ExtSlot) << log2cap); if (e != hipSuccess) { hipFree(*slots); *slots = nullptr; h->err = "hipMalloc(ext slots)"; return KMR_ERR_OOM; } }
+	return clear_table_any(h, *slots, *ext, log2cap);
+}
+
+/* read the device error word and counters; synchronises the stream */
+int sync_state(kmr_handle *h) {
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	for (int which = 0; which < 2; which++) {
+		for (auto &pr : h->pending_events[which]) {
+			float ms = 0; hipEventElapsedTime(&ms, pr.first, pr.second);
+			h->ms[which] += ms; h->launches[which]++;
+			hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+		}
+		h->pending_events[which].clear();
+	}
+	uint32_t e = 0; DevStats s;
+	HIPCHK(h, hipMemcpy(&e, h->derr, sizeof(e), hipMemcpyDeviceToHost));
+	HIPCHK(h, hipMemcpy(&s, h->dstats, sizeof(s), hipMemcpyDeviceToHost));
+	h->stats.raw_kmers = s.raw; h->stats.raw_good_kmers = s.good; h->stats.discarded = s.raw - s.good;
+	h->occupied = s.claimed; h->pending_kmers = 0;
+	if (e & ERR_READ_TOO_LONG) return fail(h, KMR_ERR_UNSUPPORTED, "a read is longer than the per-wavefront LDS tile (" + std::to_string(TILE_SPAN) + " bases)");
+	if (e & ERR_TABLE_FULL) return fail(h, KMR_ERR_CAPACITY, "device k-mer table is full; raise kmr_config.max_table_entries / estimated_raw_kmers");
+	if (e & ERR_SEGMENT_OVERFLOW) return fail(h, KMR_ERR_CAPACITY, "an owner segment overflowed seg_capacity");
+	return 0;
+}
+
+template <int W, bool EXT> int grow_table_t(kmr_handle *h, uint32_t newlog) {
+	void *ns; ExtSlot *ne;
+	int rc = alloc_table(h, newlog, &ns, &ne);
+	if (rc) return rc;
+	Table<W> src = table_of<W>(h), dst; dst.slots = (Slot<W> *)ns; dst.ext = ne; dst.log2cap = newlog;
+	hipLaunchKernelGGL((rehash_kernel<W, EXT>), dim3(grid_for(1ull << h->log2cap)), dim3(256), 0, h->stream, src, dst, h->kb, h->derr);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(h->slots); if (h->extslots) hipFree(h->extslots);
+	h->slots = ns; h->extslots = ne; h->log2cap = newlog;
+	return 0;
+}
+int grow_table(kmr_handle *h, uint32_t newlog) {
+#define GROW(Wv) (h->ext ? grow_table_t<Wv, true>(h, newlog) : grow_table_t<Wv, false>(h, newlog))
+	switch (h->W) { case 1: return GROW(1); case 2: return GROW(2); case 3: return GROW(3); default: return GROW(4); }
+#undef GROW
+}
+
+/* make room for up to 'incoming' new keys: keep the load factor below 0.85 even if all are new */
+int ensure_capacity(kmr_handle *h, uint64_t incoming) {
+	const uint64_t cap = 1ull << h->log2cap;
+	if ((double)(h->occupied + h->pending_kmers + incoming) <= 0.85 * (double)cap) { h->pending_kmers += incoming; return 0; }
+	int rc = sync_state(h);          /* learn the true occupancy */
+	if (rc) return rc;
+	if ((double)(h->occupied + incoming) > 0.85 * (double)cap) {
+		uint32_t nl = h->log2cap;
+		while ((double)(h->occupied + incoming) > 0.6 * (double)(1ull << nl)) nl++;
+		rc = grow_table(h, nl);
+		if (rc) return rc;
+	}
+	h->pending_kmers = incoming;
+	return 0;
+}
+
+void time_begin(kmr_handle *h, int which, hipEvent_t *a, hipEvent_t *b) {
+	hipEventCreate(a); hipEventCreate(b);
+	hipEventRecord(*a, h->stream);
+	(void)which;
+}
+void time_end(kmr_handle *h, int which, hipEvent_t a, hipEvent_t b) {
+	hipEventRecord(b, h->stream);
+	h->pending_events[which].push_back(std::make_pair(a, b));
+}
+
+const size_t EXTRACT_SMEM = (size_t)WAVES_PER_BLOCK * 2 * TILE_BUF;
+
+template <int W, bool EXT, class Op> int launch_extract(kmr_handle *h, const ReadsView &rv, const Op &op) {
+	static bool attr_set = false;
+	auto kern = extract_kernel<W, EXT, Op>;
+	if (!attr_set) { HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXTRACT_SMEM)); attr_set = true; }
+	const uint64_t tiles = (rv.n_reads + 63) / 64;
+	const uint64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+	if (blocks == 0) return 0;
+	if (blocks > 0x7fffffffull) return fail(h, KMR_ERR_INVALID_ARG, "too many reads in one batch");
+	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES_PER_BLOCK * 64), EXTRACT_SMEM, h->stream, rv, dev_params(h), op);
+	HIPCHK(h, hipGetLastError());
+	return 0;
+}
+
+template <int W, bool EXT> int add_reads_dev_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
+	/* chunks of reads bounded so that a chunk cannot add more than ~2^27 keys between capacity checks */
+	const uint64_t n = rvAll.n_reads;
+	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
+	uint64_t chunk = std::max<uint64_t>(64, ((1ull << 27) / avg) & ~63ull);
+	std::vector<uint64_t> off2(2);
+	for (uint64_t r = 0; r < n; r += chunk) {
+		const uint64_t m = std::min(chunk, n - r);
+		/* bases in this chunk: read the two boundary offsets */
+		HIPCHK(h, hipMemcpyAsync(&off2[0], rvAll.offsets + r, 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(h, hipMemcpyAsync(&off2[1], rvAll.offsets + r + m, 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+		const uint64_t bases = off2[1] - off2[0];
+		int rc = ensure_capacity(h, bases);     /* #k-mers <= #bases */
+		if (rc) return rc;
+		ReadsView rv = rvAll;
+		rv.offsets = rvAll.offsets + r; rv.n_reads = m;
+		rv.discarded = rvAll.discarded ? rvAll.discarded + r : nullptr;
+		rv.first_read_idx = rvAll.first_read_idx + r;
+		InsertOp<W, EXT> op; op.table = table_of<W>(h);
+		hipEvent_t a, b; time_begin(h, 0, &a, &b);
+		rc = launch_extract<W, EXT>(h, rv, op);
+		time_end(h, 0, a, b);
+		if (rc) return rc;
+	}
+	return 0;
+}
+
+int add_reads_dev_any(kmr_handle *h, const ReadsView &rv, uint64_t total_bases) {
+#define ADD(Wv) (h->ext ? add_reads_dev_t<Wv, true>(h, rv, total_bases) : add_reads_dev_t<Wv, false>(h, rv, total_bases))
+	switch (h->W) { case 1: return ADD(1); case 2: return ADD(2); case 3: return ADD(3); default: return ADD(4); }
+#undef ADD
+}
+
+int exclusive_scan(kmr_handle *h, const uint32_t *in, uint64_t n, uint64_t *out /* n+1 */) {
+	const uint64_t nblocks = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+	unsigned long long *sums, *total;
+	HIPCHK(h, hipMalloc((void **)&sums, sizeof(unsigned long long) * (nblocks + 1)));
+	total = sums + nblocks;
+	hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, h->stream, in, n, sums);
+	hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, h->stream, sums, nblocks, total);
+	hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, h->stream, in, n, sums, out);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(sums);
+	return 0;
+}
+
+void free_map(DevMap &m) {
+	if (m.start) hipFree(m.start); if (m.keys) hipFree(m.keys); if (m.vals) hipFree(m.vals);
+	if (m.sweight) hipFree(m.sweight); if (m.spkt) hipFree(m.spkt); if (m.image) hipFree(m.image);
+	m = DevMap();
+}
+
+template <int W> MapView<W> view_of(const DevMap &m, uint32_t vw) {
+	MapView<W> v; v.start = m.start; v.keys = m.keys; v.vals = m.vals; v.sweight = m.sweight; v.nb = m.present ? m.nb : 0; v.vw = vw;
+	return v;
+}
+
+template <int W, bool EXT> int finalize_t(kmr_handle *h, uint32_t min_depth) {
+	int rc = sync_state(h);
+	if (rc) return rc;
+	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
+	FinalizeParams f; f.kb = h->kb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	const bool keepSing = f.has_singletons && min_depth <= 1;
+	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr;
+	HIPCHK(h, hipMalloc((void **)&wc, 4 * h->nb_weak)); HIPCHK(h, hipMalloc((void **)&sc, 4 * h->nb_sing)); HIPCHK(h, hipMalloc((void **)&fc, sizeof(FinalizeCounters)));
+	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream)); HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream));
+	Table<W> t = table_of<W>(h);
+	const int g = grid_for(1ull << h->log2cap);
+	hipLaunchKernelGGL(classify_kernel<W>, dim3(g), dim3(256), 0, h->stream, t, f, wc, sc, fc);
+	HIPCHK(h, hipGetLastError());
+	FinalizeCounters c;
+	HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	h->stats.unique_kmers = c.unique; h->stats.singleton_kmers = c.singletons;
+	DevMap &wm = h->weak, &sm = h->sing;
+	free_map(wm); free_map(sm);
+	wm.nb = h->nb_weak; wm.n = c.weak_kept; wm.present = true;
+	sm.nb = h->nb_sing; sm.n = c.sing_kept; sm.present = keepSing;
+	const uint32_t vw = EXT ? 15 : 3;
+	HIPCHK(h, hipMalloc((void **)&wm.start, 8 * (wm.nb + 1))); HIPCHK(h, hipMalloc((void **)&sm.start, 8 * (sm.nb + 1)));
+	rc = exclusive_scan(h, wc, wm.nb, wm.start); if (rc) return rc;
+	rc = exclusive_scan(h, sc, sm.nb, sm.start); if (rc) return rc;
+	HIPCHK(h, hipMalloc((void **)&wm.keys, std::max<uint64_t>(8, 8ull * W * wm.n))); HIPCHK(h, hipMalloc((void **)&wm.vals, std::max<uint64_t>(8, 4ull * vw * wm.n)));
+	HIPCHK(h, hipMalloc((void **)&sm.keys, std::max<uint64_t>(8, 8ull * W * sm.n))); HIPCHK(h, hipMalloc((void **)&sm.sweight, std::max<uint64_t>(8, sm.n)));
+	if (EXT) HIPCHK(h, hipMalloc((void **)&sm.spkt, std::max<uint64_t>(8, 4ull * sm.n)));
+	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
+	hipLaunchKernelGGL((scatter_kernel<W, EXT>), dim3(g), dim3(256), 0, h->stream, t, f, wm.start, wc, wm.keys, wm.vals, sm.start, sc, sm.keys, sm.sweight, sm.spkt);
+	HIPCHK(h, hipGetLastError());
+	SortView<W> sv; sv.keys = wm.keys; sv.vals = wm.vals; sv.b8 = nullptr; sv.pkt = nullptr; sv.vw = vw;
+	hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(wm.nb, 64)), dim3(64), 0, h->stream, sv, wm.start, wm.nb);
+	if (sm.n) {
+		SortView<W> ss; ss.keys = sm.keys; ss.vals = nullptr; ss.b8 = sm.sweight; ss.pkt = sm.spkt; ss.vw = 0;
+		hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(sm.nb, 64)), dim3(64), 0, h->stream, ss, sm.start, sm.nb);
+	}
+	HIPCHK(h, hipGetLastError());
+	time_end(h, 1, ea, eb);
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(wc); hipFree(sc); hipFree(fc);
+	/* the table is no longer needed */
+	hipFree(h->slots); h->slots = nullptr; if (h->extslots) { hipFree(h->extslots); h->extslots = nullptr; }
+	h->has_singletons = keepSing;
+	if (!keepSing) { sm.n = 0; }
+	h->stats.weak_entries = wm.n; h->stats.singleton_entries = keepSing ? sm.n : 0;
+	h->finalized = true;
+	return sync_state(h);
+}
+
+template <int W> int build_image_t(kmr_handle *h, DevMap &m, bool weakMap) {
+	if (m.image) return 0;
+	const uint32_t vw = h->ext ? 15 : 3;
+	const uint32_t vbytes = weakMap ? (h->ext ? 60 : 12) : (h->ext ? 5 : 1);
+	m.image_bytes = 8 * (2 + m.nb) + 4 * m.nb + m.n * (h->kb + vbytes);
+	HIPCHK(h, hipMalloc((void **)&m.image, m.image_bytes));
+	hipLaunchKernelGGL(image_header_kernel, dim3(grid_for(m.nb)), dim3(256), 0, h->stream, m.image, m.start, m.nb, h->kb, vbytes);
+	if (m.n) hipLaunchKernelGGL(image_entries_kernel<W>, dim3(grid_for(m.n)), dim3(256), 0, h->stream, m.image, m.start, m.nb, h->kb, vbytes,
+	                           m.keys, weakMap ? m.vals : nullptr, vw, m.sweight, m.spkt, m.n);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	return 0;
+}
+int build_image(kmr_handle *h, DevMap &m, bool weakMap) {
+	switch (h->W) { case 1: return build_image_t<1>(h, m, weakMap); case 2: return build_image_t<2>(h, m, weakMap);
+	case 3: return build_image_t<3>(h, m, weakMap); default: return build_image_t<4>(h, m, weakMap); }
+}
+
+template <int W> int load_image_t(kmr_handle *h, DevMap &m, bool weakMap, const uint8_t *src, uint64_t len) {
+	if (len < 16) return fail(h, KMR_ERR_INVALID_ARG, "image too short");
+	uint64_t nb, mask; memcpy(&nb, src, 8); memcpy(&mask, src + 8, 8);
+	if (nb == 0 || (nb & (nb - 1)) || mask != nb - 1 || len < 8 * (2 + nb) + 4 * nb) return fail(h, KMR_ERR_INVALID_ARG, "bad image header");
+	const uint32_t vw = h->ext ? 15 : 3;
+	const uint32_t vbytes = weakMap ? (h->ext ? 60 : 12) : (h->ext ? 5 : 1);
+	if ((len - 8 * (2 + nb) - 4 * nb) % (h->kb + vbytes) != 0) return fail(h, KMR_ERR_INVALID_ARG, "image size does not match k / value type");
+	free_map(m);
+	m.nb = nb; m.n = (len - 8 * (2 + nb) - 4 * nb) / (h->kb + vbytes); m.present = true;
+	/* validate offsets on the host before any kernel dereferences them */
+	const uint64_t *offs = (const uint64_t *)(src + 16);
+	uint64_t expect = 8 * (2 + nb);
+	for (uint64_t b = 0; b < nb; b++) {
+		if (offs[b] != expect || expect + 4 > len) return fail(h, KMR_ERR_INVALID_ARG, "image offsets are not the packed store() layout");
+		uint32_t cnt; memcpy(&cnt, src + expect, 4);
+		expect += 4 + (uint64_t)cnt * (h->kb + vbytes);
+		if (expect > len) return fail(h, KMR_ERR_INVALID_ARG, "image bucket runs past the end");
+	}
+	if (expect != len) return fail(h, KMR_ERR_INVALID_ARG, "image length mismatch");
+	HIPCHK(h, hipMalloc((void **)&m.image, len)); m.image_bytes = len;
+	HIPCHK(h, hipMemcpy(m.image, src, len, hipMemcpyHostToDevice));
+	uint32_t *counts; HIPCHK(h, hipMalloc((void **)&counts, 4 * nb));
+	hipLaunchKernelGGL(image_counts_kernel, dim3(grid_for(nb)), dim3(256), 0, h->stream, m.image, nb, counts);
+	HIPCHK(h, hipMalloc((void **)&m.start, 8 * (nb + 1)));
+	int rc = exclusive_scan(h, counts, nb, m.start); hipFree(counts); if (rc) return rc;
+	HIPCHK(h, hipMalloc((void **)&m.keys, std::max<uint64_t>(8, 8ull * W * m.n)));
+	if (weakMap) HIPCHK(h, hipMalloc((void **)&m.vals, std::max<uint64_t>(8, 4ull * vw * m.n)));
+	else { HIPCHK(h, hipMalloc((void **)&m.sweight, std::max<uint64_t>(8, m.n))); if (h->ext) HIPCHK(h, hipMalloc((void **)&m.spkt, std::max<uint64_t>(8, 4 * m.n))); }
+	if (m.n) hipLaunchKernelGGL(image_unpack_kernel<W>, dim3(grid_for(m.n)), dim3(256), 0, h->stream, m.image, m.start, nb, h->kb, vbytes, m.keys, m.vals, vw, m.sweight, m.spkt, m.n);
+	/* restore() accepts unsorted buckets (setLastSorted); lookups here need them sorted */
+	SortView<W> sv; sv.keys = m.keys; sv.vals = m.vals; sv.b8 = m.sweight; sv.pkt = m.spkt; sv.vw = weakMap ? vw : 0;
+	hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(nb, 64)), dim3(64), 0, h->stream, sv, m.start, nb);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(m.image); m.image = nullptr; m.image_bytes = 0;    /* rebuilt (sorted) on demand */
+	return 0;
+}
+
+template <int W> int lookup_t(kmr_handle *h, const uint8_t *packed, uint64_t n, uint32_t *counts) {
+	uint8_t *dk; uint32_t *dc;
+	HIPCHK(h, hipMalloc((void **)&dk, std::max<uint64_t>(8, n * h->kb))); HIPCHK(h, hipMalloc((void **)&dc, std::max<uint64_t>(8, 4 * n)));
+	HIPCHK(h, hipMemcpyAsync(dk, packed, n * h->kb, hipMemcpyHostToDevice, h->stream));
+	const uint32_t vw = h->ext ? 15 : 3;
+	hipLaunchKernelGGL(lookup_keys_kernel<W>, dim3(grid_for(n)), dim3(256), 0, h->stream, view_of<W>(h->weak, vw), view_of<W>(h->sing, vw), dk, n, h->kb, dc);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipMemcpyAsync(counts, dc, 4 * n, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(dk); hipFree(dc);
+	return 0;
+}
+
+template <int W> int lookup_reads_t(kmr_handle *h, const ReadsView &rv, uint32_t *dout, const uint64_t *dout_off) {
+	LookupOp<W> op; const uint32_t vw = h->ext ? 15 : 3;
+	op.weak = view_of<W>(h->weak, vw); op.sing = view_of<W>(h->sing, vw); op.out = dout; op.out_offsets = dout_off; op.first_read_idx = rv.first_read_idx;
+	return launch_extract<W, false>(h, rv, op);
+}
+
+/* stage host read arrays on the device (padded so 16-byte tile loads stay inside the allocation) */
+struct StagedReads { uint8_t *b = nullptr, *q = nullptr, *d = nullptr; uint64_t *o = nullptr; void release() { if (b) hipFree(b); if (q) hipFree(q); if (d) hipFree(d); if (o) hipFree(o); b = q = d = nullptr; o = nullptr; } };
+int stage_reads(kmr_handle *h, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n, const uint8_t *disc, StagedReads &s, uint64_t &total) {
+	total = n ? offsets[n] - offsets[0] : 0;
+	HIPCHK(h, hipMalloc((void **)&s.b, total + 64)); HIPCHK(h, hipMalloc((void **)&s.o, 8 * (n + 1)));
+	HIPCHK(h, hipMemcpyAsync(s.b, bases + (n ? offsets[0] : 0), total, hipMemcpyHostToDevice, h->stream));
+	std::vector<uint64_t> rel(n + 1);
+	for (uint64_t i = 0; i <= n; i++) rel[i] = n ? offsets[i] - offsets[0] : 0;
+	HIPCHK(h, hipMemcpyAsync(s.o, rel.data(), 8 * (n + 1), hipMemcpyHostToDevice, h->stream));
+	if (quals) { HIPCHK(h, hipMalloc((void **)&s.q, total + 64)); HIPCHK(h, hipMemcpyAsync(s.q, quals + (n ? offsets[0] : 0), total, hipMemcpyHostToDevice, h->stream)); }
+	if (disc) { HIPCHK(h, hipMalloc((void **)&s.d, n + 8)); HIPCHK(h, hipMemcpyAsync(s.d, disc, n, hipMemcpyHostToDevice, h->stream)); }
+	HIPCHK(h, hipStreamSynchronize(h->stream));   /* rel[] goes out of scope */
+	return 0;
+}
+
+}  // namespace
+
+/* ====================================================================== */
+extern "C" {
+
+uint32_t kmr_abi_version(void) { return KMR_ABI_VERSION; }
+
+int kmr_config_init(kmr_config *c) {
+	if (!c) return KMR_ERR_INVALID_ARG;
+	memset(c, 0, sizeof(*c));
+	c->struct_size = sizeof(*c);
+	c->value_kind = KMR_VALUE_COUNT_DIR; c->min_weight = 0.10f; c->min_quality_score = 3; c->fastq_start_char = 33;
+	c->ext_min_quality = 20; c->separate_singletons = 1; c->kmer_subsample = 1; c->device = -1; c->rank = 0; c->world_size = 1;
+	c->estimated_depth = 20.0; c->estimated_error_rate = 0.35; c->kmers_per_bucket = 32; c->num_parts = 1; c->part_idx = 0;
+	return KMR_OK;
+}
+
+const char *kmr_last_error(const kmr_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int kmr_create(const kmr_config *cfg, kmr_handle **out) {
+	if (!cfg || !out) return fail(nullptr, KMR_ERR_INVALID_ARG, "null argument");
+	*out = nullptr;
+	if (cfg->struct_size != sizeof(kmr_config)) return fail(nullptr, KMR_ERR_INVALID_ARG, "kmr_config.struct_size mismatch (ABI)");
+	if (cfg->k < 1 || cfg->k > 128) return fail(nullptr, KMR_ERR_INVALID_ARG, "k must be in 1..128");
+	if (cfg->world_size < 1 || cfg->rank >= cfg->world_size) return fail(nullptr, KMR_ERR_INVALID_ARG, "bad rank/world_size");
+	if (cfg->value_kind > KMR_VALUE_EXT) return fail(nullptr, KMR_ERR_INVALID_ARG, "bad value_kind");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, KMR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+	kmr_handle *h = new kmr_handle();
+	h->cfg = *cfg;
+	if (h->cfg.kmer_subsample == 0) h->cfg.kmer_subsample = 1;
+	if (h->cfg.num_parts == 0) h->cfg.num_parts = 1;
+	h->k = cfg->k; h->kb = (cfg->k + 3) / 4; h->W = (h->kb + 7) / 8; h->ext = cfg->value_kind == KMR_VALUE_EXT;
+	memset(&h->stats, 0, sizeof(h->stats));
+	int rc = 0;
+	do {
+		if (cfg->device >= 0) { if (hipSetDevice(cfg->device) != hipSuccess) { rc = fail(nullptr, KMR_ERR_NO_DEVICE, "hipSetDevice failed"); break; } }
+		if (hipGetDevice(&h->device) != hipSuccess) { rc = fail(nullptr, KMR_ERR_NO_DEVICE, "hipGetDevice failed"); break; }
+		if (hipStreamCreate(&h->stream) != hipSuccess) { rc = fail(nullptr, KMR_ERR_HIP, "hipStreamCreate failed"); break; }
+		/* bucket sizing of the KmerSpectrum ctor (src/KmerSpectrum.h:414-416, src/Kmer.h:2837) */
+		uint64_t w = cfg->num_buckets_weak, s = cfg->num_buckets_singleton;
+		const double depth = cfg->estimated_depth > 0 ? cfg->estimated_depth : 20.0;
+		const uint32_t kpb = cfg->kmers_per_bucket ? cfg->kmers_per_bucket : 32;
+		if (w == 0) { unsigned long est = (unsigned long)(int)(cfg->estimated_raw_kmers / depth); w = est / kpb + 1; }
+		if (s == 0) { unsigned long est = cfg->separate_singletons ? (unsigned long)(cfg->estimated_raw_kmers * cfg->estimated_error_rate) : 1; s = est / kpb + 1; }
+		h->nb_weak = resize_buckets(w); h->nb_sing = resize_buckets(s);
+		h->has_singletons = cfg->separate_singletons != 0;
+		/* table capacity */
+		uint64_t want = cfg->max_table_entries ? (uint64_t)(cfg->max_table_entries / 0.7) : (uint64_t)(cfg->estimated_raw_kmers * 0.45 / 0.6);
+		if (cfg->world_size > 1 && !cfg->max_table_entries) want /= cfg->world_size;
+		uint32_t lg = 16; while ((1ull << lg) < want && lg < 40) lg++;
+		h->log2cap = lg;
+		double P[256]; quality_table(P, cfg->min_quality_score, cfg->fastq_start_char);
+		if (hipMalloc((void **)&h->dP, sizeof(P)) != hipSuccess || hipMalloc((void **)&h->dstats, sizeof(DevStats)) != hipSuccess || hipMalloc((void **)&h->derr, 4) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
+		hipMemcpy(h->dP, P, sizeof(P), hipMemcpyHostToDevice); hipMemset(h->dstats, 0, sizeof(DevStats)); hipMemset(h->derr, 0, 4);
+		rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
+		if (rc) { g_create_error = h->err; break; }
+		if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(nullptr, KMR_ERR_HIP, std::string("table clear failed: ") + hipGetErrorString(hipGetLastError())); break; }
+	} while (0);
+	if (rc) { kmr_destroy(h); return rc; }
+	*out = h;
+	return KMR_OK;
+}
+
+void kmr_destroy(kmr_handle *h) {
+	if (!h) return;
+	if (h->stream) hipStreamSynchronize(h->stream);
+	for (int which = 0; which < 2; which++) for (auto &pr : h->pending_events[which]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+	if (h->slots) hipFree(h->slots); if (h->extslots) hipFree(h->extslots);
+	if (h->dP) hipFree(h->dP); if (h->dstats) hipFree(h->dstats); if (h->derr) hipFree(h->derr);
+	free_map(h->weak); free_map(h->sing);
+	if (h->stream) hipStreamDestroy(h->stream);
+	delete h;
+}
+
+int kmr_num_buckets(const kmr_handle *h, int which, uint64_t *out) {
+	if (!h || !out) return KMR_ERR_INVALID_ARG;
+	if (which == KMR_MAP_WEAK) *out = h->finalized && h->weak.present ? h->weak.nb : h->nb_weak;
+	else if (which == KMR_MAP_SINGLETON) *out = h->finalized && h->sing.present ? h->sing.nb : h->nb_sing;
+	else return KMR_ERR_UNSUPPORTED;
+	return KMR_OK;
+}
+
+void *kmr_stream(kmr_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+int kmr_sync(kmr_handle *h) { if (!h) return KMR_ERR_INVALID_ARG; hipSetDevice(h->device); return sync_state(h); }
+
+int kmr_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals, const void *dev_offsets, uint64_t n_reads,
+                      uint64_t total_bases, uint64_t first_global_read_idx, const void *dev_discarded) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_add_reads after kmr_finalize");
+	if (n_reads == 0) return KMR_OK;
+	if (!dev_bases || !dev_offsets) return fail(h, KMR_ERR_INVALID_ARG, "null device buffer");
+	hipSetDevice(h->device);
+	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
+	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
+	int rc = add_reads_dev_any(h, rv, total_bases);
+	h->stream_base += total_bases; h->reads += n_reads; h->stats.reads = h->reads;
+	return rc;
+}
+
+int kmr_add_reads(kmr_handle *h, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n_reads,
+                  uint64_t first_global_read_idx, const uint8_t *discarded) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_add_reads after kmr_finalize");
+	if (n_reads == 0) return KMR_OK;
+	if (!bases || !offsets) return fail(h, KMR_ERR_INVALID_ARG, "null buffer");
+	hipSetDevice(h->device);
+	StagedReads s; uint64_t total = 0;
+	int rc = stage_reads(h, bases, quals, offsets, n_reads, discarded, s, total);
+	if (!rc) rc = kmr_add_reads_dev(h, s.b, s.q, s.o, n_reads, total, first_global_read_idx, s.d);
+	if (!rc) rc = sync_state(h);
+	else hipStreamSynchronize(h->stream);
+	s.release();
+	return rc;
+}
+
+int kmr_finalize(kmr_handle *h, uint32_t min_depth) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (h->finalized) return fail(h, KMR_ERR_STATE, "already finalized");
+	hipSetDevice(h->device);
+#define FIN(Wv) (h->ext ? finalize_t<Wv, true>(h, min_depth) : finalize_t<Wv, false>(h, min_depth))
+	switch (h->W) { case 1: return FIN(1); case 2: return FIN(2); case 3: return FIN(3); default: return FIN(4); }
+#undef FIN
+}
+
+int kmr_get_stats(kmr_handle *h, kmr_stats *out) {
+	if (!h || !out) return KMR_ERR_INVALID_ARG;
+	hipSetDevice(h->device);
+	if (!h->finalized) { int rc = sync_state(h); if (rc) return rc; h->stats.unique_kmers = h->occupied; }
+	h->stats.reads = h->reads;
+	*out = h->stats;
+	return KMR_OK;
+}
+
+int kmr_lookup(kmr_handle *h, const uint8_t *packed, uint64_t n, uint32_t *counts) {
+	if (!h || (n && (!packed || !counts))) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_lookup before kmr_finalize");
+	if (n == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	switch (h->W) { case 1: return lookup_t<1>(h, packed, n, counts); case 2: return lookup_t<2>(h, packed, n, counts);
+	case 3: return lookup_t<3>(h, packed, n, counts); default: return lookup_t<4>(h, packed, n, counts); }
+}
+
+int kmr_lookup_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads, uint32_t *counts_out, const uint64_t *out_offsets) {
+	if (!h || !bases || !offsets || !counts_out || !out_offsets) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_lookup_reads before kmr_finalize");
+	if (n_reads == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	StagedReads s; uint64_t total = 0;
+	int rc = stage_reads(h, bases, nullptr, offsets, n_reads, nullptr, s, total);
+	if (rc) { s.release(); return rc; }
+	/* size of the output = last offset + k-mers of the last read */
+	uint64_t outN = 0;
+	for (uint64_t r = 0; r < n_reads; r++) { uint64_t L = offsets[r + 1] - offsets[r]; uint64_t nk = L >= h->k ? L - h->k + 1 : 0; outN = std::max(outN, out_offsets[r] + nk); }
+	uint32_t *dout; uint64_t *doff;
+	HIPCHK(h, hipMalloc((void **)&dout, std::max<uint64_t>(8, 4 * outN))); HIPCHK(h, hipMalloc((void **)&doff, 8 * n_reads));
+	HIPCHK(h, hipMemsetAsync(dout, 0, 4 * outN, h->stream));
+	HIPCHK(h, hipMemcpyAsync(doff, out_offsets, 8 * n_reads, hipMemcpyHostToDevice, h->stream));
+	ReadsView rv; rv.bases = s.b; rv.quals = nullptr; rv.offsets = s.o; rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0;
+	switch (h->W) { case 1: rc = lookup_reads_t<1>(h, rv, dout, doff); break; case 2: rc = lookup_reads_t<2>(h, rv, dout, doff); break;
+	case 3: rc = lookup_reads_t<3>(h, rv, dout, doff); break; default: rc = lookup_reads_t<4>(h, rv, dout, doff); }
+	if (!rc) { HIPCHK(h, hipMemcpyAsync(counts_out, dout, 4 * outN, hipMemcpyDeviceToHost, h->stream)); rc = sync_state(h); }
+	else hipStreamSynchronize(h->stream);
+	hipFree(dout); hipFree(doff); s.release();
+	return rc;
+}
+
+static DevMap *map_of(kmr_handle *h, int which) {
+	if (which == KMR_MAP_WEAK) return &h->weak;
+	if (which == KMR_MAP_SINGLETON) return &h->sing;
+	return nullptr;
+}
+
+int kmr_image_size(kmr_handle *h, int which, uint64_t *bytes) {
+	if (!h || !bytes) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_image_size before kmr_finalize");
+	DevMap *m = map_of(h, which);
+	if (!m) return fail(h, KMR_ERR_UNSUPPORTED, "solid map is not built on this path");
+	const uint32_t vbytes = which == KMR_MAP_WEAK ? (h->ext ? 60 : 12) : (h->ext ? 5 : 1);
+	const uint64_t n = (which == KMR_MAP_SINGLETON && !m->present) ? 0 : m->n;
+	*bytes = 8 * (2 + m->nb) + 4 * m->nb + n * (h->kb + vbytes);
+	return KMR_OK;
+}
+
+int kmr_write_image(kmr_handle *h, int which, void *dst, uint64_t capacity) {
+	if (!h || !dst) return KMR_ERR_INVALID_ARG;
+	uint64_t need; int rc = kmr_image_size(h, which, &need); if (rc) return rc;
+	if (capacity < need) return fail(h, KMR_ERR_CAPACITY, "image buffer too small");
+	hipSetDevice(h->device);
+	DevMap *m = map_of(h, which);
+	if (which == KMR_MAP_SINGLETON && !m->present) {   /* cleared singleton map: numBuckets empty buckets */
+		uint8_t *p = (uint8_t *)dst; uint64_t nb = m->nb, mask = nb - 1; memcpy(p, &nb, 8); memcpy(p + 8, &mask, 8);
+		for (uint64_t b = 0; b < nb; b++) { uint64_t off = 8 * (2 + nb) + 4 * b; memcpy(p + 16 + 8 * b, &off, 8); uint32_t z = 0; memcpy(p + off, &z, 4); }
+		return KMR_OK;
+	}
+	rc = build_image(h, *m, which == KMR_MAP_WEAK); if (rc) return rc;
+	HIPCHK(h, hipMemcpy(dst, m->image, need, hipMemcpyDeviceToHost));
+	return KMR_OK;
+}
+
+int kmr_load_image(kmr_handle *h, int which, const void *src, uint64_t len) {
+	if (!h || !src) return KMR_ERR_INVALID_ARG;
+	if (h->reads != 0) return fail(h, KMR_ERR_STATE, "kmr_load_image needs a fresh handle");
+	DevMap *m = map_of(h, which);
+	if (!m) return fail(h, KMR_ERR_UNSUPPORTED, "solid map is not built on this path");
+	hipSetDevice(h->device);
+	int rc;
+	switch (h->W) { case 1: rc = load_image_t<1>(h, *m, which == KMR_MAP_WEAK, (const uint8_t *)src, len); break;
+	case 2: rc = load_image_t<2>(h, *m, which == KMR_MAP_WEAK, (const uint8_t *)src, len); break;
+	case 3: rc = load_image_t<3>(h, *m, which == KMR_MAP_WEAK, (const uint8_t *)src, len); break;
+	default: rc = load_image_t<4>(h, *m, which == KMR_MAP_WEAK, (const uint8_t *)src, len); }
+	if (rc) return rc;
+	if (h->slots) { hipFree(h->slots); h->slots = nullptr; if (h->extslots) { hipFree(h->extslots); h->extslots = nullptr; } }
+	if (which == KMR_MAP_WEAK) { h->nb_weak = m->nb; h->stats.weak_entries = m->n; if (!h->sing.present) { h->has_singletons = false; h->sing.nb = h->nb_sing; } }
+	else { h->nb_sing = m->nb; h->stats.singleton_entries = m->n; h->has_singletons = true; if (!h->weak.present) h->weak.nb = h->nb_weak; }
+	h->finalized = true;
+	return KMR_OK;
+}
+
+int kmr_count_histogram(kmr_handle *h, uint64_t *counts, double *weights, uint32_t n_bins) {
+	if (!h || !counts || n_bins < 2) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_count_histogram before kmr_finalize");
+	hipSetDevice(h->device);
+	unsigned long long *dc; double *dw = nullptr;
+	HIPCHK(h, hipMalloc((void **)&dc, 8 * n_bins)); HIPCHK(h, hipMemsetAsync(dc, 0, 8 * n_bins, h->stream));
+	if (weights) { HIPCHK(h, hipMalloc((void **)&dw, 8 * n_bins)); HIPCHK(h, hipMemsetAsync(dw, 0, 8 * n_bins, h->stream)); }
+	if (h->weak.present && h->weak.n)
+		hipLaunchKernelGGL(histogram_kernel, dim3(grid_for(h->weak.n)), dim3(256), 0, h->stream, h->weak.vals, h->ext ? 15u : 3u, h->weak.n, n_bins, dc, dw);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipMemcpyAsync(counts, dc, 8 * n_bins, hipMemcpyDeviceToHost, h->stream));
+	if (weights) HIPCHK(h, hipMemcpyAsync(weights, dw, 8 * n_bins, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(dc); if (dw) hipFree(dw);
+	return KMR_OK;
+}
+
+/* text dumps (src/Meraculous.h:107-134): formatting is host work on the downloaded weak map */
+static int dump_text(kmr_handle *h, const char *path, uint32_t min_depth, bool graph) {
+	if (!h || !path) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "dump before kmr_finalize");
+	if (graph && !h->ext) return fail(h, KMR_ERR_STATE, "mergraph needs value_kind = KMR_VALUE_EXT");
+	hipSetDevice(h->device);
+	const uint32_t vw = h->ext ? 15 : 3, W = h->W, k = h->k;
+	const uint64_t n = h->weak.n;
+	std::vector<uint64_t> keys(n * W); std::vector<uint32_t> vals(n * vw);
+	if (n) { HIPCHK(h, hipMemcpy(keys.data(), h->weak.keys, 8 * n * W, hipMemcpyDeviceToHost)); HIPCHK(h, hipMemcpy(vals.data(), h->weak.vals, 4 * n * vw, hipMemcpyDeviceToHost)); }
+	FILE *f = fopen(path, "a");
+	if (!f) return fail(h, KMR_ERR_INVALID_ARG, std::string("cannot open ") + path);
+	std::string fa(k, 'A'), rfa(k, 'A');
+	static const char dec[] = "ACGT";
+	static const int rcIdx[6] = {3, 2, 1, 0, 4, 5};
+	for (uint64_t e = 0; e < n; e++) {
+		const uint32_t *v = &vals[e * vw];
+		const uint32_t count = v[0] & 0xffff;
+		if ((int)count < (int)min_depth) continue;
+		for (uint32_t p = 0; p < k; p++) {
+			const uint32_t code = (uint32_t)(keys[e * W + (p >> 5)] >> (62 - 2 * (p & 31))) & 3;
+			fa[p] = dec[code]; rfa[k - 1 - p] = dec[3 - code];
+		}
+		if (!graph) fprintf(f, "%s\t%u\n%s\t%u\n", fa.c_str(), count, rfa.c_str(), count);
+		else {
+			const uint32_t *t = v + 3;
+			fprintf(f, "%s\t%u %u %u %u %u %u %u %u %u %u %u %u 0\n", fa.c_str(), t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]);
+			uint32_t r[12];   /* ExtensionTracking::getReverseComplement, src/KmerTrackingData.h:219-226 */
+			for (int i = 0; i < 6; i++) { r[rcIdx[i]] = t[6 + i]; r[6 + rcIdx[i]] = t[i]; }
+			fprintf(f, "%s\t%u %u %u %u %u %u %u %u %u %u %u %u 0\n", rfa.c_str(), r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]);
+		}
+	}
+	fclose(f);
+	return KMR_OK;
+}
+int kmr_dump_mercount(kmr_handle *h, const char *path, uint32_t min_depth) { return dump_text(h, path, min_depth, false); }
+int kmr_dump_mergraph(kmr_handle *h, const char *path, uint32_t min_depth) { return dump_text(h, path, min_depth, true); }
+
+/* ---- stateless helpers ------------------------------------------------- */
+uint64_t kmr_hash(const uint8_t *key, uint32_t len) {
+	if (!key || len == 0 || len > 32) return 0;
+	Key<4> k; key_from_bytes<4>(k, key, len);
+	return key_hash<4>(k, len);
+}
+uint64_t kmr_bucket_idx(uint64_t hash, uint64_t nb) { return hash & (nb - 1); }
+uint32_t kmr_local_thread_id(uint64_t hash, uint64_t nb, uint32_t t) { return (nb > 1 && t > 1) ? (uint32_t)((hash & (nb - 1)) % t) : 0; }
+uint32_t kmr_distributed_thread_id(uint64_t hash, uint32_t n) { return distributed_thread_id(hash, n); }
+
+int64_t kmr_compress_sequence(const char *bases, uint64_t len, uint8_t *out, uint32_t *mpos, char *mchar, uint64_t mcap) {
+	if (!bases) return KMR_ERR_INVALID_ARG;
+	int64_t nm = 0;
+	uint64_t offset = 0;
+	while (offset < len) {
+		uint8_t c = 0;
+		for (int i = 6; i >= 0 && offset < len; i -= 2) {
+			char b = bases[offset]; uint8_t code;
+			switch (b) { case 'A': case 'a': code = 0; break; case 'C': case 'c': code = 1; break; case 'G': case 'g': code = 2; break; case 'T': case 't': code = 3; break;
+			case '\0': len = offset; code = 255; break;
+			default: if (b == '.') b = 'N'; if ((uint64_t)nm < mcap) { if (mpos) mpos[nm] = (uint32_t)offset; if (mchar) mchar[nm] = b; } nm++; code = 0; }
+			if (code == 255) break;
+			offset++;
+			c |= code << i;
+		}
+		if (out) *out++ = c;
+	}
+	return nm;
+}
+
+int kmr_least_complement(const uint8_t *packed, uint32_t k, uint8_t *out) {
+	if (!packed || !out || k < 1 || k > 128) return KMR_ERR_INVALID_ARG;
+	const uint32_t kb = (k + 3) / 4;
+	Roller<4> r; r.init(k);
+	for (uint32_t p = 0; p < k; p++) r.push((packed[p >> 2] >> (6 - 2 * (p & 3))) & 3);
+	const bool least = key_le<4>(r.fwd, r.rc);
+	const Key<4> &c = least ? r.fwd : r.rc;
+	for (uint32_t j = 0; j < kb; j++) out[j] = key_byte<4>(c, j);
+	return least ? 1 : 0;
+}
+
+int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals, const void *dev_offsets, uint64_t n_reads,
+                             uint64_t total_bases, uint64_t first_global_read_idx, const void *dev_discarded,
+                             void *dev_records, uint64_t seg_capacity, void *dev_seg_counts) {
+	if (!h || !dev_bases || !dev_offsets || !dev_records || !dev_seg_counts) return KMR_ERR_INVALID_ARG;
+	hipSetDevice(h->device);
+	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
+	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
+	HIPCHK(h, hipMemsetAsync(dev_seg_counts, 0, 8 * h->cfg.world_size, h->stream));
+	int rc;
+#define REC(Wv, E) { RecordOp<Wv, E> op; op.records = (Record<Wv> *)dev_records; op.seg_counts = (unsigned long long *)dev_seg_counts; op.seg_capacity = seg_capacity; rc = launch_extract<Wv, E>(h, rv, op); }
+	switch (h->W) {
+	case 1: if (h->ext) REC(1, true) else REC(1, false) break;
+	case 2: if (h->ext) REC(2, true) else REC(2, false) break;
+	case 3: if (h->ext) REC(3, true) else REC(3, false) break;
+	default: if (h->ext) REC(4, true) else REC(4, false)
+	}
+#undef REC
+	h->stream_base += total_bases; h->reads += n_reads;
+	return rc;
+}
+
+int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n) {
+	if (!h || (n && !dev_records)) return KMR_ERR_INVALID_ARG;
+	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_insert_records_dev after kmr_finalize");
+	if (n == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	int rc = ensure_capacity(h, n); if (rc) return rc;
+	hipEvent_t a, b; time_begin(h, 0, &a, &b);
+#define INS(Wv, E) hipLaunchKernelGGL((insert_records_kernel<Wv, E>), dim3(grid_for(n)), dim3(256), 0, h->stream, table_of<Wv>(h), (const Record<Wv> *)dev_records, n, dev_params(h), h->stream_base)
+	switch (h->W) {
+	case 1: if (h->ext) INS(1, true); else INS(1, false); break;
+	case 2: if (h->ext) INS(2, true); else INS(2, false); break;
+	case 3: if (h->ext) INS(3, true); else INS(3, false); break;
+	default: if (h->ext) INS(4, true); else INS(4, false);
+	}
+#undef INS
+	time_end(h, 0, a, b);
+	HIPCHK(h, hipGetLastError());
+	h->stream_base += n;
+	return KMR_OK;
+}
+
+int kmr_kernel_time(kmr_handle *h, int which, double *ms, uint64_t *launches) {
+	if (!h || which < 0 || which > 1) return KMR_ERR_INVALID_ARG;
+	hipSetDevice(h->device);
+	int rc = sync_state(h); if (rc) return rc;
+	if (ms) *ms = h->ms[which];
+	if (launches) *launches = h->launches[which];
+	return KMR_OK;
+}
+int kmr_kernel_time_reset(kmr_handle *h) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	int rc = sync_state(h); if (rc) return rc;
+	h->ms[0] = h->ms[1] = 0; h->launches[0] = h->launches[1] = 0;
+	return KMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,790 @@
+/*
+ * kmr_kernels.hpp -- HIP kernels (gfx950) of the k-mer spectrum build.
+ *
+ * Kernels, in pipeline order (reference function each one replaces in brackets):
+ *
+ *  extract_kernel<W,EXT,Op>   reads -> canonical k-mers + weights + hash -> Op
+ *        [TwoBitSequence::compressSequence src/TwoBitSequence.cpp:242,
+ *         KmerArrayPair::build src/Kmer.h:1323, KmerReadUtils::buildWeightedKmers
+ *         src/KmerReadUtils.h:176, KmerHasher::getHash src/Kmer.h:207]
+ *     Op = InsertOp   open-addressed insert/increment  [KmerSpectrum::append
+ *                     src/KmerSpectrum.h:1578 + track() src/KmerTrackingData.h:427,517,641]
+ *     Op = RecordOp   bin (key, signed weight, ext) records by owner
+ *                     [_buildKmerSpectrumMPI sender side src/DistributedFunctions.h:418-438]
+ *     Op = LookupOp   per-position count lookup [ReadSelector::setKmerValues
+ *                     src/ReadSelector.h:1064-1076]
+ *  insert_records_kernel      records -> table  [StoreKmerMessageHeaderProcessor::process :323]
+ *  rehash_kernel              table growth
+ *  classify/scatter/sort/image kernels: table -> bucketed sorted maps in the
+ *        reference's store() layout [purgeMinDepth src/KmerSpectrum.h:1805,
+ *        KmerMapByKmerArrayPair::store src/Kmer.h:3143, resort :3079]
+ *  lookup_keys_kernel         packed keys -> counts [getElementIfExists src/Kmer.h:2617]
+ *
+ * Mapping to CDNA4: one read per lane (64 reads per wavefront) so the fp64
+ * weight recurrence -- sequential per read, and it decides which k-mers are
+ * counted -- runs in registers exactly as the reference computes it; each
+ * wavefront stages the contiguous byte range of its 64 reads with coalesced
+ * 16-byte loads into a private LDS tile and then walks it.  Rolling forward /
+ * reverse-complement words make canonicalisation O(1) per base.  All global
+ * traffic besides the staged input is the hash-table probe.
+ */
+#ifndef KMR_KERNELS_HPP_
+#define KMR_KERNELS_HPP_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmr_key.hpp"
+
+namespace kmr {
+
+static const uint64_t EMPTY_KEY = ~0ull;
+static const uint64_t NO_FIRST = ~0ull;
+static const int WAVES_PER_BLOCK = 4;
+static const int TILE_BUF = 9984;            /* LDS bytes per wave for bases (same again for quals) */
+static const int TILE_SPAN = TILE_BUF - 32;  /* max staged byte span of one pass */
+
+enum { ERR_READ_TOO_LONG = 1, ERR_TABLE_FULL = 2, ERR_SEGMENT_OVERFLOW = 4 };
+
+struct DevStats {
+	unsigned long long raw, good, claimed;   /* claimed = new keys inserted */
+};
+
+struct DevParams {
+	uint32_t k, kb;
+	float min_weight;
+	uint32_t fastq_start, ext_min_q;
+	uint32_t subsample, rank, world, num_parts, part_idx;
+	const double *P;       /* 256 entries, device */
+	DevStats *stats;
+	uint32_t *err;
+};
+
+struct ReadsView {
+	const uint8_t *bases;
+	const uint8_t *quals;          /* may be NULL */
+	const uint64_t *offsets;       /* n_reads + 1 */
+	const uint8_t *discarded;      /* may be NULL */
+	uint64_t n_reads;
+	uint64_t stream_base;          /* ordinal of byte 0 of this batch in the whole input */
+	uint64_t first_read_idx;
+};
+
+/* ----------------------------------------------------------------------- */
+/* device hash table: AoS slots so one probe touches one 32-byte sector      */
+template <int W> struct Slot;
+template <> struct Slot<1> {
+	uint64_t key;              /* EMPTY_KEY when free                                 */
+	unsigned long long cntfwd; /* low 32: occurrences, high 32: forward occurrences   */
+	double wsum;               /* sum of weights                                      */
+	unsigned long long first;  /* min over occurrences of (ordinal << 1 | forward)    */
+};
+template <int W> struct Slot {
+	uint64_t key[W];
+	unsigned long long cntfwd;
+	double wsum;
+	unsigned long long first;
+	uint32_t state;            /* 0 empty, 1 being written, 2 ready */
+	uint32_t pad;
+};
+struct ExtSlot {               /* EXT mode side array, 64 B */
+	uint32_t tally[12];        /* [Left,Right][A,C,G,T,N,X] */
+	uint32_t pkt;              /* leftB | rightB<<8 | leftQ<<16 | rightQ<<24 of an occurrence */
+	uint32_t pad[3];
+};
+
+template <int W> struct Table {
+	Slot<W> *slots;
+	ExtSlot *ext;              /* NULL unless EXT */
+	uint32_t log2cap;
+};
+
+__device__ __forceinline__ uint64_t ld_relaxed(const uint64_t *p) {
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* find-or-claim the slot of 'key'; returns slot index or ~0 when the table is full.
+ * 'claimed' is set when this lane inserted the key. */
+template <int W>
+__device__ __forceinline__ uint64_t table_find_or_insert(const Table<W> &t, const Key<W> &key, uint64_t hash, bool &claimed) {
+	const uint64_t mask = (1ull << t.log2cap) - 1;
+	uint64_t s = table_slot(hash, t.log2cap);
+	claimed = false;
+	uint64_t probes = 0;
+	if constexpr (W == 1) {
+		for (;;) {
+			uint64_t cur = t.slots[s].key;
+			if (cur == key.w[0]) return s;
+			if (cur == EMPTY_KEY) {
+				unsigned long long old = atomicCAS((unsigned long long *)&t.slots[s].key, (unsigned long long)EMPTY_KEY, (unsigned long long)key.w[0]);
+				if (old == EMPTY_KEY) { claimed = true; return s; }
+				if (old == key.w[0]) return s;
+			}
+			s = (s + 1) & mask;
+			if (++probes > mask) return ~0ull;
+		}
+	} else {
+		for (;;) {
+			uint32_t st = __hip_atomic_load(&t.slots[s].state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+			if (st == 0) {
+				uint32_t old = atomicCAS(&t.slots[s].state, 0u, 1u);
+				if (old == 0) {
+#pragma unroll
+					for (int i = 0; i < W; i++) __hip_atomic_store(&t.slots[s].key[i], key.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(&t.slots[s].state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					claimed = true;
+					return s;
+				}
+				st = old;
+			}
+			if (st == 1) continue;   /* the writer publishes without waiting on anyone: re-poll */
+			bool eq = true;
+#pragma unroll
+			for (int i = 0; i < W; i++) eq = eq && (ld_relaxed(&t.slots[s].key[i]) == key.w[i]);
+			if (eq) return s;
+			s = (s + 1) & mask;
+			if (++probes > mask) return ~0ull;
+		}
+	}
+}
+/* read-only probe; returns slot or ~0 */
+template <int W>
+__device__ __forceinline__ uint64_t table_find(const Table<W> &t, const Key<W> &key, uint64_t hash) {
+	const uint64_t mask = (1ull << t.log2cap) - 1;
+	uint64_t s = table_slot(hash, t.log2cap);
+	for (uint64_t probes = 0; probes <= mask; probes++) {
+		if constexpr (W == 1) {
+			uint64_t cur = t.slots[s].key;
+			if (cur == key.w[0]) return s;
+			if (cur == EMPTY_KEY) return ~0ull;
+		} else {
+			if (t.slots[s].state == 0) return ~0ull;
+			bool eq = true;
+#pragma unroll
+			for (int i = 0; i < W; i++) eq = eq && (t.slots[s].key[i] == key.w[i]);
+			if (eq) return s;
+		}
+		s = (s + 1) & mask;
+	}
+	return ~0ull;
+}
+template <int W> __device__ __forceinline__ bool slot_used(const Slot<W> &s) {
+	if constexpr (W == 1) return s.key != EMPTY_KEY; else return s.state == 2;
+}
+template <int W> __device__ __forceinline__ Key<W> slot_key(const Slot<W> &s) {
+	Key<W> k;
+	if constexpr (W == 1) k.w[0] = s.key; else {
+#pragma unroll
+		for (int i = 0; i < W; i++) k.w[i] = s.key[i];
+	}
+	return k;
+}
+
+template <int W> __global__ void table_clear_kernel(Slot<W> *slots, ExtSlot *ext, uint64_t cap) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+		Slot<W> s;
+		if constexpr (W == 1) s.key = EMPTY_KEY; else {
+#pragma unroll
+			for (int j = 0; j < W; j++) s.key[j] = 0;
+			s.state = 0; s.pad = 0;
+		}
+		s.cntfwd = 0; s.wsum = 0.0; s.first = NO_FIRST;
+		slots[i] = s;
+		if (ext) { ExtSlot e; for (int j = 0; j < 12; j++) e.tally[j] = 0; e.pkt = 0; e.pad[0] = e.pad[1] = e.pad[2] = 0; ext[i] = e; }
+	}
+}
+
+/* one occurrence -> table (KmerSpectrum::append, cascade folded into counters) */
+struct Occurrence {
+	float w;            /* |weight| (> min_weight) */
+	bool forward;       /* observed strand is the canonical one */
+	uint64_t ordinal;   /* position of the occurrence in the input stream */
+	uint32_t pkt;       /* extension packet (EXT) */
+	int ltally, rtally; /* tally index 0..11 or -1 (EXT) */
+};
+
+template <int W, bool EXT>
+__device__ __forceinline__ bool table_add(const Table<W> &t, const Key<W> &key, uint64_t hash, const Occurrence &o, unsigned &claimedCount) {
+	bool claimed;
+	uint64_t s = table_find_or_insert<W>(t, key, hash, claimed);
+	if (s == ~0ull) return false;
+	if (claimed) claimedCount++;
+	Slot<W> *sl = &t.slots[s];
+	atomicAdd(&sl->cntfwd, 1ull | ((unsigned long long)(o.forward ? 1 : 0) << 32));
+	atomicAdd(&sl->wsum, (double)o.w);
+	atomicMin(&sl->first, (unsigned long long)((o.ordinal << 1) | (o.forward ? 1ull : 0ull)));
+	if constexpr (EXT) {
+		ExtSlot *e = &t.ext[s];
+		if (o.ltally >= 0) atomicAdd(&e->tally[o.ltally], 1u);
+		if (o.rtally >= 0) atomicAdd(&e->tally[o.rtally], 1u);
+		e->pkt = o.pkt;      /* exact whenever the key ends with one occurrence, the only case it is read */
+	}
+	return true;
+}
+
+/* ----------------------------------------------------------------------- */
+/* Ops                                                                       */
+template <int W, bool EXT> struct InsertOp {
+	Table<W> table;
+	static const bool NEEDS_WEIGHT = true;
+	__device__ __forceinline__ void emit(const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
+	                                     uint64_t, uint32_t, unsigned &claimed, bool &fail) const {
+		if (!table_add<W, EXT>(table, key, hash, o, claimed)) fail = true;
+	}
+};
+
+/* record layout: W key words, then f32 signed weight, u32 ext packet */
+template <int W> struct Record {
+	uint64_t key[W];
+	float w;
+	uint32_t pkt;
+};
+
+template <int W, bool EXT> struct RecordOp {
+	Record<W> *records;
+	unsigned long long *seg_counts;   /* [world] */
+	uint64_t seg_capacity;
+	static const bool NEEDS_WEIGHT = true;
+	__device__ __forceinline__ void emit(const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
+	                                     uint64_t, uint32_t, unsigned &, bool &fail) const {
+		uint32_t owner = distributed_thread_id(hash, p.world);
+		unsigned long long pos = atomicAdd(&seg_counts[owner], 1ull);   /* hipcc folds same-address adds per wave */
+		if (pos >= seg_capacity) { fail = true; return; }
+		Record<W> r;
+#pragma unroll
+		for (int i = 0; i < W; i++) r.key[i] = key.w[i];
+		r.w = o.forward ? o.w : -o.w;
+		r.pkt = o.pkt;
+		records[(uint64_t)owner * seg_capacity + pos] = r;
+	}
+};
+
+/* ----------------------------------------------------------------------- */
+__device__ __forceinline__ uint32_t base_code(uint8_t c) {   /* compressBase: 0..3, 4 = markup */
+	switch (c) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': return 3;
+	default: return 4;
+	}
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	return v;
+}
+
+template <int W, bool EXT, class Op>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2)
+void extract_kernel(ReadsView rv, DevParams p, Op op) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	__shared__ double sP[256];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int i = threadIdx.x; i < 256; i += blockDim.x) sP[i] = p.P[i];
+	__syncthreads();                       /* the only block-wide barrier; waves are independent below */
+
+	uint8_t *tb = smem + (size_t)wave * (2 * TILE_BUF);
+	uint8_t *tq = tb + TILE_BUF;
+	const uint64_t tile = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+	const uint64_t r0 = tile * 64;
+	if (r0 >= rv.n_reads) return;
+	const uint32_t nr = (uint32_t)((rv.n_reads - r0) < 64 ? (rv.n_reads - r0) : 64);
+	const bool have = (uint32_t)lane < nr;
+	uint64_t myStart = 0, myEnd = 0;
+	bool myDiscard = true;
+	if (have) {
+		myStart = rv.offsets[r0 + lane];
+		myEnd = rv.offsets[r0 + lane + 1];
+		myDiscard = rv.discarded ? (rv.discarded[r0 + lane] != 0) : false;
+	}
+	const uint32_t k = p.k;
+	unsigned long long nRaw = 0, nGood = 0;
+	unsigned nClaimed = 0;
+	bool fail = false;
+
+	uint32_t done = 0;
+	while (done < nr) {
+		const uint64_t B0 = __shfl(myStart, (int)done, 64);
+		const bool fits = have && (uint32_t)lane >= done && (myEnd - B0 <= (uint64_t)TILE_SPAN);
+		unsigned long long m = __ballot(fits) >> done;
+		uint32_t n = (uint32_t)__builtin_ctzll(~m);          /* run of fitting reads starting at 'done' */
+		if (n > nr - done) n = nr - done;
+		if (n == 0) {                                        /* read longer than a tile */
+			if (lane == 0) atomicOr(p.err, (uint32_t)ERR_READ_TOO_LONG);
+			done += 1;
+			continue;
+		}
+		const uint64_t B1 = __shfl(myEnd, (int)(done + n - 1), 64);
+		/* stage [B0,B1) with 16-byte loads from the enclosing aligned range */
+		const uintptr_t gb = (uintptr_t)rv.bases + B0, gq = (uintptr_t)rv.quals + B0;
+		const uintptr_t ab = gb & ~(uintptr_t)15, aq = gq & ~(uintptr_t)15;
+		const uint32_t nb16 = (uint32_t)(((uintptr_t)rv.bases + B1 - ab + 15) >> 4);
+		for (uint32_t c = lane; c < nb16; c += 64) *(uint4 *)(tb + 16 * c) = *(const uint4 *)(ab + 16 * (uintptr_t)c);
+		if (rv.quals) {
+			const uint32_t nq16 = (uint32_t)(((uintptr_t)rv.quals + B1 - aq + 15) >> 4);
+			for (uint32_t c = lane; c < nq16; c += 64) *(uint4 *)(tq + 16 * c) = *(const uint4 *)(aq + 16 * (uintptr_t)c);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+		const bool active = have && (uint32_t)lane >= done && (uint32_t)lane < done + n && !myDiscard;
+		const uint32_t L = active ? (uint32_t)(myEnd - myStart) : 0;
+		const uint8_t *rb = tb + (uint32_t)(gb - ab) + (uint32_t)(myStart - B0);
+		const uint8_t *rq = tq + (uint32_t)(gq - aq) + (uint32_t)(myStart - B0);
+		uint32_t Lmax = L;
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(Lmax, off, 64); Lmax = o > Lmax ? o : Lmax; }
+
+		const bool isRef = (rv.quals == nullptr) || (L > 0 && rq[0] == 127);   /* Read::REF_QUAL */
+		Roller<W> roll;
+		roll.init(k);
+		double w = 0.0;
+		uint32_t zc = 0;                 /* positions in the window that force weight 0 */
+		uint32_t leftCode = 5, leftQ = p.ext_min_q;   /* Extension('X', minQuality) */
+		for (uint32_t j = 0; j < Lmax; j++) {
+			if (j < L) {
+				const uint8_t c = rb[j];
+				uint32_t code = base_code(c);
+				const uint32_t q = isRef ? 127u : (uint32_t)rq[j];
+				bool z = (code == 4) || (!isRef && sP[q] == 0.0);
+				if (code == 4) code = 0;                      /* markup packs as A */
+				zc += z ? 1u : 0u;
+				if (j >= k) {                                 /* position j-k leaves the window */
+					const uint32_t oc = base_code(rb[j - k]);
+					const bool oz = (oc == 4) || (!isRef && sP[rq[j - k]] == 0.0);
+					zc -= oz ? 1u : 0u;
+				}
+				roll.push(code);
+				if (j + 1 >= k) {
+					const uint32_t i = j + 1 - k;
+					if (Op::NEEDS_WEIGHT) {
+						if (zc > 0) w = 0.0;
+						else if (isRef) w = 1.0;
+						else if ((i & 1023u) == 0 || w == 0.0) {
+							w = 1.0;
+							for (uint32_t jj = 0; jj < k; jj++) w *= sP[rq[i + jj]];
+						} else {
+							const double change = sP[q] / sP[rq[i - 1]];
+							w *= change;
+						}
+					}
+					const bool isLeast = key_le<W>(roll.fwd, roll.rc);
+					const Key<W> canon = isLeast ? roll.fwd : roll.rc;
+					const uint64_t hash = key_hash<W>(canon, p.kb);
+					bool mine = true;
+					if (p.subsample > 1 && hash % p.subsample != 0) mine = false;
+					if (Op::NEEDS_WEIGHT) {   /* owner / part filters apply to the build, not to lookups */
+						if (p.world > 1 && !op_keeps_all_owners(op) && distributed_thread_id(hash, p.world) != p.rank) mine = false;
+						if (p.num_parts > 1 && distributed_thread_id(hash, p.num_parts) != p.part_idx) mine = false;
+					}
+					if (mine) {
+						const float wf = (float)w;
+						nRaw++;
+						if (!Op::NEEDS_WEIGHT || wf > p.min_weight) {
+							nGood++;
+							Occurrence o;
+							o.w = wf; o.forward = isLeast; o.ordinal = rv.stream_base + myStart + i;
+							o.pkt = 0; o.ltally = -1; o.rtally = -1;
+							if (EXT) {
+								uint32_t rc_, rq_;
+								if (j + 1 < L) { rc_ = base_code(rb[j + 1]); if (rc_ == 4) rc_ = 0; rq_ = ((isRef ? 127u : (uint32_t)rq[j + 1]) - p.fastq_start) & 0xffu; }
+								else { rc_ = 5; rq_ = p.ext_min_q; }
+								uint32_t lc = leftCode, lq = leftQ;
+								if (!isLeast) {          /* swap and complement (KmerReadUtils.h:232-235) */
+									const uint32_t tl = rc_ < 4 ? 3 - rc_ : rc_, tr = lc < 4 ? 3 - lc : lc;
+									const uint32_t tq_ = rq_; rq_ = lq; lq = tq_;
+									lc = tl; rc_ = tr;
+								}
+								const char dec[6] = {'A', 'C', 'G', 'T', 'N', 'X'};
+								o.pkt = (uint32_t)(uint8_t)dec[lc] | ((uint32_t)(uint8_t)dec[rc_] << 8) | (lq << 16) | (rq_ << 24);
+								if (lq >= p.ext_min_q || lc > 3) o.ltally = (int)lc;
+								if (rq_ >= p.ext_min_q || rc_ > 3) o.rtally = 6 + (int)rc_;
+							}
+							op.emit(p, canon, hash, o, rv.first_read_idx + r0 + lane, i, nClaimed, fail);
+						}
+					}
+					if (EXT) { leftCode = base_code(rb[i]); if (leftCode == 4) leftCode = 0; leftQ = ((isRef ? 127u : (uint32_t)rq[i]) - p.fastq_start) & 0xffu; }
+				}
+			}
+		}
+		done += n;
+		__builtin_amdgcn_wave_barrier();   /* all lanes are done reading the tile before it is overwritten */
+	}
+	nRaw = wave_sum(nRaw); nGood = wave_sum(nGood);
+	unsigned long long nc = wave_sum((unsigned long long)nClaimed);
+	if (lane == 0) {
+		atomicAdd(&p.stats->raw, nRaw);
+		atomicAdd(&p.stats->good, nGood);
+		if (nc) atomicAdd(&p.stats->claimed, nc);
+	}
+	if (__any(fail) && lane == 0) atomicOr(p.err, op_fail_code(op));
+}
+
+template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const InsertOp<W, EXT> &) { return false; }
+template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const RecordOp<W, EXT> &) { return true; }
+template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const InsertOp<W, EXT> &) { return ERR_TABLE_FULL; }
+template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const RecordOp<W, EXT> &) { return ERR_SEGMENT_OVERFLOW; }
+
+/* ----------------------------------------------------------------------- */
+/* finalized map on the device: bucketed, keys sorted inside each bucket      */
+template <int W> struct MapView {
+	const uint64_t *start;     /* [nb+1] entry index of each bucket          */
+	const uint64_t *keys;      /* [n][W]                                     */
+	const uint32_t *vals;      /* weak: [n][VW] words in the value layout    */
+	const uint8_t *sweight;    /* singleton: [n] _weight byte                */
+	uint64_t nb;               /* power of two, 0 = map absent               */
+	uint32_t vw;               /* value words per weak entry (3 or 15)       */
+};
+
+template <int W> __device__ __forceinline__ int64_t map_find(const MapView<W> &m, const Key<W> &key, uint64_t hash) {
+	if (m.nb == 0) return -1;
+	const uint64_t b = hash & (m.nb - 1);
+	uint64_t lo = m.start[b], hi = m.start[b + 1];
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		Key<W> km;
+#pragma unroll
+		for (int i = 0; i < W; i++) km.w[i] = m.keys[mid * W + i];
+		if (key_eq<W>(km, key)) return (int64_t)mid;
+		if (key_lt<W>(km, key)) lo = mid + 1; else hi = mid;
+	}
+	return -1;
+}
+/* DataPointers::getCount(false), src/KmerSpectrum.h:642-695 */
+template <int W> __device__ __forceinline__ uint32_t maps_count(const MapView<W> &weak, const MapView<W> &sing, const Key<W> &key, uint64_t hash) {
+	int64_t i = map_find<W>(weak, key, hash);
+	if (i >= 0) return weak.vals[(uint64_t)i * weak.vw] & 0xffffu;
+	i = map_find<W>(sing, key, hash);
+	if (i >= 0) return sing.sweight[i] == 0 ? 0u : 1u;
+	return 0u;
+}
+
+template <int W> struct LookupOp {
+	MapView<W> weak, sing;
+	uint32_t *out;
+	const uint64_t *out_offsets;   /* per read, indexed by global read index - first_read_idx */
+	uint64_t first_read_idx;
+	static const bool NEEDS_WEIGHT = false;
+	__device__ __forceinline__ void emit(const DevParams &, const Key<W> &key, uint64_t hash, const Occurrence &,
+	                                     uint64_t readIdx, uint32_t pos, unsigned &, bool &) const {
+		out[out_offsets[readIdx - first_read_idx] + pos] = maps_count<W>(weak, sing, key, hash);
+	}
+};
+template <int W> __device__ __forceinline__ bool op_keeps_all_owners(const LookupOp<W> &) { return true; }
+template <int W> __device__ __forceinline__ uint32_t op_fail_code(const LookupOp<W> &) { return 0; }
+
+template <int W>
+__global__ void lookup_keys_kernel(MapView<W> weak, MapView<W> sing, const uint8_t *packed, uint64_t n, uint32_t kb, uint32_t *out) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		Key<W> key;
+		key_from_bytes<W>(key, packed + i * kb, kb);
+		out[i] = maps_count<W>(weak, sing, key, key_hash<W>(key, kb));
+	}
+}
+
+/* ----------------------------------------------------------------------- */
+/* records -> table (receiver side of the exchange)                           */
+template <int W, bool EXT>
+__global__ void insert_records_kernel(Table<W> table, const Record<W> *recs, uint64_t n, DevParams p, uint64_t ordinal_base) {
+	unsigned long long nGood = 0; unsigned nClaimed = 0; bool fail = false;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		Record<W> r = recs[i];
+		Key<W> key;
+#pragma unroll
+		for (int j = 0; j < W; j++) key.w[j] = r.key[j];
+		Occurrence o;
+		o.forward = !(r.w < 0.0f); o.w = o.forward ? r.w : -r.w; o.ordinal = ordinal_base + i; o.pkt = r.pkt; o.ltally = -1; o.rtally = -1;
+		if (EXT) {   /* ExtensionTracking::trackExtension on the packet (src/KmerTrackingData.h:195-201) */
+			auto idx = [](uint32_t ch) -> int { switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'X': return 5; default: return 4; } };
+			const int lc = idx(r.pkt & 0xff), rc_ = idx((r.pkt >> 8) & 0xff);
+			const uint32_t lq = (r.pkt >> 16) & 0xff, rq_ = r.pkt >> 24;
+			if (lq >= p.ext_min_q || lc > 3) o.ltally = lc;
+			if (rq_ >= p.ext_min_q || rc_ > 3) o.rtally = 6 + rc_;
+		}
+		nGood++;
+		if (!table_add<W, EXT>(table, key, key_hash<W>(key, p.kb), o, nClaimed)) fail = true;
+	}
+	nGood = wave_sum(nGood);
+	unsigned long long nc = wave_sum((unsigned long long)nClaimed);
+	if ((threadIdx.x & 63) == 0) { atomicAdd(&p.stats->raw, nGood); atomicAdd(&p.stats->good, nGood); if (nc) atomicAdd(&p.stats->claimed, nc); }
+	if (__any(fail) && (threadIdx.x & 63) == 0) atomicOr(p.err, (uint32_t)ERR_TABLE_FULL);
+}
+
+/* table growth: move every entry of 'src' into the (cleared) 'dst' */
+template <int W, bool EXT>
+__global__ void rehash_kernel(Table<W> src, Table<W> dst, uint32_t kb, uint32_t *err) {
+	const uint64_t cap = 1ull << src.log2cap;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+		const Slot<W> s = src.slots[i];
+		if (!slot_used<W>(s)) continue;
+		const Key<W> key = slot_key<W>(s);
+		bool claimed;
+		const uint64_t d = table_find_or_insert<W>(dst, key, key_hash<W>(key, kb), claimed);
+		if (d == ~0ull) { atomicOr(err, (uint32_t)ERR_TABLE_FULL); continue; }
+		dst.slots[d].cntfwd = s.cntfwd; dst.slots[d].wsum = s.wsum; dst.slots[d].first = s.first;
+		if (EXT) dst.ext[d] = src.ext[i];
+	}
+}
+
+/* ----------------------------------------------------------------------- */
+/* finalize: table -> bucketed maps                                           */
+struct FinalizeParams {
+	uint32_t kb;
+	uint32_t min_depth;
+	uint32_t has_singletons;      /* cfg.separate_singletons */
+	uint64_t nb_weak, nb_sing;
+};
+struct FinalizeCounters { unsigned long long unique, singletons, weak_kept, sing_kept; };
+
+/* where does an entry with 'count' occurrences end up? 1 = weak, 2 = singleton, 0 = dropped.
+ * append() keeps count==1 keys in the singleton map when hasSingletons (src/KmerSpectrum.h:1646-1655);
+ * purgeMinDepth (:1805-1815) drops weak entries below min_depth only if !hasSingletons || min_depth > 2,
+ * and clears the singleton map when min_depth > 1. */
+__device__ __forceinline__ int classify(uint32_t count, const FinalizeParams &f) {
+	if (f.has_singletons && count == 1) return f.min_depth > 1 ? 0 : 2;
+	if ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1 && count < f.min_depth) return 0;
+	return 1;
+}
+
+template <int W>
+__global__ void classify_kernel(Table<W> t, FinalizeParams f, uint32_t *weakCount, uint32_t *singCount, FinalizeCounters *fc) {
+	const uint64_t cap = 1ull << t.log2cap;
+	unsigned long long u = 0, s1 = 0, wk = 0, sk = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+		const Slot<W> &s = t.slots[i];
+		if (!slot_used<W>(s)) continue;
+		const uint32_t count = (uint32_t)s.cntfwd;
+		if (count == 0) continue;
+		u++;
+		if (count == 1) s1++;
+		const int c = classify(count, f);
+		if (c == 0) continue;
+		const uint64_t hash = key_hash<W>(slot_key<W>(s), f.kb);
+		if (c == 1) { atomicAdd(&weakCount[hash & (f.nb_weak - 1)], 1u); wk++; }
+		else { atomicAdd(&singCount[hash & (f.nb_sing - 1)], 1u); sk++; }
+	}
+	u = wave_sum(u); s1 = wave_sum(s1); wk = wave_sum(wk); sk = wave_sum(sk);
+	if ((threadIdx.x & 63) == 0) {
+		if (u) atomicAdd(&fc->unique, u);
+		if (s1) atomicAdd(&fc->singletons, s1);
+		if (wk) atomicAdd(&fc->weak_kept, wk);
+		if (sk) atomicAdd(&fc->sing_kept, sk);
+	}
+}
+
+/* weak value words (TrackingDataWithDirection / ExtensionTrackingData byte layout):
+ * word0 = u16 count, word1 = f32 weightedCount, word2 = u16 directionBias, words 3..14 = ext tallies */
+template <int W, bool EXT>
+__global__ void scatter_kernel(Table<W> t, FinalizeParams f, const uint64_t *weakStart, uint32_t *weakCursor,
+                               uint64_t *weakKeys, uint32_t *weakVals, const uint64_t *singStart, uint32_t *singCursor,
+                               uint64_t *singKeys, uint8_t *singWeight, uint32_t *singPkt) {
+	const uint64_t cap = 1ull << t.log2cap;
+	const uint32_t vw = EXT ? 15 : 3;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+		const Slot<W> &s = t.slots[i];
+		if (!slot_used<W>(s)) continue;
+		const uint32_t count = (uint32_t)s.cntfwd;
+		if (count == 0) continue;
+		const int c = classify(count, f);
+		if (c == 0) continue;
+		const Key<W> key = slot_key<W>(s);
+		const uint64_t hash = key_hash<W>(key, f.kb);
+		if (c == 1) {
+			const uint64_t b = hash & (f.nb_weak - 1);
+			const uint64_t pos = weakStart[b] + atomicAdd(&weakCursor[b], 1u);
+#pragma unroll
+			for (int j = 0; j < W; j++) weakKeys[pos * W + j] = key.w[j];
+			uint32_t fwd = (uint32_t)(s.cntfwd >> 32);
+			uint32_t cnt = count;
+			/* the first sighting lived in the singleton map, which keeps no direction
+			 * (TrackingDataSingleton::getDirectionBias, src/KmerTrackingData.h:654) */
+			if (f.has_singletons && (s.first & 1ull)) fwd -= 1;
+			if (cnt > 65535u) { cnt = 65535u; if (fwd > 65534u) fwd = 65534u; }   /* MAX_COUNT, :434 */
+			if (fwd > 65535u) fwd = 65535u;
+			uint32_t *v = weakVals + pos * vw;
+			v[0] = cnt;
+			v[1] = __float_as_uint((float)s.wsum);
+			v[2] = fwd;
+			if (EXT) {
+#pragma unroll
+				for (int j = 0; j < 12; j++) v[3 + j] = t.ext[i].tally[j];
+			}
+		} else {
+			const uint64_t b = hash & (f.nb_sing - 1);
+			const uint64_t pos = singStart[b] + atomicAdd(&singCursor[b], 1u);
+#pragma unroll
+			for (int j = 0; j < W; j++) singKeys[pos * W + j] = key.w[j];
+			const float wf = (float)s.wsum;      /* one occurrence: exactly its weight */
+			singWeight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);   /* TrackingDataSingleton::track :646 */
+			if (EXT) singPkt[pos] = t.ext[i].pkt;
+		}
+	}
+}
+
+/* sort the entries of each bucket by key (KmerMapByKmerArrayPair::resort, src/Kmer.h:3079-3088).
+ * One lane per bucket: insertion sort for the usual <= 64 entries, heap sort above. */
+template <int W> struct SortView {
+	uint64_t *keys; uint32_t *vals; uint8_t *b8; uint32_t *pkt; uint32_t vw;
+	__device__ __forceinline__ Key<W> key(uint64_t i) const { Key<W> k; for (int j = 0; j < W; j++) k.w[j] = keys[i * W + j]; return k; }
+	__device__ __forceinline__ void swap(uint64_t a, uint64_t b) const {
+		for (int j = 0; j < W; j++) { uint64_t t = keys[a * W + j]; keys[a * W + j] = keys[b * W + j]; keys[b * W + j] = t; }
+		if (vals) for (uint32_t j = 0; j < vw; j++) { uint32_t t = vals[a * vw + j]; vals[a * vw + j] = vals[b * vw + j]; vals[b * vw + j] = t; }
+		if (b8) { uint8_t t = b8[a]; b8[a] = b8[b]; b8[b] = t; }
+		if (pkt) { uint32_t t = pkt[a]; pkt[a] = pkt[b]; pkt[b] = t; }
+	}
+};
+template <int W>
+__global__ void sort_buckets_kernel(SortView<W> v, const uint64_t *start, uint64_t nb) {
+	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t lo = start[b], n = start[b + 1] - lo;
+		if (n < 2) continue;
+		if (n <= 64) {
+			for (uint64_t i = 1; i < n; i++)
+				for (uint64_t j = i; j > 0 && key_lt<W>(v.key(lo + j), v.key(lo + j - 1)); j--) v.swap(lo + j, lo + j - 1);
+		} else {
+			auto sift = [&](uint64_t root, uint64_t end) {
+				for (;;) {
+					uint64_t child = 2 * root + 1;
+					if (child >= end) break;
+					if (child + 1 < end && key_lt<W>(v.key(lo + child), v.key(lo + child + 1))) child++;
+					if (key_lt<W>(v.key(lo + root), v.key(lo + child))) { v.swap(lo + root, lo + child); root = child; } else break;
+				}
+			};
+			for (uint64_t i = n / 2; i-- > 0;) sift(i, n);
+			for (uint64_t end = n - 1; end > 0; end--) { v.swap(lo, lo + end); sift(0, end); }
+		}
+	}
+}
+
+/* on-disk image (src/Kmer.h:3143-3159): header + offsets + per bucket {u32 n; keys; values} */
+__global__ void image_header_kernel(uint8_t *img, const uint64_t *start, uint64_t nb, uint32_t kb, uint32_t vbytes) {
+	uint64_t *numbers = (uint64_t *)img;
+	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+		if (b == 0) { numbers[0] = nb; numbers[1] = nb - 1; }
+		const uint64_t off = 8 * (2 + nb) + 4 * b + start[b] * (kb + vbytes);
+		numbers[2 + b] = off;
+		const uint32_t n = (uint32_t)(start[b + 1] - start[b]);
+		for (int j = 0; j < 4; j++) img[off + j] = (uint8_t)(n >> (8 * j));
+	}
+}
+template <int W>
+__global__ void image_entries_kernel(uint8_t *img, const uint64_t *start, uint64_t nb, uint32_t kb, uint32_t vbytes,
+                                     const uint64_t *keys, const uint32_t *vals, uint32_t vw, const uint8_t *b8, const uint32_t *pkt, uint64_t n) {
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		/* bucket of entry e: last b with start[b] <= e */
+		uint64_t lo = 0, hi = nb;
+		while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (start[mid] <= e) lo = mid; else hi = mid; }
+		const uint64_t b = lo, s0 = start[b], nbk = start[b + 1] - s0, i = e - s0;
+		const uint64_t off = 8 * (2 + nb) + 4 * b + s0 * (kb + vbytes) + 4;
+		Key<W> key;
+		for (int j = 0; j < W; j++) key.w[j] = keys[e * W + j];
+		uint8_t *kp = img + off + i * kb;
+		for (uint32_t j = 0; j < kb; j++) kp[j] = key_byte<W>(key, j);
+		uint8_t *vp = img + off + nbk * kb + i * vbytes;
+		if (vals) { for (uint32_t j = 0; j < vbytes; j++) vp[j] = (uint8_t)(vals[e * vw + (j >> 2)] >> (8 * (j & 3))); }
+		else { vp[0] = b8[e]; if (pkt) for (int j = 0; j < 4; j++) vp[1 + j] = (uint8_t)(pkt[e] >> (8 * j)); }
+	}
+}
+/* inverse: image -> per-bucket counts, then entries */
+__global__ void image_counts_kernel(const uint8_t *img, uint64_t nb, uint32_t *counts) {
+	const uint64_t *numbers = (const uint64_t *)img;
+	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t off = numbers[2 + b];
+		uint32_t n = 0;
+		for (int j = 0; j < 4; j++) n |= (uint32_t)img[off + j] << (8 * j);
+		counts[b] = n;
+	}
+}
+template <int W>
+__global__ void image_unpack_kernel(const uint8_t *img, const uint64_t *start, uint64_t nb, uint32_t kb, uint32_t vbytes,
+                                    uint64_t *keys, uint32_t *vals, uint32_t vw, uint8_t *b8, uint32_t *pkt, uint64_t n) {
+	const uint64_t *numbers = (const uint64_t *)img;
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t lo = 0, hi = nb;
+		while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (start[mid] <= e) lo = mid; else hi = mid; }
+		const uint64_t b = lo, s0 = start[b], nbk = start[b + 1] - s0, i = e - s0;
+		const uint64_t off = numbers[2 + b] + 4;
+		Key<W> key;
+		key_from_bytes<W>(key, img + off + i * kb, kb);
+		for (int j = 0; j < W; j++) keys[e * W + j] = key.w[j];
+		const uint8_t *vp = img + off + nbk * kb + i * vbytes;
+		if (vals) {
+			for (uint32_t j = 0; j < vw; j++) vals[e * vw + j] = 0;
+			for (uint32_t j = 0; j < vbytes; j++) vals[e * vw + (j >> 2)] |= (uint32_t)vp[j] << (8 * (j & 3));
+			vals[e * vw] &= 0xffffu; vals[e * vw + 2] &= 0xffffu;      /* struct padding bytes */
+		} else { b8[e] = vp[0]; if (pkt) { uint32_t x = 0; for (int j = 0; j < 4; j++) x |= (uint32_t)vp[1 + j] << (8 * j); pkt[e] = x; } }
+	}
+}
+
+__global__ void histogram_kernel(const uint32_t *vals, uint32_t vw, uint64_t n, uint32_t nbins, unsigned long long *counts, double *weights) {
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t c = vals[e * vw] & 0xffffu;
+		if (c >= nbins) c = nbins - 1;
+		atomicAdd(&counts[c], 1ull);
+		if (weights) atomicAdd(&weights[c], (double)__uint_as_float(vals[e * vw + 1]));
+	}
+}
+
+/* ----------------------------------------------------------------------- */
+/* exclusive scan u32 -> u64 (bucket sizes -> bucket starts), three launches */
+static const int SCAN_ITEMS = 2048;   /* per block of 256 threads */
+__global__ void scan_block_sums_kernel(const uint32_t *in, uint64_t n, unsigned long long *blockSums) {
+	__shared__ unsigned long long red[256];
+	const uint64_t base = (uint64_t)blockIdx.x * SCAN_ITEMS;
+	unsigned long long s = 0;
+	for (int j = 0; j < SCAN_ITEMS / 256; j++) { const uint64_t i = base + (uint64_t)j * 256 + threadIdx.x; if (i < n) s += in[i]; }
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+	if (threadIdx.x == 0) blockSums[blockIdx.x] = red[0];
+}
+__global__ void scan_sums_kernel(unsigned long long *blockSums, uint64_t nblocks, unsigned long long *total) {
+	/* single block; sequential over chunks of 256 */
+	__shared__ unsigned long long buf[256];
+	__shared__ unsigned long long carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (uint64_t base = 0; base < nblocks; base += 256) {
+		const uint64_t i = base + threadIdx.x;
+		const unsigned long long v = i < nblocks ? blockSums[i] : 0;
+		buf[threadIdx.x] = v;
+		__syncthreads();
+		for (int o = 1; o < 256; o <<= 1) {
+			unsigned long long t = (int)threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+			__syncthreads();
+			buf[threadIdx.x] += t;
+			__syncthreads();
+		}
+		if (i < nblocks) blockSums[i] = carry + buf[threadIdx.x] - v;
+		__syncthreads();
+		if (threadIdx.x == 255) carry += buf[255];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *total = carry;
+}
+__global__ void scan_apply_kernel(const uint32_t *in, uint64_t n, const unsigned long long *blockSums, uint64_t *out) {
+	__shared__ unsigned long long buf[256];
+	const uint64_t base = (uint64_t)blockIdx.x * SCAN_ITEMS;
+	/* each thread owns SCAN_ITEMS/256 consecutive items */
+	const int per = SCAN_ITEMS / 256;
+	unsigned long long local[per];
+	unsigned long long s = 0;
+	for (int j = 0; j < per; j++) { const uint64_t i = base + (uint64_t)threadIdx.x * per + j; local[j] = i < n ? in[i] : 0; s += local[j]; }
+	buf[threadIdx.x] = s;
+	__syncthreads();
+	for (int o = 1; o < 256; o <<= 1) {
+		unsigned long long t = (int)threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+		__syncthreads();
+		buf[threadIdx.x] += t;
+		__syncthreads();
+	}
+	unsigned long long run = blockSums[blockIdx.x] + buf[threadIdx.x] - s;
+	for (int j = 0; j < per; j++) { const uint64_t i = base + (uint64_t)threadIdx.x * per + j; if (i < n) out[i] = run; run += local[j]; }
+	if (base + SCAN_ITEMS >= n && threadIdx.x == 255) out[n] = run;   /* total at out[n] */
+}
+
+}  // namespace kmr
+#endif

@@ -1,0 +1,195 @@
+"""Host-side mirror of the reference's KmerSpectrum / KmerMap interface for the
+spectrum-build path, over the C-ABI (include/kmernator_amd.h).
+
+Method names follow the reference (src/KmerSpectrum.h): buildKmerSpectrum (:2081-2115),
+purgeMinDepth (:1805), getCount (:701), storeMmap / restoreMmap (:476-518), getRawKmers...
+(:455-459); MeraculousDistributedKmerSpectrum::dumpCounts/dumpGraphs (src/Meraculous.h:107-134).
+Errors surface as KmerSpectrumError (the reference throws LoggedException, src/Log.h:442-484).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import KMR_MAP_SINGLETON, KMR_MAP_WEAK, KmrStats
+
+
+class KmerSpectrumError(RuntimeError):
+    pass
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class KmerSpectrum:
+    """One spectrum (weak + singleton maps) resident on one MI355X."""
+
+    def __init__(self, cfg):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.k = cfg.k
+        self.kb = (cfg.k + 3) // 4
+        h = C.c_void_p()
+        rc = self.lib.kmr_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise KmerSpectrumError("kmr_create: %s: %s" % (_lib.STATUS.get(rc, rc), self.lib.kmr_last_error(None).decode()))
+        self.h = h
+
+    # -- plumbing
+    def _check(self, rc, what):
+        if rc != 0:
+            raise KmerSpectrumError("%s: %s: %s" % (what, _lib.STATUS.get(rc, rc), self.lib.kmr_last_error(self.h).decode()))
+
+    def _call(self, name, *a):
+        self._check(getattr(self.lib, "kmr_" + name)(*a), "kmr_" + name)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kmr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- build
+    def buildKmerSpectrum(self, bases, quals, offsets, first_read_idx=0, discarded=None):
+        """KmerSpectrum::buildKmerSpectrum(const ReadSet&) on flat host arrays."""
+        bases = _u8(bases)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        q = None if quals is None else _u8(quals)
+        d = None if discarded is None else _u8(discarded)
+        self._call("add_reads", self.h, bases.ctypes.data_as(C.c_void_p), None if q is None else q.ctypes.data_as(C.c_void_p),
+                   offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n, first_read_idx,
+                   None if d is None else d.ctypes.data_as(C.POINTER(C.c_uint8)))
+
+    def buildKmerSpectrumDevice(self, bases_ptr, quals_ptr, offsets_ptr, n_reads, total_bases, first_read_idx=0, discarded_ptr=None):
+        """Same, device pointers (torch tensor .data_ptr()); asynchronous, see sync()."""
+        self._call("add_reads_dev", self.h, bases_ptr, quals_ptr, offsets_ptr, n_reads, total_bases, first_read_idx, discarded_ptr)
+
+    def sync(self):
+        self._call("sync", self.h)
+
+    def purgeMinDepth(self, min_depth=2):
+        """purgeMinDepth + optimize(); the maps become immutable (kmr_finalize)."""
+        self._call("finalize", self.h, min_depth)
+
+    finalize = purgeMinDepth
+
+    # -- owner-partitioned pieces (one process per GPU)
+    def extractByOwnerDevice(self, bases_ptr, quals_ptr, offsets_ptr, n_reads, total_bases, first_read_idx,
+                             records_ptr, seg_capacity, seg_counts_ptr, discarded_ptr=None):
+        self._call("extract_by_owner_dev", self.h, bases_ptr, quals_ptr, offsets_ptr, n_reads, total_bases, first_read_idx,
+                   discarded_ptr, records_ptr, seg_capacity, seg_counts_ptr)
+
+    def insertRecordsDevice(self, records_ptr, n):
+        self._call("insert_records_dev", self.h, records_ptr, n)
+
+    def stream(self):
+        return self.lib.kmr_stream(self.h)
+
+    # -- queries
+    def stats(self):
+        s = KmrStats()
+        self._call("get_stats", self.h, C.byref(s))
+        return s.as_dict()
+
+    def getRawKmers(self):
+        return self.stats()["raw_kmers"]
+
+    def getRawGoodKmers(self):
+        return self.stats()["raw_good_kmers"]
+
+    def getUniqueKmers(self):
+        return self.stats()["unique_kmers"]
+
+    def getSingletonKmers(self):
+        return self.stats()["singleton_kmers"]
+
+    def num_buckets(self, which):
+        v = C.c_uint64()
+        self._call("num_buckets", self.h, which, C.byref(v))
+        return v.value
+
+    def getCount(self, packed_kmers):
+        """KmerSpectrum::getCount(kmer, false) for packed canonical k-mers [n, kb]."""
+        keys = _u8(packed_kmers)
+        n = keys.size // self.kb
+        out = np.zeros(n, dtype=np.uint32)
+        if n:
+            self._call("lookup", self.h, keys.ctypes.data_as(C.POINTER(C.c_uint8)), n, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return out
+
+    lookup = getCount
+
+    def getCountsForReads(self, bases, offsets):
+        """Per-position counts of every read (ReadSelector::setKmerValues)."""
+        bases = _u8(bases)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        nk = np.maximum(lens - self.k + 1, 0).astype(np.uint64)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(nk, out=out_off[1:])
+        out = np.zeros(int(out_off[-1]), dtype=np.uint32)
+        if n:
+            self._call("lookup_reads", self.h, bases.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                       out.ctypes.data_as(C.POINTER(C.c_uint32)), out_off.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return out, out_off
+
+    def histogram(self, nbins=256):
+        counts = np.zeros(nbins, dtype=np.uint64)
+        weights = np.zeros(nbins, dtype=np.float64)
+        self._call("count_histogram", self.h, counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+                   weights.ctypes.data_as(C.POINTER(C.c_double)), nbins)
+        return counts, weights
+
+    # -- export / restore in the reference's mmap format
+    def image(self, which=KMR_MAP_WEAK):
+        sz = C.c_uint64()
+        self._call("image_size", self.h, which, C.byref(sz))
+        buf = np.zeros(sz.value, dtype=np.uint8)
+        self._call("write_image", self.h, which, buf.ctypes.data_as(C.c_void_p), sz.value)
+        return buf
+
+    def load_image(self, which, buf):
+        buf = _u8(buf)
+        self._call("load_image", self.h, which, buf.ctypes.data_as(C.c_void_p), buf.size)
+
+    def storeMmap(self, filename, min_depth=2):
+        """KmerSpectrum::storeMmap: <filename> (weak) and <filename>-singleton when min_depth <= 1."""
+        self.image(KMR_MAP_WEAK).tofile(filename)
+        if min_depth <= 1:
+            self.image(KMR_MAP_SINGLETON).tofile(filename + "-singleton")
+
+    def restoreMmap(self, filename):
+        """KmerSpectrum::restoreMmap"""
+        loaded = False
+        if os.path.exists(filename) and os.path.getsize(filename) > 0:
+            self.load_image(KMR_MAP_WEAK, np.fromfile(filename, dtype=np.uint8))
+            loaded = True
+        s = filename + "-singleton"
+        if os.path.exists(s) and os.path.getsize(s) > 0:
+            self.load_image(KMR_MAP_SINGLETON, np.fromfile(s, dtype=np.uint8))
+            loaded = True
+        if not loaded:
+            raise KmerSpectrumError("Terribly sorry but there were no kmer spectrum mmap files at: %s*" % filename)
+
+    def dumpCounts(self, filename, min_depth):
+        self._call("dump_mercount", self.h, filename.encode(), min_depth)
+
+    def dumpGraphs(self, filename, min_depth):
+        self._call("dump_mergraph", self.h, filename.encode(), min_depth)
+
+    def kernel_time(self, which=0):
+        ms, n = C.c_double(), C.c_uint64()
+        self._call("kernel_time", self.h, which, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def kernel_time_reset(self):
+        self._call("kernel_time_reset", self.h)

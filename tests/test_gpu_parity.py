@@ -1,0 +1,232 @@
+"""Parity of the HIP path (through the C-ABI) with the oracle on the same inputs:
+bit-exact k-mer sets, counts, direction bias, extension tallies, statistics, singleton
+bytes and on-disk images; weightedCount within the documented tolerance (it is order
+dependent in the reference itself: the first sighting is quantised to 1/254 steps,
+src/KmerTrackingData.h:646,658)."""
+import os
+
+import numpy as np
+import pytest
+
+import kmernator_amd as ka
+from helpers import (GOLDEN, KMR_MAP_SINGLETON, KMR_MAP_WEAK, KMR_VALUE_EXT, OracleSpectrum, ReadBatch, default_config,
+                     oracle_weighted_kmers, parse_image, read_fastq, synth_reads)
+from refsemantics import median_trim_label
+
+pytestmark = pytest.mark.gpu
+
+
+def product(cfg):
+    c = ka.default_config(cfg.k)
+    for name, _ in cfg._fields_:
+        setattr(c, name, getattr(cfg, name))
+    return ka.KmerSpectrum(c)
+
+
+def add(sp, rb, first=0):
+    sp.buildKmerSpectrum(rb.bases, rb.quals, rb.offsets, first, rb.discarded)
+
+
+def compare_weak_images(img_o, img_p, kb, ext):
+    vsize = 60 if ext else 12
+    nb, mask, bo = parse_image(img_o, kb, vsize)
+    nb2, mask2, bp = parse_image(img_p, kb, vsize)
+    assert (nb, mask) == (nb2, mask2)
+    assert img_o.size == img_p.size
+    assert np.array_equal(img_o[:16 + 8 * nb], img_p[:16 + 8 * nb])   # header + offsets
+    n = 0
+    for (ko, vo), (kp, vp) in zip(bo, bp):
+        assert np.array_equal(ko, kp)
+        if len(ko) == 0:
+            continue
+        vo32 = np.ascontiguousarray(vo).view(np.uint32).reshape(len(ko), vsize // 4)
+        vp32 = np.ascontiguousarray(vp).view(np.uint32).reshape(len(kp), vsize // 4)
+        assert np.array_equal(vo32[:, 0] & 0xffff, vp32[:, 0] & 0xffff)            # count
+        assert np.array_equal(vo32[:, 2] & 0xffff, vp32[:, 2] & 0xffff)            # directionBias
+        wo, wp = vo32[:, 1].view(np.float32), vp32[:, 1].view(np.float32)
+        cnt = (vo32[:, 0] & 0xffff).astype(np.float64)
+        assert np.all(np.abs(wo.astype(np.float64) - wp) <= 1.0 / 254 + 1e-5 * cnt)
+        if ext:
+            assert np.array_equal(vo32[:, 3:], vp32[:, 3:])
+        n += len(ko)
+    return n
+
+
+def run_both(cfg, rb, min_depth=2, batches=None):
+    o = OracleSpectrum(cfg)
+    p = product(cfg)
+    if batches is None:
+        o.add_reads(rb)
+        add(p, rb)
+    else:
+        lo = 0
+        for hi in batches + [rb.n]:
+            o.add_reads(rb.slice(lo, hi), first_idx=lo)
+            add(p, rb.slice(lo, hi), first=lo)
+            lo = hi
+    so, sp_ = o.stats(), p.stats()
+    for key in ("raw_kmers", "raw_good_kmers", "discarded", "reads"):
+        assert so[key] == sp_[key], (key, so, sp_)
+    o.finalize(min_depth)
+    p.finalize(min_depth)
+    so, sp_ = o.stats(), p.stats()
+    assert so == sp_, (so, sp_)
+    return o, p
+
+
+def test_phix_meraculous_goldens(tmp_path):
+    """Config 5: MeraculousCounter k=21 on 1000.fastq, text equal to the reference's goldens."""
+    rb = read_fastq(os.path.join(GOLDEN, "1000.fastq"))
+    cfg = default_config(21, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2, fastq_start_char=64, estimated_raw_kmers=56000)
+    o, p = run_both(cfg, rb)
+    p.dumpCounts(str(tmp_path / "c"), 2)
+    p.dumpGraphs(str(tmp_path / "g"), 2)
+    for got, exp in (("c", "phix.mercount.m21"), ("g", "phix.mergraph.m21.D2")):
+        a = sorted(open(tmp_path / got).read().splitlines())
+        b = sorted(open(os.path.join(GOLDEN, exp)).read().splitlines())
+        assert a == b
+    assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, True) == 5401
+
+
+@pytest.mark.parametrize("fq,start", [("1000.fastq", 64), ("1000.std.fastq", 33)])
+@pytest.mark.parametrize("k", [21, 31])
+def test_filterreads_fixture(fq, start, k):
+    """Config 1 (k=21) and the reference's own FilterReads golden (k=31 labels)."""
+    rb = read_fastq(os.path.join(GOLDEN, fq))
+    cfg = default_config(k, fastq_start_char=start, estimated_raw_kmers=(76 - k + 1) * 1000)
+    o, p = run_both(cfg, rb)
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    if k == 31:
+        gold = read_fastq(os.path.join(GOLDEN, "1000-Filtered.fastq"))
+        counts, off = p.getCountsForReads(rb.bases, rb.offsets)
+        checked = 0
+        for i in range(rb.n):
+            if b"AFTrim" in gold.names[i]:
+                continue
+            label = median_trim_label(counts[int(off[i]):int(off[i + 1])], k)
+            assert label == gold.names[i].split(b" ", 1)[1]
+            checked += 1
+        assert checked == 949
+
+
+@pytest.mark.parametrize("k", [5, 21, 31, 32, 33, 51, 64, 65, 95, 127])
+def test_synthetic_noisy_reads(k):
+    """multi-word keys (k>32), N bases, sub-threshold qualities, ragged lengths"""
+    rl = max(100, k + 40)
+    rb = synth_reads(4000, read_len=rl, seed=k, quality="noisy", n_rate=0.003)
+    # ragged: chop some reads, including shorter than k and empty
+    rng = np.random.default_rng(k)
+    seqs, quals = [], []
+    for i in range(rb.n):
+        L = rl
+        r = rng.random()
+        if r < 0.05:
+            L = int(rng.integers(0, k + 3))
+        elif r < 0.3:
+            L = int(rng.integers(k, rl + 1))
+        seqs.append(rb.seq(i)[:L])
+        quals.append(rb.qual(i)[:L])
+    rb2 = ReadBatch(seqs, quals)
+    cfg = default_config(k, estimated_raw_kmers=4000 * (rl - k + 1))
+    o, p = run_both(cfg, rb2, batches=[1500, 1501, 3000])
+    n = compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    assert n == o.stats()["weak_entries"] and n > 0
+    # lookups: every k-mer of a few reads, plus absent keys
+    for i in (0, 7, 100):
+        if len(seqs[i]) >= k:
+            keys, w, ext = oracle_weighted_kmers(cfg, seqs[i], quals[i])
+            assert np.array_equal(o.lookup(keys), p.getCount(keys))
+    absent = np.zeros((4, p.kb), dtype=np.uint8)
+    absent[:, -1] = 0
+    assert np.array_equal(o.lookup(absent), p.getCount(absent))
+
+
+def test_singleton_map_and_min_depth_variants():
+    rb = synth_reads(2000, read_len=100, seed=9, quality="noisy")
+    for min_depth in (1, 2, 3):
+        for sep in (1, 0):
+            cfg = default_config(25, separate_singletons=sep, num_buckets_weak=512, num_buckets_singleton=2048)
+            o, p = run_both(cfg, rb, min_depth=min_depth)
+            compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+            so = o.image(KMR_MAP_SINGLETON)
+            sp_ = p.image(KMR_MAP_SINGLETON)
+            assert np.array_equal(so, sp_)      # 1-byte values: bit-exact, including the quantised weight
+
+
+def test_ext_singletons_and_image_reload():
+    rb = synth_reads(1500, read_len=90, seed=4, quality="noisy", n_rate=0.002)
+    cfg = default_config(19, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2, num_buckets_weak=256, num_buckets_singleton=256)
+    o, p = run_both(cfg, rb, min_depth=1)
+    assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+    wimg = p.image(KMR_MAP_WEAK)
+    compare_weak_images(o.image(KMR_MAP_WEAK), wimg, p.kb, True)
+    # store -> restore (test/KmerTest.cpp:545-594; runFilterTests.sh:72-74): product image into a fresh
+    # product handle and into the oracle, oracle image into the product
+    q = product(cfg)
+    q.load_image(KMR_MAP_WEAK, wimg)
+    q.load_image(KMR_MAP_SINGLETON, p.image(KMR_MAP_SINGLETON))
+    assert np.array_equal(q.image(KMR_MAP_WEAK), wimg)
+    assert np.array_equal(q.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+    o2 = OracleSpectrum(cfg)
+    o2.load_image(KMR_MAP_WEAK, wimg)
+    assert np.array_equal(o2.image(KMR_MAP_WEAK), wimg)
+    r = product(cfg)
+    r.load_image(KMR_MAP_WEAK, o.image(KMR_MAP_WEAK))
+    keys, w, ext = oracle_weighted_kmers(cfg, rb.seq(3), rb.qual(3))
+    assert np.array_equal(r.getCount(keys), o.lookup(keys))
+
+
+def test_count_saturation():
+    k = 9
+    seq = b"ACGTTGCAAGGCTA"
+    n = 66000
+    rb = ReadBatch([seq] * n, [b"I" * len(seq)] * n)
+    cfg = default_config(k, num_buckets_weak=16, num_buckets_singleton=16)
+    o, p = run_both(cfg, rb)
+    keys, w, ext = oracle_weighted_kmers(cfg, seq, b"I" * len(seq))
+    assert np.all(p.getCount(keys) == 65535)
+    assert np.array_equal(o.lookup(keys), p.getCount(keys))
+
+
+def test_table_growth():
+    rb = synth_reads(20000, read_len=100, seed=12, err=0.05)
+    cfg = default_config(31, max_table_entries=1000, num_buckets_weak=1024, num_buckets_singleton=4096)
+    o, p = run_both(cfg, rb, batches=[100, 5000])
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+
+
+def test_reference_reads_without_quals_and_discarded():
+    rb = synth_reads(500, read_len=120, seed=3, n_rate=0.01)
+    disc = np.zeros(rb.n, dtype=np.uint8)
+    disc[::7] = 1
+    rbn = ReadBatch([rb.seq(i) for i in range(rb.n)], None, disc)
+    cfg = default_config(21, num_buckets_weak=64, num_buckets_singleton=64)
+    o, p = run_both(cfg, rbn)
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+
+
+def test_owner_and_part_filters():
+    """getDistributedThreadId owner filter (src/Kmer.h:2284-2295) and --build-partitions (:1680)"""
+    rb = synth_reads(3000, read_len=100, seed=8, quality="noisy")
+    for kw in (dict(rank=1, world_size=3), dict(num_parts=4, part_idx=2), dict(kmer_subsample=3)):
+        cfg = default_config(27, num_buckets_weak=256, num_buckets_singleton=1024, **kw)
+        o, p = run_both(cfg, rb)
+        compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+
+
+def test_histogram():
+    rb = synth_reads(3000, read_len=100, seed=21)
+    cfg = default_config(31, num_buckets_weak=256, num_buckets_singleton=1024)
+    o, p = run_both(cfg, rb)
+    co, wo = o.histogram(64)
+    cp, wp = p.histogram(64)
+    assert np.array_equal(co, cp)
+    assert np.allclose(wo, wp, rtol=1e-3, atol=1.0)
+
+
+def test_read_longer_than_tile_is_an_error():
+    seq = b"ACGT" * 4000
+    rb = ReadBatch([seq], [b"I" * len(seq)])
+    p = product(default_config(21, num_buckets_weak=16, num_buckets_singleton=16))
+    with pytest.raises(ka.KmerSpectrumError, match="longer"):
+        add(p, rb)
