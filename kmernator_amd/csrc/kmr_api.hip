@@ -289,7 +289,9 @@ template <int W, bool EXT> int finalize_t(kmr_handle *h, uint32_t min_depth) {
 	FinalizeCounters c;
 	HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
-	h->stats.unique_kmers = c.unique; h->stats.singleton_kmers = c.singletons;
+	h->stats.unique_kmers = c.unique;
+	/* singletonKmers only moves inside the hasSingletons branches of append() (src/KmerSpectrum.h:1625,1649) */
+	h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
 	DevMap &wm = h->weak, &sm = h->sing;
 	free_map(wm); free_map(sm);
 	wm.nb = h->nb_weak; wm.n = c.weak_kept; wm.present = true;

@@ -173,6 +173,10 @@ def test_ext_singletons_and_image_reload():
     r = product(cfg)
     r.load_image(KMR_MAP_WEAK, o.image(KMR_MAP_WEAK))
     keys, w, ext = oracle_weighted_kmers(cfg, rb.seq(3), rb.qual(3))
+    o3 = OracleSpectrum(cfg)
+    o3.load_image(KMR_MAP_WEAK, o.image(KMR_MAP_WEAK))
+    assert np.array_equal(r.getCount(keys), o3.lookup(keys))
+    r.load_image(KMR_MAP_SINGLETON, o.image(KMR_MAP_SINGLETON))
     assert np.array_equal(r.getCount(keys), o.lookup(keys))
 
 
