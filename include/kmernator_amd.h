@@ -149,6 +149,14 @@ int kmr_sync(kmr_handle *h);
  * queryable / exportable. */
 int kmr_finalize(kmr_handle *h, uint32_t min_depth);
 
+/* Empty the maps and counters but keep the device allocations, as
+ * KmerSpectrum::buildKmerSpectrum does on entry (weak.reset(false);
+ * singleton.reset(false), src/KmerSpectrum.h:2091-2096).  Asynchronous. */
+int kmr_reset(kmr_handle *h);
+/* Give the build-time hash table back to the device once finalized (the
+ * finalized maps stay queryable); kmr_reset() re-allocates it. */
+int kmr_release_table(kmr_handle *h);
+
 int kmr_get_stats(kmr_handle *h, kmr_stats *out);
 
 /* Lookup.  Replaces KmerMap::getElementIfExists(kmer).value().getCount()

@@ -316,8 +316,7 @@ template <int W, bool EXT> int finalize_t(kmr_handle *h, uint32_t min_depth) {
 	time_end(h, 1, ea, eb);
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(wc); hipFree(sc); hipFree(fc);
-	/* the table is no longer needed */
-	hipFree(h->slots); h->slots = nullptr; if (h->extslots) { hipFree(h->extslots); h->extslots = nullptr; }
+	/* the table allocation is kept for kmr_reset(); kmr_release_table() frees it */
 	h->has_singletons = keepSing;
 	if (!keepSing) { sm.n = 0; }
 	h->stats.weak_entries = wm.n; h->stats.singleton_entries = keepSing ? sm.n : 0;
@@ -495,6 +494,33 @@ int kmr_num_buckets(const kmr_handle *h, int which, uint64_t *out) {
 	if (which == KMR_MAP_WEAK) *out = h->finalized && h->weak.present ? h->weak.nb : h->nb_weak;
 	else if (which == KMR_MAP_SINGLETON) *out = h->finalized && h->sing.present ? h->sing.nb : h->nb_sing;
 	else return KMR_ERR_UNSUPPORTED;
+	return KMR_OK;
+}
+
+/* KmerSpectrum::buildKmerSpectrum starts with weak.reset(false); singleton.reset(false)
+ * (src/KmerSpectrum.h:2091-2096): empty maps, allocations kept. */
+int kmr_reset(kmr_handle *h) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	hipSetDevice(h->device);
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	free_map(h->weak); free_map(h->sing);
+	int rc = 0;
+	if (!h->slots) rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
+	else rc = clear_table_any(h, h->slots, h->extslots, h->log2cap);
+	if (rc) return rc;
+	HIPCHK(h, hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream));
+	HIPCHK(h, hipMemsetAsync(h->derr, 0, 4, h->stream));
+	memset(&h->stats, 0, sizeof(h->stats));
+	h->occupied = h->pending_kmers = 0; h->stream_base = 0; h->reads = 0;
+	h->finalized = false; h->has_singletons = h->cfg.separate_singletons != 0;
+	return KMR_OK;
+}
+int kmr_release_table(kmr_handle *h) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_release_table before kmr_finalize");
+	hipSetDevice(h->device);
+	if (h->slots) { hipFree(h->slots); h->slots = nullptr; }
+	if (h->extslots) { hipFree(h->extslots); h->extslots = nullptr; }
 	return KMR_OK;
 }
 

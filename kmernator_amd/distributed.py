@@ -1,0 +1,76 @@
+"""Owner-partitioned spectrum build, one process per GPU (torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+Replaces the exchange of DistributedKmerSpectrum::_buildKmerSpectrumMPI
+(src/DistributedFunctions.h:340-458): every rank extracts the good k-mers of its own
+reads, bins them by owner = ((lookup3 >> 24) & 0x7ffff) % world (src/Kmer.h:2284-2295),
+and one all-to-all per chunk moves each record to its owner (MPI_Alltoallv of
+src/MPIBuffer.h:588-600; the 'int dataSize' prefix becomes the counts all-to-all).
+Termination is implicit: every rank runs the same number of chunks.
+"""
+import torch
+import torch.distributed as dist
+
+
+def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
+    """records: uint8 tensor [world * seg_capacity * rec_bytes], segment s holds
+    seg_counts[s] records for rank s.  Returns (recv uint8 tensor, n_records)."""
+    world = dist.get_world_size(group)
+    send_counts = seg_counts.to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    sc = [int(x) for x in send_counts.cpu().tolist()]
+    rc = [int(x) for x in recv_counts.cpu().tolist()]
+    if max(sc) > seg_capacity:
+        raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_capacity))
+    rec2d = records.view(world, seg_capacity * rec_bytes)
+    send = torch.cat([rec2d[s, :sc[s] * rec_bytes] for s in range(world)]) if world > 1 else rec2d[0, :sc[0] * rec_bytes]
+    recv = torch.empty(sum(rc) * rec_bytes, dtype=torch.uint8, device=records.device)
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[c * rec_bytes for c in rc],
+                           input_split_sizes=[c * rec_bytes for c in sc], group=group)
+    return recv, sum(rc)
+
+
+def all_ranks_chunk_count(n_local_chunks, group=None, device="cpu"):
+    """every rank must issue the same number of all-to-alls"""
+    t = torch.tensor([n_local_chunks], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_reads=1 << 20, group=None, slack=1.25):
+    """Device tensors in, spectrum (rank/world_size configured) built in place.
+    bases/quals: uint8 cuda tensors, offsets: int64/uint64 cuda tensor [n+1]."""
+    from . import record_bytes
+    world = dist.get_world_size(group)
+    n = offsets.numel() - 1
+    k = spectrum.k
+    rb = record_bytes(k)
+    dev = bases.device
+    off_host = offsets.cpu()
+    n_chunks = (n + chunk_reads - 1) // chunk_reads
+    total_chunks = all_ranks_chunk_count(n_chunks, group, dev)
+    max_kmers = 0
+    for c in range(n_chunks):
+        lo, hi = c * chunk_reads, min(n, (c + 1) * chunk_reads)
+        max_kmers = max(max_kmers, int(off_host[hi] - off_host[lo]))
+    seg_cap = max(1024, int(max_kmers / world * slack) + 1024)
+    records = torch.empty(world * seg_cap * rb, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    empty_off = torch.zeros(1, dtype=torch.int64, device=dev)
+    for c in range(total_chunks):
+        lo, hi = c * chunk_reads, min(n, (c + 1) * chunk_reads)
+        if lo < n:
+            nb = int(off_host[hi] - off_host[lo])
+            spectrum.extractByOwnerDevice(bases.data_ptr(), None if quals is None else quals.data_ptr(),
+                                          offsets.data_ptr() + 8 * lo, hi - lo, nb, first_read_idx + lo,
+                                          records.data_ptr(), seg_cap, counts.data_ptr())
+            spectrum.sync()
+        else:
+            counts.zero_()
+        recv, n_recv = exchange_records(records, counts, seg_cap, rb, group)
+        if n_recv:
+            torch.cuda.synchronize(dev)
+            spectrum.insertRecordsDevice(recv.data_ptr(), n_recv)
+            spectrum.sync()
+    return spectrum

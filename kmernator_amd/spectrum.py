@@ -72,6 +72,13 @@ class KmerSpectrum:
         """Same, device pointers (torch tensor .data_ptr()); asynchronous, see sync()."""
         self._call("add_reads_dev", self.h, bases_ptr, quals_ptr, offsets_ptr, n_reads, total_bases, first_read_idx, discarded_ptr)
 
+    def reset(self):
+        """weak.reset(false); singleton.reset(false) of buildKmerSpectrum (src/KmerSpectrum.h:2091-2096)"""
+        self._call("reset", self.h)
+
+    def release_table(self):
+        self._call("release_table", self.h)
+
     def sync(self):
         self._call("sync", self.h)
 
