@@ -227,6 +227,7 @@ __device__ __forceinline__ bool table_add(const Table<W> &t, const Key<W> &key, 
 template <int W, bool EXT> struct InsertOp {
 	Table<W> table;
 	static const bool NEEDS_WEIGHT = true;
+	static const bool COUNTS_STATS = true;
 	__device__ __forceinline__ void emit(const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
 	                                     uint64_t, uint32_t, unsigned &claimed, bool &fail) const {
 		if (!table_add<W, EXT>(table, key, hash, o, claimed)) fail = true;
@@ -245,6 +246,7 @@ template <int W, bool EXT> struct RecordOp {
 	unsigned long long *seg_counts;   /* [world] */
 	uint64_t seg_capacity;
 	static const bool NEEDS_WEIGHT = true;
+	static const bool COUNTS_STATS = false;
 	__device__ __forceinline__ void emit(const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
 	                                     uint64_t, uint32_t, unsigned &, bool &fail) const {
 		uint32_t owner = distributed_thread_id(hash, p.world);
@@ -415,7 +417,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 	}
 	nRaw = wave_sum(nRaw); nGood = wave_sum(nGood);
 	unsigned long long nc = wave_sum((unsigned long long)nClaimed);
-	if (lane == 0) {
+	if (lane == 0 && Op::COUNTS_STATS) {   /* the owner counts records when they are inserted */
 		atomicAdd(&p.stats->raw, nRaw);
 		atomicAdd(&p.stats->good, nGood);
 		if (nc) atomicAdd(&p.stats->claimed, nc);
@@ -468,6 +470,7 @@ template <int W> struct LookupOp {
 	const uint64_t *out_offsets;   /* per read, indexed by global read index - first_read_idx */
 	uint64_t first_read_idx;
 	static const bool NEEDS_WEIGHT = false;
+	static const bool COUNTS_STATS = false;
 	__device__ __forceinline__ void emit(const DevParams &, const Key<W> &key, uint64_t hash, const Occurrence &,
 	                                     uint64_t readIdx, uint32_t pos, unsigned &, bool &) const {
 		out[out_offsets[readIdx - first_read_idx] + pos] = maps_count<W>(weak, sing, key, hash);

@@ -599,6 +599,7 @@ struct SpectrumBase {
 	virtual uint64_t mapSize(int which) = 0;
 	virtual void dump(FILE *f, uint32_t minDepth, bool graph) = 0;
 	virtual void histogram(uint64_t *counts, double *weights, uint32_t nbins) = 0;
+	virtual void appendOne(const uint8_t *key, float w, const ExtPacket &e) = 0;
 	virtual uint64_t exportEntries(uint8_t *keys, uint32_t *count, uint32_t *dir, float *weighted, uint32_t *ext, uint64_t cap) = 0;
 };
 
@@ -648,6 +649,8 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 			}
 		}
 	}
+
+	void appendOne(const uint8_t *key, float w, const ExtPacket &e) { append(key, w, e.getLeft(), e.getRight()); }
 
 	/* sender-side filters of _buildKmerSpectrumMPI, DistributedFunctions.h:418-433,
 	 * and the part filter of append(KmerWeightedExtensions...), KmerSpectrum.h:1680 */
@@ -925,6 +928,57 @@ int64_t orc_build_weighted_kmers(const kmr_config *cfg, const char *bases, const
 		if (ext4) { ext4[4 * i] = (uint8_t)wk.exts[i].leftB; ext4[4 * i + 1] = (uint8_t)wk.exts[i].rightB; ext4[4 * i + 2] = wk.exts[i].leftQ; ext4[4 * i + 3] = wk.exts[i].rightQ; }
 	}
 	return wk.n;
+}
+/* sender side of _buildKmerSpectrumMPI (src/DistributedFunctions.h:418-438) on the CPU: good k-mers of a
+ * read batch binned by owner, in the record layout of include/kmernator_amd.h (KMR_RECORD_BYTES).  Used by the
+ * gloo tests to drive the product's exchange code without a GPU. */
+int64_t orc_extract_records_by_owner(const kmr_config *cfg, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n,
+                                     const uint8_t *disc, uint8_t *records, uint64_t seg_capacity, uint64_t *seg_counts) {
+	initTables();
+	KmerBuilder b; b.k = cfg->k; b.kb = (cfg->k + 3) / 4; b.fastqStart = cfg->fastq_start_char; b.extMinQuality = (uint8_t)cfg->ext_min_quality;
+	initializeQualityToProbability(b.P, (unsigned char)cfg->min_quality_score, cfg->fastq_start_char);
+	const uint32_t W = (b.kb + 7) / 8, rb = 8 * W + 8;
+	for (uint32_t o = 0; o < cfg->world_size; o++) seg_counts[o] = 0;
+	WeightedKmers wk;
+	int64_t total = 0;
+	for (uint64_t r = 0; r < n; r++) {
+		ReadView rv{bases + offsets[r], quals ? quals + offsets[r] : NULL, (uint32_t)(offsets[r + 1] - offsets[r]), disc ? disc[r] != 0 : false};
+		b.buildWeighted(rv, wk);
+		for (uint32_t i = 0; i < wk.n; i++) {
+			const uint8_t *key = wk.keys.data() + (size_t)i * b.kb;
+			float w = wk.weights[i];
+			if (!((w < 0 ? -w : w) > cfg->min_weight)) continue;
+			uint64_t h = getHash(key, b.kb);
+			if (cfg->kmer_subsample > 1 && h % cfg->kmer_subsample != 0) continue;
+			uint32_t owner = (uint32_t)getDistributedThreadId(h, cfg->world_size);
+			if (seg_counts[owner] >= seg_capacity) return -1;
+			uint8_t *rec = records + ((uint64_t)owner * seg_capacity + seg_counts[owner]++) * rb;
+			for (uint32_t wd = 0; wd < W; wd++) {
+				uint64_t v = 0;
+				for (uint32_t j = 0; j < 8; j++) { uint32_t idx = wd * 8 + j; v = (v << 8) | (idx < b.kb ? key[idx] : 0); }
+				memcpy(rec + 8 * wd, &v, 8);
+			}
+			memcpy(rec + 8 * W, &w, 4);
+			uint32_t pkt = (uint32_t)(uint8_t)wk.exts[i].leftB | ((uint32_t)(uint8_t)wk.exts[i].rightB << 8) | ((uint32_t)wk.exts[i].leftQ << 16) | ((uint32_t)wk.exts[i].rightQ << 24);
+			memcpy(rec + 8 * W + 4, &pkt, 4);
+			total++;
+		}
+	}
+	return total;
+}
+/* receiver side: StoreKmerMessageHeaderProcessor::process -> append (src/DistributedFunctions.h:323-328) */
+int orc_insert_records(orc_handle *h, const uint8_t *records, uint64_t n) {
+	SpectrumBase *s = h->s;
+	const uint32_t W = (s->kb + 7) / 8, rb = 8 * W + 8;
+	std::vector<uint8_t> key(s->kb);
+	for (uint64_t i = 0; i < n; i++) {
+		const uint8_t *rec = records + i * rb;
+		for (uint32_t wd = 0; wd < W; wd++) { uint64_t v; memcpy(&v, rec + 8 * wd, 8); for (uint32_t j = 0; j < 8; j++) { uint32_t idx = wd * 8 + j; if (idx < s->kb) key[idx] = (uint8_t)(v >> (56 - 8 * j)); } }
+		float w; uint32_t pkt; memcpy(&w, rec + 8 * W, 4); memcpy(&pkt, rec + 8 * W + 4, 4);
+		ExtPacket e; e.leftB = (char)(pkt & 0xff); e.rightB = (char)((pkt >> 8) & 0xff); e.leftQ = (uint8_t)(pkt >> 16); e.rightQ = (uint8_t)(pkt >> 24);
+		s->appendOne(key.data(), w, e);
+	}
+	return 0;
 }
 uint64_t orc_bucket_idx(uint64_t hash, uint64_t nb) { return hash & (nb - 1); }
 uint32_t orc_local_thread_id(uint64_t hash, uint64_t nb, uint32_t t) { return (uint32_t)getLocalThreadId(hash, nb, (int)t); }

@@ -122,6 +122,9 @@ def oracle_lib():
         lib.orc_distributed_thread_id.argtypes = [C.c_uint64, C.c_uint32]
         lib.orc_min_power_of_2.restype = C.c_uint64
         lib.orc_min_power_of_2.argtypes = [C.c_uint64]
+        lib.orc_extract_records_by_owner.restype = C.c_int64
+        lib.orc_extract_records_by_owner.argtypes = [C.POINTER(KmrConfig), C.c_char_p, C.c_char_p, u64p, C.c_uint64, u8p, u8p, C.c_uint64, u64p]
+        lib.orc_insert_records.argtypes = [C.c_void_p, u8p, C.c_uint64]
         lib.orc_derive_buckets.argtypes = [C.POINTER(KmrConfig), u64p, u64p]
         _oracle = lib
     return _oracle
@@ -252,6 +255,10 @@ class OracleSpectrum(_SpectrumCommon):
                    _ptr(rb.offsets, C.c_uint64), rb.n, first_idx,
                    None if rb.discarded is None else _ptr(rb.discarded, C.c_uint8), threads)
 
+    def insert_records(self, recs, n):
+        recs = np.ascontiguousarray(recs, dtype=np.uint8)
+        self._call("insert_records", self.h, _ptr(recs, C.c_uint8), n)
+
     def dump(self, path, min_depth, graph):
         self._call("dump", self.h, path.encode(), min_depth, 1 if graph else 0)
 
@@ -341,3 +348,19 @@ def parse_image(buf, kb, vsize):
         vals = buf[o + 4 + n * kb:o + 4 + n * (kb + vsize)].reshape(n, vsize)
         buckets.append((keys, vals))
     return nb, mask, buckets
+
+
+def oracle_extract_by_owner(cfg, rb, seg_capacity):
+    """(records uint8 [world*seg_capacity*rec_bytes], counts uint64 [world])"""
+    lib = oracle_lib()
+    W = (((cfg.k + 3) // 4) + 7) // 8
+    recb = 8 * W + 8
+    recs = np.zeros(cfg.world_size * seg_capacity * recb, dtype=np.uint8)
+    counts = np.zeros(cfg.world_size, dtype=np.uint64)
+    n = lib.orc_extract_records_by_owner(C.byref(cfg), rb.bases.ctypes.data_as(C.c_char_p),
+                                         None if rb.quals is None else rb.quals.ctypes.data_as(C.c_char_p),
+                                         _ptr(rb.offsets, C.c_uint64), rb.n,
+                                         None if rb.discarded is None else _ptr(rb.discarded, C.c_uint8),
+                                         _ptr(recs, C.c_uint8), seg_capacity, _ptr(counts, C.c_uint64))
+    assert n >= 0
+    return recs, counts

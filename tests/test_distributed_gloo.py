@@ -1,0 +1,82 @@
+"""world_size-2 (and 3) gloo runs of the owner-partitioned exchange
+(kmernator_amd/distributed.py::exchange_records) on the CPU.  The oracle stands in for
+the two device steps (extract-by-owner, insert-records); the exchange code under test is
+the product's.  Each rank owns a slice of the reads; afterwards the union of the per-rank
+spectra must equal the single-partition spectrum and every k-mer must sit on its lookup3
+owner (src/Kmer.h:2284-2295)."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import (GOLDEN, KMR_VALUE_EXT, OracleSpectrum, default_config, oracle_extract_by_owner, oracle_lib, read_fastq)
+
+
+def _worker(rank, world, port, tmp, k, ext):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmernator_amd.distributed import all_ranks_chunk_count, exchange_records
+        from kmernator_amd import record_bytes
+        rb_all = read_fastq(os.path.join(GOLDEN, "1000.fastq"))
+        per = (rb_all.n + world - 1) // world
+        lo, hi = rank * per, min(rb_all.n, (rank + 1) * per)
+        kw = dict(value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2) if ext else {}
+        cfg = default_config(k, fastq_start_char=64, estimated_raw_kmers=56000, rank=rank, world_size=world, **kw)
+        spec = OracleSpectrum(cfg)
+        recb = record_bytes(k)
+        chunk = 130                                   # uneven chunk counts across ranks on purpose
+        n_chunks = (hi - lo + chunk - 1) // chunk if rank != world - 1 else 2
+        total = all_ranks_chunk_count(n_chunks)
+        seg_cap = 20000
+        for c in range(total):
+            a = lo + c * chunk
+            b = min(hi, a + chunk) if c < n_chunks - 1 or rank != world - 1 else hi
+            if c >= n_chunks or a >= hi:
+                recs = np.zeros(world * seg_cap * recb, dtype=np.uint8)
+                counts = np.zeros(world, dtype=np.uint64)
+            else:
+                recs, counts = oracle_extract_by_owner(cfg, rb_all.slice(a, b), seg_cap)
+            recv, n = exchange_records(torch.from_numpy(recs), torch.from_numpy(counts.astype(np.int64)), seg_cap, recb)
+            if n:
+                spec.insert_records(recv.numpy(), n)
+        spec.finalize(2)
+        keys, cnt, dirb, w, extv = spec.entries()
+        lib = oracle_lib()
+        for kk in keys[:200]:
+            assert lib.orc_distributed_thread_id(lib.orc_hash(kk.tobytes(), len(kk)), world) == rank
+        spec.dump(os.path.join(tmp, "counts.%d" % rank), 2, False)
+        if ext:
+            spec.dump(os.path.join(tmp, "graph.%d" % rank), 2, True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,ext", [(2, 21, True), (3, 21, True), (2, 31, False)])
+def test_exchange_union_equals_single(world, k, ext):
+    port = 29500 + (os.getpid() % 2000) + world
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(world, port, tmp, k, ext), nprocs=world, join=True)
+        got = []
+        for r in range(world):
+            got += open(os.path.join(tmp, "counts.%d" % r)).read().splitlines()
+        if ext:
+            exp = open(os.path.join(GOLDEN, "phix.mercount.m21")).read().splitlines()
+            assert sorted(got) == sorted(exp)
+            gg = []
+            for r in range(world):
+                gg += open(os.path.join(tmp, "graph.%d" % r)).read().splitlines()
+            assert sorted(gg) == sorted(open(os.path.join(GOLDEN, "phix.mergraph.m21.D2")).read().splitlines())
+        else:
+            rb = read_fastq(os.path.join(GOLDEN, "1000.fastq"))
+            s = OracleSpectrum(default_config(k, fastq_start_char=64, estimated_raw_kmers=46000))
+            s.add_reads(rb)
+            s.finalize(2)
+            s.dump(os.path.join(tmp, "single"), 2, False)
+            assert sorted(got) == sorted(open(os.path.join(tmp, "single")).read().splitlines())

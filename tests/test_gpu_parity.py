@@ -27,7 +27,7 @@ def add(sp, rb, first=0):
     sp.buildKmerSpectrum(rb.bases, rb.quals, rb.offsets, first, rb.discarded)
 
 
-def compare_weak_images(img_o, img_p, kb, ext):
+def compare_weak_images(img_o, img_p, kb, ext, dir_tol=0):
     vsize = 60 if ext else 12
     nb, mask, bo = parse_image(img_o, kb, vsize)
     nb2, mask2, bp = parse_image(img_p, kb, vsize)
@@ -42,7 +42,8 @@ def compare_weak_images(img_o, img_p, kb, ext):
         vo32 = np.ascontiguousarray(vo).view(np.uint32).reshape(len(ko), vsize // 4)
         vp32 = np.ascontiguousarray(vp).view(np.uint32).reshape(len(kp), vsize // 4)
         assert np.array_equal(vo32[:, 0] & 0xffff, vp32[:, 0] & 0xffff)            # count
-        assert np.array_equal(vo32[:, 2] & 0xffff, vp32[:, 2] & 0xffff)            # directionBias
+        do, dp = (vo32[:, 2] & 0xffff).astype(np.int64), (vp32[:, 2] & 0xffff).astype(np.int64)
+        assert np.all(np.abs(do - dp) <= dir_tol)                                   # directionBias
         wo, wp = vo32[:, 1].view(np.float32), vp32[:, 1].view(np.float32)
         cnt = (vo32[:, 0] & 0xffff).astype(np.float64)
         assert np.all(np.abs(wo.astype(np.float64) - wp) <= 1.0 / 254 + 1e-5 * cnt)
@@ -234,3 +235,50 @@ def test_read_longer_than_tile_is_an_error():
     p = product(default_config(21, num_buckets_weak=16, num_buckets_singleton=16))
     with pytest.raises(ka.KmerSpectrumError, match="longer"):
         add(p, rb)
+
+
+@pytest.mark.parametrize("k,ext", [(31, False), (21, True), (51, False)])
+def test_extract_by_owner_and_insert_records(k, ext):
+    """The two device halves of the owner exchange (kmr_extract_by_owner_dev ->
+    [all-to-all] -> kmr_insert_records_dev) with both 'ranks' on one GPU: each rank's
+    spectrum must equal the oracle's spectrum of the k-mers that rank owns."""
+    import torch
+    world = 2
+    rb = synth_reads(3000, read_len=110, seed=33, quality="noisy", n_rate=0.002)
+    kw = dict(value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2) if ext else {}
+    cfgs = [default_config(k, num_buckets_weak=256, num_buckets_singleton=1024, rank=r, world_size=world, **kw) for r in range(world)]
+    handles = [product(c) for c in cfgs]
+    recb = ka.record_bytes(k)
+    dev = torch.device("cuda", 0)
+    half = rb.n // 2
+    seg_cap = 3000 * 110
+    incoming = [[] for _ in range(world)]
+    for r, (lo, hi) in enumerate(((0, half), (half, rb.n))):
+        part = rb.slice(lo, hi)
+        tb = torch.from_numpy(np.concatenate([part.bases, np.zeros(64, np.uint8)])).to(dev)
+        tq = torch.from_numpy(np.concatenate([part.quals, np.zeros(64, np.uint8)])).to(dev)
+        to = torch.from_numpy(part.offsets.astype(np.int64)).to(dev)
+        recs = torch.zeros(world * seg_cap * recb, dtype=torch.uint8, device=dev)
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        handles[r].extractByOwnerDevice(tb.data_ptr(), tq.data_ptr(), to.data_ptr(), part.n, int(part.offsets[-1]), lo,
+                                        recs.data_ptr(), seg_cap, counts.data_ptr())
+        handles[r].sync()
+        c = counts.cpu().tolist()
+        for o in range(world):
+            incoming[o].append(recs.view(world, seg_cap * recb)[o, :c[o] * recb].clone())
+    for o in range(world):
+        allr = torch.cat(incoming[o]).contiguous()
+        torch.cuda.synchronize()
+        handles[o].insertRecordsDevice(allr.data_ptr(), allr.numel() // recb)
+        handles[o].sync()
+        handles[o].finalize(2)
+        orc = OracleSpectrum(cfgs[o])
+        orc.add_reads(rb)
+        orc.finalize(2)
+        so, sp_ = orc.stats(), handles[o].stats()
+        for key in ("raw_good_kmers", "unique_kmers", "singleton_kmers", "weak_entries"):
+            assert so[key] == sp_[key], (key, so, sp_)
+        # which sighting is 'first' (and loses its direction in the singleton map) depends on arrival order
+        # once records travel through the exchange, exactly as in the reference's MPI build
+        compare_weak_images(orc.image(KMR_MAP_WEAK), handles[o].image(KMR_MAP_WEAK), handles[o].kb, ext, dir_tol=1)
