@@ -30,7 +30,7 @@ class KmrConfig(C.Structure):
         ("rank", C.c_uint32), ("world_size", C.c_uint32),
         ("estimated_depth", C.c_double), ("estimated_error_rate", C.c_double),
         ("kmers_per_bucket", C.c_uint32), ("num_parts", C.c_uint32),
-        ("part_idx", C.c_uint32), ("reserved0", C.c_uint32),
+        ("part_idx", C.c_uint32), ("build_mode", C.c_uint32),
         ("max_table_entries", C.c_uint64),
     ]
 

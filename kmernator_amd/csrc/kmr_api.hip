@@ -19,6 +19,7 @@
 
 #include "../../include/kmernator_amd.h"
 #include "kmr_kernels.hpp"
+#include "kmr_partition.hpp"
 
 using namespace kmr;
 
@@ -36,6 +37,11 @@ struct DevMap {                      /* a finalized map resident in HBM */
 	uint8_t *image = nullptr;        /* reference layout, built lazily */
 	uint64_t image_bytes = 0;
 	bool present = false;
+};
+
+struct HostPool {                    /* owner of one chunk pool */
+	uint8_t *base = nullptr; uint32_t *chunk_list = nullptr, *chunk_count = nullptr; unsigned int *head = nullptr;
+	uint32_t cap = 0; size_t chunk_bytes = 0;
 };
 
 }  // namespace
@@ -61,6 +67,16 @@ struct kmr_handle {
 	bool finalized = false, has_singletons = true;
 	DevMap weak, sing;
 	kmr_stats stats;
+	/* streaming (partition) build path */
+	bool partition_mode = false;
+	HostPool l1, l2;
+	int bits1 = 0;
+	uint64_t inserted_records = 0;     /* records fed through kmr_insert_records_dev (counted on the host) */
+	unsigned int *work_counter = nullptr;
+	void *linear = nullptr; uint64_t linear_cap = 0;         /* records */
+	uint32_t *tile_count = nullptr; uint64_t tile_cap = 0;
+	uint32_t *kcap = nullptr; uint64_t *koff = nullptr; uint64_t kcap_n = 0;
+	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr; uint64_t uw_cap = 0, us_cap = 0;
 	/* timing */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	double ms[2] = {0, 0};
@@ -147,11 +163,13 @@ int sync_state(kmr_handle *h) {
 	uint32_t e = 0; DevStats s;
 	HIPCHK(h, hipMemcpy(&e, h->derr, sizeof(e), hipMemcpyDeviceToHost));
 	HIPCHK(h, hipMemcpy(&s, h->dstats, sizeof(s), hipMemcpyDeviceToHost));
-	h->stats.raw_kmers = s.raw; h->stats.raw_good_kmers = s.good; h->stats.discarded = s.raw - s.good;
+	h->stats.raw_kmers = s.raw + h->inserted_records; h->stats.raw_good_kmers = s.good + h->inserted_records; h->stats.discarded = s.raw - s.good;
 	h->occupied = s.claimed; h->pending_kmers = 0;
 	if (e & ERR_READ_TOO_LONG) return fail(h, KMR_ERR_UNSUPPORTED, "a read is longer than the per-wavefront LDS tile (" + std::to_string(TILE_SPAN) + " bases)");
 	if (e & ERR_TABLE_FULL) return fail(h, KMR_ERR_CAPACITY, "device k-mer table is full; raise kmr_config.max_table_entries / estimated_raw_kmers");
 	if (e & ERR_SEGMENT_OVERFLOW) return fail(h, KMR_ERR_CAPACITY, "an owner segment overflowed seg_capacity");
+	if (e & ERR_POOL_FULL) return fail(h, KMR_ERR_CAPACITY, "record pool overflow (internal sizing error)");
+	if (e & ERR_ENTRIES_FULL) return fail(h, KMR_ERR_CAPACITY, "entry buffer overflow (internal sizing error)");
 	return 0;
 }
 
@@ -414,6 +432,296 @@ int stage_reads(kmr_handle *h, const char *bases, const char *quals, const uint6
 	return 0;
 }
 
+
+/* ---------------------------------------------------------------------- */
+/* streaming build path (kmr_partition.hpp)                                  */
+const int COUNT_LOG2S = 11;                  /* 2048-slot LDS table per final list */
+const uint64_t TARGET_LIST_RECORDS = 2048;   /* records per final list the partition bits aim for */
+const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
+const uint64_t SUB_BATCH_BASES = 1ull << 28;
+
+size_t rec_bytes(kmr_handle *h) { return 8 * h->W + 8; }
+/* partition bits per level that keep batch + staging lines inside the 160 KB of LDS */
+int max_part_bits(uint32_t W) { return W == 1 ? 10 : (W <= 3 ? 9 : 8); }
+
+PoolView pool_view(kmr_handle *h, HostPool &p) { PoolView v; v.base = p.base; v.chunk_list = p.chunk_list; v.chunk_count = p.chunk_count; v.head = p.head; v.cap = p.cap; v.err = h->derr; return v; }
+
+void pool_free(HostPool &p) {
+	if (p.base) hipFree(p.base); if (p.chunk_list) hipFree(p.chunk_list); if (p.chunk_count) hipFree(p.chunk_count); if (p.head) hipFree(p.head);
+	p = HostPool();
+}
+/* make sure the pool can take 'extra' more chunks (keeps the used prefix when it has to move) */
+int pool_reserve(kmr_handle *h, HostPool &p, uint64_t extra, bool keep) {
+	unsigned int used = 0;
+	if (p.head && keep) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipMemcpy(&used, p.head, 4, hipMemcpyDeviceToHost)); if (used > p.cap) used = p.cap; }
+	const uint64_t need = (uint64_t)used + extra + 64;
+	if (need >= 0xffffffffull) return fail(h, KMR_ERR_CAPACITY, "record pool would exceed 2^32 chunks");
+	if (!p.head) { HIPCHK(h, hipMalloc((void **)&p.head, 4)); HIPCHK(h, hipMemset(p.head, 0, 4)); }
+	if (!keep) HIPCHK(h, hipMemsetAsync(p.head, 0, 4, h->stream));
+	if (need <= p.cap) return 0;
+	const uint64_t ncap = keep && used ? need + need / 4 : need;
+	p.chunk_bytes = (size_t)CH * rec_bytes(h);
+	uint8_t *nb; uint32_t *nl, *nc;
+	HIPCHK(h, hipMalloc((void **)&nb, ncap * p.chunk_bytes));
+	HIPCHK(h, hipMalloc((void **)&nl, 4 * ncap)); HIPCHK(h, hipMalloc((void **)&nc, 4 * ncap));
+	if (used) {
+		HIPCHK(h, hipMemcpy(nb, p.base, (size_t)used * p.chunk_bytes, hipMemcpyDeviceToDevice));
+		HIPCHK(h, hipMemcpy(nl, p.chunk_list, 4ull * used, hipMemcpyDeviceToDevice));
+		HIPCHK(h, hipMemcpy(nc, p.chunk_count, 4ull * used, hipMemcpyDeviceToDevice));
+	}
+	if (p.base) hipFree(p.base); if (p.chunk_list) hipFree(p.chunk_list); if (p.chunk_count) hipFree(p.chunk_count);
+	p.base = nb; p.chunk_list = nl; p.chunk_count = nc; p.cap = (uint32_t)ncap;
+	return 0;
+}
+
+template <class T> int ensure_buf(kmr_handle *h, T *&ptr, uint64_t &cap, uint64_t need, size_t elem) {
+	if (need <= cap && ptr) return 0;
+	if (ptr) hipFree((void *)ptr);
+	ptr = nullptr; cap = 0;
+	const uint64_t n = std::max<uint64_t>(need, 16);
+	HIPCHK(h, hipMalloc((void **)&ptr, n * elem));
+	cap = n;
+	return 0;
+}
+
+int zero_work_counter(kmr_handle *h) {
+	if (!h->work_counter) HIPCHK(h, hipMalloc((void **)&h->work_counter, 4));
+	HIPCHK(h, hipMemsetAsync(h->work_counter, 0, 4, h->stream));
+	return 0;
+}
+
+int part_grid(kmr_handle *h) {
+	hipDeviceProp_t pr; int ncu = 256;
+	if (hipGetDeviceProperties(&pr, h->device) == hipSuccess) ncu = pr.multiProcessorCount;
+	return ncu * 2;
+}
+
+/* level-1 partition of a linear record buffer into h->l1 */
+template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, const uint64_t *ext_start, const uint32_t *ext_count,
+                                      uint64_t n_ext, uint32_t ext_stride, uint64_t ext_len, uint64_t total, uint64_t max_records) {
+	if (n_ext == 0) return 0;
+	const int grid = (int)std::min<uint64_t>(part_grid(h), n_ext);
+	int rc = pool_reserve(h, h->l1, max_records / CH + (uint64_t)grid * (1ull << h->bits1) + 64, true);
+	if (rc) return rc;
+	rc = zero_work_counter(h); if (rc) return rc;
+	PartSource<W> S; memset(&S, 0, sizeof(S));
+	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
+	auto kern = partition_kernel<W, 1>;
+	const size_t smem = partition_smem_bytes<W>(h->bits1);
+	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)partition_smem_bytes<W>(max_part_bits(W))));
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(PART_THREADS), smem, h->stream, S, pool_view(h, h->l1), h->work_counter, h->bits1, 0);
+	HIPCHK(h, hipGetLastError());
+	return 0;
+}
+
+void choose_bits1(kmr_handle *h, uint64_t records_hint) {
+	/* total bits aim at TARGET_LIST_RECORDS per final list; level 2 takes up to MAX_PART_BITS of them */
+	uint64_t est = std::max<uint64_t>(records_hint, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
+	const int mb = max_part_bits(h->W);
+	int T = 0; while (T < 2 * mb && (est >> T) > TARGET_LIST_RECORDS) T++;
+	h->bits1 = std::max(0, T - mb);
+}
+
+template <int W> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
+	const uint64_t n = rvAll.n_reads;
+	if (!h->l1.head) choose_bits1(h, total_bases);
+	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
+	const uint64_t chunk = std::max<uint64_t>(64, (SUB_BATCH_BASES / avg) & ~63ull);
+	for (uint64_t r = 0; r < n; r += chunk) {
+		const uint64_t m = std::min(chunk, n - r);
+		ReadsView rv = rvAll;
+		rv.offsets = rvAll.offsets + r; rv.n_reads = m;
+		rv.discarded = rvAll.discarded ? rvAll.discarded + r : nullptr;
+		rv.first_read_idx = rvAll.first_read_idx + r;
+		/* k-mer capacity of every read -> region of each 64-read tile in the linear buffer */
+		int rc = ensure_buf(h, h->kcap, h->kcap_n, m + 1, 4); if (rc) return rc;
+		if (!h->koff || true) { if (h->koff) hipFree(h->koff); h->koff = nullptr; HIPCHK(h, hipMalloc((void **)&h->koff, 8 * (m + 1))); }
+		hipLaunchKernelGGL(kmer_capacity_kernel, dim3(grid_for(m)), dim3(256), 0, h->stream, rv.offsets, rv.discarded, m, h->k, h->kcap);
+		HIPCHK(h, hipGetLastError());
+		rc = exclusive_scan(h, h->kcap, m, h->koff); if (rc) return rc;
+		uint64_t total_cap = 0;
+		HIPCHK(h, hipMemcpy(&total_cap, h->koff + m, 8, hipMemcpyDeviceToHost));
+		const uint64_t tiles = (m + 63) / 64;
+		rc = ensure_buf(h, h->linear, h->linear_cap, total_cap, rec_bytes(h)); if (rc) return rc;
+		rc = ensure_buf(h, h->tile_count, h->tile_cap, tiles, 4); if (rc) return rc;
+		LinearOp<W, false> op; op.records = (Record<W> *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
+		hipEvent_t a, b; time_begin(h, 0, &a, &b);
+		rc = launch_extract<W, false>(h, rv, op);
+		if (!rc) rc = partition_level1<W>(h, (const Record<W> *)h->linear, h->koff, h->tile_count, tiles, 64, 0, 0, total_cap);
+		time_end(h, 0, a, b);
+		if (rc) return rc;
+	}
+	return 0;
+}
+int add_reads_partition(kmr_handle *h, const ReadsView &rv, uint64_t total_bases) {
+	switch (h->W) { case 1: return add_reads_partition_t<1>(h, rv, total_bases); case 2: return add_reads_partition_t<2>(h, rv, total_bases);
+	case 3: return add_reads_partition_t<3>(h, rv, total_bases); default: return add_reads_partition_t<4>(h, rv, total_bases); }
+}
+
+/* chunk CSR of a pool: list_start[nl+1] (device) and list_chunks[n_chunks] (device) */
+int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, uint32_t **list_chunks, uint32_t *n_chunks_out) {
+	unsigned int used = 0;
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	HIPCHK(h, hipMemcpy(&used, p.head, 4, hipMemcpyDeviceToHost));
+	if (used > p.cap) used = p.cap;
+	uint32_t *cnt;
+	HIPCHK(h, hipMalloc((void **)&cnt, 4 * nl)); HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
+	HIPCHK(h, hipMalloc((void **)list_start, 8 * (nl + 1)));
+	HIPCHK(h, hipMalloc((void **)list_chunks, 4ull * std::max<unsigned>(used, 1)));
+	if (used) hipLaunchKernelGGL(chunk_hist_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, used, cnt);
+	int rc = exclusive_scan(h, cnt, nl, *list_start); if (rc) return rc;
+	HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
+	if (used) hipLaunchKernelGGL(chunk_scatter_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, used, *list_start, cnt, *list_chunks);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(cnt);
+	*n_chunks_out = used;
+	return 0;
+}
+
+int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wn, uint64_t sn, bool keepSing);
+
+template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
+	int rc = sync_state(h);
+	if (rc) return rc;
+	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
+	const uint64_t G = h->stats.raw_good_kmers;     /* records in the level-1 pool */
+	FinalizeParams f; f.kb = h->kb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	const bool keepSing = f.has_singletons && min_depth <= 1;
+	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
+	/* level-1 CSR and level-2 work items */
+	const uint64_t nl1 = 1ull << h->bits1;
+	uint64_t *ls1 = nullptr; uint32_t *lc1 = nullptr; uint32_t nch1 = 0;
+	rc = build_csr(h, h->l1, nl1, &ls1, &lc1, &nch1); if (rc) return rc;
+	std::vector<uint64_t> hs(nl1 + 1);
+	HIPCHK(h, hipMemcpy(hs.data(), ls1, 8 * (nl1 + 1), hipMemcpyDeviceToHost));
+	std::vector<uint64_t> ib, ie; std::vector<uint32_t> il;
+	for (uint64_t l = 0; l < nl1; l++)
+		for (uint64_t c = hs[l]; c < hs[l + 1]; c += L2_ITEM_CHUNKS) { ib.push_back(c); ie.push_back(std::min(hs[l + 1], c + L2_ITEM_CHUNKS)); il.push_back((uint32_t)l); }
+	const int mb = max_part_bits(W);
+	int T = 0; while (T < 2 * mb && (G >> T) > TARGET_LIST_RECORDS) T++;
+	const int bits2 = std::max(0, std::min(mb, T - h->bits1));
+	const uint64_t nl2 = 1ull << (h->bits1 + bits2);
+	rc = pool_reserve(h, h->l2, G / CH + ib.size() * (1ull << bits2) + 64, false); if (rc) return rc;
+	if (!ib.empty()) {
+		uint64_t *dib, *die; uint32_t *dil;
+		HIPCHK(h, hipMalloc((void **)&dib, 8 * ib.size())); HIPCHK(h, hipMalloc((void **)&die, 8 * ie.size())); HIPCHK(h, hipMalloc((void **)&dil, 4 * il.size()));
+		HIPCHK(h, hipMemcpy(dib, ib.data(), 8 * ib.size(), hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(die, ie.data(), 8 * ie.size(), hipMemcpyHostToDevice));
+		HIPCHK(h, hipMemcpy(dil, il.data(), 4 * il.size(), hipMemcpyHostToDevice));
+		rc = zero_work_counter(h); if (rc) return rc;
+		PartSource<W> S; memset(&S, 0, sizeof(S));
+		S.src = pool_view(h, h->l1); S.list_chunks = lc1; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size();
+		auto kern = partition_kernel<W, 2>;
+		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)partition_smem_bytes<W>(max_part_bits(W))));
+		const int grid = (int)std::min<uint64_t>(part_grid(h), ib.size());
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(PART_THREADS), partition_smem_bytes<W>(bits2), h->stream, S, pool_view(h, h->l2), h->work_counter, bits2, h->bits1);
+		HIPCHK(h, hipGetLastError());
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+		hipFree(dib); hipFree(die); hipFree(dil);
+	}
+	hipFree(ls1); hipFree(lc1);
+	/* level-2 CSR, then count every final list */
+	uint64_t *ls2 = nullptr; uint32_t *lc2 = nullptr; uint32_t nch2 = 0;
+	rc = build_csr(h, h->l2, nl2, &ls2, &lc2, &nch2); if (rc) return rc;
+	const uint32_t vw = 3;
+	const uint64_t wcap = (f.has_singletons ? G / 2 : G) + 16, scap = keepSing ? G + 16 : 16;
+	if (!h->uw_keys || h->uw_cap < wcap) {
+		if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
+		HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, hipMalloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
+	}
+	if (!h->us_keys || h->us_cap < scap) {
+		if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); h->us_keys = h->us_b8 = nullptr; h->us_cap = 0;
+		HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); h->us_cap = scap;
+	}
+	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr; unsigned long long *cursors = nullptr;
+	HIPCHK(h, hipMalloc((void **)&wc, 4 * h->nb_weak)); HIPCHK(h, hipMalloc((void **)&sc, 4 * h->nb_sing)); HIPCHK(h, hipMalloc((void **)&fc, sizeof(FinalizeCounters))); HIPCHK(h, hipMalloc((void **)&cursors, 16));
+	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
+	HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
+	CountOut out; out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wcursor = cursors; out.wcap = h->uw_cap;
+	out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = nullptr; out.scursor = cursors + 1; out.scap = h->us_cap;
+	out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
+	rc = zero_work_counter(h); if (rc) return rc;
+	{
+		auto kern = count_kernel<W, false, COUNT_LOG2S>;
+		const size_t smem = count_smem_bytes<W, COUNT_LOG2S>();
+		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+		const int grid = (int)std::min<uint64_t>((uint64_t)part_grid(h), nl2);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l2), ls2, lc2, nl2, out, f, h->work_counter);
+		HIPCHK(h, hipGetLastError());
+	}
+	FinalizeCounters c; unsigned long long cur[2];
+	HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(cur, cursors, 16, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(ls2); hipFree(lc2); hipFree(fc); hipFree(cursors);
+	h->stats.unique_kmers = c.unique;
+	h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
+	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], keepSing);
+	hipFree(wc); hipFree(sc);
+	if (rc) return rc;
+	time_end(h, 1, ea, eb);
+	h->has_singletons = keepSing;
+	h->stats.weak_entries = h->weak.n; h->stats.singleton_entries = keepSing ? h->sing.n : 0;
+	h->finalized = true;
+	return sync_state(h);
+}
+
+/* unsorted kept entries (h->uw_*, h->us_*) + per-bucket counts -> bucketed sorted maps */
+template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wn, uint64_t sn, bool keepSing) {
+	const uint32_t vw = 3;
+	DevMap &wm = h->weak, &sm = h->sing;
+	free_map(wm); free_map(sm);
+	wm.nb = h->nb_weak; wm.n = wn; wm.present = true;
+	sm.nb = h->nb_sing; sm.n = keepSing ? sn : 0; sm.present = keepSing;
+	HIPCHK(h, hipMalloc((void **)&wm.start, 8 * (wm.nb + 1))); HIPCHK(h, hipMalloc((void **)&sm.start, 8 * (sm.nb + 1)));
+	int rc = exclusive_scan(h, wc, wm.nb, wm.start); if (rc) return rc;
+	rc = exclusive_scan(h, sc, sm.nb, sm.start); if (rc) return rc;
+	HIPCHK(h, hipMalloc((void **)&wm.keys, std::max<uint64_t>(8, 8ull * W * wm.n))); HIPCHK(h, hipMalloc((void **)&wm.vals, std::max<uint64_t>(8, 4ull * vw * wm.n)));
+	HIPCHK(h, hipMalloc((void **)&sm.keys, std::max<uint64_t>(8, 8ull * W * sm.n))); HIPCHK(h, hipMalloc((void **)&sm.sweight, std::max<uint64_t>(8, sm.n)));
+	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * sm.nb, h->stream));
+	if (wm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wm.n)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
+	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wm.n, vw, h->kb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
+	if (sm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(sm.n)), dim3(256), 0, h->stream, (const uint64_t *)h->us_keys, (const uint32_t *)nullptr,
+	                            (const uint8_t *)h->us_b8, (const uint32_t *)nullptr, sm.n, 0u, h->kb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, (uint32_t *)nullptr);
+	HIPCHK(h, hipGetLastError());
+	SortView<W> sv; sv.keys = wm.keys; sv.vals = wm.vals; sv.b8 = nullptr; sv.pkt = nullptr; sv.vw = vw;
+	hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(wm.nb, 64)), dim3(64), 0, h->stream, sv, wm.start, wm.nb);
+	if (sm.n) {
+		SortView<W> ss; ss.keys = sm.keys; ss.vals = nullptr; ss.b8 = sm.sweight; ss.pkt = nullptr; ss.vw = 0;
+		hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(sm.nb, 64)), dim3(64), 0, h->stream, ss, sm.start, sm.nb);
+	}
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	return 0;
+}
+int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wn, uint64_t sn, bool keepSing) {
+	switch (h->W) { case 1: return finish_maps_t<1>(h, wc, sc, wn, sn, keepSing); case 2: return finish_maps_t<2>(h, wc, sc, wn, sn, keepSing);
+	case 3: return finish_maps_t<3>(h, wc, sc, wn, sn, keepSing); default: return finish_maps_t<4>(h, wc, sc, wn, sn, keepSing); }
+}
+int finalize_partition(kmr_handle *h, uint32_t min_depth) {
+	switch (h->W) { case 1: return finalize_partition_t<1>(h, min_depth); case 2: return finalize_partition_t<2>(h, min_depth);
+	case 3: return finalize_partition_t<3>(h, min_depth); default: return finalize_partition_t<4>(h, min_depth); }
+}
+template <int W> int insert_records_partition_t(kmr_handle *h, const void *recs, uint64_t n) {
+	if (!h->l1.head) choose_bits1(h, n);
+	hipEvent_t a, b; time_begin(h, 0, &a, &b);
+	int rc = partition_level1<W>(h, (const Record<W> *)recs, nullptr, nullptr, (n + 8191) / 8192, 0, 8192, n, n);
+	time_end(h, 0, a, b);
+	h->inserted_records += n;
+	return rc;
+}
+int insert_records_partition(kmr_handle *h, const void *recs, uint64_t n) {
+	switch (h->W) { case 1: return insert_records_partition_t<1>(h, recs, n); case 2: return insert_records_partition_t<2>(h, recs, n);
+	case 3: return insert_records_partition_t<3>(h, recs, n); default: return insert_records_partition_t<4>(h, recs, n); }
+}
+void free_partition_state(kmr_handle *h) {
+	pool_free(h->l1); pool_free(h->l2);
+	if (h->work_counter) hipFree(h->work_counter); if (h->linear) hipFree(h->linear); if (h->tile_count) hipFree(h->tile_count);
+	if (h->kcap) hipFree(h->kcap); if (h->koff) hipFree(h->koff);
+	if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8);
+	h->work_counter = nullptr; h->linear = nullptr; h->tile_count = nullptr; h->kcap = nullptr; h->koff = nullptr;
+	h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = nullptr; h->linear_cap = h->tile_cap = h->kcap_n = h->uw_cap = h->us_cap = 0;
+}
+
 }  // namespace
 
 /* ====================================================================== */
@@ -469,8 +777,13 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 		double P[256]; quality_table(P, cfg->min_quality_score, cfg->fastq_start_char);
 		if (hipMalloc((void **)&h->dP, sizeof(P)) != hipSuccess || hipMalloc((void **)&h->dstats, sizeof(DevStats)) != hipSuccess || hipMalloc((void **)&h->derr, 4) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
 		hipMemcpy(h->dP, P, sizeof(P), hipMemcpyHostToDevice); hipMemset(h->dstats, 0, sizeof(DevStats)); hipMemset(h->derr, 0, 4);
-		rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
-		if (rc) { g_create_error = h->err; break; }
+		/* build_mode: 0 auto (streaming partition path unless EXT values), 1 table, 2 partition */
+		if (cfg->build_mode > 2 || (cfg->build_mode == 2 && h->ext)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 2 (partition) does not carry extension tallies yet"); break; }
+		h->partition_mode = cfg->build_mode == 2 || (cfg->build_mode == 0 && !h->ext);
+		if (!h->partition_mode) {
+			rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
+			if (rc) { g_create_error = h->err; break; }
+		}
 		if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(nullptr, KMR_ERR_HIP, std::string("table clear failed: ") + hipGetErrorString(hipGetLastError())); break; }
 	} while (0);
 	if (rc) { kmr_destroy(h); return rc; }
@@ -485,6 +798,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->slots) hipFree(h->slots); if (h->extslots) hipFree(h->extslots);
 	if (h->dP) hipFree(h->dP); if (h->dstats) hipFree(h->dstats); if (h->derr) hipFree(h->derr);
 	free_map(h->weak); free_map(h->sing);
+	free_partition_state(h);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -505,9 +819,15 @@ int kmr_reset(kmr_handle *h) {
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	free_map(h->weak); free_map(h->sing);
 	int rc = 0;
-	if (!h->slots) rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
-	else rc = clear_table_any(h, h->slots, h->extslots, h->log2cap);
-	if (rc) return rc;
+	if (h->partition_mode) {
+		if (h->l1.head) HIPCHK(h, hipMemsetAsync(h->l1.head, 0, 4, h->stream));
+		if (h->l2.head) HIPCHK(h, hipMemsetAsync(h->l2.head, 0, 4, h->stream));
+		h->inserted_records = 0;
+	} else {
+		if (!h->slots) rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
+		else rc = clear_table_any(h, h->slots, h->extslots, h->log2cap);
+		if (rc) return rc;
+	}
 	HIPCHK(h, hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream));
 	HIPCHK(h, hipMemsetAsync(h->derr, 0, 4, h->stream));
 	memset(&h->stats, 0, sizeof(h->stats));
@@ -521,6 +841,7 @@ int kmr_release_table(kmr_handle *h) {
 	hipSetDevice(h->device);
 	if (h->slots) { hipFree(h->slots); h->slots = nullptr; }
 	if (h->extslots) { hipFree(h->extslots); h->extslots = nullptr; }
+	if (h->partition_mode) free_partition_state(h);
 	return KMR_OK;
 }
 
@@ -537,7 +858,7 @@ int kmr_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_qual
 	hipSetDevice(h->device);
 	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
 	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
-	int rc = add_reads_dev_any(h, rv, total_bases);
+	int rc = h->partition_mode ? add_reads_partition(h, rv, total_bases) : add_reads_dev_any(h, rv, total_bases);
 	h->stream_base += total_bases; h->reads += n_reads; h->stats.reads = h->reads;
 	return rc;
 }
@@ -562,6 +883,7 @@ int kmr_finalize(kmr_handle *h, uint32_t min_depth) {
 	if (!h) return KMR_ERR_INVALID_ARG;
 	if (h->finalized) return fail(h, KMR_ERR_STATE, "already finalized");
 	hipSetDevice(h->device);
+	if (h->partition_mode) return finalize_partition(h, min_depth);
 #define FIN(Wv) (h->ext ? finalize_t<Wv, true>(h, min_depth) : finalize_t<Wv, false>(h, min_depth))
 	switch (h->W) { case 1: return FIN(1); case 2: return FIN(2); case 3: return FIN(3); default: return FIN(4); }
 #undef FIN
@@ -570,7 +892,7 @@ int kmr_finalize(kmr_handle *h, uint32_t min_depth) {
 int kmr_get_stats(kmr_handle *h, kmr_stats *out) {
 	if (!h || !out) return KMR_ERR_INVALID_ARG;
 	hipSetDevice(h->device);
-	if (!h->finalized) { int rc = sync_state(h); if (rc) return rc; h->stats.unique_kmers = h->occupied; }
+	if (!h->finalized) { int rc = sync_state(h); if (rc) return rc; h->stats.unique_kmers = h->partition_mode ? 0 : h->occupied; }
 	h->stats.reads = h->reads;
 	*out = h->stats;
 	return KMR_OK;
@@ -783,6 +1105,7 @@ int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n) {
 	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_insert_records_dev after kmr_finalize");
 	if (n == 0) return KMR_OK;
 	hipSetDevice(h->device);
+	if (h->partition_mode) { int prc = insert_records_partition(h, dev_records, n); h->stream_base += n; return prc; }
 	int rc = ensure_capacity(h, n); if (rc) return rc;
 	hipEvent_t a, b; time_begin(h, 0, &a, &b);
 #define INS(Wv, E) hipLaunchKernelGGL((insert_records_kernel<Wv, E>), dim3(grid_for(n)), dim3(256), 0, h->stream, table_of<Wv>(h), (const Record<Wv> *)dev_records, n, dev_params(h), h->stream_base)

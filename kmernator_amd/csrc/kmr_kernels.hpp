@@ -228,7 +228,11 @@ template <int W, bool EXT> struct InsertOp {
 	Table<W> table;
 	static const bool NEEDS_WEIGHT = true;
 	static const bool COUNTS_STATS = true;
-	__device__ __forceinline__ void emit(const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
+	static const bool NEEDS_HASH = true;
+	struct State {};
+	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
+	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
+	__device__ __forceinline__ void emit(State &, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
 	                                     uint64_t, uint32_t, unsigned &claimed, bool &fail) const {
 		if (!table_add<W, EXT>(table, key, hash, o, claimed)) fail = true;
 	}
@@ -247,16 +251,33 @@ template <int W, bool EXT> struct RecordOp {
 	uint64_t seg_capacity;
 	static const bool NEEDS_WEIGHT = true;
 	static const bool COUNTS_STATS = false;
-	__device__ __forceinline__ void emit(const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
+	static const bool NEEDS_HASH = true;
+	struct State {};
+	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
+	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
+	/* called under divergence: one atomic per (wavefront, owner) instead of one per lane */
+	__device__ __forceinline__ void emit(State &, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
 	                                     uint64_t, uint32_t, unsigned &, bool &fail) const {
-		uint32_t owner = distributed_thread_id(hash, p.world);
-		unsigned long long pos = atomicAdd(&seg_counts[owner], 1ull);   /* hipcc folds same-address adds per wave */
+		const uint32_t owner = distributed_thread_id(hash, p.world);
+		const int lane = (int)(threadIdx.x & 63);
+		unsigned long long todo = __ballot(1);
+		unsigned long long pos = 0;
+		while (todo) {
+			const int leader = __builtin_ctzll(todo);
+			const uint32_t o_ = __shfl(owner, leader, 64);
+			const unsigned long long same = __ballot(owner == o_) & todo;
+			unsigned long long base = 0;
+			if (lane == leader) base = atomicAdd(&seg_counts[o_], (unsigned long long)__builtin_popcountll(same));
+			base = __shfl(base, leader, 64);
+			if (owner == o_) pos = base + (unsigned long long)__builtin_popcountll(same & ((1ull << lane) - 1));
+			todo &= ~same;
+		}
 		if (pos >= seg_capacity) { fail = true; return; }
 		Record<W> r;
 #pragma unroll
 		for (int i = 0; i < W; i++) r.key[i] = key.w[i];
 		r.w = o.forward ? o.w : -o.w;
-		r.pkt = o.pkt;
+		r.pkt = EXT ? o.pkt : (uint32_t)o.ordinal;
 		records[(uint64_t)owner * seg_capacity + pos] = r;
 	}
 };
@@ -283,6 +304,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2)
 void extract_kernel(ReadsView rv, DevParams p, Op op) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	__shared__ double sP[256];
+	__shared__ uint32_t s_wcount[WAVES_PER_BLOCK];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	for (int i = threadIdx.x; i < 256; i += blockDim.x) sP[i] = p.P[i];
 	__syncthreads();                       /* the only block-wide barrier; waves are independent below */
@@ -305,6 +327,9 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 	unsigned long long nRaw = 0, nGood = 0;
 	unsigned nClaimed = 0;
 	bool fail = false;
+	typename Op::State opst;
+	op.tile_begin(opst, &s_wcount[wave], r0, lane);
+	const bool needHash = Op::NEEDS_HASH || p.subsample > 1 || p.world > 1 || p.num_parts > 1;
 
 	uint32_t done = 0;
 	while (done < nr) {
@@ -375,10 +400,10 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 					}
 					const bool isLeast = key_le<W>(roll.fwd, roll.rc);
 					const Key<W> canon = isLeast ? roll.fwd : roll.rc;
-					const uint64_t hash = key_hash<W>(canon, p.kb);
+					const uint64_t hash = needHash ? key_hash<W>(canon, p.kb) : 0ull;
 					bool mine = true;
-					if (p.subsample > 1 && hash % p.subsample != 0) mine = false;
-					if (Op::NEEDS_WEIGHT) {   /* owner / part filters apply to the build, not to lookups */
+					if (Op::NEEDS_WEIGHT) {
+						if (p.subsample > 1 && hash % p.subsample != 0) mine = false;   /* owner / part filters apply to the build, not to lookups */
 						if (p.world > 1 && !op_keeps_all_owners(op) && distributed_thread_id(hash, p.world) != p.rank) mine = false;
 						if (p.num_parts > 1 && distributed_thread_id(hash, p.num_parts) != p.part_idx) mine = false;
 					}
@@ -405,7 +430,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 								if (lq >= p.ext_min_q || lc > 3) o.ltally = (int)lc;
 								if (rq_ >= p.ext_min_q || rc_ > 3) o.rtally = 6 + (int)rc_;
 							}
-							op.emit(p, canon, hash, o, rv.first_read_idx + r0 + lane, i, nClaimed, fail);
+							op.emit(opst, p, canon, hash, o, rv.first_read_idx + r0 + lane, i, nClaimed, fail);
 						}
 					}
 					if (EXT) { leftCode = base_code(rb[i]); if (leftCode == 4) leftCode = 0; leftQ = ((isRef ? 127u : (uint32_t)rq[i]) - p.fastq_start) & 0xffu; }
@@ -415,6 +440,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		done += n;
 		__builtin_amdgcn_wave_barrier();   /* all lanes are done reading the tile before it is overwritten */
 	}
+	op.tile_end(opst, tile, lane);
 	nRaw = wave_sum(nRaw); nGood = wave_sum(nGood);
 	unsigned long long nc = wave_sum((unsigned long long)nClaimed);
 	if (lane == 0 && Op::COUNTS_STATS) {   /* the owner counts records when they are inserted */
@@ -471,7 +497,11 @@ template <int W> struct LookupOp {
 	uint64_t first_read_idx;
 	static const bool NEEDS_WEIGHT = false;
 	static const bool COUNTS_STATS = false;
-	__device__ __forceinline__ void emit(const DevParams &, const Key<W> &key, uint64_t hash, const Occurrence &,
+	static const bool NEEDS_HASH = true;
+	struct State {};
+	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
+	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
+	__device__ __forceinline__ void emit(State &, const DevParams &, const Key<W> &key, uint64_t hash, const Occurrence &,
 	                                     uint64_t readIdx, uint32_t pos, unsigned &, bool &) const {
 		out[out_offsets[readIdx - first_read_idx] + pos] = maps_count<W>(weak, sing, key, hash);
 	}

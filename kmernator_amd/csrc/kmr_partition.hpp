@@ -1,0 +1,510 @@
+/*
+ * kmr_partition.hpp -- streaming build path: hash-partition the k-mer records twice,
+ * then count every final partition inside LDS.
+ *
+ * Why: the open-addressed table of kmr_kernels.hpp touches HBM randomly (one 32-byte
+ * sector and three device-scope atomics per k-mer occurrence) and runs at the chip's
+ * scattered-atomic rate, ~3 % of the HBM roofline.  Here every HBM access is a
+ * streaming one and all atomics are LDS atomics:
+ *
+ *   extract_kernel<LinearOp>      reads -> compacted 16-byte records {key, signed weight, ordinal}
+ *   partition_kernel<LEVEL 1>     records -> P1 chunked lists      (bits 63.. of a mix of the key)
+ *   partition_kernel<LEVEL 2>     each list -> P2 sub-lists        (next bits)
+ *   count_kernel                  each final list -> LDS hash table -> (key,count,fwd,weight,first)
+ *                                 -> kept entries + per-bucket counts
+ *   scan / entry_scatter / sort   entries -> bucketed sorted maps (same layout as the table path)
+ *
+ * It replaces the same reference functions as InsertOp (KmerSpectrum::append + track(),
+ * src/KmerSpectrum.h:1578-1668, src/KmerTrackingData.h:427,517,641) and purgeMinDepth
+ * (:1805-1815); the partition function is private (results do not depend on it).
+ *
+ * Write combining: a block sorts a batch of 2048 records by destination list in LDS
+ * (counting sort), then one lane per list appends the run to that list's private chunk
+ * through a 64-byte staging line, so HBM only sees whole 64-byte sectors.  Lists are
+ * linked from fixed 64-record chunks handed out by one atomic per chunk.
+ */
+#ifndef KMR_PARTITION_HPP_
+#define KMR_PARTITION_HPP_
+
+#include "kmr_kernels.hpp"
+
+namespace kmr {
+
+static const int CH = 64;                    /* records per chunk */
+static const uint32_t NO_CHUNK = 0xffffffffu;
+static const int PART_THREADS = 256;
+static const int PART_RPT = 8;               /* records per thread per batch */
+static const int PART_BATCH = PART_THREADS * PART_RPT;
+enum { ERR_POOL_FULL = 8, ERR_ENTRIES_FULL = 16 };
+
+struct PoolView {
+	uint8_t *base;             /* chunk c occupies [c*CH*sizeof(Record), +CH*sizeof(Record)) */
+	uint32_t *chunk_list;      /* list id of each chunk */
+	uint32_t *chunk_count;     /* valid records in each chunk */
+	unsigned int *head;        /* next free chunk */
+	uint32_t cap;
+	uint32_t *err;
+};
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+	x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+	return x;
+}
+/* partition hash (NOT the reference's lookup3: nothing user visible depends on it) */
+template <int W> __host__ __device__ __forceinline__ uint64_t part_hash(const uint64_t *key) {
+	uint64_t h = mix64(key[0]);
+#pragma unroll
+	for (int i = 1; i < W; i++) h = mix64(h ^ (key[i] * 0x9E3779B97F4A7C15ull));
+	return h;
+}
+
+/* ------------------------------------------------------------------ LinearOp */
+/* extract -> compacted linear records.  Each wavefront owns the region
+ * [koff[r0], koff[r0+nr)) of the record buffer (koff = exclusive scan of the per-read
+ * k-mer capacities) and appends its good records there, wave-compacted; tile_count
+ * says how many it wrote. */
+template <int W, bool EXT> struct LinearOp {
+	Record<W> *records;
+	const uint64_t *koff;          /* [n_reads+1] */
+	uint32_t *tile_count;          /* [n_tiles] */
+	uint64_t first_read_idx;
+	static const bool NEEDS_WEIGHT = true;
+	static const bool COUNTS_STATS = true;
+	static const bool NEEDS_HASH = false;
+	struct State { uint32_t *wcount; uint64_t base; };
+	__device__ __forceinline__ void tile_begin(State &st, uint32_t *wcount, uint64_t r0, int lane) const {
+		st.wcount = wcount; st.base = koff[r0];
+		if (lane == 0) *wcount = 0;
+	}
+	__device__ __forceinline__ void tile_end(State &st, uint64_t tile, int lane) const {
+		if (lane == 0) tile_count[tile] = *st.wcount;
+	}
+	/* called under divergence: compact the active lanes behind the wave's running count */
+	__device__ __forceinline__ void emit(State &st, const DevParams &, const Key<W> &key, uint64_t, const Occurrence &o,
+	                                     uint64_t, uint32_t, unsigned &, bool &) const {
+		const unsigned long long mask = __ballot(1);
+		const int lane = (int)(threadIdx.x & 63);
+		const int leader = __builtin_ctzll(mask);
+		uint32_t old = 0;
+		if (lane == leader) { old = *st.wcount; *st.wcount = old + (uint32_t)__builtin_popcountll(mask); }
+		old = __shfl(old, leader, 64);
+		const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
+		Record<W> r;
+#pragma unroll
+		for (int i = 0; i < W; i++) r.key[i] = key.w[i];
+		r.w = o.forward ? o.w : -o.w;
+		r.pkt = EXT ? o.pkt : (uint32_t)o.ordinal;
+		records[st.base + old + rank] = r;
+	}
+};
+template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const LinearOp<W, EXT> &) { return false; }
+template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const LinearOp<W, EXT> &) { return 0; }
+
+__global__ void kmer_capacity_kernel(const uint64_t *offsets, const uint8_t *discarded, uint64_t n, uint32_t k, uint32_t *cap) {
+	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t L = offsets[r + 1] - offsets[r];
+		cap[r] = (discarded && discarded[r]) ? 0u : (L >= k ? (uint32_t)(L - k + 1) : 0u);
+	}
+}
+
+/* ------------------------------------------------------------------ partition */
+template <int W> struct PartSource {
+	/* LEVEL 1: extents of a linear record buffer */
+	const Record<W> *linear;
+	const uint64_t *ext_start;     /* per extent: first record (NULL: uniform extents of ext_len) */
+	const uint32_t *ext_count;     /* per extent: valid records   (NULL with uniform extents)     */
+	uint64_t n_ext, ext_len, total;
+	uint32_t ext_stride;           /* ext_start index = extent * ext_stride (64 reads per tile)   */
+	/* LEVEL 2: work items over the chunk CSR of the level-1 pool */
+	PoolView src;
+	const uint32_t *list_chunks;   /* chunk ids grouped by list */
+	const uint64_t *item_begin;    /* per work item: range in list_chunks ... */
+	const uint64_t *item_end;
+	const uint32_t *item_list;     /* ... and the level-1 list it belongs to */
+	uint64_t n_items;
+};
+
+template <int W> struct PartShared {
+	/* sized by the kernel: see partition_smem_bytes() */
+};
+
+static const int MAX_PART_BITS = 10;
+template <int W>
+__host__ __device__ inline size_t partition_smem_bytes(int bits) {
+	return (size_t)PART_BATCH * sizeof(Record<W>)                 /* sorted batch */
+	       + ((size_t)1 << bits) * 4 * sizeof(Record<W>)          /* staging lines (4 records) */
+	       + ((size_t)1 << bits) * 4 * 5                          /* hist, pstart, cur, cnt, pend */
+	       + 64;
+}
+
+/* LOG2P = bits of this level (<= MAX_PART_BITS), SHIFT = hash bits consumed by earlier levels */
+template <int W, int LEVEL>
+__global__ __launch_bounds__(PART_THREADS)
+void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter, const int LOG2P, const int SHIFT) {
+	const int P = 1 << LOG2P;
+	constexpr int G = 4;
+	typedef Record<W> Rec;
+	extern __shared__ __attribute__((aligned(16))) uint8_t psm[];
+	Rec *sorted = (Rec *)psm;
+	Rec *stage = sorted + PART_BATCH;
+	uint32_t *hist = (uint32_t *)(stage + (size_t)P * G);
+	uint32_t *pstart = hist + P;
+	uint32_t *cur = pstart + P;
+	uint32_t *cnt = cur + P;
+	uint32_t *pend = cnt + P;
+	__shared__ uint32_t s_item;
+	__shared__ uint32_t s_scan[PART_THREADS];
+	const int t = threadIdx.x;
+
+	for (int p = t; p < P; p += PART_THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; pend[p] = 0; }
+	__syncthreads();
+
+	auto chunk_ptr = [&](uint32_t c) -> Rec * { return (Rec *)(out.base + (size_t)c * CH * sizeof(Rec)); };
+
+	/* append 'n' records src[0..n) to list p (list id 'lid' in the output pool) */
+	auto append_run = [&](int p, uint32_t lid, const Rec *src, uint32_t n) {
+		uint32_t c = cur[p], filled = cnt[p], pe = pend[p];
+		Rec *line = stage + (size_t)p * G;
+		for (uint32_t i = 0; i < n; i++) {
+			line[pe++] = src[i];
+			if (pe == G) {
+				if (c == NO_CHUNK) {
+					c = atomicAdd(out.head, 1u);
+					if (c >= out.cap) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); c = NO_CHUNK; pe = 0; continue; }
+					out.chunk_list[c] = lid; filled = 0;
+				}
+				Rec *dst = chunk_ptr(c) + filled;
+#pragma unroll
+				for (int g = 0; g < G; g++) dst[g] = line[g];
+				filled += G; pe = 0;
+				if (filled == CH) { out.chunk_count[c] = CH; c = NO_CHUNK; filled = 0; }
+			}
+		}
+		cur[p] = c; cnt[p] = filled; pend[p] = pe;
+	};
+	auto flush_all = [&](uint32_t lid_base) {
+		for (int p = t; p < P; p += PART_THREADS) {
+			uint32_t c = cur[p], filled = cnt[p], pe = pend[p];
+			if (pe) {
+				if (c == NO_CHUNK) {
+					c = atomicAdd(out.head, 1u);
+					if (c >= out.cap) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); c = NO_CHUNK; }
+					else { out.chunk_list[c] = lid_base + p; filled = 0; }
+				}
+				if (c != NO_CHUNK) {
+					Rec *dst = chunk_ptr(c) + filled;
+					Rec *line = stage + (size_t)p * G;
+					for (uint32_t g = 0; g < pe; g++) dst[g] = line[g];
+					filled += pe;
+				}
+			}
+			if (c != NO_CHUNK) out.chunk_count[c] = filled;
+			cur[p] = NO_CHUNK; cnt[p] = 0; pend[p] = 0;
+		}
+	};
+
+	/* sort the batch held in registers by destination and hand the runs out */
+	auto scatter_batch = [&](Rec (&r)[PART_RPT], uint32_t (&pid)[PART_RPT], uint32_t lid_base) {
+		for (int p = t; p < P; p += PART_THREADS) hist[p] = 0;
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < PART_RPT; i++) if (pid[i] != NO_CHUNK) atomicAdd(&hist[pid[i]], 1u);
+		__syncthreads();
+		/* exclusive scan of hist -> pstart (P / PART_THREADS consecutive entries per thread) */
+		constexpr int MAXPER = (1 << MAX_PART_BITS) / PART_THREADS;
+		const int PER = P / PART_THREADS > 0 ? P / PART_THREADS : 1;
+		uint32_t loc[MAXPER], sum = 0;
+#pragma unroll
+		for (int i = 0; i < MAXPER; i++) { int p = t * PER + i; loc[i] = (i < PER && p < P) ? hist[p] : 0; sum += loc[i]; }
+		s_scan[t] = sum;
+		__syncthreads();
+		for (int o = 1; o < PART_THREADS; o <<= 1) {
+			uint32_t v = t >= o ? s_scan[t - o] : 0;
+			__syncthreads();
+			s_scan[t] += v;
+			__syncthreads();
+		}
+		uint32_t run = s_scan[t] - sum;
+#pragma unroll
+		for (int i = 0; i < MAXPER; i++) { int p = t * PER + i; if (i < PER && p < P) { pstart[p] = run; run += loc[i]; } }
+		__syncthreads();
+		/* reuse hist as the running cursor */
+		for (int p = t; p < P; p += PART_THREADS) hist[p] = pstart[p];
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < PART_RPT; i++) if (pid[i] != NO_CHUNK) { uint32_t pos = atomicAdd(&hist[pid[i]], 1u); sorted[pos] = r[i]; }
+		__syncthreads();
+		for (int p = t; p < P; p += PART_THREADS) {
+			const uint32_t n = hist[p] - pstart[p];
+			if (n) append_run(p, lid_base + p, sorted + pstart[p], n);
+		}
+		__syncthreads();
+	};
+
+	Rec r[PART_RPT];
+	uint32_t pid[PART_RPT];
+
+	if (LEVEL == 1) {
+		/* extents are handed out dynamically so ragged tiles balance */
+		for (;;) {
+			if (t == 0) s_item = atomicAdd(work_counter, 1u);
+			__syncthreads();
+			const uint64_t e = s_item;
+			__syncthreads();
+			if (e >= S.n_ext) break;
+			uint64_t start, n;
+			if (S.ext_start) { start = S.ext_start[e * S.ext_stride]; n = S.ext_count[e]; }
+			else { start = e * S.ext_len; n = S.total - start < S.ext_len ? S.total - start : S.ext_len; }
+			for (uint64_t b = 0; b < n; b += PART_BATCH) {
+#pragma unroll
+				for (int i = 0; i < PART_RPT; i++) {
+					const uint64_t idx = b + (uint64_t)i * PART_THREADS + t;
+					pid[i] = NO_CHUNK;
+					if (idx < n) { r[i] = S.linear[start + idx]; pid[i] = LOG2P ? (uint32_t)(part_hash<W>(r[i].key) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u; }
+				}
+				scatter_batch(r, pid, 0);
+			}
+		}
+		flush_all(0);
+	} else {
+		for (;;) {
+			if (t == 0) s_item = atomicAdd(work_counter, 1u);
+			__syncthreads();
+			const uint64_t it = s_item;
+			__syncthreads();
+			if (it >= S.n_items) break;
+			const uint64_t c0 = S.item_begin[it], c1 = S.item_end[it];
+			const uint32_t lid_base = S.item_list[it] << LOG2P;
+			/* a batch = 32 chunks; wave w of the block reads chunk (i*4 + w), lane = record */
+			for (uint64_t cb = c0; cb < c1; cb += PART_BATCH / CH) {
+#pragma unroll
+				for (int i = 0; i < PART_RPT; i++) {
+					const uint64_t ci = cb + (uint64_t)i * (PART_THREADS / CH) + (t >> 6);
+					pid[i] = NO_CHUNK;
+					if (ci < c1) {
+						const uint32_t c = S.list_chunks[ci];
+						if ((uint32_t)(t & 63) < S.src.chunk_count[c]) {
+							r[i] = ((const Rec *)(S.src.base + (size_t)c * CH * sizeof(Rec)))[t & 63];
+							pid[i] = LOG2P ? (uint32_t)(part_hash<W>(r[i].key) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u;
+						}
+					}
+				}
+				scatter_batch(r, pid, lid_base);
+			}
+			flush_all(lid_base);
+			__syncthreads();
+		}
+	}
+}
+
+/* chunk CSR: chunks grouped by list */
+__global__ void chunk_hist_kernel(const uint32_t *chunk_list, uint32_t n_chunks, uint32_t *list_nchunks) {
+	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x)
+		atomicAdd(&list_nchunks[chunk_list[c]], 1u);
+}
+__global__ void chunk_scatter_kernel(const uint32_t *chunk_list, uint32_t n_chunks, const uint64_t *list_start, uint32_t *cursor, uint32_t *list_chunks) {
+	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t l = chunk_list[c];
+		list_chunks[list_start[l] + atomicAdd(&cursor[l], 1u)] = (uint32_t)c;
+	}
+}
+
+/* ------------------------------------------------------------------ count */
+static const int COUNT_THREADS = 256;
+
+struct CountOut {
+	/* unsorted kept entries */
+	uint64_t *wkeys; uint32_t *wvals; unsigned long long *wcursor; uint64_t wcap;
+	uint64_t *skeys; uint8_t *sweight; uint32_t *spkt; unsigned long long *scursor; uint64_t scap;
+	uint32_t *weakCount, *singCount;        /* per bucket */
+	FinalizeCounters *fc;
+	uint32_t *err;
+};
+
+template <int W, int LOG2S>
+__host__ __device__ constexpr size_t count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0)); }
+
+/* One block per final list.  LDS table: keys, count|fwd<<32, f64 weight sum, first
+ * (ordinal<<1|fwd).  If the table would overflow the list is split by further hash bits
+ * and done in sub-passes (a tiny LDS stack), so any input is handled. */
+template <int W, bool EXT, int LOG2S>
+__global__ __launch_bounds__(COUNT_THREADS)
+void count_kernel(PoolView pool, const uint64_t *list_start, const uint32_t *list_chunks, uint64_t n_lists,
+                  CountOut out, FinalizeParams f, unsigned int *work_counter) {
+	constexpr int S = 1 << LOG2S;
+	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
+	typedef Record<W> Rec;
+	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
+	uint64_t *tkeys = (uint64_t *)csm;                                 /* [S][W] */
+	unsigned long long *tcnt = (unsigned long long *)(tkeys + (size_t)S * W);
+	double *twsum = (double *)(tcnt + S);
+	unsigned long long *tfirst = (unsigned long long *)(twsum + S);
+	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
+	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns;
+	__shared__ unsigned long long s_wbase, s_sbase;
+	__shared__ uint32_t s_stackBits[40], s_stackVal[40];
+	const int t = threadIdx.x;
+	const uint32_t vw = EXT ? 15 : 3;
+	unsigned long long uniq = 0, single = 0;
+
+	for (;;) {
+		if (t == 0) s_list = atomicAdd(work_counter, 1u);
+		__syncthreads();
+		const uint64_t l = s_list;
+		__syncthreads();
+		if (l >= n_lists) break;
+		const uint64_t c0 = list_start[l], c1 = list_start[l + 1];
+		if (c0 == c1) continue;
+		if (t == 0) { s_sp = 1; s_stackBits[0] = 0; s_stackVal[0] = 0; }
+		__syncthreads();
+		while (s_sp > 0) {
+			const uint32_t bits = s_stackBits[s_sp - 1], val = s_stackVal[s_sp - 1];
+			__syncthreads();
+			if (t == 0) { s_sp--; s_claimed = 0; s_overflow = 0; s_nw = 0; s_ns = 0; }
+			for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; }
+			__syncthreads();
+			const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
+			/* insert: wave w takes chunk (c0 + 4*i + w), lane = record */
+			for (uint64_t cb = c0 + (t >> 6); cb < c1 && !s_overflow; cb += COUNT_THREADS / CH) {
+				const uint32_t c = list_chunks[cb];
+				if ((uint32_t)(t & 63) >= pool.chunk_count[c]) continue;
+				const Rec r = ((const Rec *)(pool.base + (size_t)c * CH * sizeof(Rec)))[t & 63];
+				const uint64_t h = part_hash<W>(r.key);
+				if (((uint32_t)h & subMask) != val) continue;
+				uint32_t s = (uint32_t)(h >> 20) & (S - 1);
+				bool placed = false;
+				for (int probe = 0; probe < S && !placed; ) {
+					if constexpr (W == 1) {
+						uint64_t curk = tkeys[s];
+						if (curk == EMPTY_KEY) {
+							const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)r.key[0]);
+							if (old == EMPTY_KEY) { if (atomicAdd(&s_claimed, 1u) + 1 > LIMIT) s_overflow = 1; placed = true; break; }
+							curk = old;
+						}
+						if (curk == r.key[0]) { placed = true; break; }
+					} else {
+						/* state word: 0 empty, 1 being written, 2 ready (same protocol as the global table) */
+						uint32_t st = __hip_atomic_load(&tstate[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (st == 0) {
+							const uint32_t old = atomicCAS(&tstate[s], 0u, 1u);
+							if (old == 0) {
+#pragma unroll
+								for (int j = 0; j < W; j++) tkeys[(size_t)s * W + j] = r.key[j];
+								__hip_atomic_store(&tstate[s], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+								if (atomicAdd(&s_claimed, 1u) + 1 > LIMIT) s_overflow = 1;
+								placed = true; break;
+							}
+							st = old;
+						}
+						if (st == 1) continue;      /* writer publishes unconditionally: re-poll the same slot */
+						bool eq = true;
+#pragma unroll
+						for (int j = 0; j < W; j++) eq = eq && (tkeys[(size_t)s * W + j] == r.key[j]);
+						if (eq) { placed = true; break; }
+					}
+					s = (s + 1) & (S - 1);
+					probe++;
+				}
+				if (!placed) { s_overflow = 1; continue; }
+				const bool fwd = !(r.w < 0.0f);
+				const float wa = fwd ? r.w : -r.w;
+				atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(fwd ? 1 : 0) << 32));
+				atomicAdd(&twsum[s], (double)wa);
+				atomicMin(&tfirst[s], ((unsigned long long)r.pkt << 1) | (fwd ? 1ull : 0ull));
+			}
+			__syncthreads();
+			if (s_overflow) {       /* split this sub-pass in two by one more hash bit */
+				if (t == 0) {
+					if (bits >= 20) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
+					else {
+						s_stackBits[s_sp] = bits + 1; s_stackVal[s_sp] = val; s_sp++;
+						s_stackBits[s_sp] = bits + 1; s_stackVal[s_sp] = val | (1u << bits); s_sp++;
+					}
+				}
+				__syncthreads();
+				continue;
+			}
+			/* emit: first count the kept entries, reserve space, then write */
+			uint32_t myKind[S / COUNT_THREADS];
+			uint32_t myIdx[S / COUNT_THREADS];
+#pragma unroll
+			for (int i = 0; i < S / COUNT_THREADS; i++) {
+				const int s = i * COUNT_THREADS + t;
+				myKind[i] = 0;
+				if (W == 1 ? tkeys[s] != EMPTY_KEY : tstate[s] == 2) {
+					const uint32_t count = (uint32_t)tcnt[s];
+					uniq++;
+					if (count == 1) single++;
+					const int c = classify(count, f);
+					myKind[i] = (uint32_t)c;
+					if (c == 1) myIdx[i] = atomicAdd(&s_nw, 1u);
+					else if (c == 2) myIdx[i] = atomicAdd(&s_ns, 1u);
+				}
+			}
+			__syncthreads();
+			if (t == 0) {
+				s_wbase = s_nw ? atomicAdd(out.wcursor, (unsigned long long)s_nw) : 0;
+				s_sbase = s_ns ? atomicAdd(out.scursor, (unsigned long long)s_ns) : 0;
+				if (s_wbase + s_nw > out.wcap || s_sbase + s_ns > out.scap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); s_nw = 0xffffffffu; }
+			}
+			__syncthreads();
+			if (s_nw != 0xffffffffu) {
+#pragma unroll
+				for (int i = 0; i < S / COUNT_THREADS; i++) {
+					if (!myKind[i]) continue;
+					const int s = i * COUNT_THREADS + t;
+					Key<W> key;
+#pragma unroll
+					for (int j = 0; j < W; j++) key.w[j] = tkeys[(size_t)s * W + j];
+					const uint64_t hash = key_hash<W>(key, f.kb);
+					const unsigned long long cf = tcnt[s];
+					const uint32_t count = (uint32_t)cf;
+					if (myKind[i] == 1) {
+						const uint64_t pos = s_wbase + myIdx[i];
+#pragma unroll
+						for (int j = 0; j < W; j++) out.wkeys[pos * W + j] = key.w[j];
+						uint32_t fwd = (uint32_t)(cf >> 32), cnt = count;
+						if (f.has_singletons && (tfirst[s] & 1ull)) fwd -= 1;
+						if (cnt > 65535u) { cnt = 65535u; if (fwd > 65534u) fwd = 65534u; }
+						if (fwd > 65535u) fwd = 65535u;
+						uint32_t *v = out.wvals + pos * vw;
+						v[0] = cnt; v[1] = __float_as_uint((float)twsum[s]); v[2] = fwd;
+						atomicAdd(&out.weakCount[hash & (f.nb_weak - 1)], 1u);
+					} else {
+						const uint64_t pos = s_sbase + myIdx[i];
+#pragma unroll
+						for (int j = 0; j < W; j++) out.skeys[pos * W + j] = key.w[j];
+						const float wf = (float)twsum[s];
+						out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
+						atomicAdd(&out.singCount[hash & (f.nb_sing - 1)], 1u);
+					}
+				}
+			}
+			__syncthreads();
+		}
+	}
+	uniq = wave_sum(uniq); single = wave_sum(single);
+	if ((t & 63) == 0) { if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single); }
+}
+
+/* unsorted entries -> their bucket segments (then sort_buckets_kernel) */
+template <int W>
+__global__ void entry_scatter_kernel(const uint64_t *ukeys, const uint32_t *uvals, const uint8_t *ub8, const uint32_t *upkt, uint64_t n,
+                                     uint32_t vw, uint32_t kb, uint64_t nb, const uint64_t *start, uint32_t *cursor,
+                                     uint64_t *keys, uint32_t *vals, uint8_t *b8, uint32_t *pkt) {
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		Key<W> key;
+#pragma unroll
+		for (int j = 0; j < W; j++) key.w[j] = ukeys[e * W + j];
+		const uint64_t b = key_hash<W>(key, kb) & (nb - 1);
+		const uint64_t pos = start[b] + atomicAdd(&cursor[b], 1u);
+#pragma unroll
+		for (int j = 0; j < W; j++) keys[pos * W + j] = key.w[j];
+		if (uvals) for (uint32_t j = 0; j < vw; j++) vals[pos * vw + j] = uvals[e * vw + j];
+		if (ub8) b8[pos] = ub8[e];
+		if (upkt) pkt[pos] = upkt[e];
+	}
+}
+
+}  // namespace kmr
+#endif

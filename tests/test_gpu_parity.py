@@ -16,10 +16,14 @@ from refsemantics import median_trim_label
 pytestmark = pytest.mark.gpu
 
 
-def product(cfg):
+MODES = [1, 2]      # kmr_config.build_mode: 1 = open-addressed device table, 2 = streaming partition + LDS counting
+
+
+def product(cfg, mode=0):
     c = ka.default_config(cfg.k)
     for name, _ in cfg._fields_:
         setattr(c, name, getattr(cfg, name))
+    c.build_mode = mode
     return ka.KmerSpectrum(c)
 
 
@@ -53,9 +57,9 @@ def compare_weak_images(img_o, img_p, kb, ext, dir_tol=0):
     return n
 
 
-def run_both(cfg, rb, min_depth=2, batches=None):
+def run_both(cfg, rb, min_depth=2, batches=None, mode=0):
     o = OracleSpectrum(cfg)
-    p = product(cfg)
+    p = product(cfg, mode)
     if batches is None:
         o.add_reads(rb)
         add(p, rb)
@@ -89,13 +93,14 @@ def test_phix_meraculous_goldens(tmp_path):
     assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, True) == 5401
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("fq,start", [("1000.fastq", 64), ("1000.std.fastq", 33)])
 @pytest.mark.parametrize("k", [21, 31])
-def test_filterreads_fixture(fq, start, k):
+def test_filterreads_fixture(fq, start, k, mode):
     """Config 1 (k=21) and the reference's own FilterReads golden (k=31 labels)."""
     rb = read_fastq(os.path.join(GOLDEN, fq))
     cfg = default_config(k, fastq_start_char=start, estimated_raw_kmers=(76 - k + 1) * 1000)
-    o, p = run_both(cfg, rb)
+    o, p = run_both(cfg, rb, mode=mode)
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
     if k == 31:
         gold = read_fastq(os.path.join(GOLDEN, "1000-Filtered.fastq"))
@@ -110,8 +115,9 @@ def test_filterreads_fixture(fq, start, k):
         assert checked == 949
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("k", [5, 21, 31, 32, 33, 51, 64, 65, 95, 127])
-def test_synthetic_noisy_reads(k):
+def test_synthetic_noisy_reads(k, mode):
     """multi-word keys (k>32), N bases, sub-threshold qualities, ragged lengths"""
     rl = max(100, k + 40)
     rb = synth_reads(4000, read_len=rl, seed=k, quality="noisy", n_rate=0.003)
@@ -129,7 +135,7 @@ def test_synthetic_noisy_reads(k):
         quals.append(rb.qual(i)[:L])
     rb2 = ReadBatch(seqs, quals)
     cfg = default_config(k, estimated_raw_kmers=4000 * (rl - k + 1))
-    o, p = run_both(cfg, rb2, batches=[1500, 1501, 3000])
+    o, p = run_both(cfg, rb2, batches=[1500, 1501, 3000], mode=mode)
     n = compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
     assert n == o.stats()["weak_entries"] and n > 0
     # lookups: every k-mer of a few reads, plus absent keys
@@ -142,12 +148,13 @@ def test_synthetic_noisy_reads(k):
     assert np.array_equal(o.lookup(absent), p.getCount(absent))
 
 
-def test_singleton_map_and_min_depth_variants():
+@pytest.mark.parametrize("mode", MODES)
+def test_singleton_map_and_min_depth_variants(mode):
     rb = synth_reads(2000, read_len=100, seed=9, quality="noisy")
     for min_depth in (1, 2, 3):
         for sep in (1, 0):
             cfg = default_config(25, separate_singletons=sep, num_buckets_weak=512, num_buckets_singleton=2048)
-            o, p = run_both(cfg, rb, min_depth=min_depth)
+            o, p = run_both(cfg, rb, min_depth=min_depth, mode=mode)
             compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
             so = o.image(KMR_MAP_SINGLETON)
             sp_ = p.image(KMR_MAP_SINGLETON)
@@ -181,13 +188,14 @@ def test_ext_singletons_and_image_reload():
     assert np.array_equal(r.getCount(keys), o.lookup(keys))
 
 
-def test_count_saturation():
+@pytest.mark.parametrize("mode", MODES)
+def test_count_saturation(mode):
     k = 9
     seq = b"ACGTTGCAAGGCTA"
     n = 66000
     rb = ReadBatch([seq] * n, [b"I" * len(seq)] * n)
     cfg = default_config(k, num_buckets_weak=16, num_buckets_singleton=16)
-    o, p = run_both(cfg, rb)
+    o, p = run_both(cfg, rb, mode=mode)
     keys, w, ext = oracle_weighted_kmers(cfg, seq, b"I" * len(seq))
     assert np.all(p.getCount(keys) == 65535)
     assert np.array_equal(o.lookup(keys), p.getCount(keys))
@@ -196,26 +204,28 @@ def test_count_saturation():
 def test_table_growth():
     rb = synth_reads(20000, read_len=100, seed=12, err=0.05)
     cfg = default_config(31, max_table_entries=1000, num_buckets_weak=1024, num_buckets_singleton=4096)
-    o, p = run_both(cfg, rb, batches=[100, 5000])
+    o, p = run_both(cfg, rb, batches=[100, 5000], mode=1)
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
 
 
-def test_reference_reads_without_quals_and_discarded():
+@pytest.mark.parametrize("mode", MODES)
+def test_reference_reads_without_quals_and_discarded(mode):
     rb = synth_reads(500, read_len=120, seed=3, n_rate=0.01)
     disc = np.zeros(rb.n, dtype=np.uint8)
     disc[::7] = 1
     rbn = ReadBatch([rb.seq(i) for i in range(rb.n)], None, disc)
     cfg = default_config(21, num_buckets_weak=64, num_buckets_singleton=64)
-    o, p = run_both(cfg, rbn)
+    o, p = run_both(cfg, rbn, mode=mode)
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
 
 
-def test_owner_and_part_filters():
+@pytest.mark.parametrize("mode", MODES)
+def test_owner_and_part_filters(mode):
     """getDistributedThreadId owner filter (src/Kmer.h:2284-2295) and --build-partitions (:1680)"""
     rb = synth_reads(3000, read_len=100, seed=8, quality="noisy")
     for kw in (dict(rank=1, world_size=3), dict(num_parts=4, part_idx=2), dict(kmer_subsample=3)):
         cfg = default_config(27, num_buckets_weak=256, num_buckets_singleton=1024, **kw)
-        o, p = run_both(cfg, rb)
+        o, p = run_both(cfg, rb, mode=mode)
         compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
 
 
@@ -237,8 +247,8 @@ def test_read_longer_than_tile_is_an_error():
         add(p, rb)
 
 
-@pytest.mark.parametrize("k,ext", [(31, False), (21, True), (51, False)])
-def test_extract_by_owner_and_insert_records(k, ext):
+@pytest.mark.parametrize("k,ext,mode", [(31, False, 1), (31, False, 2), (21, True, 1), (51, False, 1), (51, False, 2)])
+def test_extract_by_owner_and_insert_records(k, ext, mode):
     """The two device halves of the owner exchange (kmr_extract_by_owner_dev ->
     [all-to-all] -> kmr_insert_records_dev) with both 'ranks' on one GPU: each rank's
     spectrum must equal the oracle's spectrum of the k-mers that rank owns."""
@@ -247,7 +257,7 @@ def test_extract_by_owner_and_insert_records(k, ext):
     rb = synth_reads(3000, read_len=110, seed=33, quality="noisy", n_rate=0.002)
     kw = dict(value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2) if ext else {}
     cfgs = [default_config(k, num_buckets_weak=256, num_buckets_singleton=1024, rank=r, world_size=world, **kw) for r in range(world)]
-    handles = [product(c) for c in cfgs]
+    handles = [product(c, mode) for c in cfgs]
     recb = ka.record_bytes(k)
     dev = torch.device("cuda", 0)
     half = rb.n // 2
@@ -282,3 +292,13 @@ def test_extract_by_owner_and_insert_records(k, ext):
         # which sighting is 'first' (and loses its direction in the singleton map) depends on arrival order
         # once records travel through the exchange, exactly as in the reference's MPI build
         compare_weak_images(orc.image(KMR_MAP_WEAK), handles[o].image(KMR_MAP_WEAK), handles[o].kb, ext, dir_tol=1)
+
+
+def test_many_distinct_keys_force_subpass_split():
+    """low coverage, high error: nearly every k-mer is distinct, so final lists overflow the LDS
+    table and count_kernel has to split them by further hash bits"""
+    rb = synth_reads(30000, read_len=150, genome_len=40_000_000, seed=77, err=0.02)
+    cfg = default_config(31, estimated_raw_kmers=1000, num_buckets_weak=4096, num_buckets_singleton=16384)   # estimate far too low on purpose
+    o, p = run_both(cfg, rb, min_depth=1, mode=2)
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
