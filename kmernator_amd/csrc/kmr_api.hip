@@ -501,7 +501,7 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
                                       uint64_t n_ext, uint32_t ext_stride, uint64_t ext_len, uint64_t total, uint64_t max_records) {
 	if (n_ext == 0) return 0;
 	const int grid = (int)std::min<uint64_t>(part_grid(h), n_ext);
-	int rc = pool_reserve(h, h->l1, max_records / CH + (uint64_t)grid * (1ull << h->bits1) + 64, true);
+	int rc = pool_reserve(h, h->l1, max_records / CH + (uint64_t)grid * ((1ull << h->bits1) + 512) + 64, true);
 	if (rc) return rc;
 	rc = zero_work_counter(h); if (rc) return rc;
 	PartSource<W> S; memset(&S, 0, sizeof(S));
@@ -602,7 +602,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	int T = 0; while (T < 2 * mb && (G >> T) > TARGET_LIST_RECORDS) T++;
 	const int bits2 = std::max(0, std::min(mb, T - h->bits1));
 	const uint64_t nl2 = 1ull << (h->bits1 + bits2);
-	rc = pool_reserve(h, h->l2, G / CH + ib.size() * (1ull << bits2) + 64, false); if (rc) return rc;
+	rc = pool_reserve(h, h->l2, G / CH + ib.size() * (1ull << bits2) + (uint64_t)part_grid(h) * 512 + 64, false); if (rc) return rc;
 	if (!ib.empty()) {
 		uint64_t *dib, *die; uint32_t *dil;
 		HIPCHK(h, hipMalloc((void **)&dib, 8 * ib.size())); HIPCHK(h, hipMalloc((void **)&die, 8 * ie.size())); HIPCHK(h, hipMalloc((void **)&dil, 4 * il.size()));

@@ -138,7 +138,7 @@ __host__ __device__ inline size_t partition_smem_bytes(int bits) {
 }
 
 /* LOG2P = bits of this level (<= MAX_PART_BITS), SHIFT = hash bits consumed by earlier levels */
-template <int W, int LEVEL>
+template <int W, int LEVEL, int DBG = 0>
 __global__ __launch_bounds__(PART_THREADS)
 void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter, const int LOG2P, const int SHIFT) {
 	const int P = 1 << LOG2P;
@@ -154,10 +154,36 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 	uint32_t *pend = cnt + P;
 	__shared__ uint32_t s_item;
 	__shared__ uint32_t s_scan[PART_THREADS];
+	/* chunk allocator: one device atomic hands a block SLAB chunks; chunk ids are then taken by an LDS
+	 * counter through a small ring of slab bases (one word of device memory saturates at ~90 M atomics/s,
+	 * which a per-chunk atomic from every block would hit) */
+	constexpr uint32_t SLAB = 64, RING = 128;
+	__shared__ uint32_t s_ring[RING];
+	__shared__ uint32_t s_alloc, s_filled;      /* chunks taken / chunks made available so far */
 	const int t = threadIdx.x;
 
 	for (int p = t; p < P; p += PART_THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; pend[p] = 0; }
+	if (t == 0) { s_alloc = 0; s_filled = 0; }
 	__syncthreads();
+
+	/* called by thread 0 between batches: keep a few times the average need of one batch (PART_BATCH/CH chunks)
+	 * ready; a batch that needs more falls back to the device counter in alloc_chunk */
+	auto top_up = [&]() {
+		const uint32_t want = 3 * SLAB;
+		if (s_alloc > s_filled) s_alloc = s_filled;
+		const uint32_t have = s_filled - s_alloc;
+		if (have < want) {
+			const uint32_t nslab = (want - have + SLAB - 1) / SLAB;
+			const uint32_t base = atomicAdd(out.head, nslab * SLAB);
+			for (uint32_t i = 0; i < nslab; i++) s_ring[((s_filled / SLAB) + i) % RING] = base + i * SLAB;
+			s_filled += nslab * SLAB;
+		}
+	};
+	auto alloc_chunk = [&]() -> uint32_t {
+		const uint32_t idx = atomicAdd(&s_alloc, 1u);
+		const uint32_t c = idx < s_filled ? s_ring[(idx / SLAB) % RING] + (idx % SLAB) : atomicAdd(out.head, 1u);
+		return c < out.cap ? c : NO_CHUNK;
+	};
 
 	auto chunk_ptr = [&](uint32_t c) -> Rec * { return (Rec *)(out.base + (size_t)c * CH * sizeof(Rec)); };
 
@@ -169,8 +195,8 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 			line[pe++] = src[i];
 			if (pe == G) {
 				if (c == NO_CHUNK) {
-					c = atomicAdd(out.head, 1u);
-					if (c >= out.cap) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); c = NO_CHUNK; pe = 0; continue; }
+					c = alloc_chunk();
+					if (c == NO_CHUNK) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); pe = 0; continue; }
 					out.chunk_list[c] = lid; filled = 0;
 				}
 				Rec *dst = chunk_ptr(c) + filled;
@@ -183,12 +209,14 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 		cur[p] = c; cnt[p] = filled; pend[p] = pe;
 	};
 	auto flush_all = [&](uint32_t lid_base) {
+		if (t == 0) top_up();
+		__syncthreads();
 		for (int p = t; p < P; p += PART_THREADS) {
 			uint32_t c = cur[p], filled = cnt[p], pe = pend[p];
 			if (pe) {
 				if (c == NO_CHUNK) {
-					c = atomicAdd(out.head, 1u);
-					if (c >= out.cap) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); c = NO_CHUNK; }
+					c = alloc_chunk();
+					if (c == NO_CHUNK) atomicOr(out.err, (uint32_t)ERR_POOL_FULL);
 					else { out.chunk_list[c] = lid_base + p; filled = 0; }
 				}
 				if (c != NO_CHUNK) {
@@ -205,7 +233,12 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 
 	/* sort the batch held in registers by destination and hand the runs out */
 	auto scatter_batch = [&](Rec (&r)[PART_RPT], uint32_t (&pid)[PART_RPT], uint32_t lid_base) {
+		if (DBG == 2) { uint32_t acc = 0;
+#pragma unroll
+			for (int i = 0; i < PART_RPT; i++) acc += pid[i];
+			if (acc == 0x12345u) hist[0] = acc; return; }
 		for (int p = t; p < P; p += PART_THREADS) hist[p] = 0;
+		if (t == 0) top_up();
 		__syncthreads();
 #pragma unroll
 		for (int i = 0; i < PART_RPT; i++) if (pid[i] != NO_CHUNK) atomicAdd(&hist[pid[i]], 1u);
@@ -234,7 +267,7 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 #pragma unroll
 		for (int i = 0; i < PART_RPT; i++) if (pid[i] != NO_CHUNK) { uint32_t pos = atomicAdd(&hist[pid[i]], 1u); sorted[pos] = r[i]; }
 		__syncthreads();
-		for (int p = t; p < P; p += PART_THREADS) {
+		if (DBG != 1) for (int p = t; p < P; p += PART_THREADS) {
 			const uint32_t n = hist[p] - pstart[p];
 			if (n) append_run(p, lid_base + p, sorted + pstart[p], n);
 		}
@@ -295,16 +328,23 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 			__syncthreads();
 		}
 	}
+	/* chunks fetched but never handed out: mark them empty so the CSR pass can skip over them */
+	__syncthreads();
+	for (uint32_t idx = s_alloc + t; idx < s_filled; idx += PART_THREADS) {
+		const uint32_t c = s_ring[(idx / SLAB) % RING] + (idx % SLAB);
+		if (c < out.cap) { out.chunk_list[c] = NO_CHUNK; out.chunk_count[c] = 0; }
+	}
 }
 
 /* chunk CSR: chunks grouped by list */
 __global__ void chunk_hist_kernel(const uint32_t *chunk_list, uint32_t n_chunks, uint32_t *list_nchunks) {
 	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x)
-		atomicAdd(&list_nchunks[chunk_list[c]], 1u);
+		{ const uint32_t l = chunk_list[c]; if (l != NO_CHUNK) atomicAdd(&list_nchunks[l], 1u); }
 }
 __global__ void chunk_scatter_kernel(const uint32_t *chunk_list, uint32_t n_chunks, const uint64_t *list_start, uint32_t *cursor, uint32_t *list_chunks) {
 	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t l = chunk_list[c];
+		if (l == NO_CHUNK) continue;
 		list_chunks[list_start[l] + atomicAdd(&cursor[l], 1u)] = (uint32_t)c;
 	}
 }

@@ -1,0 +1,55 @@
+// micro-benchmark of partition_kernel variants (development tool, not part of the product)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../kmernator_amd/csrc/kmr_partition.hpp"
+using namespace kmr;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+__global__ void fill(Record<1> *r, uint64_t n) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { r[i].key[0] = mix64(i * 7 + 1) >> 2 << 2; r[i].w = 0.99f; r[i].pkt = (uint32_t)i; }
+}
+template <int DBG> float run(const Record<1> *lin, uint64_t n, int bits, PoolView pv, unsigned int *wc, int grid) {
+	hipMemset(pv.head, 0, 4); hipMemset(wc, 0, 4);
+	PartSource<1> S; memset(&S, 0, sizeof(S)); S.linear = lin; S.n_ext = (n + 8191) / 8192; S.ext_len = 8192; S.total = n;
+	auto kern = partition_kernel<1, 1, DBG>;
+	hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)partition_smem_bytes<1>(10));
+	hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+	hipEventRecord(a);
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(PART_THREADS), partition_smem_bytes<1>(bits), 0, S, pv, wc, bits, 0);
+	hipEventRecord(b); hipEventSynchronize(b);
+	float ms; hipEventElapsedTime(&ms, a, b);
+	printf("  err=%s\n", hipGetErrorString(hipGetLastError()));
+	return ms;
+}
+__global__ void fill_genome(Record<1> *r, uint64_t n, const uint8_t *g, uint64_t glen) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t pos = i % (glen - 31);
+		uint64_t f = 0, rc = 0;
+		for (int j = 0; j < 31; j++) { uint64_t b = g[pos + j] & 3; f = (f << 2) | b; rc = (rc >> 2) | ((3 - b) << 60); }
+		uint64_t c = f < rc ? f : rc;
+		r[i].key[0] = c << 2; r[i].w = 0.99f; r[i].pkt = (uint32_t)i;
+	}
+}
+int main(int argc, char **argv) {
+	const uint64_t n = 200000000ull;
+	Record<1> *lin; CK(hipMalloc(&lin, n * 16));
+	if (argc > 1) {
+		const uint64_t glen = 8000000; std::vector<uint8_t> g(glen); uint64_t x = 88172645463325252ull;
+		for (auto &b : g) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; b = (uint8_t)(x >> 33) & 3; }
+		uint8_t *dg; CK(hipMalloc(&dg, glen)); CK(hipMemcpy(dg, g.data(), glen, hipMemcpyHostToDevice));
+		hipLaunchKernelGGL(fill_genome, dim3(4096), dim3(256), 0, 0, lin, n, dg, glen);
+		printf("genome-derived canonical 31-mers\n");
+	} else
+	hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, lin, n);
+	PoolView pv; uint32_t cap = (uint32_t)(n / CH + 2000000);
+	CK(hipMalloc(&pv.base, (size_t)cap * CH * 16)); CK(hipMalloc(&pv.chunk_list, 4ull * cap)); CK(hipMalloc(&pv.chunk_count, 4ull * cap)); CK(hipMalloc(&pv.head, 4)); CK(hipMalloc(&pv.err, 4));
+	pv.cap = cap; hipMemset(pv.err, 0, 4);
+	unsigned int *wc; CK(hipMalloc(&wc, 4));
+	CK(hipDeviceSynchronize());
+	for (int bits : {10, 9}) for (int grid : {512}) {
+		float f0 = run<0>(lin, n, bits, pv, wc, grid), f1 = run<1>(lin, n, bits, pv, wc, grid), f2 = run<2>(lin, n, bits, pv, wc, grid);
+		printf("bits %d grid %d: full %.2f ms  noappend %.2f ms  loadonly %.2f ms   (%.1f Grec/s full)\n", bits, grid, f0, f1, f2, n / f0 / 1e6);
+	}
+	return 0;
+}
