@@ -118,6 +118,7 @@ size_t slot_bytes(uint32_t W) {
 DevParams dev_params(kmr_handle *h) {
 	DevParams p;
 	p.k = h->k; p.kb = h->kb; p.min_weight = h->cfg.min_weight; p.fastq_start = h->cfg.fastq_start_char; p.ext_min_q = h->cfg.ext_min_quality;
+	p.qzero = h->cfg.fastq_start_char + std::max<uint32_t>(1u, h->cfg.min_quality_score);   /* Q0 has probability 0 too */
 	p.subsample = h->cfg.kmer_subsample; p.rank = h->cfg.rank; p.world = h->cfg.world_size; p.num_parts = h->cfg.num_parts; p.part_idx = h->cfg.part_idx;
 	p.P = h->dP; p.stats = h->dstats; p.err = h->derr;
 	return p;

@@ -54,6 +54,7 @@ struct DevParams {
 	uint32_t k, kb;
 	float min_weight;
 	uint32_t fastq_start, ext_min_q;
+	uint32_t qzero;            /* raw quality chars below this have probability 0 (fastq_start + min_quality_score) */
 	uint32_t subsample, rank, world, num_parts, part_idx;
 	const double *P;       /* 256 entries, device */
 	DevStats *stats;
@@ -232,9 +233,9 @@ template <int W, bool EXT> struct InsertOp {
 	struct State {};
 	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
 	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
-	__device__ __forceinline__ void emit(State &, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
+	__device__ __forceinline__ void emit(State &, bool valid, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
 	                                     uint64_t, uint32_t, unsigned &claimed, bool &fail) const {
-		if (!table_add<W, EXT>(table, key, hash, o, claimed)) fail = true;
+		if (valid && !table_add<W, EXT>(table, key, hash, o, claimed)) fail = true;
 	}
 };
 
@@ -255,12 +256,12 @@ template <int W, bool EXT> struct RecordOp {
 	struct State {};
 	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
 	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
-	/* called under divergence: one atomic per (wavefront, owner) instead of one per lane */
-	__device__ __forceinline__ void emit(State &, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
+	/* one atomic per (wavefront, owner) instead of one per lane */
+	__device__ __forceinline__ void emit(State &, bool valid, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
 	                                     uint64_t, uint32_t, unsigned &, bool &fail) const {
-		const uint32_t owner = distributed_thread_id(hash, p.world);
+		const uint32_t owner = valid ? distributed_thread_id(hash, p.world) : 0xffffffffu;
 		const int lane = (int)(threadIdx.x & 63);
-		unsigned long long todo = __ballot(1);
+		unsigned long long todo = __ballot(valid);
 		unsigned long long pos = 0;
 		while (todo) {
 			const int leader = __builtin_ctzll(todo);
@@ -272,6 +273,7 @@ template <int W, bool EXT> struct RecordOp {
 			if (owner == o_) pos = base + (unsigned long long)__builtin_popcountll(same & ((1ull << lane) - 1));
 			todo &= ~same;
 		}
+		if (!valid) return;
 		if (pos >= seg_capacity) { fail = true; return; }
 		Record<W> r;
 #pragma unroll
@@ -283,14 +285,14 @@ template <int W, bool EXT> struct RecordOp {
 };
 
 /* ----------------------------------------------------------------------- */
-__device__ __forceinline__ uint32_t base_code(uint8_t c) {   /* compressBase: 0..3, 4 = markup */
-	switch (c) {
-	case 'A': case 'a': return 0;
-	case 'C': case 'c': return 1;
-	case 'G': case 'g': return 2;
-	case 'T': case 't': return 3;
-	default: return 4;
-	}
+/* compressBase (src/TwoBitSequence.cpp:124-147) without branches: 0..3 for ACGT/acgt, 4 = markup.
+ * (c>>1)&3 maps A,C,G,T to 0,1,3,2; x^(x>>1) turns that into 0,1,2,3. */
+__device__ __forceinline__ uint32_t base_code(uint8_t c) {
+	const uint32_t u = (uint32_t)c & 0xDFu;                  /* upper case */
+	const uint32_t idx = u - 'A';
+	const uint32_t valid = idx < 32u ? ((0x00080045u >> idx) & 1u) : 0u;   /* bits A=0, C=2, G=6, T=19 */
+	const uint32_t x = (u >> 1) & 3u;
+	return valid ? (x ^ (x >> 1)) : 4u;
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -372,16 +374,26 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		uint32_t zc = 0;                 /* positions in the window that force weight 0 */
 		uint32_t leftCode = 5, leftQ = p.ext_min_q;   /* Extension('X', minQuality) */
 		for (uint32_t j = 0; j < Lmax; j++) {
+			/* the occurrence of this iteration is handed to the Op after the divergent part, so that
+			 * Ops can use wave-wide primitives (ballot compaction) under uniform control flow */
+			bool valid = false;
+			Key<W> canon;
+			uint64_t hash = 0;
+			uint32_t kpos = 0;
+			Occurrence o;
+			o.w = 0.0f; o.forward = true; o.ordinal = 0; o.pkt = 0; o.ltally = -1; o.rtally = -1;
+#pragma unroll
+			for (int wi = 0; wi < W; wi++) canon.w[wi] = 0;
 			if (j < L) {
 				const uint8_t c = rb[j];
 				uint32_t code = base_code(c);
 				const uint32_t q = isRef ? 127u : (uint32_t)rq[j];
-				bool z = (code == 4) || (!isRef && sP[q] == 0.0);
+				bool z = (code == 4) || (!isRef && q < p.qzero);
 				if (code == 4) code = 0;                      /* markup packs as A */
 				zc += z ? 1u : 0u;
 				if (j >= k) {                                 /* position j-k leaves the window */
 					const uint32_t oc = base_code(rb[j - k]);
-					const bool oz = (oc == 4) || (!isRef && sP[rq[j - k]] == 0.0);
+					const bool oz = (oc == 4) || (!isRef && (uint32_t)rq[j - k] < p.qzero);
 					zc -= oz ? 1u : 0u;
 				}
 				roll.push(code);
@@ -394,13 +406,17 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 							w = 1.0;
 							for (uint32_t jj = 0; jj < k; jj++) w *= sP[rq[i + jj]];
 						} else {
-							const double change = sP[q] / sP[rq[i - 1]];
-							w *= change;
+							const uint32_t qo = rq[i - 1];
+							if (qo != q) {              /* x / x == 1.0 exactly, so equal qualities leave w unchanged */
+								const double change = sP[q] / sP[qo];
+								w *= change;
+							}
 						}
 					}
 					const bool isLeast = key_le<W>(roll.fwd, roll.rc);
-					const Key<W> canon = isLeast ? roll.fwd : roll.rc;
-					const uint64_t hash = needHash ? key_hash<W>(canon, p.kb) : 0ull;
+					canon = isLeast ? roll.fwd : roll.rc;
+					hash = needHash ? key_hash<W>(canon, p.kb) : 0ull;
+					kpos = i;
 					bool mine = true;
 					if (Op::NEEDS_WEIGHT) {
 						if (p.subsample > 1 && hash % p.subsample != 0) mine = false;   /* owner / part filters apply to the build, not to lookups */
@@ -412,9 +428,8 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 						nRaw++;
 						if (!Op::NEEDS_WEIGHT || wf > p.min_weight) {
 							nGood++;
-							Occurrence o;
+							valid = true;
 							o.w = wf; o.forward = isLeast; o.ordinal = rv.stream_base + myStart + i;
-							o.pkt = 0; o.ltally = -1; o.rtally = -1;
 							if (EXT) {
 								uint32_t rc_, rq_;
 								if (j + 1 < L) { rc_ = base_code(rb[j + 1]); if (rc_ == 4) rc_ = 0; rq_ = ((isRef ? 127u : (uint32_t)rq[j + 1]) - p.fastq_start) & 0xffu; }
@@ -430,12 +445,12 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 								if (lq >= p.ext_min_q || lc > 3) o.ltally = (int)lc;
 								if (rq_ >= p.ext_min_q || rc_ > 3) o.rtally = 6 + (int)rc_;
 							}
-							op.emit(opst, p, canon, hash, o, rv.first_read_idx + r0 + lane, i, nClaimed, fail);
 						}
 					}
 					if (EXT) { leftCode = base_code(rb[i]); if (leftCode == 4) leftCode = 0; leftQ = ((isRef ? 127u : (uint32_t)rq[i]) - p.fastq_start) & 0xffu; }
 				}
 			}
+			op.emit(opst, valid, p, canon, hash, o, rv.first_read_idx + r0 + lane, kpos, nClaimed, fail);
 		}
 		done += n;
 		__builtin_amdgcn_wave_barrier();   /* all lanes are done reading the tile before it is overwritten */
@@ -501,9 +516,9 @@ template <int W> struct LookupOp {
 	struct State {};
 	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
 	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
-	__device__ __forceinline__ void emit(State &, const DevParams &, const Key<W> &key, uint64_t hash, const Occurrence &,
+	__device__ __forceinline__ void emit(State &, bool valid, const DevParams &, const Key<W> &key, uint64_t hash, const Occurrence &,
 	                                     uint64_t readIdx, uint32_t pos, unsigned &, bool &) const {
-		out[out_offsets[readIdx - first_read_idx] + pos] = maps_count<W>(weak, sing, key, hash);
+		if (valid) out[out_offsets[readIdx - first_read_idx] + pos] = maps_count<W>(weak, sing, key, hash);
 	}
 };
 template <int W> __device__ __forceinline__ bool op_keeps_all_owners(const LookupOp<W> &) { return true; }

@@ -71,30 +71,24 @@ template <int W, bool EXT> struct LinearOp {
 	static const bool NEEDS_WEIGHT = true;
 	static const bool COUNTS_STATS = true;
 	static const bool NEEDS_HASH = false;
-	struct State { uint32_t *wcount; uint64_t base; };
-	__device__ __forceinline__ void tile_begin(State &st, uint32_t *wcount, uint64_t r0, int lane) const {
-		st.wcount = wcount; st.base = koff[r0];
-		if (lane == 0) *wcount = 0;
-	}
-	__device__ __forceinline__ void tile_end(State &st, uint64_t tile, int lane) const {
-		if (lane == 0) tile_count[tile] = *st.wcount;
-	}
-	/* called under divergence: compact the active lanes behind the wave's running count */
-	__device__ __forceinline__ void emit(State &st, const DevParams &, const Key<W> &key, uint64_t, const Occurrence &o,
+	struct State { uint64_t base; uint32_t n; };
+	__device__ __forceinline__ void tile_begin(State &st, uint32_t *, uint64_t r0, int) const { st.base = koff[r0]; st.n = 0; }
+	__device__ __forceinline__ void tile_end(State &st, uint64_t tile, int lane) const { if (lane == 0) tile_count[tile] = st.n; }
+	/* called by all lanes under uniform control flow: compact the valid lanes behind the running count */
+	__device__ __forceinline__ void emit(State &st, bool valid, const DevParams &, const Key<W> &key, uint64_t, const Occurrence &o,
 	                                     uint64_t, uint32_t, unsigned &, bool &) const {
-		const unsigned long long mask = __ballot(1);
+		const unsigned long long mask = __ballot(valid);
 		const int lane = (int)(threadIdx.x & 63);
-		const int leader = __builtin_ctzll(mask);
-		uint32_t old = 0;
-		if (lane == leader) { old = *st.wcount; *st.wcount = old + (uint32_t)__builtin_popcountll(mask); }
-		old = __shfl(old, leader, 64);
-		const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
-		Record<W> r;
+		if (valid) {
+			const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
+			Record<W> r;
 #pragma unroll
-		for (int i = 0; i < W; i++) r.key[i] = key.w[i];
-		r.w = o.forward ? o.w : -o.w;
-		r.pkt = EXT ? o.pkt : (uint32_t)o.ordinal;
-		records[st.base + old + rank] = r;
+			for (int i = 0; i < W; i++) r.key[i] = key.w[i];
+			r.w = o.forward ? o.w : -o.w;
+			r.pkt = EXT ? o.pkt : (uint32_t)o.ordinal;
+			records[st.base + st.n + rank] = r;
+		}
+		st.n += (uint32_t)__builtin_popcountll(mask);
 	}
 };
 template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const LinearOp<W, EXT> &) { return false; }
