@@ -509,6 +509,7 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
 	auto kern = partition_kernel<W, 1>;
 	const size_t smem = partition_smem_bytes<W>(h->bits1);
+	if (getenv("KMR_DEBUG")) fprintf(stderr, "partition_level1 W=%d bits1=%d smem=%zu max=%zu grid=%d n_ext=%llu\n", W, h->bits1, smem, partition_smem_bytes<W>(max_part_bits(W)), grid, (unsigned long long)n_ext);
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)partition_smem_bytes<W>(max_part_bits(W))));
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(PART_THREADS), smem, h->stream, S, pool_view(h, h->l1), h->work_counter, h->bits1, 0);
 	HIPCHK(h, hipGetLastError());
@@ -560,7 +561,7 @@ int add_reads_partition(kmr_handle *h, const ReadsView &rv, uint64_t total_bases
 }
 
 /* chunk CSR of a pool: list_start[nl+1] (device) and list_chunks[n_chunks] (device) */
-int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, uint32_t **list_chunks, uint32_t *n_chunks_out) {
+int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, uint64_t **list_chunks, uint32_t *n_chunks_out) {
 	unsigned int used = 0;
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	HIPCHK(h, hipMemcpy(&used, p.head, 4, hipMemcpyDeviceToHost));
@@ -568,11 +569,11 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, ui
 	uint32_t *cnt;
 	HIPCHK(h, hipMalloc((void **)&cnt, 4 * nl)); HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
 	HIPCHK(h, hipMalloc((void **)list_start, 8 * (nl + 1)));
-	HIPCHK(h, hipMalloc((void **)list_chunks, 4ull * std::max<unsigned>(used, 1)));
+	HIPCHK(h, hipMalloc((void **)list_chunks, 8ull * std::max<unsigned>(used, 1)));
 	if (used) hipLaunchKernelGGL(chunk_hist_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, used, cnt);
 	int rc = exclusive_scan(h, cnt, nl, *list_start); if (rc) return rc;
 	HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
-	if (used) hipLaunchKernelGGL(chunk_scatter_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, used, *list_start, cnt, *list_chunks);
+	if (used) hipLaunchKernelGGL(chunk_scatter_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, p.chunk_count, used, *list_start, cnt, *list_chunks);
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(cnt);
@@ -592,7 +593,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
 	/* level-1 CSR and level-2 work items */
 	const uint64_t nl1 = 1ull << h->bits1;
-	uint64_t *ls1 = nullptr; uint32_t *lc1 = nullptr; uint32_t nch1 = 0;
+	uint64_t *ls1 = nullptr; uint64_t *lc1 = nullptr; uint32_t nch1 = 0;
 	rc = build_csr(h, h->l1, nl1, &ls1, &lc1, &nch1); if (rc) return rc;
 	std::vector<uint64_t> hs(nl1 + 1);
 	HIPCHK(h, hipMemcpy(hs.data(), ls1, 8 * (nl1 + 1), hipMemcpyDeviceToHost));
@@ -622,7 +623,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	}
 	hipFree(ls1); hipFree(lc1);
 	/* level-2 CSR, then count every final list */
-	uint64_t *ls2 = nullptr; uint32_t *lc2 = nullptr; uint32_t nch2 = 0;
+	uint64_t *ls2 = nullptr; uint64_t *lc2 = nullptr; uint32_t nch2 = 0;
 	rc = build_csr(h, h->l2, nl2, &ls2, &lc2, &nch2); if (rc) return rc;
 	const uint32_t vw = 3;
 	const uint64_t wcap = (f.has_singletons ? G / 2 : G) + 16, scap = keepSing ? G + 16 : 16;

@@ -32,9 +32,11 @@ namespace kmr {
 
 static const int CH = 64;                    /* records per chunk */
 static const uint32_t NO_CHUNK = 0xffffffffu;
-static const int PART_THREADS = 256;
-static const int PART_RPT = 8;               /* records per thread per batch */
-static const int PART_BATCH = PART_THREADS * PART_RPT;
+static const int PART_THREADS = 512;
+/* records per thread per batch: the LDS batch buffer is PART_THREADS * rpt records */
+template <int W> __host__ __device__ constexpr int part_rpt() { return W == 1 ? 8 : 4; }
+#define PART_RPT (part_rpt<W>())
+#define PART_BATCH (PART_THREADS * PART_RPT)
 enum { ERR_POOL_FULL = 8, ERR_ENTRIES_FULL = 16 };
 
 struct PoolView {
@@ -111,7 +113,7 @@ template <int W> struct PartSource {
 	uint32_t ext_stride;           /* ext_start index = extent * ext_stride (64 reads per tile)   */
 	/* LEVEL 2: work items over the chunk CSR of the level-1 pool */
 	PoolView src;
-	const uint32_t *list_chunks;   /* chunk ids grouped by list */
+	const uint64_t *list_chunks;   /* (records << 32 | chunk id), grouped by list */
 	const uint64_t *item_begin;    /* per work item: range in list_chunks ... */
 	const uint64_t *item_end;
 	const uint32_t *item_list;     /* ... and the level-1 list it belongs to */
@@ -309,8 +311,9 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 					const uint64_t ci = cb + (uint64_t)i * (PART_THREADS / CH) + (t >> 6);
 					pid[i] = NO_CHUNK;
 					if (ci < c1) {
-						const uint32_t c = S.list_chunks[ci];
-						if ((uint32_t)(t & 63) < S.src.chunk_count[c]) {
+						const uint64_t d = S.list_chunks[ci];
+						const uint32_t c = (uint32_t)d;
+						if ((uint32_t)(t & 63) < (uint32_t)(d >> 32)) {
 							r[i] = ((const Rec *)(S.src.base + (size_t)c * CH * sizeof(Rec)))[t & 63];
 							pid[i] = LOG2P ? (uint32_t)(part_hash<W>(r[i].key) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u;
 						}
@@ -335,11 +338,12 @@ __global__ void chunk_hist_kernel(const uint32_t *chunk_list, uint32_t n_chunks,
 	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x)
 		{ const uint32_t l = chunk_list[c]; if (l != NO_CHUNK) atomicAdd(&list_nchunks[l], 1u); }
 }
-__global__ void chunk_scatter_kernel(const uint32_t *chunk_list, uint32_t n_chunks, const uint64_t *list_start, uint32_t *cursor, uint32_t *list_chunks) {
+__global__ void chunk_scatter_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, const uint64_t *list_start,
+                                     uint32_t *cursor, uint64_t *list_chunks) {
 	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t l = chunk_list[c];
 		if (l == NO_CHUNK) continue;
-		list_chunks[list_start[l] + atomicAdd(&cursor[l], 1u)] = (uint32_t)c;
+		list_chunks[list_start[l] + atomicAdd(&cursor[l], 1u)] = ((uint64_t)chunk_count[c] << 32) | c;
 	}
 }
 
@@ -363,7 +367,7 @@ __host__ __device__ constexpr size_t count_smem_bytes() { return (size_t)(1 << L
  * and done in sub-passes (a tiny LDS stack), so any input is handled. */
 template <int W, bool EXT, int LOG2S>
 __global__ __launch_bounds__(COUNT_THREADS)
-void count_kernel(PoolView pool, const uint64_t *list_start, const uint32_t *list_chunks, uint64_t n_lists,
+void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists,
                   CountOut out, FinalizeParams f, unsigned int *work_counter) {
 	constexpr int S = 1 << LOG2S;
 	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
@@ -398,11 +402,25 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint32_t *lis
 			for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; }
 			__syncthreads();
 			const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
-			/* insert: wave w takes chunk (c0 + 4*i + w), lane = record */
-			for (uint64_t cb = c0 + (t >> 6); cb < c1 && !s_overflow; cb += COUNT_THREADS / CH) {
-				const uint32_t c = list_chunks[cb];
-				if ((uint32_t)(t & 63) >= pool.chunk_count[c]) continue;
-				const Rec r = ((const Rec *)(pool.base + (size_t)c * CH * sizeof(Rec)))[t & 63];
+			/* insert: wave w takes chunks c0 + w, + waves, ...; lane = record; UNR chunks are loaded before any is
+			 * inserted so several HBM reads are in flight per wave */
+			constexpr int UNR = 4;
+			constexpr int NWAVE = COUNT_THREADS / CH;
+			for (uint64_t cb = c0 + (t >> 6); cb < c1 && !s_overflow; cb += (uint64_t)NWAVE * UNR) {
+				Rec rr[UNR]; bool ok[UNR];
+#pragma unroll
+				for (int u = 0; u < UNR; u++) {
+					const uint64_t ci = cb + (uint64_t)u * NWAVE;
+					ok[u] = false;
+					if (ci < c1) {
+						const uint64_t d = list_chunks[ci];
+						if ((uint32_t)(t & 63) < (uint32_t)(d >> 32)) { rr[u] = ((const Rec *)(pool.base + (size_t)(uint32_t)d * CH * sizeof(Rec)))[t & 63]; ok[u] = true; }
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < UNR; u++) {
+				if (!ok[u]) continue;
+				const Rec r = rr[u];
 				const uint64_t h = part_hash<W>(r.key);
 				if (((uint32_t)h & subMask) != val) continue;
 				uint32_t s = (uint32_t)(h >> 20) & (S - 1);
@@ -445,6 +463,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint32_t *lis
 				atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(fwd ? 1 : 0) << 32));
 				atomicAdd(&twsum[s], (double)wa);
 				atomicMin(&tfirst[s], ((unsigned long long)r.pkt << 1) | (fwd ? 1ull : 0ull));
+				}
 			}
 			__syncthreads();
 			if (s_overflow) {       /* split this sub-pass in two by one more hash bit */
