@@ -326,10 +326,10 @@ template <int W, bool EXT> int finalize_t(kmr_handle *h, uint32_t min_depth) {
 	hipLaunchKernelGGL((scatter_kernel<W, EXT>), dim3(g), dim3(256), 0, h->stream, t, f, wm.start, wc, wm.keys, wm.vals, sm.start, sc, sm.keys, sm.sweight, sm.spkt);
 	HIPCHK(h, hipGetLastError());
 	SortView<W> sv; sv.keys = wm.keys; sv.vals = wm.vals; sv.b8 = nullptr; sv.pkt = nullptr; sv.vw = vw;
-	hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(wm.nb, 64)), dim3(64), 0, h->stream, sv, wm.start, wm.nb);
+	hipLaunchKernelGGL((sort_buckets_kernel<W, EXT ? 15 : 3>), dim3(grid_for(wm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, wm.start, wm.nb);
 	if (sm.n) {
 		SortView<W> ss; ss.keys = sm.keys; ss.vals = nullptr; ss.b8 = sm.sweight; ss.pkt = sm.spkt; ss.vw = 0;
-		hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(sm.nb, 64)), dim3(64), 0, h->stream, ss, sm.start, sm.nb);
+		hipLaunchKernelGGL((sort_buckets_kernel<W, 0>), dim3(grid_for(sm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, ss, sm.start, sm.nb);
 	}
 	HIPCHK(h, hipGetLastError());
 	time_end(h, 1, ea, eb);
@@ -392,7 +392,9 @@ template <int W> int load_image_t(kmr_handle *h, DevMap &m, bool weakMap, const 
 	if (m.n) hipLaunchKernelGGL(image_unpack_kernel<W>, dim3(grid_for(m.n)), dim3(256), 0, h->stream, m.image, m.start, nb, h->kb, vbytes, m.keys, m.vals, vw, m.sweight, m.spkt, m.n);
 	/* restore() accepts unsorted buckets (setLastSorted); lookups here need them sorted */
 	SortView<W> sv; sv.keys = m.keys; sv.vals = m.vals; sv.b8 = m.sweight; sv.pkt = m.spkt; sv.vw = weakMap ? vw : 0;
-	hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(nb, 64)), dim3(64), 0, h->stream, sv, m.start, nb);
+	if (!weakMap) hipLaunchKernelGGL((sort_buckets_kernel<W, 0>), dim3(grid_for(nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, m.start, nb);
+	else if (h->ext) hipLaunchKernelGGL((sort_buckets_kernel<W, 15>), dim3(grid_for(nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, m.start, nb);
+	else hipLaunchKernelGGL((sort_buckets_kernel<W, 3>), dim3(grid_for(nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, m.start, nb);
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(m.image); m.image = nullptr; m.image_bytes = 0;    /* rebuilt (sorted) on demand */
@@ -436,7 +438,7 @@ int stage_reads(kmr_handle *h, const char *bases, const char *quals, const uint6
 
 /* ---------------------------------------------------------------------- */
 /* streaming build path (kmr_partition.hpp)                                  */
-const int COUNT_LOG2S = 11;                  /* 2048-slot LDS table per final list */
+const int COUNT_LOG2S = 10;                  /* 1024-slot LDS table per final list (expected ~350 distinct keys) */
 const uint64_t TARGET_LIST_RECORDS = 2048;   /* records per final list the partition bits aim for */
 const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
 const uint64_t SUB_BATCH_BASES = 1ull << 28;
@@ -581,7 +583,7 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, ui
 	return 0;
 }
 
-int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wn, uint64_t sn, bool keepSing);
+int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing);
 
 template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	int rc = sync_state(h);
@@ -626,7 +628,8 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	uint64_t *ls2 = nullptr; uint64_t *lc2 = nullptr; uint32_t nch2 = 0;
 	rc = build_csr(h, h->l2, nl2, &ls2, &lc2, &nch2); if (rc) return rc;
 	const uint32_t vw = 3;
-	const uint64_t wcap = (f.has_singletons ? G / 2 : G) + 16, scap = keepSing ? G + 16 : 16;
+	const uint64_t slack = (uint64_t)part_grid(h) * 8 * 8192 + 16;     /* one partly used output slab per block */
+	const uint64_t wcap = (f.has_singletons ? G / 2 : G) + slack, scap = keepSing ? G + slack : 16;
 	if (!h->uw_keys || h->uw_cap < wcap) {
 		if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
 		HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, hipMalloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
@@ -647,7 +650,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		auto kern = count_kernel<W, false, COUNT_LOG2S>;
 		const size_t smem = count_smem_bytes<W, COUNT_LOG2S>();
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-		const int grid = (int)std::min<uint64_t>((uint64_t)part_grid(h), nl2);
+		const int grid = (int)std::min<uint64_t>((uint64_t)part_grid(h) * (getenv("KMR_COUNT_GRIDX") ? atoi(getenv("KMR_COUNT_GRIDX")) : 2), nl2);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l2), ls2, lc2, nl2, out, f, h->work_counter);
 		HIPCHK(h, hipGetLastError());
 	}
@@ -657,7 +660,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	hipFree(ls2); hipFree(lc2); hipFree(fc); hipFree(cursors);
 	h->stats.unique_kmers = c.unique;
 	h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
-	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], keepSing);
+	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing);
 	hipFree(wc); hipFree(sc);
 	if (rc) return rc;
 	time_end(h, 1, ea, eb);
@@ -668,7 +671,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 }
 
 /* unsorted kept entries (h->uw_*, h->us_*) + per-bucket counts -> bucketed sorted maps */
-template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wn, uint64_t sn, bool keepSing) {
+template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing) {
 	const uint32_t vw = 3;
 	DevMap &wm = h->weak, &sm = h->sing;
 	free_map(wm); free_map(sm);
@@ -680,24 +683,24 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 	HIPCHK(h, hipMalloc((void **)&wm.keys, std::max<uint64_t>(8, 8ull * W * wm.n))); HIPCHK(h, hipMalloc((void **)&wm.vals, std::max<uint64_t>(8, 4ull * vw * wm.n)));
 	HIPCHK(h, hipMalloc((void **)&sm.keys, std::max<uint64_t>(8, 8ull * W * sm.n))); HIPCHK(h, hipMalloc((void **)&sm.sweight, std::max<uint64_t>(8, sm.n)));
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * sm.nb, h->stream));
-	if (wm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wm.n)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
-	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wm.n, vw, h->kb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
-	if (sm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(sm.n)), dim3(256), 0, h->stream, (const uint64_t *)h->us_keys, (const uint32_t *)nullptr,
-	                            (const uint8_t *)h->us_b8, (const uint32_t *)nullptr, sm.n, 0u, h->kb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, (uint32_t *)nullptr);
+	if (wm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
+	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->kb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
+	if (sm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(sslots)), dim3(256), 0, h->stream, (const uint64_t *)h->us_keys, (const uint32_t *)nullptr,
+	                            (const uint8_t *)h->us_b8, (const uint32_t *)nullptr, sslots, 0u, h->kb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, (uint32_t *)nullptr);
 	HIPCHK(h, hipGetLastError());
 	SortView<W> sv; sv.keys = wm.keys; sv.vals = wm.vals; sv.b8 = nullptr; sv.pkt = nullptr; sv.vw = vw;
-	hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(wm.nb, 64)), dim3(64), 0, h->stream, sv, wm.start, wm.nb);
+	hipLaunchKernelGGL((sort_buckets_kernel<W, 3>), dim3(grid_for(wm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, wm.start, wm.nb);
 	if (sm.n) {
 		SortView<W> ss; ss.keys = sm.keys; ss.vals = nullptr; ss.b8 = sm.sweight; ss.pkt = nullptr; ss.vw = 0;
-		hipLaunchKernelGGL(sort_buckets_kernel<W>, dim3(grid_for(sm.nb, 64)), dim3(64), 0, h->stream, ss, sm.start, sm.nb);
+		hipLaunchKernelGGL((sort_buckets_kernel<W, 0>), dim3(grid_for(sm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, ss, sm.start, sm.nb);
 	}
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	return 0;
 }
-int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wn, uint64_t sn, bool keepSing) {
-	switch (h->W) { case 1: return finish_maps_t<1>(h, wc, sc, wn, sn, keepSing); case 2: return finish_maps_t<2>(h, wc, sc, wn, sn, keepSing);
-	case 3: return finish_maps_t<3>(h, wc, sc, wn, sn, keepSing); default: return finish_maps_t<4>(h, wc, sc, wn, sn, keepSing); }
+int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing) {
+	switch (h->W) { case 1: return finish_maps_t<1>(h, wc, sc, wslots, sslots, wn, sn, keepSing); case 2: return finish_maps_t<2>(h, wc, sc, wslots, sslots, wn, sn, keepSing);
+	case 3: return finish_maps_t<3>(h, wc, sc, wslots, sslots, wn, sn, keepSing); default: return finish_maps_t<4>(h, wc, sc, wslots, sslots, wn, sn, keepSing); }
 }
 int finalize_partition(kmr_handle *h, uint32_t min_depth) {
 	switch (h->W) { case 1: return finalize_partition_t<1>(h, min_depth); case 2: return finalize_partition_t<2>(h, min_depth);

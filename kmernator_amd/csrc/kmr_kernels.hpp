@@ -684,15 +684,46 @@ template <int W> struct SortView {
 		if (pkt) { uint32_t t = pkt[a]; pkt[a] = pkt[b]; pkt[b] = t; }
 	}
 };
-template <int W>
-__global__ void sort_buckets_kernel(SortView<W> v, const uint64_t *start, uint64_t nb) {
-	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+/* One wavefront per bucket.  Up to 64 entries (the normal case: kmers-per-bucket is 32): every lane loads one
+ * entry, its rank is the number of smaller keys in the bucket (keys broadcast lane by lane), and it stores the
+ * entry at that rank -- all loads happen before any store, so this is in place.  Larger buckets: lane 0 heap-sorts. */
+template <int W, int VW>
+__global__ __launch_bounds__(256)
+void sort_buckets_kernel(SortView<W> v, const uint64_t *start, uint64_t nb) {
+	const int lane = threadIdx.x & 63;
+	const uint64_t wavesPerGrid = (uint64_t)gridDim.x * (blockDim.x >> 6);
+	for (uint64_t b = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < nb; b += wavesPerGrid) {
 		const uint64_t lo = start[b], n = start[b + 1] - lo;
 		if (n < 2) continue;
 		if (n <= 64) {
-			for (uint64_t i = 1; i < n; i++)
-				for (uint64_t j = i; j > 0 && key_lt<W>(v.key(lo + j), v.key(lo + j - 1)); j--) v.swap(lo + j, lo + j - 1);
-		} else {
+			const bool have = (uint64_t)lane < n;
+			Key<W> key;
+			uint32_t vals[VW > 0 ? VW : 1];
+			uint8_t b8 = 0; uint32_t pkt = 0;
+#pragma unroll
+			for (int j = 0; j < W; j++) key.w[j] = have ? v.keys[(lo + lane) * W + j] : ~0ull;
+			if (have) {
+#pragma unroll
+				for (int j = 0; j < VW; j++) vals[j] = v.vals[(lo + lane) * VW + j];
+				if (v.b8) b8 = v.b8[lo + lane];
+				if (v.pkt) pkt = v.pkt[lo + lane];
+			}
+			uint32_t rank = 0;
+			for (uint32_t i = 0; i < (uint32_t)n; i++) {
+				Key<W> other;
+#pragma unroll
+				for (int j = 0; j < W; j++) other.w[j] = __shfl(key.w[j], (int)i, 64);
+				rank += key_lt<W>(other, key) ? 1u : 0u;
+			}
+			if (have) {
+#pragma unroll
+				for (int j = 0; j < W; j++) v.keys[(lo + rank) * W + j] = key.w[j];
+#pragma unroll
+				for (int j = 0; j < VW; j++) v.vals[(lo + rank) * VW + j] = vals[j];
+				if (v.b8) v.b8[lo + rank] = b8;
+				if (v.pkt) v.pkt[lo + rank] = pkt;
+			}
+		} else if (lane == 0) {
 			auto sift = [&](uint64_t root, uint64_t end) {
 				for (;;) {
 					uint64_t child = 2 * root + 1;

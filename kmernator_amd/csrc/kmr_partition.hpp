@@ -275,12 +275,14 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 
 	if (LEVEL == 1) {
 		/* extents are handed out dynamically so ragged tiles balance */
+		constexpr uint32_t EBATCH = 8;
 		for (;;) {
-			if (t == 0) s_item = atomicAdd(work_counter, 1u);
+			if (t == 0) s_item = atomicAdd(work_counter, EBATCH);
 			__syncthreads();
-			const uint64_t e = s_item;
+			const uint64_t efirst = s_item;
 			__syncthreads();
-			if (e >= S.n_ext) break;
+			if (efirst >= S.n_ext) break;
+			for (uint64_t e = efirst; e < efirst + EBATCH && e < S.n_ext; e++) {
 			uint64_t start, n;
 			if (S.ext_start) { start = S.ext_start[e * S.ext_stride]; n = S.ext_count[e]; }
 			else { start = e * S.ext_len; n = S.total - start < S.ext_len ? S.total - start : S.ext_len; }
@@ -292,6 +294,7 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 					if (idx < n) { r[i] = S.linear[start + idx]; pid[i] = LOG2P ? (uint32_t)(part_hash<W>(r[i].key) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u; }
 				}
 				scatter_batch(r, pid, 0);
+			}
 			}
 		}
 		flush_all(0);
@@ -380,17 +383,25 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
 	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns;
 	__shared__ unsigned long long s_wbase, s_sbase;
+	/* output space is taken from the global cursors one slab at a time (a per-list atomic on one word would
+	 * serialise ~10^6 lists); the unused tail of a slab is marked as holes (count 0 / weight 0) */
+	__shared__ unsigned long long s_wpos, s_wend, s_spos, s_send;
 	__shared__ uint32_t s_stackBits[40], s_stackVal[40];
 	const int t = threadIdx.x;
 	const uint32_t vw = EXT ? 15 : 3;
-	unsigned long long uniq = 0, single = 0;
+	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;   /* kept*: thread 0 only */
+	constexpr unsigned long long OSLAB = 8192;
+	if (t == 0) { s_wpos = s_wend = 0; s_spos = s_send = 0; }
+	__syncthreads();
 
+	constexpr uint32_t LBATCH = 16;       /* lists per grab: one word of device memory serves ~90 M atomics/s */
 	for (;;) {
-		if (t == 0) s_list = atomicAdd(work_counter, 1u);
+		if (t == 0) s_list = atomicAdd(work_counter, LBATCH);
 		__syncthreads();
-		const uint64_t l = s_list;
+		const uint64_t lfirst = s_list;
 		__syncthreads();
-		if (l >= n_lists) break;
+		if (lfirst >= n_lists) break;
+		for (uint64_t l = lfirst; l < lfirst + LBATCH && l < n_lists; l++) {
 		const uint64_t c0 = list_start[l], c1 = list_start[l + 1];
 		if (c0 == c1) continue;
 		if (t == 0) { s_sp = 1; s_stackBits[0] = 0; s_stackVal[0] = 0; }
@@ -495,10 +506,22 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 				}
 			}
 			__syncthreads();
+			if (s_nw && s_wpos + s_nw > s_wend) {          /* uniform: retire the rest of the slab, take a new one */
+				for (unsigned long long e = s_wpos + t; e < s_wend; e += COUNT_THREADS) out.wvals[e * vw] = 0;
+				__syncthreads();
+				if (t == 0) { const unsigned long long g = s_nw > OSLAB ? s_nw : OSLAB; s_wpos = atomicAdd(out.wcursor, g); s_wend = s_wpos + g; }
+				__syncthreads();
+			}
+			if (s_ns && s_spos + s_ns > s_send) {
+				for (unsigned long long e = s_spos + t; e < s_send; e += COUNT_THREADS) out.sweight[e] = 0;
+				__syncthreads();
+				if (t == 0) { const unsigned long long g = s_ns > OSLAB ? s_ns : OSLAB; s_spos = atomicAdd(out.scursor, g); s_send = s_spos + g; }
+				__syncthreads();
+			}
 			if (t == 0) {
-				s_wbase = s_nw ? atomicAdd(out.wcursor, (unsigned long long)s_nw) : 0;
-				s_sbase = s_ns ? atomicAdd(out.scursor, (unsigned long long)s_ns) : 0;
-				if (s_wbase + s_nw > out.wcap || s_sbase + s_ns > out.scap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); s_nw = 0xffffffffu; }
+				s_wbase = s_wpos; s_wpos += s_nw; keptW += s_nw;
+				s_sbase = s_spos; s_spos += s_ns; keptS += s_ns;
+				if (s_wend > out.wcap || s_send > out.scap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); s_nw = 0xffffffffu; }
 			}
 			__syncthreads();
 			if (s_nw != 0xffffffffu) {
@@ -535,9 +558,14 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 			}
 			__syncthreads();
 		}
+		}
 	}
+	__syncthreads();
+	for (unsigned long long e = s_wpos + t; e < s_wend; e += COUNT_THREADS) out.wvals[e * vw] = 0;
+	for (unsigned long long e = s_spos + t; e < s_send; e += COUNT_THREADS) out.sweight[e] = 0;
 	uniq = wave_sum(uniq); single = wave_sum(single);
 	if ((t & 63) == 0) { if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single); }
+	if (t == 0) { if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS); }
 }
 
 /* unsorted entries -> their bucket segments (then sort_buckets_kernel) */
@@ -546,6 +574,7 @@ __global__ void entry_scatter_kernel(const uint64_t *ukeys, const uint32_t *uval
                                      uint32_t vw, uint32_t kb, uint64_t nb, const uint64_t *start, uint32_t *cursor,
                                      uint64_t *keys, uint32_t *vals, uint8_t *b8, uint32_t *pkt) {
 	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		if (uvals ? uvals[e * vw] == 0 : ub8[e] == 0) continue;      /* hole left at the end of an output slab */
 		Key<W> key;
 #pragma unroll
 		for (int j = 0; j < W; j++) key.w[j] = ukeys[e * W + j];
