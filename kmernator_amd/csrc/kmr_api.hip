@@ -572,10 +572,11 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, ui
 	HIPCHK(h, hipMalloc((void **)&cnt, 4 * nl)); HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
 	HIPCHK(h, hipMalloc((void **)list_start, 8 * (nl + 1)));
 	HIPCHK(h, hipMalloc((void **)list_chunks, 8ull * std::max<unsigned>(used, 1)));
-	if (used) hipLaunchKernelGGL(chunk_hist_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, used, cnt);
+	const unsigned csr_grid = (unsigned)(((uint64_t)used + CSR_THREADS * CSR_ITEMS - 1) / (CSR_THREADS * CSR_ITEMS));
+	if (used) hipLaunchKernelGGL(chunk_hist_kernel, dim3(csr_grid), dim3(CSR_THREADS), 0, h->stream, p.chunk_list, used, cnt, (uint32_t)nl);
 	int rc = exclusive_scan(h, cnt, nl, *list_start); if (rc) return rc;
 	HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
-	if (used) hipLaunchKernelGGL(chunk_scatter_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, p.chunk_count, used, *list_start, cnt, *list_chunks);
+	if (used) hipLaunchKernelGGL(chunk_scatter_kernel, dim3(csr_grid), dim3(CSR_THREADS), 0, h->stream, p.chunk_list, p.chunk_count, used, *list_start, cnt, *list_chunks, (uint32_t)nl);
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(cnt);

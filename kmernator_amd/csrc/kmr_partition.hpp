@@ -128,8 +128,9 @@ static const int MAX_PART_BITS = 10;
 template <int W>
 __host__ __device__ inline size_t partition_smem_bytes(int bits) {
 	return (size_t)PART_BATCH * sizeof(Record<W>)                 /* sorted batch */
-	       + ((size_t)1 << bits) * 4 * sizeof(Record<W>)          /* staging lines (4 records) */
+	       + ((size_t)1 << bits) * 3 * sizeof(Record<W>)          /* up to 3 pending records per list */
 	       + ((size_t)1 << bits) * 4 * 5                          /* hist, pstart, cur, cnt, pend */
+	       + ((size_t)PART_BATCH / 4 + (((size_t)1 << bits) * 3) / 4 + 8) * 8   /* line tasks of one batch */
 	       + 64;
 }
 
@@ -142,14 +143,16 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 	typedef Record<W> Rec;
 	extern __shared__ __attribute__((aligned(16))) uint8_t psm[];
 	Rec *sorted = (Rec *)psm;
-	Rec *stage = sorted + PART_BATCH;
-	uint32_t *hist = (uint32_t *)(stage + (size_t)P * G);
+	Rec *stage = sorted + PART_BATCH;                 /* pending record j of list p at stage[j * P + p] */
+	uint32_t *hist = (uint32_t *)(stage + (size_t)P * 3);
 	uint32_t *pstart = hist + P;
 	uint32_t *cur = pstart + P;
 	uint32_t *cnt = cur + P;
 	uint32_t *pend = cnt + P;
+	unsigned long long *tasks = (unsigned long long *)(pend + P);   /* 8-byte aligned: all sizes above are multiples of 8 */
 	__shared__ uint32_t s_item;
 	__shared__ uint32_t s_scan[PART_THREADS];
+	__shared__ uint32_t s_ntasks;
 	/* chunk allocator: one device atomic hands a block SLAB chunks; chunk ids are then taken by an LDS
 	 * counter through a small ring of slab bases (one word of device memory saturates at ~90 M atomics/s,
 	 * which a per-chunk atomic from every block would hit) */
@@ -159,7 +162,7 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 	const int t = threadIdx.x;
 
 	for (int p = t; p < P; p += PART_THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; pend[p] = 0; }
-	if (t == 0) { s_alloc = 0; s_filled = 0; }
+	if (t == 0) { s_alloc = 0; s_filled = 0; s_ntasks = 0; }
 	__syncthreads();
 
 	/* called by thread 0 between batches: keep a few times the average need of one batch (PART_BATCH/CH chunks)
@@ -183,26 +186,45 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 
 	auto chunk_ptr = [&](uint32_t c) -> Rec * { return (Rec *)(out.base + (size_t)c * CH * sizeof(Rec)); };
 
-	/* append 'n' records src[0..n) to list p (list id 'lid' in the output pool) */
-	auto append_run = [&](int p, uint32_t lid, const Rec *src, uint32_t n) {
-		uint32_t c = cur[p], filled = cnt[p], pe = pend[p];
-		Rec *line = stage + (size_t)p * G;
-		for (uint32_t i = 0; i < n; i++) {
-			line[pe++] = src[i];
-			if (pe == G) {
-				if (c == NO_CHUNK) {
-					c = alloc_chunk();
-					if (c == NO_CHUNK) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); pe = 0; continue; }
-					out.chunk_list[c] = lid; filled = 0;
-				}
-				Rec *dst = chunk_ptr(c) + filled;
-#pragma unroll
-				for (int g = 0; g < G; g++) dst[g] = line[g];
-				filled += G; pe = 0;
-				if (filled == CH) { out.chunk_count[c] = CH; c = NO_CHUNK; filled = 0; }
+	/* Hand a run of n new records of list p (sorted[s0..s0+n)) out.  Book-keeping only: every full 4-record
+	 * line (pending records first, then the run) becomes a task {chunk, line slot, list, line index}; the
+	 * stores themselves are done by four lanes per line in flush_tasks so each line is one 64-byte request. */
+	auto plan_run = [&](int p, uint32_t lid, uint32_t n) {
+		uint32_t c = cur[p], filled = cnt[p];
+		const uint32_t pe = pend[p];
+		const uint32_t lines = (pe + n) >> 2;
+		for (uint32_t l = 0; l < lines; l++) {
+			if (c == NO_CHUNK) {
+				c = alloc_chunk();
+				if (c == NO_CHUNK) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); break; }
+				out.chunk_list[c] = lid; filled = 0;
 			}
+			const uint32_t q = atomicAdd(&s_ntasks, 1u);
+			tasks[q] = ((unsigned long long)c << 32) | ((unsigned long long)(filled >> 2) << 24) | ((unsigned long long)l << 12) | (unsigned long long)p;
+			filled += 4;
+			if (filled == CH) { out.chunk_count[c] = CH; c = NO_CHUNK; filled = 0; }
 		}
-		cur[p] = c; cnt[p] = filled; pend[p] = pe;
+		cur[p] = c; cnt[p] = filled;
+	};
+	auto flush_tasks = [&]() {
+		const uint32_t nt = s_ntasks;
+		const int g = t & 3;
+		for (uint32_t q = t >> 2; q < nt; q += PART_THREADS / 4) {
+			const unsigned long long tk = tasks[q];
+			const uint32_t c = (uint32_t)(tk >> 32), slot = (uint32_t)(tk >> 24) & 0xff, l = (uint32_t)(tk >> 12) & 0xfff, p = (uint32_t)tk & 0xfff;
+			const uint32_t pe = pend[p];
+			const uint32_t r = 4 * l + g;                       /* record index in (pending ++ run) */
+			const Rec rec = r < pe ? stage[(size_t)r * P + p] : sorted[pstart[p] + r - pe];
+			chunk_ptr(c)[slot * 4 + g] = rec;
+		}
+	};
+	/* after the flush: what is left of (pending ++ run) becomes the new pending set */
+	auto keep_rest = [&](int p, uint32_t n) {
+		const uint32_t pe = pend[p];
+		const uint32_t lines = (pe + n) >> 2, rem = (pe + n) & 3;
+		if (lines) for (uint32_t j = 0; j < rem; j++) stage[(size_t)j * P + p] = sorted[pstart[p] + 4 * lines + j - pe];
+		else for (uint32_t j = pe; j < rem; j++) stage[(size_t)j * P + p] = sorted[pstart[p] + j - pe];
+		pend[p] = rem;
 	};
 	auto flush_all = [&](uint32_t lid_base) {
 		if (t == 0) top_up();
@@ -217,8 +239,7 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 				}
 				if (c != NO_CHUNK) {
 					Rec *dst = chunk_ptr(c) + filled;
-					Rec *line = stage + (size_t)p * G;
-					for (uint32_t g = 0; g < pe; g++) dst[g] = line[g];
+					for (uint32_t g = 0; g < pe; g++) dst[g] = stage[(size_t)g * P + p];
 					filled += pe;
 				}
 			}
@@ -263,9 +284,19 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 #pragma unroll
 		for (int i = 0; i < PART_RPT; i++) if (pid[i] != NO_CHUNK) { uint32_t pos = atomicAdd(&hist[pid[i]], 1u); sorted[pos] = r[i]; }
 		__syncthreads();
-		if (DBG != 1) for (int p = t; p < P; p += PART_THREADS) {
-			const uint32_t n = hist[p] - pstart[p];
-			if (n) append_run(p, lid_base + p, sorted + pstart[p], n);
+		if (DBG != 1) {
+			for (int p = t; p < P; p += PART_THREADS) {
+				const uint32_t n = hist[p] - pstart[p];
+				if (n) plan_run(p, lid_base + p, n);
+			}
+			__syncthreads();
+			flush_tasks();
+			__syncthreads();
+			for (int p = t; p < P; p += PART_THREADS) {
+				const uint32_t n = hist[p] - pstart[p];
+				if (n) keep_rest(p, n);
+			}
+			if (t == 0) s_ntasks = 0;
 		}
 		__syncthreads();
 	};
@@ -336,17 +367,52 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 	}
 }
 
-/* chunk CSR: chunks grouped by list */
-__global__ void chunk_hist_kernel(const uint32_t *chunk_list, uint32_t n_chunks, uint32_t *list_nchunks) {
-	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x)
-		{ const uint32_t l = chunk_list[c]; if (l != NO_CHUNK) atomicAdd(&list_nchunks[l], 1u); }
-}
-__global__ void chunk_scatter_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, const uint64_t *list_start,
-                                     uint32_t *cursor, uint64_t *list_chunks) {
-	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
+/* chunk CSR: chunks grouped by list.  With few lists (level 1: <= 1024) millions of chunks would hammer the same
+ * few counters, so a block first ranks its chunks per list in LDS and touches the device counters once per
+ * (block, list). */
+static const int CSR_LDS_LISTS = 4096;
+static const int CSR_THREADS = 256, CSR_ITEMS = 16;       /* chunks per thread */
+__global__ __launch_bounds__(CSR_THREADS)
+void chunk_hist_kernel(const uint32_t *chunk_list, uint32_t n_chunks, uint32_t *list_nchunks, uint32_t nl) {
+	__shared__ uint32_t lh[CSR_LDS_LISTS];
+	const bool priv = nl <= (uint32_t)CSR_LDS_LISTS;
+	if (priv) { for (uint32_t i = threadIdx.x; i < nl; i += CSR_THREADS) lh[i] = 0; __syncthreads(); }
+	const uint64_t base = (uint64_t)blockIdx.x * CSR_THREADS * CSR_ITEMS;
+	for (int j = 0; j < CSR_ITEMS; j++) {
+		const uint64_t c = base + (uint64_t)j * CSR_THREADS + threadIdx.x;
+		if (c >= n_chunks) break;
 		const uint32_t l = chunk_list[c];
 		if (l == NO_CHUNK) continue;
-		list_chunks[list_start[l] + atomicAdd(&cursor[l], 1u)] = ((uint64_t)chunk_count[c] << 32) | c;
+		if (priv) atomicAdd(&lh[l], 1u); else atomicAdd(&list_nchunks[l], 1u);
+	}
+	if (priv) { __syncthreads(); for (uint32_t i = threadIdx.x; i < nl; i += CSR_THREADS) if (lh[i]) atomicAdd(&list_nchunks[i], lh[i]); }
+}
+__global__ __launch_bounds__(CSR_THREADS)
+void chunk_scatter_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, const uint64_t *list_start,
+                          uint32_t *cursor, uint64_t *list_chunks, uint32_t nl) {
+	__shared__ uint32_t lh[CSR_LDS_LISTS];
+	const bool priv = nl <= (uint32_t)CSR_LDS_LISTS;
+	const uint64_t base = (uint64_t)blockIdx.x * CSR_THREADS * CSR_ITEMS;
+	uint32_t myl[CSR_ITEMS], myr[CSR_ITEMS];
+	if (priv) { for (uint32_t i = threadIdx.x; i < nl; i += CSR_THREADS) lh[i] = 0; __syncthreads(); }
+#pragma unroll
+	for (int j = 0; j < CSR_ITEMS; j++) {
+		const uint64_t c = base + (uint64_t)j * CSR_THREADS + threadIdx.x;
+		myl[j] = c < n_chunks ? chunk_list[c] : NO_CHUNK;
+		if (myl[j] != NO_CHUNK && priv) myr[j] = atomicAdd(&lh[myl[j]], 1u);      /* rank inside the block */
+	}
+	if (priv) {
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < nl; i += CSR_THREADS) { const uint32_t n = lh[i]; lh[i] = n ? atomicAdd(&cursor[i], n) : 0u; }   /* block's base in the list */
+		__syncthreads();
+	}
+#pragma unroll
+	for (int j = 0; j < CSR_ITEMS; j++) {
+		const uint32_t l = myl[j];
+		if (l == NO_CHUNK) continue;
+		const uint64_t c = base + (uint64_t)j * CSR_THREADS + threadIdx.x;
+		const uint32_t pos = priv ? lh[l] + myr[j] : atomicAdd(&cursor[l], 1u);
+		list_chunks[list_start[l] + pos] = ((uint64_t)chunk_count[c] << 32) | c;
 	}
 }
 
