@@ -530,7 +530,8 @@ template <int W> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll
 	const uint64_t n = rvAll.n_reads;
 	if (!h->l1.head) choose_bits1(h, total_bases);
 	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
-	const uint64_t chunk = std::max<uint64_t>(64, (SUB_BATCH_BASES / avg) & ~63ull);
+	const uint64_t sub_bases = getenv("KMR_SUB_BATCH_BASES") ? strtoull(getenv("KMR_SUB_BATCH_BASES"), nullptr, 10) : SUB_BATCH_BASES;
+	const uint64_t chunk = std::max<uint64_t>(64, (sub_bases / avg) & ~63ull);
 	for (uint64_t r = 0; r < n; r += chunk) {
 		const uint64_t m = std::min(chunk, n - r);
 		ReadsView rv = rvAll;

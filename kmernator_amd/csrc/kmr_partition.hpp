@@ -470,6 +470,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 		for (uint64_t l = lfirst; l < lfirst + LBATCH && l < n_lists; l++) {
 		const uint64_t c0 = list_start[l], c1 = list_start[l + 1];
 		if (c0 == c1) continue;
+		__syncthreads();       /* every thread has left the previous list's while (s_sp > 0) before s_sp is re-armed */
 		if (t == 0) { s_sp = 1; s_stackBits[0] = 0; s_stackVal[0] = 0; }
 		__syncthreads();
 		while (s_sp > 0) {

@@ -302,3 +302,76 @@ def test_many_distinct_keys_force_subpass_split():
     o, p = run_both(cfg, rb, min_depth=1, mode=2)
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
     assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+
+
+def test_build_modes_agree_at_scale():
+    """3M reads (360M k-mers, two sub-batches, ~2.6e5 final lists): the device-table path and the streaming
+    partition path are independent algorithms; their statistics and weak images must be byte-identical
+    (this caught a list hand-off race that only showed above ~1e8 k-mers)."""
+    n = 3000000
+    rb = synth_reads(n, read_len=150, genome_len=5 * n, seed=1)
+    res = []
+    for mode in MODES:
+        c = ka.default_config(31, estimated_raw_kmers=n * 120, build_mode=mode)
+        p = ka.KmerSpectrum(c)
+        add(p, rb)
+        p.finalize(2)
+        res.append((p.stats(), p.image(KMR_MAP_WEAK), p.histogram(1024)[0]))
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1])
+    st, _, hist = res[1]
+    # size-independent bookkeeping: every good occurrence is in exactly one entry
+    assert int(hist.sum()) == st["weak_entries"]
+    assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
+    assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
+
+
+def test_c2_full_size_properties():
+    """BASELINE.json configs[1] at full size (10M reads x 150 bp, k=31, 1.2e9 k-mers) through the device-pointer
+    entry point bench.py times: counts conserve the k-mers, the image is sorted and bucket-consistent (sampled),
+    lookups of k-mers taken from the reads return their image counts, and a second build is bit-identical."""
+    import torch
+    import bench
+    n = 10_000_000
+    dev = torch.device("cuda", 0)
+    bases, quals, offsets = bench.gen_reads(n, 5 * n, 1, 0, dev)
+    torch.cuda.synchronize()
+    c = ka.default_config(31, estimated_raw_kmers=n * 120, device=0)
+    p = ka.KmerSpectrum(c)
+    imgs = []
+    for rep in range(2):
+        p.reset()
+        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
+        p.finalize(2)
+        st = p.stats()
+        assert st["raw_kmers"] == n * 120 == st["raw_good_kmers"]
+        hist = p.histogram(4096)[0]
+        assert int(hist.sum()) == st["weak_entries"]
+        assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
+        assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
+        imgs.append(p.image(KMR_MAP_WEAK))
+    assert np.array_equal(imgs[0], imgs[1])          # deterministic, including the f32 weight sums
+    img = imgs[0]
+    nb = int(np.frombuffer(img[:8].tobytes(), dtype=np.uint64)[0])
+    assert nb == 1 << 21                              # reference sizing for 1.2e9 raw k-mers (SURVEY 8a8)
+    offs = np.frombuffer(img[16:16 + 8 * nb].tobytes(), dtype=np.uint64)
+    lib = ka.load()
+    rng = np.random.default_rng(5)
+    checked = 0
+    for b in rng.integers(0, nb, 300):
+        o = int(offs[b])
+        cnt = int(np.frombuffer(img[o:o + 4].tobytes(), dtype=np.uint32)[0])
+        keys = img[o + 4:o + 4 + 8 * cnt].reshape(cnt, 8)
+        vals = img[o + 4 + 8 * cnt:o + 4 + 20 * cnt].reshape(cnt, 12)
+        prev = None
+        for kk in keys:
+            kb_ = kk.tobytes()
+            assert lib.kmr_hash(kb_, 8) & (nb - 1) == b
+            assert prev is None or prev < kb_
+            prev = kb_
+        if cnt:
+            counts = np.ascontiguousarray(vals[:, :2]).view(np.uint16).reshape(-1)
+            assert np.array_equal(p.getCount(keys), counts.astype(np.uint32))
+            assert counts.min() >= 2
+            checked += cnt
+    assert checked > 1000

@@ -6,7 +6,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_
 grep metric $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log | python3 -c "
 import sys,json
 try:
-    d=json.loads(sys.stdin.read()); print('%.2f G kmers/s  %.1f ms/step  build %.1f ms x%d  finalize %.1f ms' % (d['value']/1e9, d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['launches_per_step'], d['roofline']['finalize_ms_per_step']))
+    d=json.loads(sys.stdin.read()); print('%.2f G kmers/s  %.1f ms/step  build %.1f ms x%d  finalize %.1f ms' % (d['value']/1e9, d['ms_per_step'], d['roofline']['build_ms_per_step'], d['roofline']['build_launch_groups_per_step'], d['roofline']['finalize_ms_per_step']))
 except Exception as e: print('no json', e)"
 python3 -c "
 import csv,glob
