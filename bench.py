@@ -209,6 +209,15 @@ def main():
                          "build_ms_per_step": build_ms / max(1, args.steps), "build_launch_groups_per_step": build_launches // max(1, args.steps),
                          "finalize_ms_per_step": fin_ms / max(1, args.steps)},
         }
+        # HBM bytes from the PMC counters: bench.py cannot run rocprofv3 on itself, so the committed summary of
+        # the same command (profiles/r01_pmc_traffic.json, tools/pmc.sh) is quoted when it describes this workload
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if args.build_mode != 1 and n_reads == 10_000_000 and world == 1:
+                out["roofline"]["traffic"] = tj["hot_path_total_GB_per_step"] * 1e9
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (bytes per step, FETCH_SIZE x2 corrected)"
+        except Exception:
+            pass
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(bases, quals, min(args.cpu_sample, n_reads))
         print(json.dumps(out))

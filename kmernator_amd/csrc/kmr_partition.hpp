@@ -290,9 +290,9 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 				if (n) plan_run(p, lid_base + p, n);
 			}
 			__syncthreads();
-			flush_tasks();
+			if (DBG != 3) flush_tasks();
 			__syncthreads();
-			for (int p = t; p < P; p += PART_THREADS) {
+			if (DBG != 3 && DBG != 4) for (int p = t; p < P; p += PART_THREADS) {
 				const uint32_t n = hist[p] - pstart[p];
 				if (n) keep_rest(p, n);
 			}
@@ -301,35 +301,74 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 		__syncthreads();
 	};
 
-	Rec r[PART_RPT];
-	uint32_t pid[PART_RPT];
+	/* the loads of batch i+1 are issued before batch i is sorted and flushed (register double buffering), so
+	 * the HBM read latency overlaps the LDS work of the current batch */
+	Rec r[PART_RPT], rn[PART_RPT];
+	uint32_t pid[PART_RPT], pidn[PART_RPT];
+	auto pid_of = [&](const Rec &x) -> uint32_t { return LOG2P ? (uint32_t)(part_hash<W>(x.key) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u; };
 
 	if (LEVEL == 1) {
-		/* extents are handed out dynamically so ragged tiles balance */
-		constexpr uint32_t EBATCH = 8;
+		/* extents are handed out dynamically (EBATCH at a time) so ragged tiles balance; their batches are
+		 * listed in LDS first so the prefetch can run across extent boundaries */
+		constexpr uint32_t EBATCH = 8, MAXB = 64;
+		__shared__ unsigned long long s_bstart[MAXB];
+		__shared__ uint32_t s_bcount[MAXB];
+		__shared__ uint32_t s_nb;
+		auto load1 = [&](uint32_t bi, Rec (&rr)[PART_RPT], uint32_t (&pp)[PART_RPT]) {
+			const uint64_t start = s_bstart[bi]; const uint32_t n = s_bcount[bi];
+#pragma unroll
+			for (int i = 0; i < PART_RPT; i++) {
+				const uint32_t idx = (uint32_t)i * PART_THREADS + t;
+				pp[i] = NO_CHUNK;
+				if (idx < n) { rr[i] = S.linear[start + idx]; pp[i] = pid_of(rr[i]); }
+			}
+		};
 		for (;;) {
 			if (t == 0) s_item = atomicAdd(work_counter, EBATCH);
 			__syncthreads();
 			const uint64_t efirst = s_item;
-			__syncthreads();
 			if (efirst >= S.n_ext) break;
-			for (uint64_t e = efirst; e < efirst + EBATCH && e < S.n_ext; e++) {
-			uint64_t start, n;
-			if (S.ext_start) { start = S.ext_start[e * S.ext_stride]; n = S.ext_count[e]; }
-			else { start = e * S.ext_len; n = S.total - start < S.ext_len ? S.total - start : S.ext_len; }
-			for (uint64_t b = 0; b < n; b += PART_BATCH) {
-#pragma unroll
-				for (int i = 0; i < PART_RPT; i++) {
-					const uint64_t idx = b + (uint64_t)i * PART_THREADS + t;
-					pid[i] = NO_CHUNK;
-					if (idx < n) { r[i] = S.linear[start + idx]; pid[i] = LOG2P ? (uint32_t)(part_hash<W>(r[i].key) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u; }
+			if (t == 0) {
+				uint32_t nb = 0;
+				for (uint64_t e = efirst; e < efirst + EBATCH && e < S.n_ext; e++) {
+					uint64_t start, n;
+					if (S.ext_start) { start = S.ext_start[e * S.ext_stride]; n = S.ext_count[e]; }
+					else { start = e * S.ext_len; n = S.total - start < S.ext_len ? S.total - start : S.ext_len; }
+					for (uint64_t b = 0; b < n && nb < MAXB; b += PART_BATCH) { s_bstart[nb] = start + b; s_bcount[nb] = (uint32_t)(n - b < (uint64_t)PART_BATCH ? n - b : (uint64_t)PART_BATCH); nb++; }
 				}
+				s_nb = nb;
+			}
+			__syncthreads();
+			const uint32_t nb = s_nb;
+			if (nb) load1(0, r, pid);
+			for (uint32_t bi = 0; bi < nb; bi++) {
+				if (bi + 1 < nb) load1(bi + 1, rn, pidn);
 				scatter_batch(r, pid, 0);
+				if (bi + 1 < nb) {
+#pragma unroll
+					for (int i = 0; i < PART_RPT; i++) { r[i] = rn[i]; pid[i] = pidn[i]; }
+				}
 			}
-			}
+			__syncthreads();
 		}
 		flush_all(0);
 	} else {
+		auto load2 = [&](uint64_t cb, uint64_t c1, Rec (&rr)[PART_RPT], uint32_t (&pp)[PART_RPT]) {
+			/* a batch = PART_BATCH/CH chunks; wave w reads chunk (i * waves + w), lane = record */
+#pragma unroll
+			for (int i = 0; i < PART_RPT; i++) {
+				const uint64_t ci = cb + (uint64_t)i * (PART_THREADS / CH) + (t >> 6);
+				pp[i] = NO_CHUNK;
+				if (ci < c1) {
+					const uint64_t d = S.list_chunks[ci];
+					const uint32_t c = (uint32_t)d;
+					if ((uint32_t)(t & 63) < (uint32_t)(d >> 32)) {
+						rr[i] = ((const Rec *)(S.src.base + (size_t)c * CH * sizeof(Rec)))[t & 63];
+						pp[i] = pid_of(rr[i]);
+					}
+				}
+			}
+		};
 		for (;;) {
 			if (t == 0) s_item = atomicAdd(work_counter, 1u);
 			__syncthreads();
@@ -338,22 +377,15 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 			if (it >= S.n_items) break;
 			const uint64_t c0 = S.item_begin[it], c1 = S.item_end[it];
 			const uint32_t lid_base = S.item_list[it] << LOG2P;
-			/* a batch = 32 chunks; wave w of the block reads chunk (i*4 + w), lane = record */
-			for (uint64_t cb = c0; cb < c1; cb += PART_BATCH / CH) {
-#pragma unroll
-				for (int i = 0; i < PART_RPT; i++) {
-					const uint64_t ci = cb + (uint64_t)i * (PART_THREADS / CH) + (t >> 6);
-					pid[i] = NO_CHUNK;
-					if (ci < c1) {
-						const uint64_t d = S.list_chunks[ci];
-						const uint32_t c = (uint32_t)d;
-						if ((uint32_t)(t & 63) < (uint32_t)(d >> 32)) {
-							r[i] = ((const Rec *)(S.src.base + (size_t)c * CH * sizeof(Rec)))[t & 63];
-							pid[i] = LOG2P ? (uint32_t)(part_hash<W>(r[i].key) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u;
-						}
-					}
-				}
+			constexpr uint64_t STEP = PART_BATCH / CH;
+			if (c0 < c1) load2(c0, c1, r, pid);
+			for (uint64_t cb = c0; cb < c1; cb += STEP) {
+				if (cb + STEP < c1) load2(cb + STEP, c1, rn, pidn);
 				scatter_batch(r, pid, lid_base);
+				if (cb + STEP < c1) {
+#pragma unroll
+					for (int i = 0; i < PART_RPT; i++) { r[i] = rn[i]; pid[i] = pidn[i]; }
+				}
 			}
 			flush_all(lid_base);
 			__syncthreads();
