@@ -75,7 +75,7 @@ struct kmr_handle {
 	unsigned int *work_counter = nullptr;
 	void *linear = nullptr; uint64_t linear_cap = 0;         /* records */
 	uint32_t *tile_count = nullptr; uint64_t tile_cap = 0;
-	uint32_t *kcap = nullptr; uint64_t *koff = nullptr; uint64_t kcap_n = 0;
+	uint32_t *kcap = nullptr; uint64_t *koff = nullptr; uint64_t kcap_n = 0, koff_n = 0;
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr; uint64_t uw_cap = 0, us_cap = 0;
 	/* timing */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -471,6 +471,8 @@ int pool_reserve(kmr_handle *h, HostPool &p, uint64_t extra, bool keep) {
 		HIPCHK(h, hipMemcpy(nb, p.base, (size_t)used * p.chunk_bytes, hipMemcpyDeviceToDevice));
 		HIPCHK(h, hipMemcpy(nl, p.chunk_list, 4ull * used, hipMemcpyDeviceToDevice));
 		HIPCHK(h, hipMemcpy(nc, p.chunk_count, 4ull * used, hipMemcpyDeviceToDevice));
+		/* device-to-device copies may return before they have run: the sources are freed next */
+		HIPCHK(h, hipDeviceSynchronize());
 	}
 	if (p.base) hipFree(p.base); if (p.chunk_list) hipFree(p.chunk_list); if (p.chunk_count) hipFree(p.chunk_count);
 	p.base = nb; p.chunk_list = nl; p.chunk_count = nc; p.cap = (uint32_t)ncap;
@@ -479,7 +481,7 @@ int pool_reserve(kmr_handle *h, HostPool &p, uint64_t extra, bool keep) {
 
 template <class T> int ensure_buf(kmr_handle *h, T *&ptr, uint64_t &cap, uint64_t need, size_t elem) {
 	if (need <= cap && ptr) return 0;
-	if (ptr) hipFree((void *)ptr);
+	if (ptr) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree((void *)ptr); }   /* kernels in flight may still read it */
 	ptr = nullptr; cap = 0;
 	const uint64_t n = std::max<uint64_t>(need, 16);
 	HIPCHK(h, hipMalloc((void **)&ptr, n * elem));
@@ -504,6 +506,12 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
                                       uint64_t n_ext, uint32_t ext_stride, uint64_t ext_len, uint64_t total, uint64_t max_records) {
 	if (n_ext == 0) return 0;
 	const int grid = (int)std::min<uint64_t>(part_grid(h), n_ext);
+	if (!h->l1.base) {
+		const uint64_t est = std::max<uint64_t>(max_records, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
+		const uint64_t launches = est / std::max<uint64_t>(1, max_records) + 2;
+		int rc0 = pool_reserve(h, h->l1, est / CH + launches * (uint64_t)grid * ((1ull << h->bits1) + 512) + 64, true);
+		if (rc0) return rc0;
+	}
 	int rc = pool_reserve(h, h->l1, max_records / CH + (uint64_t)grid * ((1ull << h->bits1) + 512) + 64, true);
 	if (rc) return rc;
 	rc = zero_work_counter(h); if (rc) return rc;
@@ -540,7 +548,7 @@ template <int W> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll
 		rv.first_read_idx = rvAll.first_read_idx + r;
 		/* k-mer capacity of every read -> region of each 64-read tile in the linear buffer */
 		int rc = ensure_buf(h, h->kcap, h->kcap_n, m + 1, 4); if (rc) return rc;
-		if (!h->koff || true) { if (h->koff) hipFree(h->koff); h->koff = nullptr; HIPCHK(h, hipMalloc((void **)&h->koff, 8 * (m + 1))); }
+		rc = ensure_buf(h, h->koff, h->koff_n, m + 1, 8); if (rc) return rc;
 		hipLaunchKernelGGL(kmer_capacity_kernel, dim3(grid_for(m)), dim3(256), 0, h->stream, rv.offsets, rv.discarded, m, h->k, h->kcap);
 		HIPCHK(h, hipGetLastError());
 		rc = exclusive_scan(h, h->kcap, m, h->koff); if (rc) return rc;
@@ -582,6 +590,14 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, ui
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(cnt);
 	*n_chunks_out = used;
+	if (getenv("KMR_DEBUG")) {
+		unsigned long long *d, hv[2] = {0, 0};
+		HIPCHK(h, hipMalloc((void **)&d, 16)); HIPCHK(h, hipMemset(d, 0, 16));
+		if (used) hipLaunchKernelGGL(pool_records_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, p.chunk_count, used, d, d + 1);
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+		HIPCHK(h, hipMemcpy(hv, d, 16, hipMemcpyDeviceToHost)); hipFree(d);
+		fprintf(stderr, "build_csr: lists %llu chunks %u valid %llu records %llu (expected %llu)\n", (unsigned long long)nl, used, hv[1], hv[0], (unsigned long long)h->stats.raw_good_kmers);
+	}
 	return 0;
 }
 
@@ -726,7 +742,7 @@ void free_partition_state(kmr_handle *h) {
 	if (h->kcap) hipFree(h->kcap); if (h->koff) hipFree(h->koff);
 	if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8);
 	h->work_counter = nullptr; h->linear = nullptr; h->tile_count = nullptr; h->kcap = nullptr; h->koff = nullptr;
-	h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = nullptr; h->linear_cap = h->tile_cap = h->kcap_n = h->uw_cap = h->us_cap = 0;
+	h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = nullptr; h->linear_cap = h->tile_cap = h->kcap_n = h->koff_n = h->uw_cap = h->us_cap = 0;
 }
 
 }  // namespace

@@ -128,9 +128,9 @@ static const int MAX_PART_BITS = 10;
 template <int W>
 __host__ __device__ inline size_t partition_smem_bytes(int bits) {
 	return (size_t)PART_BATCH * sizeof(Record<W>)                 /* sorted batch */
-	       + ((size_t)1 << bits) * 3 * sizeof(Record<W>)          /* up to 3 pending records per list */
-	       + ((size_t)1 << bits) * 4 * 5                          /* hist, pstart, cur, cnt, pend */
-	       + ((size_t)PART_BATCH / 4 + (((size_t)1 << bits) * 3) / 4 + 8) * 8   /* line tasks of one batch */
+	       + (size_t)PART_BATCH * 2                               /* list id of every sorted record */
+	       + ((size_t)1 << bits) * 4 * 7                          /* hist, pstart, cur, cnt, pos0, c0, xoff */
+	       + ((size_t)PART_BATCH / CH + ((size_t)1 << bits) + 8) * 4   /* chunks opened by one batch beyond the first */
 	       + 64;
 }
 
@@ -143,16 +143,18 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 	typedef Record<W> Rec;
 	extern __shared__ __attribute__((aligned(16))) uint8_t psm[];
 	Rec *sorted = (Rec *)psm;
-	Rec *stage = sorted + PART_BATCH;                 /* pending record j of list p at stage[j * P + p] */
-	uint32_t *hist = (uint32_t *)(stage + (size_t)P * 3);
+	uint16_t *spid = (uint16_t *)(sorted + PART_BATCH);          /* list id of sorted[i] */
+	uint32_t *hist = (uint32_t *)(spid + PART_BATCH);
 	uint32_t *pstart = hist + P;
-	uint32_t *cur = pstart + P;
-	uint32_t *cnt = cur + P;
-	uint32_t *pend = cnt + P;
-	unsigned long long *tasks = (unsigned long long *)(pend + P);   /* 8-byte aligned: all sizes above are multiples of 8 */
+	uint32_t *cur = pstart + P;       /* open chunk of each list (NO_CHUNK if none)          */
+	uint32_t *cnt = cur + P;          /* records already in it                                */
+	uint32_t *pos0 = cnt + P;         /* per batch: position of the run's first record        */
+	uint32_t *c0 = pos0 + P;          /* per batch: chunk that position falls into            */
+	uint32_t *xoff = c0 + P;          /* per batch: index of the run's further chunks in extra[] */
+	uint32_t *extra = xoff + P;
 	__shared__ uint32_t s_item;
 	__shared__ uint32_t s_scan[PART_THREADS];
-	__shared__ uint32_t s_ntasks;
+	__shared__ uint32_t s_nextra;
 	/* chunk allocator: one device atomic hands a block SLAB chunks; chunk ids are then taken by an LDS
 	 * counter through a small ring of slab bases (one word of device memory saturates at ~90 M atomics/s,
 	 * which a per-chunk atomic from every block would hit) */
@@ -161,8 +163,8 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 	__shared__ uint32_t s_alloc, s_filled;      /* chunks taken / chunks made available so far */
 	const int t = threadIdx.x;
 
-	for (int p = t; p < P; p += PART_THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; pend[p] = 0; }
-	if (t == 0) { s_alloc = 0; s_filled = 0; s_ntasks = 0; }
+	for (int p = t; p < P; p += PART_THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; }
+	if (t == 0) { s_alloc = 0; s_filled = 0; s_nextra = 0; }
 	__syncthreads();
 
 	/* called by thread 0 between batches: keep a few times the average need of one batch (PART_BATCH/CH chunks)
@@ -178,73 +180,56 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 			s_filled += nslab * SLAB;
 		}
 	};
-	auto alloc_chunk = [&]() -> uint32_t {
+	auto alloc_chunk = [&](uint32_t lid) -> uint32_t {
 		const uint32_t idx = atomicAdd(&s_alloc, 1u);
 		const uint32_t c = idx < s_filled ? s_ring[(idx / SLAB) % RING] + (idx % SLAB) : atomicAdd(out.head, 1u);
-		return c < out.cap ? c : NO_CHUNK;
+		if (c >= out.cap) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); return NO_CHUNK; }
+		out.chunk_list[c] = lid;
+		return c;
 	};
 
 	auto chunk_ptr = [&](uint32_t c) -> Rec * { return (Rec *)(out.base + (size_t)c * CH * sizeof(Rec)); };
 
-	/* Hand a run of n new records of list p (sorted[s0..s0+n)) out.  Book-keeping only: every full 4-record
-	 * line (pending records first, then the run) becomes a task {chunk, line slot, list, line index}; the
-	 * stores themselves are done by four lanes per line in flush_tasks so each line is one 64-byte request. */
+	/* Book-keeping for the run of n new records of list p: they continue the list's open chunk at position
+	 * cnt[p] and spill into freshly opened chunks.  Nothing is staged: store_batch writes every record of the
+	 * sorted batch straight to its slot (runs are contiguous, so neighbouring lanes write neighbouring 16-byte
+	 * slots); a 64-byte sector that a run leaves half written is completed by the same block's next batch
+	 * while it is still in the XCD's L2. */
 	auto plan_run = [&](int p, uint32_t lid, uint32_t n) {
 		uint32_t c = cur[p], filled = cnt[p];
-		const uint32_t pe = pend[p];
-		const uint32_t lines = (pe + n) >> 2;
-		for (uint32_t l = 0; l < lines; l++) {
-			if (c == NO_CHUNK) {
-				c = alloc_chunk();
-				if (c == NO_CHUNK) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); break; }
-				out.chunk_list[c] = lid; filled = 0;
+		if (c == NO_CHUNK) { c = alloc_chunk(lid); filled = 0; }
+		pos0[p] = filled; c0[p] = c;
+		const uint32_t endpos = filled + n;                 /* positions [filled, endpos) */
+		const uint32_t nextra = endpos > (uint32_t)CH ? (endpos - 1) / CH : 0;   /* chunks beyond the first */
+		uint32_t last = c;
+		if (nextra) {
+			const uint32_t xo = atomicAdd(&s_nextra, nextra);
+			xoff[p] = xo;
+			if (c != NO_CHUNK) out.chunk_count[c] = CH;
+			for (uint32_t q = 0; q < nextra; q++) {
+				last = alloc_chunk(lid);
+				extra[xo + q] = last;
+				if (q + 1 < nextra && last != NO_CHUNK) out.chunk_count[last] = CH;
 			}
-			const uint32_t q = atomicAdd(&s_ntasks, 1u);
-			tasks[q] = ((unsigned long long)c << 32) | ((unsigned long long)(filled >> 2) << 24) | ((unsigned long long)l << 12) | (unsigned long long)p;
-			filled += 4;
-			if (filled == CH) { out.chunk_count[c] = CH; c = NO_CHUNK; filled = 0; }
 		}
-		cur[p] = c; cnt[p] = filled;
+		uint32_t rem = endpos - nextra * CH;                 /* records in the last chunk: 1..CH */
+		if (rem == (uint32_t)CH) { if (last != NO_CHUNK) out.chunk_count[last] = CH; last = NO_CHUNK; rem = 0; }
+		cur[p] = last; cnt[p] = rem;
 	};
-	auto flush_tasks = [&]() {
-		const uint32_t nt = s_ntasks;
-		const int g = t & 3;
-		for (uint32_t q = t >> 2; q < nt; q += PART_THREADS / 4) {
-			const unsigned long long tk = tasks[q];
-			const uint32_t c = (uint32_t)(tk >> 32), slot = (uint32_t)(tk >> 24) & 0xff, l = (uint32_t)(tk >> 12) & 0xfff, p = (uint32_t)tk & 0xfff;
-			const uint32_t pe = pend[p];
-			const uint32_t r = 4 * l + g;                       /* record index in (pending ++ run) */
-			const Rec rec = r < pe ? stage[(size_t)r * P + p] : sorted[pstart[p] + r - pe];
-			chunk_ptr(c)[slot * 4 + g] = rec;
+	auto store_batch = [&](uint32_t total) {
+		for (uint32_t i = t; i < total; i += PART_THREADS) {
+			const uint32_t p = spid[i];
+			const uint32_t pos = pos0[p] + (i - pstart[p]);
+			const uint32_t q = pos / CH;
+			const uint32_t c = q == 0 ? c0[p] : extra[xoff[p] + q - 1];
+			if (c != NO_CHUNK) chunk_ptr(c)[pos % CH] = sorted[i];
 		}
 	};
-	/* after the flush: what is left of (pending ++ run) becomes the new pending set */
-	auto keep_rest = [&](int p, uint32_t n) {
-		const uint32_t pe = pend[p];
-		const uint32_t lines = (pe + n) >> 2, rem = (pe + n) & 3;
-		if (lines) for (uint32_t j = 0; j < rem; j++) stage[(size_t)j * P + p] = sorted[pstart[p] + 4 * lines + j - pe];
-		else for (uint32_t j = pe; j < rem; j++) stage[(size_t)j * P + p] = sorted[pstart[p] + j - pe];
-		pend[p] = rem;
-	};
-	auto flush_all = [&](uint32_t lid_base) {
-		if (t == 0) top_up();
-		__syncthreads();
+	auto flush_all = [&](uint32_t) {
 		for (int p = t; p < P; p += PART_THREADS) {
-			uint32_t c = cur[p], filled = cnt[p], pe = pend[p];
-			if (pe) {
-				if (c == NO_CHUNK) {
-					c = alloc_chunk();
-					if (c == NO_CHUNK) atomicOr(out.err, (uint32_t)ERR_POOL_FULL);
-					else { out.chunk_list[c] = lid_base + p; filled = 0; }
-				}
-				if (c != NO_CHUNK) {
-					Rec *dst = chunk_ptr(c) + filled;
-					for (uint32_t g = 0; g < pe; g++) dst[g] = stage[(size_t)g * P + p];
-					filled += pe;
-				}
-			}
-			if (c != NO_CHUNK) out.chunk_count[c] = filled;
-			cur[p] = NO_CHUNK; cnt[p] = 0; pend[p] = 0;
+			const uint32_t c = cur[p];
+			if (c != NO_CHUNK) out.chunk_count[c] = cnt[p];
+			cur[p] = NO_CHUNK; cnt[p] = 0;
 		}
 	};
 
@@ -282,7 +267,7 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 		for (int p = t; p < P; p += PART_THREADS) hist[p] = pstart[p];
 		__syncthreads();
 #pragma unroll
-		for (int i = 0; i < PART_RPT; i++) if (pid[i] != NO_CHUNK) { uint32_t pos = atomicAdd(&hist[pid[i]], 1u); sorted[pos] = r[i]; }
+		for (int i = 0; i < PART_RPT; i++) if (pid[i] != NO_CHUNK) { uint32_t pos = atomicAdd(&hist[pid[i]], 1u); sorted[pos] = r[i]; spid[pos] = (uint16_t)pid[i]; }
 		__syncthreads();
 		if (DBG != 1) {
 			for (int p = t; p < P; p += PART_THREADS) {
@@ -290,13 +275,8 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 				if (n) plan_run(p, lid_base + p, n);
 			}
 			__syncthreads();
-			if (DBG != 3) flush_tasks();
-			__syncthreads();
-			if (DBG != 3 && DBG != 4) for (int p = t; p < P; p += PART_THREADS) {
-				const uint32_t n = hist[p] - pstart[p];
-				if (n) keep_rest(p, n);
-			}
-			if (t == 0) s_ntasks = 0;
+			if (DBG != 3) store_batch(s_scan[PART_THREADS - 1]);      /* inclusive scan total = records in the batch */
+			if (t == 0) s_nextra = 0;
 		}
 		__syncthreads();
 	};
@@ -314,6 +294,7 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 		__shared__ unsigned long long s_bstart[MAXB];
 		__shared__ uint32_t s_bcount[MAXB];
 		__shared__ uint32_t s_nb;
+		__shared__ unsigned long long s_ecur, s_eoff;
 		auto load1 = [&](uint32_t bi, Rec (&rr)[PART_RPT], uint32_t (&pp)[PART_RPT]) {
 			const uint64_t start = s_bstart[bi]; const uint32_t n = s_bcount[bi];
 #pragma unroll
@@ -328,25 +309,33 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 			__syncthreads();
 			const uint64_t efirst = s_item;
 			if (efirst >= S.n_ext) break;
-			if (t == 0) {
-				uint32_t nb = 0;
-				for (uint64_t e = efirst; e < efirst + EBATCH && e < S.n_ext; e++) {
-					uint64_t start, n;
-					if (S.ext_start) { start = S.ext_start[e * S.ext_stride]; n = S.ext_count[e]; }
-					else { start = e * S.ext_len; n = S.total - start < S.ext_len ? S.total - start : S.ext_len; }
-					for (uint64_t b = 0; b < n && nb < MAXB; b += PART_BATCH) { s_bstart[nb] = start + b; s_bcount[nb] = (uint32_t)(n - b < (uint64_t)PART_BATCH ? n - b : (uint64_t)PART_BATCH); nb++; }
+			/* the batches of these extents are listed MAXB at a time (an extent can be a tile of long reads) */
+			if (t == 0) { s_ecur = efirst; s_eoff = 0; }
+			for (;;) {
+				__syncthreads();
+				if (t == 0) {
+					uint32_t nb = 0;
+					uint64_t e = s_ecur, off = s_eoff;
+					while (e < efirst + EBATCH && e < S.n_ext && nb < MAXB) {
+						uint64_t start, n;
+						if (S.ext_start) { start = S.ext_start[e * S.ext_stride]; n = S.ext_count[e]; }
+						else { start = e * S.ext_len; n = S.total - start < S.ext_len ? S.total - start : S.ext_len; }
+						while (off < n && nb < MAXB) { s_bstart[nb] = start + off; s_bcount[nb] = (uint32_t)(n - off < (uint64_t)PART_BATCH ? n - off : (uint64_t)PART_BATCH); nb++; off += PART_BATCH; }
+						if (off >= n) { e++; off = 0; }
+					}
+					s_ecur = e; s_eoff = off; s_nb = nb;
 				}
-				s_nb = nb;
-			}
-			__syncthreads();
-			const uint32_t nb = s_nb;
-			if (nb) load1(0, r, pid);
-			for (uint32_t bi = 0; bi < nb; bi++) {
-				if (bi + 1 < nb) load1(bi + 1, rn, pidn);
-				scatter_batch(r, pid, 0);
-				if (bi + 1 < nb) {
+				__syncthreads();
+				const uint32_t nb = s_nb;
+				if (nb == 0) break;
+				load1(0, r, pid);
+				for (uint32_t bi = 0; bi < nb; bi++) {
+					if (bi + 1 < nb) load1(bi + 1, rn, pidn);
+					scatter_batch(r, pid, 0);
+					if (bi + 1 < nb) {
 #pragma unroll
-					for (int i = 0; i < PART_RPT; i++) { r[i] = rn[i]; pid[i] = pidn[i]; }
+						for (int i = 0; i < PART_RPT; i++) { r[i] = rn[i]; pid[i] = pidn[i]; }
+					}
 				}
 			}
 			__syncthreads();
@@ -446,6 +435,15 @@ void chunk_scatter_kernel(const uint32_t *chunk_list, const uint32_t *chunk_coun
 		const uint32_t pos = priv ? lh[l] + myr[j] : atomicAdd(&cursor[l], 1u);
 		list_chunks[list_start[l] + pos] = ((uint64_t)chunk_count[c] << 32) | c;
 	}
+}
+
+/* debugging aid (KMR_DEBUG): records held by a pool */
+__global__ void pool_records_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, unsigned long long *total, unsigned long long *nvalid) {
+	unsigned long long s = 0, v = 0;
+	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x)
+		if (chunk_list[c] != NO_CHUNK) { s += chunk_count[c]; v++; }
+	s = wave_sum(s); v = wave_sum(v);
+	if ((threadIdx.x & 63) == 0) { atomicAdd(total, s); atomicAdd(nvalid, v); }
 }
 
 /* ------------------------------------------------------------------ count */

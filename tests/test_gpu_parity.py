@@ -375,3 +375,13 @@ def test_c2_full_size_properties():
             assert counts.min() >= 2
             checked += cnt
     assert checked > 1000
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_long_reads_within_tile(mode):
+    """reads near the per-wavefront LDS tile limit (9 952 bases): one tile then holds few reads but
+    hundreds of thousands of k-mers, i.e. many partition batches per extent"""
+    rb = synth_reads(300, read_len=5000, genome_len=400000, seed=41, quality="noisy", n_rate=0.001)
+    cfg = default_config(31, num_buckets_weak=1024, num_buckets_singleton=4096)
+    o, p = run_both(cfg, rb, mode=mode)
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)

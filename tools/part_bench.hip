@@ -47,7 +47,7 @@ int main(int argc, char **argv) {
 	pv.cap = cap; hipMemset(pv.err, 0, 4);
 	unsigned int *wc; CK(hipMalloc(&wc, 4));
 	CK(hipDeviceSynchronize());
-	for (int bits : {10}) for (int grid : {512}) {
+	for (int bits : {8, 7, 6, 5}) for (int grid : {512}) {
 		float f0 = run<0>(lin, n, bits, pv, wc, grid), f1 = run<1>(lin, n, bits, pv, wc, grid), f2 = run<2>(lin, n, bits, pv, wc, grid), f3 = run<3>(lin, n, bits, pv, wc, grid), f4 = run<4>(lin, n, bits, pv, wc, grid);
 		printf("   planonly %.2f  plan+flush %.2f\n", f3, f4);
 		printf("bits %d grid %d: full %.2f ms  noappend %.2f ms  loadonly %.2f ms   (%.1f Grec/s full)\n", bits, grid, f0, f1, f2, n / f0 / 1e6);
