@@ -372,8 +372,30 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		roll.init(k);
 		double w = 0.0;
 		uint32_t zc = 0;                 /* positions in the window that force weight 0 */
+		uint64_t zbits[3] = {0, 0, 0};   /* zero flag of the last positions (bit i = position j-i), so the flag that
+		                                    leaves the window is read from a register instead of the tile */
+		uint32_t qprev = 0x100, qrun = 0; /* length of the current run of equal quality chars */
 		uint32_t leftCode = 5, leftQ = p.ext_min_q;   /* Extension('X', minQuality) */
-		for (uint32_t j = 0; j < Lmax; j++) {
+		const uint32_t rbOff = (uint32_t)(rb - tb), rqOff = (uint32_t)(rq - tq);
+		const bool haveQuals = rv.quals != nullptr;
+		for (uint32_t jb = 0; jb < Lmax; jb += 4) {
+		/* bases and quals of the next four positions: one aligned 8-byte LDS window each per four iterations
+		 * (the tile buffers are 16-byte aligned and 32 bytes longer than the staged span) */
+		uint64_t bwin = 0, qwin = 0;
+		if (jb < L) {
+			const uint32_t a = rbOff + jb;
+			const uint32_t *pw = (const uint32_t *)(tb + (a & ~3u));
+			bwin = ((uint64_t)pw[0] | ((uint64_t)pw[1] << 32)) >> (8 * (a & 3u));
+			if (haveQuals) {
+				const uint32_t aq_ = rqOff + jb;
+				const uint32_t *pq = (const uint32_t *)(tq + (aq_ & ~3u));
+				qwin = ((uint64_t)pq[0] | ((uint64_t)pq[1] << 32)) >> (8 * (aq_ & 3u));
+			}
+		}
+#pragma unroll
+		for (uint32_t ju = 0; ju < 4; ju++) {
+			const uint32_t j = jb + ju;
+			if (j >= Lmax) break;
 			/* the occurrence of this iteration is handed to the Op after the divergent part, so that
 			 * Ops can use wave-wide primitives (ballot compaction) under uniform control flow */
 			bool valid = false;
@@ -385,17 +407,15 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 #pragma unroll
 			for (int wi = 0; wi < W; wi++) canon.w[wi] = 0;
 			if (j < L) {
-				const uint8_t c = rb[j];
+				const uint8_t c = (uint8_t)(bwin >> (8 * ju));
 				uint32_t code = base_code(c);
-				const uint32_t q = isRef ? 127u : (uint32_t)rq[j];
+				const uint32_t q = isRef ? 127u : (uint32_t)((qwin >> (8 * ju)) & 0xffu);
 				bool z = (code == 4) || (!isRef && q < p.qzero);
 				if (code == 4) code = 0;                      /* markup packs as A */
+				zbits[2] = (zbits[2] << 1) | (zbits[1] >> 63); zbits[1] = (zbits[1] << 1) | (zbits[0] >> 63); zbits[0] = (zbits[0] << 1) | (z ? 1ull : 0ull);
 				zc += z ? 1u : 0u;
-				if (j >= k) {                                 /* position j-k leaves the window */
-					const uint32_t oc = base_code(rb[j - k]);
-					const bool oz = (oc == 4) || (!isRef && (uint32_t)rq[j - k] < p.qzero);
-					zc -= oz ? 1u : 0u;
-				}
+				zc -= (uint32_t)((zbits[k >> 6] >> (k & 63)) & 1ull);   /* position j-k leaves the window (0 while j < k) */
+				qrun = (q == qprev) ? qrun + 1 : 0; qprev = q;
 				roll.push(code);
 				if (j + 1 >= k) {
 					const uint32_t i = j + 1 - k;
@@ -406,10 +426,14 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 							w = 1.0;
 							for (uint32_t jj = 0; jj < k; jj++) w *= sP[rq[i + jj]];
 						} else {
-							const uint32_t qo = rq[i - 1];
-							if (qo != q) {              /* x / x == 1.0 exactly, so equal qualities leave w unchanged */
-								const double change = sP[q] / sP[qo];
-								w *= change;
+							/* x / x == 1.0 exactly, so equal qualities leave w unchanged; a run of k+1 equal
+							 * chars proves that without touching the tile */
+							if (qrun < k) {
+								const uint32_t qo = rq[i - 1];
+								if (qo != q) {
+									const double change = sP[q] / sP[qo];
+									w *= change;
+								}
 							}
 						}
 					}
@@ -451,6 +475,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 				}
 			}
 			op.emit(opst, valid, p, canon, hash, o, rv.first_read_idx + r0 + lane, kpos, nClaimed, fail);
+		}
 		}
 		done += n;
 		__builtin_amdgcn_wave_barrier();   /* all lanes are done reading the tile before it is overwritten */
