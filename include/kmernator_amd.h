@@ -173,6 +173,17 @@ int kmr_lookup(kmr_handle *h, const uint8_t *packed_kmers, uint64_t n, uint32_t 
 int kmr_lookup_reads(kmr_handle *h, const char *bases, const uint64_t *offsets,
                      uint64_t n_reads, uint32_t *counts_out, const uint64_t *out_offsets);
 
+/* Trim and score whole reads against the weak map: ReadSelector::scoreAndTrimReads
+ * (src/ReadSelector.h:1182-1207) = per-position counts (getValue :924-931, weak map only), cut at the first
+ * N/X markup (_setNumKmers :1037-1047), first longest run of k-mers with count >= minimum_kmer_score
+ * (trimReadByMinimumKmerScore :949-1014, bimodal detection off), score of that run (scoreReadByScoringType
+ * :1094-1180) and setTrimHeaders (:1015-1036).  Per read: trim_offset (bases), trim_length (bases, run + k - 1,
+ * 0 = nothing left), score (-1 if nothing left; KS_SUM leaves 0 as the reference does), was_trimmed. */
+typedef enum kmr_scoring { KMR_SCORE_SUM = 0, KMR_SCORE_MEDIAN = 1, KMR_SCORE_MIN = 2, KMR_SCORE_MAX = 3, KMR_SCORE_AVG = 4 } kmr_scoring;
+int kmr_score_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                    double minimum_kmer_score, int scoring_type,
+                    uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed);
+
 /* Export in the reference's on-disk / mmap format so the caller can
  * WeakMapType::restore(dst) it.  Replaces KmerMapByKmerArrayPair::getSizeToStore /
  * store(void*) (src/Kmer.h:3143-3159,3181-3191) and KmerSpectrum::storeMmap

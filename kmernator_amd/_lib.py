@@ -52,7 +52,7 @@ EXPORTS = [
     "kmr_lookup_reads", "kmr_image_size", "kmr_write_image", "kmr_load_image", "kmr_count_histogram",
     "kmr_dump_mercount", "kmr_dump_mergraph", "kmr_hash", "kmr_bucket_idx", "kmr_local_thread_id",
     "kmr_distributed_thread_id", "kmr_compress_sequence", "kmr_least_complement", "kmr_extract_by_owner_dev",
-    "kmr_insert_records_dev", "kmr_stream", "kmr_kernel_time", "kmr_kernel_time_reset", "kmr_reset", "kmr_release_table",
+    "kmr_insert_records_dev", "kmr_stream", "kmr_kernel_time", "kmr_kernel_time_reset", "kmr_reset", "kmr_release_table", "kmr_score_reads",
 ]
 
 _lib = None
@@ -105,6 +105,7 @@ def load():
     lib.kmr_stream.argtypes = [vp]
     lib.kmr_kernel_time.argtypes = [vp, C.c_int, f64p, u64p]
     lib.kmr_kernel_time_reset.argtypes = [vp]
+    lib.kmr_score_reads.argtypes = [vp, vp, u64p, C.c_uint64, C.c_double, C.c_int, u32p, u32p, C.POINTER(C.c_float), u8p]
     lib.kmr_reset.argtypes = [vp]
     lib.kmr_release_table.argtypes = [vp]
     _lib = lib

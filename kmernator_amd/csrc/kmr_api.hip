@@ -414,8 +414,8 @@ template <int W> int lookup_t(kmr_handle *h, const uint8_t *packed, uint64_t n, 
 	return 0;
 }
 
-template <int W> int lookup_reads_t(kmr_handle *h, const ReadsView &rv, uint32_t *dout, const uint64_t *dout_off) {
-	LookupOp<W> op; const uint32_t vw = h->ext ? 15 : 3;
+template <int W> int lookup_reads_t(kmr_handle *h, const ReadsView &rv, uint32_t *dout, const uint64_t *dout_off, bool weak_only = false) {
+	LookupOp<W> op; const uint32_t vw = h->ext ? 15 : 3; op.weak_only = weak_only;
 	op.weak = view_of<W>(h->weak, vw); op.sing = view_of<W>(h->sing, vw); op.out = dout; op.out_offsets = dout_off; op.first_read_idx = rv.first_read_idx;
 	return launch_extract<W, false>(h, rv, op);
 }
@@ -951,6 +951,40 @@ int kmr_lookup_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, 
 	if (!rc) { HIPCHK(h, hipMemcpyAsync(counts_out, dout, 4 * outN, hipMemcpyDeviceToHost, h->stream)); rc = sync_state(h); }
 	else hipStreamSynchronize(h->stream);
 	hipFree(dout); hipFree(doff); s.release();
+	return rc;
+}
+
+/* ReadSelector::scoreAndTrimReads (src/ReadSelector.h:1182-1207) on the weak map */
+int kmr_score_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads, double minimum_kmer_score, int scoring_type,
+                    uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed) {
+	if (!h || !bases || !offsets || !trim_offset || !trim_length || !score || !was_trimmed) return KMR_ERR_INVALID_ARG;
+	if (scoring_type < 0 || scoring_type > 4) return fail(h, KMR_ERR_INVALID_ARG, "bad scoring_type");
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_score_reads before kmr_finalize");
+	if (n_reads == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	StagedReads s; uint64_t total = 0;
+	int rc = stage_reads(h, bases, nullptr, offsets, n_reads, nullptr, s, total);
+	if (rc) { s.release(); return rc; }
+	std::vector<uint64_t> coff(n_reads + 1, 0);
+	for (uint64_t r = 0; r < n_reads; r++) { const uint64_t L = offsets[r + 1] - offsets[r]; coff[r + 1] = coff[r] + (L >= h->k ? L - h->k + 1 : 0); }
+	const uint64_t outN = coff[n_reads];
+	uint32_t *dcounts, *dto, *dtl; uint64_t *dcoff; float *dsc; uint8_t *dwt;
+	HIPCHK(h, hipMalloc((void **)&dcounts, std::max<uint64_t>(8, 4 * outN))); HIPCHK(h, hipMalloc((void **)&dcoff, 8 * (n_reads + 1)));
+	HIPCHK(h, hipMalloc((void **)&dto, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dtl, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dsc, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dwt, n_reads));
+	HIPCHK(h, hipMemsetAsync(dcounts, 0, 4 * outN, h->stream));
+	HIPCHK(h, hipMemcpyAsync(dcoff, coff.data(), 8 * (n_reads + 1), hipMemcpyHostToDevice, h->stream));
+	ReadsView rv; rv.bases = s.b; rv.quals = nullptr; rv.offsets = s.o; rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0;
+	switch (h->W) { case 1: rc = lookup_reads_t<1>(h, rv, dcounts, dcoff, true); break; case 2: rc = lookup_reads_t<2>(h, rv, dcounts, dcoff, true); break;
+	case 3: rc = lookup_reads_t<3>(h, rv, dcounts, dcoff, true); break; default: rc = lookup_reads_t<4>(h, rv, dcounts, dcoff, true); }
+	if (!rc) {
+		hipLaunchKernelGGL(score_reads_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, s.b, s.o, n_reads, h->k, dcounts, dcoff,
+		                   (float)minimum_kmer_score, scoring_type, dto, dtl, dsc, dwt);
+		HIPCHK(h, hipGetLastError());
+		HIPCHK(h, hipMemcpyAsync(trim_offset, dto, 4 * n_reads, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(trim_length, dtl, 4 * n_reads, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(h, hipMemcpyAsync(score, dsc, 4 * n_reads, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(was_trimmed, dwt, n_reads, hipMemcpyDeviceToHost, h->stream));
+		rc = sync_state(h);
+	} else hipStreamSynchronize(h->stream);
+	hipFree(dcounts); hipFree(dcoff); hipFree(dto); hipFree(dtl); hipFree(dsc); hipFree(dwt); s.release();
 	return rc;
 }
 

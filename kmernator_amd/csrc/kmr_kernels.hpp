@@ -535,6 +535,7 @@ template <int W> struct LookupOp {
 	uint32_t *out;
 	const uint64_t *out_offsets;   /* per read, indexed by global read index - first_read_idx */
 	uint64_t first_read_idx;
+	bool weak_only;                /* ReadSelector looks at spectrum.weak only (src/ReadSelector.h:924-931) */
 	static const bool NEEDS_WEIGHT = false;
 	static const bool COUNTS_STATS = false;
 	static const bool NEEDS_HASH = true;
@@ -543,7 +544,12 @@ template <int W> struct LookupOp {
 	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
 	__device__ __forceinline__ void emit(State &, bool valid, const DevParams &, const Key<W> &key, uint64_t hash, const Occurrence &,
 	                                     uint64_t readIdx, uint32_t pos, unsigned &, bool &) const {
-		if (valid) out[out_offsets[readIdx - first_read_idx] + pos] = maps_count<W>(weak, sing, key, hash);
+		if (valid) {
+			uint32_t c;
+			if (weak_only) { const int64_t i = map_find<W>(weak, key, hash); c = i >= 0 ? (weak.vals[(uint64_t)i * weak.vw] & 0xffffu) : 0u; }
+			else c = maps_count<W>(weak, sing, key, hash);
+			out[out_offsets[readIdx - first_read_idx] + pos] = c;
+		}
 	}
 };
 template <int W> __device__ __forceinline__ bool op_keeps_all_owners(const LookupOp<W> &) { return true; }
@@ -555,6 +561,61 @@ __global__ void lookup_keys_kernel(MapView<W> weak, MapView<W> sing, const uint8
 		Key<W> key;
 		key_from_bytes<W>(key, packed + i * kb, kb);
 		out[i] = maps_count<W>(weak, sing, key, key_hash<W>(key, kb));
+	}
+}
+
+/* ReadSelector::scoreAndTrimReads for one read per lane (src/ReadSelector.h:1182-1207): numKmers is cut at the
+ * first N/X markup (_setNumKmers :1037-1047), the read is trimmed to the first longest run of k-mers whose count
+ * is >= minScore (trimReadByMinimumKmerScore :949-1014, bimodal detection off), the run is scored
+ * (scoreReadByScoringType :1094-1180) and setTrimHeaders (:1015-1036) converts the run to bases. */
+enum { SCORE_SUM = 0, SCORE_MEDIAN = 1, SCORE_MIN = 2, SCORE_MAX = 3, SCORE_AVG = 4 };
+__global__ void score_reads_kernel(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, uint32_t k, const uint32_t *counts,
+                                   const uint64_t *count_off, float minScore, int scoring, uint32_t *trimOffset, uint32_t *trimLength,
+                                   float *score, uint8_t *wasTrimmed) {
+	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t b0 = offsets[r], L = offsets[r + 1] - b0;
+		uint32_t numKmers = L >= k ? (uint32_t)(L - k + 1) : 0;
+		for (uint64_t i = 0; i < L; i++) {                      /* TwoBitSequence::firstMarkupNorX */
+			uint8_t c = bases[b0 + i];
+			if (c == '.') c = 'N';
+			if (c == 'N' || c == 'X') { const uint32_t m = (uint32_t)i + 1; numKmers = m > k ? (m - k < numKmers ? m - k : numKmers) : 0; break; }
+		}
+		const uint32_t *cv = counts + count_off[r];
+		uint32_t bestOff = 0, bestLen = 0, off = 0, len = 0;
+		for (uint32_t i = 0; i < numKmers; i++) {
+			const float v = (float)cv[i];
+			if (v >= minScore) len++;
+			else { if (len > bestLen) { bestLen = len; bestOff = off; } off += len + 1; len = 0; }
+		}
+		if (len > bestLen) { bestLen = len; bestOff = off; }
+		const bool trimmed = bestLen < numKmers;
+		float sc = -1.0f;
+		if (bestLen > 0) {
+			const uint32_t *run = cv + bestOff;
+			if (scoring == SCORE_MEDIAN) {
+				/* sorted[n/2]: the smallest v with #(x <= v) > n/2, found by bisection on the 16-bit count */
+				const uint32_t t = bestLen / 2;
+				uint32_t lo = 0, hi = 65535;
+				while (lo < hi) {
+					const uint32_t mid = (lo + hi) >> 1;
+					uint32_t le = 0;
+					for (uint32_t i = 0; i < bestLen; i++) le += run[i] <= mid ? 1u : 0u;
+					if (le > t) hi = mid; else lo = mid + 1;
+				}
+				sc = (float)lo;
+			} else if (scoring == SCORE_AVG) {
+				double sum = 0.0; for (uint32_t i = 0; i < bestLen; i++) sum += (float)run[i];
+				sc = (float)(sum / (double)bestLen);
+			} else if (scoring == SCORE_MIN || scoring == SCORE_MAX) {
+				uint32_t m = run[0];
+				for (uint32_t i = 1; i < bestLen; i++) m = scoring == SCORE_MAX ? (run[i] > m ? run[i] : m) : (run[i] < m ? run[i] : m);
+				sc = (float)m;
+			} else sc = 0.0f;     /* KS_SUM: scoreReadBySumKmer only assigns the score when byAvg (:1149-1162) */
+		}
+		trimOffset[r] = bestLen > 0 ? bestOff : 0u;
+		trimLength[r] = bestLen > 0 ? bestLen + k - 1 : 0u;
+		score[r] = sc;
+		wasTrimmed[r] = trimmed ? 1 : 0;
 	}
 }
 

@@ -149,6 +149,23 @@ class KmerSpectrum:
                        out.ctypes.data_as(C.POINTER(C.c_uint32)), out_off.ctypes.data_as(C.POINTER(C.c_uint64)))
         return out, out_off
 
+    SCORING = {"SUM": 0, "MEDIAN": 1, "MIN": 2, "MAX": 3, "AVG": 4}
+
+    def scoreAndTrimReads(self, bases, offsets, minimum_kmer_score, scoring_type="MEDIAN"):
+        """ReadSelector::scoreAndTrimReads: (trim_offset, trim_length, score, was_trimmed) per read."""
+        bases = _u8(bases)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        to = np.zeros(n, dtype=np.uint32)
+        tl = np.zeros(n, dtype=np.uint32)
+        sc = np.zeros(n, dtype=np.float32)
+        wt = np.zeros(n, dtype=np.uint8)
+        if n:
+            self._call("score_reads", self.h, bases.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                       float(minimum_kmer_score), self.SCORING[scoring_type], to.ctypes.data_as(C.POINTER(C.c_uint32)),
+                       tl.ctypes.data_as(C.POINTER(C.c_uint32)), sc.ctypes.data_as(C.POINTER(C.c_float)), wt.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return to, tl, sc, wt.astype(bool)
+
     def histogram(self, nbins=256):
         counts = np.zeros(nbins, dtype=np.uint64)
         weights = np.zeros(nbins, dtype=np.float64)

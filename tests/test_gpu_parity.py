@@ -11,7 +11,7 @@ import pytest
 import kmernator_amd as ka
 from helpers import (GOLDEN, KMR_MAP_SINGLETON, KMR_MAP_WEAK, KMR_VALUE_EXT, OracleSpectrum, ReadBatch, default_config,
                      oracle_weighted_kmers, parse_image, read_fastq, synth_reads)
-from refsemantics import median_trim_label
+from refsemantics import median_trim_label, score_and_trim
 
 pytestmark = pytest.mark.gpu
 
@@ -385,3 +385,42 @@ def test_long_reads_within_tile(mode):
     cfg = default_config(31, num_buckets_weak=1024, num_buckets_singleton=4096)
     o, p = run_both(cfg, rb, mode=mode)
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+
+
+def test_score_and_trim_reads_golden_labels():
+    """f1: ReadSelector::scoreAndTrimReads on the device against the reference's FilterReads golden
+    (test/1000-Filtered.fastq: MedianScore / Trim labels of the 949 reads without AFTrim)."""
+    import re
+    k = 31
+    rb = read_fastq(os.path.join(GOLDEN, "1000.fastq"))
+    gold = read_fastq(os.path.join(GOLDEN, "1000-Filtered.fastq"))
+    p = product(default_config(k, fastq_start_char=64, estimated_raw_kmers=46000))
+    add(p, rb)
+    p.finalize(2)
+    to, tl, sc, wt = p.scoreAndTrimReads(rb.bases, rb.offsets, 2, "MEDIAN")
+    checked = 0
+    for i in range(rb.n):
+        if b"AFTrim" in gold.names[i]:
+            continue
+        label = b""
+        if wt[i]:
+            label += b"Trim:%d+%d " % (to[i], tl[i])
+        label += b"MedianScore:%d" % int(sc[i] + 0.5)
+        assert label == gold.names[i].split(b" ", 1)[1], (i, label, gold.names[i])
+        checked += 1
+    assert checked == 949
+
+
+@pytest.mark.parametrize("scoring", ["MEDIAN", "AVG", "MIN", "MAX", "SUM"])
+def test_score_and_trim_reads_all_types(scoring):
+    k = 25
+    rb = synth_reads(1500, read_len=120, seed=6, quality="noisy", n_rate=0.004)
+    cfg = default_config(k, num_buckets_weak=256, num_buckets_singleton=1024)
+    o, p = run_both(cfg, rb)
+    to, tl, sc, wt = p.scoreAndTrimReads(rb.bases, rb.offsets, 3, scoring)
+    counts, off = p.getCountsForReads(rb.bases, rb.offsets)
+    for i in range(rb.n):
+        cnt = counts[int(off[i]):int(off[i + 1])]
+        eo, el, es, et = score_and_trim(cnt, rb.seq(i), k, 3, scoring)
+        assert (int(to[i]), int(tl[i]), bool(wt[i])) == (eo, el, et), (i, scoring)
+        assert abs(float(sc[i]) - es) <= 1e-5 * max(1.0, abs(es)), (i, scoring, sc[i], es)
