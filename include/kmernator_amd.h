@@ -247,8 +247,10 @@ int kmr_least_complement(const uint8_t *packed, uint32_t k, uint8_t *out);
 /* Extract all good k-mers of a device-resident read batch and bin them by
  * owner = kmr_distributed_thread_id(hash, world_size) into world_size
  * contiguous segments of dev_records.  dev_seg_counts[world_size] (u64, device)
- * receives the records per owner; segment s starts at record
- * seg_capacity * s.  Returns KMR_ERR_CAPACITY (after sync) if a segment
+ * receives the SLOTS handed out per owner; segment s starts at record
+ * seg_capacity * s.  Wavefronts take slots in runs of 512, so a segment also holds
+ * holes (records with weight 0) which kmr_insert_records_dev skips; size
+ * seg_capacity for the expected records plus 512 * 4096 slots of slack.  Returns KMR_ERR_CAPACITY (after sync) if a segment
  * overflowed.  Asynchronous on the handle's stream otherwise. */
 int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals,
                              const void *dev_offsets, uint64_t n_reads, uint64_t total_bases,

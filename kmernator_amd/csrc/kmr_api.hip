@@ -164,7 +164,7 @@ int sync_state(kmr_handle *h) {
 	uint32_t e = 0; DevStats s;
 	HIPCHK(h, hipMemcpy(&e, h->derr, sizeof(e), hipMemcpyDeviceToHost));
 	HIPCHK(h, hipMemcpy(&s, h->dstats, sizeof(s), hipMemcpyDeviceToHost));
-	h->stats.raw_kmers = s.raw + h->inserted_records; h->stats.raw_good_kmers = s.good + h->inserted_records; h->stats.discarded = s.raw - s.good;
+	h->stats.raw_kmers = s.raw + s.inserted; h->stats.raw_good_kmers = s.good + s.inserted; h->stats.discarded = s.raw - s.good;
 	h->occupied = s.claimed; h->pending_kmers = 0;
 	if (e & ERR_READ_TOO_LONG) return fail(h, KMR_ERR_UNSUPPORTED, "a read is longer than the per-wavefront LDS tile (" + std::to_string(TILE_SPAN) + " bases)");
 	if (e & ERR_TABLE_FULL) return fail(h, KMR_ERR_CAPACITY, "device k-mer table is full; raise kmr_config.max_table_entries / estimated_raw_kmers");
@@ -220,13 +220,14 @@ void time_end(kmr_handle *h, int which, hipEvent_t a, hipEvent_t b) {
 
 const size_t EXTRACT_SMEM = (size_t)WAVES_PER_BLOCK * 2 * TILE_BUF;
 
-template <int W, bool EXT, class Op> int launch_extract(kmr_handle *h, const ReadsView &rv, const Op &op) {
+template <int W, bool EXT, class Op> int launch_extract(kmr_handle *h, const ReadsView &rv, const Op &op, uint64_t max_blocks = 0) {
 	static bool attr_set = false;
 	auto kern = extract_kernel<W, EXT, Op>;
 	if (!attr_set) { HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXTRACT_SMEM)); attr_set = true; }
 	const uint64_t tiles = (rv.n_reads + 63) / 64;
-	const uint64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+	uint64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
 	if (blocks == 0) return 0;
+	if (max_blocks && blocks > max_blocks) blocks = max_blocks;      /* wavefronts then walk several tiles */
 	if (blocks > 0x7fffffffull) return fail(h, KMR_ERR_INVALID_ARG, "too many reads in one batch");
 	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES_PER_BLOCK * 64), EXTRACT_SMEM, h->stream, rv, dev_params(h), op);
 	HIPCHK(h, hipGetLastError());
@@ -503,7 +504,8 @@ int part_grid(kmr_handle *h) {
 
 /* level-1 partition of a linear record buffer into h->l1 */
 template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, const uint64_t *ext_start, const uint32_t *ext_count,
-                                      uint64_t n_ext, uint32_t ext_stride, uint64_t ext_len, uint64_t total, uint64_t max_records) {
+                                      uint64_t n_ext, uint32_t ext_stride, uint64_t ext_len, uint64_t total, uint64_t max_records,
+                                      unsigned long long *valid_counter = nullptr) {
 	if (n_ext == 0) return 0;
 	const int grid = (int)std::min<uint64_t>(part_grid(h), n_ext);
 	if (!h->l1.base) {
@@ -517,6 +519,7 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	rc = zero_work_counter(h); if (rc) return rc;
 	PartSource<W> S; memset(&S, 0, sizeof(S));
 	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
+	S.valid_counter = valid_counter;
 	auto kern = partition_kernel<W, 1>;
 	const size_t smem = partition_smem_bytes<W>(h->bits1);
 	if (getenv("KMR_DEBUG")) fprintf(stderr, "partition_level1 W=%d bits1=%d smem=%zu max=%zu grid=%d n_ext=%llu\n", W, h->bits1, smem, partition_smem_bytes<W>(max_part_bits(W)), grid, (unsigned long long)n_ext);
@@ -727,9 +730,9 @@ int finalize_partition(kmr_handle *h, uint32_t min_depth) {
 template <int W> int insert_records_partition_t(kmr_handle *h, const void *recs, uint64_t n) {
 	if (!h->l1.head) choose_bits1(h, n);
 	hipEvent_t a, b; time_begin(h, 0, &a, &b);
-	int rc = partition_level1<W>(h, (const Record<W> *)recs, nullptr, nullptr, (n + 8191) / 8192, 0, 8192, n, n);
+	/* received segments contain holes (weight 0): the device counts the real records into stats.raw/good */
+	int rc = partition_level1<W>(h, (const Record<W> *)recs, nullptr, nullptr, (n + 8191) / 8192, 0, 8192, n, n, &h->dstats->inserted);
 	time_end(h, 0, a, b);
-	h->inserted_records += n;
 	return rc;
 }
 int insert_records_partition(kmr_handle *h, const void *recs, uint64_t n) {
@@ -1140,12 +1143,13 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
                              uint64_t total_bases, uint64_t first_global_read_idx, const void *dev_discarded,
                              void *dev_records, uint64_t seg_capacity, void *dev_seg_counts) {
 	if (!h || !dev_bases || !dev_offsets || !dev_records || !dev_seg_counts) return KMR_ERR_INVALID_ARG;
+	if (h->cfg.world_size > (uint32_t)RECORD_MAX_OWNERS) return fail(h, KMR_ERR_UNSUPPORTED, "owner exchange supports up to 8 ranks per node");
 	hipSetDevice(h->device);
 	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
 	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
 	HIPCHK(h, hipMemsetAsync(dev_seg_counts, 0, 8 * h->cfg.world_size, h->stream));
 	int rc;
-#define REC(Wv, E) { RecordOp<Wv, E> op; op.records = (Record<Wv> *)dev_records; op.seg_counts = (unsigned long long *)dev_seg_counts; op.seg_capacity = seg_capacity; rc = launch_extract<Wv, E>(h, rv, op); }
+#define REC(Wv, E) { RecordOp<Wv, E> op; op.records = (Record<Wv> *)dev_records; op.seg_counts = (unsigned long long *)dev_seg_counts; op.seg_capacity = seg_capacity; op.world = h->cfg.world_size; rc = launch_extract<Wv, E>(h, rv, op, 1024); }
 	switch (h->W) {
 	case 1: if (h->ext) REC(1, true) else REC(1, false) break;
 	case 2: if (h->ext) REC(2, true) else REC(2, false) break;

@@ -48,6 +48,7 @@ enum { ERR_READ_TOO_LONG = 1, ERR_TABLE_FULL = 2, ERR_SEGMENT_OVERFLOW = 4 };
 
 struct DevStats {
 	unsigned long long raw, good, claimed;   /* claimed = new keys inserted */
+	unsigned long long inserted;             /* records received through the owner exchange (holes excluded) */
 };
 
 struct DevParams {
@@ -231,6 +232,8 @@ template <int W, bool EXT> struct InsertOp {
 	static const bool COUNTS_STATS = true;
 	static const bool NEEDS_HASH = true;
 	struct State {};
+	__device__ __forceinline__ void wave_begin(State &, int) const {}
+	__device__ __forceinline__ void wave_end(State &, int) const {}
 	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
 	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
 	__device__ __forceinline__ void emit(State &, bool valid, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
@@ -246,41 +249,67 @@ template <int W> struct Record {
 	uint32_t pkt;
 };
 
+/* Sender side of the owner exchange.  Every wavefront keeps, per owner, a private run [pos, end) of the
+ * owner's segment and takes a new run of RSLAB records with ONE device atomic when it is used up (a per-emit
+ * atomic on `world` counters would serialise: one word serves ~90 M atomics/s).  The slots a wavefront leaves
+ * unused are written as holes (weight 0: no valid record has that), which the receiver skips. */
+static const int RECORD_MAX_OWNERS = 8;
+static const uint32_t RSLAB = 512;
 template <int W, bool EXT> struct RecordOp {
 	Record<W> *records;
-	unsigned long long *seg_counts;   /* [world] */
+	unsigned long long *seg_counts;   /* [world]: slots handed out per owner (valid records + holes) */
 	uint64_t seg_capacity;
+	uint32_t world;
 	static const bool NEEDS_WEIGHT = true;
 	static const bool COUNTS_STATS = false;
 	static const bool NEEDS_HASH = true;
-	struct State {};
+	struct State { unsigned long long pos[RECORD_MAX_OWNERS], end[RECORD_MAX_OWNERS]; };
+	__device__ __forceinline__ void wave_begin(State &st, int) const {
+#pragma unroll
+		for (int o = 0; o < RECORD_MAX_OWNERS; o++) { st.pos[o] = 0; st.end[o] = 0; }
+	}
 	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
 	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
-	/* one atomic per (wavefront, owner) instead of one per lane */
-	__device__ __forceinline__ void emit(State &, bool valid, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
+	__device__ __forceinline__ void wave_end(State &st, int lane) const {
+#pragma unroll
+		for (int o = 0; o < RECORD_MAX_OWNERS; o++) {
+			if ((uint32_t)o >= world) continue;
+			for (unsigned long long e = st.pos[o] + lane; e < st.end[o]; e += 64) {
+				if (e < seg_capacity) { Record<W> r; for (int i = 0; i < W; i++) r.key[i] = 0; r.w = 0.0f; r.pkt = 0; records[(uint64_t)o * seg_capacity + e] = r; }
+			}
+		}
+	}
+	/* called by all lanes under uniform control flow */
+	__device__ __forceinline__ void emit(State &st, bool valid, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
 	                                     uint64_t, uint32_t, unsigned &, bool &fail) const {
 		const uint32_t owner = valid ? distributed_thread_id(hash, p.world) : 0xffffffffu;
 		const int lane = (int)(threadIdx.x & 63);
-		unsigned long long todo = __ballot(valid);
-		unsigned long long pos = 0;
-		while (todo) {
-			const int leader = __builtin_ctzll(todo);
-			const uint32_t o_ = __shfl(owner, leader, 64);
-			const unsigned long long same = __ballot(owner == o_) & todo;
-			unsigned long long base = 0;
-			if (lane == leader) base = atomicAdd(&seg_counts[o_], (unsigned long long)__builtin_popcountll(same));
-			base = __shfl(base, leader, 64);
-			if (owner == o_) pos = base + (unsigned long long)__builtin_popcountll(same & ((1ull << lane) - 1));
-			todo &= ~same;
+		unsigned long long mypos = ~0ull;
+#pragma unroll
+		for (int ow = 0; ow < RECORD_MAX_OWNERS; ow++) {
+			if ((uint32_t)ow >= world) continue;              /* wave-uniform */
+			const unsigned long long m = __ballot(owner == (uint32_t)ow);
+			const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+			if (cnt == 0) continue;
+			if (st.pos[ow] + cnt > st.end[ow]) {               /* run exhausted: retire its tail as holes, take a new one */
+				for (unsigned long long e = st.pos[ow] + lane; e < st.end[ow]; e += 64)
+					if (e < seg_capacity) { Record<W> r; for (int i = 0; i < W; i++) r.key[i] = 0; r.w = 0.0f; r.pkt = 0; records[(uint64_t)ow * seg_capacity + e] = r; }
+				unsigned long long base = 0;
+				if (lane == 0) base = atomicAdd(&seg_counts[ow], (unsigned long long)RSLAB);
+				base = __shfl(base, 0, 64);
+				st.pos[ow] = base; st.end[ow] = base + RSLAB;
+			}
+			if (owner == (uint32_t)ow) mypos = st.pos[ow] + (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1));
+			st.pos[ow] += cnt;
 		}
 		if (!valid) return;
-		if (pos >= seg_capacity) { fail = true; return; }
+		if (mypos >= seg_capacity) { fail = true; return; }
 		Record<W> r;
 #pragma unroll
 		for (int i = 0; i < W; i++) r.key[i] = key.w[i];
 		r.w = o.forward ? o.w : -o.w;
 		r.pkt = EXT ? o.pkt : (uint32_t)o.ordinal;
-		records[(uint64_t)owner * seg_capacity + pos] = r;
+		records[(uint64_t)owner * seg_capacity + mypos] = r;
 	}
 };
 
@@ -313,9 +342,18 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 
 	uint8_t *tb = smem + (size_t)wave * (2 * TILE_BUF);
 	uint8_t *tq = tb + TILE_BUF;
-	const uint64_t tile = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+	const uint32_t k = p.k;
+	unsigned long long nRaw = 0, nGood = 0;
+	unsigned nClaimed = 0;
+	bool fail = false;
+	typename Op::State opst;
+	op.wave_begin(opst, lane);
+	const bool needHash = Op::NEEDS_HASH || p.subsample > 1 || p.world > 1 || p.num_parts > 1;
+	/* a wavefront walks tiles tile0, tile0 + stride, ... (stride = all wavefronts of the grid): with a full grid
+	 * that is one tile each; Ops that keep per-wavefront state (RecordOp's owner slabs) launch fewer blocks */
+	const uint64_t n_tiles = (rv.n_reads + 63) / 64;
+	for (uint64_t tile = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
 	const uint64_t r0 = tile * 64;
-	if (r0 >= rv.n_reads) return;
 	const uint32_t nr = (uint32_t)((rv.n_reads - r0) < 64 ? (rv.n_reads - r0) : 64);
 	const bool have = (uint32_t)lane < nr;
 	uint64_t myStart = 0, myEnd = 0;
@@ -325,13 +363,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		myEnd = rv.offsets[r0 + lane + 1];
 		myDiscard = rv.discarded ? (rv.discarded[r0 + lane] != 0) : false;
 	}
-	const uint32_t k = p.k;
-	unsigned long long nRaw = 0, nGood = 0;
-	unsigned nClaimed = 0;
-	bool fail = false;
-	typename Op::State opst;
 	op.tile_begin(opst, &s_wcount[wave], r0, lane);
-	const bool needHash = Op::NEEDS_HASH || p.subsample > 1 || p.world > 1 || p.num_parts > 1;
 
 	uint32_t done = 0;
 	while (done < nr) {
@@ -481,6 +513,8 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		__builtin_amdgcn_wave_barrier();   /* all lanes are done reading the tile before it is overwritten */
 	}
 	op.tile_end(opst, tile, lane);
+	}
+	op.wave_end(opst, lane);
 	nRaw = wave_sum(nRaw); nGood = wave_sum(nGood);
 	unsigned long long nc = wave_sum((unsigned long long)nClaimed);
 	if (lane == 0 && Op::COUNTS_STATS) {   /* the owner counts records when they are inserted */
@@ -540,6 +574,8 @@ template <int W> struct LookupOp {
 	static const bool COUNTS_STATS = false;
 	static const bool NEEDS_HASH = true;
 	struct State {};
+	__device__ __forceinline__ void wave_begin(State &, int) const {}
+	__device__ __forceinline__ void wave_end(State &, int) const {}
 	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
 	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
 	__device__ __forceinline__ void emit(State &, bool valid, const DevParams &, const Key<W> &key, uint64_t hash, const Occurrence &,
@@ -626,6 +662,7 @@ __global__ void insert_records_kernel(Table<W> table, const Record<W> *recs, uin
 	unsigned long long nGood = 0; unsigned nClaimed = 0; bool fail = false;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		Record<W> r = recs[i];
+		if (r.w == 0.0f) continue;                   /* hole left by the sender's slab allocation */
 		Key<W> key;
 #pragma unroll
 		for (int j = 0; j < W; j++) key.w[j] = r.key[j];

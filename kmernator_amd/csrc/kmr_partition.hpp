@@ -74,6 +74,8 @@ template <int W, bool EXT> struct LinearOp {
 	static const bool COUNTS_STATS = true;
 	static const bool NEEDS_HASH = false;
 	struct State { uint64_t base; uint32_t n; };
+	__device__ __forceinline__ void wave_begin(State &, int) const {}
+	__device__ __forceinline__ void wave_end(State &, int) const {}
 	__device__ __forceinline__ void tile_begin(State &st, uint32_t *, uint64_t r0, int) const { st.base = koff[r0]; st.n = 0; }
 	__device__ __forceinline__ void tile_end(State &st, uint64_t tile, int lane) const { if (lane == 0) tile_count[tile] = st.n; }
 	/* called by all lanes under uniform control flow: compact the valid lanes behind the running count */
@@ -111,6 +113,7 @@ template <int W> struct PartSource {
 	const uint32_t *ext_count;     /* per extent: valid records   (NULL with uniform extents)     */
 	uint64_t n_ext, ext_len, total;
 	uint32_t ext_stride;           /* ext_start index = extent * ext_stride (64 reads per tile)   */
+	unsigned long long *valid_counter;  /* optional: += records with weight != 0 (exchange input)    */
 	/* LEVEL 2: work items over the chunk CSR of the level-1 pool */
 	PoolView src;
 	const uint64_t *list_chunks;   /* (records << 32 | chunk id), grouped by list */
@@ -295,13 +298,14 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 		__shared__ uint32_t s_bcount[MAXB];
 		__shared__ uint32_t s_nb;
 		__shared__ unsigned long long s_ecur, s_eoff;
+		unsigned long long nvalid = 0;      /* records that are not exchange holes */
 		auto load1 = [&](uint32_t bi, Rec (&rr)[PART_RPT], uint32_t (&pp)[PART_RPT]) {
 			const uint64_t start = s_bstart[bi]; const uint32_t n = s_bcount[bi];
 #pragma unroll
 			for (int i = 0; i < PART_RPT; i++) {
 				const uint32_t idx = (uint32_t)i * PART_THREADS + t;
 				pp[i] = NO_CHUNK;
-				if (idx < n) { rr[i] = S.linear[start + idx]; pp[i] = pid_of(rr[i]); }
+				if (idx < n) { rr[i] = S.linear[start + idx]; if (rr[i].w != 0.0f) { pp[i] = pid_of(rr[i]); nvalid++; } }
 			}
 		};
 		for (;;) {
@@ -341,6 +345,7 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 			__syncthreads();
 		}
 		flush_all(0);
+		if (S.valid_counter) { nvalid = wave_sum(nvalid); if ((t & 63) == 0 && nvalid) atomicAdd(S.valid_counter, nvalid); }
 	} else {
 		auto load2 = [&](uint64_t cb, uint64_t c1, Rec (&rr)[PART_RPT], uint32_t (&pp)[PART_RPT]) {
 			/* a batch = PART_BATCH/CH chunks; wave w reads chunk (i * waves + w), lane = record */

@@ -14,7 +14,10 @@ import torch.distributed as dist
 
 def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
     """records: uint8 tensor [world * seg_capacity * rec_bytes], segment s holds
-    seg_counts[s] records for rank s.  Returns (recv uint8 tensor, n_records)."""
+    seg_counts[s] records for rank s.  Returns (recv uint8 tensor, n_records).
+
+    The payload travels as int64 rows of one record each, so the split sizes handed to the
+    collective count records (a byte count overflows 32 bits at ~1.3e8 sixteen-byte records)."""
     world = dist.get_world_size(group)
     send_counts = seg_counts.to(torch.int64)
     recv_counts = torch.empty_like(send_counts)
@@ -23,12 +26,16 @@ def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
     rc = [int(x) for x in recv_counts.cpu().tolist()]
     if max(sc) > seg_capacity:
         raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_capacity))
-    rec2d = records.view(world, seg_capacity * rec_bytes)
-    send = torch.cat([rec2d[s, :sc[s] * rec_bytes] for s in range(world)]) if world > 1 else rec2d[0, :sc[0] * rec_bytes]
-    recv = torch.empty(sum(rc) * rec_bytes, dtype=torch.uint8, device=records.device)
-    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[c * rec_bytes for c in rc],
-                           input_split_sizes=[c * rec_bytes for c in sc], group=group)
-    return recv, sum(rc)
+    assert rec_bytes % 8 == 0
+    words = rec_bytes // 8
+    rows = records.view(torch.int64).view(world, seg_capacity, words)
+    if world > 1:
+        send = torch.cat([rows[s, :sc[s]] for s in range(world)])
+    else:
+        send = rows[0, :sc[0]]
+    recv = torch.empty((sum(rc), words), dtype=torch.int64, device=records.device)
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=rc, input_split_sizes=sc, group=group)
+    return recv.view(torch.uint8).view(-1), sum(rc)
 
 
 def all_ranks_chunk_count(n_local_chunks, group=None, device="cpu"):
@@ -38,7 +45,10 @@ def all_ranks_chunk_count(n_local_chunks, group=None, device="cpu"):
     return int(t.item())
 
 
-def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_reads=1 << 20, group=None, slack=1.25):
+MAX_CHUNK_BYTES = 1 << 30      # payload of one all-to-all per rank; collectives above 2 GiB are not trusted
+
+
+def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_reads=None, group=None, slack=1.25):
     """Device tensors in, spectrum (rank/world_size configured) built in place.
     bases/quals: uint8 cuda tensors, offsets: int64/uint64 cuda tensor [n+1]."""
     from . import record_bytes
@@ -48,13 +58,16 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
     rb = record_bytes(k)
     dev = bases.device
     off_host = offsets.cpu()
+    if chunk_reads is None:
+        avg = max(1, int(off_host[n] - off_host[0]) // max(1, n))
+        chunk_reads = max(1024, (MAX_CHUNK_BYTES // rb) // avg)
     n_chunks = (n + chunk_reads - 1) // chunk_reads
     total_chunks = all_ranks_chunk_count(n_chunks, group, dev)
     max_kmers = 0
     for c in range(n_chunks):
         lo, hi = c * chunk_reads, min(n, (c + 1) * chunk_reads)
         max_kmers = max(max_kmers, int(off_host[hi] - off_host[lo]))
-    seg_cap = max(1024, int(max_kmers / world * slack) + 1024)
+    seg_cap = max(1024, int(max_kmers / world * slack) + 1024) + 512 * 4096      # + one partly used 512-slot run per wavefront
     records = torch.empty(world * seg_cap * rb, dtype=torch.uint8, device=dev)
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     empty_off = torch.zeros(1, dtype=torch.int64, device=dev)
