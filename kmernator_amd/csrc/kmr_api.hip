@@ -42,6 +42,7 @@ struct DevMap {                      /* a finalized map resident in HBM */
 struct HostPool {                    /* owner of one chunk pool */
 	uint8_t *base = nullptr; uint32_t *chunk_list = nullptr, *chunk_count = nullptr; unsigned int *head = nullptr;
 	uint32_t cap = 0; size_t chunk_bytes = 0;
+	uint64_t used_ub = 0;            /* host-side upper bound of chunks handed out */
 };
 
 }  // namespace
@@ -457,7 +458,14 @@ void pool_free(HostPool &p) {
 /* make sure the pool can take 'extra' more chunks (keeps the used prefix when it has to move) */
 int pool_reserve(kmr_handle *h, HostPool &p, uint64_t extra, bool keep) {
 	unsigned int used = 0;
-	if (p.head && keep) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipMemcpy(&used, p.head, 4, hipMemcpyDeviceToHost)); if (used > p.cap) used = p.cap; }
+	if (!keep) p.used_ub = 0;
+	if (p.head && keep) {
+		/* the host keeps an upper bound of the chunks handed out so far (every launch adds what it reserved); only
+		 * when that bound no longer fits is the stream drained and the real allocator head read back */
+		if (p.base && p.used_ub + extra + 64 <= p.cap) { p.used_ub += extra; return 0; }
+		HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipMemcpy(&used, p.head, 4, hipMemcpyDeviceToHost)); if (used > p.cap) used = p.cap;
+	}
+	p.used_ub = (uint64_t)used + extra;
 	const uint64_t need = (uint64_t)used + extra + 64;
 	if (need >= 0xffffffffull) return fail(h, KMR_ERR_CAPACITY, "record pool would exceed 2^32 chunks");
 	if (!p.head) { HIPCHK(h, hipMalloc((void **)&p.head, 4)); HIPCHK(h, hipMemset(p.head, 0, 4)); }
@@ -848,6 +856,7 @@ int kmr_reset(kmr_handle *h) {
 	if (h->partition_mode) {
 		if (h->l1.head) HIPCHK(h, hipMemsetAsync(h->l1.head, 0, 4, h->stream));
 		if (h->l2.head) HIPCHK(h, hipMemsetAsync(h->l2.head, 0, 4, h->stream));
+		h->l1.used_ub = 0; h->l2.used_ub = 0;
 		h->inserted_records = 0;
 	} else {
 		if (!h->slots) rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);

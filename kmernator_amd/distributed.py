@@ -48,42 +48,99 @@ def all_ranks_chunk_count(n_local_chunks, group=None, device="cpu"):
 MAX_CHUNK_BYTES = 1 << 30      # payload of one all-to-all per rank; collectives above 2 GiB are not trusted
 
 
-def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_reads=None, group=None, slack=1.25):
-    """Device tensors in, spectrum (rank/world_size configured) built in place.
-    bases/quals: uint8 cuda tensors, offsets: int64/uint64 cuda tensor [n+1]."""
-    from . import record_bytes
-    world = dist.get_world_size(group)
-    n = offsets.numel() - 1
-    k = spectrum.k
-    rb = record_bytes(k)
-    dev = bases.device
-    off_host = offsets.cpu()
+def _plan_chunks(offsets_host, n, rb, chunk_reads):
     if chunk_reads is None:
-        avg = max(1, int(off_host[n] - off_host[0]) // max(1, n))
+        avg = max(1, int(offsets_host[n] - offsets_host[0]) // max(1, n))
         chunk_reads = max(1024, (MAX_CHUNK_BYTES // rb) // avg)
     n_chunks = (n + chunk_reads - 1) // chunk_reads
-    total_chunks = all_ranks_chunk_count(n_chunks, group, dev)
     max_kmers = 0
     for c in range(n_chunks):
         lo, hi = c * chunk_reads, min(n, (c + 1) * chunk_reads)
-        max_kmers = max(max_kmers, int(off_host[hi] - off_host[lo]))
+        max_kmers = max(max_kmers, int(offsets_host[hi] - offsets_host[lo]))
+    return chunk_reads, n_chunks, max_kmers
+
+
+def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_reads=None, group=None, slack=1.25, pipeline=True):
+    """Device tensors in, spectrum (rank/world_size configured) built in place.
+    bases/quals: uint8 cuda tensors, offsets: int64/uint64 cuda tensor [n+1].
+
+    pipeline=True overlaps the all-to-all of chunk c with the extraction of chunk c+1: the library's stream S
+    runs extract(0), extract(1), [wait comm 0] insert(0), extract(2), [wait comm 1] insert(1), ... while a second
+    stream compacts the owner segments and runs the collectives; two record buffers alternate."""
+    from . import record_bytes
+    world = dist.get_world_size(group)
+    n = offsets.numel() - 1
+    rb = record_bytes(spectrum.k)
+    dev = bases.device
+    off_host = offsets.cpu()
+    chunk_reads, n_chunks, max_kmers = _plan_chunks(off_host, n, rb, chunk_reads)
+    total_chunks = all_ranks_chunk_count(n_chunks, group, dev)
     seg_cap = max(1024, int(max_kmers / world * slack) + 1024) + 512 * 4096      # + one partly used 512-slot run per wavefront
-    records = torch.empty(world * seg_cap * rb, dtype=torch.uint8, device=dev)
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    empty_off = torch.zeros(1, dtype=torch.int64, device=dev)
-    for c in range(total_chunks):
+    nbuf = 2 if pipeline else 1
+    records = [torch.empty(world * seg_cap * rb, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    counts = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(nbuf)]
+    qptr = None if quals is None else quals.data_ptr()
+
+    def submit_extract(c):
+        b = c % nbuf
         lo, hi = c * chunk_reads, min(n, (c + 1) * chunk_reads)
         if lo < n:
             nb = int(off_host[hi] - off_host[lo])
-            spectrum.extractByOwnerDevice(bases.data_ptr(), None if quals is None else quals.data_ptr(),
-                                          offsets.data_ptr() + 8 * lo, hi - lo, nb, first_read_idx + lo,
-                                          records.data_ptr(), seg_cap, counts.data_ptr())
-            spectrum.sync()
+            spectrum.extractByOwnerDevice(bases.data_ptr(), qptr, offsets.data_ptr() + 8 * lo, hi - lo, nb, first_read_idx + lo,
+                                          records[b].data_ptr(), seg_cap, counts[b].data_ptr())
         else:
-            counts.zero_()
-        recv, n_recv = exchange_records(records, counts, seg_cap, rb, group)
-        if n_recv:
+            with torch.cuda.stream(lib_stream):
+                counts[b].zero_()
+
+    if not pipeline:
+        lib_stream = torch.cuda.current_stream(dev)
+        for c in range(total_chunks):
             torch.cuda.synchronize(dev)
-            spectrum.insertRecordsDevice(recv.data_ptr(), n_recv)
+            submit_extract(c)
             spectrum.sync()
+            recv, n_recv = exchange_records(records[0], counts[0], seg_cap, rb, group)
+            if n_recv:
+                torch.cuda.synchronize(dev)
+                spectrum.insertRecordsDevice(recv.data_ptr(), n_recv)
+                spectrum.sync()
+        return spectrum
+
+    lib_stream = torch.cuda.ExternalStream(spectrum.stream(), device=dev)
+    comm_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize(dev)
+    ev_extract = [torch.cuda.Event() for _ in range(nbuf)]
+    keep_alive = []
+    words = rb // 8
+    submit_extract(0)
+    ev_extract[0].record(lib_stream)
+    for c in range(total_chunks):
+        b = c % nbuf
+        if c + 1 < total_chunks:
+            submit_extract(c + 1)
+            ev_extract[(c + 1) % nbuf].record(lib_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev_extract[b])
+            send_counts = counts[b].clone()
+            recv_counts = torch.empty_like(send_counts)
+            dist.all_to_all_single(recv_counts, send_counts, group=group)
+            sc = [int(x) for x in send_counts.cpu().tolist()]          # host waits for extract(c) and the counts exchange only
+            rc = [int(x) for x in recv_counts.cpu().tolist()]
+            if max(sc) > seg_cap:
+                raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_cap))
+            rows = records[b].view(torch.int64).view(world, seg_cap, words)
+            send = torch.cat([rows[s, :sc[s]] for s in range(world)]) if world > 1 else rows[0, :sc[0]].contiguous()
+            recv = torch.empty((sum(rc), words), dtype=torch.int64, device=dev)
+            dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+            ev_comm = torch.cuda.Event()
+            ev_comm.record(comm_stream)
+        recv.record_stream(lib_stream)
+        send.record_stream(comm_stream)
+        keep_alive.append((recv, send))
+        if len(keep_alive) > 3:
+            keep_alive.pop(0)
+        lib_stream.wait_event(ev_comm)
+        if sum(rc):
+            spectrum.insertRecordsDevice(recv.data_ptr(), sum(rc))
+    spectrum.sync()
+    torch.cuda.synchronize(dev)
     return spectrum

@@ -424,3 +424,37 @@ def test_score_and_trim_reads_all_types(scoring):
         eo, el, es, et = score_and_trim(cnt, rb.seq(i), k, 3, scoring)
         assert (int(to[i]), int(tl[i]), bool(wt[i])) == (eo, el, et), (i, scoring)
         assert abs(float(sc[i]) - es) <= 1e-5 * max(1.0, abs(es)), (i, scoring, sc[i], es)
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_build_partitioned_driver_single_rank(pipeline):
+    """kmernator_amd.distributed.build_partitioned (the N>1 driver of bench.py) with a one-rank RCCL group:
+    chunked extract-by-owner -> all-to-all -> insert must equal the direct build, with and without the
+    comm/compute pipeline."""
+    import torch
+    import torch.distributed as dist
+    from kmernator_amd.distributed import build_partitioned
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29600 + (os.getpid() % 300) + (1 if pipeline else 0))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n = 400000
+        rb = synth_reads(n, read_len=150, genome_len=5 * n, seed=2, quality="noisy")
+        tb = torch.from_numpy(np.concatenate([rb.bases, np.zeros(64, np.uint8)])).to(dev)
+        tq = torch.from_numpy(np.concatenate([rb.quals, np.zeros(64, np.uint8)])).to(dev)
+        to = torch.from_numpy(rb.offsets.astype(np.int64)).to(dev)
+        torch.cuda.synchronize()
+        a = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0))
+        a.buildKmerSpectrumDevice(tb.data_ptr(), tq.data_ptr(), to.data_ptr(), n, n * 150, 0)
+        a.finalize(2)
+        b = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0))
+        build_partitioned(b, tb, tq, to, chunk_reads=70000, pipeline=pipeline)
+        b.finalize(2)
+        sa, sb = a.stats(), b.stats()
+        for key in ("raw_good_kmers", "unique_kmers", "singleton_kmers", "weak_entries"):
+            assert sa[key] == sb[key], (key, sa, sb)
+        compare_weak_images(a.image(KMR_MAP_WEAK), b.image(KMR_MAP_WEAK), a.kb, False, dir_tol=1)
+    finally:
+        dist.destroy_process_group()
