@@ -77,6 +77,9 @@ struct kmr_handle {
 	void *linear = nullptr; uint64_t linear_cap = 0;         /* records */
 	uint32_t *tile_count = nullptr; uint64_t tile_cap = 0;
 	uint32_t *kcap = nullptr; uint64_t *koff = nullptr; uint64_t kcap_n = 0, koff_n = 0;
+	/* work units of batches that contain reads longer than one tile */
+	uint32_t *ucnt = nullptr; uint64_t *ufirst = nullptr, *u_start = nullptr, *u_end = nullptr, *u_read = nullptr;
+	uint64_t ucnt_n = 0, ufirst_n = 0, units_n = 0; unsigned int *umax = nullptr;
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr; uint64_t uw_cap = 0, us_cap = 0;
 	/* timing */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -221,11 +224,44 @@ void time_end(kmr_handle *h, int which, hipEvent_t a, hipEvent_t b) {
 
 const size_t EXTRACT_SMEM = (size_t)WAVES_PER_BLOCK * 2 * TILE_BUF;
 
+int exclusive_scan(kmr_handle *h, const uint32_t *in, uint64_t n, uint64_t *out);
+
+/* If the batch holds reads longer than one LDS tile, cut them into work units (see ReadsView) and point rv at them. */
+int prepare_units(kmr_handle *h, ReadsView &rv) {
+	rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
+	const uint64_t n = rv.n_reads;
+	if (n == 0) return 0;
+	if (!h->umax) HIPCHK(h, hipMalloc((void **)&h->umax, 4));
+	HIPCHK(h, hipMemsetAsync(h->umax, 0, 4, h->stream));
+	if (!h->ucnt || h->ucnt_n < n + 1) { if (h->ucnt) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->ucnt); } h->ucnt = nullptr; HIPCHK(h, hipMalloc((void **)&h->ucnt, 4 * (n + 1))); h->ucnt_n = n + 1; }
+	hipLaunchKernelGGL(unit_count_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, rv.offsets, n, h->k, (uint32_t)TILE_SPAN, h->ucnt, h->umax);
+	HIPCHK(h, hipGetLastError());
+	unsigned int mx = 0;
+	HIPCHK(h, hipMemcpyAsync(&mx, h->umax, 4, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	if (mx <= (unsigned)TILE_SPAN) return 0;                   /* the usual case: every read is one unit */
+	if (h->ext) return fail(h, KMR_ERR_UNSUPPORTED, "reads longer than one tile are not segmented for extension tallies yet");
+	if (!h->ufirst || h->ufirst_n < n + 1) { if (h->ufirst) hipFree(h->ufirst); h->ufirst = nullptr; HIPCHK(h, hipMalloc((void **)&h->ufirst, 8 * (n + 1))); h->ufirst_n = n + 1; }
+	int rc = exclusive_scan(h, h->ucnt, n, h->ufirst); if (rc) return rc;
+	uint64_t U = 0;
+	HIPCHK(h, hipMemcpy(&U, h->ufirst + n, 8, hipMemcpyDeviceToHost));
+	if (h->units_n < U) {
+		if (h->u_start) { hipFree(h->u_start); hipFree(h->u_end); hipFree(h->u_read); }
+		h->u_start = h->u_end = h->u_read = nullptr; h->units_n = 0;
+		HIPCHK(h, hipMalloc((void **)&h->u_start, 8 * U)); HIPCHK(h, hipMalloc((void **)&h->u_end, 8 * U)); HIPCHK(h, hipMalloc((void **)&h->u_read, 8 * U));
+		h->units_n = U;
+	}
+	hipLaunchKernelGGL(unit_fill_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, rv.offsets, n, h->k, (uint32_t)TILE_SPAN, h->ufirst, h->u_start, h->u_end, h->u_read);
+	HIPCHK(h, hipGetLastError());
+	rv.u_start = h->u_start; rv.u_end = h->u_end; rv.u_read = h->u_read; rv.n_units = U;
+	return 0;
+}
+
 template <int W, bool EXT, class Op> int launch_extract(kmr_handle *h, const ReadsView &rv, const Op &op, uint64_t max_blocks = 0) {
 	static bool attr_set = false;
 	auto kern = extract_kernel<W, EXT, Op>;
 	if (!attr_set) { HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXTRACT_SMEM)); attr_set = true; }
-	const uint64_t tiles = (rv.n_reads + 63) / 64;
+	const uint64_t tiles = ((rv.u_start ? rv.n_units : rv.n_reads) + 63) / 64;
 	uint64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
 	if (blocks == 0) return 0;
 	if (max_blocks && blocks > max_blocks) blocks = max_blocks;      /* wavefronts then walk several tiles */
@@ -254,6 +290,7 @@ template <int W, bool EXT> int add_reads_dev_t(kmr_handle *h, const ReadsView &r
 		rv.offsets = rvAll.offsets + r; rv.n_reads = m;
 		rv.discarded = rvAll.discarded ? rvAll.discarded + r : nullptr;
 		rv.first_read_idx = rvAll.first_read_idx + r;
+		rc = prepare_units(h, rv); if (rc) return rc;
 		InsertOp<W, EXT> op; op.table = table_of<W>(h);
 		hipEvent_t a, b; time_begin(h, 0, &a, &b);
 		rc = launch_extract<W, EXT>(h, rv, op);
@@ -557,15 +594,17 @@ template <int W> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll
 		rv.offsets = rvAll.offsets + r; rv.n_reads = m;
 		rv.discarded = rvAll.discarded ? rvAll.discarded + r : nullptr;
 		rv.first_read_idx = rvAll.first_read_idx + r;
-		/* k-mer capacity of every read -> region of each 64-read tile in the linear buffer */
-		int rc = ensure_buf(h, h->kcap, h->kcap_n, m + 1, 4); if (rc) return rc;
-		rc = ensure_buf(h, h->koff, h->koff_n, m + 1, 8); if (rc) return rc;
-		hipLaunchKernelGGL(kmer_capacity_kernel, dim3(grid_for(m)), dim3(256), 0, h->stream, rv.offsets, rv.discarded, m, h->k, h->kcap);
+		/* k-mer capacity of every work unit -> region of each 64-unit tile in the linear buffer */
+		int rc = prepare_units(h, rv); if (rc) return rc;
+		const uint64_t nu = rv.u_start ? rv.n_units : m;
+		rc = ensure_buf(h, h->kcap, h->kcap_n, nu + 1, 4); if (rc) return rc;
+		rc = ensure_buf(h, h->koff, h->koff_n, nu + 1, 8); if (rc) return rc;
+		hipLaunchKernelGGL(kmer_capacity_kernel, dim3(grid_for(nu)), dim3(256), 0, h->stream, rv, h->k, h->kcap);
 		HIPCHK(h, hipGetLastError());
-		rc = exclusive_scan(h, h->kcap, m, h->koff); if (rc) return rc;
+		rc = exclusive_scan(h, h->kcap, nu, h->koff); if (rc) return rc;
 		uint64_t total_cap = 0;
-		HIPCHK(h, hipMemcpy(&total_cap, h->koff + m, 8, hipMemcpyDeviceToHost));
-		const uint64_t tiles = (m + 63) / 64;
+		HIPCHK(h, hipMemcpy(&total_cap, h->koff + nu, 8, hipMemcpyDeviceToHost));
+		const uint64_t tiles = (nu + 63) / 64;
 		rc = ensure_buf(h, h->linear, h->linear_cap, total_cap, rec_bytes(h)); if (rc) return rc;
 		rc = ensure_buf(h, h->tile_count, h->tile_cap, tiles, 4); if (rc) return rc;
 		LinearOp<W, false> op; op.records = (Record<W> *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
@@ -751,6 +790,8 @@ void free_partition_state(kmr_handle *h) {
 	pool_free(h->l1); pool_free(h->l2);
 	if (h->work_counter) hipFree(h->work_counter); if (h->linear) hipFree(h->linear); if (h->tile_count) hipFree(h->tile_count);
 	if (h->kcap) hipFree(h->kcap); if (h->koff) hipFree(h->koff);
+	if (h->ucnt) hipFree(h->ucnt); if (h->ufirst) hipFree(h->ufirst); if (h->u_start) { hipFree(h->u_start); hipFree(h->u_end); hipFree(h->u_read); } if (h->umax) hipFree(h->umax);
+	h->ucnt = nullptr; h->ufirst = nullptr; h->u_start = h->u_end = h->u_read = nullptr; h->umax = nullptr; h->ucnt_n = h->ufirst_n = h->units_n = 0;
 	if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8);
 	h->work_counter = nullptr; h->linear = nullptr; h->tile_count = nullptr; h->kcap = nullptr; h->koff = nullptr;
 	h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = nullptr; h->linear_cap = h->tile_cap = h->kcap_n = h->koff_n = h->uw_cap = h->us_cap = 0;
@@ -893,6 +934,7 @@ int kmr_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_qual
 	hipSetDevice(h->device);
 	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
 	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
+	rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
 	int rc = h->partition_mode ? add_reads_partition(h, rv, total_bases) : add_reads_dev_any(h, rv, total_bases);
 	h->stream_base += total_bases; h->reads += n_reads; h->stats.reads = h->reads;
 	return rc;
@@ -957,7 +999,8 @@ int kmr_lookup_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, 
 	HIPCHK(h, hipMalloc((void **)&dout, std::max<uint64_t>(8, 4 * outN))); HIPCHK(h, hipMalloc((void **)&doff, 8 * n_reads));
 	HIPCHK(h, hipMemsetAsync(dout, 0, 4 * outN, h->stream));
 	HIPCHK(h, hipMemcpyAsync(doff, out_offsets, 8 * n_reads, hipMemcpyHostToDevice, h->stream));
-	ReadsView rv; rv.bases = s.b; rv.quals = nullptr; rv.offsets = s.o; rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0;
+	ReadsView rv; rv.bases = s.b; rv.quals = nullptr; rv.offsets = s.o; rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0; rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
+	{ int urc = prepare_units(h, rv); if (urc) { s.release(); return urc; } }
 	switch (h->W) { case 1: rc = lookup_reads_t<1>(h, rv, dout, doff); break; case 2: rc = lookup_reads_t<2>(h, rv, dout, doff); break;
 	case 3: rc = lookup_reads_t<3>(h, rv, dout, doff); break; default: rc = lookup_reads_t<4>(h, rv, dout, doff); }
 	if (!rc) { HIPCHK(h, hipMemcpyAsync(counts_out, dout, 4 * outN, hipMemcpyDeviceToHost, h->stream)); rc = sync_state(h); }
@@ -985,7 +1028,8 @@ int kmr_score_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, u
 	HIPCHK(h, hipMalloc((void **)&dto, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dtl, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dsc, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dwt, n_reads));
 	HIPCHK(h, hipMemsetAsync(dcounts, 0, 4 * outN, h->stream));
 	HIPCHK(h, hipMemcpyAsync(dcoff, coff.data(), 8 * (n_reads + 1), hipMemcpyHostToDevice, h->stream));
-	ReadsView rv; rv.bases = s.b; rv.quals = nullptr; rv.offsets = s.o; rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0;
+	ReadsView rv; rv.bases = s.b; rv.quals = nullptr; rv.offsets = s.o; rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0; rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
+	{ int urc = prepare_units(h, rv); if (urc) { s.release(); return urc; } }
 	switch (h->W) { case 1: rc = lookup_reads_t<1>(h, rv, dcounts, dcoff, true); break; case 2: rc = lookup_reads_t<2>(h, rv, dcounts, dcoff, true); break;
 	case 3: rc = lookup_reads_t<3>(h, rv, dcounts, dcoff, true); break; default: rc = lookup_reads_t<4>(h, rv, dcounts, dcoff, true); }
 	if (!rc) {
@@ -1156,8 +1200,10 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
 	hipSetDevice(h->device);
 	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
 	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
+	rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
 	HIPCHK(h, hipMemsetAsync(dev_seg_counts, 0, 8 * h->cfg.world_size, h->stream));
-	int rc;
+	int rc = prepare_units(h, rv);
+	if (rc) return rc;
 #define REC(Wv, E) { RecordOp<Wv, E> op; op.records = (Record<Wv> *)dev_records; op.seg_counts = (unsigned long long *)dev_seg_counts; op.seg_capacity = seg_capacity; op.world = h->cfg.world_size; rc = launch_extract<Wv, E>(h, rv, op, 1024); }
 	switch (h->W) {
 	case 1: if (h->ext) REC(1, true) else REC(1, false) break;

@@ -70,7 +70,37 @@ struct ReadsView {
 	uint64_t n_reads;
 	uint64_t stream_base;          /* ordinal of byte 0 of this batch in the whole input */
 	uint64_t first_read_idx;
+	/* optional work units (reads longer than one LDS tile are cut into segments whose first k-mer index is a
+	 * multiple of 1024, where buildWeightedKmers restarts its weight product anyway, src/KmerReadUtils.h:204):
+	 * unit u covers bases [u_start[u], u_end[u]) of read u_read[u]; NULL = one unit per read */
+	const uint64_t *u_start, *u_end, *u_read;
+	uint64_t n_units;
 };
+
+static const uint32_t UNIT_KMERS = 9216;     /* k-mers per segment: 9 * 1024, and 9216 + 127 bases fit a tile */
+__global__ void unit_count_kernel(const uint64_t *offsets, uint64_t n, uint32_t k, uint32_t span, uint32_t *counts, unsigned int *maxLen) {
+	unsigned int mx = 0;
+	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t L = offsets[r + 1] - offsets[r];
+		mx = L > mx ? (unsigned int)(L > 0xffffffffull ? 0xffffffffu : L) : mx;
+		counts[r] = L <= span ? 1u : (uint32_t)((L - k + 1 + UNIT_KMERS - 1) / UNIT_KMERS);
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
+	if ((threadIdx.x & 63) == 0 && mx) atomicMax(maxLen, mx);
+}
+__global__ void unit_fill_kernel(const uint64_t *offsets, uint64_t n, uint32_t k, uint32_t span, const uint64_t *ufirst,
+                                 uint64_t *u_start, uint64_t *u_end, uint64_t *u_read) {
+	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t b = offsets[r], e = offsets[r + 1], L = e - b;
+		const uint64_t u0 = ufirst[r], nu = ufirst[r + 1] - u0;
+		if (L <= span) { u_start[u0] = b; u_end[u0] = e; u_read[u0] = r; continue; }
+		for (uint64_t g = 0; g < nu; g++) {
+			const uint64_t s0 = b + g * UNIT_KMERS, e0 = s0 + UNIT_KMERS + k - 1;
+			u_start[u0 + g] = s0; u_end[u0 + g] = e0 < e ? e0 : e; u_read[u0 + g] = r;
+		}
+	}
+}
 
 /* ----------------------------------------------------------------------- */
 /* device hash table: AoS slots so one probe touches one 32-byte sector      */
@@ -351,17 +381,27 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 	const bool needHash = Op::NEEDS_HASH || p.subsample > 1 || p.world > 1 || p.num_parts > 1;
 	/* a wavefront walks tiles tile0, tile0 + stride, ... (stride = all wavefronts of the grid): with a full grid
 	 * that is one tile each; Ops that keep per-wavefront state (RecordOp's owner slabs) launch fewer blocks */
-	const uint64_t n_tiles = (rv.n_reads + 63) / 64;
+	const uint64_t n_items = rv.u_start ? rv.n_units : rv.n_reads;
+	const uint64_t n_tiles = (n_items + 63) / 64;
 	for (uint64_t tile = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
 	const uint64_t r0 = tile * 64;
-	const uint32_t nr = (uint32_t)((rv.n_reads - r0) < 64 ? (rv.n_reads - r0) : 64);
+	const uint32_t nr = (uint32_t)((n_items - r0) < 64 ? (n_items - r0) : 64);
 	const bool have = (uint32_t)lane < nr;
-	uint64_t myStart = 0, myEnd = 0;
-	bool myDiscard = true;
+	uint64_t myStart = 0, myEnd = 0, myRead = 0;
+	uint32_t kfirst = 0;               /* index in the read of the unit's first k-mer */
+	bool myDiscard = true, myRefQual = false;
 	if (have) {
-		myStart = rv.offsets[r0 + lane];
-		myEnd = rv.offsets[r0 + lane + 1];
-		myDiscard = rv.discarded ? (rv.discarded[r0 + lane] != 0) : false;
+		if (rv.u_start) {
+			myStart = rv.u_start[r0 + lane]; myEnd = rv.u_end[r0 + lane]; myRead = rv.u_read[r0 + lane];
+			const uint64_t rs = rv.offsets[myRead];
+			kfirst = (uint32_t)(myStart - rs);
+			myRefQual = rv.quals && rv.offsets[myRead + 1] > rs && rv.quals[rs] == 127;
+		} else {
+			myRead = r0 + lane;
+			myStart = rv.offsets[myRead];
+			myEnd = rv.offsets[myRead + 1];
+		}
+		myDiscard = rv.discarded ? (rv.discarded[myRead] != 0) : false;
 	}
 	op.tile_begin(opst, &s_wcount[wave], r0, lane);
 
@@ -399,7 +439,8 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(Lmax, off, 64); Lmax = o > Lmax ? o : Lmax; }
 
-		const bool isRef = (rv.quals == nullptr) || (L > 0 && rq[0] == 127);   /* Read::REF_QUAL */
+		/* Read::REF_QUAL in the read's first quality char (the unit's own first char when units are whole reads) */
+		const bool isRef = (rv.quals == nullptr) || (rv.u_start ? myRefQual : (L > 0 && rq[0] == 127));
 		Roller<W> roll;
 		roll.init(k);
 		double w = 0.0;
@@ -472,7 +513,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 					const bool isLeast = key_le<W>(roll.fwd, roll.rc);
 					canon = isLeast ? roll.fwd : roll.rc;
 					hash = needHash ? key_hash<W>(canon, p.kb) : 0ull;
-					kpos = i;
+					kpos = kfirst + i;
 					bool mine = true;
 					if (Op::NEEDS_WEIGHT) {
 						if (p.subsample > 1 && hash % p.subsample != 0) mine = false;   /* owner / part filters apply to the build, not to lookups */
@@ -506,7 +547,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 					if (EXT) { leftCode = base_code(rb[i]); if (leftCode == 4) leftCode = 0; leftQ = ((isRef ? 127u : (uint32_t)rq[i]) - p.fastq_start) & 0xffu; }
 				}
 			}
-			op.emit(opst, valid, p, canon, hash, o, rv.first_read_idx + r0 + lane, kpos, nClaimed, fail);
+			op.emit(opst, valid, p, canon, hash, o, rv.first_read_idx + myRead, kpos, nClaimed, fail);
 		}
 		}
 		done += n;

@@ -98,10 +98,13 @@ template <int W, bool EXT> struct LinearOp {
 template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const LinearOp<W, EXT> &) { return false; }
 template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const LinearOp<W, EXT> &) { return 0; }
 
-__global__ void kmer_capacity_kernel(const uint64_t *offsets, const uint8_t *discarded, uint64_t n, uint32_t k, uint32_t *cap) {
-	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
-		const uint64_t L = offsets[r + 1] - offsets[r];
-		cap[r] = (discarded && discarded[r]) ? 0u : (L >= k ? (uint32_t)(L - k + 1) : 0u);
+/* k-mer capacity of every work unit (a read, or a segment of a long read) */
+__global__ void kmer_capacity_kernel(ReadsView rv, uint32_t k, uint32_t *cap) {
+	const uint64_t n = rv.u_start ? rv.n_units : rv.n_reads;
+	for (uint64_t u = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u < n; u += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t r = rv.u_start ? rv.u_read[u] : u;
+		const uint64_t L = rv.u_start ? rv.u_end[u] - rv.u_start[u] : rv.offsets[u + 1] - rv.offsets[u];
+		cap[u] = (rv.discarded && rv.discarded[r]) ? 0u : (L >= k ? (uint32_t)(L - k + 1) : 0u);
 	}
 }
 

@@ -239,10 +239,41 @@ def test_histogram():
     assert np.allclose(wo, wp, rtol=1e-3, atol=1.0)
 
 
-def test_read_longer_than_tile_is_an_error():
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k", [31, 51])
+def test_reads_longer_than_a_tile_are_segmented(k, mode):
+    """Reads beyond the 9 952-base LDS tile are cut into segments that start at k-mer indices which are
+    multiples of 1024 -- where buildWeightedKmers restarts its weight product (src/KmerReadUtils.h:204) -- so
+    weights, and with them the counted k-mers, stay bit-exact."""
+    rng = np.random.default_rng(k)
+    lens = [30000, 9953, 16000, 200, 9952, 25000, 150, 12345]
+    seqs, quals = [], []
+    genome = rng.integers(0, 4, 40000)
+    qv = np.array([40, 30, 20, 10, 2]) + 33
+    for L in lens * 3:
+        st = int(rng.integers(0, 40000 - L)) if L < 40000 else 0
+        codes = genome[st:st + L].copy()
+        errs = rng.random(L) < 0.01
+        codes[errs] = (codes[errs] + rng.integers(1, 4, errs.sum())) & 3
+        b = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].copy()
+        b[rng.random(L) < 0.0005] = ord("N")
+        q = qv[rng.choice(5, size=L, p=[0.80, 0.10, 0.05, 0.04, 0.01])].astype(np.uint8)
+        seqs.append(b.tobytes())
+        quals.append(q.tobytes())
+    rb = ReadBatch(seqs, quals)
+    cfg = default_config(k, num_buckets_weak=512, num_buckets_singleton=2048)
+    o, p = run_both(cfg, rb, mode=mode, batches=[5])
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    counts, off = p.getCountsForReads(rb.bases, rb.offsets)
+    for i in (0, 2, 5):
+        keys, w, ext = oracle_weighted_kmers(cfg, seqs[i], quals[i])
+        assert np.array_equal(o.lookup(keys), counts[int(off[i]):int(off[i + 1])])
+
+
+def test_long_read_with_extension_values_is_rejected():
     seq = b"ACGT" * 4000
     rb = ReadBatch([seq], [b"I" * len(seq)])
-    p = product(default_config(21, num_buckets_weak=16, num_buckets_singleton=16))
+    p = product(default_config(21, value_kind=KMR_VALUE_EXT, num_buckets_weak=16, num_buckets_singleton=16))
     with pytest.raises(ka.KmerSpectrumError, match="longer"):
         add(p, rb)
 
