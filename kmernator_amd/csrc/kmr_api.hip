@@ -51,7 +51,7 @@ struct kmr_handle {
 	kmr_config cfg;
 	uint32_t k = 0, kb = 0, W = 0;
 	bool ext = false;
-	int device = 0;
+	int device = 0, ncu = 0;
 	hipStream_t stream = nullptr;
 	std::string err;
 	/* device table */
@@ -483,10 +483,22 @@ const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M rec
 const uint64_t SUB_BATCH_BASES = 1ull << 28;
 
 size_t rec_bytes(kmr_handle *h) { return 8 * h->W + 8; }
-/* partition bits per level that keep batch + staging lines inside the 160 KB of LDS */
-int max_part_bits(uint32_t W) { return W == 1 ? 10 : (W <= 3 ? 9 : 8); }
-
+/* partition kernel shape: one 1024-thread block per compute unit, 8 records per thread per batch, a
+ * 4-record write-combining line per list in LDS (see partition_direct_kernel) */
+const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
+/* partition bits per level that keep the per-list book-keeping and lines inside the 160 KB of LDS */
+int max_part_bits(uint32_t W) { return W <= 2 ? 10 : 9; }
 PoolView pool_view(kmr_handle *h, HostPool &p) { PoolView v; v.base = p.base; v.chunk_list = p.chunk_list; v.chunk_count = p.chunk_count; v.head = p.head; v.cap = p.cap; v.err = h->derr; return v; }
+template <int W, int LEVEL> int launch_partition(kmr_handle *h, const PartSource<W> &S, HostPool &pool, int grid, int bits, int shift) {
+	auto kern = partition_direct_kernel<W, LEVEL, PD_THREADS, PD_RPT, W == 1, PD_LINE>;
+	const size_t smem = partition_direct_smem_bytes<W, PD_THREADS, PD_RPT, PD_LINE>(bits);
+	if (getenv("KMR_DEBUG")) fprintf(stderr, "partition level %d W=%d bits=%d shift=%d smem=%zu grid=%d\n", LEVEL, W, bits, shift, smem, grid);
+	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+	                              (int)partition_direct_smem_bytes<W, PD_THREADS, PD_RPT, PD_LINE>(max_part_bits(W))));
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), smem, h->stream, S, pool_view(h, pool), h->work_counter, bits, shift);
+	HIPCHK(h, hipGetLastError());
+	return 0;
+}
 
 void pool_free(HostPool &p) {
 	if (p.base) hipFree(p.base); if (p.chunk_list) hipFree(p.chunk_list); if (p.chunk_count) hipFree(p.chunk_count); if (p.head) hipFree(p.head);
@@ -541,18 +553,24 @@ int zero_work_counter(kmr_handle *h) {
 	return 0;
 }
 
-int part_grid(kmr_handle *h) {
-	hipDeviceProp_t pr; int ncu = 256;
-	if (hipGetDeviceProperties(&pr, h->device) == hipSuccess) ncu = pr.multiProcessorCount;
-	return ncu * 2;
+int num_cus(kmr_handle *h) {
+	if (h->ncu <= 0) {
+		hipDeviceProp_t pr; h->ncu = 256;
+		if (hipGetDeviceProperties(&pr, h->device) == hipSuccess) h->ncu = pr.multiProcessorCount;
+	}
+	return h->ncu;
 }
+int part_grid(kmr_handle *h) { return num_cus(h) * 2; }
+/* the partition kernel wants a compute unit to itself: every (block, list) pair is a write stream, and the fewer of
+ * those there are the longer the runs each batch appends */
+int partition_blocks(kmr_handle *h) { return getenv("KMR_PART_BLOCKS") ? atoi(getenv("KMR_PART_BLOCKS")) : num_cus(h); }
 
 /* level-1 partition of a linear record buffer into h->l1 */
 template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, const uint64_t *ext_start, const uint32_t *ext_count,
                                       uint64_t n_ext, uint32_t ext_stride, uint64_t ext_len, uint64_t total, uint64_t max_records,
                                       unsigned long long *valid_counter = nullptr) {
 	if (n_ext == 0) return 0;
-	const int grid = (int)std::min<uint64_t>(part_grid(h), n_ext);
+	const int grid = (int)std::min<uint64_t>(partition_blocks(h), n_ext);
 	if (!h->l1.base) {
 		const uint64_t est = std::max<uint64_t>(max_records, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
 		const uint64_t launches = est / std::max<uint64_t>(1, max_records) + 2;
@@ -565,17 +583,11 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	PartSource<W> S; memset(&S, 0, sizeof(S));
 	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
 	S.valid_counter = valid_counter;
-	auto kern = partition_kernel<W, 1>;
-	const size_t smem = partition_smem_bytes<W>(h->bits1);
-	if (getenv("KMR_DEBUG")) fprintf(stderr, "partition_level1 W=%d bits1=%d smem=%zu max=%zu grid=%d n_ext=%llu\n", W, h->bits1, smem, partition_smem_bytes<W>(max_part_bits(W)), grid, (unsigned long long)n_ext);
-	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)partition_smem_bytes<W>(max_part_bits(W))));
-	hipLaunchKernelGGL(kern, dim3(grid), dim3(PART_THREADS), smem, h->stream, S, pool_view(h, h->l1), h->work_counter, h->bits1, 0);
-	HIPCHK(h, hipGetLastError());
-	return 0;
+	return launch_partition<W, 1>(h, S, h->l1, grid, h->bits1, 0);
 }
 
 void choose_bits1(kmr_handle *h, uint64_t records_hint) {
-	/* total bits aim at TARGET_LIST_RECORDS per final list; level 2 takes up to MAX_PART_BITS of them */
+	/* total bits aim at TARGET_LIST_RECORDS per final list; level 2 takes up to max_part_bits(W) of them */
 	uint64_t est = std::max<uint64_t>(records_hint, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
 	const int mb = max_part_bits(h->W);
 	int T = 0; while (T < 2 * mb && (est >> T) > TARGET_LIST_RECORDS) T++;
@@ -647,6 +659,19 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, ui
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		HIPCHK(h, hipMemcpy(hv, d, 16, hipMemcpyDeviceToHost)); hipFree(d);
 		fprintf(stderr, "build_csr: lists %llu chunks %u valid %llu records %llu (expected %llu)\n", (unsigned long long)nl, used, hv[1], hv[0], (unsigned long long)h->stats.raw_good_kmers);
+		unsigned long long *v, vv[3] = {0, 0, 0};
+		int bits = 0; while ((1ull << bits) < nl) bits++;
+		HIPCHK(h, hipMalloc((void **)&v, 24)); HIPCHK(h, hipMemset(v, 0, 24));
+		PoolView pvw = pool_view(h, p);
+		switch (h->W) {
+		case 1: hipLaunchKernelGGL(verify_lists_kernel<1>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, v, v + 1, v + 2); break;
+		case 2: hipLaunchKernelGGL(verify_lists_kernel<2>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, v, v + 1, v + 2); break;
+		case 3: hipLaunchKernelGGL(verify_lists_kernel<3>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, v, v + 1, v + 2); break;
+		default: hipLaunchKernelGGL(verify_lists_kernel<4>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, v, v + 1, v + 2); break;
+		}
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+		HIPCHK(h, hipMemcpy(vv, v, 24, hipMemcpyDeviceToHost)); hipFree(v);
+		fprintf(stderr, "verify_lists: records via CSR %llu misfiled %llu zero-weight %llu\n", vv[0], vv[1], vv[2]);
 	}
 	return 0;
 }
@@ -683,11 +708,8 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		rc = zero_work_counter(h); if (rc) return rc;
 		PartSource<W> S; memset(&S, 0, sizeof(S));
 		S.src = pool_view(h, h->l1); S.list_chunks = lc1; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size();
-		auto kern = partition_kernel<W, 2>;
-		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)partition_smem_bytes<W>(max_part_bits(W))));
-		const int grid = (int)std::min<uint64_t>(part_grid(h), ib.size());
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(PART_THREADS), partition_smem_bytes<W>(bits2), h->stream, S, pool_view(h, h->l2), h->work_counter, bits2, h->bits1);
-		HIPCHK(h, hipGetLastError());
+		const int grid = (int)std::min<uint64_t>(partition_blocks(h), ib.size());
+		rc = launch_partition<W, 2>(h, S, h->l2, grid, bits2, h->bits1); if (rc) return rc;
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		hipFree(dib); hipFree(die); hipFree(dil);
 	}
@@ -714,7 +736,18 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = nullptr; out.scursor = cursors + 1; out.scap = h->us_cap;
 	out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
 	rc = zero_work_counter(h); if (rc) return rc;
-	{
+	const int count_reps = getenv("KMR_COUNT_CHECK") ? atoi(getenv("KMR_COUNT_CHECK")) : 0;
+	for (int cr = 0; cr <= count_reps; cr++) {
+		if (cr) {      /* debugging aid: the count pass is repeated on the same input and must report the same numbers */
+			FinalizeCounters c0; unsigned long long cur0[2];
+			HIPCHK(h, hipStreamSynchronize(h->stream));
+			HIPCHK(h, hipMemcpy(&c0, fc, sizeof(c0), hipMemcpyDeviceToHost)); HIPCHK(h, hipMemcpy(cur0, cursors, 16, hipMemcpyDeviceToHost));
+			fprintf(stderr, "count pass %d: unique %llu singletons %llu weak_kept %llu sing_kept %llu slots %llu/%llu\n", cr - 1, (unsigned long long)c0.unique,
+			        (unsigned long long)c0.singletons, (unsigned long long)c0.weak_kept, (unsigned long long)c0.sing_kept, cur0[0], cur0[1]);
+			HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
+			HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
+			rc = zero_work_counter(h); if (rc) return rc;
+		}
 		auto kern = count_kernel<W, false, COUNT_LOG2S>;
 		const size_t smem = count_smem_bytes<W, COUNT_LOG2S>();
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

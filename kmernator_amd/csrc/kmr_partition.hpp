@@ -8,8 +8,8 @@
  * streaming one and all atomics are LDS atomics:
  *
  *   extract_kernel<LinearOp>      reads -> compacted 16-byte records {key, signed weight, ordinal}
- *   partition_kernel<LEVEL 1>     records -> P1 chunked lists      (bits 63.. of a mix of the key)
- *   partition_kernel<LEVEL 2>     each list -> P2 sub-lists        (next bits)
+ *   partition_direct_kernel<1>   records -> P1 chunked lists      (bits 63.. of a mix of the key)
+ *   partition_direct_kernel<2>   each list -> P2 sub-lists        (next bits)
  *   count_kernel                  each final list -> LDS hash table -> (key,count,fwd,weight,first)
  *                                 -> kept entries + per-bucket counts
  *   scan / entry_scatter / sort   entries -> bucketed sorted maps (same layout as the table path)
@@ -18,10 +18,12 @@
  * src/KmerSpectrum.h:1578-1668, src/KmerTrackingData.h:427,517,641) and purgeMinDepth
  * (:1805-1815); the partition function is private (results do not depend on it).
  *
- * Write combining: a block sorts a batch of 2048 records by destination list in LDS
- * (counting sort), then one lane per list appends the run to that list's private chunk
- * through a 64-byte staging line, so HBM only sees whole 64-byte sectors.  Lists are
- * linked from fixed 64-record chunks handed out by one atomic per chunk.
+ * Write combining: one 1024-thread block per compute unit holds a batch of 8192 records in
+ * registers, counts it per destination list in LDS, lets one thread per list plan where the
+ * list's run goes, and then every thread stores its own records at (run base + rank).  A
+ * list only ever sends whole groups of 4 records (64 bytes for 16-byte records) to HBM; the
+ * remainder waits in a per-list LDS line for the next batch.  Lists are linked from fixed
+ * 64-record chunks which a block takes from the pool 64 at a time.
  */
 #ifndef KMR_PARTITION_HPP_
 #define KMR_PARTITION_HPP_
@@ -30,13 +32,11 @@
 
 namespace kmr {
 
-static const int CH = 64;                    /* records per chunk */
+#ifndef KMR_CH
+#define KMR_CH 64
+#endif
+static const int CH = KMR_CH;                /* records per chunk */
 static const uint32_t NO_CHUNK = 0xffffffffu;
-static const int PART_THREADS = 512;
-/* records per thread per batch: the LDS batch buffer is PART_THREADS * rpt records */
-template <int W> __host__ __device__ constexpr int part_rpt() { return W == 1 ? 8 : 4; }
-#define PART_RPT (part_rpt<W>())
-#define PART_BATCH (PART_THREADS * PART_RPT)
 enum { ERR_POOL_FULL = 8, ERR_ENTRIES_FULL = 16 };
 
 struct PoolView {
@@ -126,57 +126,57 @@ template <int W> struct PartSource {
 	uint64_t n_items;
 };
 
-template <int W> struct PartShared {
-	/* sized by the kernel: see partition_smem_bytes() */
-};
-
-static const int MAX_PART_BITS = 10;
-template <int W>
-__host__ __device__ inline size_t partition_smem_bytes(int bits) {
-	return (size_t)PART_BATCH * sizeof(Record<W>)                 /* sorted batch */
-	       + (size_t)PART_BATCH * 2                               /* list id of every sorted record */
-	       + ((size_t)1 << bits) * 4 * 7                          /* hist, pstart, cur, cnt, pos0, c0, xoff */
-	       + ((size_t)PART_BATCH / CH + ((size_t)1 << bits) + 8) * 4   /* chunks opened by one batch beyond the first */
+/* ------------------------------------------------------------------ partition kernel */
+/* Per batch (THREADS * RPT records held in registers, RPT per thread):
+ *   1. hist[list]++ for every record (LDS atomics);
+ *   2. one thread per list: n = hist[list] new records + the sn records waiting in the list's write-combining
+ *      line; the largest multiple of G among them leaves the block now.  plan_run books their positions in the
+ *      list's open chunk and in freshly opened chunks, and the planning thread itself copies the waiting records
+ *      out of the LDS line;
+ *   3. every thread takes a rank per record from an LDS cursor (hist again) and stores the record straight from
+ *      its registers to chunk position (run base + rank), or into the LDS line if it belongs to the remainder.
+ * Nothing is sorted or staged besides the G-record lines, so LDS holds ~8 words + one line per list and the
+ * block is 1024 threads wide: the number of (block, list) write streams, which is what HBM efficiency of this
+ * scatter depends on, stays at CUs * lists.  Measured on MI355X at 1024 lists and 16-byte records: 2.0 ms per
+ * 2e8 records against 3.1 ms for an LDS-sorted 4096-record batch with two blocks per CU (tools/part_bench.hip). */
+template <int W, int THREADS, int RPT, int G>
+__host__ __device__ inline size_t partition_direct_smem_bytes(int bits) {
+	return ((size_t)1 << bits) * 4 * (G ? 8 : 6)                               /* hist, cur, cnt, pos0, c0, xoff (, stage_n, stage_plan) */
+	       + ((size_t)THREADS * RPT / CH + ((size_t)1 << bits) + 8) * 4        /* chunks opened by one batch beyond the first */
+	       + ((size_t)G << bits) * sizeof(Record<W>)                            /* write-combining line of every list */
 	       + 64;
 }
 
-/* LOG2P = bits of this level (<= MAX_PART_BITS), SHIFT = hash bits consumed by earlier levels */
-template <int W, int LEVEL, int DBG = 0>
-__global__ __launch_bounds__(PART_THREADS)
-void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter, const int LOG2P, const int SHIFT) {
+template <int W, int LEVEL, int THREADS, int RPT, bool PREFETCH, int G>
+__global__ __launch_bounds__(THREADS)
+void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter, const int LOG2P, const int SHIFT) {
 	const int P = 1 << LOG2P;
-	constexpr int G = 4;
+	constexpr int BATCH = THREADS * RPT;
 	typedef Record<W> Rec;
 	extern __shared__ __attribute__((aligned(16))) uint8_t psm[];
-	Rec *sorted = (Rec *)psm;
-	uint16_t *spid = (uint16_t *)(sorted + PART_BATCH);          /* list id of sorted[i] */
-	uint32_t *hist = (uint32_t *)(spid + PART_BATCH);
-	uint32_t *pstart = hist + P;
-	uint32_t *cur = pstart + P;       /* open chunk of each list (NO_CHUNK if none)          */
+	uint32_t *hist = (uint32_t *)psm;
+	uint32_t *cur = hist + P;         /* open chunk of each list (NO_CHUNK if none)          */
 	uint32_t *cnt = cur + P;          /* records already in it                                */
 	uint32_t *pos0 = cnt + P;         /* per batch: position of the run's first record        */
 	uint32_t *c0 = pos0 + P;          /* per batch: chunk that position falls into            */
 	uint32_t *xoff = c0 + P;          /* per batch: index of the run's further chunks in extra[] */
-	uint32_t *extra = xoff + P;
+	uint32_t *stage_n = xoff + P;                    /* G: records waiting in the list's write-combining line  */
+	uint32_t *stage_plan = stage_n + (G ? P : 0);    /* G: per batch, (records that go out << 8) | waiting before */
+	uint32_t *extra = stage_plan + (G ? P : 0);
+	Rec *stage = (Rec *)(((uintptr_t)(extra + BATCH / CH + P + 8) + 15) & ~(uintptr_t)15);
 	__shared__ uint32_t s_item;
-	__shared__ uint32_t s_scan[PART_THREADS];
 	__shared__ uint32_t s_nextra;
-	/* chunk allocator: one device atomic hands a block SLAB chunks; chunk ids are then taken by an LDS
-	 * counter through a small ring of slab bases (one word of device memory saturates at ~90 M atomics/s,
-	 * which a per-chunk atomic from every block would hit) */
 	constexpr uint32_t SLAB = 64, RING = 128;
 	__shared__ uint32_t s_ring[RING];
-	__shared__ uint32_t s_alloc, s_filled;      /* chunks taken / chunks made available so far */
+	__shared__ uint32_t s_alloc, s_filled;
 	const int t = threadIdx.x;
 
-	for (int p = t; p < P; p += PART_THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; }
+	for (int p = t; p < P; p += THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; hist[p] = 0; if (G) stage_n[p] = 0; }
 	if (t == 0) { s_alloc = 0; s_filled = 0; s_nextra = 0; }
 	__syncthreads();
 
-	/* called by thread 0 between batches: keep a few times the average need of one batch (PART_BATCH/CH chunks)
-	 * ready; a batch that needs more falls back to the device counter in alloc_chunk */
 	auto top_up = [&]() {
-		const uint32_t want = 3 * SLAB;
+		const uint32_t want = 2 * (BATCH / CH) + SLAB;
 		if (s_alloc > s_filled) s_alloc = s_filled;
 		const uint32_t have = s_filled - s_alloc;
 		if (have < want) {
@@ -193,20 +193,13 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 		out.chunk_list[c] = lid;
 		return c;
 	};
-
 	auto chunk_ptr = [&](uint32_t c) -> Rec * { return (Rec *)(out.base + (size_t)c * CH * sizeof(Rec)); };
-
-	/* Book-keeping for the run of n new records of list p: they continue the list's open chunk at position
-	 * cnt[p] and spill into freshly opened chunks.  Nothing is staged: store_batch writes every record of the
-	 * sorted batch straight to its slot (runs are contiguous, so neighbouring lanes write neighbouring 16-byte
-	 * slots); a 64-byte sector that a run leaves half written is completed by the same block's next batch
-	 * while it is still in the XCD's L2. */
 	auto plan_run = [&](int p, uint32_t lid, uint32_t n) {
 		uint32_t c = cur[p], filled = cnt[p];
 		if (c == NO_CHUNK) { c = alloc_chunk(lid); filled = 0; }
 		pos0[p] = filled; c0[p] = c;
-		const uint32_t endpos = filled + n;                 /* positions [filled, endpos) */
-		const uint32_t nextra = endpos > (uint32_t)CH ? (endpos - 1) / CH : 0;   /* chunks beyond the first */
+		const uint32_t endpos = filled + n;
+		const uint32_t nextra = endpos > (uint32_t)CH ? (endpos - 1) / CH : 0;
 		uint32_t last = c;
 		if (nextra) {
 			const uint32_t xo = atomicAdd(&s_nextra, nextra);
@@ -218,97 +211,105 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 				if (q + 1 < nextra && last != NO_CHUNK) out.chunk_count[last] = CH;
 			}
 		}
-		uint32_t rem = endpos - nextra * CH;                 /* records in the last chunk: 1..CH */
+		uint32_t rem = endpos - nextra * CH;
 		if (rem == (uint32_t)CH) { if (last != NO_CHUNK) out.chunk_count[last] = CH; last = NO_CHUNK; rem = 0; }
 		cur[p] = last; cnt[p] = rem;
 	};
-	auto store_batch = [&](uint32_t total) {
-		for (uint32_t i = t; i < total; i += PART_THREADS) {
-			const uint32_t p = spid[i];
-			const uint32_t pos = pos0[p] + (i - pstart[p]);
-			const uint32_t q = pos / CH;
-			const uint32_t c = q == 0 ? c0[p] : extra[xoff[p] + q - 1];
-			if (c != NO_CHUNK) chunk_ptr(c)[pos % CH] = sorted[i];
+	auto flush_all = [&](uint32_t lid_base) {
+		if (G) {
+			/* the waiting records go out as a last (short) run */
+			for (int p = t; p < P; p += THREADS) {
+				const uint32_t sn = stage_n[p];
+				if (sn) {
+					plan_run(p, lid_base + p, sn);
+					const uint32_t c = c0[p];
+					if (c != NO_CHUNK) for (uint32_t j = 0; j < sn; j++) chunk_ptr(c)[pos0[p] + j] = stage[(size_t)p * G + j];
+					stage_n[p] = 0;
+				}
+			}
+			if (t == 0) s_nextra = 0;
 		}
-	};
-	auto flush_all = [&](uint32_t) {
-		for (int p = t; p < P; p += PART_THREADS) {
+		for (int p = t; p < P; p += THREADS) {
 			const uint32_t c = cur[p];
 			if (c != NO_CHUNK) out.chunk_count[c] = cnt[p];
 			cur[p] = NO_CHUNK; cnt[p] = 0;
 		}
 	};
-
-	/* sort the batch held in registers by destination and hand the runs out */
-	auto scatter_batch = [&](Rec (&r)[PART_RPT], uint32_t (&pid)[PART_RPT], uint32_t lid_base) {
-		if (DBG == 2) { uint32_t acc = 0;
-#pragma unroll
-			for (int i = 0; i < PART_RPT; i++) acc += pid[i];
-			if (acc == 0x12345u) hist[0] = acc; return; }
-		for (int p = t; p < P; p += PART_THREADS) hist[p] = 0;
+	/* hist[] is all zero on entry and on exit */
+	auto scatter_batch = [&](Rec (&r)[RPT], uint32_t (&pid)[RPT], uint32_t lid_base) {
 		if (t == 0) top_up();
-		__syncthreads();
 #pragma unroll
-		for (int i = 0; i < PART_RPT; i++) if (pid[i] != NO_CHUNK) atomicAdd(&hist[pid[i]], 1u);
+		for (int i = 0; i < RPT; i++) if (pid[i] != NO_CHUNK) atomicAdd(&hist[pid[i]], 1u);
 		__syncthreads();
-		/* exclusive scan of hist -> pstart (P / PART_THREADS consecutive entries per thread) */
-		constexpr int MAXPER = (1 << MAX_PART_BITS) / PART_THREADS;
-		const int PER = P / PART_THREADS > 0 ? P / PART_THREADS : 1;
-		uint32_t loc[MAXPER], sum = 0;
-#pragma unroll
-		for (int i = 0; i < MAXPER; i++) { int p = t * PER + i; loc[i] = (i < PER && p < P) ? hist[p] : 0; sum += loc[i]; }
-		s_scan[t] = sum;
-		__syncthreads();
-		for (int o = 1; o < PART_THREADS; o <<= 1) {
-			uint32_t v = t >= o ? s_scan[t - o] : 0;
-			__syncthreads();
-			s_scan[t] += v;
-			__syncthreads();
+		for (int p = t; p < P; p += THREADS) {
+			const uint32_t n = hist[p];
+			if (G) {
+				/* only whole groups of G records (aligned 16*G bytes: chunk positions stay multiples of G) leave
+				 * the block; the remainder waits in the list's LDS line for the next batch */
+				if (n) {
+					const uint32_t sn = stage_n[p], m = sn + n, nout = m / G * G;
+					stage_plan[p] = nout << 8 | sn;
+					stage_n[p] = m - nout;
+					if (nout) {
+						plan_run(p, lid_base + p, nout);
+						const uint32_t c = c0[p];
+						if (c != NO_CHUNK) for (uint32_t j = 0; j < sn; j++) chunk_ptr(c)[pos0[p] + j] = stage[(size_t)p * G + j];
+					}
+					hist[p] = 0;
+				}
+			} else if (n) { plan_run(p, lid_base + p, n); hist[p] = 0; }
 		}
-		uint32_t run = s_scan[t] - sum;
-#pragma unroll
-		for (int i = 0; i < MAXPER; i++) { int p = t * PER + i; if (i < PER && p < P) { pstart[p] = run; run += loc[i]; } }
-		__syncthreads();
-		/* reuse hist as the running cursor */
-		for (int p = t; p < P; p += PART_THREADS) hist[p] = pstart[p];
 		__syncthreads();
 #pragma unroll
-		for (int i = 0; i < PART_RPT; i++) if (pid[i] != NO_CHUNK) { uint32_t pos = atomicAdd(&hist[pid[i]], 1u); sorted[pos] = r[i]; spid[pos] = (uint16_t)pid[i]; }
-		__syncthreads();
-		if (DBG != 1) {
-			for (int p = t; p < P; p += PART_THREADS) {
-				const uint32_t n = hist[p] - pstart[p];
-				if (n) plan_run(p, lid_base + p, n);
+		for (int i = 0; i < RPT; i++) if (pid[i] != NO_CHUNK) {
+			const uint32_t p = pid[i];
+			uint32_t rank = atomicAdd(&hist[p], 1u);
+			if (G) {
+				const uint32_t sp = stage_plan[p], nout = sp >> 8;
+				rank += sp & 0xff;
+				if (rank >= nout) { stage[(size_t)p * G + (rank - nout)] = r[i]; continue; }
 			}
-			__syncthreads();
-			if (DBG != 3) store_batch(s_scan[PART_THREADS - 1]);      /* inclusive scan total = records in the batch */
-			if (t == 0) s_nextra = 0;
+			const uint32_t pos = pos0[p] + rank;
+			const uint32_t q = pos / CH;
+			const uint32_t c = q == 0 ? c0[p] : extra[xoff[p] + q - 1];
+			if (c != NO_CHUNK) chunk_ptr(c)[pos % CH] = r[i];
 		}
+		__syncthreads();
+		for (int p = t; p < P; p += THREADS) hist[p] = 0;
+		if (t == 0) s_nextra = 0;
 		__syncthreads();
 	};
 
-	/* the loads of batch i+1 are issued before batch i is sorted and flushed (register double buffering), so
-	 * the HBM read latency overlaps the LDS work of the current batch */
-	Rec r[PART_RPT], rn[PART_RPT];
-	uint32_t pid[PART_RPT], pidn[PART_RPT];
+	/* with PREFETCH the loads of batch i+1 are issued before batch i is counted and stored (register double
+	 * buffering), so a block that has a compute unit to itself still overlaps its reads with its writes */
+	Rec r[RPT], rn[PREFETCH ? RPT : 1];
+	uint32_t pid[RPT], pidn[PREFETCH ? RPT : 1];
 	auto pid_of = [&](const Rec &x) -> uint32_t { return LOG2P ? (uint32_t)(part_hash<W>(x.key) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u; };
 
 	if (LEVEL == 1) {
-		/* extents are handed out dynamically (EBATCH at a time) so ragged tiles balance; their batches are
-		 * listed in LDS first so the prefetch can run across extent boundaries */
+		/* extents are handed out dynamically (EBATCH at a time) so ragged tiles balance.  Thread 0 cuts them into
+		 * pieces of at most BATCH records and packs consecutive pieces into groups of at most BATCH records: one
+		 * group = one batch (a tile of short reads is about half a batch). */
 		constexpr uint32_t EBATCH = 8, MAXB = 64;
 		__shared__ unsigned long long s_bstart[MAXB];
-		__shared__ uint32_t s_bcount[MAXB];
-		__shared__ uint32_t s_nb;
+		__shared__ uint32_t s_bcount[MAXB], s_bslot[MAXB], s_gfirst[MAXB + 1];
+		__shared__ uint32_t s_ng;
 		__shared__ unsigned long long s_ecur, s_eoff;
-		unsigned long long nvalid = 0;      /* records that are not exchange holes */
-		auto load1 = [&](uint32_t bi, Rec (&rr)[PART_RPT], uint32_t (&pp)[PART_RPT]) {
-			const uint64_t start = s_bstart[bi]; const uint32_t n = s_bcount[bi];
+		unsigned long long nvalid = 0;
+		auto load1 = [&](uint32_t g, auto &rr, auto &pp) {
 #pragma unroll
-			for (int i = 0; i < PART_RPT; i++) {
-				const uint32_t idx = (uint32_t)i * PART_THREADS + t;
-				pp[i] = NO_CHUNK;
-				if (idx < n) { rr[i] = S.linear[start + idx]; if (rr[i].w != 0.0f) { pp[i] = pid_of(rr[i]); nvalid++; } }
+			for (int i = 0; i < RPT; i++) pp[i] = NO_CHUNK;
+			const uint32_t b1 = s_gfirst[g + 1];
+			for (uint32_t bj = s_gfirst[g]; bj < b1; bj++) {
+				const uint64_t start = s_bstart[bj]; const uint32_t n = s_bcount[bj], first = s_bslot[bj];
+#pragma unroll
+				for (int i = 0; i < RPT; i++) {
+					const uint32_t slot = (uint32_t)i * THREADS + t;
+					if (slot >= first && slot < first + n) {
+						rr[i] = S.linear[start + (slot - first)];
+						if (rr[i].w != 0.0f) { pp[i] = pid_of(rr[i]); nvalid++; }
+					}
+				}
 			}
 		};
 		for (;;) {
@@ -316,47 +317,57 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 			__syncthreads();
 			const uint64_t efirst = s_item;
 			if (efirst >= S.n_ext) break;
-			/* the batches of these extents are listed MAXB at a time (an extent can be a tile of long reads) */
 			if (t == 0) { s_ecur = efirst; s_eoff = 0; }
 			for (;;) {
 				__syncthreads();
 				if (t == 0) {
-					uint32_t nb = 0;
+					uint32_t nb = 0, ng = 0, filled = BATCH;       /* filled == BATCH: no group open */
 					uint64_t e = s_ecur, off = s_eoff;
 					while (e < efirst + EBATCH && e < S.n_ext && nb < MAXB) {
 						uint64_t start, n;
 						if (S.ext_start) { start = S.ext_start[e * S.ext_stride]; n = S.ext_count[e]; }
 						else { start = e * S.ext_len; n = S.total - start < S.ext_len ? S.total - start : S.ext_len; }
-						while (off < n && nb < MAXB) { s_bstart[nb] = start + off; s_bcount[nb] = (uint32_t)(n - off < (uint64_t)PART_BATCH ? n - off : (uint64_t)PART_BATCH); nb++; off += PART_BATCH; }
+						while (off < n && nb < MAXB) {
+							const uint32_t c = (uint32_t)(n - off < (uint64_t)BATCH ? n - off : (uint64_t)BATCH);
+							if (filled + c > (uint32_t)BATCH) { s_gfirst[ng++] = nb; filled = 0; }
+							s_bstart[nb] = start + off; s_bcount[nb] = c; s_bslot[nb] = filled;
+							filled += c; nb++; off += c;
+						}
 						if (off >= n) { e++; off = 0; }
 					}
-					s_ecur = e; s_eoff = off; s_nb = nb;
+					s_gfirst[ng] = nb;
+					s_ecur = e; s_eoff = off; s_ng = ng;
 				}
 				__syncthreads();
-				const uint32_t nb = s_nb;
-				if (nb == 0) break;
-				load1(0, r, pid);
-				for (uint32_t bi = 0; bi < nb; bi++) {
-					if (bi + 1 < nb) load1(bi + 1, rn, pidn);
-					scatter_batch(r, pid, 0);
-					if (bi + 1 < nb) {
+				const uint32_t ng = s_ng;
+				if (ng == 0) break;
+				if (PREFETCH) {
+					load1(0, r, pid);
+					for (uint32_t g = 0; g < ng; g++) {
+						if (g + 1 < ng) load1(g + 1, rn, pidn);
+						scatter_batch(r, pid, 0);
+						if (g + 1 < ng) {
 #pragma unroll
-						for (int i = 0; i < PART_RPT; i++) { r[i] = rn[i]; pid[i] = pidn[i]; }
+							for (int i = 0; i < RPT; i++) { r[i] = rn[PREFETCH ? i : 0]; pid[i] = pidn[PREFETCH ? i : 0]; }
+						}
 					}
+				} else {
+					for (uint32_t g = 0; g < ng; g++) { load1(g, r, pid); scatter_batch(r, pid, 0); }
 				}
 			}
 			__syncthreads();
 		}
+		__syncthreads();
 		flush_all(0);
 		if (S.valid_counter) { nvalid = wave_sum(nvalid); if ((t & 63) == 0 && nvalid) atomicAdd(S.valid_counter, nvalid); }
 	} else {
-		auto load2 = [&](uint64_t cb, uint64_t c1, Rec (&rr)[PART_RPT], uint32_t (&pp)[PART_RPT]) {
-			/* a batch = PART_BATCH/CH chunks; wave w reads chunk (i * waves + w), lane = record */
+		auto load2 = [&](uint64_t cb, uint64_t cb1, auto &rr, auto &pp) {
+			/* a batch = BATCH/CH chunks; wave w reads chunk (i * waves + w), lane = record */
 #pragma unroll
-			for (int i = 0; i < PART_RPT; i++) {
-				const uint64_t ci = cb + (uint64_t)i * (PART_THREADS / CH) + (t >> 6);
+			for (int i = 0; i < RPT; i++) {
+				const uint64_t ci = cb + (uint64_t)i * (THREADS / CH) + (t >> 6);
 				pp[i] = NO_CHUNK;
-				if (ci < c1) {
+				if (ci < cb1) {
 					const uint64_t d = S.list_chunks[ci];
 					const uint32_t c = (uint32_t)d;
 					if ((uint32_t)(t & 63) < (uint32_t)(d >> 32)) {
@@ -372,25 +383,28 @@ void partition_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter,
 			const uint64_t it = s_item;
 			__syncthreads();
 			if (it >= S.n_items) break;
-			const uint64_t c0 = S.item_begin[it], c1 = S.item_end[it];
+			const uint64_t cb0 = S.item_begin[it], cb1 = S.item_end[it];
 			const uint32_t lid_base = S.item_list[it] << LOG2P;
-			constexpr uint64_t STEP = PART_BATCH / CH;
-			if (c0 < c1) load2(c0, c1, r, pid);
-			for (uint64_t cb = c0; cb < c1; cb += STEP) {
-				if (cb + STEP < c1) load2(cb + STEP, c1, rn, pidn);
-				scatter_batch(r, pid, lid_base);
-				if (cb + STEP < c1) {
+			constexpr uint64_t STEP = BATCH / CH;
+			if (PREFETCH) {
+				if (cb0 < cb1) load2(cb0, cb1, r, pid);
+				for (uint64_t cb = cb0; cb < cb1; cb += STEP) {
+					if (cb + STEP < cb1) load2(cb + STEP, cb1, rn, pidn);
+					scatter_batch(r, pid, lid_base);
+					if (cb + STEP < cb1) {
 #pragma unroll
-					for (int i = 0; i < PART_RPT; i++) { r[i] = rn[i]; pid[i] = pidn[i]; }
+						for (int i = 0; i < RPT; i++) { r[i] = rn[PREFETCH ? i : 0]; pid[i] = pidn[PREFETCH ? i : 0]; }
+					}
 				}
+			} else {
+				for (uint64_t cb = cb0; cb < cb1; cb += STEP) { load2(cb, cb1, r, pid); scatter_batch(r, pid, lid_base); }
 			}
 			flush_all(lid_base);
 			__syncthreads();
 		}
 	}
-	/* chunks fetched but never handed out: mark them empty so the CSR pass can skip over them */
 	__syncthreads();
-	for (uint32_t idx = s_alloc + t; idx < s_filled; idx += PART_THREADS) {
+	for (uint32_t idx = s_alloc + t; idx < s_filled; idx += THREADS) {
 		const uint32_t c = s_ring[(idx / SLAB) % RING] + (idx % SLAB);
 		if (c < out.cap) { out.chunk_list[c] = NO_CHUNK; out.chunk_count[c] = 0; }
 	}
@@ -454,6 +468,28 @@ __global__ void pool_records_kernel(const uint32_t *chunk_list, const uint32_t *
 	if ((threadIdx.x & 63) == 0) { atomicAdd(total, s); atomicAdd(nvalid, v); }
 }
 
+/* debugging aid (KMR_DEBUG): walk a pool through its chunk CSR; count the records and those whose partition hash
+ * does not match the list they are filed under */
+template <int W>
+__global__ void verify_lists_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, int bits,
+                                    unsigned long long *total, unsigned long long *misfiled, unsigned long long *zero_w) {
+	typedef Record<W> Rec;
+	unsigned long long n = 0, bad = 0, zw = 0;
+	for (uint64_t l = blockIdx.x; l < n_lists; l += gridDim.x) {
+		for (uint64_t ci = list_start[l] + (threadIdx.x >> 6); ci < list_start[l + 1]; ci += blockDim.x >> 6) {
+			const uint64_t d = list_chunks[ci];
+			if ((uint32_t)(threadIdx.x & 63) < (uint32_t)(d >> 32)) {
+				const Rec r = ((const Rec *)(pool.base + (size_t)(uint32_t)d * CH * sizeof(Rec)))[threadIdx.x & 63];
+				n++;
+				if (bits && (part_hash<W>(r.key) >> (64 - bits)) != l) bad++;
+				if (r.w == 0.0f) zw++;
+			}
+		}
+	}
+	n = wave_sum(n); bad = wave_sum(bad); zw = wave_sum(zw);
+	if ((threadIdx.x & 63) == 0) { atomicAdd(total, n); atomicAdd(misfiled, bad); atomicAdd(zero_w, zw); }
+}
+
 /* ------------------------------------------------------------------ count */
 static const int COUNT_THREADS = 256;
 
@@ -490,6 +526,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 	/* output space is taken from the global cursors one slab at a time (a per-list atomic on one word would
 	 * serialise ~10^6 lists); the unused tail of a slab is marked as holes (count 0 / weight 0) */
 	__shared__ unsigned long long s_wpos, s_wend, s_spos, s_send;
+	__shared__ unsigned long long s_holeW0, s_holeW1, s_holeS0, s_holeS1;
 	__shared__ uint32_t s_stackBits[40], s_stackVal[40];
 	const int t = threadIdx.x;
 	const uint32_t vw = EXT ? 15 : 3;
@@ -611,24 +648,26 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 				}
 			}
 			__syncthreads();
-			if (s_nw && s_wpos + s_nw > s_wend) {          /* uniform: retire the rest of the slab, take a new one */
-				for (unsigned long long e = s_wpos + t; e < s_wend; e += COUNT_THREADS) out.wvals[e * vw] = 0;
-				__syncthreads();
-				if (t == 0) { const unsigned long long g = s_nw > OSLAB ? s_nw : OSLAB; s_wpos = atomicAdd(out.wcursor, g); s_wend = s_wpos + g; }
-				__syncthreads();
-			}
-			if (s_ns && s_spos + s_ns > s_send) {
-				for (unsigned long long e = s_spos + t; e < s_send; e += COUNT_THREADS) out.sweight[e] = 0;
-				__syncthreads();
-				if (t == 0) { const unsigned long long g = s_ns > OSLAB ? s_ns : OSLAB; s_spos = atomicAdd(out.scursor, g); s_send = s_spos + g; }
-				__syncthreads();
-			}
+			/* thread 0 alone does the slab book-keeping between these two barriers (the other threads must not look
+			 * at s_wpos & co. while it moves them); a slab that cannot take this list is retired and its unused
+			 * tail, shorter than the list's entry count, is handed to the block to be marked as holes */
 			if (t == 0) {
+				s_holeW0 = s_holeW1 = 0; s_holeS0 = s_holeS1 = 0;
+				if (s_nw && s_wpos + s_nw > s_wend) {
+					s_holeW0 = s_wpos; s_holeW1 = s_wend < out.wcap ? s_wend : out.wcap;
+					const unsigned long long g = s_nw > OSLAB ? s_nw : OSLAB; s_wpos = atomicAdd(out.wcursor, g); s_wend = s_wpos + g;
+				}
+				if (s_ns && s_spos + s_ns > s_send) {
+					s_holeS0 = s_spos; s_holeS1 = s_send < out.scap ? s_send : out.scap;
+					const unsigned long long g = s_ns > OSLAB ? s_ns : OSLAB; s_spos = atomicAdd(out.scursor, g); s_send = s_spos + g;
+				}
 				s_wbase = s_wpos; s_wpos += s_nw; keptW += s_nw;
 				s_sbase = s_spos; s_spos += s_ns; keptS += s_ns;
 				if (s_wend > out.wcap || s_send > out.scap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); s_nw = 0xffffffffu; }
 			}
 			__syncthreads();
+			for (unsigned long long e = s_holeW0 + t; e < s_holeW1; e += COUNT_THREADS) out.wvals[e * vw] = 0;
+			for (unsigned long long e = s_holeS0 + t; e < s_holeS1; e += COUNT_THREADS) out.sweight[e] = 0;
 			if (s_nw != 0xffffffffu) {
 #pragma unroll
 				for (int i = 0; i < S / COUNT_THREADS; i++) {
@@ -666,8 +705,8 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 		}
 	}
 	__syncthreads();
-	for (unsigned long long e = s_wpos + t; e < s_wend; e += COUNT_THREADS) out.wvals[e * vw] = 0;
-	for (unsigned long long e = s_spos + t; e < s_send; e += COUNT_THREADS) out.sweight[e] = 0;
+	for (unsigned long long e = s_wpos + t; e < s_wend && e < out.wcap; e += COUNT_THREADS) out.wvals[e * vw] = 0;
+	for (unsigned long long e = s_spos + t; e < s_send && e < out.scap; e += COUNT_THREADS) out.sweight[e] = 0;
 	uniq = wave_sum(uniq); single = wave_sum(single);
 	if ((t & 63) == 0) { if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single); }
 	if (t == 0) { if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS); }

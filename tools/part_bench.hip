@@ -1,4 +1,4 @@
-// micro-benchmark of partition_kernel variants (development tool, not part of the product)
+// micro-benchmark of partition_direct_kernel shapes (development tool, not part of the product)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -9,17 +9,19 @@ using namespace kmr;
 __global__ void fill(Record<1> *r, uint64_t n) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { r[i].key[0] = mix64(i * 7 + 1) >> 2 << 2; r[i].w = 0.99f; r[i].pkt = (uint32_t)i; }
 }
-template <int DBG> float run(const Record<1> *lin, uint64_t n, int bits, PoolView pv, unsigned int *wc, int grid) {
-	hipMemset(pv.head, 0, 4); hipMemset(wc, 0, 4);
+template <int THREADS, int RPT, bool PREFETCH, int G> float run_direct(const Record<1> *lin, uint64_t n, int bits, PoolView pv, unsigned int *wc, int grid) {
+	(void)hipMemset(pv.head, 0, 4); (void)hipMemset(wc, 0, 4);
 	PartSource<1> S; memset(&S, 0, sizeof(S)); S.linear = lin; S.n_ext = (n + 8191) / 8192; S.ext_len = 8192; S.total = n;
-	auto kern = partition_kernel<1, 1, DBG>;
-	hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)partition_smem_bytes<1>(10));
-	hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-	hipEventRecord(a);
-	hipLaunchKernelGGL(kern, dim3(grid), dim3(PART_THREADS), partition_smem_bytes<1>(bits), 0, S, pv, wc, bits, 0);
-	hipEventRecord(b); hipEventSynchronize(b);
-	float ms; hipEventElapsedTime(&ms, a, b);
-	printf("  err=%s\n", hipGetErrorString(hipGetLastError()));
+	auto kern = partition_direct_kernel<1, 1, THREADS, RPT, PREFETCH, G>;
+	(void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+	hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+	(void)hipEventRecord(a);
+	const size_t smem = partition_direct_smem_bytes<1, THREADS, RPT, G>(bits);
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), smem, 0, S, pv, wc, bits, 0);
+	(void)hipEventRecord(b); (void)hipEventSynchronize(b);
+	float ms; (void)hipEventElapsedTime(&ms, a, b);
+	unsigned int head = 0; (void)hipMemcpy(&head, pv.head, 4, hipMemcpyDeviceToHost);
+	printf("  <%d thr, %d rec/thr, prefetch %d, line %d> bits %d grid %d: %.2f ms  chunks %u err=%s\n", THREADS, RPT, (int)PREFETCH, G, bits, grid, ms, head, hipGetErrorString(hipGetLastError()));
 	return ms;
 }
 __global__ void fill_genome(Record<1> *r, uint64_t n, const uint8_t *g, uint64_t glen) {
@@ -44,13 +46,15 @@ int main(int argc, char **argv) {
 	hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, lin, n);
 	PoolView pv; uint32_t cap = (uint32_t)(n / CH + 2000000);
 	CK(hipMalloc(&pv.base, (size_t)cap * CH * 16)); CK(hipMalloc(&pv.chunk_list, 4ull * cap)); CK(hipMalloc(&pv.chunk_count, 4ull * cap)); CK(hipMalloc(&pv.head, 4)); CK(hipMalloc(&pv.err, 4));
-	pv.cap = cap; hipMemset(pv.err, 0, 4);
+	pv.cap = cap; (void)hipMemset(pv.err, 0, 4);
 	unsigned int *wc; CK(hipMalloc(&wc, 4));
 	CK(hipDeviceSynchronize());
-	for (int bits : {8, 7, 6, 5}) for (int grid : {512}) {
-		float f0 = run<0>(lin, n, bits, pv, wc, grid), f1 = run<1>(lin, n, bits, pv, wc, grid), f2 = run<2>(lin, n, bits, pv, wc, grid), f3 = run<3>(lin, n, bits, pv, wc, grid), f4 = run<4>(lin, n, bits, pv, wc, grid);
-		printf("   planonly %.2f  plan+flush %.2f\n", f3, f4);
-		printf("bits %d grid %d: full %.2f ms  noappend %.2f ms  loadonly %.2f ms   (%.1f Grec/s full)\n", bits, grid, f0, f1, f2, n / f0 / 1e6);
+	for (int rep = 0; rep < 2; rep++) for (int bits : {10, 9, 8}) {
+		run_direct<1024, 16, false, 0>(lin, n, bits, pv, wc, 256);
+		run_direct<1024, 8, false, 0>(lin, n, bits, pv, wc, 256);
+		run_direct<1024, 8, true, 4>(lin, n, bits, pv, wc, 256);
+		run_direct<1024, 8, false, 4>(lin, n, bits, pv, wc, 256);
+		run_direct<512, 8, true, 4>(lin, n, bits, pv, wc, 512);
 	}
 	return 0;
 }
