@@ -748,11 +748,18 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 			HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
 			rc = zero_work_counter(h); if (rc) return rc;
 		}
+		const int grid = (int)std::min<uint64_t>((uint64_t)part_grid(h) * (getenv("KMR_COUNT_GRIDX") ? atoi(getenv("KMR_COUNT_GRIDX")) : 2), nl2);
+		if (getenv("KMR_COUNT_LOG2S") && atoi(getenv("KMR_COUNT_LOG2S")) == 9) {
+			auto kern = count_kernel<W, false, 9>;
+			const size_t smem = count_smem_bytes<W, 9>();
+			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l2), ls2, lc2, nl2, out, f, h->work_counter);
+		} else {
 		auto kern = count_kernel<W, false, COUNT_LOG2S>;
 		const size_t smem = count_smem_bytes<W, COUNT_LOG2S>();
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-		const int grid = (int)std::min<uint64_t>((uint64_t)part_grid(h) * (getenv("KMR_COUNT_GRIDX") ? atoi(getenv("KMR_COUNT_GRIDX")) : 2), nl2);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l2), ls2, lc2, nl2, out, f, h->work_counter);
+		}
 		HIPCHK(h, hipGetLastError());
 	}
 	FinalizeCounters c; unsigned long long cur[2];

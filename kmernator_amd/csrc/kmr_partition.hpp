@@ -108,6 +108,12 @@ __global__ void kmer_capacity_kernel(ReadsView rv, uint32_t k, uint32_t *cap) {
 	}
 }
 
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every global load and store the
+ * wavefront has in flight (s_waitcnt vmcnt(0)), which would expose the HBM latency of the prefetched records and
+ * of the fire-and-forget stores at every barrier.  The kernels below never read, inside a launch, global memory
+ * that another thread of the block wrote, so LDS ordering is all their barriers need. */
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 /* ------------------------------------------------------------------ partition */
 template <int W> struct PartSource {
 	/* LEVEL 1: extents of a linear record buffer */
@@ -173,7 +179,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 
 	for (int p = t; p < P; p += THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; hist[p] = 0; if (G) stage_n[p] = 0; }
 	if (t == 0) { s_alloc = 0; s_filled = 0; s_nextra = 0; }
-	__syncthreads();
+	lds_barrier();
 
 	auto top_up = [&]() {
 		const uint32_t want = 2 * (BATCH / CH) + SLAB;
@@ -240,7 +246,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 		if (t == 0) top_up();
 #pragma unroll
 		for (int i = 0; i < RPT; i++) if (pid[i] != NO_CHUNK) atomicAdd(&hist[pid[i]], 1u);
-		__syncthreads();
+		lds_barrier();
 		for (int p = t; p < P; p += THREADS) {
 			const uint32_t n = hist[p];
 			if (G) {
@@ -259,7 +265,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 				}
 			} else if (n) { plan_run(p, lid_base + p, n); hist[p] = 0; }
 		}
-		__syncthreads();
+		lds_barrier();
 #pragma unroll
 		for (int i = 0; i < RPT; i++) if (pid[i] != NO_CHUNK) {
 			const uint32_t p = pid[i];
@@ -274,10 +280,10 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 			const uint32_t c = q == 0 ? c0[p] : extra[xoff[p] + q - 1];
 			if (c != NO_CHUNK) chunk_ptr(c)[pos % CH] = r[i];
 		}
-		__syncthreads();
+		lds_barrier();
 		for (int p = t; p < P; p += THREADS) hist[p] = 0;
 		if (t == 0) s_nextra = 0;
-		__syncthreads();
+		lds_barrier();
 	};
 
 	/* with PREFETCH the loads of batch i+1 are issued before batch i is counted and stored (register double
@@ -314,12 +320,12 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 		};
 		for (;;) {
 			if (t == 0) s_item = atomicAdd(work_counter, EBATCH);
-			__syncthreads();
+			lds_barrier();
 			const uint64_t efirst = s_item;
 			if (efirst >= S.n_ext) break;
 			if (t == 0) { s_ecur = efirst; s_eoff = 0; }
 			for (;;) {
-				__syncthreads();
+				lds_barrier();
 				if (t == 0) {
 					uint32_t nb = 0, ng = 0, filled = BATCH;       /* filled == BATCH: no group open */
 					uint64_t e = s_ecur, off = s_eoff;
@@ -338,7 +344,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 					s_gfirst[ng] = nb;
 					s_ecur = e; s_eoff = off; s_ng = ng;
 				}
-				__syncthreads();
+				lds_barrier();
 				const uint32_t ng = s_ng;
 				if (ng == 0) break;
 				if (PREFETCH) {
@@ -355,9 +361,9 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 					for (uint32_t g = 0; g < ng; g++) { load1(g, r, pid); scatter_batch(r, pid, 0); }
 				}
 			}
-			__syncthreads();
+			lds_barrier();
 		}
-		__syncthreads();
+		lds_barrier();
 		flush_all(0);
 		if (S.valid_counter) { nvalid = wave_sum(nvalid); if ((t & 63) == 0 && nvalid) atomicAdd(S.valid_counter, nvalid); }
 	} else {
@@ -379,9 +385,9 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 		};
 		for (;;) {
 			if (t == 0) s_item = atomicAdd(work_counter, 1u);
-			__syncthreads();
+			lds_barrier();
 			const uint64_t it = s_item;
-			__syncthreads();
+			lds_barrier();
 			if (it >= S.n_items) break;
 			const uint64_t cb0 = S.item_begin[it], cb1 = S.item_end[it];
 			const uint32_t lid_base = S.item_list[it] << LOG2P;
@@ -400,10 +406,10 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 				for (uint64_t cb = cb0; cb < cb1; cb += STEP) { load2(cb, cb1, r, pid); scatter_batch(r, pid, lid_base); }
 			}
 			flush_all(lid_base);
-			__syncthreads();
+			lds_barrier();
 		}
 	}
-	__syncthreads();
+	lds_barrier();
 	for (uint32_t idx = s_alloc + t; idx < s_filled; idx += THREADS) {
 		const uint32_t c = s_ring[(idx / SLAB) % RING] + (idx % SLAB);
 		if (c < out.cap) { out.chunk_list[c] = NO_CHUNK; out.chunk_count[c] = 0; }
@@ -527,63 +533,117 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 	 * serialise ~10^6 lists); the unused tail of a slab is marked as holes (count 0 / weight 0) */
 	__shared__ unsigned long long s_wpos, s_wend, s_spos, s_send;
 	__shared__ unsigned long long s_holeW0, s_holeW1, s_holeS0, s_holeS1;
+	__shared__ uint16_t s_kept[S];
 	__shared__ uint32_t s_stackBits[40], s_stackVal[40];
 	const int t = threadIdx.x;
 	const uint32_t vw = EXT ? 15 : 3;
 	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;   /* kept*: thread 0 only */
 	constexpr unsigned long long OSLAB = 8192;
 	if (t == 0) { s_wpos = s_wend = 0; s_spos = s_send = 0; }
-	__syncthreads();
+	lds_barrier();
 
-	constexpr uint32_t LBATCH = 16;       /* lists per grab: one word of device memory serves ~90 M atomics/s */
+	/* Lists are taken LBATCH at a time (one word of device memory serves ~90 M atomics/s).  A batch's chunk
+	 * descriptors are contiguous in list_chunks and are copied to LDS once, so the records of list j+1 can be
+	 * requested (one chunk per wavefront per register slot, HEAD chunks in all) before list j is counted: the
+	 * HBM latency of a list is hidden behind the LDS work of the one before it. */
+	constexpr uint32_t LBATCH = 32, DESC_CAP = 1024;
+	constexpr int UNR = W == 1 ? 5 : (W == 2 ? 4 : 3);
+	constexpr int NWAVE = COUNT_THREADS / CH;
+	constexpr uint64_t HEAD = (uint64_t)NWAVE * UNR;
+	__shared__ unsigned long long s_ls[LBATCH + 1];
+	__shared__ unsigned long long s_desc[DESC_CAP];
+	Rec rr[UNR], rn[UNR];
 	for (;;) {
 		if (t == 0) s_list = atomicAdd(work_counter, LBATCH);
-		__syncthreads();
+		lds_barrier();
 		const uint64_t lfirst = s_list;
-		__syncthreads();
 		if (lfirst >= n_lists) break;
-		for (uint64_t l = lfirst; l < lfirst + LBATCH && l < n_lists; l++) {
-		const uint64_t c0 = list_start[l], c1 = list_start[l + 1];
+		const uint32_t nl = (uint32_t)(n_lists - lfirst < (uint64_t)LBATCH ? n_lists - lfirst : (uint64_t)LBATCH);
+		if ((uint32_t)t <= nl) s_ls[t] = list_start[lfirst + t];
+		lds_barrier();
+		const uint64_t dbase = s_ls[0], dend = s_ls[nl];
+		for (uint64_t i = dbase + t; i < dend && i - dbase < DESC_CAP; i += COUNT_THREADS) s_desc[i - dbase] = list_chunks[i];
+		lds_barrier();
+		/* descriptors first (all from LDS, or for a list beyond the LDS window all from global memory: the two
+		 * are never mixed in one access, which would turn it into a flat load that waits for everything in
+		 * flight), then the record loads back to back */
+		auto load_round = [&](uint64_t cb, uint64_t c1, Rec (&dst)[UNR]) {
+			uint64_t d[UNR];
+			const bool in_lds = c1 - dbase <= (uint64_t)DESC_CAP;      /* uniform */
+			if (in_lds) {
+#pragma unroll
+				for (int u = 0; u < UNR; u++) { const uint64_t ci = cb + (t >> 6) + (uint64_t)u * NWAVE; d[u] = ci < c1 ? s_desc[ci - dbase] : 0ull; }
+			} else {
+#pragma unroll
+				for (int u = 0; u < UNR; u++) { const uint64_t ci = cb + (t >> 6) + (uint64_t)u * NWAVE; d[u] = ci < c1 ? list_chunks[ci] : 0ull; }
+			}
+			/* a register slot without a record is marked by weight 0 (no record in a pool has it) */
+#pragma unroll
+			for (int u = 0; u < UNR; u++) {
+				dst[u].w = 0.0f;
+				if ((uint32_t)(t & 63) < (uint32_t)(d[u] >> 32)) dst[u] = ((const Rec *)(pool.base + (size_t)(uint32_t)d[u] * CH * sizeof(Rec)))[t & 63];
+			}
+		};
+		load_round(s_ls[0], s_ls[1], rn);
+		for (uint32_t j = 0; j < nl; j++) {
+		const uint64_t c0 = s_ls[j], c1 = s_ls[j + 1];
+#pragma unroll
+		for (int u = 0; u < UNR; u++) rr[u] = rn[u];
+		if (j + 1 < nl) load_round(s_ls[j + 1], s_ls[j + 2], rn);
 		if (c0 == c1) continue;
-		__syncthreads();       /* every thread has left the previous list's while (s_sp > 0) before s_sp is re-armed */
+		bool head_in_regs = true;       /* rr holds chunks [c0, c0 + HEAD) until a later round or sub-pass reloads it */
+		lds_barrier();       /* every thread has left the previous list's while (s_sp > 0) before s_sp is re-armed */
 		if (t == 0) { s_sp = 1; s_stackBits[0] = 0; s_stackVal[0] = 0; }
-		__syncthreads();
+		lds_barrier();
 		while (s_sp > 0) {
 			const uint32_t bits = s_stackBits[s_sp - 1], val = s_stackVal[s_sp - 1];
-			__syncthreads();
+			lds_barrier();
 			if (t == 0) { s_sp--; s_claimed = 0; s_overflow = 0; s_nw = 0; s_ns = 0; }
 			for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; }
-			__syncthreads();
+			lds_barrier();
 			const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
-			/* insert: wave w takes chunks c0 + w, + waves, ...; lane = record; UNR chunks are loaded before any is
-			 * inserted so several HBM reads are in flight per wave */
-			constexpr int UNR = 4;
-			constexpr int NWAVE = COUNT_THREADS / CH;
-			for (uint64_t cb = c0 + (t >> 6); cb < c1 && !s_overflow; cb += (uint64_t)NWAVE * UNR) {
-				Rec rr[UNR]; bool ok[UNR];
+			/* insert: wave w takes chunks cb + w, + waves, ...; lane = record */
+			for (uint64_t cb = c0; cb < c1 && !s_overflow && s_claimed <= LIMIT; cb += HEAD) {
+				if (!(head_in_regs && cb == c0)) { load_round(cb, c1, rr); head_in_regs = false; }
+				/* The probe of a record is a chain of dependent LDS round trips, so the first probe of the UNR
+				 * records a thread holds is issued as one group (most records repeat a key that sits in its home
+				 * slot); only what is left goes through the one-record-at-a-time loop.  New keys are counted per
+				 * wavefront and added to s_claimed once a round, without waiting for the sum. */
+				constexpr uint32_t NO_SLOT = 0xffffffffu;
+				uint32_t slot[UNR], claimedHere = 0;
+				uint64_t seen[UNR];          /* W == 1: key read from the home slot */
 #pragma unroll
 				for (int u = 0; u < UNR; u++) {
-					const uint64_t ci = cb + (uint64_t)u * NWAVE;
-					ok[u] = false;
-					if (ci < c1) {
-						const uint64_t d = list_chunks[ci];
-						if ((uint32_t)(t & 63) < (uint32_t)(d >> 32)) { rr[u] = ((const Rec *)(pool.base + (size_t)(uint32_t)d * CH * sizeof(Rec)))[t & 63]; ok[u] = true; }
-					}
+					const uint64_t h = part_hash<W>(rr[u].key);
+					const bool mine = rr[u].w != 0.0f && ((uint32_t)h & subMask) == val;
+					slot[u] = mine ? (uint32_t)(h >> 20) & (S - 1) : NO_SLOT;
+					seen[u] = 0;
+					if constexpr (W == 1) if (mine) seen[u] = tkeys[slot[u]];
 				}
 #pragma unroll
 				for (int u = 0; u < UNR; u++) {
-				if (!ok[u]) continue;
+				if (slot[u] == NO_SLOT) continue;
 				const Rec r = rr[u];
-				const uint64_t h = part_hash<W>(r.key);
-				if (((uint32_t)h & subMask) != val) continue;
-				uint32_t s = (uint32_t)(h >> 20) & (S - 1);
+				uint32_t s = slot[u];
 				bool placed = false;
-				for (int probe = 0; probe < S && !placed; ) {
+				int probe = 0;
+				if constexpr (W == 1) {
+					/* home slot, from the grouped read */
+					uint64_t curk = seen[u];
+					if (curk == EMPTY_KEY) {
+						const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)r.key[0]);
+						if (old == EMPTY_KEY) { claimedHere++; placed = true; }
+						curk = old;
+					}
+					if (!placed && curk == r.key[0]) placed = true;
+					if (!placed) { s = (s + 1) & (S - 1); probe = 1; }
+				}
+				for (; probe < S && !placed; ) {
 					if constexpr (W == 1) {
 						uint64_t curk = tkeys[s];
 						if (curk == EMPTY_KEY) {
 							const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)r.key[0]);
-							if (old == EMPTY_KEY) { if (atomicAdd(&s_claimed, 1u) + 1 > LIMIT) s_overflow = 1; placed = true; break; }
+							if (old == EMPTY_KEY) { claimedHere++; placed = true; break; }
 							curk = old;
 						}
 						if (curk == r.key[0]) { placed = true; break; }
@@ -596,7 +656,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 #pragma unroll
 								for (int j = 0; j < W; j++) tkeys[(size_t)s * W + j] = r.key[j];
 								__hip_atomic_store(&tstate[s], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-								if (atomicAdd(&s_claimed, 1u) + 1 > LIMIT) s_overflow = 1;
+								claimedHere++;
 								placed = true; break;
 							}
 							st = old;
@@ -610,16 +670,18 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 					s = (s + 1) & (S - 1);
 					probe++;
 				}
-				if (!placed) { s_overflow = 1; continue; }
+				if (!placed) { s_overflow = 1; continue; }      /* table full */
 				const bool fwd = !(r.w < 0.0f);
 				const float wa = fwd ? r.w : -r.w;
 				atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(fwd ? 1 : 0) << 32));
 				atomicAdd(&twsum[s], (double)wa);
 				atomicMin(&tfirst[s], ((unsigned long long)r.pkt << 1) | (fwd ? 1ull : 0ull));
 				}
+				claimedHere = (uint32_t)wave_sum((unsigned long long)claimedHere);
+				if ((t & 63) == 0 && claimedHere) atomicAdd(&s_claimed, claimedHere);
 			}
-			__syncthreads();
-			if (s_overflow) {       /* split this sub-pass in two by one more hash bit */
+			lds_barrier();
+			if (s_overflow || s_claimed > LIMIT) {       /* split this sub-pass in two by one more hash bit */
 				if (t == 0) {
 					if (bits >= 20) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
 					else {
@@ -627,27 +689,25 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 						s_stackBits[s_sp] = bits + 1; s_stackVal[s_sp] = val | (1u << bits); s_sp++;
 					}
 				}
-				__syncthreads();
+				lds_barrier();
 				continue;
 			}
-			/* emit: first count the kept entries, reserve space, then write */
-			uint32_t myKind[S / COUNT_THREADS];
-			uint32_t myIdx[S / COUNT_THREADS];
+			/* emit: the slots of the kept entries are first collected in LDS (weak entries from the front of
+			 * s_kept, singletons from its back), so that the bucket hash and the stores below run on a dense
+			 * range of threads instead of once per table slot */
 #pragma unroll
 			for (int i = 0; i < S / COUNT_THREADS; i++) {
 				const int s = i * COUNT_THREADS + t;
-				myKind[i] = 0;
 				if (W == 1 ? tkeys[s] != EMPTY_KEY : tstate[s] == 2) {
 					const uint32_t count = (uint32_t)tcnt[s];
 					uniq++;
 					if (count == 1) single++;
 					const int c = classify(count, f);
-					myKind[i] = (uint32_t)c;
-					if (c == 1) myIdx[i] = atomicAdd(&s_nw, 1u);
-					else if (c == 2) myIdx[i] = atomicAdd(&s_ns, 1u);
+					if (c == 1) s_kept[atomicAdd(&s_nw, 1u)] = (uint16_t)s;
+					else if (c == 2) s_kept[S - 1 - atomicAdd(&s_ns, 1u)] = (uint16_t)s;
 				}
 			}
-			__syncthreads();
+			lds_barrier();
 			/* thread 0 alone does the slab book-keeping between these two barriers (the other threads must not look
 			 * at s_wpos & co. while it moves them); a slab that cannot take this list is retired and its unused
 			 * tail, shorter than the list's entry count, is handed to the block to be marked as holes */
@@ -665,46 +725,47 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 				s_sbase = s_spos; s_spos += s_ns; keptS += s_ns;
 				if (s_wend > out.wcap || s_send > out.scap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); s_nw = 0xffffffffu; }
 			}
-			__syncthreads();
+			lds_barrier();
 			for (unsigned long long e = s_holeW0 + t; e < s_holeW1; e += COUNT_THREADS) out.wvals[e * vw] = 0;
 			for (unsigned long long e = s_holeS0 + t; e < s_holeS1; e += COUNT_THREADS) out.sweight[e] = 0;
 			if (s_nw != 0xffffffffu) {
-#pragma unroll
-				for (int i = 0; i < S / COUNT_THREADS; i++) {
-					if (!myKind[i]) continue;
-					const int s = i * COUNT_THREADS + t;
+				for (uint32_t e = t; e < s_nw; e += COUNT_THREADS) {
+					const uint32_t s = s_kept[e];
 					Key<W> key;
 #pragma unroll
 					for (int j = 0; j < W; j++) key.w[j] = tkeys[(size_t)s * W + j];
 					const uint64_t hash = key_hash<W>(key, f.kb);
 					const unsigned long long cf = tcnt[s];
-					const uint32_t count = (uint32_t)cf;
-					if (myKind[i] == 1) {
-						const uint64_t pos = s_wbase + myIdx[i];
+					const uint64_t pos = s_wbase + e;
 #pragma unroll
-						for (int j = 0; j < W; j++) out.wkeys[pos * W + j] = key.w[j];
-						uint32_t fwd = (uint32_t)(cf >> 32), cnt = count;
-						if (f.has_singletons && (tfirst[s] & 1ull)) fwd -= 1;
-						if (cnt > 65535u) { cnt = 65535u; if (fwd > 65534u) fwd = 65534u; }
-						if (fwd > 65535u) fwd = 65535u;
-						uint32_t *v = out.wvals + pos * vw;
-						v[0] = cnt; v[1] = __float_as_uint((float)twsum[s]); v[2] = fwd;
-						atomicAdd(&out.weakCount[hash & (f.nb_weak - 1)], 1u);
-					} else {
-						const uint64_t pos = s_sbase + myIdx[i];
+					for (int j = 0; j < W; j++) out.wkeys[pos * W + j] = key.w[j];
+					uint32_t fwd = (uint32_t)(cf >> 32), cnt = (uint32_t)cf;
+					if (f.has_singletons && (tfirst[s] & 1ull)) fwd -= 1;
+					if (cnt > 65535u) { cnt = 65535u; if (fwd > 65534u) fwd = 65534u; }
+					if (fwd > 65535u) fwd = 65535u;
+					uint32_t *v = out.wvals + pos * vw;
+					v[0] = cnt; v[1] = __float_as_uint((float)twsum[s]); v[2] = fwd;
+					atomicAdd(&out.weakCount[hash & (f.nb_weak - 1)], 1u);
+				}
+				for (uint32_t e = t; e < s_ns; e += COUNT_THREADS) {
+					const uint32_t s = s_kept[S - 1 - e];
+					Key<W> key;
 #pragma unroll
-						for (int j = 0; j < W; j++) out.skeys[pos * W + j] = key.w[j];
-						const float wf = (float)twsum[s];
-						out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
-						atomicAdd(&out.singCount[hash & (f.nb_sing - 1)], 1u);
-					}
+					for (int j = 0; j < W; j++) key.w[j] = tkeys[(size_t)s * W + j];
+					const uint64_t hash = key_hash<W>(key, f.kb);
+					const uint64_t pos = s_sbase + e;
+#pragma unroll
+					for (int j = 0; j < W; j++) out.skeys[pos * W + j] = key.w[j];
+					const float wf = (float)twsum[s];
+					out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
+					atomicAdd(&out.singCount[hash & (f.nb_sing - 1)], 1u);
 				}
 			}
-			__syncthreads();
+			lds_barrier();
 		}
 		}
 	}
-	__syncthreads();
+	lds_barrier();
 	for (unsigned long long e = s_wpos + t; e < s_wend && e < out.wcap; e += COUNT_THREADS) out.wvals[e * vw] = 0;
 	for (unsigned long long e = s_spos + t; e < s_send && e < out.scap; e += COUNT_THREADS) out.sweight[e] = 0;
 	uniq = wave_sum(uniq); single = wave_sum(single);
