@@ -489,8 +489,10 @@ const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
 /* partition bits per level that keep the per-list book-keeping and lines inside the 160 KB of LDS */
 int max_part_bits(uint32_t W) { return W <= 2 ? 10 : 9; }
 PoolView pool_view(kmr_handle *h, HostPool &p) { PoolView v; v.base = p.base; v.chunk_list = p.chunk_list; v.chunk_count = p.chunk_count; v.head = p.head; v.cap = p.cap; v.err = h->derr; return v; }
+/* log2 of the weak map's bucket count: the partition is cut along the bucket index (part_order) */
+uint32_t part_rot(kmr_handle *h) { uint32_t r = 0; while ((1ull << (r + 1)) <= h->nb_weak) r++; return r; }
 template <int W, int LEVEL> int launch_partition(kmr_handle *h, const PartSource<W> &S, HostPool &pool, int grid, int bits, int shift) {
-	auto kern = partition_direct_kernel<W, LEVEL, PD_THREADS, PD_RPT, W == 1, PD_LINE>;
+	auto kern = partition_direct_kernel<W, LEVEL, PD_THREADS, PD_RPT, PD_LINE>;
 	const size_t smem = partition_direct_smem_bytes<W, PD_THREADS, PD_RPT, PD_LINE>(bits);
 	if (getenv("KMR_DEBUG")) fprintf(stderr, "partition level %d W=%d bits=%d shift=%d smem=%zu grid=%d\n", LEVEL, W, bits, shift, smem, grid);
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -582,7 +584,7 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	rc = zero_work_counter(h); if (rc) return rc;
 	PartSource<W> S; memset(&S, 0, sizeof(S));
 	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
-	S.valid_counter = valid_counter;
+	S.valid_counter = valid_counter; S.kb = h->kb; S.rot = part_rot(h);
 	return launch_partition<W, 1>(h, S, h->l1, grid, h->bits1, 0);
 }
 
@@ -664,10 +666,10 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, ui
 		HIPCHK(h, hipMalloc((void **)&v, 24)); HIPCHK(h, hipMemset(v, 0, 24));
 		PoolView pvw = pool_view(h, p);
 		switch (h->W) {
-		case 1: hipLaunchKernelGGL(verify_lists_kernel<1>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, v, v + 1, v + 2); break;
-		case 2: hipLaunchKernelGGL(verify_lists_kernel<2>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, v, v + 1, v + 2); break;
-		case 3: hipLaunchKernelGGL(verify_lists_kernel<3>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, v, v + 1, v + 2); break;
-		default: hipLaunchKernelGGL(verify_lists_kernel<4>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, v, v + 1, v + 2); break;
+		case 1: hipLaunchKernelGGL(verify_lists_kernel<1>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2); break;
+		case 2: hipLaunchKernelGGL(verify_lists_kernel<2>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2); break;
+		case 3: hipLaunchKernelGGL(verify_lists_kernel<3>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2); break;
+		default: hipLaunchKernelGGL(verify_lists_kernel<4>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2); break;
 		}
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		HIPCHK(h, hipMemcpy(vv, v, 24, hipMemcpyDeviceToHost)); hipFree(v);
@@ -707,7 +709,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		HIPCHK(h, hipMemcpy(dil, il.data(), 4 * il.size(), hipMemcpyHostToDevice));
 		rc = zero_work_counter(h); if (rc) return rc;
 		PartSource<W> S; memset(&S, 0, sizeof(S));
-		S.src = pool_view(h, h->l1); S.list_chunks = lc1; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size();
+		S.src = pool_view(h, h->l1); S.list_chunks = lc1; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size(); S.kb = h->kb; S.rot = part_rot(h);
 		const int grid = (int)std::min<uint64_t>(partition_blocks(h), ib.size());
 		rc = launch_partition<W, 2>(h, S, h->l2, grid, bits2, h->bits1); if (rc) return rc;
 		HIPCHK(h, hipStreamSynchronize(h->stream));

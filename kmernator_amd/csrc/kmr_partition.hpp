@@ -52,12 +52,24 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 	x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
 	return x;
 }
-/* partition hash (NOT the reference's lookup3: nothing user visible depends on it) */
+/* table-slot / sub-pass hash of the count pass (nothing user visible depends on it) */
 template <int W> __host__ __device__ __forceinline__ uint64_t part_hash(const uint64_t *key) {
 	uint64_t h = mix64(key[0]);
 #pragma unroll
 	for (int i = 1; i < W; i++) h = mix64(h ^ (key[i] * 0x9E3779B97F4A7C15ull));
 	return h;
+}
+/* Partition order of a k-mer: the reference's bucket hash (KmerHasher, lookup3) rotated so that the bucket index
+ * of the weak map, h & (NB - 1) with NB = 2^rot, becomes the most significant bits.  Lists are cut from the top
+ * bits of this value, so a final list is a contiguous range of buckets (or, with more lists than buckets, a bucket
+ * is a contiguous range of lists) and the entries a list produces land next to each other in the bucketed map:
+ * entry_scatter_kernel then writes ~1 KB regions instead of one random 20-byte entry at a time. */
+template <int W> __host__ __device__ __forceinline__ uint64_t part_order(const uint64_t *key, uint32_t kb, uint32_t rot) {
+	Key<W> k;
+#pragma unroll
+	for (int i = 0; i < W; i++) k.w[i] = key[i];
+	const uint64_t h = key_hash<W>(k, kb);
+	return rot ? (h >> rot) | (h << (64 - rot)) : h;
 }
 
 /* ------------------------------------------------------------------ LinearOp */
@@ -123,6 +135,7 @@ template <int W> struct PartSource {
 	uint64_t n_ext, ext_len, total;
 	uint32_t ext_stride;           /* ext_start index = extent * ext_stride (64 reads per tile)   */
 	unsigned long long *valid_counter;  /* optional: += records with weight != 0 (exchange input)    */
+	uint32_t kb, rot;              /* key bytes and log2(buckets of the weak map): see part_order()  */
 	/* LEVEL 2: work items over the chunk CSR of the level-1 pool */
 	PoolView src;
 	const uint64_t *list_chunks;   /* (records << 32 | chunk id), grouped by list */
@@ -153,7 +166,7 @@ __host__ __device__ inline size_t partition_direct_smem_bytes(int bits) {
 	       + 64;
 }
 
-template <int W, int LEVEL, int THREADS, int RPT, bool PREFETCH, int G>
+template <int W, int LEVEL, int THREADS, int RPT, int G>
 __global__ __launch_bounds__(THREADS)
 void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter, const int LOG2P, const int SHIFT) {
 	const int P = 1 << LOG2P;
@@ -286,11 +299,9 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 		lds_barrier();
 	};
 
-	/* with PREFETCH the loads of batch i+1 are issued before batch i is counted and stored (register double
-	 * buffering), so a block that has a compute unit to itself still overlaps its reads with its writes */
-	Rec r[RPT], rn[PREFETCH ? RPT : 1];
-	uint32_t pid[RPT], pidn[PREFETCH ? RPT : 1];
-	auto pid_of = [&](const Rec &x) -> uint32_t { return LOG2P ? (uint32_t)(part_hash<W>(x.key) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u; };
+	Rec r[RPT];
+	uint32_t pid[RPT];
+	auto pid_of = [&](const Rec &x) -> uint32_t { return LOG2P ? (uint32_t)(part_order<W>(x.key, S.kb, S.rot) >> (64 - SHIFT - LOG2P)) & (P - 1) : 0u; };
 
 	if (LEVEL == 1) {
 		/* extents are handed out dynamically (EBATCH at a time) so ragged tiles balance.  Thread 0 cuts them into
@@ -347,19 +358,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 				lds_barrier();
 				const uint32_t ng = s_ng;
 				if (ng == 0) break;
-				if (PREFETCH) {
-					load1(0, r, pid);
-					for (uint32_t g = 0; g < ng; g++) {
-						if (g + 1 < ng) load1(g + 1, rn, pidn);
-						scatter_batch(r, pid, 0);
-						if (g + 1 < ng) {
-#pragma unroll
-							for (int i = 0; i < RPT; i++) { r[i] = rn[PREFETCH ? i : 0]; pid[i] = pidn[PREFETCH ? i : 0]; }
-						}
-					}
-				} else {
-					for (uint32_t g = 0; g < ng; g++) { load1(g, r, pid); scatter_batch(r, pid, 0); }
-				}
+				for (uint32_t g = 0; g < ng; g++) { load1(g, r, pid); scatter_batch(r, pid, 0); }
 			}
 			lds_barrier();
 		}
@@ -392,19 +391,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 			const uint64_t cb0 = S.item_begin[it], cb1 = S.item_end[it];
 			const uint32_t lid_base = S.item_list[it] << LOG2P;
 			constexpr uint64_t STEP = BATCH / CH;
-			if (PREFETCH) {
-				if (cb0 < cb1) load2(cb0, cb1, r, pid);
-				for (uint64_t cb = cb0; cb < cb1; cb += STEP) {
-					if (cb + STEP < cb1) load2(cb + STEP, cb1, rn, pidn);
-					scatter_batch(r, pid, lid_base);
-					if (cb + STEP < cb1) {
-#pragma unroll
-						for (int i = 0; i < RPT; i++) { r[i] = rn[PREFETCH ? i : 0]; pid[i] = pidn[PREFETCH ? i : 0]; }
-					}
-				}
-			} else {
-				for (uint64_t cb = cb0; cb < cb1; cb += STEP) { load2(cb, cb1, r, pid); scatter_batch(r, pid, lid_base); }
-			}
+			for (uint64_t cb = cb0; cb < cb1; cb += STEP) { load2(cb, cb1, r, pid); scatter_batch(r, pid, lid_base); }
 			flush_all(lid_base);
 			lds_barrier();
 		}
@@ -477,7 +464,7 @@ __global__ void pool_records_kernel(const uint32_t *chunk_list, const uint32_t *
 /* debugging aid (KMR_DEBUG): walk a pool through its chunk CSR; count the records and those whose partition hash
  * does not match the list they are filed under */
 template <int W>
-__global__ void verify_lists_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, int bits,
+__global__ void verify_lists_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, int bits, uint32_t kb, uint32_t rot,
                                     unsigned long long *total, unsigned long long *misfiled, unsigned long long *zero_w) {
 	typedef Record<W> Rec;
 	unsigned long long n = 0, bad = 0, zw = 0;
@@ -487,7 +474,7 @@ __global__ void verify_lists_kernel(PoolView pool, const uint64_t *list_start, c
 			if ((uint32_t)(threadIdx.x & 63) < (uint32_t)(d >> 32)) {
 				const Rec r = ((const Rec *)(pool.base + (size_t)(uint32_t)d * CH * sizeof(Rec)))[threadIdx.x & 63];
 				n++;
-				if (bits && (part_hash<W>(r.key) >> (64 - bits)) != l) bad++;
+				if (bits && (part_order<W>(r.key, kb, rot) >> (64 - bits)) != l) bad++;
 				if (r.w == 0.0f) zw++;
 			}
 		}

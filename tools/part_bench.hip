@@ -9,10 +9,10 @@ using namespace kmr;
 __global__ void fill(Record<1> *r, uint64_t n) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { r[i].key[0] = mix64(i * 7 + 1) >> 2 << 2; r[i].w = 0.99f; r[i].pkt = (uint32_t)i; }
 }
-template <int THREADS, int RPT, bool PREFETCH, int G> float run_direct(const Record<1> *lin, uint64_t n, int bits, PoolView pv, unsigned int *wc, int grid) {
+template <int THREADS, int RPT, int G> float run_direct(const Record<1> *lin, uint64_t n, int bits, PoolView pv, unsigned int *wc, int grid) {
 	(void)hipMemset(pv.head, 0, 4); (void)hipMemset(wc, 0, 4);
-	PartSource<1> S; memset(&S, 0, sizeof(S)); S.linear = lin; S.n_ext = (n + 8191) / 8192; S.ext_len = 8192; S.total = n;
-	auto kern = partition_direct_kernel<1, 1, THREADS, RPT, PREFETCH, G>;
+	PartSource<1> S; memset(&S, 0, sizeof(S)); S.kb = 8; S.rot = 21; S.linear = lin; S.n_ext = (n + 8191) / 8192; S.ext_len = 8192; S.total = n;
+	auto kern = partition_direct_kernel<1, 1, THREADS, RPT, G>;
 	(void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
 	hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
 	(void)hipEventRecord(a);
@@ -21,7 +21,7 @@ template <int THREADS, int RPT, bool PREFETCH, int G> float run_direct(const Rec
 	(void)hipEventRecord(b); (void)hipEventSynchronize(b);
 	float ms; (void)hipEventElapsedTime(&ms, a, b);
 	unsigned int head = 0; (void)hipMemcpy(&head, pv.head, 4, hipMemcpyDeviceToHost);
-	printf("  <%d thr, %d rec/thr, prefetch %d, line %d> bits %d grid %d: %.2f ms  chunks %u err=%s\n", THREADS, RPT, (int)PREFETCH, G, bits, grid, ms, head, hipGetErrorString(hipGetLastError()));
+	printf("  <%d thr, %d rec/thr, line %d> bits %d grid %d: %.2f ms  chunks %u err=%s\n", THREADS, RPT, G, bits, grid, ms, head, hipGetErrorString(hipGetLastError()));
 	return ms;
 }
 __global__ void fill_genome(Record<1> *r, uint64_t n, const uint8_t *g, uint64_t glen) {
@@ -50,11 +50,11 @@ int main(int argc, char **argv) {
 	unsigned int *wc; CK(hipMalloc(&wc, 4));
 	CK(hipDeviceSynchronize());
 	for (int rep = 0; rep < 2; rep++) for (int bits : {10, 9, 8}) {
-		run_direct<1024, 16, false, 0>(lin, n, bits, pv, wc, 256);
-		run_direct<1024, 8, false, 0>(lin, n, bits, pv, wc, 256);
-		run_direct<1024, 8, true, 4>(lin, n, bits, pv, wc, 256);
-		run_direct<1024, 8, false, 4>(lin, n, bits, pv, wc, 256);
-		run_direct<512, 8, true, 4>(lin, n, bits, pv, wc, 512);
+		run_direct<1024, 16, 0>(lin, n, bits, pv, wc, 256);
+		run_direct<1024, 8, 0>(lin, n, bits, pv, wc, 256);
+		run_direct<1024, 8, 4>(lin, n, bits, pv, wc, 256);
+		run_direct<1024, 8, 4>(lin, n, bits, pv, wc, 256);
+		run_direct<512, 8, 4>(lin, n, bits, pv, wc, 512);
 	}
 	return 0;
 }
