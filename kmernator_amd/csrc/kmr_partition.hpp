@@ -483,6 +483,25 @@ __global__ void verify_lists_kernel(PoolView pool, const uint64_t *list_start, c
 	if ((threadIdx.x & 63) == 0) { atomicAdd(total, n); atomicAdd(misfiled, bad); atomicAdd(zero_w, zw); }
 }
 
+/* counts[bucket] += 1 for every live lane of the wavefront (all 64 lanes call it).  The entries of a final list
+ * share a few buckets, so lanes with equal buckets elect one of them to add their number; lanes still unserved
+ * after a few rounds add for themselves. */
+__device__ __forceinline__ void bucket_count_add(uint32_t *counts, uint64_t bucket, bool live) {
+	const int lane = (int)(threadIdx.x & 63);
+	bool done = !live;
+	for (int round = 0; round < 6; round++) {
+		const unsigned long long pending = __ballot(!done);
+		if (!pending) break;
+		const int leader = __ffsll((long long)pending) - 1;
+		const uint64_t lb = ((uint64_t)(uint32_t)__shfl((int)(bucket >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)bucket, leader);
+		const bool mine = !done && bucket == lb;
+		const unsigned long long same = __ballot(mine);
+		if (lane == leader) atomicAdd(&counts[lb], (uint32_t)__builtin_popcountll(same));
+		if (mine) done = true;
+	}
+	if (!done) atomicAdd(&counts[bucket], 1u);
+}
+
 /* ------------------------------------------------------------------ count */
 static const int COUNT_THREADS = 256;
 
@@ -716,36 +735,46 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 			for (unsigned long long e = s_holeW0 + t; e < s_holeW1; e += COUNT_THREADS) out.wvals[e * vw] = 0;
 			for (unsigned long long e = s_holeS0 + t; e < s_holeS1; e += COUNT_THREADS) out.sweight[e] = 0;
 			if (s_nw != 0xffffffffu) {
-				for (uint32_t e = t; e < s_nw; e += COUNT_THREADS) {
-					const uint32_t s = s_kept[e];
-					Key<W> key;
+				for (uint32_t e0 = (uint32_t)t & ~63u; e0 < s_nw; e0 += COUNT_THREADS) {
+					const uint32_t e = e0 + (uint32_t)(t & 63);
+					const bool live = e < s_nw;
+					uint64_t bucket = 0;
+					if (live) {
+						const uint32_t s = s_kept[e];
+						Key<W> key;
 #pragma unroll
-					for (int j = 0; j < W; j++) key.w[j] = tkeys[(size_t)s * W + j];
-					const uint64_t hash = key_hash<W>(key, f.kb);
-					const unsigned long long cf = tcnt[s];
-					const uint64_t pos = s_wbase + e;
+						for (int j = 0; j < W; j++) key.w[j] = tkeys[(size_t)s * W + j];
+						bucket = key_hash<W>(key, f.kb) & (f.nb_weak - 1);
+						const unsigned long long cf = tcnt[s];
+						const uint64_t pos = s_wbase + e;
 #pragma unroll
-					for (int j = 0; j < W; j++) out.wkeys[pos * W + j] = key.w[j];
-					uint32_t fwd = (uint32_t)(cf >> 32), cnt = (uint32_t)cf;
-					if (f.has_singletons && (tfirst[s] & 1ull)) fwd -= 1;
-					if (cnt > 65535u) { cnt = 65535u; if (fwd > 65534u) fwd = 65534u; }
-					if (fwd > 65535u) fwd = 65535u;
-					uint32_t *v = out.wvals + pos * vw;
-					v[0] = cnt; v[1] = __float_as_uint((float)twsum[s]); v[2] = fwd;
-					atomicAdd(&out.weakCount[hash & (f.nb_weak - 1)], 1u);
+						for (int j = 0; j < W; j++) out.wkeys[pos * W + j] = key.w[j];
+						uint32_t fwd = (uint32_t)(cf >> 32), cnt = (uint32_t)cf;
+						if (f.has_singletons && (tfirst[s] & 1ull)) fwd -= 1;
+						if (cnt > 65535u) { cnt = 65535u; if (fwd > 65534u) fwd = 65534u; }
+						if (fwd > 65535u) fwd = 65535u;
+						uint32_t *v = out.wvals + pos * vw;
+						v[0] = cnt; v[1] = __float_as_uint((float)twsum[s]); v[2] = fwd;
+					}
+					bucket_count_add(out.weakCount, bucket, live);
 				}
-				for (uint32_t e = t; e < s_ns; e += COUNT_THREADS) {
-					const uint32_t s = s_kept[S - 1 - e];
-					Key<W> key;
+				for (uint32_t e0 = (uint32_t)t & ~63u; e0 < s_ns; e0 += COUNT_THREADS) {
+					const uint32_t e = e0 + (uint32_t)(t & 63);
+					const bool live = e < s_ns;
+					uint64_t bucket = 0;
+					if (live) {
+						const uint32_t s = s_kept[S - 1 - e];
+						Key<W> key;
 #pragma unroll
-					for (int j = 0; j < W; j++) key.w[j] = tkeys[(size_t)s * W + j];
-					const uint64_t hash = key_hash<W>(key, f.kb);
-					const uint64_t pos = s_sbase + e;
+						for (int j = 0; j < W; j++) key.w[j] = tkeys[(size_t)s * W + j];
+						bucket = key_hash<W>(key, f.kb) & (f.nb_sing - 1);
+						const uint64_t pos = s_sbase + e;
 #pragma unroll
-					for (int j = 0; j < W; j++) out.skeys[pos * W + j] = key.w[j];
-					const float wf = (float)twsum[s];
-					out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
-					atomicAdd(&out.singCount[hash & (f.nb_sing - 1)], 1u);
+						for (int j = 0; j < W; j++) out.skeys[pos * W + j] = key.w[j];
+						const float wf = (float)twsum[s];
+						out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
+					}
+					bucket_count_add(out.singCount, bucket, live);
 				}
 			}
 			lds_barrier();
@@ -760,18 +789,42 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 	if (t == 0) { if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS); }
 }
 
-/* unsorted entries -> their bucket segments (then sort_buckets_kernel) */
+/* unsorted entries -> their bucket segments (then sort_buckets_kernel).  The entries one wavefront sees come
+ * from one or two final lists and with the partition cut along the bucket index (part_order) they fall into a
+ * handful of neighbouring buckets: lanes with the same bucket share one cursor update (a few rounds of
+ * ballot-and-elect) instead of serialising on it; what is left after the rounds takes its own atomic. */
 template <int W>
 __global__ void entry_scatter_kernel(const uint64_t *ukeys, const uint32_t *uvals, const uint8_t *ub8, const uint32_t *upkt, uint64_t n,
                                      uint32_t vw, uint32_t kb, uint64_t nb, const uint64_t *start, uint32_t *cursor,
                                      uint64_t *keys, uint32_t *vals, uint8_t *b8, uint32_t *pkt) {
-	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
-		if (uvals ? uvals[e * vw] == 0 : ub8[e] == 0) continue;      /* hole left at the end of an output slab */
+	const int lane = (int)(threadIdx.x & 63);
+	for (uint64_t e0 = blockIdx.x * (uint64_t)blockDim.x + (threadIdx.x & ~63u); e0 < n; e0 += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t e = e0 + lane;
+		const bool live = e < n && (uvals ? uvals[e * vw] != 0 : ub8[e] != 0);      /* holes end an output slab */
 		Key<W> key;
+		uint64_t b = 0;
+		if (live) {
 #pragma unroll
-		for (int j = 0; j < W; j++) key.w[j] = ukeys[e * W + j];
-		const uint64_t b = key_hash<W>(key, kb) & (nb - 1);
-		const uint64_t pos = start[b] + atomicAdd(&cursor[b], 1u);
+			for (int j = 0; j < W; j++) key.w[j] = ukeys[e * W + j];
+			b = key_hash<W>(key, kb) & (nb - 1);
+		}
+		bool done = !live;
+		uint32_t rank = 0;
+		for (int round = 0; round < 6; round++) {
+			const unsigned long long pending = __ballot(!done);
+			if (!pending) break;
+			const int leader = __ffsll((long long)pending) - 1;
+			const uint64_t lb = ((uint64_t)(uint32_t)__shfl((int)(b >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)b, leader);
+			const bool mine = !done && b == lb;
+			const unsigned long long same = __ballot(mine);
+			uint32_t base = 0;
+			if (lane == leader) base = atomicAdd(&cursor[lb], (uint32_t)__builtin_popcountll(same));
+			base = (uint32_t)__shfl((int)base, leader);
+			if (mine) { rank = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1)); done = true; }
+		}
+		if (live && !done) rank = atomicAdd(&cursor[b], 1u);
+		if (!live) continue;
+		const uint64_t pos = start[b] + rank;
 #pragma unroll
 		for (int j = 0; j < W; j++) keys[pos * W + j] = key.w[j];
 		if (uvals) for (uint32_t j = 0; j < vw; j++) vals[pos * vw + j] = uvals[e * vw + j];
