@@ -203,12 +203,35 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
                          "kernel": ("extract_kernel<1,false,InsertOp>" if args.build_mode == 1 else
-                                    "hot path of one step: extract_kernel<LinearOp> + partition_kernel<1,1> per sub-batch, then "
-                                    "partition_kernel<1,2> (dominant) + count_kernel + bucket scatter/sort"),
+                                    "hot path of one step: extract_kernel<LinearOp> + partition_direct_kernel<1,1> per sub-batch, "
+                                    "then partition_direct_kernel<1,2> + count_kernel + entry_scatter/sort_buckets"),
                          "algorithmic_bytes_per_step": alg_bytes, "hot_path_ms_per_step": hot_ms,
                          "build_ms_per_step": build_ms / max(1, args.steps), "build_launch_groups_per_step": build_launches // max(1, args.steps),
                          "finalize_ms_per_step": fin_ms / max(1, args.steps)},
         }
+        if args.build_mode != 1:
+            # per-kernel view of the same step: every kernel against the bytes its own role has to move (16-byte
+            # records at k=31; weak entries are 8-byte key + 12-byte value), each timed with HIP events on the handle's
+            # stream; rocprofv3 averages of the same command are in profiles/ (kernel_stats csv)
+            rec = 8 * ((kb + 7) // 8) + 8
+            weak = st["weak_entries"]
+            per = [("extract_kernel<LinearOp>", 2, k_local * (2.0 * READ_LEN / kmers_per_read + rec)),
+                   ("partition_direct_kernel<level 1>", 3, k_local * 2.0 * rec),
+                   ("partition_direct_kernel<level 2>", 4, k_local * 2.0 * rec),
+                   ("count_kernel", 5, k_local * rec + weak * 20.0),
+                   ("bucket scan + entry_scatter_kernel + sort_buckets_kernel", 6, weak * 60.0)]
+            kernels = []
+            for name, grp, nbytes in per:
+                ms, launches = sp.kernel_time(grp)
+                if launches == 0:
+                    continue
+                ms_step = ms / max(1, args.steps)
+                kernels.append({"name": name, "ms_per_step": ms_step, "launches_per_step": launches // max(1, args.steps),
+                                "ms_per_launch": ms / launches, "bytes_per_step": nbytes,
+                                "achieved_GBps": nbytes / (ms_step / 1e3) / 1e9, "frac": nbytes / (ms_step / 1e3) / HBM_PEAK})
+            out["roofline"]["kernels"] = kernels
+            if kernels:
+                out["roofline"]["dominant_kernel"] = max(kernels, key=lambda k: k["ms_per_step"])["name"]
         # HBM bytes from the PMC counters: bench.py cannot run rocprofv3 on itself, so the committed summary of
         # the same command (profiles/r01_pmc_traffic.json, tools/pmc.sh) is quoted when it describes this workload
         try:

@@ -263,10 +263,21 @@ int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n_re
  * work (torch.cuda.ExternalStream) against it. */
 void *kmr_stream(kmr_handle *h);
 
-/* Timing of the dominant kernels measured with HIP events on the handle's
- * stream (used by bench.py for the roofline object).  which: 0 = build
- * (extract+insert), 1 = finalize.  Returns accumulated milliseconds and
- * launch count since the last reset. */
+/* Timing of the hot path measured with HIP events on the handle's stream
+ * (used by bench.py for the roofline object).  Returns the accumulated
+ * milliseconds and the number of timed launch groups since the last reset.
+ * Groups 0 and 1 span whole phases, the others single kernels of the
+ * streaming build path (they nest inside 0 and 1). */
+enum kmr_time_group {
+	KMR_TIME_BUILD = 0,       /* kmr_add_reads*: extract + insert / level-1 partition, per sub-batch */
+	KMR_TIME_FINALIZE = 1,    /* kmr_finalize: everything                                           */
+	KMR_TIME_EXTRACT = 2,     /* extract_kernel launches                                             */
+	KMR_TIME_PARTITION1 = 3,  /* level-1 partition launches                                          */
+	KMR_TIME_PARTITION2 = 4,  /* level-2 partition launch                                            */
+	KMR_TIME_COUNT = 5,       /* count pass                                                          */
+	KMR_TIME_BUCKETS = 6,     /* bucket scan + entry scatter + bucket sort                           */
+	KMR_TIME_GROUPS = 7
+};
 int kmr_kernel_time(kmr_handle *h, int which, double *ms, uint64_t *launches);
 int kmr_kernel_time_reset(kmr_handle *h);
 

@@ -83,9 +83,9 @@ struct kmr_handle {
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr; uint64_t uw_cap = 0, us_cap = 0;
 	/* timing */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	double ms[2] = {0, 0};
-	uint64_t launches[2] = {0, 0};
-	std::vector<std::pair<hipEvent_t, hipEvent_t> > pending_events[2];
+	double ms[KMR_TIME_GROUPS] = {0};
+	uint64_t launches[KMR_TIME_GROUPS] = {0};
+	std::vector<std::pair<hipEvent_t, hipEvent_t> > pending_events[KMR_TIME_GROUPS];
 };
 
 namespace {
@@ -157,7 +157,7 @@ int alloc_table(kmr_handle *h, uint32_t log2cap, void **slots, ExtSlot **ext) {
 /* read the device error word and counters; synchronises the stream */
 int sync_state(kmr_handle *h) {
 	HIPCHK(h, hipStreamSynchronize(h->stream));
-	for (int which = 0; which < 2; which++) {
+	for (int which = 0; which < KMR_TIME_GROUPS; which++) {
 		for (auto &pr : h->pending_events[which]) {
 			float ms = 0; hipEventElapsedTime(&ms, pr.first, pr.second);
 			h->ms[which] += ms; h->launches[which]++;
@@ -478,7 +478,8 @@ int stage_reads(kmr_handle *h, const char *bases, const char *quals, const uint6
 /* ---------------------------------------------------------------------- */
 /* streaming build path (kmr_partition.hpp)                                  */
 const int COUNT_LOG2S = 10;                  /* 1024-slot LDS table per final list (expected ~350 distinct keys) */
-const uint64_t TARGET_LIST_RECORDS = 2048;   /* records per final list the partition bits aim for */
+static uint64_t target_list_records() { static const uint64_t v = getenv("KMR_TARGET_LIST") ? strtoull(getenv("KMR_TARGET_LIST"), nullptr, 10) : 2048; return v; }   /* records per final list the partition bits aim for */
+#define TARGET_LIST_RECORDS (target_list_records())
 const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
 const uint64_t SUB_BATCH_BASES = 1ull << 28;
 
@@ -585,7 +586,10 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	PartSource<W> S; memset(&S, 0, sizeof(S));
 	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
 	S.valid_counter = valid_counter; S.kb = h->kb; S.rot = part_rot(h);
-	return launch_partition<W, 1>(h, S, h->l1, grid, h->bits1, 0);
+	hipEvent_t ta, tb; time_begin(h, KMR_TIME_PARTITION1, &ta, &tb);
+	rc = launch_partition<W, 1>(h, S, h->l1, grid, h->bits1, 0);
+	time_end(h, KMR_TIME_PARTITION1, ta, tb);
+	return rc;
 }
 
 void choose_bits1(kmr_handle *h, uint64_t records_hint) {
@@ -622,10 +626,12 @@ template <int W> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll
 		rc = ensure_buf(h, h->linear, h->linear_cap, total_cap, rec_bytes(h)); if (rc) return rc;
 		rc = ensure_buf(h, h->tile_count, h->tile_cap, tiles, 4); if (rc) return rc;
 		LinearOp<W, false> op; op.records = (Record<W> *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
-		hipEvent_t a, b; time_begin(h, 0, &a, &b);
+		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b);
+		time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
 		rc = launch_extract<W, false>(h, rv, op);
+		time_end(h, KMR_TIME_EXTRACT, a2, b2);
 		if (!rc) rc = partition_level1<W>(h, (const Record<W> *)h->linear, h->koff, h->tile_count, tiles, 64, 0, 0, total_cap);
-		time_end(h, 0, a, b);
+		time_end(h, KMR_TIME_BUILD, a, b);
 		if (rc) return rc;
 	}
 	return 0;
@@ -711,7 +717,10 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		PartSource<W> S; memset(&S, 0, sizeof(S));
 		S.src = pool_view(h, h->l1); S.list_chunks = lc1; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size(); S.kb = h->kb; S.rot = part_rot(h);
 		const int grid = (int)std::min<uint64_t>(partition_blocks(h), ib.size());
-		rc = launch_partition<W, 2>(h, S, h->l2, grid, bits2, h->bits1); if (rc) return rc;
+		hipEvent_t ta, tb; time_begin(h, KMR_TIME_PARTITION2, &ta, &tb);
+		rc = launch_partition<W, 2>(h, S, h->l2, grid, bits2, h->bits1);
+		time_end(h, KMR_TIME_PARTITION2, ta, tb);
+		if (rc) return rc;
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		hipFree(dib); hipFree(die); hipFree(dil);
 	}
@@ -739,6 +748,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
 	rc = zero_work_counter(h); if (rc) return rc;
 	const int count_reps = getenv("KMR_COUNT_CHECK") ? atoi(getenv("KMR_COUNT_CHECK")) : 0;
+	hipEvent_t tca, tcb; time_begin(h, KMR_TIME_COUNT, &tca, &tcb);
 	for (int cr = 0; cr <= count_reps; cr++) {
 		if (cr) {      /* debugging aid: the count pass is repeated on the same input and must report the same numbers */
 			FinalizeCounters c0; unsigned long long cur0[2];
@@ -764,13 +774,16 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		}
 		HIPCHK(h, hipGetLastError());
 	}
+	time_end(h, KMR_TIME_COUNT, tca, tcb);
 	FinalizeCounters c; unsigned long long cur[2];
 	HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(cur, cursors, 16, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(ls2); hipFree(lc2); hipFree(fc); hipFree(cursors);
 	h->stats.unique_kmers = c.unique;
 	h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
+	hipEvent_t tma, tmb; time_begin(h, KMR_TIME_BUCKETS, &tma, &tmb);
 	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing);
+	time_end(h, KMR_TIME_BUCKETS, tma, tmb);
 	hipFree(wc); hipFree(sc);
 	if (rc) return rc;
 	time_end(h, 1, ea, eb);
@@ -911,7 +924,7 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 void kmr_destroy(kmr_handle *h) {
 	if (!h) return;
 	if (h->stream) hipStreamSynchronize(h->stream);
-	for (int which = 0; which < 2; which++) for (auto &pr : h->pending_events[which]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+	for (int which = 0; which < KMR_TIME_GROUPS; which++) for (auto &pr : h->pending_events[which]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 	if (h->slots) hipFree(h->slots); if (h->extslots) hipFree(h->extslots);
 	if (h->dP) hipFree(h->dP); if (h->dstats) hipFree(h->dstats); if (h->derr) hipFree(h->derr);
 	free_map(h->weak); free_map(h->sing);
@@ -1281,7 +1294,7 @@ int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n) {
 }
 
 int kmr_kernel_time(kmr_handle *h, int which, double *ms, uint64_t *launches) {
-	if (!h || which < 0 || which > 1) return KMR_ERR_INVALID_ARG;
+	if (!h || which < 0 || which >= KMR_TIME_GROUPS) return KMR_ERR_INVALID_ARG;
 	hipSetDevice(h->device);
 	int rc = sync_state(h); if (rc) return rc;
 	if (ms) *ms = h->ms[which];
@@ -1291,7 +1304,7 @@ int kmr_kernel_time(kmr_handle *h, int which, double *ms, uint64_t *launches) {
 int kmr_kernel_time_reset(kmr_handle *h) {
 	if (!h) return KMR_ERR_INVALID_ARG;
 	int rc = sync_state(h); if (rc) return rc;
-	h->ms[0] = h->ms[1] = 0; h->launches[0] = h->launches[1] = 0;
+	for (int i = 0; i < KMR_TIME_GROUPS; i++) { h->ms[i] = 0; h->launches[i] = 0; }
 	return KMR_OK;
 }
 
