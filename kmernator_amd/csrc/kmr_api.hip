@@ -480,6 +480,7 @@ int stage_reads(kmr_handle *h, const char *bases, const char *quals, const uint6
 const int COUNT_LOG2S = 10;                  /* 1024-slot LDS table per final list (expected ~350 distinct keys) */
 static uint64_t target_list_records() { static const uint64_t v = getenv("KMR_TARGET_LIST") ? strtoull(getenv("KMR_TARGET_LIST"), nullptr, 10) : 2048; return v; }   /* records per final list the partition bits aim for */
 #define TARGET_LIST_RECORDS (target_list_records())
+const double MAX_LIST_DISTINCT = 600.0;       /* distinct keys per final list the 1024-slot table takes comfortably (limit 819) */
 const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
 const uint64_t SUB_BATCH_BASES = 1ull << 28;
 
@@ -593,11 +594,13 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 }
 
 void choose_bits1(kmr_handle *h, uint64_t records_hint) {
-	/* total bits aim at TARGET_LIST_RECORDS per final list; level 2 takes up to max_part_bits(W) of them */
+	/* total bits aim at TARGET_LIST_RECORDS per final list; level 2 takes up to max_part_bits(W) of them.  Two of
+	 * those are held back: if most k-mers turn out to be distinct the lists have to be up to 4x smaller (see the
+	 * distinct probe in finalize_partition_t). */
 	uint64_t est = std::max<uint64_t>(records_hint, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
 	const int mb = max_part_bits(h->W);
 	int T = 0; while (T < 2 * mb && (est >> T) > TARGET_LIST_RECORDS) T++;
-	h->bits1 = std::max(0, T - mb);
+	h->bits1 = std::max(0, std::min(mb, T + 2 - mb));
 }
 
 template <int W> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
@@ -703,10 +706,30 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	std::vector<uint64_t> ib, ie; std::vector<uint32_t> il;
 	for (uint64_t l = 0; l < nl1; l++)
 		for (uint64_t c = hs[l]; c < hs[l + 1]; c += L2_ITEM_CHUNKS) { ib.push_back(c); ie.push_back(std::min(hs[l + 1], c + L2_ITEM_CHUNKS)); il.push_back((uint32_t)l); }
+	/* Final lists are sized by what the count pass can hold in its LDS table: measure the share of distinct keys
+	 * on a sample of level-1 lists, then take enough level-2 bits for ~MAX_LIST_DISTINCT distinct keys per list (and
+	 * at most TARGET_LIST_RECORDS records); if the bits run out the count pass uses its 2048-slot table, and beyond
+	 * that its sub-passes. */
+	double distinct_share = 1.0;
+	if (G) {
+		unsigned long long *dpr, hpr[2] = {0, 0};
+		const uint32_t n_probes = (uint32_t)std::min<uint64_t>(PROBE_LISTS, nl1);
+		const size_t tbytes = 8 * ((size_t)n_probes * PROBE_SLOTS + 2);
+		HIPCHK(h, hipMalloc((void **)&dpr, tbytes)); HIPCHK(h, hipMemsetAsync(dpr, 0, tbytes, h->stream));
+		hipLaunchKernelGGL(distinct_probe_kernel<W>, dim3(n_probes * PROBE_SPLIT), dim3(256), 0, h->stream, pool_view(h, h->l1), ls1, lc1, nl1, h->kb, part_rot(h),
+		                   (int)h->bits1, n_probes, dpr + 2, dpr);
+		HIPCHK(h, hipGetLastError());
+		HIPCHK(h, hipMemcpyAsync(hpr, dpr, 16, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
+		hipFree(dpr);
+		if (hpr[0] >= 256) distinct_share = std::min(1.0, std::max(0.01, (double)hpr[1] / (double)hpr[0]));
+		if (getenv("KMR_DEBUG")) fprintf(stderr, "distinct probe: %llu records, %llu distinct -> share %.3f\n", hpr[0], hpr[1], distinct_share);
+	}
 	const int mb = max_part_bits(W);
-	int T = 0; while (T < 2 * mb && (G >> T) > TARGET_LIST_RECORDS) T++;
+	int T = 0; while (T < h->bits1 + mb && ((G >> T) > TARGET_LIST_RECORDS || (double)(G >> T) * distinct_share > MAX_LIST_DISTINCT)) T++;
 	const int bits2 = std::max(0, std::min(mb, T - h->bits1));
 	const uint64_t nl2 = 1ull << (h->bits1 + bits2);
+	const int count_log2s = (double)(G >> (h->bits1 + bits2)) * distinct_share > MAX_LIST_DISTINCT ? 11 : COUNT_LOG2S;
+	if (getenv("KMR_DEBUG")) fprintf(stderr, "count pass: %llu lists of ~%llu records, table 2^%d\n", (unsigned long long)nl2, (unsigned long long)(G >> (h->bits1 + bits2)), count_log2s);
 	rc = pool_reserve(h, h->l2, G / CH + ib.size() * (1ull << bits2) + (uint64_t)part_grid(h) * 512 + 64, false); if (rc) return rc;
 	if (!ib.empty()) {
 		uint64_t *dib, *die; uint32_t *dil;
@@ -760,17 +783,17 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 			HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
 			rc = zero_work_counter(h); if (rc) return rc;
 		}
-		const int grid = (int)std::min<uint64_t>((uint64_t)part_grid(h) * (getenv("KMR_COUNT_GRIDX") ? atoi(getenv("KMR_COUNT_GRIDX")) : 2), nl2);
-		if (getenv("KMR_COUNT_LOG2S") && atoi(getenv("KMR_COUNT_LOG2S")) == 9) {
-			auto kern = count_kernel<W, false, 9>;
-			const size_t smem = count_smem_bytes<W, 9>();
+		const int grid = (int)std::min<uint64_t>((uint64_t)part_grid(h) * 2, nl2);
+		if (count_log2s == 11) {
+			auto kern = count_kernel<W, false, 11>;
+			const size_t smem = count_smem_bytes<W, 11>();
 			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l2), ls2, lc2, nl2, out, f, h->work_counter);
 		} else {
-		auto kern = count_kernel<W, false, COUNT_LOG2S>;
-		const size_t smem = count_smem_bytes<W, COUNT_LOG2S>();
-		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l2), ls2, lc2, nl2, out, f, h->work_counter);
+			auto kern = count_kernel<W, false, COUNT_LOG2S>;
+			const size_t smem = count_smem_bytes<W, COUNT_LOG2S>();
+			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l2), ls2, lc2, nl2, out, f, h->work_counter);
 		}
 		HIPCHK(h, hipGetLastError());
 	}

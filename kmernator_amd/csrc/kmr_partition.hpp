@@ -461,6 +461,55 @@ __global__ void pool_records_kernel(const uint32_t *chunk_list, const uint32_t *
 	if ((threadIdx.x & 63) == 0) { atomicAdd(total, s); atomicAdd(nvalid, v); }
 }
 
+/* Share of distinct keys among the records, measured on a sample, so the count pass can size its lists: a k-mer's
+ * copies all have the same partition order, so the PROBE_SPLIT blocks of probe p scan ONE level-1 list and keep the
+ * records whose next `sel` order bits are zero -- the records one would-be final list would receive, all copies
+ * included -- and count them and their distinct 64-bit fingerprints in a small table in device memory (few records
+ * pass the filter, so its atomics are few).  out[0] += records, out[1] += distinct. */
+static const int PROBE_SLOTS = 8192, PROBE_SPLIT = 16, PROBE_LISTS = 64;
+template <int W>
+__global__ __launch_bounds__(256)
+void distinct_probe_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t kb, uint32_t rot,
+                           int bits1, uint32_t n_probes, unsigned long long *tables /* [n_probes][PROBE_SLOTS], zero */, unsigned long long *out) {
+	typedef Record<W> Rec;
+	const uint32_t p = blockIdx.x / PROBE_SPLIT, part = blockIdx.x % PROBE_SPLIT;
+	const uint64_t l = (uint64_t)p * n_lists / n_probes;
+	const uint64_t c0 = list_start[l], c1 = list_start[l + 1];
+	unsigned long long *fp = tables + (size_t)p * PROBE_SLOTS;
+	/* about 2000 records of the list pass the filter */
+	int sel = 0; while (sel < 40 - bits1 && (((c1 - c0) * CH) >> sel) > 2000) sel++;
+	unsigned long long mine = 0, fresh = 0;
+	constexpr int UNR = 4;
+	const uint64_t nw = (uint64_t)(blockDim.x >> 6) * PROBE_SPLIT;
+	for (uint64_t cb = c0 + (uint64_t)part * (blockDim.x >> 6) + (threadIdx.x >> 6); cb < c1; cb += nw * UNR) {
+		uint64_t d[UNR]; Rec r[UNR];
+#pragma unroll
+		for (int u = 0; u < UNR; u++) { const uint64_t ci = cb + (uint64_t)u * nw; d[u] = ci < c1 ? list_chunks[ci] : 0ull; }
+#pragma unroll
+		for (int u = 0; u < UNR; u++) {
+			r[u].w = 0.0f;
+			if ((uint32_t)(threadIdx.x & 63) < (uint32_t)(d[u] >> 32)) r[u] = ((const Rec *)(pool.base + (size_t)(uint32_t)d[u] * CH * sizeof(Rec)))[threadIdx.x & 63];
+		}
+#pragma unroll
+		for (int u = 0; u < UNR; u++) {
+			if (r[u].w == 0.0f) continue;
+			const uint64_t g = part_order<W>(r[u].key, kb, rot);
+			if (sel && ((g << bits1) >> (64 - sel)) != 0) continue;
+			mine++;
+			const unsigned long long f = part_hash<W>(r[u].key) | 1ull;
+			uint32_t s = (uint32_t)(f >> 40) & (PROBE_SLOTS - 1);
+			for (int probe = 0; probe < PROBE_SLOTS; probe++) {
+				const unsigned long long old = atomicCAS(&fp[s], 0ull, f);
+				if (old == 0ull) { fresh++; break; }
+				if (old == f) break;
+				s = (s + 1) & (PROBE_SLOTS - 1);
+			}
+		}
+	}
+	mine = wave_sum(mine); fresh = wave_sum(fresh);
+	if ((threadIdx.x & 63) == 0) { if (mine) atomicAdd(&out[0], mine); if (fresh) atomicAdd(&out[1], fresh); }
+}
+
 /* debugging aid (KMR_DEBUG): walk a pool through its chunk CSR; count the records and those whose partition hash
  * does not match the list they are filed under */
 template <int W>

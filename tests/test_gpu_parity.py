@@ -357,6 +357,25 @@ def test_build_modes_agree_at_scale():
     assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
 
 
+@pytest.mark.parametrize("k", [31, 127])
+def test_mostly_distinct_kmers_both_modes_agree(k):
+    """Low coverage (most k-mers seen once): the streaming path sizes its final lists from the measured share of
+    distinct keys (distinct_probe_kernel) instead of overflowing the count pass's LDS table into sub-passes; the
+    result must not depend on that choice -- byte-identical weak image and statistics against the table path."""
+    n = 400000
+    rb = synth_reads(n, read_len=150, genome_len=60 * n, seed=11)      # ~2.5x coverage
+    res = []
+    for mode in MODES:
+        c = ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), build_mode=mode)
+        p = ka.KmerSpectrum(c)
+        add(p, rb)
+        p.finalize(2)
+        res.append((p.stats(), p.image(KMR_MAP_WEAK)))
+    assert res[0][0] == res[1][0]
+    assert res[0][0]["unique_kmers"] > 0.6 * res[0][0]["raw_good_kmers"]
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 def test_c2_full_size_properties():
     """BASELINE.json configs[1] at full size (10M reads x 150 bp, k=31, 1.2e9 k-mers) through the device-pointer
     entry point bench.py times: counts conserve the k-mers, the image is sorted and bucket-consistent (sampled),
