@@ -202,6 +202,13 @@ int kmr_load_image(kmr_handle *h, int which_map, const void *src, uint64_t len);
  * counts[c] = number of weak entries with count == c for c < n_bins-1, last bin
  * collects the rest; weights[c] = sum of weightedCount (may be NULL). */
 int kmr_count_histogram(kmr_handle *h, uint64_t *counts, double *weights, uint32_t n_bins);
+/* KmerSpectrum::Histogram(zoom_max, log_base).set(spectrum) (src/KmerSpectrum.h:909-1057; getHistogram uses
+ * Histogram(256), :1066-1071): per bucket visits, visitedCount and visitedWeight over the weak map and, when it
+ * is kept, the singleton map.  Bucket of a count: count <= zoom_max ? count : log(count)/log(log_base) -
+ * zoomLogSkip + zoom_max (:936-938).  The arrays need kmr_histogram_bins(zoom_max) = 65538 + zoom_max entries. */
+uint32_t kmr_histogram_bins(uint32_t zoom_max);
+int kmr_histogram(kmr_handle *h, uint32_t zoom_max, double log_base, uint64_t *visits,
+                  uint64_t *visited_count, double *visited_weight, uint32_t n_bins);
 
 /* MeraculousDistributedKmerSpectrum::dumpCounts / dumpGraphs
  * (src/Meraculous.h:107-134): text lines for every weak entry with
@@ -258,6 +265,35 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
                              void *dev_records, uint64_t seg_capacity, void *dev_seg_counts);
 /* Insert n records (any owner mix that belongs to this handle) into the table. */
 int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n_records);
+
+/* ---- f2: FASTQ ingest on the device -------------------------------------
+ * Parses a whole in-memory FASTQ block into a device-resident read batch:
+ * FastqStreamParser::readRecord (src/ReadFileReader.h:768-835) + ReadFileReader::nextRead
+ * (:296-329: Casava-1.8 failed-filter reads are dropped, bases upper-cased, #bases == #quals)
+ * + ReadSet::appendFasta/addRead/validateFastqStart (src/ReadSet.cpp:136-141,311-345,
+ * src/ReadSet.h:171-209): qualities are rescaled from input_quality_base (33, 64, or 0 = the
+ * handle's fastq_start_char; --fastq-base-quality) to the handle's fastq_start_char, and a read
+ * among the first 19 999 whose minimum quality lies outside [start, start+40] flips the input base
+ * once for the whole batch, as __setFastqStart does.  store_comment = GlobalOptions::isCommentStored()
+ * (the reference's default is 1).  Malformed input (what makes the reference throw, plus non-'@' junk
+ * between records, which the reference skips) returns KMR_ERR_INVALID_ARG. */
+typedef struct kmr_reads kmr_reads;
+int kmr_ingest_fastq(kmr_handle *h, const char *text, uint64_t len, uint32_t input_quality_base,
+                     int store_comment, kmr_reads **out);
+int kmr_ingest_fastq_dev(kmr_handle *h, const void *dev_text, uint64_t len, uint32_t input_quality_base,
+                         int store_comment, kmr_reads **out);
+/* n_filtered = records dropped by the Casava filter; input_quality_base = the base after detection */
+int kmr_reads_info(const kmr_reads *r, uint64_t *n_reads, uint64_t *total_bases,
+                   uint32_t *input_quality_base, uint64_t *n_filtered);
+/* device arrays in the layout kmr_add_reads_dev takes: bases[total], quals[total], u64 offsets[n+1] */
+int kmr_reads_device_ptrs(const kmr_reads *r, void **dev_bases, void **dev_quals, void **dev_offsets);
+/* copies to host; any pointer may be NULL.  name_off/name_len: span of each read's name line
+ * (after '@') in the input text, for the host-side Read names */
+int kmr_reads_copy(const kmr_reads *r, char *bases, char *quals, uint64_t *offsets,
+                   uint64_t *name_off, uint32_t *name_len);
+/* kmr_add_reads_dev on the batch, then kmr_sync */
+int kmr_add_read_batch(kmr_handle *h, const kmr_reads *r, uint64_t first_global_read_idx);
+void kmr_reads_free(kmr_reads *r);
 
 /* Raw HIP stream of the handle (hipStream_t) so callers can order their own
  * work (torch.cuda.ExternalStream) against it. */

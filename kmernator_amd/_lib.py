@@ -53,6 +53,8 @@ EXPORTS = [
     "kmr_dump_mercount", "kmr_dump_mergraph", "kmr_hash", "kmr_bucket_idx", "kmr_local_thread_id",
     "kmr_distributed_thread_id", "kmr_compress_sequence", "kmr_least_complement", "kmr_extract_by_owner_dev",
     "kmr_insert_records_dev", "kmr_stream", "kmr_kernel_time", "kmr_kernel_time_reset", "kmr_reset", "kmr_release_table", "kmr_score_reads",
+    "kmr_ingest_fastq", "kmr_ingest_fastq_dev", "kmr_reads_info", "kmr_reads_device_ptrs", "kmr_reads_copy",
+    "kmr_add_read_batch", "kmr_reads_free", "kmr_histogram", "kmr_histogram_bins",
 ]
 
 _lib = None
@@ -108,6 +110,17 @@ def load():
     lib.kmr_score_reads.argtypes = [vp, vp, u64p, C.c_uint64, C.c_double, C.c_int, u32p, u32p, C.POINTER(C.c_float), u8p]
     lib.kmr_reset.argtypes = [vp]
     lib.kmr_release_table.argtypes = [vp]
+    lib.kmr_ingest_fastq.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(vp)]
+    lib.kmr_ingest_fastq_dev.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(vp)]
+    lib.kmr_reads_info.argtypes = [vp, u64p, u64p, u32p, u64p]
+    lib.kmr_reads_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.kmr_reads_copy.argtypes = [vp, vp, vp, u64p, u64p, u32p]
+    lib.kmr_add_read_batch.argtypes = [vp, vp, C.c_uint64]
+    lib.kmr_reads_free.argtypes = [vp]
+    lib.kmr_reads_free.restype = None
+    lib.kmr_histogram_bins.restype = C.c_uint32
+    lib.kmr_histogram_bins.argtypes = [C.c_uint32]
+    lib.kmr_histogram.argtypes = [vp, C.c_uint32, C.c_double, u64p, u64p, f64p, C.c_uint32]
     _lib = lib
     return lib
 

@@ -20,6 +20,7 @@
 #include "../../include/kmernator_amd.h"
 #include "kmr_kernels.hpp"
 #include "kmr_partition.hpp"
+#include "kmr_ingest.hpp"
 
 using namespace kmr;
 
@@ -86,6 +87,16 @@ struct kmr_handle {
 	double ms[KMR_TIME_GROUPS] = {0};
 	uint64_t launches[KMR_TIME_GROUPS] = {0};
 	std::vector<std::pair<hipEvent_t, hipEvent_t> > pending_events[KMR_TIME_GROUPS];
+};
+
+/* device-resident read batch produced by kmr_ingest_fastq* */
+struct kmr_reads {
+	int device = 0;
+	uint8_t *bases = nullptr, *quals = nullptr;   /* 64 bytes of padding behind the data: extract_kernel stages 16-byte blocks */
+	uint64_t *offsets = nullptr;                  /* [n + 1] */
+	uint64_t *name_off = nullptr; uint32_t *name_len = nullptr;
+	uint64_t n = 0, total = 0, filtered = 0;
+	uint32_t input_base = 0;
 };
 
 namespace {
@@ -1191,6 +1202,36 @@ int kmr_count_histogram(kmr_handle *h, uint64_t *counts, double *weights, uint32
 	return KMR_OK;
 }
 
+/* KmerSpectrum::Histogram (src/KmerSpectrum.h:909-1057) of the finalized spectrum: Histogram(zoom_max, log_base).set(ks) */
+uint32_t kmr_histogram_bins(uint32_t zoom_max) { return (1u << 16) + 1u + zoom_max + 1u; }       /* ctor :948-950 */
+int kmr_histogram(kmr_handle *h, uint32_t zoom_max, double log_base, uint64_t *visits, uint64_t *visited_count, double *visited_weight, uint32_t n_bins) {
+	if (!h || !visits || !visited_count || !visited_weight) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_histogram before kmr_finalize");
+	if (zoom_max > 65535 || !(log_base > 1.0)) return fail(h, KMR_ERR_INVALID_ARG, "bad zoom_max / log_base");
+	const uint32_t nb = kmr_histogram_bins(zoom_max);
+	if (n_bins < nb) return fail(h, KMR_ERR_CAPACITY, "histogram arrays need kmr_histogram_bins(zoom_max) entries");
+	hipSetDevice(h->device);
+	/* getIdx (:936-938) for every 16-bit count, with the host's libm */
+	std::vector<uint32_t> lut(65536, 0);
+	const double logFactor = log(log_base);
+	const unsigned int zoomLogSkip = (unsigned int)(log((double)zoom_max + 1.0) / logFactor - 1.0);
+	for (uint32_t c = 1; c < 65536; c++) lut[c] = c <= zoom_max ? c : (unsigned int)(log((double)c) / logFactor - zoomLogSkip + zoom_max);
+	uint32_t *dl; unsigned long long *dv, *dc; double *dw;
+	HIPCHK(h, hipMalloc((void **)&dl, 4 * 65536)); HIPCHK(h, hipMalloc((void **)&dv, 8ull * nb)); HIPCHK(h, hipMalloc((void **)&dc, 8ull * nb)); HIPCHK(h, hipMalloc((void **)&dw, 8ull * nb));
+	HIPCHK(h, hipMemcpyAsync(dl, lut.data(), 4 * 65536, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(h, hipMemsetAsync(dv, 0, 8ull * nb, h->stream)); HIPCHK(h, hipMemsetAsync(dc, 0, 8ull * nb, h->stream)); HIPCHK(h, hipMemsetAsync(dw, 0, 8ull * nb, h->stream));
+	if (h->weak.present && h->weak.n)
+		hipLaunchKernelGGL(ref_histogram_kernel, dim3(grid_for(h->weak.n, 256, 2048)), dim3(256), 0, h->stream, h->weak.vals, h->ext ? 15u : 3u, (const uint8_t *)nullptr, h->weak.n, dl, dv, dc, dw);
+	if (h->has_singletons && h->sing.present && h->sing.n)
+		hipLaunchKernelGGL(ref_histogram_kernel, dim3(grid_for(h->sing.n, 256, 2048)), dim3(256), 0, h->stream, (const uint32_t *)nullptr, 0u, h->sing.sweight, h->sing.n, dl, dv, dc, dw);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipMemcpyAsync(visits, dv, 8ull * nb, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(visited_count, dc, 8ull * nb, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipMemcpyAsync(visited_weight, dw, 8ull * nb, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(dl); hipFree(dv); hipFree(dc); hipFree(dw);
+	return KMR_OK;
+}
+
 /* text dumps (src/Meraculous.h:107-134): formatting is host work on the downloaded weak map */
 static int dump_text(kmr_handle *h, const char *path, uint32_t min_depth, bool graph) {
 	if (!h || !path) return KMR_ERR_INVALID_ARG;
@@ -1228,6 +1269,137 @@ static int dump_text(kmr_handle *h, const char *path, uint32_t min_depth, bool g
 }
 int kmr_dump_mercount(kmr_handle *h, const char *path, uint32_t min_depth) { return dump_text(h, path, min_depth, false); }
 int kmr_dump_mergraph(kmr_handle *h, const char *path, uint32_t min_depth) { return dump_text(h, path, min_depth, true); }
+
+/* ---- f2: FASTQ ingest on the device (kmr_ingest.hpp) ------------------------ */
+static int ingest_dev(kmr_handle *h, const uint8_t *text, uint64_t len, uint32_t input_base, int store_comment, kmr_reads **out) {
+	const uint32_t start = h->cfg.fastq_start_char;
+	if (input_base == 0) input_base = start;
+	if ((input_base != 33 && input_base != 64) || (start != 33 && start != 64))
+		return fail(h, KMR_ERR_INVALID_ARG, "fastq quality base must be 33 or 64 (src/Options.h:490)");
+	kmr_reads *R = new kmr_reads(); R->device = h->device; R->input_base = input_base;
+	uint32_t *blk = nullptr, *derr = nullptr, *llen = nullptr, *keep = nullptr, *klen = nullptr;
+	uint64_t *bbase = nullptr, *lstart = nullptr, *kidx = nullptr, *boff = nullptr;
+	auto cleanup = [&]() { hipFree(blk); hipFree(derr); hipFree(llen); hipFree(keep); hipFree(klen); hipFree(bbase); hipFree(lstart); hipFree(kidx); hipFree(boff); };
+#define ING(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); kmr_reads_free(R); \
+	return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+#define INGRC(expr) do { int rc_ = (expr); if (rc_) { cleanup(); kmr_reads_free(R); return rc_; } } while (0)
+	const uint64_t nblk = (len + (uint64_t)ING_THREADS * ING_BYTES - 1) / ((uint64_t)ING_THREADS * ING_BYTES);
+	uint64_t n_lines = 0;
+	ING(hipMalloc((void **)&derr, 8)); ING(hipMemsetAsync(derr, 0, 8, h->stream));
+	if (nblk) {
+		if (nblk > 0x7fffffffull) { cleanup(); kmr_reads_free(R); return fail(h, KMR_ERR_INVALID_ARG, "FASTQ block too large for one call"); }
+		ING(hipMalloc((void **)&blk, 4 * nblk)); ING(hipMalloc((void **)&bbase, 8 * (nblk + 1)));
+		hipLaunchKernelGGL(ingest_count_lines, dim3((unsigned)nblk), dim3(ING_THREADS), 0, h->stream, text, len, blk);
+		ING(hipGetLastError());
+		INGRC(exclusive_scan(h, blk, nblk, bbase));
+		ING(hipMemcpy(&n_lines, bbase + nblk, 8, hipMemcpyDeviceToHost));
+	}
+	if (n_lines % 4 != 0) { cleanup(); kmr_reads_free(R); return fail(h, KMR_ERR_INVALID_ARG, "malformed FASTQ: " + std::to_string(n_lines) + " non-empty lines is not a multiple of 4 (truncated record)"); }
+	const uint64_t nrec = n_lines / 4;
+	uint64_t n_kept = 0, total = 0;
+	if (nrec) {
+		ING(hipMalloc((void **)&lstart, 8 * n_lines)); ING(hipMalloc((void **)&llen, 4 * n_lines));
+		hipLaunchKernelGGL(ingest_index_lines, dim3((unsigned)nblk), dim3(ING_THREADS), 0, h->stream, text, len, bbase, lstart, llen, derr);
+		ING(hipMalloc((void **)&keep, 4 * nrec)); ING(hipMalloc((void **)&klen, 4 * nrec));
+		ING(hipMalloc((void **)&kidx, 8 * (nrec + 1))); ING(hipMalloc((void **)&boff, 8 * (nrec + 1)));
+		hipLaunchKernelGGL(ingest_records, dim3(grid_for(nrec)), dim3(256), 0, h->stream, text, lstart, llen, nrec, store_comment, keep, klen, derr);
+		ING(hipGetLastError());
+		INGRC(exclusive_scan(h, keep, nrec, kidx));
+		INGRC(exclusive_scan(h, klen, nrec, boff));
+		uint32_t e = 0;
+		ING(hipMemcpy(&e, derr, 4, hipMemcpyDeviceToHost));
+		if (e) {
+			std::string why;
+			if (e & ING_ERR_NAME) why += " a record does not start with '@' or has an empty name;";
+			if (e & ING_ERR_BLANK) why += " an empty line inside a record;";
+			if (e & ING_ERR_PLUS) why += " missing '+' line;";
+			if (e & ING_ERR_LEN) why += " number of bases and quals not equal;";
+			cleanup(); kmr_reads_free(R);
+			return fail(h, KMR_ERR_INVALID_ARG, "malformed FASTQ:" + why);
+		}
+		ING(hipMemcpy(&n_kept, kidx + nrec, 8, hipMemcpyDeviceToHost)); ING(hipMemcpy(&total, boff + nrec, 8, hipMemcpyDeviceToHost));
+	}
+	R->n = n_kept; R->total = total; R->filtered = nrec - n_kept;
+	ING(hipMalloc((void **)&R->bases, total + 64)); ING(hipMalloc((void **)&R->quals, total + 64)); ING(hipMalloc((void **)&R->offsets, 8 * (n_kept + 1)));
+	ING(hipMalloc((void **)&R->name_off, 8 * std::max<uint64_t>(1, n_kept))); ING(hipMalloc((void **)&R->name_len, 4 * std::max<uint64_t>(1, n_kept)));
+	ING(hipMemsetAsync(R->bases + total, 0, 64, h->stream)); ING(hipMemsetAsync(R->quals + total, 0, 64, h->stream));
+	ING(hipMemcpyAsync(R->offsets + n_kept, &total, 8, hipMemcpyHostToDevice, h->stream));
+	if (nrec) {
+		/* appendFasta rescales every read from the input base to Read::FASTQ_START_CHAR as it is read (src/ReadSet.cpp:324,336) */
+		hipLaunchKernelGGL(ingest_copy, dim3(grid_for(nrec, 4, 1 << 16)), dim3(256), 0, h->stream, text, lstart, llen, nrec, keep, kidx, boff,
+		                   (int)start - (int)input_base, start, R->bases, R->quals, R->offsets, R->name_off, R->name_len, derr + 1);
+		ING(hipGetLastError());
+		uint32_t flip = 0;
+		ING(hipMemcpyAsync(&flip, derr + 1, 4, hipMemcpyDeviceToHost, h->stream)); ING(hipStreamSynchronize(h->stream));
+		const uint32_t want = start == 33 ? 64u : 33u;        /* __setFastqStart(the other base), src/ReadSet.h:174-186 */
+		if (flip && want != input_base) {
+			if (total) hipLaunchKernelGGL(ingest_shift_quals, dim3(grid_for(total)), dim3(256), 0, h->stream, R->quals, total, (int)input_base - (int)want);
+			ING(hipGetLastError());
+			R->input_base = want;
+		}
+	}
+	ING(hipStreamSynchronize(h->stream));
+#undef ING
+#undef INGRC
+	cleanup();
+	*out = R;
+	return KMR_OK;
+}
+
+int kmr_ingest_fastq_dev(kmr_handle *h, const void *dev_text, uint64_t len, uint32_t input_quality_base, int store_comment, kmr_reads **out) {
+	if (!h || !out || (len && !dev_text)) return KMR_ERR_INVALID_ARG;
+	*out = nullptr;
+	hipSetDevice(h->device);
+	return ingest_dev(h, (const uint8_t *)dev_text, len, input_quality_base, store_comment, out);
+}
+int kmr_ingest_fastq(kmr_handle *h, const char *text, uint64_t len, uint32_t input_quality_base, int store_comment, kmr_reads **out) {
+	if (!h || !out || (len && !text)) return KMR_ERR_INVALID_ARG;
+	*out = nullptr;
+	hipSetDevice(h->device);
+	uint8_t *d = nullptr;
+	HIPCHK(h, hipMalloc((void **)&d, len + 16));
+	hipError_t e = hipMemcpy(d, text, len, hipMemcpyHostToDevice);
+	if (e != hipSuccess) { hipFree(d); h->err = std::string("hipMemcpy(FASTQ text): ") + hipGetErrorString(e); return KMR_ERR_HIP; }
+	const int rc = ingest_dev(h, d, len, input_quality_base, store_comment, out);
+	hipFree(d);
+	return rc;
+}
+void kmr_reads_free(kmr_reads *r) {
+	if (!r) return;
+	hipSetDevice(r->device);
+	if (r->bases) hipFree(r->bases); if (r->quals) hipFree(r->quals); if (r->offsets) hipFree(r->offsets);
+	if (r->name_off) hipFree(r->name_off); if (r->name_len) hipFree(r->name_len);
+	delete r;
+}
+int kmr_reads_info(const kmr_reads *r, uint64_t *n_reads, uint64_t *total_bases, uint32_t *input_quality_base, uint64_t *n_filtered) {
+	if (!r) return KMR_ERR_INVALID_ARG;
+	if (n_reads) *n_reads = r->n; if (total_bases) *total_bases = r->total;
+	if (input_quality_base) *input_quality_base = r->input_base; if (n_filtered) *n_filtered = r->filtered;
+	return KMR_OK;
+}
+int kmr_reads_device_ptrs(const kmr_reads *r, void **bases, void **quals, void **offsets) {
+	if (!r) return KMR_ERR_INVALID_ARG;
+	if (bases) *bases = r->bases; if (quals) *quals = r->quals; if (offsets) *offsets = r->offsets;
+	return KMR_OK;
+}
+int kmr_reads_copy(const kmr_reads *r, char *bases, char *quals, uint64_t *offsets, uint64_t *name_off, uint32_t *name_len) {
+	if (!r) return KMR_ERR_INVALID_ARG;
+	hipSetDevice(r->device);
+	hipError_t e = hipSuccess;
+	if (bases && r->total && e == hipSuccess) e = hipMemcpy(bases, r->bases, r->total, hipMemcpyDeviceToHost);
+	if (quals && r->total && e == hipSuccess) e = hipMemcpy(quals, r->quals, r->total, hipMemcpyDeviceToHost);
+	if (offsets && e == hipSuccess) e = hipMemcpy(offsets, r->offsets, 8 * (r->n + 1), hipMemcpyDeviceToHost);
+	if (name_off && r->n && e == hipSuccess) e = hipMemcpy(name_off, r->name_off, 8 * r->n, hipMemcpyDeviceToHost);
+	if (name_len && r->n && e == hipSuccess) e = hipMemcpy(name_len, r->name_len, 4 * r->n, hipMemcpyDeviceToHost);
+	return e == hipSuccess ? KMR_OK : KMR_ERR_HIP;
+}
+int kmr_add_read_batch(kmr_handle *h, const kmr_reads *r, uint64_t first_global_read_idx) {
+	if (!h || !r) return KMR_ERR_INVALID_ARG;
+	if (r->device != h->device) return fail(h, KMR_ERR_INVALID_ARG, "read batch lives on another device");
+	int rc = kmr_add_reads_dev(h, r->bases, r->quals, r->offsets, r->n, r->total, first_global_read_idx, nullptr);
+	if (!rc) rc = kmr_sync(h);
+	return rc;
+}
 
 /* ---- stateless helpers ------------------------------------------------- */
 uint64_t kmr_hash(const uint8_t *key, uint32_t len) {

@@ -1,0 +1,154 @@
+/*
+ * kmr_ingest.hpp -- FASTQ text -> device-resident read batch.
+ *
+ * Replaces, for a whole in-memory FASTQ block, FastqStreamParser::readRecord
+ * (src/ReadFileReader.h:768-835), ReadFileReader::nextRead (:296-329: Casava-1.8 failed-filter
+ * reads are skipped, bases upper-cased, #bases == #quals), SequenceRecordParser::trimName /
+ * isCommentCasava18 (src/Utils.h:561-598,678-685) and the quality handling of
+ * ReadSet::appendFasta/addRead/validateFastqStart/__setFastqStart (src/ReadSet.cpp:136-141,311-345,
+ * src/ReadSet.h:171-209, src/Sequence.h:456-479).
+ *
+ * The reference walks the text line by line; here every byte is looked at once, in parallel:
+ *   ingest_count_lines   per 4 KB block: number of non-empty line starts
+ *   (exclusive scan)
+ *   ingest_index_lines   line_start[i], line_len[i] for the i-th non-empty line
+ *   ingest_records       record r = lines 4r..4r+3: markers, lengths, Casava filter -> keep[r], len[r]
+ *   (two exclusive scans: kept index, base offset)
+ *   ingest_copy          one wavefront per record: upper-cased bases, rescaled quals, offsets, name
+ *                        spans, and the quality-base check of the first 19 999 kept reads
+ *   ingest_shift_quals   the one-time 33 <-> 64 flip of __setFastqStart, applied to the whole batch
+ *
+ * Strictness: the reference silently skips up to 100 000 lines that do not start with '@' where a
+ * record should begin (readName); this parser accepts blank lines between records only and reports
+ * anything else as malformed.  Every input the parser accepts is parsed exactly as the reference does.
+ */
+#ifndef KMR_INGEST_HPP_
+#define KMR_INGEST_HPP_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmr {
+
+enum { ING_ERR_NAME = 1, ING_ERR_PLUS = 2, ING_ERR_LEN = 4, ING_ERR_BLANK = 8, ING_ERR_TRUNC = 16, ING_ERR_BASE = 32 };
+static const int ING_THREADS = 256, ING_BYTES = 16;      /* bytes per thread: one block looks at 4 KB */
+static const uint32_t ING_VALIDATE_READS = 20000;        /* validateFastqStart: getSize() < 20000, src/ReadSet.h:172 */
+
+__device__ __forceinline__ bool ing_is_start(const uint8_t *text, uint64_t p) { return (p == 0 || text[p - 1] == '\n') && text[p] != '\n'; }
+
+/* exclusive prefix of v over the block (256 threads); total in *sum */
+__device__ __forceinline__ uint32_t ing_block_scan(uint32_t v, uint32_t *sum) {
+	__shared__ uint32_t wsum[ING_THREADS / 64];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t inc = v;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+	if (lane == 63) wsum[wave] = inc;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < ING_THREADS / 64; w++) { if (w < wave) base += wsum[w]; tot += wsum[w]; }
+	*sum = tot;
+	__syncthreads();
+	return base + inc - v;
+}
+
+__global__ __launch_bounds__(ING_THREADS)
+void ingest_count_lines(const uint8_t *text, uint64_t len, uint32_t *block_lines) {
+	const uint64_t p0 = ((uint64_t)blockIdx.x * ING_THREADS + threadIdx.x) * ING_BYTES;
+	uint32_t c = 0;
+	for (int j = 0; j < ING_BYTES; j++) { const uint64_t p = p0 + j; if (p < len && ing_is_start(text, p)) c++; }
+	uint32_t tot;
+	ing_block_scan(c, &tot);
+	if (threadIdx.x == 0) block_lines[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(ING_THREADS)
+void ingest_index_lines(const uint8_t *text, uint64_t len, const uint64_t *block_base, uint64_t *line_start, uint32_t *line_len, uint32_t *err) {
+	const uint64_t p0 = ((uint64_t)blockIdx.x * ING_THREADS + threadIdx.x) * ING_BYTES;
+	uint32_t c = 0;
+	for (int j = 0; j < ING_BYTES; j++) { const uint64_t p = p0 + j; if (p < len && ing_is_start(text, p)) c++; }
+	uint32_t tot;
+	uint64_t idx = block_base[blockIdx.x] + ing_block_scan(c, &tot);
+	if (!c) return;
+	for (int j = 0; j < ING_BYTES; j++) {
+		const uint64_t p = p0 + j;
+		if (p < len && ing_is_start(text, p)) {
+			uint64_t e = p;
+			while (e < len && text[e] != '\n') e++;
+			if (e - p > 0xffffffffull) { atomicOr(err, (uint32_t)ING_ERR_LEN); e = p; }
+			line_start[idx] = p; line_len[idx] = (uint32_t)(e - p);
+			idx++;
+		}
+	}
+}
+
+/* one thread per record */
+__global__ void ingest_records(const uint8_t *text, const uint64_t *line_start, const uint32_t *line_len, uint64_t n_records, int store_comment,
+                               uint32_t *keep, uint32_t *kept_len, uint32_t *err) {
+	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n_records; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t s0 = line_start[4 * r], s1 = line_start[4 * r + 1], s2 = line_start[4 * r + 2], s3 = line_start[4 * r + 3];
+		const uint32_t l0 = line_len[4 * r], l1 = line_len[4 * r + 1], l2 = line_len[4 * r + 2], l3 = line_len[4 * r + 3];
+		uint32_t e = 0;
+		if (text[s0] != '@' || l0 < 2) e |= ING_ERR_NAME;
+		if (s1 != s0 + l0 + 1 || s2 != s1 + l1 + 1 || s3 != s2 + l2 + 1) e |= ING_ERR_BLANK;   /* an empty line inside a record */
+		if (text[s2] != '+') e |= ING_ERR_PLUS;
+		if (l3 != l1) e |= ING_ERR_LEN;
+		if (e) { atomicOr(err, e); keep[r] = 0; kept_len[r] = 0; continue; }
+		/* trimName on the name line without its marker (src/Utils.h:561-598) */
+		const uint8_t *nm = text + s0 + 1; const uint32_t nl = l0 - 1;
+		uint32_t ws = nl;
+		for (uint32_t i = 0; i < nl; i++) { const uint8_t c = nm[i]; if (c == ' ' || c == '\t' || c == '\r' || c == '\n') { ws = i; break; } }
+		if (ws == 0) { atomicOr(err, (uint32_t)ING_ERR_NAME); keep[r] = 0; kept_len[r] = 0; continue; }   /* an empty name ends the reference's stream */
+		bool good = true;
+		if (ws < nl && nl >= ws + 2) {
+			const uint8_t *c = nm + ws + 1; const uint32_t cl = nl - ws - 1;
+			const bool casava = cl >= 6 && c[1] == ':' && c[3] == ':' && c[5] == ':' && (c[0] == '1' || c[0] == '2') && (c[2] == 'Y' || c[2] == 'N');
+			if (casava && (ws <= 2 || nm[ws - 2] != '/')) {
+				const uint32_t p2 = store_comment ? ws : ws + 2;     /* the reference moves pos when it rewrites "name 1:Y" to "name/1" */
+				if (nm[p2 + 3] == 'Y') good = false;
+			}
+		}
+		keep[r] = good ? 1u : 0u;
+		kept_len[r] = good ? l1 : 0u;
+	}
+}
+
+/* one wavefront per record */
+__global__ __launch_bounds__(256)
+void ingest_copy(const uint8_t *text, const uint64_t *line_start, const uint32_t *line_len, uint64_t n_records, const uint32_t *keep,
+                 const uint64_t *kept_idx, const uint64_t *base_off, int qdelta, uint32_t start_char,
+                 uint8_t *bases, uint8_t *quals, uint64_t *offsets, uint64_t *name_off, uint32_t *name_len, uint32_t *flip) {
+	const int lane = threadIdx.x & 63;
+	const uint64_t wavesPerGrid = (uint64_t)gridDim.x * (blockDim.x >> 6);
+	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_records; r += wavesPerGrid) {
+		if (!keep[r]) continue;
+		const uint64_t j = kept_idx[r], o = base_off[r];
+		const uint64_t sb = line_start[4 * r + 1], sq = line_start[4 * r + 3];
+		const uint32_t L = line_len[4 * r + 1];
+		uint32_t mn = 255;
+		for (uint32_t i = lane; i < L; i += 64) {
+			uint8_t c = text[sb + i];
+			if (c >= 'a' && c <= 'z') c -= 32;                       /* std::toupper, src/ReadFileReader.h:311 */
+			bases[o + i] = c;
+			const uint8_t q = (uint8_t)(text[sq + i] + qdelta);      /* Read::rescaleQuality, src/Sequence.h:443-447 */
+			quals[o + i] = q;
+			mn = q < mn ? q : mn;
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) { const uint32_t x = __shfl_xor(mn, off, 64); mn = x < mn ? x : mn; }
+		if (lane == 0) {
+			offsets[j] = o;
+			name_off[j] = line_start[4 * r] + 1; name_len[j] = line_len[4 * r] - 1;
+			/* validateFastqStart (src/ReadSet.h:171-191, src/Sequence.h:456-479: min_element for both bounds) */
+			if (j + 1 < ING_VALIDATE_READS && L > 0 && (uint8_t)(text[sq] + qdelta) != 127 && (mn < start_char || mn > start_char + 40)) atomicOr(flip, 1u);
+		}
+	}
+}
+
+__global__ void ingest_shift_quals(uint8_t *quals, uint64_t n, int delta) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) quals[i] = (uint8_t)(quals[i] + delta);
+}
+
+}  // namespace kmr
+#endif

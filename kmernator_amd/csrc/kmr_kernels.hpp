@@ -971,6 +971,32 @@ __global__ void histogram_kernel(const uint32_t *vals, uint32_t vw, uint64_t n, 
 	}
 }
 
+/* KmerSpectrum::Histogram::set/addRecord (src/KmerSpectrum.h:964-974,1036-1056) over the weak map (vals != NULL) or the
+ * singleton map (sweight != NULL).  getIdx (:936-938) goes through a 65536-entry table the host fills with its own libm, so
+ * the log() that decides a bucket is the one the reference would have used.  Buckets below HIST_LDS (where nearly all
+ * entries fall) are accumulated per block in LDS. */
+static const int HIST_LDS = 512;
+__global__ __launch_bounds__(256)
+void ref_histogram_kernel(const uint32_t *vals, uint32_t vw, const uint8_t *sweight, uint64_t n, const uint32_t *idx_of_count,
+                          unsigned long long *visits, unsigned long long *visitedCount, double *visitedWeight) {
+	__shared__ uint32_t lv[HIST_LDS];
+	__shared__ unsigned long long lc[HIST_LDS];
+	__shared__ double lw[HIST_LDS];
+	for (int i = threadIdx.x; i < HIST_LDS; i += blockDim.x) { lv[i] = 0; lc[i] = 0; lw[i] = 0.0; }
+	__syncthreads();
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t c; double w;
+		if (vals) { c = vals[e * vw] & 0xffffu; w = (double)__uint_as_float(vals[e * vw + 1]); }
+		else { const uint32_t b = sweight[e]; c = b ? 1u : 0u; w = b ? (double)(int)(b - 1) / 254.0 : 0.0; }
+		if (c == 0) continue;
+		const uint32_t idx = idx_of_count[c];
+		if (idx < (uint32_t)HIST_LDS) { atomicAdd(&lv[idx], 1u); atomicAdd(&lc[idx], (unsigned long long)c); atomicAdd(&lw[idx], w); }
+		else { atomicAdd(&visits[idx], 1ull); atomicAdd(&visitedCount[idx], (unsigned long long)c); atomicAdd(&visitedWeight[idx], w); }
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < HIST_LDS; i += blockDim.x) if (lv[i]) { atomicAdd(&visits[i], (unsigned long long)lv[i]); atomicAdd(&visitedCount[i], lc[i]); atomicAdd(&visitedWeight[i], lw[i]); }
+}
+
 /* ----------------------------------------------------------------------- */
 /* exclusive scan u32 -> u64 (bucket sizes -> bucket starts), three launches */
 static const int SCAN_ITEMS = 2048;   /* per block of 256 threads */

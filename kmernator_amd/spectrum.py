@@ -72,6 +72,10 @@ class KmerSpectrum:
         """Same, device pointers (torch tensor .data_ptr()); asynchronous, see sync()."""
         self._call("add_reads_dev", self.h, bases_ptr, quals_ptr, offsets_ptr, n_reads, total_bases, first_read_idx, discarded_ptr)
 
+    def buildKmerSpectrumFromReadSet(self, read_set, first_read_idx=0):
+        """KmerSpectrum::buildKmerSpectrum(const ReadSet&) on a device-resident ReadSet (kmr_add_read_batch)."""
+        self._call("add_read_batch", self.h, read_set.r, first_read_idx)
+
     def reset(self):
         """weak.reset(false); singleton.reset(false) of buildKmerSpectrum (src/KmerSpectrum.h:2091-2096)"""
         self._call("reset", self.h)
@@ -217,3 +221,49 @@ class KmerSpectrum:
 
     def kernel_time_reset(self):
         self._call("kernel_time_reset", self.h)
+
+
+class ReadSet:
+    """Device-resident reads parsed from FASTQ text on the GPU: the reference's ReadSet::appendFastq path
+    (src/ReadSet.cpp:311-345 over FastqStreamParser, src/ReadFileReader.h:768-835) incl. the Casava-1.8 filter and the
+    quality-base detection of validateFastqStart (src/ReadSet.h:171-209).  Bound to the device of `spectrum`."""
+
+    def __init__(self, spectrum, text, input_quality_base=0, store_comment=True):
+        self.sp = spectrum
+        self.text = bytes(text)
+        r = C.c_void_p()
+        buf = np.frombuffer(self.text, dtype=np.uint8)
+        spectrum._call("ingest_fastq", spectrum.h, buf.ctypes.data_as(C.c_void_p) if buf.size else None, buf.size,
+                       input_quality_base, 1 if store_comment else 0, C.byref(r))
+        self.r = r
+        n, tot, qb, nf = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()
+        spectrum.lib.kmr_reads_info(self.r, C.byref(n), C.byref(tot), C.byref(qb), C.byref(nf))
+        self.n, self.total_bases, self.input_quality_base, self.filtered = n.value, tot.value, qb.value, nf.value
+
+    def getSize(self):
+        return self.n
+
+    def arrays(self):
+        """(bases, quals, offsets, names) on the host"""
+        b = np.zeros(self.total_bases, dtype=np.uint8)
+        q = np.zeros(self.total_bases, dtype=np.uint8)
+        o = np.zeros(self.n + 1, dtype=np.uint64)
+        no = np.zeros(max(1, self.n), dtype=np.uint64)
+        nl = np.zeros(max(1, self.n), dtype=np.uint32)
+        rc = self.sp.lib.kmr_reads_copy(self.r, b.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        no.ctypes.data_as(C.POINTER(C.c_uint64)), nl.ctypes.data_as(C.POINTER(C.c_uint32)))
+        if rc != 0:
+            raise KmerSpectrumError("kmr_reads_copy: %s" % _lib.STATUS.get(rc, rc))
+        names = [self.text[int(no[i]):int(no[i]) + int(nl[i])] for i in range(self.n)]
+        return b, q, o, names
+
+    def close(self):
+        if getattr(self, "r", None):
+            self.sp.lib.kmr_reads_free(self.r)
+            self.r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -22,6 +22,7 @@
  *   a12 store()/restore image                   src/Kmer.h:3143-3191, 960-984
  *   a13 owner partition of _buildKmerSpectrumMPI src/DistributedFunctions.h:340-458
  *   a14 dumpCounts/dumpGraphs                   src/Meraculous.h:107-134
+ *   f2  FASTQ stream parser + quality-base detection  src/ReadFileReader.h:583-835, src/ReadSet.h:171-209
  *
  * Pinning (tests/test_oracle_*.py): the reference's own golden fixtures
  * test/phix.mercount.m21 and test/phix.mergraph.m21.D2 (sorted-output equality
@@ -38,6 +39,7 @@
  */
 #include <algorithm>
 #include <cassert>
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -599,6 +601,7 @@ struct SpectrumBase {
 	virtual uint64_t mapSize(int which) = 0;
 	virtual void dump(FILE *f, uint32_t minDepth, bool graph) = 0;
 	virtual void histogram(uint64_t *counts, double *weights, uint32_t nbins) = 0;
+	virtual void refHistogram(uint32_t zoomMax, double logBase, uint64_t *visits, uint64_t *visitedCount, double *visitedWeight) = 0;
 	virtual void appendOne(const uint8_t *key, float w, const ExtPacket &e) = 0;
 	virtual uint64_t exportEntries(uint8_t *keys, uint32_t *count, uint32_t *dir, float *weighted, uint32_t *ext, uint64_t cap) = 0;
 };
@@ -811,6 +814,28 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 			counts[c]++; if (weights) weights[c] += v.weightedCount;
 		}
 	}
+	/* KmerSpectrum::Histogram (src/KmerSpectrum.h:909-1057): ctor :943-951, getIdx :936-938, addRecord :964-974, set() :1036-1056
+	 * over the weak map, then the singleton map (count = _weight ? 1 : 0, weight = (_weight-1)/254, src/KmerTrackingData.h:651-659).
+	 * The arrays hold (1<<16) + 2 + zoomMax buckets. */
+	void refHistogram(uint32_t zoomMax, double logBase, uint64_t *visits, uint64_t *visitedCount, double *visitedWeight) {
+		const double logFactor = log(logBase);
+		const unsigned int zoomLogSkip = (unsigned int)(log((double)zoomMax + 1.0) / logFactor - 1.0);
+		const unsigned int nb = (1u << 16) + 1 + zoomMax + 1;
+		for (unsigned int i = 0; i < nb; i++) { visits[i] = 0; visitedCount[i] = 0; visitedWeight[i] = 0.0; }
+		auto addRecord = [&](unsigned long count, double weight) {
+			if (count == 0) return;
+			const unsigned int idx = count <= zoomMax ? (unsigned int)count : (unsigned int)(log((double)count) / logFactor - zoomLogSkip + zoomMax);
+			visits[idx]++; visitedCount[idx] += count; visitedWeight[idx] += weight;
+		};
+		for (size_t bi = 0; bi < weak.buckets.size(); bi++) for (uint32_t j = 0; j < weak.buckets[bi].size(); j++) {
+			const WV &v = weak.buckets[bi].vals[j];
+			addRecord(v.count, v.weightedCount);
+		}
+		if (hasSingletons) for (size_t bi = 0; bi < singleton.buckets.size(); bi++) for (uint32_t j = 0; j < singleton.buckets[bi].size(); j++) {
+			const SV &v = singleton.buckets[bi].vals[j];
+			addRecord(v._weight == 0 ? 0 : 1, v._weight == 0 ? 0.0 : (v._weight - 1) / 254.0);
+		}
+	}
 	static void copyExt(uint32_t *, const TDDir &) {}
 	static void copyExt(uint32_t *dst, const TDExt &v) { memcpy(dst, v.ext, 48); }
 	/* flat dump of the weak map in bucket order, for field-by-field parity tests */
@@ -889,6 +914,7 @@ int orc_image_size(orc_handle *h, int which, uint64_t *bytes) { *bytes = h->s->i
 int orc_write_image(orc_handle *h, int which, void *dst, uint64_t cap) { if (cap < h->s->imageSize(which)) return KMR_ERR_CAPACITY; h->s->writeImage(which, (uint8_t *)dst); return 0; }
 int orc_load_image(orc_handle *h, int which, const void *src, uint64_t len) { return h->s->loadImage(which, (const uint8_t *)src, len) ? 0 : KMR_ERR_INVALID_ARG; }
 int orc_count_histogram(orc_handle *h, uint64_t *counts, double *weights, uint32_t nbins) { h->s->histogram(counts, weights, nbins); return 0; }
+int orc_histogram(orc_handle *h, uint32_t zoomMax, double logBase, uint64_t *visits, uint64_t *visitedCount, double *visitedWeight) { h->s->refHistogram(zoomMax, logBase, visits, visitedCount, visitedWeight); return 0; }
 int orc_dump(orc_handle *h, const char *path, uint32_t minDepth, int graph) {
 	FILE *f = fopen(path, "a"); if (!f) return KMR_ERR_INVALID_ARG; h->s->dump(f, minDepth, graph != 0); fclose(f); return 0;
 }
@@ -990,6 +1016,90 @@ int orc_max_threads(void) {
 #else
 	return 1;
 #endif
+}
+
+/* f2 -- FASTQ ingest.  FastqStreamParser::readRecord (src/ReadFileReader.h:768-835) over SequenceStreamParser::readName
+ * (:583-617, std::getline lines, no '\r' handling), ReadFileReader::nextRead(name,bases,quals,comment) (:296-329: reads that
+ * failed the Casava-1.8 filter are skipped, bases are upper-cased, #bases == #quals is enforced), SequenceRecordParser::trimName /
+ * isCommentCasava18 (src/Utils.h:561-598,678-685), then ReadSet::appendFasta + addRead + validateFastqStart + __setFastqStart
+ * (src/ReadSet.cpp:136-141,311-345, src/ReadSet.h:171-209, src/Sequence.h:456-479): qualities are rescaled from the input base
+ * to Read::FASTQ_START_CHAR, and a read among the first 19 999 whose MINIMUM quality char lies outside [start, start+40]
+ * (the reference takes min_element for both ends) flips the input base between 33 and 64 once, rescaling everything read so far.
+ * Returns the number of reads, or -1 where the reference throws.  name_off/name_len: span of the whole name line after '@'. */
+int64_t orc_parse_fastq(const char *text, uint64_t len, uint32_t start_char, uint32_t input_base, int store_comment,
+                        char *bases, char *quals, uint64_t *offsets, uint64_t *name_off, uint32_t *name_len,
+                        uint64_t cap_reads, uint64_t cap_bases, uint32_t *final_input_base) {
+	uint64_t pos = 0;
+	bool eof = false;
+	auto nextLine = [&](uint64_t &b, uint64_t &e) {            /* std::getline */
+		if (pos >= len) { b = e = len; eof = true; return; }
+		b = pos;
+		const void *nl = memchr(text + pos, '\n', len - pos);
+		if (nl) { e = (const char *)nl - text; pos = e + 1; } else { e = len; pos = len; eof = true; }
+	};
+	uint64_t n = 0, nb = 0;
+	uint32_t inBase = input_base;
+	offsets[0] = 0;
+	for (;;) {
+		/* readName: skip lines that are empty or do not start with the marker */
+		uint64_t b, e;
+		nextLine(b, e);
+		int count = 0;
+		bool stop = false;
+		while (e == b || text[b] != '@') {
+			if (eof || pos >= len) { stop = true; break; }
+			nextLine(b, e);
+			if (++count > 100000) break;
+		}
+		if (stop || e == b) break;
+		if (text[b] != '@') return -1;
+		/* trimName on the line without its marker */
+		const uint64_t nm0 = b + 1, nmLen = e - nm0;
+		bool isGood = true;
+		uint64_t ws = nmLen;
+		for (uint64_t i = 0; i < nmLen; i++) { const char c = text[nm0 + i]; if (c == ' ' || c == '\t' || c == '\r' || c == '\n') { ws = i; break; } }
+		if (ws == 0) break;                                        /* empty name: readRecord() reports the end of the stream */
+		if (ws < nmLen && nmLen >= ws + 2) {
+			const char *c = text + nm0 + ws + 1; const uint64_t cl = nmLen - ws - 1;
+			const bool casava = cl >= 6 && c[1] == ':' && c[3] == ':' && c[5] == ':' && (c[0] == '1' || c[0] == '2') && (c[2] == 'Y' || c[2] == 'N');
+			if (casava && (ws <= 2 || text[nm0 + ws - 2] != '/')) {
+				const uint64_t p2 = store_comment ? ws : ws + 2;        /* the reference advances pos when it rewrites the name */
+				if (text[nm0 + p2 + 3] == 'Y') isGood = false;
+			}
+		}
+		uint64_t bb, be, pb, pe, qb, qe;
+		nextLine(bb, be);
+		if (be == bb) return -1;                                   /* "Missing or too many bases" */
+		nextLine(pb, pe);
+		if (pe == pb || text[pb] != '+') return -1;                /* "Missing '+' in fastq" */
+		nextLine(qb, qe);
+		if (!isGood) continue;                                     /* failed-filter read: skipped */
+		const uint64_t L = be - bb;
+		if (qe - qb != L && !(qe - qb == 1 && (uint8_t)text[qb] == 127)) return -1;
+		if (n >= cap_reads || nb + L > cap_bases) return -2;
+		for (uint64_t i = 0; i < L; i++) bases[nb + i] = (char)toupper((unsigned char)text[bb + i]);
+		const bool refq = qe - qb == 1 && (uint8_t)text[qb] == 127 && L != 1;
+		for (uint64_t i = 0; i < L; i++) quals[nb + i] = refq ? (char)127 : text[qb + i];
+		if (inBase != start_char) for (uint64_t i = 0; i < L; i++) quals[nb + i] = (char)(quals[nb + i] + (int)start_char - (int)inBase);
+		name_off[n] = nm0; name_len[n] = (uint32_t)nmLen;
+		n++; nb += L; offsets[n] = nb;
+		/* validateFastqStart: getSize() counts this read */
+		if (n < 20000 && L > 0 && (uint8_t)quals[nb - L] != 127) {
+			uint8_t mn = 255;
+			for (uint64_t i = 0; i < L; i++) mn = std::min<uint8_t>(mn, (uint8_t)quals[nb - L + i]);
+			if (mn < start_char || mn > start_char + 40) {
+				uint32_t want;
+				if (start_char == 33) want = 64; else if (start_char == 64) want = 33; else return -1;
+				if (want != inBase) {
+					const int delta = (int)inBase - (int)want;
+					for (uint64_t i = 0; i < nb; i++) quals[i] = (char)(quals[i] + delta);
+					inBase = want;
+				}
+			}
+		}
+	}
+	if (final_input_base) *final_input_base = inBase;
+	return (int64_t)n;
 }
 
 }  // extern "C"

@@ -126,6 +126,9 @@ def oracle_lib():
         lib.orc_extract_records_by_owner.argtypes = [C.POINTER(KmrConfig), C.c_char_p, C.c_char_p, u64p, C.c_uint64, u8p, u8p, C.c_uint64, u64p]
         lib.orc_insert_records.argtypes = [C.c_void_p, u8p, C.c_uint64]
         lib.orc_derive_buckets.argtypes = [C.POINTER(KmrConfig), u64p, u64p]
+        lib.orc_parse_fastq.restype = C.c_int64
+        lib.orc_parse_fastq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, u32p,
+                                        C.c_uint64, C.c_uint64, u32p]
         _oracle = lib
     return _oracle
 
@@ -364,3 +367,26 @@ def oracle_extract_by_owner(cfg, rb, seg_capacity):
                                          _ptr(recs, C.c_uint8), seg_capacity, _ptr(counts, C.c_uint64))
     assert n >= 0
     return recs, counts
+
+
+def oracle_parse_fastq(text, start_char=33, input_base=33, store_comment=True):
+    """oracle restatement of the reference's FASTQ stream parser: (ReadBatch with .names, final input base) or None
+    where the reference throws"""
+    lib = oracle_lib()
+    text = bytes(text)
+    cap_reads = text.count(b"\n") // 4 + 2
+    bases = np.zeros(len(text) + 1, dtype=np.uint8)
+    quals = np.zeros(len(text) + 1, dtype=np.uint8)
+    offsets = np.zeros(cap_reads + 1, dtype=np.uint64)
+    noff = np.zeros(cap_reads, dtype=np.uint64)
+    nlen = np.zeros(cap_reads, dtype=np.uint32)
+    fb = C.c_uint32()
+    n = lib.orc_parse_fastq(text, len(text), start_char, input_base, 1 if store_comment else 0, bases.ctypes.data_as(C.c_void_p),
+                            quals.ctypes.data_as(C.c_void_p), _ptr(offsets, C.c_uint64), _ptr(noff, C.c_uint64), _ptr(nlen, C.c_uint32),
+                            cap_reads, len(text), C.byref(fb))
+    if n < 0:
+        return None
+    tot = int(offsets[n])
+    rb = ReadBatch.from_arrays(bases[:tot].copy(), quals[:tot].copy(), offsets[:n + 1].copy())
+    rb.names = [text[int(noff[i]):int(noff[i]) + int(nlen[i])] for i in range(n)]
+    return rb, fb.value

@@ -49,12 +49,15 @@ int main(int argc, char **argv) {
 	pv.cap = cap; (void)hipMemset(pv.err, 0, 4);
 	unsigned int *wc; CK(hipMalloc(&wc, 4));
 	CK(hipDeviceSynchronize());
-	for (int rep = 0; rep < 2; rep++) for (int bits : {10, 9, 8}) {
-		run_direct<1024, 16, 0>(lin, n, bits, pv, wc, 256);
-		run_direct<1024, 8, 0>(lin, n, bits, pv, wc, 256);
-		run_direct<1024, 8, 4>(lin, n, bits, pv, wc, 256);
-		run_direct<1024, 8, 4>(lin, n, bits, pv, wc, 256);
-		run_direct<512, 8, 4>(lin, n, bits, pv, wc, 512);
+	for (int rep = 0; rep < 2; rep++) {
+		run_direct<1024, 8, 4>(lin, n, 10, pv, wc, 256);
+		run_direct<1024, 8, 4>(lin, n, 9, pv, wc, 256);
+		run_direct<1024, 8, 8>(lin, n, 9, pv, wc, 256);
+		run_direct<1024, 16, 8>(lin, n, 9, pv, wc, 256);
+		run_direct<1024, 8, 8>(lin, n, 8, pv, wc, 256);
+		run_direct<1024, 8, 16>(lin, n, 8, pv, wc, 256);
+		run_direct<1024, 8, 4>(lin, n, 7, pv, wc, 256);
+		run_direct<1024, 8, 16>(lin, n, 7, pv, wc, 256);
 	}
 	return 0;
 }
