@@ -197,6 +197,11 @@ int kmr_write_image(kmr_handle *h, int which_map, void *dst, uint64_t capacity);
  * (src/KmerSpectrum.h:489-518, src/Kmer.h:3124-3135).  The handle must be fresh
  * (no reads added); it becomes finalized. */
 int kmr_load_image(kmr_handle *h, int which_map, const void *src, uint64_t len);
+/* Union of a stored map with the handle's finalized map of the same kind and bucket count: the restore-and-merge
+ * loop of KmerSpectrum::buildKmerSpectrumInParts (src/KmerSpectrum.h:1871-1884; KmerMapByKmerArrayPair::mergeAdd,
+ * src/Kmer.h:3209-3261, for disjoint key sets).  Parts are built with kmr_config.num_parts / part_idx.
+ * KMR_ERR_UNSUPPORTED if the two maps share a k-mer. */
+int kmr_merge_image(kmr_handle *h, int which_map, const void *src, uint64_t len);
 
 /* Histogram of weak counts (KmerSpectrum::Histogram, src/KmerSpectrum.h:909-1057):
  * counts[c] = number of weak entries with count == c for c < n_bins-1, last bin

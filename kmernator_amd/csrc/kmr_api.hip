@@ -251,7 +251,6 @@ int prepare_units(kmr_handle *h, ReadsView &rv) {
 	HIPCHK(h, hipMemcpyAsync(&mx, h->umax, 4, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	if (mx <= (unsigned)TILE_SPAN) return 0;                   /* the usual case: every read is one unit */
-	if (h->ext) return fail(h, KMR_ERR_UNSUPPORTED, "reads longer than one tile are not segmented for extension tallies yet");
 	if (!h->ufirst || h->ufirst_n < n + 1) { if (h->ufirst) hipFree(h->ufirst); h->ufirst = nullptr; HIPCHK(h, hipMalloc((void **)&h->ufirst, 8 * (n + 1))); h->ufirst_n = n + 1; }
 	int rc = exclusive_scan(h, h->ucnt, n, h->ufirst); if (rc) return rc;
 	uint64_t U = 0;
@@ -448,6 +447,43 @@ template <int W> int load_image_t(kmr_handle *h, DevMap &m, bool weakMap, const 
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(m.image); m.image = nullptr; m.image_bytes = 0;    /* rebuilt (sorted) on demand */
+	return 0;
+}
+
+template <int W, int VW> void launch_sort(kmr_handle *h, DevMap &m, bool weakMap) {
+	SortView<W> sv; sv.keys = m.keys; sv.vals = weakMap ? m.vals : nullptr; sv.b8 = m.sweight; sv.pkt = m.spkt; sv.vw = weakMap ? VW : 0;
+	hipLaunchKernelGGL((sort_buckets_kernel<W, VW>), dim3(grid_for(m.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, m.start, m.nb);
+}
+/* union of the handle's map with a stored map of the same shape (see merge_copy_kernel) */
+template <int W> int merge_image_t(kmr_handle *h, DevMap &m, bool weakMap, const uint8_t *src, uint64_t len) {
+	DevMap t;
+	int rc = load_image_t<W>(h, t, weakMap, src, len);
+	if (rc) { free_map(t); return rc; }
+	if (t.nb != m.nb) { free_map(t); return fail(h, KMR_ERR_INVALID_ARG, "Can not merge two maps of differing sizes (src/Kmer.h:3210)"); }
+	const uint32_t vw = h->ext ? 15 : 3;
+	DevMap d; d.nb = m.nb; d.n = m.n + t.n; d.present = true;
+	uint32_t *counts = nullptr, *dup = nullptr;
+	auto bail = [&](int code) { free_map(t); free_map(d); if (counts) hipFree(counts); if (dup) hipFree(dup); return code; };
+#define MCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP); } } while (0)
+	MCHK(hipMalloc((void **)&counts, 4 * m.nb)); MCHK(hipMalloc((void **)&dup, 4)); MCHK(hipMemsetAsync(dup, 0, 4, h->stream));
+	MCHK(hipMalloc((void **)&d.start, 8 * (m.nb + 1)));
+	hipLaunchKernelGGL(merge_counts_kernel, dim3(grid_for(m.nb)), dim3(256), 0, h->stream, m.start, t.start, m.nb, counts);
+	rc = exclusive_scan(h, counts, m.nb, d.start); if (rc) return bail(rc);
+	MCHK(hipMalloc((void **)&d.keys, std::max<uint64_t>(8, 8ull * W * d.n)));
+	if (weakMap) MCHK(hipMalloc((void **)&d.vals, std::max<uint64_t>(8, 4ull * vw * d.n)));
+	else { MCHK(hipMalloc((void **)&d.sweight, std::max<uint64_t>(8, d.n))); if (h->ext) MCHK(hipMalloc((void **)&d.spkt, std::max<uint64_t>(8, 4 * d.n))); }
+	if (m.n) hipLaunchKernelGGL(merge_copy_kernel<W>, dim3(grid_for(m.n)), dim3(256), 0, h->stream, m.start, t.start, false, m.nb, m.n, m.keys, weakMap ? m.vals : nullptr, vw, m.sweight, m.spkt, d.start, d.keys, d.vals, d.sweight, d.spkt);
+	if (t.n) hipLaunchKernelGGL(merge_copy_kernel<W>, dim3(grid_for(t.n)), dim3(256), 0, h->stream, t.start, m.start, true, m.nb, t.n, t.keys, weakMap ? t.vals : nullptr, vw, t.sweight, t.spkt, d.start, d.keys, d.vals, d.sweight, d.spkt);
+	if (!weakMap) launch_sort<W, 0>(h, d, false); else if (h->ext) launch_sort<W, 15>(h, d, true); else launch_sort<W, 3>(h, d, true);
+	hipLaunchKernelGGL(duplicate_keys_kernel<W>, dim3(grid_for(d.nb)), dim3(256), 0, h->stream, d.start, d.nb, d.keys, dup);
+	MCHK(hipGetLastError());
+	uint32_t hdup = 0;
+	MCHK(hipMemcpyAsync(&hdup, dup, 4, hipMemcpyDeviceToHost, h->stream)); MCHK(hipStreamSynchronize(h->stream));
+#undef MCHK
+	if (hdup) { bail(0); return fail(h, KMR_ERR_UNSUPPORTED, "the two maps share k-mers: only disjoint parts (buildKmerSpectrumInParts) are merged"); }
+	hipFree(counts); hipFree(dup); free_map(t);
+	free_map(m);
+	m = d;
 	return 0;
 }
 
@@ -1199,6 +1235,23 @@ int kmr_count_histogram(kmr_handle *h, uint64_t *counts, double *weights, uint32
 	if (weights) HIPCHK(h, hipMemcpyAsync(weights, dw, 8 * n_bins, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(dc); if (dw) hipFree(dw);
+	return KMR_OK;
+}
+
+/* merge a stored part into the finalized maps (buildKmerSpectrumInParts' restore-and-merge loop, src/KmerSpectrum.h:1871-1884) */
+int kmr_merge_image(kmr_handle *h, int which, const void *src, uint64_t len) {
+	if (!h || !src) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_merge_image before kmr_finalize / kmr_load_image");
+	DevMap *m = map_of(h, which);
+	if (!m) return fail(h, KMR_ERR_UNSUPPORTED, "solid map is not built on this path");
+	if (!m->present) return fail(h, KMR_ERR_STATE, "this map is not present in the handle (singletons purged?)");
+	hipSetDevice(h->device);
+	const bool weakMap = which == KMR_MAP_WEAK;
+	int rc;
+	switch (h->W) { case 1: rc = merge_image_t<1>(h, *m, weakMap, (const uint8_t *)src, len); break; case 2: rc = merge_image_t<2>(h, *m, weakMap, (const uint8_t *)src, len); break;
+	case 3: rc = merge_image_t<3>(h, *m, weakMap, (const uint8_t *)src, len); break; default: rc = merge_image_t<4>(h, *m, weakMap, (const uint8_t *)src, len); }
+	if (rc) return rc;
+	if (weakMap) h->stats.weak_entries = m->n; else h->stats.singleton_entries = m->n;
 	return KMR_OK;
 }
 

@@ -388,6 +388,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 	const uint32_t nr = (uint32_t)((n_items - r0) < 64 ? (n_items - r0) : 64);
 	const bool have = (uint32_t)lane < nr;
 	uint64_t myStart = 0, myEnd = 0, myRead = 0;
+	uint64_t myReadEnd = 0;            /* units only: end of the whole read (a segment's outer extensions lie outside it) */
 	uint32_t kfirst = 0;               /* index in the read of the unit's first k-mer */
 	bool myDiscard = true, myRefQual = false;
 	if (have) {
@@ -395,6 +396,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 			myStart = rv.u_start[r0 + lane]; myEnd = rv.u_end[r0 + lane]; myRead = rv.u_read[r0 + lane];
 			const uint64_t rs = rv.offsets[myRead];
 			kfirst = (uint32_t)(myStart - rs);
+			myReadEnd = rv.offsets[myRead + 1];
 			myRefQual = rv.quals && rv.offsets[myRead + 1] > rs && rv.quals[rs] == 127;
 		} else {
 			myRead = r0 + lane;
@@ -449,6 +451,10 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		                                    leaves the window is read from a register instead of the tile */
 		uint32_t qprev = 0x100, qrun = 0; /* length of the current run of equal quality chars */
 		uint32_t leftCode = 5, leftQ = p.ext_min_q;   /* Extension('X', minQuality) */
+		if (EXT && active && kfirst > 0) {            /* a later segment of a long read: its left neighbour is in global memory */
+			leftCode = base_code(rv.bases[myStart - 1]); if (leftCode == 4) leftCode = 0;
+			leftQ = ((isRef ? 127u : (uint32_t)rv.quals[myStart - 1]) - p.fastq_start) & 0xffu;
+		}
 		const uint32_t rbOff = (uint32_t)(rb - tb), rqOff = (uint32_t)(rq - tq);
 		const bool haveQuals = rv.quals != nullptr;
 		for (uint32_t jb = 0; jb < Lmax; jb += 4) {
@@ -530,6 +536,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 							if (EXT) {
 								uint32_t rc_, rq_;
 								if (j + 1 < L) { rc_ = base_code(rb[j + 1]); if (rc_ == 4) rc_ = 0; rq_ = ((isRef ? 127u : (uint32_t)rq[j + 1]) - p.fastq_start) & 0xffu; }
+								else if (rv.u_start && myEnd < myReadEnd) { rc_ = base_code(rv.bases[myEnd]); if (rc_ == 4) rc_ = 0; rq_ = ((isRef ? 127u : (uint32_t)rv.quals[myEnd]) - p.fastq_start) & 0xffu; }
 								else { rc_ = 5; rq_ = p.ext_min_q; }
 								uint32_t lc = leftCode, lq = leftQ;
 								if (!isLeast) {          /* swap and complement (KmerReadUtils.h:232-235) */
@@ -960,6 +967,38 @@ __global__ void image_unpack_kernel(const uint8_t *img, const uint64_t *start, u
 			vals[e * vw] &= 0xffffu; vals[e * vw + 2] &= 0xffffu;      /* struct padding bytes */
 		} else { b8[e] = vp[0]; if (pkt) { uint32_t x = 0; for (int j = 0; j < 4; j++) x |= (uint32_t)vp[1 + j] << (8 * j); pkt[e] = x; } }
 	}
+}
+
+/* merge of two bucketed maps with the same bucket count (KmerMapByKmerArrayPair::mergeAdd src/Kmer.h:3209-3261 for
+ * disjoint key sets, which is what buildKmerSpectrumInParts merges, src/KmerSpectrum.h:1871-1884): entry e of the source
+ * map goes to dst_start[b] + shift[b] + (e - src_start[b]); the buckets are sorted afterwards and checked for duplicates. */
+__global__ void merge_counts_kernel(const uint64_t *a_start, const uint64_t *b_start, uint64_t nb, uint32_t *counts) {
+	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x)
+		counts[b] = (uint32_t)((a_start[b + 1] - a_start[b]) + (b_start[b + 1] - b_start[b]));
+}
+template <int W>
+__global__ void merge_copy_kernel(const uint64_t *src_start, const uint64_t *other_start, bool after_other, uint64_t nb, uint64_t n,
+                                  const uint64_t *skeys, const uint32_t *svals, uint32_t vw, const uint8_t *sb8, const uint32_t *spkt,
+                                  const uint64_t *dst_start, uint64_t *dkeys, uint32_t *dvals, uint8_t *db8, uint32_t *dpkt) {
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t lo = 0, hi = nb;
+		while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (src_start[mid] <= e) lo = mid; else hi = mid; }
+		const uint64_t b = lo;
+		const uint64_t pos = dst_start[b] + (after_other ? other_start[b + 1] - other_start[b] : 0) + (e - src_start[b]);
+		for (int j = 0; j < W; j++) dkeys[pos * W + j] = skeys[e * W + j];
+		if (svals) for (uint32_t j = 0; j < vw; j++) dvals[pos * vw + j] = svals[e * vw + j];
+		if (sb8) db8[pos] = sb8[e];
+		if (spkt) dpkt[pos] = spkt[e];
+	}
+}
+template <int W>
+__global__ void duplicate_keys_kernel(const uint64_t *start, uint64_t nb, const uint64_t *keys, uint32_t *found) {
+	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x)
+		for (uint64_t e = start[b] + 1; e < start[b + 1]; e++) {
+			bool eq = true;
+			for (int j = 0; j < W; j++) eq = eq && keys[e * W + j] == keys[(e - 1) * W + j];
+			if (eq) { atomicOr(found, 1u); break; }
+		}
 }
 
 __global__ void histogram_kernel(const uint32_t *vals, uint32_t vw, uint64_t n, uint32_t nbins, unsigned long long *counts, double *weights) {

@@ -177,6 +177,16 @@ class KmerSpectrum:
                    weights.ctypes.data_as(C.POINTER(C.c_double)), nbins)
         return counts, weights
 
+    def getHistogram(self, zoom_max=256, log_base=2.0):
+        """KmerSpectrum::getHistogram (src/KmerSpectrum.h:1066-1071): Histogram(256).set(*this) -> Histogram"""
+        nb = self.lib.kmr_histogram_bins(zoom_max)
+        visits = np.zeros(nb, dtype=np.uint64)
+        vcount = np.zeros(nb, dtype=np.uint64)
+        vweight = np.zeros(nb, dtype=np.float64)
+        self._call("histogram", self.h, zoom_max, log_base, visits.ctypes.data_as(C.POINTER(C.c_uint64)),
+                   vcount.ctypes.data_as(C.POINTER(C.c_uint64)), vweight.ctypes.data_as(C.POINTER(C.c_double)), nb)
+        return Histogram(zoom_max, log_base, visits, vcount, vweight)
+
     # -- export / restore in the reference's mmap format
     def image(self, which=KMR_MAP_WEAK):
         sz = C.c_uint64()
@@ -188,6 +198,11 @@ class KmerSpectrum:
     def load_image(self, which, buf):
         buf = _u8(buf)
         self._call("load_image", self.h, which, buf.ctypes.data_as(C.c_void_p), buf.size)
+
+    def merge_image(self, which, buf):
+        """restore-and-merge of one stored part (KmerSpectrum::buildKmerSpectrumInParts, src/KmerSpectrum.h:1871-1884)"""
+        buf = _u8(buf)
+        self._call("merge_image", self.h, which, buf.ctypes.data_as(C.c_void_p), buf.size)
 
     def storeMmap(self, filename, min_depth=2):
         """KmerSpectrum::storeMmap: <filename> (weak) and <filename>-singleton when min_depth <= 1."""
@@ -221,6 +236,51 @@ class KmerSpectrum:
 
     def kernel_time_reset(self):
         self._call("kernel_time_reset", self.h)
+
+
+class Histogram:
+    """KmerSpectrum::Histogram (src/KmerSpectrum.h:909-1057): buckets filled on the device, finish()/toString() here."""
+
+    def __init__(self, zoom_max, log_base, visits, visited_count, visited_weight):
+        import math
+        self.zoomMax, self.logBase = zoom_max, log_base
+        self.logFactor = math.log(log_base)
+        self.zoomLogSkip = int(math.log(zoom_max + 1.0) / self.logFactor - 1.0)
+        self.visits, self.visitedCount, self.visitedWeight = visits, visited_count, visited_weight
+        self.finish()
+
+    def getBucketValue(self, idx):
+        return idx if idx <= self.zoomMax else int(self.logBase ** float(idx + self.zoomLogSkip - self.zoomMax))
+
+    def finish(self):
+        """:986-1001"""
+        self.cumulativeVisits = np.cumsum(self.visits[::-1])[::-1].copy()
+        self.count = int(self.visits.sum())
+        nz = np.nonzero(self.visits)[0]
+        self.lastBucket = int(nz[-1]) if nz.size else 0
+        self.totalCount = float(self.visitedCount[nz].astype(np.float64).sum()) if nz.size else 0.0
+        # the reference sums from the last bucket down
+        tw = 0.0
+        for i in nz[::-1]:
+            tw += float(self.visitedWeight[i])
+        self.totalWeightedCount = tw
+
+    def toString(self):
+        """:1002-1035, std::fixed << std::setprecision(3)"""
+        f = lambda x: "%.3f" % x
+        div = lambda a, b: (a / b) if b else float("nan")
+        out = ["Counts, Weights and Directions",
+               "Counts:\t%d\t%s\t%s\t" % (self.count, f(self.totalCount), f(div(self.totalCount, self.count))),
+               "Weights:\t%d\t%s\t%s\t%s" % (self.count, f(self.totalWeightedCount), f(div(self.totalWeightedCount, self.count)),
+                                                f(div(self.totalWeightedCount, self.totalCount))),
+               "",
+               "Bucket\tCumulative\tUnique\t%Unique\tCount\t%Count\tWeight\tQualProb\t%Weight"]
+        for i in range(1, self.lastBucket + 1):
+            v, c, w = int(self.visits[i]), int(self.visitedCount[i]), float(self.visitedWeight[i])
+            out.append("%d\t%d\t%d\t%s\t%d\t%s\t\t%s\t%s\t%s\t" % (
+                self.getBucketValue(i), int(self.cumulativeVisits[i]), v, f(div(100.0 * v, self.count)), c,
+                f(div(100.0 * c, self.totalCount)), f(w), f(div(w, c)), f(div(100.0 * w, self.totalWeightedCount))))
+        return "\n".join(out) + "\n"
 
 
 class ReadSet:

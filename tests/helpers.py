@@ -126,6 +126,7 @@ def oracle_lib():
         lib.orc_extract_records_by_owner.argtypes = [C.POINTER(KmrConfig), C.c_char_p, C.c_char_p, u64p, C.c_uint64, u8p, u8p, C.c_uint64, u64p]
         lib.orc_insert_records.argtypes = [C.c_void_p, u8p, C.c_uint64]
         lib.orc_derive_buckets.argtypes = [C.POINTER(KmrConfig), u64p, u64p]
+        lib.orc_histogram.argtypes = [C.c_void_p, C.c_uint32, C.c_double, u64p, u64p, f64p]
         lib.orc_parse_fastq.restype = C.c_int64
         lib.orc_parse_fastq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, u32p,
                                         C.c_uint64, C.c_uint64, u32p]
@@ -261,6 +262,12 @@ class OracleSpectrum(_SpectrumCommon):
     def insert_records(self, recs, n):
         recs = np.ascontiguousarray(recs, dtype=np.uint8)
         self._call("insert_records", self.h, _ptr(recs, C.c_uint8), n)
+
+    def ref_histogram(self, zoom_max=256, log_base=2.0):
+        nb = (1 << 16) + 2 + zoom_max
+        v, c, w = np.zeros(nb, dtype=np.uint64), np.zeros(nb, dtype=np.uint64), np.zeros(nb, dtype=np.float64)
+        self._call("histogram", self.h, zoom_max, log_base, _ptr(v, C.c_uint64), _ptr(c, C.c_uint64), _ptr(w, C.c_double))
+        return v, c, w
 
     def dump(self, path, min_depth, graph):
         self._call("dump", self.h, path.encode(), min_depth, 1 if graph else 0)

@@ -239,6 +239,30 @@ def test_histogram():
     assert np.allclose(wo, wp, rtol=1e-3, atol=1.0)
 
 
+@pytest.mark.parametrize("min_depth,ext", [(1, False), (2, False), (1, True)])
+def test_reference_histogram(min_depth, ext):
+    """KmerSpectrum::Histogram(256).set(): visits and visitedCount bit-exact per bucket (weak + singleton maps, buckets
+    above zoomMax through the reference's log formula), visitedWeight within the weightedCount tolerance; a count of
+    600 exercises a log bucket"""
+    rb = synth_reads(3000, read_len=100, seed=21, quality="noisy")
+    hot = ReadBatch([b"ACGTTGCAAGGCTTAACCGGTATGCATCGAT" + b"G" * 5] * 600, [b"I" * 36] * 600)
+    rb = ReadBatch([rb.seq(i) for i in range(rb.n)] + [hot.seq(i) for i in range(hot.n)], [rb.qual(i) for i in range(rb.n)] + [hot.qual(i) for i in range(hot.n)])
+    cfg = default_config(31, num_buckets_weak=256, num_buckets_singleton=1024, value_kind=KMR_VALUE_EXT if ext else 0)
+    o, p = run_both(cfg, rb, min_depth=min_depth)
+    vo, co, wo = o.ref_histogram(256, 2.0)
+    h = p.getHistogram(256, 2.0)
+    assert np.array_equal(vo, h.visits) and np.array_equal(co, h.visitedCount)
+    assert vo[257:].sum() > 0 and (min_depth > 1 or vo[1] > 0)
+    assert np.all(np.abs(wo - h.visitedWeight) <= vo * (1.0 / 254) + 1e-5 * co + 1e-9)
+    text = h.toString()
+    assert text.startswith("Counts, Weights and Directions\nCounts:\t%d\t" % int(vo.sum()))
+    assert "\n512\t" in text                                  # getBucketValue of the log bucket that holds count 600
+    # other zoom / base
+    vo2, co2, _ = o.ref_histogram(15, 1.5)
+    h2 = p.getHistogram(15, 1.5)
+    assert np.array_equal(vo2, h2.visits) and np.array_equal(co2, h2.visitedCount)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("k", [31, 51])
 def test_reads_longer_than_a_tile_are_segmented(k, mode):
@@ -270,12 +294,27 @@ def test_reads_longer_than_a_tile_are_segmented(k, mode):
         assert np.array_equal(o.lookup(keys), counts[int(off[i]):int(off[i + 1])])
 
 
-def test_long_read_with_extension_values_is_rejected():
-    seq = b"ACGT" * 4000
-    rb = ReadBatch([seq], [b"I" * len(seq)])
-    p = product(default_config(21, value_kind=KMR_VALUE_EXT, num_buckets_weak=16, num_buckets_singleton=16))
-    with pytest.raises(ka.KmerSpectrumError, match="longer"):
-        add(p, rb)
+def test_long_reads_with_extension_values():
+    """Segments of a long read take the extension base outside their own span from the read (left neighbour of a
+    later segment's first k-mer, right neighbour of an earlier segment's last k-mer): tallies stay bit-exact."""
+    rng = np.random.default_rng(5)
+    genome = rng.integers(0, 4, 30000)
+    seqs, quals = [], []
+    qv = np.array([40, 30, 20, 10, 2]) + 33
+    for L in (30000, 9953, 18432 + 20, 200, 18432 + 21, 12000) * 2:
+        st = int(rng.integers(0, 30000 - L + 1))
+        codes = genome[st:st + L].copy()
+        errs = rng.random(L) < 0.01
+        codes[errs] = (codes[errs] + rng.integers(1, 4, errs.sum())) & 3
+        b = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].copy()
+        b[rng.random(L) < 0.0005] = ord("N")
+        seqs.append(b.tobytes())
+        quals.append(qv[rng.choice(5, size=L, p=[0.70, 0.10, 0.10, 0.09, 0.01])].astype(np.uint8).tobytes())
+    rb = ReadBatch(seqs, quals)
+    cfg = default_config(21, value_kind=KMR_VALUE_EXT, num_buckets_weak=512, num_buckets_singleton=2048, min_weight=0.0, min_quality_score=2)
+    o, p = run_both(cfg, rb, min_depth=1)
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, True)
+    assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
 
 
 @pytest.mark.parametrize("k,ext,mode", [(31, False, 1), (31, False, 2), (21, True, 1), (51, False, 1), (51, False, 2)])
