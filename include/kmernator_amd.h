@@ -160,6 +160,13 @@ int kmr_release_table(kmr_handle *h);
 
 int kmr_get_stats(kmr_handle *h, kmr_stats *out);
 
+/* KmerSpectrum::subtractReference (src/KmerSpectrum.h:472-474; apps/FilterReads-P.cpp:117): k-mers present in the
+ * finalized spectrum `reference` (same k, same device) are skipped by later kmr_add_reads* calls on h before they
+ * count as raw k-mers (append(), :1582-1588).  kmr_finalize(h) drops the link as optimize() does; NULL drops it now.
+ * kmr_subtracted = the `subtracted` counter. */
+int kmr_subtract_reference(kmr_handle *h, kmr_handle *reference);
+int kmr_subtracted(kmr_handle *h, uint64_t *out);
+
 /* Lookup.  Replaces KmerMap::getElementIfExists(kmer).value().getCount()
  * (src/Kmer.h:2617-2624; consumer src/ReadSelector.h:924-931) and
  * KmerSpectrum::getCount(kmer,false) (src/KmerSpectrum.h:701-725): weak count

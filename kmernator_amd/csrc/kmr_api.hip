@@ -67,6 +67,8 @@ struct kmr_handle {
 	uint64_t stream_base = 0, reads = 0;
 	uint64_t nb_weak = 0, nb_sing = 0;
 	bool finalized = false, has_singletons = true;
+	kmr_handle *subtract = nullptr;    /* finalized spectrum whose k-mers are skipped (kmr_subtract_reference) */
+	uint64_t subtracted = 0;
 	DevMap weak, sing;
 	kmr_stats stats;
 	/* streaming (partition) build path */
@@ -136,6 +138,12 @@ DevParams dev_params(kmr_handle *h) {
 	p.qzero = h->cfg.fastq_start_char + std::max<uint32_t>(1u, h->cfg.min_quality_score);   /* Q0 has probability 0 too */
 	p.subsample = h->cfg.kmer_subsample; p.rank = h->cfg.rank; p.world = h->cfg.world_size; p.num_parts = h->cfg.num_parts; p.part_idx = h->cfg.part_idx;
 	p.P = h->dP; p.stats = h->dstats; p.err = h->derr;
+	p.sub_wstart = p.sub_wkeys = p.sub_sstart = p.sub_skeys = nullptr; p.sub_wvals = nullptr; p.sub_sweight = nullptr; p.sub_wnb = p.sub_snb = 0; p.sub_vw = 0;
+	if (h->subtract) {
+		const kmr_handle *o = h->subtract;
+		if (o->weak.present && o->weak.n) { p.sub_wstart = o->weak.start; p.sub_wkeys = o->weak.keys; p.sub_wvals = o->weak.vals; p.sub_wnb = o->weak.nb; p.sub_vw = o->ext ? 15 : 3; }
+		if (o->sing.present && o->sing.n) { p.sub_sstart = o->sing.start; p.sub_skeys = o->sing.keys; p.sub_sweight = o->sing.sweight; p.sub_snb = o->sing.nb; }
+	}
 	return p;
 }
 
@@ -180,7 +188,7 @@ int sync_state(kmr_handle *h) {
 	HIPCHK(h, hipMemcpy(&e, h->derr, sizeof(e), hipMemcpyDeviceToHost));
 	HIPCHK(h, hipMemcpy(&s, h->dstats, sizeof(s), hipMemcpyDeviceToHost));
 	h->stats.raw_kmers = s.raw + s.inserted; h->stats.raw_good_kmers = s.good + s.inserted; h->stats.discarded = s.raw - s.good;
-	h->occupied = s.claimed; h->pending_kmers = 0;
+	h->occupied = s.claimed; h->pending_kmers = 0; h->subtracted = s.subtracted;
 	if (e & ERR_READ_TOO_LONG) return fail(h, KMR_ERR_UNSUPPORTED, "a read is longer than the per-wavefront LDS tile (" + std::to_string(TILE_SPAN) + " bases)");
 	if (e & ERR_TABLE_FULL) return fail(h, KMR_ERR_CAPACITY, "device k-mer table is full; raise kmr_config.max_table_entries / estimated_raw_kmers");
 	if (e & ERR_SEGMENT_OVERFLOW) return fail(h, KMR_ERR_CAPACITY, "an owner segment overflowed seg_capacity");
@@ -268,15 +276,16 @@ int prepare_units(kmr_handle *h, ReadsView &rv) {
 }
 
 template <int W, bool EXT, class Op> int launch_extract(kmr_handle *h, const ReadsView &rv, const Op &op, uint64_t max_blocks = 0) {
-	static bool attr_set = false;
-	auto kern = extract_kernel<W, EXT, Op>;
-	if (!attr_set) { HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXTRACT_SMEM)); attr_set = true; }
+	const DevParams dp = dev_params(h);
+	const bool sub = Op::NEEDS_WEIGHT && (dp.sub_wnb | dp.sub_snb) != 0;      /* lookups ignore the subtracting reference */
+	auto kern = sub ? extract_kernel<W, EXT, Op, true> : extract_kernel<W, EXT, Op, false>;
+	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXTRACT_SMEM));
 	const uint64_t tiles = ((rv.u_start ? rv.n_units : rv.n_reads) + 63) / 64;
 	uint64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
 	if (blocks == 0) return 0;
 	if (max_blocks && blocks > max_blocks) blocks = max_blocks;      /* wavefronts then walk several tiles */
 	if (blocks > 0x7fffffffull) return fail(h, KMR_ERR_INVALID_ARG, "too many reads in one batch");
-	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES_PER_BLOCK * 64), EXTRACT_SMEM, h->stream, rv, dev_params(h), op);
+	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES_PER_BLOCK * 64), EXTRACT_SMEM, h->stream, rv, dp, op);
 	HIPCHK(h, hipGetLastError());
 	return 0;
 }
@@ -1032,7 +1041,7 @@ int kmr_reset(kmr_handle *h) {
 	HIPCHK(h, hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream));
 	HIPCHK(h, hipMemsetAsync(h->derr, 0, 4, h->stream));
 	memset(&h->stats, 0, sizeof(h->stats));
-	h->occupied = h->pending_kmers = 0; h->stream_base = 0; h->reads = 0;
+	h->occupied = h->pending_kmers = 0; h->stream_base = 0; h->reads = 0; h->subtracted = 0;
 	h->finalized = false; h->has_singletons = h->cfg.separate_singletons != 0;
 	return KMR_OK;
 }
@@ -1085,6 +1094,8 @@ int kmr_finalize(kmr_handle *h, uint32_t min_depth) {
 	if (!h) return KMR_ERR_INVALID_ARG;
 	if (h->finalized) return fail(h, KMR_ERR_STATE, "already finalized");
 	hipSetDevice(h->device);
+	{ int src_ = sync_state(h); if (src_) return src_; }
+	h->subtract = nullptr;                             /* optimize(): subtractingReference.reset() */
 	if (h->partition_mode) return finalize_partition(h, min_depth);
 #define FIN(Wv) (h->ext ? finalize_t<Wv, true>(h, min_depth) : finalize_t<Wv, false>(h, min_depth))
 	switch (h->W) { case 1: return FIN(1); case 2: return FIN(2); case 3: return FIN(3); default: return FIN(4); }
@@ -1235,6 +1246,30 @@ int kmr_count_histogram(kmr_handle *h, uint64_t *counts, double *weights, uint32
 	if (weights) HIPCHK(h, hipMemcpyAsync(weights, dw, 8 * n_bins, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(dc); if (dw) hipFree(dw);
+	return KMR_OK;
+}
+
+/* KmerSpectrum::subtractReference (src/KmerSpectrum.h:472-474; apps/FilterReads-P.cpp:117): k-mers that exist in the finalized
+ * spectrum `reference` are skipped by every later kmr_add_reads* of h (append(), :1582-1588).  kmr_finalize(h) drops the link,
+ * as optimize() does (:463-464); reference == NULL drops it at once.  `reference` must stay alive and unchanged meanwhile. */
+int kmr_subtract_reference(kmr_handle *h, kmr_handle *reference) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (reference) {
+		if (reference == h) return fail(h, KMR_ERR_INVALID_ARG, "a spectrum cannot subtract itself");
+		if (!reference->finalized) return fail(h, KMR_ERR_STATE, "the subtracting spectrum must be finalized");
+		if (reference->k != h->k || reference->device != h->device) return fail(h, KMR_ERR_INVALID_ARG, "the subtracting spectrum must have the same k and live on the same device");
+		if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_subtract_reference after kmr_finalize");
+	}
+	hipSetDevice(h->device);
+	int rc = sync_state(h); if (rc) return rc;         /* launches in flight carry the old link */
+	h->subtract = reference;
+	return KMR_OK;
+}
+int kmr_subtracted(kmr_handle *h, uint64_t *out) {
+	if (!h || !out) return KMR_ERR_INVALID_ARG;
+	hipSetDevice(h->device);
+	if (!h->finalized) { int rc = sync_state(h); if (rc) return rc; }
+	*out = h->subtracted;
 	return KMR_OK;
 }
 

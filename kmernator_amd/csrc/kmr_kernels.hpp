@@ -49,6 +49,7 @@ enum { ERR_READ_TOO_LONG = 1, ERR_TABLE_FULL = 2, ERR_SEGMENT_OVERFLOW = 4 };
 struct DevStats {
 	unsigned long long raw, good, claimed;   /* claimed = new keys inserted */
 	unsigned long long inserted;             /* records received through the owner exchange (holes excluded) */
+	unsigned long long subtracted;           /* occurrences found in the subtracting reference spectrum */
 };
 
 struct DevParams {
@@ -60,6 +61,10 @@ struct DevParams {
 	const double *P;       /* 256 entries, device */
 	DevStats *stats;
 	uint32_t *err;
+	/* KmerSpectrum::subtractReference (src/KmerSpectrum.h:472-474,1582-1588): finalized maps of another spectrum whose
+	 * k-mers are skipped before they are counted; sub_wnb == 0 and sub_snb == 0 when there is none */
+	const uint64_t *sub_wstart, *sub_wkeys; const uint32_t *sub_wvals; uint64_t sub_wnb; uint32_t sub_vw;
+	const uint64_t *sub_sstart, *sub_skeys; const uint8_t *sub_sweight; uint64_t sub_snb;
 };
 
 struct ReadsView {
@@ -344,6 +349,40 @@ template <int W, bool EXT> struct RecordOp {
 };
 
 /* ----------------------------------------------------------------------- */
+/* finalized map on the device: bucketed, keys sorted inside each bucket      */
+template <int W> struct MapView {
+	const uint64_t *start;     /* [nb+1] entry index of each bucket          */
+	const uint64_t *keys;      /* [n][W]                                     */
+	const uint32_t *vals;      /* weak: [n][VW] words in the value layout    */
+	const uint8_t *sweight;    /* singleton: [n] _weight byte                */
+	uint64_t nb;               /* power of two, 0 = map absent               */
+	uint32_t vw;               /* value words per weak entry (3 or 15)       */
+};
+
+template <int W> __device__ __forceinline__ int64_t map_find(const MapView<W> &m, const Key<W> &key, uint64_t hash) {
+	if (m.nb == 0) return -1;
+	const uint64_t b = hash & (m.nb - 1);
+	uint64_t lo = m.start[b], hi = m.start[b + 1];
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		Key<W> km;
+#pragma unroll
+		for (int i = 0; i < W; i++) km.w[i] = m.keys[mid * W + i];
+		if (key_eq<W>(km, key)) return (int64_t)mid;
+		if (key_lt<W>(km, key)) lo = mid + 1; else hi = mid;
+	}
+	return -1;
+}
+/* DataPointers::getCount(false), src/KmerSpectrum.h:642-695 */
+template <int W> __device__ __forceinline__ uint32_t maps_count(const MapView<W> &weak, const MapView<W> &sing, const Key<W> &key, uint64_t hash) {
+	int64_t i = map_find<W>(weak, key, hash);
+	if (i >= 0) return weak.vals[(uint64_t)i * weak.vw] & 0xffffu;
+	i = map_find<W>(sing, key, hash);
+	if (i >= 0) return sing.sweight[i] == 0 ? 0u : 1u;
+	return 0u;
+}
+
+/* ----------------------------------------------------------------------- */
 /* compressBase (src/TwoBitSequence.cpp:124-147) without branches: 0..3 for ACGT/acgt, 4 = markup.
  * (c>>1)&3 maps A,C,G,T to 0,1,3,2; x^(x>>1) turns that into 0,1,2,3. */
 __device__ __forceinline__ uint32_t base_code(uint8_t c) {
@@ -360,7 +399,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 	return v;
 }
 
-template <int W, bool EXT, class Op>
+template <int W, bool EXT, class Op, bool SUB = false>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 2)
 void extract_kernel(ReadsView rv, DevParams p, Op op) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -378,7 +417,9 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 	bool fail = false;
 	typename Op::State opst;
 	op.wave_begin(opst, lane);
-	const bool needHash = Op::NEEDS_HASH || p.subsample > 1 || p.world > 1 || p.num_parts > 1;
+	constexpr bool haveSub = SUB;       /* a subtracting reference spectrum is set: its own instantiation, the usual build pays nothing */
+	const bool needHash = Op::NEEDS_HASH || p.subsample > 1 || p.world > 1 || p.num_parts > 1 || haveSub;
+	unsigned long long nSub = 0;
 	/* a wavefront walks tiles tile0, tile0 + stride, ... (stride = all wavefronts of the grid): with a full grid
 	 * that is one tile each; Ops that keep per-wavefront state (RecordOp's owner slabs) launch fewer blocks */
 	const uint64_t n_items = rv.u_start ? rv.n_units : rv.n_reads;
@@ -525,6 +566,12 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 						if (p.subsample > 1 && hash % p.subsample != 0) mine = false;   /* owner / part filters apply to the build, not to lookups */
 						if (p.world > 1 && !op_keeps_all_owners(op) && distributed_thread_id(hash, p.world) != p.rank) mine = false;
 						if (p.num_parts > 1 && distributed_thread_id(hash, p.num_parts) != p.part_idx) mine = false;
+						if (haveSub && mine) {          /* subtractingReference->exists(least): skipped before rawKmers++ */
+							MapView<W> sw, ss;
+							sw.start = p.sub_wstart; sw.keys = p.sub_wkeys; sw.vals = p.sub_wvals; sw.sweight = nullptr; sw.nb = p.sub_wnb; sw.vw = p.sub_vw;
+							ss.start = p.sub_sstart; ss.keys = p.sub_skeys; ss.vals = nullptr; ss.sweight = p.sub_sweight; ss.nb = p.sub_snb; ss.vw = 0;
+							if (maps_count<W>(sw, ss, canon, hash) > 0) { mine = false; nSub++; }
+						}
 					}
 					if (mine) {
 						const float wf = (float)w;
@@ -570,6 +617,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		atomicAdd(&p.stats->good, nGood);
 		if (nc) atomicAdd(&p.stats->claimed, nc);
 	}
+	if (haveSub) { nSub = wave_sum(nSub); if (lane == 0 && nSub) atomicAdd(&p.stats->subtracted, nSub); }
 	if (__any(fail) && lane == 0) atomicOr(p.err, op_fail_code(op));
 }
 
@@ -577,40 +625,6 @@ template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(c
 template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const RecordOp<W, EXT> &) { return true; }
 template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const InsertOp<W, EXT> &) { return ERR_TABLE_FULL; }
 template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const RecordOp<W, EXT> &) { return ERR_SEGMENT_OVERFLOW; }
-
-/* ----------------------------------------------------------------------- */
-/* finalized map on the device: bucketed, keys sorted inside each bucket      */
-template <int W> struct MapView {
-	const uint64_t *start;     /* [nb+1] entry index of each bucket          */
-	const uint64_t *keys;      /* [n][W]                                     */
-	const uint32_t *vals;      /* weak: [n][VW] words in the value layout    */
-	const uint8_t *sweight;    /* singleton: [n] _weight byte                */
-	uint64_t nb;               /* power of two, 0 = map absent               */
-	uint32_t vw;               /* value words per weak entry (3 or 15)       */
-};
-
-template <int W> __device__ __forceinline__ int64_t map_find(const MapView<W> &m, const Key<W> &key, uint64_t hash) {
-	if (m.nb == 0) return -1;
-	const uint64_t b = hash & (m.nb - 1);
-	uint64_t lo = m.start[b], hi = m.start[b + 1];
-	while (lo < hi) {
-		const uint64_t mid = (lo + hi) >> 1;
-		Key<W> km;
-#pragma unroll
-		for (int i = 0; i < W; i++) km.w[i] = m.keys[mid * W + i];
-		if (key_eq<W>(km, key)) return (int64_t)mid;
-		if (key_lt<W>(km, key)) lo = mid + 1; else hi = mid;
-	}
-	return -1;
-}
-/* DataPointers::getCount(false), src/KmerSpectrum.h:642-695 */
-template <int W> __device__ __forceinline__ uint32_t maps_count(const MapView<W> &weak, const MapView<W> &sing, const Key<W> &key, uint64_t hash) {
-	int64_t i = map_find<W>(weak, key, hash);
-	if (i >= 0) return weak.vals[(uint64_t)i * weak.vw] & 0xffffu;
-	i = map_find<W>(sing, key, hash);
-	if (i >= 0) return sing.sweight[i] == 0 ? 0u : 1u;
-	return 0u;
-}
 
 template <int W> struct LookupOp {
 	MapView<W> weak, sing;

@@ -76,6 +76,16 @@ class KmerSpectrum:
         """KmerSpectrum::buildKmerSpectrum(const ReadSet&) on a device-resident ReadSet (kmr_add_read_batch)."""
         self._call("add_read_batch", self.h, read_set.r, first_read_idx)
 
+    def subtractReference(self, other):
+        """KmerSpectrum::subtractReference: k-mers of the finalized spectrum `other` are skipped by later builds"""
+        self._subtracting = other          # keep it alive
+        self._call("subtract_reference", self.h, None if other is None else other.h)
+
+    def getSubtracted(self):
+        v = C.c_uint64()
+        self._call("subtracted", self.h, C.byref(v))
+        return v.value
+
     def reset(self):
         """weak.reset(false); singleton.reset(false) of buildKmerSpectrum (src/KmerSpectrum.h:2091-2096)"""
         self._call("reset", self.h)

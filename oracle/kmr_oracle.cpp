@@ -587,6 +587,8 @@ struct SpectrumBase {
 	Globals g;
 	bool hasSingletons, finalized;
 	long rawKmers, rawGoodKmers, uniqueKmers, singletonKmers;
+	SpectrumBase *subtractingReference = nullptr;   /* KmerSpectrum::subtractReference, src/KmerSpectrum.h:472-474 */
+	long subtracted = 0;
 	uint64_t reads;
 	double P[256];
 	std::string err;
@@ -612,6 +614,11 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 
 	/* KmerSpectrum::append, KmerSpectrum.h:1578-1668 (isSolid = false, no subtractingReference) */
 	inline void append(const uint8_t *least, float weight, const Extension &left, const Extension &right) {
+		if (subtractingReference && subtractingReference->lookup(least) > 0) {      /* :1582-1588 */
+#pragma omp atomic
+			subtracted++;
+			return;
+		}
 #pragma omp atomic
 		rawKmers++;
 		bool keepDirection = true;
@@ -908,6 +915,8 @@ int orc_get_stats(orc_handle *h, kmr_stats *o) {
 	o->discarded = s->rawKmers - s->rawGoodKmers; o->weak_entries = s->mapSize(KMR_MAP_WEAK); o->singleton_entries = s->mapSize(KMR_MAP_SINGLETON); o->reads = s->reads;
 	return 0;
 }
+int orc_subtract_reference(orc_handle *h, orc_handle *other) { h->s->subtractingReference = other ? other->s : nullptr; return 0; }
+uint64_t orc_subtracted(orc_handle *h) { return (uint64_t)h->s->subtracted; }
 int orc_num_buckets(orc_handle *h, int which, uint64_t *out) { *out = h->s->numBuckets(which); return 0; }
 int orc_lookup(orc_handle *h, const uint8_t *keys, uint64_t n, uint32_t *counts) { for (uint64_t i = 0; i < n; i++) counts[i] = h->s->lookup(keys + i * h->s->kb); return 0; }
 int orc_image_size(orc_handle *h, int which, uint64_t *bytes) { *bytes = h->s->imageSize(which); return 0; }

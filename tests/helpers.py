@@ -127,6 +127,9 @@ def oracle_lib():
         lib.orc_insert_records.argtypes = [C.c_void_p, u8p, C.c_uint64]
         lib.orc_derive_buckets.argtypes = [C.POINTER(KmrConfig), u64p, u64p]
         lib.orc_histogram.argtypes = [C.c_void_p, C.c_uint32, C.c_double, u64p, u64p, f64p]
+        lib.orc_subtract_reference.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_subtracted.restype = C.c_uint64
+        lib.orc_subtracted.argtypes = [C.c_void_p]
         lib.orc_parse_fastq.restype = C.c_int64
         lib.orc_parse_fastq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, u32p,
                                         C.c_uint64, C.c_uint64, u32p]

@@ -239,6 +239,74 @@ def test_histogram():
     assert np.allclose(wo, wp, rtol=1e-3, atol=1.0)
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k,parts", [(31, 3), (51, 2)])
+def test_build_in_parts_and_merge(k, parts, mode):
+    """KmerSpectrum::buildKmerSpectrumInParts (src/KmerSpectrum.h:1818-1902): every part keeps the k-mers with
+    getDMPThread(kmer, numParts) == partIdx, is purged and stored; the parts are restored and merged.  The merged maps
+    equal the one-pass build bit for bit (the reference's own merge, mergeStripedBuckets, expects bucket-striped parts)."""
+    rb = synth_reads(4000, read_len=120, seed=9, quality="noisy", n_rate=0.002)
+    cfg = default_config(k, num_buckets_weak=512, num_buckets_singleton=1024)
+    whole = product(cfg, mode)
+    add(whole, rb)
+    whole.finalize(1)
+    acc = None
+    for part in range(parts):
+        c = default_config(k, num_buckets_weak=512, num_buckets_singleton=1024, num_parts=parts, part_idx=part)
+        o = OracleSpectrum(c)
+        o.add_reads(rb)
+        o.finalize(1)
+        p = product(c, mode)
+        add(p, rb)
+        p.finalize(1)
+        assert p.stats() == o.stats()
+        wi, si = p.image(KMR_MAP_WEAK), p.image(KMR_MAP_SINGLETON)
+        assert np.array_equal(si, o.image(KMR_MAP_SINGLETON))
+        if acc is None:
+            acc = p
+        else:
+            acc.merge_image(KMR_MAP_WEAK, wi)
+            acc.merge_image(KMR_MAP_SINGLETON, si)
+    assert np.array_equal(acc.image(KMR_MAP_WEAK), whole.image(KMR_MAP_WEAK))
+    assert np.array_equal(acc.image(KMR_MAP_SINGLETON), whole.image(KMR_MAP_SINGLETON))
+    assert acc.stats()["weak_entries"] == whole.stats()["weak_entries"]
+    with pytest.raises(ka.KmerSpectrumError, match="share"):
+        acc.merge_image(KMR_MAP_WEAK, whole.image(KMR_MAP_WEAK))
+    wrong = product(default_config(k, num_buckets_weak=256, num_buckets_singleton=1024), mode)
+    add(wrong, rb.slice(0, 10))
+    wrong.finalize(1)
+    with pytest.raises(ka.KmerSpectrumError, match="differing"):
+        acc.merge_image(KMR_MAP_WEAK, wrong.image(KMR_MAP_WEAK))
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k", [21, 51])
+def test_subtract_reference(k, mode):
+    """KmerSpectrum::subtractReference (apps/FilterReads-P.cpp:117): k-mers of the reference spectrum are skipped before
+    they count as raw k-mers (append(), src/KmerSpectrum.h:1582-1588); the link ends with optimize()."""
+    lib = __import__("helpers").oracle_lib()
+    rb = synth_reads(3000, read_len=100, seed=4, quality="noisy")
+    ref_reads = rb.slice(0, 400)
+    cfg = default_config(k, num_buckets_weak=256, num_buckets_singleton=512)
+    o_ref, p_ref = run_both(cfg, ref_reads, min_depth=1, mode=mode)
+    o = OracleSpectrum(cfg)
+    lib.orc_subtract_reference(o.h, o_ref.h)
+    o.add_reads(rb)
+    p = product(cfg, mode)
+    p.subtractReference(p_ref)
+    add(p, rb)
+    assert p.getSubtracted() == lib.orc_subtracted(o.h) > 0
+    o.finalize(2)
+    p.finalize(2)
+    assert o.stats() == p.stats()
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    ko, cnt, _, _, _ = o_ref.entries()
+    assert not p.getCount(ko).any()                 # nothing of the reference is left
+    # lookups ignore the link; a finalized spectrum refuses a new one
+    with pytest.raises(ka.KmerSpectrumError):
+        p.subtractReference(p_ref)
+
+
 @pytest.mark.parametrize("min_depth,ext", [(1, False), (2, False), (1, True)])
 def test_reference_histogram(min_depth, ext):
     """KmerSpectrum::Histogram(256).set(): visits and visitedCount bit-exact per bucket (weak + singleton maps, buckets
