@@ -280,6 +280,8 @@ template <int W, bool EXT, class Op> int launch_extract(kmr_handle *h, const Rea
 	const bool sub = Op::NEEDS_WEIGHT && (dp.sub_wnb | dp.sub_snb) != 0;      /* lookups ignore the subtracting reference */
 	auto kern = sub ? extract_kernel<W, EXT, Op, true> : extract_kernel<W, EXT, Op, false>;
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXTRACT_SMEM));
+	if (getenv("KMR_DEBUG")) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, WAVES_PER_BLOCK * 64, EXTRACT_SMEM); fprintf(stderr, "extract: %d blocks of %d waves per CU (dynamic LDS %zu)\n", nb, WAVES_PER_BLOCK, EXTRACT_SMEM);
+		for (size_t tr : {(size_t)79872, (size_t)65536, (size_t)52000, (size_t)38000}) { hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, WAVES_PER_BLOCK * 64, tr); fprintf(stderr, "   with %zu bytes: %d blocks\n", tr, nb); } }
 	const uint64_t tiles = ((rv.u_start ? rv.n_units : rv.n_reads) + 63) / 64;
 	uint64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
 	if (blocks == 0) return 0;

@@ -41,7 +41,13 @@ namespace kmr {
 static const uint64_t EMPTY_KEY = ~0ull;
 static const uint64_t NO_FIRST = ~0ull;
 static const int WAVES_PER_BLOCK = 4;
-static const int TILE_BUF = 9984;            /* LDS bytes per wave for bases (same again for quals) */
+/* LDS bytes per wave for bases (same again for quals).  Two 4-wave blocks must fit the 160 KiB of a CU:
+ * 2 * (8 * TILE_BUF + 2064 static) <= 163840, i.e. TILE_BUF <= 9982 -- 9984 left room for ONE block per CU (one wave
+ * per SIMD, nothing to hide LDS latency behind).  9856 = 64 reads of up to 153 bases in one pass. */
+#ifndef KMR_TILE_BUF
+#define KMR_TILE_BUF 9856
+#endif
+static const int TILE_BUF = KMR_TILE_BUF;
 static const int TILE_SPAN = TILE_BUF - 32;  /* max staged byte span of one pass */
 
 enum { ERR_READ_TOO_LONG = 1, ERR_TABLE_FULL = 2, ERR_SEGMENT_OVERFLOW = 4 };
@@ -498,6 +504,9 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		}
 		const uint32_t rbOff = (uint32_t)(rb - tb), rqOff = (uint32_t)(rq - tq);
 		const bool haveQuals = rv.quals != nullptr;
+		/* wave-uniform: the steady-state group below serves builds (not lookups) without extension packets and without a
+		 * subsample / part / owner / subtraction filter */
+		const bool fastOK = Op::NEEDS_WEIGHT && !EXT && !SUB && haveQuals && p.subsample <= 1 && p.num_parts <= 1 && (p.world <= 1 || op_keeps_all_owners(op));
 		for (uint32_t jb = 0; jb < Lmax; jb += 4) {
 		/* bases and quals of the next four positions: one aligned 8-byte LDS window each per four iterations
 		 * (the tile buffers are 16-byte aligned and 32 bytes longer than the staged span) */
@@ -510,6 +519,47 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 				const uint32_t aq_ = rqOff + jb;
 				const uint32_t *pq = (const uint32_t *)(tq + (aq_ & ~3u));
 				qwin = ((uint64_t)pq[0] | ((uint64_t)pq[1] << 32)) >> (8 * (aq_ & 3u));
+			}
+		}
+		/* Steady-state group: every lane that still has bases is past its first k-mer, has four more positions, an
+		 * all-clear window (no N, no zero-probability quality: zc == 0 and none among the four new positions), a live
+		 * weight chain (w != 0) and no restart of the product inside the group.  Then the four positions need none of
+		 * the per-position case analysis below -- the same arithmetic in the same order, without the branches (the
+		 * general path spends about as many scalar exec-mask instructions as vector ones). */
+		if (fastOK && jb >= k && ((jb + 1 - k) & 1023u) != 0 && ((jb + 1 - k) & 1023u) <= 1020u) {
+			const bool live = jb < L;
+			uint32_t fc[4], fq[4];
+			bool ok = !live || (jb + 4 <= L && !isRef && zc == 0 && w != 0.0);
+#pragma unroll
+			for (int ju = 0; ju < 4; ju++) {
+				fc[ju] = base_code((uint8_t)(bwin >> (8 * ju)));
+				fq[ju] = (uint32_t)((qwin >> (8 * ju)) & 0xffu);
+				ok = ok && !(live && (fc[ju] == 4 || fq[ju] < p.qzero));
+			}
+			if (__all(ok)) {
+				zbits[2] = (zbits[2] << 4) | (zbits[1] >> 60); zbits[1] = (zbits[1] << 4) | (zbits[0] >> 60); zbits[0] <<= 4;
+				if (live) nRaw += 4;
+#pragma unroll
+				for (uint32_t ju = 0; ju < 4; ju++) {
+					const uint32_t i = jb + ju + 1 - k;
+					const uint32_t q = fq[ju];
+					qrun = (q == qprev) ? qrun + 1 : 0; qprev = q;
+					roll.push(fc[ju] & 3u);
+					if (live && qrun < k) {                   /* same update as the general path below */
+						const uint32_t qo = rq[i - 1];
+						if (qo != q) { const double change = sP[q] / sP[qo]; w *= change; }
+					}
+					const bool isLeast = key_le<W>(roll.fwd, roll.rc);
+					const Key<W> canon = isLeast ? roll.fwd : roll.rc;
+					const float wf = (float)w;
+					const bool valid = live && wf > p.min_weight;
+					if (valid) nGood++;
+					Occurrence o;
+					o.w = wf; o.forward = isLeast; o.ordinal = rv.stream_base + myStart + i; o.pkt = 0; o.ltally = -1; o.rtally = -1;
+					const uint64_t hash = Op::NEEDS_HASH ? key_hash<W>(canon, p.kb) : 0ull;
+					op.emit(opst, valid, p, canon, hash, o, rv.first_read_idx + myRead, kfirst + i, nClaimed, fail);
+				}
+				continue;
 			}
 		}
 #pragma unroll
