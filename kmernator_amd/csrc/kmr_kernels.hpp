@@ -453,6 +453,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		myDiscard = rv.discarded ? (rv.discarded[myRead] != 0) : false;
 	}
 	op.tile_begin(opst, &s_wcount[wave], r0, lane);
+	uint32_t tRaw = 0, tGood = 0;      /* per lane and tile: at most 64 units of < 2^14 positions */
 
 	uint32_t done = 0;
 	while (done < nr) {
@@ -471,10 +472,27 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		const uintptr_t gb = (uintptr_t)rv.bases + B0, gq = (uintptr_t)rv.quals + B0;
 		const uintptr_t ab = gb & ~(uintptr_t)15, aq = gq & ~(uintptr_t)15;
 		const uint32_t nb16 = (uint32_t)(((uintptr_t)rv.bases + B1 - ab + 15) >> 4);
-		for (uint32_t c = lane; c < nb16; c += 64) *(uint4 *)(tb + 16 * c) = *(const uint4 *)(ab + 16 * (uintptr_t)c);
-		if (rv.quals) {
-			const uint32_t nq16 = (uint32_t)(((uintptr_t)rv.quals + B1 - aq + 15) >> 4);
-			for (uint32_t c = lane; c < nq16; c += 64) *(uint4 *)(tq + 16 * c) = *(const uint4 *)(aq + 16 * (uintptr_t)c);
+		/* LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land at a wave-uniform LDS base + lane * 16): every KB of the
+		 * tile is requested before the first one is waited for, and no registers are held meanwhile (a load-wait-store
+		 * loop pays the HBM latency once per KB) */
+		{
+			typedef __attribute__((address_space(1))) const void *gptr_t;
+			typedef __attribute__((address_space(3))) void *lptr_t;
+			constexpr int STG = (TILE_BUF / 16 + 63) / 64;
+			const uint4 *gbp = (const uint4 *)(rv.bases + (ptrdiff_t)(ab - (uintptr_t)rv.bases));
+			const uint4 *gqp = (const uint4 *)(rv.quals + (ptrdiff_t)(aq - (uintptr_t)rv.quals));
+			const uint32_t nq16 = rv.quals ? (uint32_t)(((uintptr_t)rv.quals + B1 - aq + 15) >> 4) : 0u;
+#pragma unroll
+			for (int c = 0; c < STG; c++) {
+				const uint32_t idx = (uint32_t)lane + 64u * c;
+				if (64u * c < nb16 && idx < nb16) __builtin_amdgcn_global_load_lds((gptr_t)(gbp + idx), (lptr_t)(tb + 1024 * c), 16, 0, 0);
+			}
+#pragma unroll
+			for (int c = 0; c < STG; c++) {
+				const uint32_t idx = (uint32_t)lane + 64u * c;
+				if (64u * c < nq16 && idx < nq16) __builtin_amdgcn_global_load_lds((gptr_t)(gqp + idx), (lptr_t)(tq + 1024 * c), 16, 0, 0);
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_wave_barrier();
@@ -538,7 +556,8 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 			}
 			if (__all(ok)) {
 				zbits[2] = (zbits[2] << 4) | (zbits[1] >> 60); zbits[1] = (zbits[1] << 4) | (zbits[0] >> 60); zbits[0] <<= 4;
-				if (live) nRaw += 4;
+				if (live) tRaw += 4;
+				float wf = (float)w;          /* narrowed again only when the chain moves */
 #pragma unroll
 				for (uint32_t ju = 0; ju < 4; ju++) {
 					const uint32_t i = jb + ju + 1 - k;
@@ -547,13 +566,13 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 					roll.push(fc[ju] & 3u);
 					if (live && qrun < k) {                   /* same update as the general path below */
 						const uint32_t qo = rq[i - 1];
-						if (qo != q) { const double change = sP[q] / sP[qo]; w *= change; }
+						if (qo != q) { const double change = sP[q] / sP[qo]; w *= change; wf = (float)w; }
 					}
-					const bool isLeast = key_le<W>(roll.fwd, roll.rc);
-					const Key<W> canon = isLeast ? roll.fwd : roll.rc;
-					const float wf = (float)w;
+					const Key<W> kf = roll.getFwd(), kr = roll.getRc();
+					const bool isLeast = key_le<W>(kf, kr);
+					const Key<W> canon = isLeast ? kf : kr;
 					const bool valid = live && wf > p.min_weight;
-					if (valid) nGood++;
+					if (valid) tGood++;
 					Occurrence o;
 					o.w = wf; o.forward = isLeast; o.ordinal = rv.stream_base + myStart + i; o.pkt = 0; o.ltally = -1; o.rtally = -1;
 					const uint64_t hash = Op::NEEDS_HASH ? key_hash<W>(canon, p.kb) : 0ull;
@@ -607,8 +626,9 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 							}
 						}
 					}
-					const bool isLeast = key_le<W>(roll.fwd, roll.rc);
-					canon = isLeast ? roll.fwd : roll.rc;
+					const Key<W> kf = roll.getFwd(), kr = roll.getRc();
+					const bool isLeast = key_le<W>(kf, kr);
+					canon = isLeast ? kf : kr;
 					hash = needHash ? key_hash<W>(canon, p.kb) : 0ull;
 					kpos = kfirst + i;
 					bool mine = true;
@@ -625,9 +645,9 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 					}
 					if (mine) {
 						const float wf = (float)w;
-						nRaw++;
+						tRaw++;
 						if (!Op::NEEDS_WEIGHT || wf > p.min_weight) {
-							nGood++;
+							tGood++;
 							valid = true;
 							o.w = wf; o.forward = isLeast; o.ordinal = rv.stream_base + myStart + i;
 							if (EXT) {
@@ -658,6 +678,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		__builtin_amdgcn_wave_barrier();   /* all lanes are done reading the tile before it is overwritten */
 	}
 	op.tile_end(opst, tile, lane);
+	nRaw += tRaw; nGood += tGood;
 	}
 	op.wave_end(opst, lane);
 	nRaw = wave_sum(nRaw); nGood = wave_sum(nGood);

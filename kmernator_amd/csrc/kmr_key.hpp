@@ -85,6 +85,30 @@ template <int W> struct Roller {
 			else if (i > lastWord) rc.w[i] = 0;
 		}
 	}
+	KMR_HD Key<W> getFwd() const { return fwd; }
+	KMR_HD Key<W> getRc() const { return rc; }
+};
+
+/* One-word k-mers (k <= 32) roll in 32-bit halves: 64-bit shifts run at a fraction of the 32-bit rate on CDNA, and the
+ * two funnel shifts below are single v_alignbit_b32 instructions. */
+template <> struct Roller<1> {
+	uint32_t fh, fl, rh, rl;       /* forward and reverse-complement word, high and low half */
+	int lastShift;                 /* bit shift of base k-1 in the 64-bit word */
+	uint32_t maskH, maskL;         /* bits of the word that belong to the k-mer */
+	KMR_HD void init(uint32_t k) {
+		fh = fl = rh = rl = 0;
+		lastShift = 62 - (int)(2 * (k - 1));
+		const uint64_t m = ~0ull << lastShift;
+		maskH = (uint32_t)(m >> 32); maskL = (uint32_t)m;
+	}
+	KMR_HD void push(uint32_t b) {
+		fh = (fh << 2) | (fl >> 30); fl <<= 2;
+		if (lastShift >= 32) fh |= b << (lastShift - 32); else fl |= b << lastShift;
+		rl = (rl >> 2) | (rh << 30); rh = (rh >> 2) | ((3u - b) << 30);
+		rh &= maskH; rl &= maskL;
+	}
+	KMR_HD Key<1> getFwd() const { Key<1> k; k.w[0] = ((uint64_t)fh << 32) | fl; return k; }
+	KMR_HD Key<1> getRc() const { Key<1> k; k.w[0] = ((uint64_t)rh << 32) | rl; return k; }
 };
 
 KMR_HD uint32_t rot32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }

@@ -88,7 +88,12 @@ template <int W, bool EXT> struct LinearOp {
 	struct State { uint64_t base; uint32_t n; };
 	__device__ __forceinline__ void wave_begin(State &, int) const {}
 	__device__ __forceinline__ void wave_end(State &, int) const {}
-	__device__ __forceinline__ void tile_begin(State &st, uint32_t *, uint64_t r0, int) const { st.base = koff[r0]; st.n = 0; }
+	__device__ __forceinline__ void tile_begin(State &st, uint32_t *, uint64_t r0, int) const {
+		/* the same for every lane: made a scalar so that the record address is (scalar base + 32-bit lane offset) */
+		const uint64_t b = koff[r0];
+		st.base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+		st.n = 0;
+	}
 	__device__ __forceinline__ void tile_end(State &st, uint64_t tile, int lane) const { if (lane == 0) tile_count[tile] = st.n; }
 	/* called by all lanes under uniform control flow: compact the valid lanes behind the running count */
 	__device__ __forceinline__ void emit(State &st, bool valid, const DevParams &, const Key<W> &key, uint64_t, const Occurrence &o,
@@ -102,7 +107,7 @@ template <int W, bool EXT> struct LinearOp {
 			for (int i = 0; i < W; i++) r.key[i] = key.w[i];
 			r.w = o.forward ? o.w : -o.w;
 			r.pkt = EXT ? o.pkt : (uint32_t)o.ordinal;
-			records[st.base + st.n + rank] = r;
+			(records + (st.base + st.n))[rank] = r;
 		}
 		st.n += (uint32_t)__builtin_popcountll(mask);
 	}
