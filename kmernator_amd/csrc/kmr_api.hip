@@ -762,8 +762,14 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	std::vector<uint64_t> hs(nl1 + 1);
 	HIPCHK(h, hipMemcpy(hs.data(), ls1, 8 * (nl1 + 1), hipMemcpyDeviceToHost));
 	std::vector<uint64_t> ib, ie; std::vector<uint32_t> il;
-	for (uint64_t l = 0; l < nl1; l++)
-		for (uint64_t c = hs[l]; c < hs[l + 1]; c += L2_ITEM_CHUNKS) { ib.push_back(c); ie.push_back(std::min(hs[l + 1], c + L2_ITEM_CHUNKS)); il.push_back((uint32_t)l); }
+	for (uint64_t l = 0; l < nl1; l++) {
+		/* a list longer than one work item is cut into equal items (every item ends with a flush of partly filled chunks,
+		 * and a short leftover item would cost as many of those as a full one) */
+		const uint64_t nch = hs[l + 1] - hs[l];
+		if (!nch) continue;
+		const uint64_t nit = (nch + L2_ITEM_CHUNKS - 1) / L2_ITEM_CHUNKS, per = (nch + nit - 1) / nit;
+		for (uint64_t c = hs[l]; c < hs[l + 1]; c += per) { ib.push_back(c); ie.push_back(std::min(hs[l + 1], c + per)); il.push_back((uint32_t)l); }
+	}
 	/* Final lists are sized by what the count pass can hold in its LDS table: measure the share of distinct keys
 	 * on a sample of level-1 lists, then take enough level-2 bits for ~MAX_LIST_DISTINCT distinct keys per list (and
 	 * at most TARGET_LIST_RECORDS records); if the bits run out the count pass uses its 2048-slot table, and beyond

@@ -575,7 +575,7 @@ __host__ __device__ constexpr size_t count_smem_bytes() { return (size_t)(1 << L
  * (ordinal<<1|fwd).  If the table would overflow the list is split by further hash bits
  * and done in sub-passes (a tiny LDS stack), so any input is handled. */
 template <int W, bool EXT, int LOG2S>
-__global__ __launch_bounds__(COUNT_THREADS)
+__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10) ? 4 : 1)      /* W == 1: four blocks per CU (<= 128 VGPRs, < 40 KB LDS each) */
 void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists,
                   CountOut out, FinalizeParams f, unsigned int *work_counter) {
 	constexpr int S = 1 << LOG2S;
@@ -606,7 +606,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 	 * descriptors are contiguous in list_chunks and are copied to LDS once, so the records of list j+1 can be
 	 * requested (one chunk per wavefront per register slot, HEAD chunks in all) before list j is counted: the
 	 * HBM latency of a list is hidden behind the LDS work of the one before it. */
-	constexpr uint32_t LBATCH = 32, DESC_CAP = 1024;
+	constexpr uint32_t LBATCH = 24, DESC_CAP = 512;        /* ~20 chunk descriptors per list at the usual list size */
 	constexpr int UNR = W == 1 ? 5 : (W == 2 ? 4 : 3);
 	constexpr int NWAVE = COUNT_THREADS / CH;
 	constexpr uint64_t HEAD = (uint64_t)NWAVE * UNR;
@@ -758,14 +758,21 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 #pragma unroll
 			for (int i = 0; i < S / COUNT_THREADS; i++) {
 				const int s = i * COUNT_THREADS + t;
+				int c = 0;
 				if (W == 1 ? tkeys[s] != EMPTY_KEY : tstate[s] == 2) {
 					const uint32_t count = (uint32_t)tcnt[s];
 					uniq++;
 					if (count == 1) single++;
-					const int c = classify(count, f);
-					if (c == 1) s_kept[atomicAdd(&s_nw, 1u)] = (uint16_t)s;
-					else if (c == 2) s_kept[S - 1 - atomicAdd(&s_ns, 1u)] = (uint16_t)s;
+					c = classify(count, f);
 				}
+				/* one LDS atomic per wavefront and class instead of one per entry on the same word */
+				const unsigned long long mw = __ballot(c == 1), ms = __ballot(c == 2);
+				const unsigned long long below = (1ull << (t & 63)) - 1;
+				uint32_t bw = 0, bs = 0;
+				if ((t & 63) == 0) { if (mw) bw = atomicAdd(&s_nw, (uint32_t)__builtin_popcountll(mw)); if (ms) bs = atomicAdd(&s_ns, (uint32_t)__builtin_popcountll(ms)); }
+				bw = (uint32_t)__shfl((int)bw, 0, 64); bs = (uint32_t)__shfl((int)bs, 0, 64);
+				if (c == 1) s_kept[bw + (uint32_t)__builtin_popcountll(mw & below)] = (uint16_t)s;
+				else if (c == 2) s_kept[S - 1 - (bs + (uint32_t)__builtin_popcountll(ms & below))] = (uint16_t)s;
 			}
 			lds_barrier();
 			/* thread 0 alone does the slab book-keeping between these two barriers (the other threads must not look
