@@ -661,6 +661,40 @@ void choose_bits1(kmr_handle *h, uint64_t records_hint) {
 	h->bits1 = std::max(0, std::min(mb, T + 2 - mb));
 }
 
+/* sender side of the exchange: reads -> linear records (every owner's) -> owner segments */
+template <int W, bool EXT> int extract_by_owner_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases, void *dev_records, uint64_t seg_capacity, void *dev_seg_counts) {
+	const uint64_t n = rvAll.n_reads;
+	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
+	const uint64_t chunk = std::max<uint64_t>(64, (SUB_BATCH_BASES / avg) & ~63ull);
+	for (uint64_t r = 0; r < n; r += chunk) {
+		const uint64_t m = std::min(chunk, n - r);
+		ReadsView rv = rvAll;
+		rv.offsets = rvAll.offsets + r; rv.n_reads = m;
+		rv.discarded = rvAll.discarded ? rvAll.discarded + r : nullptr;
+		rv.first_read_idx = rvAll.first_read_idx + r;
+		int rc = prepare_units(h, rv); if (rc) return rc;
+		const uint64_t nu = rv.u_start ? rv.n_units : m;
+		rc = ensure_buf(h, h->kcap, h->kcap_n, nu + 1, 4); if (rc) return rc;
+		rc = ensure_buf(h, h->koff, h->koff_n, nu + 1, 8); if (rc) return rc;
+		hipLaunchKernelGGL(kmer_capacity_kernel, dim3(grid_for(nu)), dim3(256), 0, h->stream, rv, h->k, h->kcap);
+		HIPCHK(h, hipGetLastError());
+		rc = exclusive_scan(h, h->kcap, nu, h->koff); if (rc) return rc;
+		uint64_t total_cap = 0;
+		HIPCHK(h, hipMemcpy(&total_cap, h->koff + nu, 8, hipMemcpyDeviceToHost));
+		const uint64_t tiles = (nu + 63) / 64;
+		rc = ensure_buf(h, h->linear, h->linear_cap, total_cap, rec_bytes(h)); if (rc) return rc;
+		rc = ensure_buf(h, h->tile_count, h->tile_cap, tiles, 4); if (rc) return rc;
+		LinearOp<W, EXT, false> op; op.records = (Record<W> *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
+		rc = launch_extract<W, EXT>(h, rv, op); if (rc) return rc;
+		rc = zero_work_counter(h); if (rc) return rc;
+		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 8, tiles);
+		hipLaunchKernelGGL(owner_scatter_kernel<W>, dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const Record<W> *)h->linear, h->koff, h->tile_count, tiles, h->kb,
+		                   h->cfg.world_size, (Record<W> *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr);
+		HIPCHK(h, hipGetLastError());
+	}
+	return 0;
+}
+
 template <int W> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
 	const uint64_t n = rvAll.n_reads;
 	if (!h->l1.head) choose_bits1(h, total_bases);
@@ -1548,9 +1582,8 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
 	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
 	rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
 	HIPCHK(h, hipMemsetAsync(dev_seg_counts, 0, 8 * h->cfg.world_size, h->stream));
-	int rc = prepare_units(h, rv);
-	if (rc) return rc;
-#define REC(Wv, E) { RecordOp<Wv, E> op; op.records = (Record<Wv> *)dev_records; op.seg_counts = (unsigned long long *)dev_seg_counts; op.seg_capacity = seg_capacity; op.world = h->cfg.world_size; rc = launch_extract<Wv, E>(h, rv, op, 1024); }
+	int rc = 0;
+#define REC(Wv, E) rc = extract_by_owner_t<Wv, E>(h, rv, total_bases, dev_records, seg_capacity, dev_seg_counts);
 	switch (h->W) {
 	case 1: if (h->ext) REC(1, true) else REC(1, false) break;
 	case 2: if (h->ext) REC(2, true) else REC(2, false) break;

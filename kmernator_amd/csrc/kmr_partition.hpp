@@ -77,13 +77,13 @@ template <int W> __host__ __device__ __forceinline__ uint64_t part_order(const u
  * [koff[r0], koff[r0+nr)) of the record buffer (koff = exclusive scan of the per-read
  * k-mer capacities) and appends its good records there, wave-compacted; tile_count
  * says how many it wrote. */
-template <int W, bool EXT> struct LinearOp {
+template <int W, bool EXT, bool STATS = true> struct LinearOp {
 	Record<W> *records;
 	const uint64_t *koff;          /* [n_reads+1] */
 	uint32_t *tile_count;          /* [n_tiles] */
 	uint64_t first_read_idx;
 	static const bool NEEDS_WEIGHT = true;
-	static const bool COUNTS_STATS = true;
+	static const bool COUNTS_STATS = STATS;      /* false on the sender side of the exchange: the owner counts what it receives */
 	static const bool NEEDS_HASH = false;
 	struct State { uint64_t base; uint32_t n; };
 	__device__ __forceinline__ void wave_begin(State &, int) const {}
@@ -112,8 +112,76 @@ template <int W, bool EXT> struct LinearOp {
 		st.n += (uint32_t)__builtin_popcountll(mask);
 	}
 };
-template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const LinearOp<W, EXT> &) { return false; }
-template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const LinearOp<W, EXT> &) { return 0; }
+/* STATS == false is the exchange sender: it keeps the k-mers of every owner */
+template <int W, bool EXT, bool STATS> __device__ __forceinline__ bool op_keeps_all_owners(const LinearOp<W, EXT, STATS> &) { return !STATS; }
+template <int W, bool EXT, bool STATS> __device__ __forceinline__ uint32_t op_fail_code(const LinearOp<W, EXT, STATS> &) { return 0; }
+
+/* Sender side of the owner exchange, second half (the first is extract_kernel<LinearOp<.., false>>): the linear records
+ * of a read batch -> `world` contiguous owner segments, owner = getDistributedThreadId(lookup3(key), world)
+ * (src/Kmer.h:2284-2295; the routing of _buildKmerSpectrumMPI, src/DistributedFunctions.h:418-438).  One wavefront per
+ * tile of the linear buffer, in pieces of OSEG records: pass 1 hashes every record, keeps its owner in LDS and counts per
+ * owner; one device atomic per owner reserves the piece's run in each segment; pass 2 reads the records again (L2 / MALL)
+ * and stores them behind the runs in order.  No holes: seg_counts are exact record counts. */
+static const int OSEG = 2048, OWNER_THREADS = 256, OWNER_MAX = 8;
+template <int W>
+__global__ __launch_bounds__(OWNER_THREADS)
+void owner_scatter_kernel(const Record<W> *linear, const uint64_t *koff, const uint32_t *tile_count, uint64_t n_tiles, uint32_t kb, uint32_t world,
+                          Record<W> *out, uint64_t seg_capacity, unsigned long long *seg_counts, unsigned int *work_counter, uint32_t *err) {
+	/* One block per tile of the linear buffer, in pieces of OSEG records that are read from HBM once and held in
+	 * registers: every thread hashes its records and takes a rank per owner from an LDS counter, one thread per owner
+	 * reserves the piece's run in that owner's segment with ONE device atomic, and every thread stores its records at
+	 * (run base + rank): the stores of a piece fill one contiguous run per owner. */
+	typedef Record<W> Rec;
+	__shared__ uint32_t s_cnt[OWNER_MAX];
+	__shared__ unsigned long long s_base[OWNER_MAX];
+	__shared__ uint32_t s_tile;
+	const int t = threadIdx.x;
+	constexpr int PER = OSEG / OWNER_THREADS;
+	for (;;) {
+		__syncthreads();
+		if (t == 0) s_tile = atomicAdd(work_counter, 1u);
+		__syncthreads();
+		const uint32_t tile = s_tile;
+		if (tile >= n_tiles) break;
+		const uint64_t start = koff[(uint64_t)tile * 64];
+		const uint32_t n = tile_count[tile];
+		for (uint32_t s0 = 0; s0 < n; s0 += OSEG) {
+			const uint32_t m = n - s0 < (uint32_t)OSEG ? n - s0 : (uint32_t)OSEG;
+			const Rec *src = linear + start + s0;
+			if (t < OWNER_MAX) s_cnt[t] = 0;
+			__syncthreads();
+			Rec r[PER];
+			uint32_t ow[PER], rank[PER];
+#pragma unroll
+			for (int u = 0; u < PER; u++) { const uint32_t i = (uint32_t)u * OWNER_THREADS + t; r[u] = src[i < m ? i : m - 1]; }
+#pragma unroll
+			for (int u = 0; u < PER; u++) {
+				const uint32_t i = (uint32_t)u * OWNER_THREADS + t;
+				ow[u] = 0xffu; rank[u] = 0;
+				if (i < m) {
+					Key<W> key;
+#pragma unroll
+					for (int j = 0; j < W; j++) key.w[j] = r[u].key[j];
+					ow[u] = distributed_thread_id(key_hash<W>(key, kb), world);
+					rank[u] = atomicAdd(&s_cnt[ow[u]], 1u);
+				}
+			}
+			__syncthreads();
+			if ((uint32_t)t < world) {
+				const uint32_t c = s_cnt[t];
+				unsigned long long b = c ? atomicAdd(&seg_counts[t], (unsigned long long)c) : 0ull;
+				if (b + c > seg_capacity) { atomicOr(err, (uint32_t)ERR_SEGMENT_OVERFLOW); b = ~0ull; }
+				s_base[t] = b;
+			}
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < PER; u++) {
+				const uint32_t i = (uint32_t)u * OWNER_THREADS + t;
+				if (i < m) { const unsigned long long b = s_base[ow[u]]; if (b != ~0ull) out[(uint64_t)ow[u] * seg_capacity + b + rank[u]] = r[u]; }
+			}
+		}
+	}
+}
 
 /* k-mer capacity of every work unit (a read, or a segment of a long read) */
 __global__ void kmer_capacity_kernel(ReadsView rv, uint32_t k, uint32_t *cap) {

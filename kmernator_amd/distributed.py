@@ -29,13 +29,22 @@ def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
     assert rec_bytes % 8 == 0
     words = rec_bytes // 8
     rows = records.view(torch.int64).view(world, seg_capacity, words)
-    if world > 1:
-        send = torch.cat([rows[s, :sc[s]] for s in range(world)])
-    else:
-        send = rows[0, :sc[0]]
-    recv = torch.empty((sum(rc), words), dtype=torch.int64, device=records.device)
-    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=rc, input_split_sizes=sc, group=group)
+    recv = _all_to_all_rows(rows, sc, rc, group)
     return recv.view(torch.uint8).view(-1), sum(rc)
+
+
+def _all_to_all_rows(rows, sc, rc, group=None):
+    """rows: int64 [world, seg_cap, words]; rank s gets rows[s, :sc[s]].  Returns the received rows [sum(rc), words].
+    RCCL takes the owner segments as they lie (a list of views: grouped send/recv, no staging copy of the payload);
+    gloo only has the single-tensor form, so the CPU tests go through one concatenation."""
+    world = rows.shape[0]
+    recv = torch.empty((sum(rc), rows.shape[2]), dtype=rows.dtype, device=rows.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all(list(recv.split(rc)), [rows[s, :sc[s]] for s in range(world)], group=group)
+    else:
+        send = torch.cat([rows[s, :sc[s]] for s in range(world)]) if world > 1 else rows[0, :sc[0]].contiguous()
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+    return recv
 
 
 def all_ranks_chunk_count(n_local_chunks, group=None, device="cpu"):
@@ -75,7 +84,7 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
     off_host = offsets.cpu()
     chunk_reads, n_chunks, max_kmers = _plan_chunks(off_host, n, rb, chunk_reads)
     total_chunks = all_ranks_chunk_count(n_chunks, group, dev)
-    seg_cap = max(1024, int(max_kmers / world * slack) + 1024) + 512 * 4096      # + one partly used 512-slot run per wavefront
+    seg_cap = max(1024, int(max_kmers / world * slack) + 1024)
     nbuf = 2 if pipeline else 1
     records = [torch.empty(world * seg_cap * rb, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     counts = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(nbuf)]
@@ -128,14 +137,11 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
             if max(sc) > seg_cap:
                 raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_cap))
             rows = records[b].view(torch.int64).view(world, seg_cap, words)
-            send = torch.cat([rows[s, :sc[s]] for s in range(world)]) if world > 1 else rows[0, :sc[0]].contiguous()
-            recv = torch.empty((sum(rc), words), dtype=torch.int64, device=dev)
-            dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+            recv = _all_to_all_rows(rows, sc, rc, group)
             ev_comm = torch.cuda.Event()
             ev_comm.record(comm_stream)
         recv.record_stream(lib_stream)
-        send.record_stream(comm_stream)
-        keep_alive.append((recv, send))
+        keep_alive.append(recv)
         if len(keep_alive) > 3:
             keep_alive.pop(0)
         lib_stream.wait_event(ev_comm)
