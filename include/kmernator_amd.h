@@ -255,22 +255,21 @@ int kmr_least_complement(const uint8_t *packed, uint32_t k, uint8_t *out);
  * all-to-all over xGMI via torch.distributed); receiver side =
  * StoreKmerMessageHeaderProcessor::process -> append (:323-328).
  *
- * A record is KMR_RECORD_BYTES(k) bytes: u64 key words (big-endian packed
- * k-mer, zero padded), f32 signed weight (negative = observed strand was the
- * reverse complement, as StoreKmerMessageHeader::weight :279), u32 extension
- * packet (leftBase,rightBase chars, leftQ,rightQ; ExtensionMessagePacket,
- * src/KmerTrackingData.h:232-288). */
+ * A record is KMR_RECORD_BYTES(k, value_kind) bytes, 4-byte aligned: the u64 key words (big-endian packed
+ * k-mer, zero padded; each word as two little-endian u32, low half first), an f32 signed weight (negative =
+ * observed strand was the reverse complement, as StoreKmerMessageHeader::weight :279) and, for
+ * KMR_VALUE_EXT only, the u32 extension packet (leftBase,rightBase chars, leftQ,rightQ;
+ * ExtensionMessagePacket, src/KmerTrackingData.h:232-288).  12 bytes per k-mer at k <= 32 against the
+ * reference's 24 + kb byte message (src/DistributedFunctions.h:274-303). */
 #define KMR_KEY_WORDS(k) ((((k) + 3u) / 4u + 7u) / 8u)
-#define KMR_RECORD_BYTES(k) (8u * KMR_KEY_WORDS(k) + 8u)
+#define KMR_RECORD_BYTES(k, value_kind) (8u * KMR_KEY_WORDS(k) + ((value_kind) == KMR_VALUE_EXT ? 8u : 4u))
 
 /* Extract all good k-mers of a device-resident read batch and bin them by
  * owner = kmr_distributed_thread_id(hash, world_size) into world_size
- * contiguous segments of dev_records.  dev_seg_counts[world_size] (u64, device)
- * receives the SLOTS handed out per owner; segment s starts at record
- * seg_capacity * s.  Wavefronts take slots in runs of 512, so a segment also holds
- * holes (records with weight 0) which kmr_insert_records_dev skips; size
- * seg_capacity for the expected records plus 512 * 4096 slots of slack.  Returns KMR_ERR_CAPACITY (after sync) if a segment
- * overflowed.  Asynchronous on the handle's stream otherwise. */
+ * contiguous segments of dev_records; segment s starts at record seg_capacity * s.
+ * dev_seg_counts[world_size] (u64, device) receives the number of records per owner.
+ * Returns KMR_ERR_CAPACITY (after sync) if a segment overflowed.  Asynchronous on the
+ * handle's stream otherwise. */
 int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals,
                              const void *dev_offsets, uint64_t n_reads, uint64_t total_bases,
                              uint64_t first_global_read_idx, const void *dev_discarded,

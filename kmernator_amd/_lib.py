@@ -137,6 +137,6 @@ def default_config(k, **kw):
     return c
 
 
-def record_bytes(k):
-    """KMR_RECORD_BYTES(k)"""
-    return 8 * ((((k + 3) // 4) + 7) // 8) + 8
+def record_bytes(k, value_kind=KMR_VALUE_COUNT_DIR):
+    """KMR_RECORD_BYTES(k, value_kind)"""
+    return 8 * ((((k + 3) // 4) + 7) // 8) + (8 if value_kind == KMR_VALUE_EXT else 4)

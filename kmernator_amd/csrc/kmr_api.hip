@@ -77,6 +77,7 @@ struct kmr_handle {
 	int bits1 = 0;
 	uint64_t inserted_records = 0;     /* records fed through kmr_insert_records_dev (counted on the host) */
 	unsigned int *work_counter = nullptr;
+	uint8_t *l1_state = nullptr; size_t l1_state_bytes = 0; bool l1_state_dirty = false;   /* see PartSource::state */
 	void *linear = nullptr; uint64_t linear_cap = 0;         /* records */
 	uint32_t *tile_count = nullptr; uint64_t tile_cap = 0;
 	uint32_t *kcap = nullptr; uint64_t *koff = nullptr; uint64_t kcap_n = 0, koff_n = 0;
@@ -627,10 +628,33 @@ int part_grid(kmr_handle *h) { return num_cus(h) * 2; }
  * those there are the longer the runs each batch appends */
 int partition_blocks(kmr_handle *h) { return getenv("KMR_PART_BLOCKS") ? atoi(getenv("KMR_PART_BLOCKS")) : num_cus(h); }
 
+/* per-block level-1 state, allocated (and emptied) on first use */
+template <int W> int ensure_l1_state(kmr_handle *h) {
+	const size_t stride = partition_state_bytes<W, PD_LINE>(h->bits1), need = stride * (size_t)partition_blocks(h);
+	if (h->l1_state && h->l1_state_bytes == need) return 0;
+	if (h->l1_state) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->l1_state); h->l1_state = nullptr; }
+	HIPCHK(h, hipMalloc((void **)&h->l1_state, need)); h->l1_state_bytes = need;
+	hipLaunchKernelGGL(partition_state_init_kernel, dim3(partition_blocks(h)), dim3(256), 0, h->stream, h->l1_state, stride, h->bits1, (uint32_t)partition_blocks(h));
+	HIPCHK(h, hipGetLastError());
+	h->l1_state_dirty = false;
+	return 0;
+}
+/* last level-1 launch of a build: no input, every block flushes what it kept back */
+template <int W> int flush_l1_state(kmr_handle *h) {
+	if (!h->l1_state || !h->l1_state_dirty) return 0;
+	int rc = pool_reserve(h, h->l1, (uint64_t)partition_blocks(h) * ((1ull << h->bits1) + 512) + 64, true); if (rc) return rc;
+	rc = zero_work_counter(h); if (rc) return rc;
+	PartSource<W> S; memset(&S, 0, sizeof(S));
+	S.kb = h->kb; S.rot = part_rot(h); S.state = h->l1_state; S.state_final = 1;
+	rc = launch_partition<W, 1>(h, S, h->l1, partition_blocks(h), h->bits1, 0);
+	h->l1_state_dirty = false;
+	return rc;
+}
+
 /* level-1 partition of a linear record buffer into h->l1 */
 template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, const uint64_t *ext_start, const uint32_t *ext_count,
                                       uint64_t n_ext, uint32_t ext_stride, uint64_t ext_len, uint64_t total, uint64_t max_records,
-                                      unsigned long long *valid_counter = nullptr) {
+                                      unsigned long long *valid_counter = nullptr, uint32_t packed_words = 0, uint64_t ordinal_base = 0) {
 	if (n_ext == 0) return 0;
 	const int grid = (int)std::min<uint64_t>(partition_blocks(h), n_ext);
 	if (!h->l1.base) {
@@ -644,7 +668,9 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	rc = zero_work_counter(h); if (rc) return rc;
 	PartSource<W> S; memset(&S, 0, sizeof(S));
 	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
-	S.valid_counter = valid_counter; S.kb = h->kb; S.rot = part_rot(h);
+	S.valid_counter = valid_counter; S.kb = h->kb; S.rot = part_rot(h); S.packed_words = packed_words; S.ordinal_base = ordinal_base;
+	rc = ensure_l1_state<W>(h); if (rc) return rc;
+	S.state = h->l1_state; S.state_final = 0; h->l1_state_dirty = true;
 	hipEvent_t ta, tb; time_begin(h, KMR_TIME_PARTITION1, &ta, &tb);
 	rc = launch_partition<W, 1>(h, S, h->l1, grid, h->bits1, 0);
 	time_end(h, KMR_TIME_PARTITION1, ta, tb);
@@ -688,8 +714,8 @@ template <int W, bool EXT> int extract_by_owner_t(kmr_handle *h, const ReadsView
 		rc = launch_extract<W, EXT>(h, rv, op); if (rc) return rc;
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 8, tiles);
-		hipLaunchKernelGGL(owner_scatter_kernel<W>, dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const Record<W> *)h->linear, h->koff, h->tile_count, tiles, h->kb,
-		                   h->cfg.world_size, (Record<W> *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr);
+		hipLaunchKernelGGL((owner_scatter_kernel<W, EXT>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const Record<W> *)h->linear, h->koff, h->tile_count, tiles, h->kb,
+		                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr);
 		HIPCHK(h, hipGetLastError());
 	}
 	return 0;
@@ -789,6 +815,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	FinalizeParams f; f.kb = h->kb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
+	rc = flush_l1_state<W>(h); if (rc) return rc;
 	/* level-1 CSR and level-2 work items */
 	const uint64_t nl1 = 1ull << h->bits1;
 	uint64_t *ls1 = nullptr; uint64_t *lc1 = nullptr; uint32_t nch1 = 0;
@@ -954,7 +981,8 @@ template <int W> int insert_records_partition_t(kmr_handle *h, const void *recs,
 	if (!h->l1.head) choose_bits1(h, n);
 	hipEvent_t a, b; time_begin(h, 0, &a, &b);
 	/* received segments contain holes (weight 0): the device counts the real records into stats.raw/good */
-	int rc = partition_level1<W>(h, (const Record<W> *)recs, nullptr, nullptr, (n + 8191) / 8192, 0, 8192, n, n, &h->dstats->inserted);
+	int rc = partition_level1<W>(h, (const Record<W> *)recs, nullptr, nullptr, (n + 8191) / 8192, 0, 8192, n, n, &h->dstats->inserted,
+	                             2 * W + (h->ext ? 2 : 1), h->stream_base);
 	time_end(h, 0, a, b);
 	return rc;
 }
@@ -964,6 +992,7 @@ int insert_records_partition(kmr_handle *h, const void *recs, uint64_t n) {
 }
 void free_partition_state(kmr_handle *h) {
 	pool_free(h->l1); pool_free(h->l2);
+	if (h->l1_state) hipFree(h->l1_state); h->l1_state = nullptr; h->l1_state_bytes = 0; h->l1_state_dirty = false;
 	if (h->work_counter) hipFree(h->work_counter); if (h->linear) hipFree(h->linear); if (h->tile_count) hipFree(h->tile_count);
 	if (h->kcap) hipFree(h->kcap); if (h->koff) hipFree(h->koff);
 	if (h->ucnt) hipFree(h->ucnt); if (h->ufirst) hipFree(h->ufirst); if (h->u_start) { hipFree(h->u_start); hipFree(h->u_end); hipFree(h->u_read); } if (h->umax) hipFree(h->umax);
@@ -1075,6 +1104,11 @@ int kmr_reset(kmr_handle *h) {
 		if (h->l2.head) HIPCHK(h, hipMemsetAsync(h->l2.head, 0, 4, h->stream));
 		h->l1.used_ub = 0; h->l2.used_ub = 0;
 		h->inserted_records = 0;
+		if (h->l1_state) {      /* what an unfinished build kept back is dropped with its pool */
+			hipLaunchKernelGGL(partition_state_init_kernel, dim3(partition_blocks(h)), dim3(256), 0, h->stream, h->l1_state,
+			                   h->l1_state_bytes / (size_t)partition_blocks(h), h->bits1, (uint32_t)partition_blocks(h));
+			h->l1_state_dirty = false;
+		}
 	} else {
 		if (!h->slots) rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
 		else rc = clear_table_any(h, h->slots, h->extslots, h->log2cap);
@@ -1603,7 +1637,7 @@ int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n) {
 	if (h->partition_mode) { int prc = insert_records_partition(h, dev_records, n); h->stream_base += n; return prc; }
 	int rc = ensure_capacity(h, n); if (rc) return rc;
 	hipEvent_t a, b; time_begin(h, 0, &a, &b);
-#define INS(Wv, E) hipLaunchKernelGGL((insert_records_kernel<Wv, E>), dim3(grid_for(n)), dim3(256), 0, h->stream, table_of<Wv>(h), (const Record<Wv> *)dev_records, n, dev_params(h), h->stream_base)
+#define INS(Wv, E) hipLaunchKernelGGL((insert_records_kernel<Wv, E>), dim3(grid_for(n)), dim3(256), 0, h->stream, table_of<Wv>(h), (const uint32_t *)dev_records, n, dev_params(h), h->stream_base)
 	switch (h->W) {
 	case 1: if (h->ext) INS(1, true); else INS(1, false); break;
 	case 2: if (h->ext) INS(2, true); else INS(2, false); break;

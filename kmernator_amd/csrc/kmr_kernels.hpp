@@ -791,10 +791,16 @@ __global__ void score_reads_kernel(const uint8_t *bases, const uint64_t *offsets
 /* ----------------------------------------------------------------------- */
 /* records -> table (receiver side of the exchange)                           */
 template <int W, bool EXT>
-__global__ void insert_records_kernel(Table<W> table, const Record<W> *recs, uint64_t n, DevParams p, uint64_t ordinal_base) {
+__global__ void insert_records_kernel(Table<W> table, const uint32_t *recs, uint64_t n, DevParams p, uint64_t ordinal_base) {
+	constexpr uint32_t RW = 2 * W + (EXT ? 2 : 1);      /* dwords of a wire record (KMR_RECORD_BYTES) */
 	unsigned long long nGood = 0; unsigned nClaimed = 0; bool fail = false;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-		Record<W> r = recs[i];
+		Record<W> r;
+		const uint32_t *p32 = recs + i * RW;
+#pragma unroll
+		for (int j = 0; j < W; j++) r.key[j] = (uint64_t)p32[2 * j] | ((uint64_t)p32[2 * j + 1] << 32);
+		r.w = __uint_as_float(p32[2 * W]);
+		r.pkt = EXT ? p32[2 * W + (EXT ? 1 : 0)] : 0u;
 		if (r.w == 0.0f) continue;                   /* hole left by the sender's slab allocation */
 		Key<W> key;
 #pragma unroll

@@ -121,12 +121,13 @@ template <int W, bool EXT, bool STATS> __device__ __forceinline__ uint32_t op_fa
  * (src/Kmer.h:2284-2295; the routing of _buildKmerSpectrumMPI, src/DistributedFunctions.h:418-438).  One wavefront per
  * tile of the linear buffer, in pieces of OSEG records: pass 1 hashes every record, keeps its owner in LDS and counts per
  * owner; one device atomic per owner reserves the piece's run in each segment; pass 2 reads the records again (L2 / MALL)
- * and stores them behind the runs in order.  No holes: seg_counts are exact record counts. */
+ * and stores them behind the runs in order, in the wire format.  No holes: seg_counts are exact record counts. */
 static const int OSEG = 2048, OWNER_THREADS = 256, OWNER_MAX = 8;
-template <int W>
+template <int W, bool EXT>
 __global__ __launch_bounds__(OWNER_THREADS)
 void owner_scatter_kernel(const Record<W> *linear, const uint64_t *koff, const uint32_t *tile_count, uint64_t n_tiles, uint32_t kb, uint32_t world,
-                          Record<W> *out, uint64_t seg_capacity, unsigned long long *seg_counts, unsigned int *work_counter, uint32_t *err) {
+                          uint32_t *out, uint64_t seg_capacity, unsigned long long *seg_counts, unsigned int *work_counter, uint32_t *err) {
+	constexpr uint32_t RW = 2 * W + (EXT ? 2 : 1);      /* dwords of a wire record (KMR_RECORD_BYTES) */
 	/* One block per tile of the linear buffer, in pieces of OSEG records that are read from HBM once and held in
 	 * registers: every thread hashes its records and takes a rank per owner from an LDS counter, one thread per owner
 	 * reserves the piece's run in that owner's segment with ONE device atomic, and every thread stores its records at
@@ -177,7 +178,16 @@ void owner_scatter_kernel(const Record<W> *linear, const uint64_t *koff, const u
 #pragma unroll
 			for (int u = 0; u < PER; u++) {
 				const uint32_t i = (uint32_t)u * OWNER_THREADS + t;
-				if (i < m) { const unsigned long long b = s_base[ow[u]]; if (b != ~0ull) out[(uint64_t)ow[u] * seg_capacity + b + rank[u]] = r[u]; }
+				if (i < m) {
+					const unsigned long long b = s_base[ow[u]];
+					if (b != ~0ull) {
+						uint32_t *dst = out + ((uint64_t)ow[u] * seg_capacity + b + rank[u]) * RW;
+#pragma unroll
+						for (int j = 0; j < W; j++) { dst[2 * j] = (uint32_t)r[u].key[j]; dst[2 * j + 1] = (uint32_t)(r[u].key[j] >> 32); }
+						dst[2 * W] = __float_as_uint(r[u].w);
+						if (EXT) dst[2 * W + 1] = r[u].pkt;
+					}
+				}
 			}
 		}
 	}
@@ -216,7 +226,28 @@ template <int W> struct PartSource {
 	const uint64_t *item_end;
 	const uint32_t *item_list;     /* ... and the level-1 list it belongs to */
 	uint64_t n_items;
+	/* LEVEL 1: per-block state (open chunk, fill and write-combining line of every list) kept in device memory between
+	 * launches, so that a build fed in many sub-batches does not end every launch with ~lists half-empty chunks per
+	 * block; state_final: flush instead of saving (the last launch, with no input) */
+	uint8_t *state;
+	uint32_t state_final;
+	/* LEVEL 1 input in the exchange wire format (KMR_RECORD_BYTES: 2W key dwords, weight, [extension packet]) instead of
+	 * Record<W>: dwords per record, 0 = Record<W>.  Records without a packet get their arrival ordinal. */
+	uint32_t packed_words;
+	uint64_t ordinal_base;
 };
+
+template <int W, int G> __host__ __device__ inline size_t partition_state_bytes(int bits) {
+	return ((((size_t)3 << bits) * 4 + 15) & ~(size_t)15) + ((size_t)G << bits) * sizeof(Record<W>);
+}
+/* empty state: no open chunk, nothing waiting */
+__global__ void partition_state_init_kernel(uint8_t *state, size_t stride, int bits, uint32_t n_blocks) {
+	const uint32_t P = 1u << bits;
+	for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+		uint32_t *gs = (uint32_t *)(state + (size_t)b * stride);
+		for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) { gs[p] = NO_CHUNK; gs[P + p] = 0; gs[2 * P + p] = 0; }
+	}
+}
 
 /* ------------------------------------------------------------------ partition kernel */
 /* Per batch (THREADS * RPT records held in registers, RPT per thread):
@@ -263,7 +294,17 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 	__shared__ uint32_t s_alloc, s_filled;
 	const int t = threadIdx.x;
 
-	for (int p = t; p < P; p += THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; hist[p] = 0; if (G) stage_n[p] = 0; }
+	uint32_t *gstate = nullptr; Rec *glines = nullptr;
+	if (LEVEL == 1 && G && S.state) {
+		gstate = (uint32_t *)(S.state + (size_t)blockIdx.x * partition_state_bytes<W, G>(LOG2P));
+		glines = (Rec *)((uint8_t *)gstate + ((((size_t)3 << LOG2P) * 4 + 15) & ~(size_t)15));
+	}
+	if (gstate) {
+		for (int p = t; p < P; p += THREADS) { cur[p] = gstate[p]; cnt[p] = gstate[P + p]; hist[p] = 0; stage_n[p] = gstate[2 * P + p]; }
+		for (int i = t; i < P * G; i += THREADS) stage[i] = glines[i];
+	} else {
+		for (int p = t; p < P; p += THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; hist[p] = 0; if (G) stage_n[p] = 0; }
+	}
 	if (t == 0) { s_alloc = 0; s_filled = 0; s_nextra = 0; }
 	lds_barrier();
 
@@ -396,7 +437,14 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 				for (int i = 0; i < RPT; i++) {
 					const uint32_t slot = (uint32_t)i * THREADS + t;
 					if (slot >= first && slot < first + n) {
-						rr[i] = S.linear[start + (slot - first)];
+						const uint64_t ri = start + (slot - first);
+						if (S.packed_words) {
+							const uint32_t *p32 = (const uint32_t *)S.linear + ri * S.packed_words;
+#pragma unroll
+							for (int j = 0; j < W; j++) rr[i].key[j] = (uint64_t)p32[2 * j] | ((uint64_t)p32[2 * j + 1] << 32);
+							rr[i].w = __uint_as_float(p32[2 * W]);
+							rr[i].pkt = S.packed_words > 2u * W + 1u ? p32[2 * W + 1] : (uint32_t)(S.ordinal_base + ri);
+						} else rr[i] = S.linear[ri];
 						if (rr[i].w != 0.0f) { pp[i] = pid_of(rr[i]); nvalid++; }
 					}
 				}
@@ -436,7 +484,13 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 			lds_barrier();
 		}
 		lds_barrier();
-		flush_all(0);
+		if (gstate && !S.state_final) {
+			for (int p = t; p < P; p += THREADS) { gstate[p] = cur[p]; gstate[P + p] = cnt[p]; gstate[2 * P + p] = stage_n[p]; }
+			for (int i = t; i < P * G; i += THREADS) glines[i] = stage[i];
+		} else {
+			flush_all(0);
+			if (gstate) for (int p = t; p < P; p += THREADS) { gstate[p] = NO_CHUNK; gstate[P + p] = 0; gstate[2 * P + p] = 0; }
+		}
 		if (S.valid_counter) { nvalid = wave_sum(nvalid); if ((t & 63) == 0 && nvalid) atomicAdd(S.valid_counter, nvalid); }
 	} else {
 		auto load2 = [&](uint64_t cb, uint64_t cb1, auto &rr, auto &pp) {

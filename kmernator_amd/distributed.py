@@ -16,8 +16,8 @@ def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
     """records: uint8 tensor [world * seg_capacity * rec_bytes], segment s holds
     seg_counts[s] records for rank s.  Returns (recv uint8 tensor, n_records).
 
-    The payload travels as int64 rows of one record each, so the split sizes handed to the
-    collective count records (a byte count overflows 32 bits at ~1.3e8 sixteen-byte records)."""
+    The payload travels as int32 rows of one record each, so the split sizes handed to the
+    collective count records (a byte count overflows 32 bits at ~1.8e8 twelve-byte records)."""
     world = dist.get_world_size(group)
     send_counts = seg_counts.to(torch.int64)
     recv_counts = torch.empty_like(send_counts)
@@ -26,15 +26,15 @@ def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
     rc = [int(x) for x in recv_counts.cpu().tolist()]
     if max(sc) > seg_capacity:
         raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_capacity))
-    assert rec_bytes % 8 == 0
-    words = rec_bytes // 8
-    rows = records.view(torch.int64).view(world, seg_capacity, words)
+    assert rec_bytes % 4 == 0
+    words = rec_bytes // 4
+    rows = records.view(torch.int32).view(world, seg_capacity, words)
     recv = _all_to_all_rows(rows, sc, rc, group)
     return recv.view(torch.uint8).view(-1), sum(rc)
 
 
 def _all_to_all_rows(rows, sc, rc, group=None):
-    """rows: int64 [world, seg_cap, words]; rank s gets rows[s, :sc[s]].  Returns the received rows [sum(rc), words].
+    """rows: int32 [world, seg_cap, words]; rank s gets rows[s, :sc[s]].  Returns the received rows [sum(rc), words].
     RCCL takes the owner segments as they lie (a list of views: grouped send/recv, no staging copy of the payload);
     gloo only has the single-tensor form, so the CPU tests go through one concatenation."""
     world = rows.shape[0]
@@ -79,7 +79,7 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
     from . import record_bytes
     world = dist.get_world_size(group)
     n = offsets.numel() - 1
-    rb = record_bytes(spectrum.k)
+    rb = record_bytes(spectrum.k, spectrum.cfg.value_kind)
     dev = bases.device
     off_host = offsets.cpu()
     chunk_reads, n_chunks, max_kmers = _plan_chunks(off_host, n, rb, chunk_reads)
@@ -119,7 +119,7 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
     torch.cuda.synchronize(dev)
     ev_extract = [torch.cuda.Event() for _ in range(nbuf)]
     keep_alive = []
-    words = rb // 8
+    words = rb // 4
     submit_extract(0)
     ev_extract[0].record(lib_stream)
     for c in range(total_chunks):
@@ -136,7 +136,7 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
             rc = [int(x) for x in recv_counts.cpu().tolist()]
             if max(sc) > seg_cap:
                 raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_cap))
-            rows = records[b].view(torch.int64).view(world, seg_cap, words)
+            rows = records[b].view(torch.int32).view(world, seg_cap, words)
             recv = _all_to_all_rows(rows, sc, rc, group)
             ev_comm = torch.cuda.Event()
             ev_comm.record(comm_stream)

@@ -972,7 +972,8 @@ int64_t orc_extract_records_by_owner(const kmr_config *cfg, const char *bases, c
 	initTables();
 	KmerBuilder b; b.k = cfg->k; b.kb = (cfg->k + 3) / 4; b.fastqStart = cfg->fastq_start_char; b.extMinQuality = (uint8_t)cfg->ext_min_quality;
 	initializeQualityToProbability(b.P, (unsigned char)cfg->min_quality_score, cfg->fastq_start_char);
-	const uint32_t W = (b.kb + 7) / 8, rb = 8 * W + 8;
+	const bool extv = cfg->value_kind == KMR_VALUE_EXT;
+	const uint32_t W = (b.kb + 7) / 8, rb = 8 * W + (extv ? 8 : 4);      /* KMR_RECORD_BYTES */
 	for (uint32_t o = 0; o < cfg->world_size; o++) seg_counts[o] = 0;
 	WeightedKmers wk;
 	int64_t total = 0;
@@ -995,7 +996,7 @@ int64_t orc_extract_records_by_owner(const kmr_config *cfg, const char *bases, c
 			}
 			memcpy(rec + 8 * W, &w, 4);
 			uint32_t pkt = (uint32_t)(uint8_t)wk.exts[i].leftB | ((uint32_t)(uint8_t)wk.exts[i].rightB << 8) | ((uint32_t)wk.exts[i].leftQ << 16) | ((uint32_t)wk.exts[i].rightQ << 24);
-			memcpy(rec + 8 * W + 4, &pkt, 4);
+			if (extv) memcpy(rec + 8 * W + 4, &pkt, 4);
 			total++;
 		}
 	}
@@ -1004,12 +1005,13 @@ int64_t orc_extract_records_by_owner(const kmr_config *cfg, const char *bases, c
 /* receiver side: StoreKmerMessageHeaderProcessor::process -> append (src/DistributedFunctions.h:323-328) */
 int orc_insert_records(orc_handle *h, const uint8_t *records, uint64_t n) {
 	SpectrumBase *s = h->s;
-	const uint32_t W = (s->kb + 7) / 8, rb = 8 * W + 8;
+	const bool extv = s->cfg.value_kind == KMR_VALUE_EXT;
+	const uint32_t W = (s->kb + 7) / 8, rb = 8 * W + (extv ? 8 : 4);
 	std::vector<uint8_t> key(s->kb);
 	for (uint64_t i = 0; i < n; i++) {
 		const uint8_t *rec = records + i * rb;
 		for (uint32_t wd = 0; wd < W; wd++) { uint64_t v; memcpy(&v, rec + 8 * wd, 8); for (uint32_t j = 0; j < 8; j++) { uint32_t idx = wd * 8 + j; if (idx < s->kb) key[idx] = (uint8_t)(v >> (56 - 8 * j)); } }
-		float w; uint32_t pkt; memcpy(&w, rec + 8 * W, 4); memcpy(&pkt, rec + 8 * W + 4, 4);
+		float w; uint32_t pkt = 0; memcpy(&w, rec + 8 * W, 4); if (extv) memcpy(&pkt, rec + 8 * W + 4, 4);
 		ExtPacket e; e.leftB = (char)(pkt & 0xff); e.rightB = (char)((pkt >> 8) & 0xff); e.leftQ = (uint8_t)(pkt >> 16); e.rightQ = (uint8_t)(pkt >> 24);
 		s->appendOne(key.data(), w, e);
 	}

@@ -367,7 +367,7 @@ def oracle_extract_by_owner(cfg, rb, seg_capacity):
     """(records uint8 [world*seg_capacity*rec_bytes], counts uint64 [world])"""
     lib = oracle_lib()
     W = (((cfg.k + 3) // 4) + 7) // 8
-    recb = 8 * W + 8
+    recb = 8 * W + (8 if cfg.value_kind == KMR_VALUE_EXT else 4)
     recs = np.zeros(cfg.world_size * seg_capacity * recb, dtype=np.uint8)
     counts = np.zeros(cfg.world_size, dtype=np.uint64)
     n = lib.orc_extract_records_by_owner(C.byref(cfg), rb.bases.ctypes.data_as(C.c_char_p),

@@ -30,7 +30,7 @@ def _worker(rank, world, port, tmp, k, ext):
         kw = dict(value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2) if ext else {}
         cfg = default_config(k, fastq_start_char=64, estimated_raw_kmers=56000, rank=rank, world_size=world, **kw)
         spec = OracleSpectrum(cfg)
-        recb = record_bytes(k)
+        recb = record_bytes(k, cfg.value_kind)
         chunk = 130                                   # uneven chunk counts across ranks on purpose
         n_chunks = (hi - lo + chunk - 1) // chunk if rank != world - 1 else 2
         total = all_ranks_chunk_count(n_chunks)

@@ -396,7 +396,7 @@ def test_extract_by_owner_and_insert_records(k, ext, mode):
     kw = dict(value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2) if ext else {}
     cfgs = [default_config(k, num_buckets_weak=256, num_buckets_singleton=1024, rank=r, world_size=world, **kw) for r in range(world)]
     handles = [product(c, mode) for c in cfgs]
-    recb = ka.record_bytes(k)
+    recb = ka.record_bytes(k, cfgs[0].value_kind)
     dev = torch.device("cuda", 0)
     half = rb.n // 2
     seg_cap = 3000 * 110
