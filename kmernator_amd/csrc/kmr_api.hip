@@ -38,6 +38,8 @@ struct DevMap {                      /* a finalized map resident in HBM */
 	uint8_t *image = nullptr;        /* reference layout, built lazily */
 	uint64_t image_bytes = 0;
 	bool present = false;
+	/* bytes allocated behind start / keys / vals / sweight: kmr_reset() keeps the buffers of the streaming path for the next build */
+	size_t c_start = 0, c_keys = 0, c_vals = 0, c_sw = 0;
 };
 
 struct HostPool {                    /* owner of one chunk pool */
@@ -78,6 +80,10 @@ struct kmr_handle {
 	uint64_t inserted_records = 0;     /* records fed through kmr_insert_records_dev (counted on the host) */
 	unsigned int *work_counter = nullptr;
 	uint8_t *l1_state = nullptr; size_t l1_state_bytes = 0; bool l1_state_dirty = false;   /* see PartSource::state */
+	/* temporaries of kmr_finalize (chunk CSRs, work items, counters): one grow-only block handed out by bumping a
+	 * cursor, so a finalize neither allocates nor frees device memory once the handle has seen one build */
+	uint8_t *arena = nullptr; size_t arena_cap = 0, arena_used = 0, arena_want = 0; std::vector<void *> arena_overflow;
+	unsigned long long *scan_sums = nullptr; uint64_t scan_sums_n = 0;
 	void *linear = nullptr; uint64_t linear_cap = 0;         /* records */
 	uint32_t *tile_count = nullptr; uint64_t tile_cap = 0;
 	uint32_t *kcap = nullptr; uint64_t *koff = nullptr; uint64_t kcap_n = 0, koff_n = 0;
@@ -331,21 +337,66 @@ int add_reads_dev_any(kmr_handle *h, const ReadsView &rv, uint64_t total_bases) 
 int exclusive_scan(kmr_handle *h, const uint32_t *in, uint64_t n, uint64_t *out /* n+1 */) {
 	const uint64_t nblocks = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
 	unsigned long long *sums, *total;
-	HIPCHK(h, hipMalloc((void **)&sums, sizeof(unsigned long long) * (nblocks + 1)));
+	if (h->scan_sums_n < nblocks + 1) {
+		if (h->scan_sums) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->scan_sums); h->scan_sums = nullptr; h->scan_sums_n = 0; }
+		const uint64_t want = std::max<uint64_t>(nblocks + 1, 4096);
+		HIPCHK(h, hipMalloc((void **)&h->scan_sums, sizeof(unsigned long long) * want)); h->scan_sums_n = want;
+	}
+	sums = h->scan_sums;
 	total = sums + nblocks;
 	hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, h->stream, in, n, sums);
 	hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, h->stream, sums, nblocks, total);
 	hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, h->stream, in, n, sums, out);
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipStreamSynchronize(h->stream));
-	hipFree(sums);
 	return 0;
 }
+
+/* bump allocation out of the finalize arena (256-byte aligned); what does not fit is allocated on the side, freed by
+ * arena_reset() and added to the size the arena gets next time */
+int arena_alloc(kmr_handle *h, void **out, size_t bytes) {
+	const size_t need = (bytes + 255) & ~(size_t)255;
+	if (h->arena && h->arena_used + need <= h->arena_cap) { *out = h->arena + h->arena_used; h->arena_used += need; h->arena_want += need; return 0; }
+	h->arena_want += need;
+	HIPCHK(h, hipMalloc(out, std::max<size_t>(need, 256)));
+	h->arena_overflow.push_back(*out);
+	return 0;
+}
+/* start of a finalize: everything handed out before is dead (the stream is idle) */
+int arena_reset(kmr_handle *h) {
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	for (void *p : h->arena_overflow) hipFree(p);
+	h->arena_overflow.clear();
+	if (h->arena_want > h->arena_cap) {
+		if (h->arena) hipFree(h->arena);
+		h->arena = nullptr; h->arena_cap = 0;
+		const size_t want = h->arena_want + h->arena_want / 8 + (1 << 20);
+		if (hipMalloc((void **)&h->arena, want) == hipSuccess) h->arena_cap = want; else { h->arena = nullptr; (void)hipGetLastError(); }
+	}
+	h->arena_used = 0; h->arena_want = 0;
+	return 0;
+}
+template <class T> int arena_get(kmr_handle *h, T **out, size_t count) { return arena_alloc(h, (void **)out, count * sizeof(T)); }
 
 void free_map(DevMap &m) {
 	if (m.start) hipFree(m.start); if (m.keys) hipFree(m.keys); if (m.vals) hipFree(m.vals);
 	if (m.sweight) hipFree(m.sweight); if (m.spkt) hipFree(m.spkt); if (m.image) hipFree(m.image);
 	m = DevMap();
+}
+
+/* empty the map but keep its buffers */
+void clear_map(DevMap &m) {
+	if (m.image) hipFree(m.image);
+	m.image = nullptr; m.image_bytes = 0; m.n = 0; m.present = false;
+}
+int reserve_bytes(kmr_handle *h, void **ptr, size_t &cap, size_t need) {
+	need = std::max<size_t>(need, 8);
+	if (*ptr && cap >= need) return 0;
+	if (*ptr) hipFree(*ptr);
+	*ptr = nullptr; cap = 0;
+	HIPCHK(h, hipMalloc(ptr, need));
+	cap = need;
+	return 0;
 }
 
 template <int W> MapView<W> view_of(const DevMap &m, uint32_t vw) {
@@ -669,8 +720,11 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	PartSource<W> S; memset(&S, 0, sizeof(S));
 	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
 	S.valid_counter = valid_counter; S.kb = h->kb; S.rot = part_rot(h); S.packed_words = packed_words; S.ordinal_base = ordinal_base;
-	rc = ensure_l1_state<W>(h); if (rc) return rc;
-	S.state = h->l1_state; S.state_final = 0; h->l1_state_dirty = true;
+	static const bool keep_state = !getenv("KMR_NO_L1_STATE");
+	if (keep_state) {
+		rc = ensure_l1_state<W>(h); if (rc) return rc;
+		S.state = h->l1_state; S.state_final = 0; h->l1_state_dirty = true;
+	}
 	hipEvent_t ta, tb; time_begin(h, KMR_TIME_PARTITION1, &ta, &tb);
 	rc = launch_partition<W, 1>(h, S, h->l1, grid, h->bits1, 0);
 	time_end(h, KMR_TIME_PARTITION1, ta, tb);
@@ -769,17 +823,15 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, ui
 	HIPCHK(h, hipMemcpy(&used, p.head, 4, hipMemcpyDeviceToHost));
 	if (used > p.cap) used = p.cap;
 	uint32_t *cnt;
-	HIPCHK(h, hipMalloc((void **)&cnt, 4 * nl)); HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
-	HIPCHK(h, hipMalloc((void **)list_start, 8 * (nl + 1)));
-	HIPCHK(h, hipMalloc((void **)list_chunks, 8ull * std::max<unsigned>(used, 1)));
+	{ int arc = arena_get(h, &cnt, nl); if (arc) return arc; arc = arena_get(h, list_start, nl + 1); if (arc) return arc;
+	  arc = arena_get(h, list_chunks, std::max<unsigned>(used, 1)); if (arc) return arc; }
+	HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
 	const unsigned csr_grid = (unsigned)(((uint64_t)used + CSR_THREADS * CSR_ITEMS - 1) / (CSR_THREADS * CSR_ITEMS));
 	if (used) hipLaunchKernelGGL(chunk_hist_kernel, dim3(csr_grid), dim3(CSR_THREADS), 0, h->stream, p.chunk_list, used, cnt, (uint32_t)nl);
 	int rc = exclusive_scan(h, cnt, nl, *list_start); if (rc) return rc;
 	HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
 	if (used) hipLaunchKernelGGL(chunk_scatter_kernel, dim3(csr_grid), dim3(CSR_THREADS), 0, h->stream, p.chunk_list, p.chunk_count, used, *list_start, cnt, *list_chunks, (uint32_t)nl);
 	HIPCHK(h, hipGetLastError());
-	HIPCHK(h, hipStreamSynchronize(h->stream));
-	hipFree(cnt);
 	*n_chunks_out = used;
 	if (getenv("KMR_DEBUG")) {
 		unsigned long long *d, hv[2] = {0, 0};
@@ -815,6 +867,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	FinalizeParams f; f.kb = h->kb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
+	rc = arena_reset(h); if (rc) return rc;
 	rc = flush_l1_state<W>(h); if (rc) return rc;
 	/* level-1 CSR and level-2 work items */
 	const uint64_t nl1 = 1ull << h->bits1;
@@ -840,12 +893,12 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		unsigned long long *dpr, hpr[2] = {0, 0};
 		const uint32_t n_probes = (uint32_t)std::min<uint64_t>(PROBE_LISTS, nl1);
 		const size_t tbytes = 8 * ((size_t)n_probes * PROBE_SLOTS + 2);
-		HIPCHK(h, hipMalloc((void **)&dpr, tbytes)); HIPCHK(h, hipMemsetAsync(dpr, 0, tbytes, h->stream));
+		rc = arena_alloc(h, (void **)&dpr, tbytes); if (rc) return rc;
+		HIPCHK(h, hipMemsetAsync(dpr, 0, tbytes, h->stream));
 		hipLaunchKernelGGL(distinct_probe_kernel<W>, dim3(n_probes * PROBE_SPLIT), dim3(256), 0, h->stream, pool_view(h, h->l1), ls1, lc1, nl1, h->kb, part_rot(h),
 		                   (int)h->bits1, n_probes, dpr + 2, dpr);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipMemcpyAsync(hpr, dpr, 16, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
-		hipFree(dpr);
 		if (hpr[0] >= 256) distinct_share = std::min(1.0, std::max(0.01, (double)hpr[1] / (double)hpr[0]));
 		if (getenv("KMR_DEBUG")) fprintf(stderr, "distinct probe: %llu records, %llu distinct -> share %.3f\n", hpr[0], hpr[1], distinct_share);
 	}
@@ -858,9 +911,9 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	rc = pool_reserve(h, h->l2, G / CH + ib.size() * (1ull << bits2) + (uint64_t)part_grid(h) * 512 + 64, false); if (rc) return rc;
 	if (!ib.empty()) {
 		uint64_t *dib, *die; uint32_t *dil;
-		HIPCHK(h, hipMalloc((void **)&dib, 8 * ib.size())); HIPCHK(h, hipMalloc((void **)&die, 8 * ie.size())); HIPCHK(h, hipMalloc((void **)&dil, 4 * il.size()));
-		HIPCHK(h, hipMemcpy(dib, ib.data(), 8 * ib.size(), hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(die, ie.data(), 8 * ie.size(), hipMemcpyHostToDevice));
-		HIPCHK(h, hipMemcpy(dil, il.data(), 4 * il.size(), hipMemcpyHostToDevice));
+		rc = arena_get(h, &dib, ib.size()); if (rc) return rc; rc = arena_get(h, &die, ie.size()); if (rc) return rc; rc = arena_get(h, &dil, il.size()); if (rc) return rc;
+		HIPCHK(h, hipMemcpyAsync(dib, ib.data(), 8 * ib.size(), hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipMemcpyAsync(die, ie.data(), 8 * ie.size(), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(h, hipMemcpyAsync(dil, il.data(), 4 * il.size(), hipMemcpyHostToDevice, h->stream));
 		rc = zero_work_counter(h); if (rc) return rc;
 		PartSource<W> S; memset(&S, 0, sizeof(S));
 		S.src = pool_view(h, h->l1); S.list_chunks = lc1; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size(); S.kb = h->kb; S.rot = part_rot(h);
@@ -869,10 +922,8 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		rc = launch_partition<W, 2>(h, S, h->l2, grid, bits2, h->bits1);
 		time_end(h, KMR_TIME_PARTITION2, ta, tb);
 		if (rc) return rc;
-		HIPCHK(h, hipStreamSynchronize(h->stream));
-		hipFree(dib); hipFree(die); hipFree(dil);
+		HIPCHK(h, hipStreamSynchronize(h->stream));      /* the host vectors behind the item copies go out of scope */
 	}
-	hipFree(ls1); hipFree(lc1);
 	/* level-2 CSR, then count every final list */
 	uint64_t *ls2 = nullptr; uint64_t *lc2 = nullptr; uint32_t nch2 = 0;
 	rc = build_csr(h, h->l2, nl2, &ls2, &lc2, &nch2); if (rc) return rc;
@@ -888,7 +939,8 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); h->us_cap = scap;
 	}
 	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr; unsigned long long *cursors = nullptr;
-	HIPCHK(h, hipMalloc((void **)&wc, 4 * h->nb_weak)); HIPCHK(h, hipMalloc((void **)&sc, 4 * h->nb_sing)); HIPCHK(h, hipMalloc((void **)&fc, sizeof(FinalizeCounters))); HIPCHK(h, hipMalloc((void **)&cursors, 16));
+	rc = arena_get(h, &wc, h->nb_weak); if (rc) return rc; rc = arena_get(h, &sc, h->nb_sing); if (rc) return rc;
+	rc = arena_get(h, &fc, 1); if (rc) return rc; rc = arena_get(h, &cursors, 2); if (rc) return rc;
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
 	HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
 	CountOut out; out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wcursor = cursors; out.wcap = h->uw_cap;
@@ -926,13 +978,11 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	FinalizeCounters c; unsigned long long cur[2];
 	HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(cur, cursors, 16, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
-	hipFree(ls2); hipFree(lc2); hipFree(fc); hipFree(cursors);
 	h->stats.unique_kmers = c.unique;
 	h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
 	hipEvent_t tma, tmb; time_begin(h, KMR_TIME_BUCKETS, &tma, &tmb);
 	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing);
 	time_end(h, KMR_TIME_BUCKETS, tma, tmb);
-	hipFree(wc); hipFree(sc);
 	if (rc) return rc;
 	time_end(h, 1, ea, eb);
 	h->has_singletons = keepSing;
@@ -945,14 +995,17 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing) {
 	const uint32_t vw = 3;
 	DevMap &wm = h->weak, &sm = h->sing;
-	free_map(wm); free_map(sm);
+	clear_map(wm); clear_map(sm);          /* the buffers of the previous build are reused when they are large enough */
 	wm.nb = h->nb_weak; wm.n = wn; wm.present = true;
 	sm.nb = h->nb_sing; sm.n = keepSing ? sn : 0; sm.present = keepSing;
-	HIPCHK(h, hipMalloc((void **)&wm.start, 8 * (wm.nb + 1))); HIPCHK(h, hipMalloc((void **)&sm.start, 8 * (sm.nb + 1)));
-	int rc = exclusive_scan(h, wc, wm.nb, wm.start); if (rc) return rc;
+	int rc = reserve_bytes(h, (void **)&wm.start, wm.c_start, 8 * (wm.nb + 1)); if (rc) return rc;
+	rc = reserve_bytes(h, (void **)&sm.start, sm.c_start, 8 * (sm.nb + 1)); if (rc) return rc;
+	rc = exclusive_scan(h, wc, wm.nb, wm.start); if (rc) return rc;
 	rc = exclusive_scan(h, sc, sm.nb, sm.start); if (rc) return rc;
-	HIPCHK(h, hipMalloc((void **)&wm.keys, std::max<uint64_t>(8, 8ull * W * wm.n))); HIPCHK(h, hipMalloc((void **)&wm.vals, std::max<uint64_t>(8, 4ull * vw * wm.n)));
-	HIPCHK(h, hipMalloc((void **)&sm.keys, std::max<uint64_t>(8, 8ull * W * sm.n))); HIPCHK(h, hipMalloc((void **)&sm.sweight, std::max<uint64_t>(8, sm.n)));
+	rc = reserve_bytes(h, (void **)&wm.keys, wm.c_keys, 8ull * W * wm.n); if (rc) return rc;
+	rc = reserve_bytes(h, (void **)&wm.vals, wm.c_vals, 4ull * vw * wm.n); if (rc) return rc;
+	rc = reserve_bytes(h, (void **)&sm.keys, sm.c_keys, 8ull * W * sm.n); if (rc) return rc;
+	rc = reserve_bytes(h, (void **)&sm.sweight, sm.c_sw, sm.n); if (rc) return rc;
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * sm.nb, h->stream));
 	if (wm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
 	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->kb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
@@ -993,6 +1046,9 @@ int insert_records_partition(kmr_handle *h, const void *recs, uint64_t n) {
 void free_partition_state(kmr_handle *h) {
 	pool_free(h->l1); pool_free(h->l2);
 	if (h->l1_state) hipFree(h->l1_state); h->l1_state = nullptr; h->l1_state_bytes = 0; h->l1_state_dirty = false;
+	for (void *p : h->arena_overflow) hipFree(p);
+	h->arena_overflow.clear();
+	if (h->arena) hipFree(h->arena); h->arena = nullptr; h->arena_cap = h->arena_used = h->arena_want = 0;
 	if (h->work_counter) hipFree(h->work_counter); if (h->linear) hipFree(h->linear); if (h->tile_count) hipFree(h->tile_count);
 	if (h->kcap) hipFree(h->kcap); if (h->koff) hipFree(h->koff);
 	if (h->ucnt) hipFree(h->ucnt); if (h->ufirst) hipFree(h->ufirst); if (h->u_start) { hipFree(h->u_start); hipFree(h->u_end); hipFree(h->u_read); } if (h->umax) hipFree(h->umax);
@@ -1079,6 +1135,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->dP) hipFree(h->dP); if (h->dstats) hipFree(h->dstats); if (h->derr) hipFree(h->derr);
 	free_map(h->weak); free_map(h->sing);
 	free_partition_state(h);
+	if (h->scan_sums) hipFree(h->scan_sums);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -1097,7 +1154,7 @@ int kmr_reset(kmr_handle *h) {
 	if (!h) return KMR_ERR_INVALID_ARG;
 	hipSetDevice(h->device);
 	HIPCHK(h, hipStreamSynchronize(h->stream));
-	free_map(h->weak); free_map(h->sing);
+	clear_map(h->weak); clear_map(h->sing);      /* empty maps, allocations kept (reset(false)) */
 	int rc = 0;
 	if (h->partition_mode) {
 		if (h->l1.head) HIPCHK(h, hipMemsetAsync(h->l1.head, 0, 4, h->stream));
@@ -1610,7 +1667,7 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
                              uint64_t total_bases, uint64_t first_global_read_idx, const void *dev_discarded,
                              void *dev_records, uint64_t seg_capacity, void *dev_seg_counts) {
 	if (!h || !dev_bases || !dev_offsets || !dev_records || !dev_seg_counts) return KMR_ERR_INVALID_ARG;
-	if (h->cfg.world_size > (uint32_t)RECORD_MAX_OWNERS) return fail(h, KMR_ERR_UNSUPPORTED, "owner exchange supports up to 8 ranks per node");
+	if (h->cfg.world_size > (uint32_t)OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "owner exchange supports up to 8 ranks per node");
 	hipSetDevice(h->device);
 	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
 	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;

@@ -9,8 +9,8 @@
  *         src/KmerReadUtils.h:176, KmerHasher::getHash src/Kmer.h:207]
  *     Op = InsertOp   open-addressed insert/increment  [KmerSpectrum::append
  *                     src/KmerSpectrum.h:1578 + track() src/KmerTrackingData.h:427,517,641]
- *     Op = RecordOp   bin (key, signed weight, ext) records by owner
- *                     [_buildKmerSpectrumMPI sender side src/DistributedFunctions.h:418-438]
+ *     Op = LinearOp   compacted linear records (kmr_partition.hpp); with owner_scatter_kernel the sender side of
+ *                     the exchange [_buildKmerSpectrumMPI src/DistributedFunctions.h:418-438]
  *     Op = LookupOp   per-position count lookup [ReadSelector::setKmerValues
  *                     src/ReadSelector.h:1064-1076]
  *  insert_records_kernel      records -> table  [StoreKmerMessageHeaderProcessor::process :323]
@@ -290,70 +290,6 @@ template <int W> struct Record {
 	uint32_t pkt;
 };
 
-/* Sender side of the owner exchange.  Every wavefront keeps, per owner, a private run [pos, end) of the
- * owner's segment and takes a new run of RSLAB records with ONE device atomic when it is used up (a per-emit
- * atomic on `world` counters would serialise: one word serves ~90 M atomics/s).  The slots a wavefront leaves
- * unused are written as holes (weight 0: no valid record has that), which the receiver skips. */
-static const int RECORD_MAX_OWNERS = 8;
-static const uint32_t RSLAB = 512;
-template <int W, bool EXT> struct RecordOp {
-	Record<W> *records;
-	unsigned long long *seg_counts;   /* [world]: slots handed out per owner (valid records + holes) */
-	uint64_t seg_capacity;
-	uint32_t world;
-	static const bool NEEDS_WEIGHT = true;
-	static const bool COUNTS_STATS = false;
-	static const bool NEEDS_HASH = true;
-	struct State { unsigned long long pos[RECORD_MAX_OWNERS], end[RECORD_MAX_OWNERS]; };
-	__device__ __forceinline__ void wave_begin(State &st, int) const {
-#pragma unroll
-		for (int o = 0; o < RECORD_MAX_OWNERS; o++) { st.pos[o] = 0; st.end[o] = 0; }
-	}
-	__device__ __forceinline__ void tile_begin(State &, uint32_t *, uint64_t, int) const {}
-	__device__ __forceinline__ void tile_end(State &, uint64_t, int) const {}
-	__device__ __forceinline__ void wave_end(State &st, int lane) const {
-#pragma unroll
-		for (int o = 0; o < RECORD_MAX_OWNERS; o++) {
-			if ((uint32_t)o >= world) continue;
-			for (unsigned long long e = st.pos[o] + lane; e < st.end[o]; e += 64) {
-				if (e < seg_capacity) { Record<W> r; for (int i = 0; i < W; i++) r.key[i] = 0; r.w = 0.0f; r.pkt = 0; records[(uint64_t)o * seg_capacity + e] = r; }
-			}
-		}
-	}
-	/* called by all lanes under uniform control flow */
-	__device__ __forceinline__ void emit(State &st, bool valid, const DevParams &p, const Key<W> &key, uint64_t hash, const Occurrence &o,
-	                                     uint64_t, uint32_t, unsigned &, bool &fail) const {
-		const uint32_t owner = valid ? distributed_thread_id(hash, p.world) : 0xffffffffu;
-		const int lane = (int)(threadIdx.x & 63);
-		unsigned long long mypos = ~0ull;
-#pragma unroll
-		for (int ow = 0; ow < RECORD_MAX_OWNERS; ow++) {
-			if ((uint32_t)ow >= world) continue;              /* wave-uniform */
-			const unsigned long long m = __ballot(owner == (uint32_t)ow);
-			const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
-			if (cnt == 0) continue;
-			if (st.pos[ow] + cnt > st.end[ow]) {               /* run exhausted: retire its tail as holes, take a new one */
-				for (unsigned long long e = st.pos[ow] + lane; e < st.end[ow]; e += 64)
-					if (e < seg_capacity) { Record<W> r; for (int i = 0; i < W; i++) r.key[i] = 0; r.w = 0.0f; r.pkt = 0; records[(uint64_t)ow * seg_capacity + e] = r; }
-				unsigned long long base = 0;
-				if (lane == 0) base = atomicAdd(&seg_counts[ow], (unsigned long long)RSLAB);
-				base = __shfl(base, 0, 64);
-				st.pos[ow] = base; st.end[ow] = base + RSLAB;
-			}
-			if (owner == (uint32_t)ow) mypos = st.pos[ow] + (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1));
-			st.pos[ow] += cnt;
-		}
-		if (!valid) return;
-		if (mypos >= seg_capacity) { fail = true; return; }
-		Record<W> r;
-#pragma unroll
-		for (int i = 0; i < W; i++) r.key[i] = key.w[i];
-		r.w = o.forward ? o.w : -o.w;
-		r.pkt = EXT ? o.pkt : (uint32_t)o.ordinal;
-		records[(uint64_t)owner * seg_capacity + mypos] = r;
-	}
-};
-
 /* ----------------------------------------------------------------------- */
 /* finalized map on the device: bucketed, keys sorted inside each bucket      */
 template <int W> struct MapView {
@@ -427,7 +363,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 	const bool needHash = Op::NEEDS_HASH || p.subsample > 1 || p.world > 1 || p.num_parts > 1 || haveSub;
 	unsigned long long nSub = 0;
 	/* a wavefront walks tiles tile0, tile0 + stride, ... (stride = all wavefronts of the grid): with a full grid
-	 * that is one tile each; Ops that keep per-wavefront state (RecordOp's owner slabs) launch fewer blocks */
+	 * that is one tile each */
 	const uint64_t n_items = rv.u_start ? rv.n_units : rv.n_reads;
 	const uint64_t n_tiles = (n_items + 63) / 64;
 	for (uint64_t tile = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
@@ -693,9 +629,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 }
 
 template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const InsertOp<W, EXT> &) { return false; }
-template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const RecordOp<W, EXT> &) { return true; }
 template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const InsertOp<W, EXT> &) { return ERR_TABLE_FULL; }
-template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const RecordOp<W, EXT> &) { return ERR_SEGMENT_OVERFLOW; }
 
 template <int W> struct LookupOp {
 	MapView<W> weak, sing;

@@ -59,6 +59,14 @@ template <int W> __host__ __device__ __forceinline__ uint64_t part_hash(const ui
 	for (int i = 1; i < W; i++) h = mix64(h ^ (key[i] * 0x9E3779B97F4A7C15ull));
 	return h;
 }
+/* slot hash of the count pass: one multiply per key word (Fibonacci hashing); the table slot comes from the top bits, the
+ * sub-pass selector from bits 20..39 (the low bits of a product only see the low bits of the key, and those are pad) */
+template <int W> __host__ __device__ __forceinline__ uint64_t slot_hash(const uint64_t *key) {
+	uint64_t h = key[0] * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+	for (int i = 1; i < W; i++) h = (h ^ (h >> 31)) * 0xD6E8FEB86659FD93ull + key[i] * 0x9E3779B97F4A7C15ull;
+	return h;
+}
 /* Partition order of a k-mer: the reference's bucket hash (KmerHasher, lookup3) rotated so that the bucket index
  * of the weak map, h & (NB - 1) with NB = 2^rot, becomes the most significant bits.  Lists are cut from the top
  * bits of this value, so a final list is a contiguous range of buckets (or, with more lists than buckets, a bucket
@@ -796,9 +804,9 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 				uint64_t seen[UNR];          /* W == 1: key read from the home slot */
 #pragma unroll
 				for (int u = 0; u < UNR; u++) {
-					const uint64_t h = part_hash<W>(rr[u].key);
-					const bool mine = rr[u].w != 0.0f && ((uint32_t)h & subMask) == val;
-					slot[u] = mine ? (uint32_t)(h >> 20) & (S - 1) : NO_SLOT;
+					const uint64_t h = slot_hash<W>(rr[u].key);
+					const bool mine = rr[u].w != 0.0f && ((uint32_t)(h >> 20) & subMask) == val;
+					slot[u] = mine ? (uint32_t)(h >> (64 - LOG2S)) : NO_SLOT;
 					seen[u] = 0;
 					if constexpr (W == 1) if (mine) seen[u] = tkeys[slot[u]];
 				}
