@@ -98,7 +98,8 @@ __global__ void unit_count_kernel(const uint64_t *offsets, uint64_t n, uint32_t 
 	}
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
-	if ((threadIdx.x & 63) == 0 && mx) atomicMax(maxLen, mx);
+	/* one word serves ~90 M atomics/s: only a wavefront that would raise the maximum it can see touches it */
+	if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(maxLen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxLen, mx);
 }
 __global__ void unit_fill_kernel(const uint64_t *offsets, uint64_t n, uint32_t k, uint32_t span, const uint64_t *ufirst,
                                  uint64_t *u_start, uint64_t *u_end, uint64_t *u_read) {
