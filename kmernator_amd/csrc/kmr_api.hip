@@ -592,7 +592,7 @@ static uint64_t target_list_records() { static const uint64_t v = getenv("KMR_TA
 #define TARGET_LIST_RECORDS (target_list_records())
 const double MAX_LIST_DISTINCT = 600.0;       /* distinct keys per final list the 1024-slot table takes comfortably (limit 819) */
 const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
-const uint64_t SUB_BATCH_BASES = 1ull << 28;
+const uint64_t SUB_BATCH_BASES = 1ull << 30;      /* linear records of one sub-batch: <= 17 GB at 16 bytes; 2^28 cost 2 ms per C2 step in launch tails */
 
 size_t rec_bytes(kmr_handle *h) { return 8 * h->W + 8; }
 /* partition kernel shape: one 1024-thread block per compute unit, 8 records per thread per batch, a
