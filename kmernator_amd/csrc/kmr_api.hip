@@ -711,6 +711,17 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	if (!h->l1.base) {
 		const uint64_t est = std::max<uint64_t>(max_records, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
 		const uint64_t launches = est / std::max<uint64_t>(1, max_records) + 2;
+		{	/* what only kmr_finalize uses (level-2 pool, entry buffers) is dead during a build: released if the level-1
+			 * pool would not fit beside it (a handle rebuilt at C4 size: each pool is 120 GB) */
+			const uint64_t chunks = est / CH + launches * (uint64_t)grid * ((1ull << h->bits1) + 512) + 64;
+			size_t mfree = 0, mtotal = 0;
+			if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)mfree < (double)chunks * CH * rec_bytes(h) * 1.02 + (double)(2ull << 30)) {
+				HIPCHK(h, hipStreamSynchronize(h->stream));
+				pool_free(h->l2);
+				if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8);
+				h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = nullptr; h->uw_cap = h->us_cap = 0;
+			}
+		}
 		int rc0 = pool_reserve(h, h->l1, est / CH + launches * (uint64_t)grid * ((1ull << h->bits1) + 512) + 64, true);
 		if (rc0) return rc0;
 	}
@@ -888,19 +899,19 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	 * on a sample of level-1 lists, then take enough level-2 bits for ~MAX_LIST_DISTINCT distinct keys per list (and
 	 * at most TARGET_LIST_RECORDS records); if the bits run out the count pass uses its 2048-slot table, and beyond
 	 * that its sub-passes. */
-	double distinct_share = 1.0;
+	double distinct_share = 1.0, repeated_share = 0.5;      /* distinct keys, and distinct keys seen more than once, per record */
 	if (G) {
-		unsigned long long *dpr, hpr[2] = {0, 0};
+		unsigned long long *dpr, hpr[4] = {0, 0, 0, 0};
 		const uint32_t n_probes = (uint32_t)std::min<uint64_t>(PROBE_LISTS, nl1);
-		const size_t tbytes = 8 * ((size_t)n_probes * PROBE_SLOTS + 2);
+		const size_t tbytes = 8 * ((size_t)n_probes * PROBE_SLOTS + 4);
 		rc = arena_alloc(h, (void **)&dpr, tbytes); if (rc) return rc;
 		HIPCHK(h, hipMemsetAsync(dpr, 0, tbytes, h->stream));
 		hipLaunchKernelGGL(distinct_probe_kernel<W>, dim3(n_probes * PROBE_SPLIT), dim3(256), 0, h->stream, pool_view(h, h->l1), ls1, lc1, nl1, h->kb, part_rot(h),
-		                   (int)h->bits1, n_probes, dpr + 2, dpr);
+		                   (int)h->bits1, n_probes, dpr + 4, dpr);
 		HIPCHK(h, hipGetLastError());
-		HIPCHK(h, hipMemcpyAsync(hpr, dpr, 16, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
-		if (hpr[0] >= 256) distinct_share = std::min(1.0, std::max(0.01, (double)hpr[1] / (double)hpr[0]));
-		if (getenv("KMR_DEBUG")) fprintf(stderr, "distinct probe: %llu records, %llu distinct -> share %.3f\n", hpr[0], hpr[1], distinct_share);
+		HIPCHK(h, hipMemcpyAsync(hpr, dpr, 32, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
+		if (hpr[0] >= 256) { distinct_share = std::min(1.0, std::max(0.01, (double)hpr[1] / (double)hpr[0])); repeated_share = std::min(0.5, (double)hpr[2] / (double)hpr[0]); }
+		if (getenv("KMR_DEBUG")) fprintf(stderr, "distinct probe: %llu records, %llu distinct (%llu repeated) -> shares %.3f %.3f\n", hpr[0], hpr[1], hpr[2], distinct_share, repeated_share);
 	}
 	const int mb = max_part_bits(W);
 	int T = 0; while (T < h->bits1 + mb && ((G >> T) > TARGET_LIST_RECORDS || (double)(G >> T) * distinct_share > MAX_LIST_DISTINCT)) T++;
@@ -908,6 +919,14 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	const uint64_t nl2 = 1ull << (h->bits1 + bits2);
 	const int count_log2s = (double)(G >> (h->bits1 + bits2)) * distinct_share > MAX_LIST_DISTINCT ? 11 : COUNT_LOG2S;
 	if (getenv("KMR_DEBUG")) fprintf(stderr, "count pass: %llu lists of ~%llu records, table 2^%d\n", (unsigned long long)nl2, (unsigned long long)(G >> (h->bits1 + bits2)), count_log2s);
+	{	/* the linear record buffer is dead from here on: give it back if the level-2 pool would not fit beside it */
+		const uint64_t l2_chunks = G / CH + ib.size() * (1ull << bits2) + (uint64_t)part_grid(h) * 512 + 64;
+		size_t mfree = 0, mtotal = 0;
+		if (l2_chunks > h->l2.cap && h->linear && hipMemGetInfo(&mfree, &mtotal) == hipSuccess &&
+		    (double)mfree < (double)l2_chunks * CH * rec_bytes(h) * 1.02 + 8.0 * l2_chunks + (double)(1ull << 30)) {
+			hipFree(h->linear); h->linear = nullptr; h->linear_cap = 0;
+		}
+	}
 	rc = pool_reserve(h, h->l2, G / CH + ib.size() * (1ull << bits2) + (uint64_t)part_grid(h) * 512 + 64, false); if (rc) return rc;
 	if (!ib.empty()) {
 		uint64_t *dib, *die; uint32_t *dil;
@@ -929,7 +948,36 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	rc = build_csr(h, h->l2, nl2, &ls2, &lc2, &nch2); if (rc) return rc;
 	const uint32_t vw = 3;
 	const uint64_t slack = (uint64_t)part_grid(h) * 8 * 8192 + 16;     /* one partly used output slab per block */
-	const uint64_t wcap = (f.has_singletons ? G / 2 : G) + slack, scap = keepSing ? G + slack : 16;
+	/* entry buffers: the worst case (every second record a weak entry, or every record a singleton) is 5-10 x what
+	 * sequencing data produces, and at C4 size it is 70 GB; they are sized from the probe's shares with 50 % headroom and
+	 * the count pass is simply run again with larger ones if that was not enough */
+	const uint64_t wmax = (f.has_singletons ? G / 2 : G) + slack, smax = keepSing ? G + slack : 16;
+	uint64_t wcap = std::min<uint64_t>(wmax, (uint64_t)((double)G * (f.has_singletons ? repeated_share : distinct_share) * 1.5) + G / 64 + slack);
+	uint64_t scap = keepSing ? std::min<uint64_t>(smax, (uint64_t)((double)G * std::max(0.0, distinct_share - repeated_share) * 1.5) + G / 64 + slack) : 16;
+	if (getenv("KMR_ENTRY_SHARE")) {       /* test hook: start from a hopeless estimate so that the retry below has to run */
+		const double sh = atof(getenv("KMR_ENTRY_SHARE"));
+		wcap = std::min<uint64_t>(wmax, (uint64_t)((double)G * sh) + 16384); if (keepSing) scap = std::min<uint64_t>(smax, (uint64_t)((double)G * sh) + 16384);
+		if (h->uw_keys) { hipFree(h->uw_keys); hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0; }
+		if (h->us_keys) { hipFree(h->us_keys); hipFree(h->us_b8); h->us_keys = h->us_b8 = nullptr; h->us_cap = 0; }
+	}
+	if (h->uw_keys && h->uw_cap >= wcap) wcap = h->uw_cap;
+	if (h->us_keys && h->us_cap >= scap) scap = h->us_cap;
+	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr; unsigned long long *cursors = nullptr;
+	rc = arena_get(h, &wc, h->nb_weak); if (rc) return rc; rc = arena_get(h, &sc, h->nb_sing); if (rc) return rc;
+	rc = arena_get(h, &fc, 1); if (rc) return rc; rc = arena_get(h, &cursors, 2); if (rc) return rc;
+	FinalizeCounters c; unsigned long long cur[2];
+	hipEvent_t tca, tcb; time_begin(h, KMR_TIME_COUNT, &tca, &tcb);
+	for (int attempt = 0; ; attempt++) {
+	{	/* the level-1 pool is dead after the level-2 pass: released when the entry buffers would not fit beside it
+		 * (C4: 5 x 10^9 two-word records make both pools 120 GB each); the next build of the handle allocates it again */
+		const double need = (!h->uw_keys || h->uw_cap < wcap ? (8.0 * W + 4.0 * vw) * (double)wcap : 0.0) + (!h->us_keys || h->us_cap < scap ? (8.0 * W + 1.0) * (double)scap : 0.0);
+		size_t mfree = 0, mtotal = 0;
+		if (need > 0 && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)mfree < need + (double)G * 0.6 * (8.0 * W + 12.0) + (double)(2ull << 30)) {
+			HIPCHK(h, hipStreamSynchronize(h->stream));
+			if (h->linear) { hipFree(h->linear); h->linear = nullptr; h->linear_cap = 0; }
+			pool_free(h->l1);
+		}
+	}
 	if (!h->uw_keys || h->uw_cap < wcap) {
 		if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
 		HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, hipMalloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
@@ -938,9 +986,6 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); h->us_keys = h->us_b8 = nullptr; h->us_cap = 0;
 		HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); h->us_cap = scap;
 	}
-	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr; unsigned long long *cursors = nullptr;
-	rc = arena_get(h, &wc, h->nb_weak); if (rc) return rc; rc = arena_get(h, &sc, h->nb_sing); if (rc) return rc;
-	rc = arena_get(h, &fc, 1); if (rc) return rc; rc = arena_get(h, &cursors, 2); if (rc) return rc;
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
 	HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
 	CountOut out; out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wcursor = cursors; out.wcap = h->uw_cap;
@@ -948,7 +993,6 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
 	rc = zero_work_counter(h); if (rc) return rc;
 	const int count_reps = getenv("KMR_COUNT_CHECK") ? atoi(getenv("KMR_COUNT_CHECK")) : 0;
-	hipEvent_t tca, tcb; time_begin(h, KMR_TIME_COUNT, &tca, &tcb);
 	for (int cr = 0; cr <= count_reps; cr++) {
 		if (cr) {      /* debugging aid: the count pass is repeated on the same input and must report the same numbers */
 			FinalizeCounters c0; unsigned long long cur0[2];
@@ -974,10 +1018,19 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		}
 		HIPCHK(h, hipGetLastError());
 	}
-	time_end(h, KMR_TIME_COUNT, tca, tcb);
-	FinalizeCounters c; unsigned long long cur[2];
+	uint32_t cerr = 0;
 	HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(cur, cursors, 16, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipMemcpyAsync(&cerr, h->derr, 4, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
+	if (!(cerr & ERR_ENTRIES_FULL) || (wcap >= wmax && scap >= smax) || attempt >= 8) break;
+	/* more kept entries than the probe promised: larger buffers, same pass again */
+	cerr &= ~(uint32_t)ERR_ENTRIES_FULL;
+	HIPCHK(h, hipMemcpy(h->derr, &cerr, 4, hipMemcpyHostToDevice));
+	wcap = std::min<uint64_t>(wmax, wcap * 2); if (keepSing) scap = std::min<uint64_t>(smax, scap * 2);
+	if (getenv("KMR_DEBUG")) fprintf(stderr, "count pass: entry buffers too small, retrying with %llu / %llu\n", (unsigned long long)wcap, (unsigned long long)scap);
+	}
+	time_end(h, KMR_TIME_COUNT, tca, tcb);
+
 	h->stats.unique_kmers = c.unique;
 	h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
 	hipEvent_t tma, tmb; time_begin(h, KMR_TIME_BUCKETS, &tma, &tmb);

@@ -600,7 +600,7 @@ __global__ void pool_records_kernel(const uint32_t *chunk_list, const uint32_t *
  * copies all have the same partition order, so the PROBE_SPLIT blocks of probe p scan ONE level-1 list and keep the
  * records whose next `sel` order bits are zero -- the records one would-be final list would receive, all copies
  * included -- and count them and their distinct 64-bit fingerprints in a small table in device memory (few records
- * pass the filter, so its atomics are few).  out[0] += records, out[1] += distinct. */
+ * pass the filter, so its atomics are few).  out[0] += records, out[1] += distinct, out[2] += distinct keys seen more than once. */
 static const int PROBE_SLOTS = 8192, PROBE_SPLIT = 16, PROBE_LISTS = 64;
 template <int W>
 __global__ __launch_bounds__(256)
@@ -613,7 +613,7 @@ void distinct_probe_kernel(PoolView pool, const uint64_t *list_start, const uint
 	unsigned long long *fp = tables + (size_t)p * PROBE_SLOTS;
 	/* about 2000 records of the list pass the filter */
 	int sel = 0; while (sel < 40 - bits1 && (((c1 - c0) * CH) >> sel) > 2000) sel++;
-	unsigned long long mine = 0, fresh = 0;
+	unsigned long long mine = 0, fresh = 0, again = 0;
 	constexpr int UNR = 4;
 	const uint64_t nw = (uint64_t)(blockDim.x >> 6) * PROBE_SPLIT;
 	for (uint64_t cb = c0 + (uint64_t)part * (blockDim.x >> 6) + (threadIdx.x >> 6); cb < c1; cb += nw * UNR) {
@@ -631,18 +631,19 @@ void distinct_probe_kernel(PoolView pool, const uint64_t *list_start, const uint
 			const uint64_t g = part_order<W>(r[u].key, kb, rot);
 			if (sel && ((g << bits1) >> (64 - sel)) != 0) continue;
 			mine++;
-			const unsigned long long f = part_hash<W>(r[u].key) | 1ull;
+			/* bit 0: slot taken, bit 1: the fingerprint has been seen again (counted once: the key will be a weak entry) */
+			const unsigned long long f = (part_hash<W>(r[u].key) & ~3ull) | 1ull;
 			uint32_t s = (uint32_t)(f >> 40) & (PROBE_SLOTS - 1);
 			for (int probe = 0; probe < PROBE_SLOTS; probe++) {
 				const unsigned long long old = atomicCAS(&fp[s], 0ull, f);
 				if (old == 0ull) { fresh++; break; }
-				if (old == f) break;
+				if ((old & ~2ull) == f) { if (!(old & 2ull) && !(atomicOr(&fp[s], 2ull) & 2ull)) again++; break; }
 				s = (s + 1) & (PROBE_SLOTS - 1);
 			}
 		}
 	}
-	mine = wave_sum(mine); fresh = wave_sum(fresh);
-	if ((threadIdx.x & 63) == 0) { if (mine) atomicAdd(&out[0], mine); if (fresh) atomicAdd(&out[1], fresh); }
+	mine = wave_sum(mine); fresh = wave_sum(fresh); again = wave_sum(again);
+	if ((threadIdx.x & 63) == 0) { if (mine) atomicAdd(&out[0], mine); if (fresh) atomicAdd(&out[1], fresh); if (again) atomicAdd(&out[2], again); }
 }
 
 /* debugging aid (KMR_DEBUG): walk a pool through its chunk CSR; count the records and those whose partition hash

@@ -239,6 +239,18 @@ def test_histogram():
     assert np.allclose(wo, wp, rtol=1e-3, atol=1.0)
 
 
+@pytest.mark.parametrize("min_depth", [1, 2])
+def test_entry_buffers_grow_when_the_estimate_was_too_small(min_depth, monkeypatch):
+    """The count pass writes kept entries into buffers sized from a sampled share of repeated keys; if they overflow the
+    pass is run again with larger ones (here the estimate is forced to almost nothing)."""
+    monkeypatch.setenv("KMR_ENTRY_SHARE", "0.00001")
+    rb = synth_reads(40000, read_len=100, seed=23, quality="noisy")
+    cfg = default_config(31, estimated_raw_kmers=40000 * 70)
+    o, p = run_both(cfg, rb, min_depth=min_depth, mode=2)
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+
+
 @pytest.mark.parametrize("k", [31, 51])
 def test_many_sub_batches_keep_level1_state(k, monkeypatch):
     """A build cut into ~60 sub-batches (level-1 partition state carried from launch to launch, flushed once at finalize)
