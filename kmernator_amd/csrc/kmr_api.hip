@@ -588,7 +588,7 @@ int stage_reads(kmr_handle *h, const char *bases, const char *quals, const uint6
 /* ---------------------------------------------------------------------- */
 /* streaming build path (kmr_partition.hpp)                                  */
 const int COUNT_LOG2S = 10;                  /* 1024-slot LDS table per final list (expected ~350 distinct keys) */
-static uint64_t target_list_records() { static const uint64_t v = getenv("KMR_TARGET_LIST") ? strtoull(getenv("KMR_TARGET_LIST"), nullptr, 10) : 2048; return v; }   /* records per final list the partition bits aim for */
+static uint64_t target_list_records() { const char *e = getenv("KMR_TARGET_LIST"); return e ? strtoull(e, nullptr, 10) : 2048; }   /* records per final list the partition bits aim for */
 #define TARGET_LIST_RECORDS (target_list_records())
 const double MAX_LIST_DISTINCT = 600.0;       /* distinct keys per final list the 1024-slot table takes comfortably (limit 819) */
 const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
@@ -711,18 +711,24 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	if (!h->l1.base) {
 		const uint64_t est = std::max<uint64_t>(max_records, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
 		const uint64_t launches = est / std::max<uint64_t>(1, max_records) + 2;
-		{	/* what only kmr_finalize uses (level-2 pool, entry buffers) is dead during a build: released if the level-1
-			 * pool would not fit beside it (a handle rebuilt at C4 size: each pool is 120 GB) */
-			const uint64_t chunks = est / CH + launches * (uint64_t)grid * ((1ull << h->bits1) + 512) + 64;
+		/* level 2 writes into the same pool (it recycles the chunks it reads): room for its partly filled chunks */
+		const uint64_t l2_allowance = (est / CH / L2_ITEM_CHUNKS + (1ull << h->bits1) + 1) * (1ull << max_part_bits(h->W)) + (uint64_t)part_grid(h) * 512;
+		{	/* what only kmr_finalize uses (entry buffers) is dead during a build: released if the pool would not fit beside it */
+			const uint64_t chunks = est / CH + launches * (uint64_t)grid * ((1ull << h->bits1) + 512) + 64 + l2_allowance;
 			size_t mfree = 0, mtotal = 0;
 			if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)mfree < (double)chunks * CH * rec_bytes(h) * 1.02 + (double)(2ull << 30)) {
 				HIPCHK(h, hipStreamSynchronize(h->stream));
-				pool_free(h->l2);
 				if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8);
 				h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = nullptr; h->uw_cap = h->us_cap = 0;
 			}
 		}
-		int rc0 = pool_reserve(h, h->l1, est / CH + launches * (uint64_t)grid * ((1ull << h->bits1) + 512) + 64, true);
+		uint64_t want = est / CH + launches * (uint64_t)grid * ((1ull << h->bits1) + 512) + 64 + l2_allowance;
+		{	/* with room to spare the pool takes a second copy of the records, so that level 2 can append fresh chunks */
+			size_t mfree = 0, mtotal = 0;
+			const double twice = (double)(want + est / CH) * CH * rec_bytes(h) * 1.02;
+			if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && twice + (double)(8ull << 30) < (double)mfree * 0.5) want += est / CH;
+		}
+		int rc0 = pool_reserve(h, h->l1, want, true);
 		if (rc0) return rc0;
 	}
 	int rc = pool_reserve(h, h->l1, max_records / CH + (uint64_t)grid * ((1ull << h->bits1) + 512) + 64, true);
@@ -828,20 +834,21 @@ int add_reads_partition(kmr_handle *h, const ReadsView &rv, uint64_t total_bases
 }
 
 /* chunk CSR of a pool: list_start[nl+1] (device) and list_chunks[n_chunks] (device) */
-int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint64_t **list_start, uint64_t **list_chunks, uint32_t *n_chunks_out) {
+int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint32_t first, uint64_t **list_start, uint64_t **list_chunks, uint32_t *n_chunks_out) {
 	unsigned int used = 0;
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	HIPCHK(h, hipMemcpy(&used, p.head, 4, hipMemcpyDeviceToHost));
 	if (used > p.cap) used = p.cap;
+	used = used > first ? used - first : 0;            /* only chunks [first, head) are looked at */
 	uint32_t *cnt;
 	{ int arc = arena_get(h, &cnt, nl); if (arc) return arc; arc = arena_get(h, list_start, nl + 1); if (arc) return arc;
 	  arc = arena_get(h, list_chunks, std::max<unsigned>(used, 1)); if (arc) return arc; }
 	HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
 	const unsigned csr_grid = (unsigned)(((uint64_t)used + CSR_THREADS * CSR_ITEMS - 1) / (CSR_THREADS * CSR_ITEMS));
-	if (used) hipLaunchKernelGGL(chunk_hist_kernel, dim3(csr_grid), dim3(CSR_THREADS), 0, h->stream, p.chunk_list, used, cnt, (uint32_t)nl);
+	if (used) hipLaunchKernelGGL(chunk_hist_kernel, dim3(csr_grid), dim3(CSR_THREADS), 0, h->stream, p.chunk_list + first, used, cnt, (uint32_t)nl);
 	int rc = exclusive_scan(h, cnt, nl, *list_start); if (rc) return rc;
 	HIPCHK(h, hipMemsetAsync(cnt, 0, 4 * nl, h->stream));
-	if (used) hipLaunchKernelGGL(chunk_scatter_kernel, dim3(csr_grid), dim3(CSR_THREADS), 0, h->stream, p.chunk_list, p.chunk_count, used, *list_start, cnt, *list_chunks, (uint32_t)nl);
+	if (used) hipLaunchKernelGGL(chunk_scatter_kernel, dim3(csr_grid), dim3(CSR_THREADS), 0, h->stream, p.chunk_list + first, p.chunk_count + first, used, first, *list_start, cnt, *list_chunks, (uint32_t)nl);
 	HIPCHK(h, hipGetLastError());
 	*n_chunks_out = used;
 	if (getenv("KMR_DEBUG")) {
@@ -880,25 +887,14 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
 	rc = arena_reset(h); if (rc) return rc;
 	rc = flush_l1_state<W>(h); if (rc) return rc;
-	/* level-1 CSR and level-2 work items */
+	/* level-1 CSR */
 	const uint64_t nl1 = 1ull << h->bits1;
 	uint64_t *ls1 = nullptr; uint64_t *lc1 = nullptr; uint32_t nch1 = 0;
-	rc = build_csr(h, h->l1, nl1, &ls1, &lc1, &nch1); if (rc) return rc;
-	std::vector<uint64_t> hs(nl1 + 1);
-	HIPCHK(h, hipMemcpy(hs.data(), ls1, 8 * (nl1 + 1), hipMemcpyDeviceToHost));
-	std::vector<uint64_t> ib, ie; std::vector<uint32_t> il;
-	for (uint64_t l = 0; l < nl1; l++) {
-		/* a list longer than one work item is cut into equal items (every item ends with a flush of partly filled chunks,
-		 * and a short leftover item would cost as many of those as a full one) */
-		const uint64_t nch = hs[l + 1] - hs[l];
-		if (!nch) continue;
-		const uint64_t nit = (nch + L2_ITEM_CHUNKS - 1) / L2_ITEM_CHUNKS, per = (nch + nit - 1) / nit;
-		for (uint64_t c = hs[l]; c < hs[l + 1]; c += per) { ib.push_back(c); ie.push_back(std::min(hs[l + 1], c + per)); il.push_back((uint32_t)l); }
-	}
+	rc = build_csr(h, h->l1, nl1, 0, &ls1, &lc1, &nch1); if (rc) return rc;
 	/* Final lists are sized by what the count pass can hold in its LDS table: measure the share of distinct keys
-	 * on a sample of level-1 lists, then take enough level-2 bits for ~MAX_LIST_DISTINCT distinct keys per list (and
-	 * at most TARGET_LIST_RECORDS records); if the bits run out the count pass uses its 2048-slot table, and beyond
-	 * that its sub-passes. */
+	 * on a sample of level-1 lists, then take enough further bits for ~MAX_LIST_DISTINCT distinct keys per list (and
+	 * at most TARGET_LIST_RECORDS records), up to max_part_bits per pass and as many passes as that takes (C2: one,
+	 * 10 + 10 bits; C4 with 5 x 10^9 two-word records: 10 + 10 + 2). */
 	double distinct_share = 1.0, repeated_share = 0.5;      /* distinct keys, and distinct keys seen more than once, per record */
 	if (G) {
 		unsigned long long *dpr, hpr[4] = {0, 0, 0, 0};
@@ -914,38 +910,58 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		if (getenv("KMR_DEBUG")) fprintf(stderr, "distinct probe: %llu records, %llu distinct (%llu repeated) -> shares %.3f %.3f\n", hpr[0], hpr[1], hpr[2], distinct_share, repeated_share);
 	}
 	const int mb = max_part_bits(W);
-	int T = 0; while (T < h->bits1 + mb && ((G >> T) > TARGET_LIST_RECORDS || (double)(G >> T) * distinct_share > MAX_LIST_DISTINCT)) T++;
-	const int bits2 = std::max(0, std::min(mb, T - h->bits1));
-	const uint64_t nl2 = 1ull << (h->bits1 + bits2);
-	const int count_log2s = (double)(G >> (h->bits1 + bits2)) * distinct_share > MAX_LIST_DISTINCT ? 11 : COUNT_LOG2S;
-	if (getenv("KMR_DEBUG")) fprintf(stderr, "count pass: %llu lists of ~%llu records, table 2^%d\n", (unsigned long long)nl2, (unsigned long long)(G >> (h->bits1 + bits2)), count_log2s);
-	{	/* the linear record buffer is dead from here on: give it back if the level-2 pool would not fit beside it */
-		const uint64_t l2_chunks = G / CH + ib.size() * (1ull << bits2) + (uint64_t)part_grid(h) * 512 + 64;
-		size_t mfree = 0, mtotal = 0;
-		if (l2_chunks > h->l2.cap && h->linear && hipMemGetInfo(&mfree, &mtotal) == hipSuccess &&
-		    (double)mfree < (double)l2_chunks * CH * rec_bytes(h) * 1.02 + 8.0 * l2_chunks + (double)(1ull << 30)) {
-			hipFree(h->linear); h->linear = nullptr; h->linear_cap = 0;
+	int T = 0; while (T < 40 && ((G >> T) > TARGET_LIST_RECORDS || (double)(G >> T) * distinct_share > MAX_LIST_DISTINCT)) T++;
+	T = std::min(T, 28);                              /* list ids are 32-bit with room to spare */
+	int cur_bits = h->bits1;
+	uint64_t *ls2 = ls1, *lc2 = lc1;                  /* CSR of the current (finally: the last) level */
+	uint32_t valid_from = 0;                          /* chunks below belong to levels that were left behind by a fresh-chunk pass */
+	for (int level = 2; cur_bits < T; level++) {
+		const int nbits = std::min(mb, T - cur_bits);
+		const uint64_t nl_prev = 1ull << cur_bits;
+		/* work items: the lists of the previous level, long ones cut into equal items (every item ends with a flush of
+		 * partly filled chunks, and a short leftover item would cost as many of those as a full one) */
+		std::vector<uint64_t> hs(nl_prev + 1);
+		HIPCHK(h, hipMemcpy(hs.data(), ls2, 8 * (nl_prev + 1), hipMemcpyDeviceToHost));
+		std::vector<uint64_t> ib, ie; std::vector<uint32_t> il;
+		for (uint64_t l = 0; l < nl_prev; l++) {
+			const uint64_t nch = hs[l + 1] - hs[l];
+			if (!nch) continue;
+			const uint64_t nit = (nch + L2_ITEM_CHUNKS - 1) / L2_ITEM_CHUNKS, per = (nch + nit - 1) / nit;
+			for (uint64_t c = hs[l]; c < hs[l + 1]; c += per) { ib.push_back(c); ie.push_back(std::min(hs[l + 1], c + per)); il.push_back((uint32_t)l); }
 		}
-	}
-	rc = pool_reserve(h, h->l2, G / CH + ib.size() * (1ull << bits2) + (uint64_t)part_grid(h) * 512 + 64, false); if (rc) return rc;
-	if (!ib.empty()) {
+		if (ib.empty()) { cur_bits += nbits; rc = build_csr(h, h->l1, 1ull << cur_bits, valid_from, &ls2, &lc2, &nch1); if (rc) return rc; continue; }
+		/* The pass writes into the pool it reads.  With room for a second copy of the records it appends fresh chunks
+		 * (compact, slab by slab: the faster writes); without, a block recycles the chunks it has just read. */
+		const uint64_t partials = ib.size() * (1ull << nbits) + (uint64_t)part_grid(h) * 512 + 64;
+		unsigned int head_before = 0;
+		HIPCHK(h, hipMemcpy(&head_before, h->l1.head, 4, hipMemcpyDeviceToHost));
+		const bool recycle = getenv("KMR_RECYCLE") ? atoi(getenv("KMR_RECYCLE")) != 0 : (uint64_t)head_before + G / CH + partials + 64 > h->l1.cap;
+		h->l1.used_ub = head_before;
+		rc = pool_reserve(h, h->l1, (recycle ? 0 : G / CH) + partials, true); if (rc) return rc;
 		uint64_t *dib, *die; uint32_t *dil;
 		rc = arena_get(h, &dib, ib.size()); if (rc) return rc; rc = arena_get(h, &die, ie.size()); if (rc) return rc; rc = arena_get(h, &dil, il.size()); if (rc) return rc;
 		HIPCHK(h, hipMemcpyAsync(dib, ib.data(), 8 * ib.size(), hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipMemcpyAsync(die, ie.data(), 8 * ie.size(), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(h, hipMemcpyAsync(dil, il.data(), 4 * il.size(), hipMemcpyHostToDevice, h->stream));
 		rc = zero_work_counter(h); if (rc) return rc;
 		PartSource<W> S; memset(&S, 0, sizeof(S));
-		S.src = pool_view(h, h->l1); S.list_chunks = lc1; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size(); S.kb = h->kb; S.rot = part_rot(h);
+		S.src = pool_view(h, h->l1); S.list_chunks = lc2; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size(); S.kb = h->kb; S.rot = part_rot(h);
+		S.recycle = recycle ? 1 : 0;
 		const int grid = (int)std::min<uint64_t>(partition_blocks(h), ib.size());
+		if (getenv("KMR_DEBUG")) fprintf(stderr, "level %d: %d bits after %d, %zu items, %s\n", level, nbits, cur_bits, ib.size(), recycle ? "recycling chunks" : "fresh chunks");
 		hipEvent_t ta, tb; time_begin(h, KMR_TIME_PARTITION2, &ta, &tb);
-		rc = launch_partition<W, 2>(h, S, h->l2, grid, bits2, h->bits1);
+		rc = launch_partition<W, 2>(h, S, h->l1, grid, nbits, cur_bits);
 		time_end(h, KMR_TIME_PARTITION2, ta, tb);
 		if (rc) return rc;
 		HIPCHK(h, hipStreamSynchronize(h->stream));      /* the host vectors behind the item copies go out of scope */
+		cur_bits += nbits;
+		/* CSR of the new level: fresh chunks lie behind the old head (what is below keeps the list ids of the level
+		 * left behind and is never looked at again); recycled ones anywhere in the range that was valid before */
+		if (!recycle) valid_from = head_before;
+		rc = build_csr(h, h->l1, 1ull << cur_bits, valid_from, &ls2, &lc2, &nch1); if (rc) return rc;
 	}
-	/* level-2 CSR, then count every final list */
-	uint64_t *ls2 = nullptr; uint64_t *lc2 = nullptr; uint32_t nch2 = 0;
-	rc = build_csr(h, h->l2, nl2, &ls2, &lc2, &nch2); if (rc) return rc;
+	const uint64_t nl2 = 1ull << cur_bits;
+	const int count_log2s = (double)(G >> cur_bits) * distinct_share > MAX_LIST_DISTINCT ? 11 : COUNT_LOG2S;
+	if (getenv("KMR_DEBUG")) fprintf(stderr, "count pass: %llu lists of ~%llu records, table 2^%d\n", (unsigned long long)nl2, (unsigned long long)(G >> cur_bits), count_log2s);
 	const uint32_t vw = 3;
 	const uint64_t slack = (uint64_t)part_grid(h) * 8 * 8192 + 16;     /* one partly used output slab per block */
 	/* entry buffers: the worst case (every second record a weak entry, or every record a singleton) is 5-10 x what
@@ -968,14 +984,12 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	FinalizeCounters c; unsigned long long cur[2];
 	hipEvent_t tca, tcb; time_begin(h, KMR_TIME_COUNT, &tca, &tcb);
 	for (int attempt = 0; ; attempt++) {
-	{	/* the level-1 pool is dead after the level-2 pass: released when the entry buffers would not fit beside it
-		 * (C4: 5 x 10^9 two-word records make both pools 120 GB each); the next build of the handle allocates it again */
+	{	/* the linear record buffer is dead during finalize: given back when the entry buffers would not fit beside it */
 		const double need = (!h->uw_keys || h->uw_cap < wcap ? (8.0 * W + 4.0 * vw) * (double)wcap : 0.0) + (!h->us_keys || h->us_cap < scap ? (8.0 * W + 1.0) * (double)scap : 0.0);
 		size_t mfree = 0, mtotal = 0;
-		if (need > 0 && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)mfree < need + (double)G * 0.6 * (8.0 * W + 12.0) + (double)(2ull << 30)) {
+		if (need > 0 && h->linear && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)mfree < need + (double)G * 0.3 * (8.0 * W + 12.0) + (double)(2ull << 30)) {
 			HIPCHK(h, hipStreamSynchronize(h->stream));
-			if (h->linear) { hipFree(h->linear); h->linear = nullptr; h->linear_cap = 0; }
-			pool_free(h->l1);
+			hipFree(h->linear); h->linear = nullptr; h->linear_cap = 0;
 		}
 	}
 	if (!h->uw_keys || h->uw_cap < wcap) {
@@ -1009,12 +1023,12 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 			auto kern = count_kernel<W, false, 11>;
 			const size_t smem = count_smem_bytes<W, 11>();
 			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l2), ls2, lc2, nl2, out, f, h->work_counter);
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter);
 		} else {
 			auto kern = count_kernel<W, false, COUNT_LOG2S>;
 			const size_t smem = count_smem_bytes<W, COUNT_LOG2S>();
 			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l2), ls2, lc2, nl2, out, f, h->work_counter);
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter);
 		}
 		HIPCHK(h, hipGetLastError());
 	}

@@ -243,6 +243,11 @@ template <int W> struct PartSource {
 	 * Record<W>: dwords per record, 0 = Record<W>.  Records without a packet get their arrival ordinal. */
 	uint32_t packed_words;
 	uint64_t ordinal_base;
+	/* LEVEL 2: the output pool is the input pool.  A block hands the chunks of a batch it has read back to itself as
+	 * free chunks for the lists it writes (it reads ~128 chunks per batch and fills ~128), so level 2 needs fresh
+	 * chunks only for the first batch of an item and for partly filled ones: one pool of ~1.15 x the records
+	 * instead of two pools. */
+	uint32_t recycle;
 };
 
 template <int W, int G> __host__ __device__ inline size_t partition_state_bytes(int bits) {
@@ -300,6 +305,9 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 	constexpr uint32_t SLAB = 64, RING = 128;
 	__shared__ uint32_t s_ring[RING];
 	__shared__ uint32_t s_alloc, s_filled;
+	constexpr int FREE_CAP = LEVEL == 2 ? 2048 : 1;
+	__shared__ uint32_t s_free[FREE_CAP];      /* recycled input chunks (LEVEL 2, S.recycle) */
+	__shared__ int s_free_n;
 	const int t = threadIdx.x;
 
 	uint32_t *gstate = nullptr; Rec *glines = nullptr;
@@ -313,7 +321,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 	} else {
 		for (int p = t; p < P; p += THREADS) { cur[p] = NO_CHUNK; cnt[p] = 0; hist[p] = 0; if (G) stage_n[p] = 0; }
 	}
-	if (t == 0) { s_alloc = 0; s_filled = 0; s_nextra = 0; }
+	if (t == 0) { s_alloc = 0; s_filled = 0; s_nextra = 0; s_free_n = 0; }
 	lds_barrier();
 
 	auto top_up = [&]() {
@@ -328,6 +336,11 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 		}
 	};
 	auto alloc_chunk = [&](uint32_t lid) -> uint32_t {
+		if (LEVEL == 2 && S.recycle) {          /* pops race only with pops: pushes happen in another phase of the batch */
+			const int old = atomicSub(&s_free_n, 1);
+			if (old > 0) { const uint32_t c = s_free[old - 1]; out.chunk_list[c] = lid; return c; }
+			atomicAdd(&s_free_n, 1);
+		}
 		const uint32_t idx = atomicAdd(&s_alloc, 1u);
 		const uint32_t c = idx < s_filled ? s_ring[(idx / SLAB) % RING] + (idx % SLAB) : atomicAdd(out.head, 1u);
 		if (c >= out.cap) { atomicOr(out.err, (uint32_t)ERR_POOL_FULL); return NO_CHUNK; }
@@ -501,15 +514,17 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 		}
 		if (S.valid_counter) { nvalid = wave_sum(nvalid); if ((t & 63) == 0 && nvalid) atomicAdd(S.valid_counter, nvalid); }
 	} else {
+		uint32_t cid[RPT];       /* chunks this wavefront read in the current batch */
 		auto load2 = [&](uint64_t cb, uint64_t cb1, auto &rr, auto &pp) {
 			/* a batch = BATCH/CH chunks; wave w reads chunk (i * waves + w), lane = record */
 #pragma unroll
 			for (int i = 0; i < RPT; i++) {
 				const uint64_t ci = cb + (uint64_t)i * (THREADS / CH) + (t >> 6);
-				pp[i] = NO_CHUNK;
+				pp[i] = NO_CHUNK; cid[i] = NO_CHUNK;
 				if (ci < cb1) {
 					const uint64_t d = S.list_chunks[ci];
 					const uint32_t c = (uint32_t)d;
+					cid[i] = c;
 					if ((uint32_t)(t & 63) < (uint32_t)(d >> 32)) {
 						rr[i] = ((const Rec *)(S.src.base + (size_t)c * CH * sizeof(Rec)))[t & 63];
 						pp[i] = pid_of(rr[i]);
@@ -526,12 +541,28 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 			const uint64_t cb0 = S.item_begin[it], cb1 = S.item_end[it];
 			const uint32_t lid_base = S.item_list[it] << LOG2P;
 			constexpr uint64_t STEP = BATCH / CH;
-			for (uint64_t cb = cb0; cb < cb1; cb += STEP) { load2(cb, cb1, r, pid); scatter_batch(r, pid, lid_base); }
+			for (uint64_t cb = cb0; cb < cb1; cb += STEP) {
+				load2(cb, cb1, r, pid);
+				scatter_batch(r, pid, lid_base);
+				/* every record of the batch has left its registers: its chunks are free (scatter_batch ends with a
+				 * barrier, and the next one has a barrier between this push and the first pop) */
+				if (S.recycle && (t & 63) == 0) {
+#pragma unroll
+					for (int i = 0; i < RPT; i++) if (cid[i] != NO_CHUNK) {
+						const int pos = atomicAdd(&s_free_n, 1);
+						if (pos < FREE_CAP) s_free[pos] = cid[i];
+						else { atomicSub(&s_free_n, 1); out.chunk_list[cid[i]] = NO_CHUNK; out.chunk_count[cid[i]] = 0; }      /* belongs to no list of the new level */
+					}
+				}
+			}
+			lds_barrier();
 			flush_all(lid_base);
 			lds_barrier();
 		}
 	}
 	lds_barrier();
+	if (LEVEL == 2 && S.recycle)       /* consumed chunks nobody took: not part of any list */
+		for (int i = t; i < s_free_n && i < FREE_CAP; i += THREADS) { out.chunk_list[s_free[i]] = NO_CHUNK; out.chunk_count[s_free[i]] = 0; }
 	for (uint32_t idx = s_alloc + t; idx < s_filled; idx += THREADS) {
 		const uint32_t c = s_ring[(idx / SLAB) % RING] + (idx % SLAB);
 		if (c < out.cap) { out.chunk_list[c] = NO_CHUNK; out.chunk_count[c] = 0; }
@@ -559,7 +590,7 @@ void chunk_hist_kernel(const uint32_t *chunk_list, uint32_t n_chunks, uint32_t *
 	if (priv) { __syncthreads(); for (uint32_t i = threadIdx.x; i < nl; i += CSR_THREADS) if (lh[i]) atomicAdd(&list_nchunks[i], lh[i]); }
 }
 __global__ __launch_bounds__(CSR_THREADS)
-void chunk_scatter_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, const uint64_t *list_start,
+void chunk_scatter_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, uint32_t first, const uint64_t *list_start,
                           uint32_t *cursor, uint64_t *list_chunks, uint32_t nl) {
 	__shared__ uint32_t lh[CSR_LDS_LISTS];
 	const bool priv = nl <= (uint32_t)CSR_LDS_LISTS;
@@ -583,7 +614,7 @@ void chunk_scatter_kernel(const uint32_t *chunk_list, const uint32_t *chunk_coun
 		if (l == NO_CHUNK) continue;
 		const uint64_t c = base + (uint64_t)j * CSR_THREADS + threadIdx.x;
 		const uint32_t pos = priv ? lh[l] + myr[j] : atomicAdd(&cursor[l], 1u);
-		list_chunks[list_start[l] + pos] = ((uint64_t)chunk_count[c] << 32) | c;
+		list_chunks[list_start[l] + pos] = ((uint64_t)chunk_count[c] << 32) | (c + first);      /* chunk_list/chunk_count point at chunk `first` */
 	}
 }
 

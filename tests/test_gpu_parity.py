@@ -239,6 +239,35 @@ def test_histogram():
     assert np.allclose(wo, wp, rtol=1e-3, atol=1.0)
 
 
+@pytest.mark.parametrize("k,recycle", [(31, "1"), (31, "0"), (51, "1")])
+def test_three_partition_levels_and_chunk_recycling(k, recycle, monkeypatch):
+    """More records than two partition passes can cut into countable lists (forced here by a tiny target list size)
+    take a third pass; with KMR_RECYCLE=1 every pass after the first writes into the chunks it has just read instead
+    of fresh ones.  Both must give the maps of the device-table build byte for byte."""
+    monkeypatch.setenv("KMR_TARGET_LIST", "6")
+    monkeypatch.setenv("KMR_RECYCLE", recycle)
+    rb = synth_reads(300000, read_len=150, seed=31, quality="noisy", n_rate=0.001)
+    cfg = default_config(k, estimated_raw_kmers=300000 * (150 - k + 1))
+    a = product(cfg, 2)
+    add(a, rb)
+    a.finalize(1)
+    monkeypatch.delenv("KMR_TARGET_LIST")
+    b = product(cfg, 1)
+    add(b, rb)
+    b.finalize(1)
+    assert a.stats() == b.stats()
+    assert np.array_equal(a.image(KMR_MAP_WEAK), b.image(KMR_MAP_WEAK))
+    assert np.array_equal(a.image(KMR_MAP_SINGLETON), b.image(KMR_MAP_SINGLETON))
+    # a second build on the same handle starts from a clean pool
+    a.reset()
+    add(a, rb.slice(0, 1000))
+    a.finalize(1)
+    c = product(cfg, 1)
+    add(c, rb.slice(0, 1000))
+    c.finalize(1)
+    assert np.array_equal(a.image(KMR_MAP_WEAK), c.image(KMR_MAP_WEAK))
+
+
 @pytest.mark.parametrize("min_depth", [1, 2])
 def test_entry_buffers_grow_when_the_estimate_was_too_small(min_depth, monkeypatch):
     """The count pass writes kept entries into buffers sized from a sampled share of repeated keys; if they overflow the
