@@ -75,7 +75,7 @@ struct kmr_handle {
 	kmr_stats stats;
 	/* streaming (partition) build path */
 	bool partition_mode = false;
-	HostPool l1, l2;
+	HostPool l1;                       /* the record pool of every partition level */
 	int bits1 = 0;
 	uint64_t inserted_records = 0;     /* records fed through kmr_insert_records_dev (counted on the host) */
 	unsigned int *work_counter = nullptr;
@@ -1111,7 +1111,7 @@ int insert_records_partition(kmr_handle *h, const void *recs, uint64_t n) {
 	case 3: return insert_records_partition_t<3>(h, recs, n); default: return insert_records_partition_t<4>(h, recs, n); }
 }
 void free_partition_state(kmr_handle *h) {
-	pool_free(h->l1); pool_free(h->l2);
+	pool_free(h->l1);
 	if (h->l1_state) hipFree(h->l1_state); h->l1_state = nullptr; h->l1_state_bytes = 0; h->l1_state_dirty = false;
 	for (void *p : h->arena_overflow) hipFree(p);
 	h->arena_overflow.clear();
@@ -1225,8 +1225,7 @@ int kmr_reset(kmr_handle *h) {
 	int rc = 0;
 	if (h->partition_mode) {
 		if (h->l1.head) HIPCHK(h, hipMemsetAsync(h->l1.head, 0, 4, h->stream));
-		if (h->l2.head) HIPCHK(h, hipMemsetAsync(h->l2.head, 0, 4, h->stream));
-		h->l1.used_ub = 0; h->l2.used_ub = 0;
+		h->l1.used_ub = 0;
 		h->inserted_records = 0;
 		if (h->l1_state) {      /* what an unfinished build kept back is dropped with its pool */
 			hipLaunchKernelGGL(partition_state_init_kernel, dim3(partition_blocks(h)), dim3(256), 0, h->stream, h->l1_state,
