@@ -70,7 +70,9 @@ typedef struct kmr_config {
 	uint32_t k;                      /* k-mer length in bases, 1..128                          */
 	uint64_t num_buckets_weak;       /* 0 => derive from estimated_raw_kmers like the ctor     */
 	uint64_t num_buckets_singleton;  /* 0 => derive; both rounded up to a power of two <= 2^26 */
-	uint64_t estimated_raw_kmers;    /* KmerSpectrum::estimateRawKmers() of the caller         */
+	uint64_t estimated_raw_kmers;    /* KmerSpectrum::estimateRawKmers() of the whole job; with world_size > 1 a
+	                                  * rank sizes its maps for estimated_raw_kmers / world_size, as
+	                                  * DistributedKmerSpectrum::estimateRawKmers does (src/DistributedFunctions.h:144-162) */
 	uint32_t value_kind;             /* kmr_value_kind                                         */
 	float    min_weight;             /* --min-kmer-quality (TrackingData::minimumWeight), 0.10 */
 	uint32_t min_quality_score;      /* --min-quality-score, 3 (MeraculousCounter: 2)          */

@@ -1168,8 +1168,11 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 		uint64_t w = cfg->num_buckets_weak, s = cfg->num_buckets_singleton;
 		const double depth = cfg->estimated_depth > 0 ? cfg->estimated_depth : 20.0;
 		const uint32_t kpb = cfg->kmers_per_bucket ? cfg->kmers_per_bucket : 32;
-		if (w == 0) { unsigned long est = (unsigned long)(int)(cfg->estimated_raw_kmers / depth); w = est / kpb + 1; }
-		if (s == 0) { unsigned long est = cfg->separate_singletons ? (unsigned long)(cfg->estimated_raw_kmers * cfg->estimated_error_rate) : 1; s = est / kpb + 1; }
+		/* estimated_raw_kmers is the whole job's; a rank's maps are built for its share, the figure
+		 * DistributedKmerSpectrum::estimateRawKmers (src/DistributedFunctions.h:144-162) hands the constructor */
+		const uint64_t raw = cfg->estimated_raw_kmers / (cfg->world_size > 1 ? cfg->world_size : 1);
+		if (w == 0) { unsigned long est = (unsigned long)(int)(raw / depth); w = est / kpb + 1; }
+		if (s == 0) { unsigned long est = cfg->separate_singletons ? (unsigned long)(raw * cfg->estimated_error_rate) : 1; s = est / kpb + 1; }
 		h->nb_weak = resize_buckets(w); h->nb_sing = resize_buckets(s);
 		h->has_singletons = cfg->separate_singletons != 0;
 		/* table capacity */

@@ -883,8 +883,11 @@ int orc_config_init(kmr_config *c) {
  * via KmerMapByKmerArrayPair(estimatedRawKmers), Kmer.h:2837 */
 void orc_derive_buckets(const kmr_config *c, uint64_t *weak, uint64_t *singleton) {
 	uint64_t w = c->num_buckets_weak, s = c->num_buckets_singleton;
-	if (w == 0) { unsigned long est = (unsigned long)(int)(c->estimated_raw_kmers / c->estimated_depth); w = est / c->kmers_per_bucket + 1; }
-	if (s == 0) { unsigned long est = c->separate_singletons ? (unsigned long)(c->estimated_raw_kmers * c->estimated_error_rate) : 1; s = est / c->kmers_per_bucket + 1; }
+	/* estimated_raw_kmers is the whole job's; a rank's maps are built for its share, the figure
+	 * DistributedKmerSpectrum::estimateRawKmers (src/DistributedFunctions.h:144-162) hands the constructor */
+	const uint64_t raw = c->estimated_raw_kmers / (c->world_size > 1 ? c->world_size : 1);
+	if (w == 0) { unsigned long est = (unsigned long)(int)(raw / c->estimated_depth); w = est / c->kmers_per_bucket + 1; }
+	if (s == 0) { unsigned long est = c->separate_singletons ? (unsigned long)(raw * c->estimated_error_rate) : 1; s = est / c->kmers_per_bucket + 1; }
 	*weak = resizeBuckets(w); *singleton = resizeBuckets(s);
 }
 
