@@ -515,6 +515,12 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 		if (S.valid_counter) { nvalid = wave_sum(nvalid); if ((t & 63) == 0 && nvalid) atomicAdd(S.valid_counter, nvalid); }
 	} else {
 		uint32_t cid[RPT];       /* chunks this wavefront read in the current batch */
+		uint64_t dsc[RPT];       /* their descriptors, requested one batch ahead (a descriptor load in front of every
+		                            record load would put two HBM latencies in series) */
+		auto load_desc = [&](uint64_t cb, uint64_t cb1) {
+#pragma unroll
+			for (int i = 0; i < RPT; i++) { const uint64_t ci = cb + (uint64_t)i * (THREADS / CH) + (t >> 6); dsc[i] = ci < cb1 ? S.list_chunks[ci] : ~0ull; }
+		};
 		auto load2 = [&](uint64_t cb, uint64_t cb1, auto &rr, auto &pp) {
 			/* a batch = BATCH/CH chunks; wave w reads chunk (i * waves + w), lane = record */
 #pragma unroll
@@ -522,7 +528,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 				const uint64_t ci = cb + (uint64_t)i * (THREADS / CH) + (t >> 6);
 				pp[i] = NO_CHUNK; cid[i] = NO_CHUNK;
 				if (ci < cb1) {
-					const uint64_t d = S.list_chunks[ci];
+					const uint64_t d = dsc[i];
 					const uint32_t c = (uint32_t)d;
 					cid[i] = c;
 					if ((uint32_t)(t & 63) < (uint32_t)(d >> 32)) {
@@ -541,8 +547,10 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 			const uint64_t cb0 = S.item_begin[it], cb1 = S.item_end[it];
 			const uint32_t lid_base = S.item_list[it] << LOG2P;
 			constexpr uint64_t STEP = BATCH / CH;
+			load_desc(cb0, cb1);
 			for (uint64_t cb = cb0; cb < cb1; cb += STEP) {
 				load2(cb, cb1, r, pid);
+				load_desc(cb + STEP, cb1);
 				scatter_batch(r, pid, lid_base);
 				/* every record of the batch has left its registers: its chunks are free (scatter_batch ends with a
 				 * barrier, and the next one has a barrier between this push and the first pop) */
