@@ -447,6 +447,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 		__shared__ uint32_t s_bcount[MAXB], s_bslot[MAXB], s_gfirst[MAXB + 1];
 		__shared__ uint32_t s_ng;
 		__shared__ unsigned long long s_ecur, s_eoff;
+		__shared__ unsigned long long s_estart[EBATCH], s_ecount[EBATCH];      /* the grabbed extents, fetched by EBATCH threads at once */
 		unsigned long long nvalid = 0;
 		auto load1 = [&](uint32_t g, auto &rr, auto &pp) {
 #pragma unroll
@@ -477,15 +478,18 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 			const uint64_t efirst = s_item;
 			if (efirst >= S.n_ext) break;
 			if (t == 0) { s_ecur = efirst; s_eoff = 0; }
+			if ((uint32_t)t < EBATCH && efirst + t < S.n_ext) {
+				const uint64_t e = efirst + t;
+				if (S.ext_start) { s_estart[t] = S.ext_start[e * S.ext_stride]; s_ecount[t] = S.ext_count[e]; }
+				else { const uint64_t st = e * S.ext_len; s_estart[t] = st; s_ecount[t] = S.total - st < S.ext_len ? S.total - st : S.ext_len; }
+			}
 			for (;;) {
 				lds_barrier();
 				if (t == 0) {
 					uint32_t nb = 0, ng = 0, filled = BATCH;       /* filled == BATCH: no group open */
 					uint64_t e = s_ecur, off = s_eoff;
 					while (e < efirst + EBATCH && e < S.n_ext && nb < MAXB) {
-						uint64_t start, n;
-						if (S.ext_start) { start = S.ext_start[e * S.ext_stride]; n = S.ext_count[e]; }
-						else { start = e * S.ext_len; n = S.total - start < S.ext_len ? S.total - start : S.ext_len; }
+						const uint64_t start = s_estart[e - efirst], n = s_ecount[e - efirst];
 						while (off < n && nb < MAXB) {
 							const uint32_t c = (uint32_t)(n - off < (uint64_t)BATCH ? n - off : (uint64_t)BATCH);
 							if (filled + c > (uint32_t)BATCH) { s_gfirst[ng++] = nb; filled = 0; }
