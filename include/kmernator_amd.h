@@ -307,6 +307,10 @@ int kmr_reads_copy(const kmr_reads *r, char *bases, char *quals, uint64_t *offse
 /* kmr_add_reads_dev on the batch, then kmr_sync */
 int kmr_add_read_batch(kmr_handle *h, const kmr_reads *r, uint64_t first_global_read_idx);
 void kmr_reads_free(kmr_reads *r);
+/* kmr_score_reads on a device-resident read batch: FASTQ text -> reads -> spectrum -> trim / score without the host
+ * staging the reads (outputs are host arrays of kmr_reads_info's n_reads entries) */
+int kmr_score_read_batch(kmr_handle *h, const kmr_reads *r, double minimum_kmer_score, int scoring_type,
+                         uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed);
 
 /* Raw HIP stream of the handle (hipStream_t) so callers can order their own
  * work (torch.cuda.ExternalStream) against it. */

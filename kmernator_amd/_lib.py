@@ -54,7 +54,7 @@ EXPORTS = [
     "kmr_distributed_thread_id", "kmr_compress_sequence", "kmr_least_complement", "kmr_extract_by_owner_dev",
     "kmr_insert_records_dev", "kmr_stream", "kmr_kernel_time", "kmr_kernel_time_reset", "kmr_reset", "kmr_release_table", "kmr_score_reads",
     "kmr_ingest_fastq", "kmr_ingest_fastq_dev", "kmr_reads_info", "kmr_reads_device_ptrs", "kmr_reads_copy",
-    "kmr_add_read_batch", "kmr_reads_free", "kmr_histogram", "kmr_histogram_bins", "kmr_merge_image", "kmr_subtract_reference", "kmr_subtracted",
+    "kmr_add_read_batch", "kmr_reads_free", "kmr_histogram", "kmr_histogram_bins", "kmr_merge_image", "kmr_subtract_reference", "kmr_subtracted", "kmr_score_read_batch",
 ]
 
 _lib = None
@@ -118,6 +118,7 @@ def load():
     lib.kmr_add_read_batch.argtypes = [vp, vp, C.c_uint64]
     lib.kmr_reads_free.argtypes = [vp]
     lib.kmr_reads_free.restype = None
+    lib.kmr_score_read_batch.argtypes = [vp, vp, C.c_double, C.c_int, u32p, u32p, C.POINTER(C.c_float), u8p]
     lib.kmr_merge_image.argtypes = [vp, C.c_int, vp, C.c_uint64]
     lib.kmr_subtract_reference.argtypes = [vp, vp]
     lib.kmr_subtracted.argtypes = [vp, u64p]

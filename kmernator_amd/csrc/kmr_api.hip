@@ -1347,17 +1347,12 @@ int kmr_lookup_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, 
 	return rc;
 }
 
-/* ReadSelector::scoreAndTrimReads (src/ReadSelector.h:1182-1207) on the weak map */
-int kmr_score_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads, double minimum_kmer_score, int scoring_type,
-                    uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed) {
-	if (!h || !bases || !offsets || !trim_offset || !trim_length || !score || !was_trimmed) return KMR_ERR_INVALID_ARG;
-	if (scoring_type < 0 || scoring_type > 4) return fail(h, KMR_ERR_INVALID_ARG, "bad scoring_type");
-	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_score_reads before kmr_finalize");
-	if (n_reads == 0) return KMR_OK;
-	hipSetDevice(h->device);
-	StagedReads s; uint64_t total = 0;
-	int rc = stage_reads(h, bases, nullptr, offsets, n_reads, nullptr, s, total);
-	if (rc) { s.release(); return rc; }
+/* ReadSelector::scoreAndTrimReads (src/ReadSelector.h:1182-1207) on the weak map; s_b / s_o: device bases and offsets,
+ * offsets: the same offsets on the host */
+static int score_reads_core(kmr_handle *h, const uint8_t *s_b, const uint64_t *s_o, const uint64_t *offsets, uint64_t n_reads, double minimum_kmer_score, int scoring_type,
+                            uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed) {
+	struct { const uint8_t *b; const uint64_t *o; void release() {} } s = {s_b, s_o};
+	int rc = 0;
 	std::vector<uint64_t> coff(n_reads + 1, 0);
 	for (uint64_t r = 0; r < n_reads; r++) { const uint64_t L = offsets[r + 1] - offsets[r]; coff[r + 1] = coff[r] + (L >= h->k ? L - h->k + 1 : 0); }
 	const uint64_t outN = coff[n_reads];
@@ -1378,8 +1373,39 @@ int kmr_score_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, u
 		HIPCHK(h, hipMemcpyAsync(score, dsc, 4 * n_reads, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(was_trimmed, dwt, n_reads, hipMemcpyDeviceToHost, h->stream));
 		rc = sync_state(h);
 	} else hipStreamSynchronize(h->stream);
-	hipFree(dcounts); hipFree(dcoff); hipFree(dto); hipFree(dtl); hipFree(dsc); hipFree(dwt); s.release();
+	hipFree(dcounts); hipFree(dcoff); hipFree(dto); hipFree(dtl); hipFree(dsc); hipFree(dwt);
 	return rc;
+}
+int kmr_score_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads, double minimum_kmer_score, int scoring_type,
+                    uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed) {
+	if (!h || !bases || !offsets || !trim_offset || !trim_length || !score || !was_trimmed) return KMR_ERR_INVALID_ARG;
+	if (scoring_type < 0 || scoring_type > 4) return fail(h, KMR_ERR_INVALID_ARG, "bad scoring_type");
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_score_reads before kmr_finalize");
+	if (n_reads == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	StagedReads s; uint64_t total = 0;
+	int rc = stage_reads(h, bases, nullptr, offsets, n_reads, nullptr, s, total);
+	if (!rc) {
+		std::vector<uint64_t> rel(n_reads + 1);
+		for (uint64_t i = 0; i <= n_reads; i++) rel[i] = offsets[i] - offsets[0];
+		rc = score_reads_core(h, s.b, s.o, rel.data(), n_reads, minimum_kmer_score, scoring_type, trim_offset, trim_length, score, was_trimmed);
+	}
+	s.release();
+	return rc;
+}
+/* the same on a device-resident read batch (kmr_ingest_fastq): FASTQ text -> reads -> spectrum -> trim/score without the
+ * reads ever being staged by the host */
+int kmr_score_read_batch(kmr_handle *h, const kmr_reads *r, double minimum_kmer_score, int scoring_type,
+                         uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed) {
+	if (!h || !r || !trim_offset || !trim_length || !score || !was_trimmed) return KMR_ERR_INVALID_ARG;
+	if (scoring_type < 0 || scoring_type > 4) return fail(h, KMR_ERR_INVALID_ARG, "bad scoring_type");
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_score_read_batch before kmr_finalize");
+	if (r->device != h->device) return fail(h, KMR_ERR_INVALID_ARG, "read batch lives on another device");
+	if (r->n == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	std::vector<uint64_t> off(r->n + 1);
+	HIPCHK(h, hipMemcpy(off.data(), r->offsets, 8 * (r->n + 1), hipMemcpyDeviceToHost));
+	return score_reads_core(h, r->bases, r->offsets, off.data(), r->n, minimum_kmer_score, scoring_type, trim_offset, trim_length, score, was_trimmed);
 }
 
 static DevMap *map_of(kmr_handle *h, int which) {

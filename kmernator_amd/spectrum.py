@@ -180,6 +180,18 @@ class KmerSpectrum:
                        tl.ctypes.data_as(C.POINTER(C.c_uint32)), sc.ctypes.data_as(C.POINTER(C.c_float)), wt.ctypes.data_as(C.POINTER(C.c_uint8)))
         return to, tl, sc, wt.astype(bool)
 
+    def scoreAndTrimReadSet(self, read_set, minimum_kmer_score, scoring_type="MEDIAN"):
+        """scoreAndTrimReads on a device-resident ReadSet (kmr_score_read_batch)"""
+        n = read_set.n
+        to = np.zeros(n, dtype=np.uint32)
+        tl = np.zeros(n, dtype=np.uint32)
+        sc = np.zeros(n, dtype=np.float32)
+        wt = np.zeros(n, dtype=np.uint8)
+        if n:
+            self._call("score_read_batch", self.h, read_set.r, float(minimum_kmer_score), self.SCORING[scoring_type], to.ctypes.data_as(C.POINTER(C.c_uint32)),
+                       tl.ctypes.data_as(C.POINTER(C.c_uint32)), sc.ctypes.data_as(C.POINTER(C.c_float)), wt.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return to, tl, sc, wt.astype(bool)
+
     def histogram(self, nbins=256):
         counts = np.zeros(nbins, dtype=np.uint64)
         weights = np.zeros(nbins, dtype=np.float64)

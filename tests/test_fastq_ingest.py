@@ -156,3 +156,29 @@ def test_ingest_then_build_equals_host_parsed_build(mode):
     assert np.array_equal(sp.getCount(ko), cnt)
     nb = o.num_buckets(KMR_MAP_WEAK)
     assert np.array_equal(sp.image(KMR_MAP_WEAK)[:16 + 8 * nb], o.image(KMR_MAP_WEAK)[:16 + 8 * nb])
+
+
+@pytest.mark.gpu
+def test_filterreads_from_fastq_text_on_the_device():
+    """FASTQ text -> device ReadSet (quality base detected: 1000.fastq is Phred-64) -> spectrum -> scoreAndTrimReads,
+    the reads never staged by the host: the MedianScore / Trim labels of the 949 reads without AFTrim in the reference's
+    FilterReads golden test/1000-Filtered.fastq."""
+    import kmernator_amd as ka
+    gold = read_fastq(os.path.join(GOLDEN, "1000-Filtered.fastq"))
+    sp = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=46000, device=0))
+    rs = ka.ReadSet(sp, _text("1000.fastq"))
+    assert rs.input_quality_base == 64 and rs.n == 1000
+    sp.buildKmerSpectrumFromReadSet(rs)
+    sp.finalize(2)
+    to, tl, sc, wt = sp.scoreAndTrimReadSet(rs, 2, "MEDIAN")
+    checked = 0
+    for i in range(rs.n):
+        if b"AFTrim" in gold.names[i]:
+            continue
+        label = b""
+        if wt[i]:
+            label += b"Trim:%d+%d " % (to[i], tl[i])
+        label += b"MedianScore:%d" % int(sc[i] + 0.5)
+        assert label == gold.names[i].split(b" ", 1)[1], (i, label, gold.names[i])
+        checked += 1
+    assert checked == 949
