@@ -929,19 +929,28 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 			/* emit: the slots of the kept entries are first collected in LDS (weak entries from the front of
 			 * s_kept, singletons from its back), so that the bucket hash and the stores below run on a dense
 			 * range of threads instead of once per table slot */
+			/* classify() of kmr_kernels.hpp with its case analysis folded into two launch-wide scalars: a count of one goes
+			 * to class singC when singletons are separate, any other count below weakMin is dropped */
+			const uint32_t singC = f.has_singletons ? (f.min_depth > 1 ? 0u : 2u) : 3u;       /* 3: no special case */
+			const uint32_t weakMin = ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1) ? f.min_depth : 0u;
+			/* all four slots of a thread are read first, then ranked: one LDS atomic per wavefront and class */
+			uint32_t cls[S / COUNT_THREADS];
 #pragma unroll
 			for (int i = 0; i < S / COUNT_THREADS; i++) {
 				const int s = i * COUNT_THREADS + t;
-				int c = 0;
-				if (W == 1 ? tkeys[s] != EMPTY_KEY : tstate[s] == 2) {
-					const uint32_t count = (uint32_t)tcnt[s];
-					uniq++;
-					if (count == 1) single++;
-					c = classify(count, f);
-				}
-				/* one LDS atomic per wavefront and class instead of one per entry on the same word */
+				const bool used = W == 1 ? tkeys[s] != EMPTY_KEY : tstate[s] == 2;
+				const uint32_t count = (uint32_t)tcnt[s];            /* 0 in a free slot */
+				uniq += used ? 1u : 0u;
+				single += (used && count == 1) ? 1u : 0u;
+				cls[i] = !used ? 0u : ((count == 1 && singC != 3u) ? singC : (count < weakMin ? 0u : 1u));
+			}
+			const unsigned long long below = (1ull << (t & 63)) - 1;
+#pragma unroll
+			for (int i = 0; i < S / COUNT_THREADS; i++) {
+				const int s = i * COUNT_THREADS + t;
+				const uint32_t c = cls[i];
 				const unsigned long long mw = __ballot(c == 1), ms = __ballot(c == 2);
-				const unsigned long long below = (1ull << (t & 63)) - 1;
+				if ((mw | ms) == 0) continue;                          /* wave-uniform: most slots are free or dropped */
 				uint32_t bw = 0, bs = 0;
 				if ((t & 63) == 0) { if (mw) bw = atomicAdd(&s_nw, (uint32_t)__builtin_popcountll(mw)); if (ms) bs = atomicAdd(&s_ns, (uint32_t)__builtin_popcountll(ms)); }
 				bw = (uint32_t)__shfl((int)bw, 0, 64); bs = (uint32_t)__shfl((int)bs, 0, 64);
