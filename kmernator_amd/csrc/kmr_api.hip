@@ -39,7 +39,7 @@ struct DevMap {                      /* a finalized map resident in HBM */
 	uint64_t image_bytes = 0;
 	bool present = false;
 	/* bytes allocated behind start / keys / vals / sweight: kmr_reset() keeps the buffers of the streaming path for the next build */
-	size_t c_start = 0, c_keys = 0, c_vals = 0, c_sw = 0;
+	size_t c_start = 0, c_keys = 0, c_vals = 0, c_sw = 0, c_pkt = 0;
 };
 
 struct HostPool {                    /* owner of one chunk pool */
@@ -90,7 +90,7 @@ struct kmr_handle {
 	/* work units of batches that contain reads longer than one tile */
 	uint32_t *ucnt = nullptr; uint64_t *ufirst = nullptr, *u_start = nullptr, *u_end = nullptr, *u_read = nullptr;
 	uint64_t ucnt_n = 0, ufirst_n = 0, units_n = 0; unsigned int *umax = nullptr;
-	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr; uint64_t uw_cap = 0, us_cap = 0;
+	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr, *us_pkt = nullptr; uint64_t uw_cap = 0, us_cap = 0;
 	/* timing */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	double ms[KMR_TIME_GROUPS] = {0};
@@ -594,21 +594,21 @@ const double MAX_LIST_DISTINCT = 600.0;       /* distinct keys per final list th
 const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
 const uint64_t SUB_BATCH_BASES = 1ull << 30;      /* linear records of one sub-batch: <= 17 GB at 16 bytes; 2^28 cost 2 ms per C2 step in launch tails */
 
-size_t rec_bytes(kmr_handle *h) { return 8 * h->W + 8; }
+size_t rec_bytes(kmr_handle *h) { return 8 * h->W + (h->ext ? 16 : 8); }      /* Record<W> / RecordX<W> */
 /* partition kernel shape: one 1024-thread block per compute unit, 8 records per thread per batch, a
  * 4-record write-combining line per list in LDS (see partition_direct_kernel) */
 const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
 /* partition bits per level that keep the per-list book-keeping and lines inside the 160 KB of LDS */
-int max_part_bits(uint32_t W) { return W <= 2 ? 10 : 9; }
+int max_part_bits(kmr_handle *h) { return rec_bytes(h) <= 24 ? 10 : 9; }
 PoolView pool_view(kmr_handle *h, HostPool &p) { PoolView v; v.base = p.base; v.chunk_list = p.chunk_list; v.chunk_count = p.chunk_count; v.head = p.head; v.cap = p.cap; v.err = h->derr; return v; }
 /* log2 of the weak map's bucket count: the partition is cut along the bucket index (part_order) */
 uint32_t part_rot(kmr_handle *h) { uint32_t r = 0; while ((1ull << (r + 1)) <= h->nb_weak) r++; return r; }
-template <int W, int LEVEL> int launch_partition(kmr_handle *h, const PartSource<W> &S, HostPool &pool, int grid, int bits, int shift) {
-	auto kern = partition_direct_kernel<W, LEVEL, PD_THREADS, PD_RPT, PD_LINE>;
-	const size_t smem = partition_direct_smem_bytes<W, PD_THREADS, PD_RPT, PD_LINE>(bits);
+template <int W, bool EXT, int LEVEL> int launch_partition(kmr_handle *h, const PartSource<W> &S, HostPool &pool, int grid, int bits, int shift) {
+	auto kern = partition_direct_kernel<W, EXT, LEVEL, PD_THREADS, PD_RPT, PD_LINE>;
+	const size_t smem = partition_direct_smem_bytes<W, EXT, PD_THREADS, PD_RPT, PD_LINE>(bits);
 	if (getenv("KMR_DEBUG")) fprintf(stderr, "partition level %d W=%d bits=%d shift=%d smem=%zu grid=%d\n", LEVEL, W, bits, shift, smem, grid);
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-	                              (int)partition_direct_smem_bytes<W, PD_THREADS, PD_RPT, PD_LINE>(max_part_bits(W))));
+	                              (int)partition_direct_smem_bytes<W, EXT, PD_THREADS, PD_RPT, PD_LINE>(max_part_bits(h))));
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), smem, h->stream, S, pool_view(h, pool), h->work_counter, bits, shift);
 	HIPCHK(h, hipGetLastError());
 	return 0;
@@ -680,8 +680,8 @@ int part_grid(kmr_handle *h) { return num_cus(h) * 2; }
 int partition_blocks(kmr_handle *h) { return getenv("KMR_PART_BLOCKS") ? atoi(getenv("KMR_PART_BLOCKS")) : num_cus(h); }
 
 /* per-block level-1 state, allocated (and emptied) on first use */
-template <int W> int ensure_l1_state(kmr_handle *h) {
-	const size_t stride = partition_state_bytes<W, PD_LINE>(h->bits1), need = stride * (size_t)partition_blocks(h);
+template <int W, bool EXT> int ensure_l1_state(kmr_handle *h) {
+	const size_t stride = partition_state_bytes<W, EXT, PD_LINE>(h->bits1), need = stride * (size_t)partition_blocks(h);
 	if (h->l1_state && h->l1_state_bytes == need) return 0;
 	if (h->l1_state) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->l1_state); h->l1_state = nullptr; }
 	HIPCHK(h, hipMalloc((void **)&h->l1_state, need)); h->l1_state_bytes = need;
@@ -691,19 +691,19 @@ template <int W> int ensure_l1_state(kmr_handle *h) {
 	return 0;
 }
 /* last level-1 launch of a build: no input, every block flushes what it kept back */
-template <int W> int flush_l1_state(kmr_handle *h) {
+template <int W, bool EXT> int flush_l1_state(kmr_handle *h) {
 	if (!h->l1_state || !h->l1_state_dirty) return 0;
 	int rc = pool_reserve(h, h->l1, (uint64_t)partition_blocks(h) * ((1ull << h->bits1) + 512) + 64, true); if (rc) return rc;
 	rc = zero_work_counter(h); if (rc) return rc;
 	PartSource<W> S; memset(&S, 0, sizeof(S));
 	S.kb = h->kb; S.rot = part_rot(h); S.state = h->l1_state; S.state_final = 1;
-	rc = launch_partition<W, 1>(h, S, h->l1, partition_blocks(h), h->bits1, 0);
+	rc = launch_partition<W, EXT, 1>(h, S, h->l1, partition_blocks(h), h->bits1, 0);
 	h->l1_state_dirty = false;
 	return rc;
 }
 
 /* level-1 partition of a linear record buffer into h->l1 */
-template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, const uint64_t *ext_start, const uint32_t *ext_count,
+template <int W, bool EXT> int partition_level1(kmr_handle *h, const void *linear, const uint64_t *ext_start, const uint32_t *ext_count,
                                       uint64_t n_ext, uint32_t ext_stride, uint64_t ext_len, uint64_t total, uint64_t max_records,
                                       unsigned long long *valid_counter = nullptr, uint32_t packed_words = 0, uint64_t ordinal_base = 0) {
 	if (n_ext == 0) return 0;
@@ -712,14 +712,14 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 		const uint64_t est = std::max<uint64_t>(max_records, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
 		const uint64_t launches = est / std::max<uint64_t>(1, max_records) + 2;
 		/* level 2 writes into the same pool (it recycles the chunks it reads): room for its partly filled chunks */
-		const uint64_t l2_allowance = (est / CH / L2_ITEM_CHUNKS + (1ull << h->bits1) + 1) * (1ull << max_part_bits(h->W)) + (uint64_t)part_grid(h) * 512;
+		const uint64_t l2_allowance = (est / CH / L2_ITEM_CHUNKS + (1ull << h->bits1) + 1) * (1ull << max_part_bits(h)) + (uint64_t)part_grid(h) * 512;
 		{	/* what only kmr_finalize uses (entry buffers) is dead during a build: released if the pool would not fit beside it */
 			const uint64_t chunks = est / CH + launches * (uint64_t)grid * ((1ull << h->bits1) + 512) + 64 + l2_allowance;
 			size_t mfree = 0, mtotal = 0;
 			if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)mfree < (double)chunks * CH * rec_bytes(h) * 1.02 + (double)(2ull << 30)) {
 				HIPCHK(h, hipStreamSynchronize(h->stream));
-				if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8);
-				h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = nullptr; h->uw_cap = h->us_cap = 0;
+				if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt);
+				h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->uw_cap = h->us_cap = 0;
 			}
 		}
 		uint64_t want = est / CH + launches * (uint64_t)grid * ((1ull << h->bits1) + 512) + 64 + l2_allowance;
@@ -739,21 +739,21 @@ template <int W> int partition_level1(kmr_handle *h, const Record<W> *linear, co
 	S.valid_counter = valid_counter; S.kb = h->kb; S.rot = part_rot(h); S.packed_words = packed_words; S.ordinal_base = ordinal_base;
 	static const bool keep_state = !getenv("KMR_NO_L1_STATE");
 	if (keep_state) {
-		rc = ensure_l1_state<W>(h); if (rc) return rc;
+		rc = ensure_l1_state<W, EXT>(h); if (rc) return rc;
 		S.state = h->l1_state; S.state_final = 0; h->l1_state_dirty = true;
 	}
 	hipEvent_t ta, tb; time_begin(h, KMR_TIME_PARTITION1, &ta, &tb);
-	rc = launch_partition<W, 1>(h, S, h->l1, grid, h->bits1, 0);
+	rc = launch_partition<W, EXT, 1>(h, S, h->l1, grid, h->bits1, 0);
 	time_end(h, KMR_TIME_PARTITION1, ta, tb);
 	return rc;
 }
 
 void choose_bits1(kmr_handle *h, uint64_t records_hint) {
-	/* total bits aim at TARGET_LIST_RECORDS per final list; level 2 takes up to max_part_bits(W) of them.  Two of
+	/* total bits aim at TARGET_LIST_RECORDS per final list; level 2 takes up to max_part_bits(h) of them.  Two of
 	 * those are held back: if most k-mers turn out to be distinct the lists have to be up to 4x smaller (see the
 	 * distinct probe in finalize_partition_t). */
 	uint64_t est = std::max<uint64_t>(records_hint, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
-	const int mb = max_part_bits(h->W);
+	const int mb = max_part_bits(h);
 	int T = 0; while (T < 2 * mb && (est >> T) > TARGET_LIST_RECORDS) T++;
 	h->bits1 = std::max(0, std::min(mb, T + 2 - mb));
 }
@@ -781,18 +781,18 @@ template <int W, bool EXT> int extract_by_owner_t(kmr_handle *h, const ReadsView
 		const uint64_t tiles = (nu + 63) / 64;
 		rc = ensure_buf(h, h->linear, h->linear_cap, total_cap, rec_bytes(h)); if (rc) return rc;
 		rc = ensure_buf(h, h->tile_count, h->tile_cap, tiles, 4); if (rc) return rc;
-		LinearOp<W, EXT, false> op; op.records = (Record<W> *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
+		LinearOp<W, EXT, false> op; op.records = (typename PoolRec<W, EXT>::type *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
 		rc = launch_extract<W, EXT>(h, rv, op); if (rc) return rc;
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 8, tiles);
-		hipLaunchKernelGGL((owner_scatter_kernel<W, EXT>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const Record<W> *)h->linear, h->koff, h->tile_count, tiles, h->kb,
+		hipLaunchKernelGGL((owner_scatter_kernel<W, EXT>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->kb,
 		                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr);
 		HIPCHK(h, hipGetLastError());
 	}
 	return 0;
 }
 
-template <int W> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
+template <int W, bool EXT> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
 	const uint64_t n = rvAll.n_reads;
 	if (!h->l1.head) choose_bits1(h, total_bases);
 	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
@@ -817,20 +817,21 @@ template <int W> int add_reads_partition_t(kmr_handle *h, const ReadsView &rvAll
 		const uint64_t tiles = (nu + 63) / 64;
 		rc = ensure_buf(h, h->linear, h->linear_cap, total_cap, rec_bytes(h)); if (rc) return rc;
 		rc = ensure_buf(h, h->tile_count, h->tile_cap, tiles, 4); if (rc) return rc;
-		LinearOp<W, false> op; op.records = (Record<W> *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
+		LinearOp<W, EXT> op; op.records = (typename PoolRec<W, EXT>::type *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
 		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b);
 		time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
-		rc = launch_extract<W, false>(h, rv, op);
+		rc = launch_extract<W, EXT>(h, rv, op);
 		time_end(h, KMR_TIME_EXTRACT, a2, b2);
-		if (!rc) rc = partition_level1<W>(h, (const Record<W> *)h->linear, h->koff, h->tile_count, tiles, 64, 0, 0, total_cap);
+		if (!rc) rc = partition_level1<W, EXT>(h, h->linear, h->koff, h->tile_count, tiles, 64, 0, 0, total_cap);
 		time_end(h, KMR_TIME_BUILD, a, b);
 		if (rc) return rc;
 	}
 	return 0;
 }
 int add_reads_partition(kmr_handle *h, const ReadsView &rv, uint64_t total_bases) {
-	switch (h->W) { case 1: return add_reads_partition_t<1>(h, rv, total_bases); case 2: return add_reads_partition_t<2>(h, rv, total_bases);
-	case 3: return add_reads_partition_t<3>(h, rv, total_bases); default: return add_reads_partition_t<4>(h, rv, total_bases); }
+#define ARP(Wv) (h->ext ? add_reads_partition_t<Wv, true>(h, rv, total_bases) : add_reads_partition_t<Wv, false>(h, rv, total_bases))
+	switch (h->W) { case 1: return ARP(1); case 2: return ARP(2); case 3: return ARP(3); default: return ARP(4); }
+#undef ARP
 }
 
 /* chunk CSR of a pool: list_start[nl+1] (device) and list_chunks[n_chunks] (device) */
@@ -862,12 +863,14 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint32_t first, uint64_t 
 		int bits = 0; while ((1ull << bits) < nl) bits++;
 		HIPCHK(h, hipMalloc((void **)&v, 24)); HIPCHK(h, hipMemset(v, 0, 24));
 		PoolView pvw = pool_view(h, p);
+#define VLK(Wv, E) hipLaunchKernelGGL((verify_lists_kernel<Wv, E>), dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2)
 		switch (h->W) {
-		case 1: hipLaunchKernelGGL(verify_lists_kernel<1>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2); break;
-		case 2: hipLaunchKernelGGL(verify_lists_kernel<2>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2); break;
-		case 3: hipLaunchKernelGGL(verify_lists_kernel<3>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2); break;
-		default: hipLaunchKernelGGL(verify_lists_kernel<4>, dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2); break;
+		case 1: if (h->ext) VLK(1, true); else VLK(1, false); break;
+		case 2: if (h->ext) VLK(2, true); else VLK(2, false); break;
+		case 3: if (h->ext) VLK(3, true); else VLK(3, false); break;
+		default: if (h->ext) VLK(4, true); else VLK(4, false); break;
 		}
+#undef VLK
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		HIPCHK(h, hipMemcpy(vv, v, 24, hipMemcpyDeviceToHost)); hipFree(v);
 		fprintf(stderr, "verify_lists: records via CSR %llu misfiled %llu zero-weight %llu\n", vv[0], vv[1], vv[2]);
@@ -877,16 +880,16 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint32_t first, uint64_t 
 
 int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing);
 
-template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
+template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	int rc = sync_state(h);
 	if (rc) return rc;
 	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
 	const uint64_t G = h->stats.raw_good_kmers;     /* records in the level-1 pool */
-	FinalizeParams f; f.kb = h->kb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	FinalizeParams f; f.kb = h->kb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
 	rc = arena_reset(h); if (rc) return rc;
-	rc = flush_l1_state<W>(h); if (rc) return rc;
+	rc = flush_l1_state<W, EXT>(h); if (rc) return rc;
 	/* level-1 CSR */
 	const uint64_t nl1 = 1ull << h->bits1;
 	uint64_t *ls1 = nullptr; uint64_t *lc1 = nullptr; uint32_t nch1 = 0;
@@ -902,14 +905,14 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		const size_t tbytes = 8 * ((size_t)n_probes * PROBE_SLOTS + 4);
 		rc = arena_alloc(h, (void **)&dpr, tbytes); if (rc) return rc;
 		HIPCHK(h, hipMemsetAsync(dpr, 0, tbytes, h->stream));
-		hipLaunchKernelGGL(distinct_probe_kernel<W>, dim3(n_probes * PROBE_SPLIT), dim3(256), 0, h->stream, pool_view(h, h->l1), ls1, lc1, nl1, h->kb, part_rot(h),
+		hipLaunchKernelGGL((distinct_probe_kernel<W, EXT>), dim3(n_probes * PROBE_SPLIT), dim3(256), 0, h->stream, pool_view(h, h->l1), ls1, lc1, nl1, h->kb, part_rot(h),
 		                   (int)h->bits1, n_probes, dpr + 4, dpr);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipMemcpyAsync(hpr, dpr, 32, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
 		if (hpr[0] >= 256) { distinct_share = std::min(1.0, std::max(0.01, (double)hpr[1] / (double)hpr[0])); repeated_share = std::min(0.5, (double)hpr[2] / (double)hpr[0]); }
 		if (getenv("KMR_DEBUG")) fprintf(stderr, "distinct probe: %llu records, %llu distinct (%llu repeated) -> shares %.3f %.3f\n", hpr[0], hpr[1], hpr[2], distinct_share, repeated_share);
 	}
-	const int mb = max_part_bits(W);
+	const int mb = max_part_bits(h);
 	int T = 0; while (T < 40 && ((G >> T) > TARGET_LIST_RECORDS || (double)(G >> T) * distinct_share > MAX_LIST_DISTINCT)) T++;
 	T = std::min(T, 28);                              /* list ids are 32-bit with room to spare */
 	int cur_bits = h->bits1;
@@ -949,7 +952,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		const int grid = (int)std::min<uint64_t>(partition_blocks(h), ib.size());
 		if (getenv("KMR_DEBUG")) fprintf(stderr, "level %d: %d bits after %d, %zu items, %s\n", level, nbits, cur_bits, ib.size(), recycle ? "recycling chunks" : "fresh chunks");
 		hipEvent_t ta, tb; time_begin(h, KMR_TIME_PARTITION2, &ta, &tb);
-		rc = launch_partition<W, 2>(h, S, h->l1, grid, nbits, cur_bits);
+		rc = launch_partition<W, EXT, 2>(h, S, h->l1, grid, nbits, cur_bits);
 		time_end(h, KMR_TIME_PARTITION2, ta, tb);
 		if (rc) return rc;
 		HIPCHK(h, hipStreamSynchronize(h->stream));      /* the host vectors behind the item copies go out of scope */
@@ -960,9 +963,9 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		rc = build_csr(h, h->l1, 1ull << cur_bits, valid_from, &ls2, &lc2, &nch1); if (rc) return rc;
 	}
 	const uint64_t nl2 = 1ull << cur_bits;
-	const int count_log2s = (double)(G >> cur_bits) * distinct_share > MAX_LIST_DISTINCT ? 11 : COUNT_LOG2S;
+	const int count_log2s = (!EXT && (double)(G >> cur_bits) * distinct_share > MAX_LIST_DISTINCT) ? 11 : COUNT_LOG2S;      /* with extension tallies 2048 slots do not fit LDS */
 	if (getenv("KMR_DEBUG")) fprintf(stderr, "count pass: %llu lists of ~%llu records, table 2^%d\n", (unsigned long long)nl2, (unsigned long long)(G >> cur_bits), count_log2s);
-	const uint32_t vw = 3;
+	const uint32_t vw = EXT ? 15 : 3;
 	const uint64_t slack = (uint64_t)part_grid(h) * 8 * 8192 + 16;     /* one partly used output slab per block */
 	/* entry buffers: the worst case (every second record a weak entry, or every record a singleton) is 5-10 x what
 	 * sequencing data produces, and at C4 size it is 70 GB; they are sized from the probe's shares with 50 % headroom and
@@ -974,7 +977,7 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		const double sh = atof(getenv("KMR_ENTRY_SHARE"));
 		wcap = std::min<uint64_t>(wmax, (uint64_t)((double)G * sh) + 16384); if (keepSing) scap = std::min<uint64_t>(smax, (uint64_t)((double)G * sh) + 16384);
 		if (h->uw_keys) { hipFree(h->uw_keys); hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0; }
-		if (h->us_keys) { hipFree(h->us_keys); hipFree(h->us_b8); h->us_keys = h->us_b8 = nullptr; h->us_cap = 0; }
+		if (h->us_keys) { hipFree(h->us_keys); hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0; }
 	}
 	if (h->uw_keys && h->uw_cap >= wcap) wcap = h->uw_cap;
 	if (h->us_keys && h->us_cap >= scap) scap = h->us_cap;
@@ -997,13 +1000,13 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, hipMalloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
 	}
 	if (!h->us_keys || h->us_cap < scap) {
-		if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); h->us_keys = h->us_b8 = nullptr; h->us_cap = 0;
-		HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); h->us_cap = scap;
+		if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0;
+		HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); if (EXT) HIPCHK(h, hipMalloc(&h->us_pkt, 4 * scap)); h->us_cap = scap;
 	}
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
 	HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
 	CountOut out; out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wcursor = cursors; out.wcap = h->uw_cap;
-	out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = nullptr; out.scursor = cursors + 1; out.scap = h->us_cap;
+	out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = (uint32_t *)h->us_pkt; out.scursor = cursors + 1; out.scap = h->us_cap;
 	out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
 	rc = zero_work_counter(h); if (rc) return rc;
 	const int count_reps = getenv("KMR_COUNT_CHECK") ? atoi(getenv("KMR_COUNT_CHECK")) : 0;
@@ -1020,13 +1023,13 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 		}
 		const int grid = (int)std::min<uint64_t>((uint64_t)part_grid(h) * 2, nl2);
 		if (count_log2s == 11) {
-			auto kern = count_kernel<W, false, 11>;
-			const size_t smem = count_smem_bytes<W, 11>();
+			auto kern = count_kernel<W, EXT, 11>;
+			const size_t smem = count_smem_bytes<W, EXT, 11>();
 			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter);
 		} else {
-			auto kern = count_kernel<W, false, COUNT_LOG2S>;
-			const size_t smem = count_smem_bytes<W, COUNT_LOG2S>();
+			auto kern = count_kernel<W, EXT, COUNT_LOG2S>;
+			const size_t smem = count_smem_bytes<W, EXT, COUNT_LOG2S>();
 			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter);
 		}
@@ -1055,12 +1058,16 @@ template <int W> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	h->has_singletons = keepSing;
 	h->stats.weak_entries = h->weak.n; h->stats.singleton_entries = keepSing ? h->sing.n : 0;
 	h->finalized = true;
-	return sync_state(h);
+	rc = sync_state(h);
+	/* the temporaries are dead: if some of them had to be allocated on the side, the arena is brought to size now,
+	 * so that it is this build (a handle's first) that pays for it and not the next one */
+	if (!rc && !h->arena_overflow.empty()) rc = arena_reset(h);
+	return rc;
 }
 
 /* unsorted kept entries (h->uw_*, h->us_*) + per-bucket counts -> bucketed sorted maps */
 template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing) {
-	const uint32_t vw = 3;
+	const uint32_t vw = h->ext ? 15 : 3;
 	DevMap &wm = h->weak, &sm = h->sing;
 	clear_map(wm); clear_map(sm);          /* the buffers of the previous build are reused when they are large enough */
 	wm.nb = h->nb_weak; wm.n = wn; wm.present = true;
@@ -1073,16 +1080,18 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 	rc = reserve_bytes(h, (void **)&wm.vals, wm.c_vals, 4ull * vw * wm.n); if (rc) return rc;
 	rc = reserve_bytes(h, (void **)&sm.keys, sm.c_keys, 8ull * W * sm.n); if (rc) return rc;
 	rc = reserve_bytes(h, (void **)&sm.sweight, sm.c_sw, sm.n); if (rc) return rc;
+	if (h->ext) { rc = reserve_bytes(h, (void **)&sm.spkt, sm.c_pkt, 4 * sm.n); if (rc) return rc; }
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * sm.nb, h->stream));
 	if (wm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
 	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->kb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
 	if (sm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(sslots)), dim3(256), 0, h->stream, (const uint64_t *)h->us_keys, (const uint32_t *)nullptr,
-	                            (const uint8_t *)h->us_b8, (const uint32_t *)nullptr, sslots, 0u, h->kb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, (uint32_t *)nullptr);
+	                            (const uint8_t *)h->us_b8, (const uint32_t *)h->us_pkt, sslots, 0u, h->kb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, h->ext ? sm.spkt : (uint32_t *)nullptr);
 	HIPCHK(h, hipGetLastError());
 	SortView<W> sv; sv.keys = wm.keys; sv.vals = wm.vals; sv.b8 = nullptr; sv.pkt = nullptr; sv.vw = vw;
-	hipLaunchKernelGGL((sort_buckets_kernel<W, 3>), dim3(grid_for(wm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, wm.start, wm.nb);
+	if (h->ext) hipLaunchKernelGGL((sort_buckets_kernel<W, 15>), dim3(grid_for(wm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, wm.start, wm.nb);
+	else hipLaunchKernelGGL((sort_buckets_kernel<W, 3>), dim3(grid_for(wm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, wm.start, wm.nb);
 	if (sm.n) {
-		SortView<W> ss; ss.keys = sm.keys; ss.vals = nullptr; ss.b8 = sm.sweight; ss.pkt = nullptr; ss.vw = 0;
+		SortView<W> ss; ss.keys = sm.keys; ss.vals = nullptr; ss.b8 = sm.sweight; ss.pkt = h->ext ? sm.spkt : nullptr; ss.vw = 0;
 		hipLaunchKernelGGL((sort_buckets_kernel<W, 0>), dim3(grid_for(sm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, ss, sm.start, sm.nb);
 	}
 	HIPCHK(h, hipGetLastError());
@@ -1094,21 +1103,23 @@ int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t
 	case 3: return finish_maps_t<3>(h, wc, sc, wslots, sslots, wn, sn, keepSing); default: return finish_maps_t<4>(h, wc, sc, wslots, sslots, wn, sn, keepSing); }
 }
 int finalize_partition(kmr_handle *h, uint32_t min_depth) {
-	switch (h->W) { case 1: return finalize_partition_t<1>(h, min_depth); case 2: return finalize_partition_t<2>(h, min_depth);
-	case 3: return finalize_partition_t<3>(h, min_depth); default: return finalize_partition_t<4>(h, min_depth); }
+#define FPT(Wv) (h->ext ? finalize_partition_t<Wv, true>(h, min_depth) : finalize_partition_t<Wv, false>(h, min_depth))
+	switch (h->W) { case 1: return FPT(1); case 2: return FPT(2); case 3: return FPT(3); default: return FPT(4); }
+#undef FPT
 }
-template <int W> int insert_records_partition_t(kmr_handle *h, const void *recs, uint64_t n) {
+template <int W, bool EXT> int insert_records_partition_t(kmr_handle *h, const void *recs, uint64_t n) {
 	if (!h->l1.head) choose_bits1(h, n);
 	hipEvent_t a, b; time_begin(h, 0, &a, &b);
 	/* received segments contain holes (weight 0): the device counts the real records into stats.raw/good */
-	int rc = partition_level1<W>(h, (const Record<W> *)recs, nullptr, nullptr, (n + 8191) / 8192, 0, 8192, n, n, &h->dstats->inserted,
+	int rc = partition_level1<W, EXT>(h, recs, nullptr, nullptr, (n + 8191) / 8192, 0, 8192, n, n, &h->dstats->inserted,
 	                             2 * W + (h->ext ? 2 : 1), h->stream_base);
 	time_end(h, 0, a, b);
 	return rc;
 }
 int insert_records_partition(kmr_handle *h, const void *recs, uint64_t n) {
-	switch (h->W) { case 1: return insert_records_partition_t<1>(h, recs, n); case 2: return insert_records_partition_t<2>(h, recs, n);
-	case 3: return insert_records_partition_t<3>(h, recs, n); default: return insert_records_partition_t<4>(h, recs, n); }
+#define IRP(Wv) (h->ext ? insert_records_partition_t<Wv, true>(h, recs, n) : insert_records_partition_t<Wv, false>(h, recs, n))
+	switch (h->W) { case 1: return IRP(1); case 2: return IRP(2); case 3: return IRP(3); default: return IRP(4); }
+#undef IRP
 }
 void free_partition_state(kmr_handle *h) {
 	pool_free(h->l1);
@@ -1120,8 +1131,8 @@ void free_partition_state(kmr_handle *h) {
 	if (h->kcap) hipFree(h->kcap); if (h->koff) hipFree(h->koff);
 	if (h->ucnt) hipFree(h->ucnt); if (h->ufirst) hipFree(h->ufirst); if (h->u_start) { hipFree(h->u_start); hipFree(h->u_end); hipFree(h->u_read); } if (h->umax) hipFree(h->umax);
 	h->ucnt = nullptr; h->ufirst = nullptr; h->u_start = h->u_end = h->u_read = nullptr; h->umax = nullptr; h->ucnt_n = h->ufirst_n = h->units_n = 0;
-	if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8);
-	h->work_counter = nullptr; h->linear = nullptr; h->tile_count = nullptr; h->kcap = nullptr; h->koff = nullptr;
+	if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt);
+	h->us_pkt = nullptr; h->work_counter = nullptr; h->linear = nullptr; h->tile_count = nullptr; h->kcap = nullptr; h->koff = nullptr;
 	h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = nullptr; h->linear_cap = h->tile_cap = h->kcap_n = h->koff_n = h->uw_cap = h->us_cap = 0;
 }
 
@@ -1184,8 +1195,8 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 		if (hipMalloc((void **)&h->dP, sizeof(P)) != hipSuccess || hipMalloc((void **)&h->dstats, sizeof(DevStats)) != hipSuccess || hipMalloc((void **)&h->derr, 4) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
 		hipMemcpy(h->dP, P, sizeof(P), hipMemcpyHostToDevice); hipMemset(h->dstats, 0, sizeof(DevStats)); hipMemset(h->derr, 0, 4);
 		/* build_mode: 0 auto (streaming partition path unless EXT values), 1 table, 2 partition */
-		if (cfg->build_mode > 2 || (cfg->build_mode == 2 && h->ext)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 2 (partition) does not carry extension tallies yet"); break; }
-		h->partition_mode = cfg->build_mode == 2 || (cfg->build_mode == 0 && !h->ext);
+		if (cfg->build_mode > 2) { rc = fail(nullptr, KMR_ERR_INVALID_ARG, "bad build_mode"); break; }
+		h->partition_mode = cfg->build_mode != 1;
 		if (!h->partition_mode) {
 			rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
 			if (rc) { g_create_error = h->err; break; }

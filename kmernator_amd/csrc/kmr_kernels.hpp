@@ -290,6 +290,22 @@ template <int W> struct Record {
 	float w;
 	uint32_t pkt;
 };
+/* record of the streaming path with extension values: the packet AND the stream ordinal travel (24 bytes at k <= 32) */
+template <int W> struct RecordX {
+	uint64_t key[W];
+	float w;
+	uint32_t pkt;
+	uint32_t ord;
+	uint32_t pad;
+};
+template <int W, bool EXT> struct PoolRec { typedef Record<W> type; };
+template <int W> struct PoolRec<W, true> { typedef RecordX<W> type; };
+template <int W> __device__ __forceinline__ uint32_t rec_ordinal(const Record<W> &r) { return r.pkt; }
+template <int W> __device__ __forceinline__ uint32_t rec_ordinal(const RecordX<W> &r) { return r.ord; }
+template <int W> __device__ __forceinline__ void rec_set(Record<W> &r, uint32_t pkt, uint32_t ord) { r.pkt = ord; (void)pkt; }
+template <int W> __device__ __forceinline__ void rec_set(RecordX<W> &r, uint32_t pkt, uint32_t ord) { r.pkt = pkt; r.ord = ord; r.pad = 0; }
+/* ExtensionTracking::trackExtension on a packet (src/KmerTrackingData.h:195-201): tally index 0..11 or -1 */
+__device__ __forceinline__ int ext_tally_index(uint32_t ch) { switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'X': return 5; default: return 4; } }
 
 /* ----------------------------------------------------------------------- */
 /* finalized map on the device: bucketed, keys sorted inside each bucket      */
@@ -778,6 +794,7 @@ __global__ void rehash_kernel(Table<W> src, Table<W> dst, uint32_t kb, uint32_t 
 /* finalize: table -> bucketed maps                                           */
 struct FinalizeParams {
 	uint32_t kb;
+	uint32_t ext_min_q;           /* ExtensionTracking::getMinQuality (streaming path with extension values) */
 	uint32_t min_depth;
 	uint32_t has_singletons;      /* cfg.separate_singletons */
 	uint64_t nb_weak, nb_sing;

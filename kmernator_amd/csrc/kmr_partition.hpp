@@ -86,7 +86,8 @@ template <int W> __host__ __device__ __forceinline__ uint64_t part_order(const u
  * k-mer capacities) and appends its good records there, wave-compacted; tile_count
  * says how many it wrote. */
 template <int W, bool EXT, bool STATS = true> struct LinearOp {
-	Record<W> *records;
+	typedef typename PoolRec<W, EXT>::type Rec;
+	Rec *records;
 	const uint64_t *koff;          /* [n_reads+1] */
 	uint32_t *tile_count;          /* [n_tiles] */
 	uint64_t first_read_idx;
@@ -110,11 +111,11 @@ template <int W, bool EXT, bool STATS = true> struct LinearOp {
 		const int lane = (int)(threadIdx.x & 63);
 		if (valid) {
 			const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
-			Record<W> r;
+			Rec r;
 #pragma unroll
 			for (int i = 0; i < W; i++) r.key[i] = key.w[i];
 			r.w = o.forward ? o.w : -o.w;
-			r.pkt = EXT ? o.pkt : (uint32_t)o.ordinal;
+			rec_set<W>(r, o.pkt, (uint32_t)o.ordinal);
 			(records + (st.base + st.n))[rank] = r;
 		}
 		st.n += (uint32_t)__builtin_popcountll(mask);
@@ -133,14 +134,14 @@ template <int W, bool EXT, bool STATS> __device__ __forceinline__ uint32_t op_fa
 static const int OSEG = 2048, OWNER_THREADS = 256, OWNER_MAX = 8;
 template <int W, bool EXT>
 __global__ __launch_bounds__(OWNER_THREADS)
-void owner_scatter_kernel(const Record<W> *linear, const uint64_t *koff, const uint32_t *tile_count, uint64_t n_tiles, uint32_t kb, uint32_t world,
+void owner_scatter_kernel(const typename PoolRec<W, EXT>::type *linear, const uint64_t *koff, const uint32_t *tile_count, uint64_t n_tiles, uint32_t kb, uint32_t world,
                           uint32_t *out, uint64_t seg_capacity, unsigned long long *seg_counts, unsigned int *work_counter, uint32_t *err) {
 	constexpr uint32_t RW = 2 * W + (EXT ? 2 : 1);      /* dwords of a wire record (KMR_RECORD_BYTES) */
 	/* One block per tile of the linear buffer, in pieces of OSEG records that are read from HBM once and held in
 	 * registers: every thread hashes its records and takes a rank per owner from an LDS counter, one thread per owner
 	 * reserves the piece's run in that owner's segment with ONE device atomic, and every thread stores its records at
 	 * (run base + rank): the stores of a piece fill one contiguous run per owner. */
-	typedef Record<W> Rec;
+	typedef typename PoolRec<W, EXT>::type Rec;
 	__shared__ uint32_t s_cnt[OWNER_MAX];
 	__shared__ unsigned long long s_base[OWNER_MAX];
 	__shared__ uint32_t s_tile;
@@ -220,7 +221,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 /* ------------------------------------------------------------------ partition */
 template <int W> struct PartSource {
 	/* LEVEL 1: extents of a linear record buffer */
-	const Record<W> *linear;
+	const void *linear;            /* PoolRec<W, EXT>::type records, or wire records (packed_words) */
 	const uint64_t *ext_start;     /* per extent: first record (NULL: uniform extents of ext_len) */
 	const uint32_t *ext_count;     /* per extent: valid records   (NULL with uniform extents)     */
 	uint64_t n_ext, ext_len, total;
@@ -250,8 +251,8 @@ template <int W> struct PartSource {
 	uint32_t recycle;
 };
 
-template <int W, int G> __host__ __device__ inline size_t partition_state_bytes(int bits) {
-	return ((((size_t)3 << bits) * 4 + 15) & ~(size_t)15) + ((size_t)G << bits) * sizeof(Record<W>);
+template <int W, bool EXT, int G> __host__ __device__ inline size_t partition_state_bytes(int bits) {
+	return ((((size_t)3 << bits) * 4 + 15) & ~(size_t)15) + ((size_t)G << bits) * sizeof(typename PoolRec<W, EXT>::type);
 }
 /* empty state: no open chunk, nothing waiting */
 __global__ void partition_state_init_kernel(uint8_t *state, size_t stride, int bits, uint32_t n_blocks) {
@@ -275,20 +276,20 @@ __global__ void partition_state_init_kernel(uint8_t *state, size_t stride, int b
  * block is 1024 threads wide: the number of (block, list) write streams, which is what HBM efficiency of this
  * scatter depends on, stays at CUs * lists.  Measured on MI355X at 1024 lists and 16-byte records: 2.0 ms per
  * 2e8 records against 3.1 ms for an LDS-sorted 4096-record batch with two blocks per CU (tools/part_bench.hip). */
-template <int W, int THREADS, int RPT, int G>
+template <int W, bool EXT, int THREADS, int RPT, int G>
 __host__ __device__ inline size_t partition_direct_smem_bytes(int bits) {
 	return ((size_t)1 << bits) * 4 * (G ? 8 : 6)                               /* hist, cur, cnt, pos0, c0, xoff (, stage_n, stage_plan) */
 	       + ((size_t)THREADS * RPT / CH + ((size_t)1 << bits) + 8) * 4        /* chunks opened by one batch beyond the first */
-	       + ((size_t)G << bits) * sizeof(Record<W>)                            /* write-combining line of every list */
+	       + ((size_t)G << bits) * sizeof(typename PoolRec<W, EXT>::type)       /* write-combining line of every list */
 	       + 64;
 }
 
-template <int W, int LEVEL, int THREADS, int RPT, int G>
+template <int W, bool EXT, int LEVEL, int THREADS, int RPT, int G>
 __global__ __launch_bounds__(THREADS)
 void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_counter, const int LOG2P, const int SHIFT) {
 	const int P = 1 << LOG2P;
 	constexpr int BATCH = THREADS * RPT;
-	typedef Record<W> Rec;
+	typedef typename PoolRec<W, EXT>::type Rec;
 	extern __shared__ __attribute__((aligned(16))) uint8_t psm[];
 	uint32_t *hist = (uint32_t *)psm;
 	uint32_t *cur = hist + P;         /* open chunk of each list (NO_CHUNK if none)          */
@@ -312,7 +313,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 
 	uint32_t *gstate = nullptr; Rec *glines = nullptr;
 	if (LEVEL == 1 && G && S.state) {
-		gstate = (uint32_t *)(S.state + (size_t)blockIdx.x * partition_state_bytes<W, G>(LOG2P));
+		gstate = (uint32_t *)(S.state + (size_t)blockIdx.x * partition_state_bytes<W, EXT, G>(LOG2P));
 		glines = (Rec *)((uint8_t *)gstate + ((((size_t)3 << LOG2P) * 4 + 15) & ~(size_t)15));
 	}
 	if (gstate) {
@@ -465,8 +466,8 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 #pragma unroll
 							for (int j = 0; j < W; j++) rr[i].key[j] = (uint64_t)p32[2 * j] | ((uint64_t)p32[2 * j + 1] << 32);
 							rr[i].w = __uint_as_float(p32[2 * W]);
-							rr[i].pkt = S.packed_words > 2u * W + 1u ? p32[2 * W + 1] : (uint32_t)(S.ordinal_base + ri);
-						} else rr[i] = S.linear[ri];
+							rec_set<W>(rr[i], S.packed_words > 2u * W + 1u ? p32[2 * W + 1] : 0u, (uint32_t)(S.ordinal_base + ri));      /* arrival ordinal */
+						} else rr[i] = ((const Rec *)S.linear)[ri];
 						if (rr[i].w != 0.0f) { pp[i] = pid_of(rr[i]); nvalid++; }
 					}
 				}
@@ -645,11 +646,11 @@ __global__ void pool_records_kernel(const uint32_t *chunk_list, const uint32_t *
  * included -- and count them and their distinct 64-bit fingerprints in a small table in device memory (few records
  * pass the filter, so its atomics are few).  out[0] += records, out[1] += distinct, out[2] += distinct keys seen more than once. */
 static const int PROBE_SLOTS = 8192, PROBE_SPLIT = 16, PROBE_LISTS = 64;
-template <int W>
+template <int W, bool EXT>
 __global__ __launch_bounds__(256)
 void distinct_probe_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t kb, uint32_t rot,
                            int bits1, uint32_t n_probes, unsigned long long *tables /* [n_probes][PROBE_SLOTS], zero */, unsigned long long *out) {
-	typedef Record<W> Rec;
+	typedef typename PoolRec<W, EXT>::type Rec;
 	const uint32_t p = blockIdx.x / PROBE_SPLIT, part = blockIdx.x % PROBE_SPLIT;
 	const uint64_t l = (uint64_t)p * n_lists / n_probes;
 	const uint64_t c0 = list_start[l], c1 = list_start[l + 1];
@@ -691,10 +692,10 @@ void distinct_probe_kernel(PoolView pool, const uint64_t *list_start, const uint
 
 /* debugging aid (KMR_DEBUG): walk a pool through its chunk CSR; count the records and those whose partition hash
  * does not match the list they are filed under */
-template <int W>
+template <int W, bool EXT>
 __global__ void verify_lists_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, int bits, uint32_t kb, uint32_t rot,
                                     unsigned long long *total, unsigned long long *misfiled, unsigned long long *zero_w) {
-	typedef Record<W> Rec;
+	typedef typename PoolRec<W, EXT>::type Rec;
 	unsigned long long n = 0, bad = 0, zw = 0;
 	for (uint64_t l = blockIdx.x; l < n_lists; l += gridDim.x) {
 		for (uint64_t ci = list_start[l] + (threadIdx.x >> 6); ci < list_start[l + 1]; ci += blockDim.x >> 6) {
@@ -742,25 +743,27 @@ struct CountOut {
 	uint32_t *err;
 };
 
-template <int W, int LOG2S>
-__host__ __device__ constexpr size_t count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0)); }
+template <int W, bool EXT, int LOG2S>
+__host__ __device__ constexpr size_t count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (EXT ? 52 : 0)); }
 
 /* One block per final list.  LDS table: keys, count|fwd<<32, f64 weight sum, first
  * (ordinal<<1|fwd).  If the table would overflow the list is split by further hash bits
  * and done in sub-passes (a tiny LDS stack), so any input is handled. */
 template <int W, bool EXT, int LOG2S>
-__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10) ? 4 : 1)      /* W == 1: four blocks per CU (<= 128 VGPRs, < 40 KB LDS each) */
+__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && !EXT && LOG2S <= 10) ? 4 : 1)      /* W == 1: four blocks per CU (<= 128 VGPRs, < 40 KB LDS each) */
 void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists,
                   CountOut out, FinalizeParams f, unsigned int *work_counter) {
 	constexpr int S = 1 << LOG2S;
 	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
-	typedef Record<W> Rec;
+	typedef typename PoolRec<W, EXT>::type Rec;
 	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
 	uint64_t *tkeys = (uint64_t *)csm;                                 /* [S][W] */
 	unsigned long long *tcnt = (unsigned long long *)(tkeys + (size_t)S * W);
 	double *twsum = (double *)(tcnt + S);
 	unsigned long long *tfirst = (unsigned long long *)(twsum + S);
 	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
+	uint32_t *ttally = tstate + (W > 1 ? S : 0);                       /* EXT: [S][12] extension tallies, then [S] one packet */
+	uint32_t *tpkt = ttally + (EXT ? 12 * S : 0);
 	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns;
 	__shared__ unsigned long long s_wbase, s_sbase;
 	/* output space is taken from the global cursors one slab at a time (a per-list atomic on one word would
@@ -834,6 +837,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 			lds_barrier();
 			if (t == 0) { s_sp--; s_claimed = 0; s_overflow = 0; s_nw = 0; s_ns = 0; }
 			for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; }
+			if (EXT) for (int i = t; i < 12 * S; i += COUNT_THREADS) ttally[i] = 0;
 			lds_barrier();
 			const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
 			/* insert: wave w takes chunks cb + w, + waves, ...; lane = record */
@@ -909,7 +913,14 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 				const float wa = fwd ? r.w : -r.w;
 				atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(fwd ? 1 : 0) << 32));
 				atomicAdd(&twsum[s], (double)wa);
-				atomicMin(&tfirst[s], ((unsigned long long)r.pkt << 1) | (fwd ? 1ull : 0ull));
+				atomicMin(&tfirst[s], ((unsigned long long)rec_ordinal<W>(r) << 1) | (fwd ? 1ull : 0ull));
+				if constexpr (EXT) {      /* ExtensionTracking::trackExtension (src/KmerTrackingData.h:195-201) */
+					const int lc = ext_tally_index(r.pkt & 0xff), rc_ = ext_tally_index((r.pkt >> 8) & 0xff);
+					const uint32_t lq = (r.pkt >> 16) & 0xff, rq_ = r.pkt >> 24;
+					if (lq >= f.ext_min_q || lc > 3) atomicAdd(&ttally[(size_t)s * 12 + lc], 1u);
+					if (rq_ >= f.ext_min_q || rc_ > 3) atomicAdd(&ttally[(size_t)s * 12 + 6 + rc_], 1u);
+					tpkt[s] = r.pkt;      /* exact whenever the key ends with one occurrence, the only case it is read */
+				}
 				}
 				claimedHere = (uint32_t)wave_sum((unsigned long long)claimedHere);
 				if ((t & 63) == 0 && claimedHere) atomicAdd(&s_claimed, claimedHere);
@@ -999,6 +1010,10 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 						if (fwd > 65535u) fwd = 65535u;
 						uint32_t *v = out.wvals + pos * vw;
 						v[0] = cnt; v[1] = __float_as_uint((float)twsum[s]); v[2] = fwd;
+						if (EXT) {
+#pragma unroll
+							for (int j = 0; j < 12; j++) v[3 + j] = ttally[(size_t)s * 12 + j];
+						}
 					}
 					bucket_count_add(out.weakCount, bucket, live);
 				}
@@ -1017,6 +1032,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 						for (int j = 0; j < W; j++) out.skeys[pos * W + j] = key.w[j];
 						const float wf = (float)twsum[s];
 						out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
+						if (EXT) out.spkt[pos] = tpkt[s];
 					}
 					bucket_count_add(out.singCount, bucket, live);
 				}

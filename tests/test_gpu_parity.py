@@ -79,11 +79,12 @@ def run_both(cfg, rb, min_depth=2, batches=None, mode=0):
     return o, p
 
 
-def test_phix_meraculous_goldens(tmp_path):
+@pytest.mark.parametrize("mode", MODES)
+def test_phix_meraculous_goldens(tmp_path, mode):
     """Config 5: MeraculousCounter k=21 on 1000.fastq, text equal to the reference's goldens."""
     rb = read_fastq(os.path.join(GOLDEN, "1000.fastq"))
     cfg = default_config(21, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2, fastq_start_char=64, estimated_raw_kmers=56000)
-    o, p = run_both(cfg, rb)
+    o, p = run_both(cfg, rb, mode=mode)
     p.dumpCounts(str(tmp_path / "c"), 2)
     p.dumpGraphs(str(tmp_path / "g"), 2)
     for got, exp in (("c", "phix.mercount.m21"), ("g", "phix.mergraph.m21.D2")):
@@ -161,10 +162,11 @@ def test_singleton_map_and_min_depth_variants(mode):
             assert np.array_equal(so, sp_)      # 1-byte values: bit-exact, including the quantised weight
 
 
-def test_ext_singletons_and_image_reload():
-    rb = synth_reads(1500, read_len=90, seed=4, quality="noisy", n_rate=0.002)
-    cfg = default_config(19, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2, num_buckets_weak=256, num_buckets_singleton=256)
-    o, p = run_both(cfg, rb, min_depth=1)
+@pytest.mark.parametrize("mode,k", [(1, 19), (2, 19), (2, 41), (2, 95)])
+def test_ext_singletons_and_image_reload(mode, k):
+    rb = synth_reads(1500, read_len=110 if k > 32 else 90, seed=4, quality="noisy", n_rate=0.002)
+    cfg = default_config(k, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2, num_buckets_weak=256, num_buckets_singleton=256)
+    o, p = run_both(cfg, rb, min_depth=1, mode=mode)
     assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
     wimg = p.image(KMR_MAP_WEAK)
     compare_weak_images(o.image(KMR_MAP_WEAK), wimg, p.kb, True)
@@ -421,7 +423,8 @@ def test_reads_longer_than_a_tile_are_segmented(k, mode):
         assert np.array_equal(o.lookup(keys), counts[int(off[i]):int(off[i + 1])])
 
 
-def test_long_reads_with_extension_values():
+@pytest.mark.parametrize("mode", MODES)
+def test_long_reads_with_extension_values(mode):
     """Segments of a long read take the extension base outside their own span from the read (left neighbour of a
     later segment's first k-mer, right neighbour of an earlier segment's last k-mer): tallies stay bit-exact."""
     rng = np.random.default_rng(5)
@@ -439,12 +442,12 @@ def test_long_reads_with_extension_values():
         quals.append(qv[rng.choice(5, size=L, p=[0.70, 0.10, 0.10, 0.09, 0.01])].astype(np.uint8).tobytes())
     rb = ReadBatch(seqs, quals)
     cfg = default_config(21, value_kind=KMR_VALUE_EXT, num_buckets_weak=512, num_buckets_singleton=2048, min_weight=0.0, min_quality_score=2)
-    o, p = run_both(cfg, rb, min_depth=1)
+    o, p = run_both(cfg, rb, min_depth=1, mode=mode)
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, True)
     assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
 
 
-@pytest.mark.parametrize("k,ext,mode", [(31, False, 1), (31, False, 2), (21, True, 1), (51, False, 1), (51, False, 2)])
+@pytest.mark.parametrize("k,ext,mode", [(31, False, 1), (31, False, 2), (21, True, 1), (21, True, 2), (51, False, 1), (51, False, 2)])
 def test_extract_by_owner_and_insert_records(k, ext, mode):
     """The two device halves of the owner exchange (kmr_extract_by_owner_dev ->
     [all-to-all] -> kmr_insert_records_dev) with both 'ranks' on one GPU: each rank's

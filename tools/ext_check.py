@@ -1,0 +1,21 @@
+"""development tool: extension values (Meraculous) at scale, streaming vs device-table mode"""
+import sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import torch, numpy as np
+import bench, kmernator_amd as ka
+from helpers import KMR_MAP_WEAK, KMR_VALUE_EXT
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000000
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 21
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+bases, quals, offsets = bench.gen_reads(n, 5 * n, 3, 0, dev)
+torch.cuda.synchronize()
+imgs = {}
+for mode in (2, 1):
+    sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2))
+    for rep in range(2):
+        sp.reset(); torch.cuda.synchronize(); t0 = time.time()
+        sp.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
+        sp.finalize(2); dt = time.time() - t0
+    st = sp.stats(); print("mode", mode, "k", k, "%.1f ms" % (dt * 1e3), "%.2f G kmers/s" % (st["raw_kmers"] / dt / 1e9), st, flush=True)
+    imgs[mode] = sp.image(KMR_MAP_WEAK); del sp
+print("images identical:", np.array_equal(imgs[1], imgs[2]))
