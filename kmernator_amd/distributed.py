@@ -54,7 +54,9 @@ def all_ranks_chunk_count(n_local_chunks, group=None, device="cpu"):
     return int(t.item())
 
 
-MAX_CHUNK_BYTES = 1 << 30      # payload of one all-to-all per rank; collectives above 2 GiB are not trusted
+MAX_CHUNK_BYTES = 1 << 30      # payload of one all-to-all per rank.  Measured with tools/a2a_check.py (RCCL 2.26.6, one rank): a 1.0 GiB
+                               # message arrives intact, at 1.5 GiB half of the rows do not -- so no message may exceed 1 GiB,
+                               # although every chunk costs a counts exchange, a host round trip and a launch tail in level 1
 
 
 def _plan_chunks(offsets_host, n, rb, chunk_reads):
