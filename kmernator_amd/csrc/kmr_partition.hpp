@@ -878,13 +878,24 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 				}
 				for (; probe < S && !placed; ) {
 					if constexpr (W == 1) {
-						uint64_t curk = tkeys[s];
+						/* two slots per round trip: in a wavefront the longest probe sequence of 64 lanes sets the pace (about
+						 * four slots at this load), and every step of it is an LDS latency */
+						const uint32_t s2 = (s + 1) & (S - 1);
+						uint64_t curk = tkeys[s], nextk = tkeys[s2];
 						if (curk == EMPTY_KEY) {
 							const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)r.key[0]);
 							if (old == EMPTY_KEY) { claimedHere++; placed = true; break; }
 							curk = old;
 						}
 						if (curk == r.key[0]) { placed = true; break; }
+						/* slot s holds another key for good: slot s2 is next in this key's probe order */
+						s = s2; probe++;
+						if (nextk == EMPTY_KEY) {
+							const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)r.key[0]);
+							if (old == EMPTY_KEY) { claimedHere++; placed = true; break; }
+							nextk = old;
+						}
+						if (nextk == r.key[0]) { placed = true; break; }
 					} else {
 						/* state word: 0 empty, 1 being written, 2 ready (same protocol as the global table) */
 						uint32_t st = __hip_atomic_load(&tstate[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
