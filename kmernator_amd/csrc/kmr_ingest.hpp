@@ -36,6 +36,48 @@ static const uint32_t ING_VALIDATE_READS = 20000;        /* validateFastqStart: 
 
 __device__ __forceinline__ bool ing_is_start(const uint8_t *text, uint64_t p) { return (p == 0 || text[p - 1] == '\n') && text[p] != '\n'; }
 
+/* The ING_BYTES bytes of a thread and the byte in front of them: one 16-byte load when the text is 16-byte aligned and the
+ * chunk lies inside it, single bytes otherwise.  Bytes past the end read as '\n'. */
+struct IngChunk { uint8_t b[ING_BYTES]; uint8_t prev; };
+__device__ __forceinline__ IngChunk ing_load_chunk(const uint8_t *text, uint64_t len, uint64_t p0, bool aligned) {
+	IngChunk c;
+	if (aligned && p0 + ING_BYTES <= len) {
+		const uint4 v = *(const uint4 *)(text + p0);
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int j = 0; j < ING_BYTES; j++) c.b[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+	} else {
+#pragma unroll
+		for (int j = 0; j < ING_BYTES; j++) c.b[j] = p0 + j < len ? text[p0 + j] : (uint8_t)'\n';
+	}
+	c.prev = (p0 == 0 || p0 > len) ? (uint8_t)'\n' : text[p0 - 1];
+	return c;
+}
+__device__ __forceinline__ uint32_t ing_start_mask(const IngChunk &c, uint64_t p0, uint64_t len) {
+	uint32_t m = 0;
+#pragma unroll
+	for (int j = 0; j < ING_BYTES; j++) {
+		const uint8_t pv = j ? c.b[j - 1] : c.prev;
+		if (p0 + j < len && pv == '\n' && c.b[j] != '\n') m |= 1u << j;
+	}
+	return m;
+}
+/* first '\n' at or after p (or len): eight bytes per load once p is 8-byte aligned */
+__device__ __forceinline__ uint64_t ing_line_end(const uint8_t *text, uint64_t len, uint64_t p, bool aligned) {
+	uint64_t e = p;
+	if (aligned) {
+		while (e < len && (e & 7)) { if (text[e] == '\n') return e; e++; }
+		while (e + 8 <= len) {
+			const uint64_t x = *(const uint64_t *)(text + e) ^ 0x0a0a0a0a0a0a0a0aull;
+			const uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+			if (z) return e + (__builtin_ctzll(z) >> 3);
+			e += 8;
+		}
+	}
+	while (e < len && text[e] != '\n') e++;
+	return e;
+}
+
 /* exclusive prefix of v over the block (256 threads); total in *sum */
 __device__ __forceinline__ uint32_t ing_block_scan(uint32_t v, uint32_t *sum) {
 	__shared__ uint32_t wsum[ING_THREADS / 64];
@@ -56,8 +98,8 @@ __device__ __forceinline__ uint32_t ing_block_scan(uint32_t v, uint32_t *sum) {
 __global__ __launch_bounds__(ING_THREADS)
 void ingest_count_lines(const uint8_t *text, uint64_t len, uint32_t *block_lines) {
 	const uint64_t p0 = ((uint64_t)blockIdx.x * ING_THREADS + threadIdx.x) * ING_BYTES;
-	uint32_t c = 0;
-	for (int j = 0; j < ING_BYTES; j++) { const uint64_t p = p0 + j; if (p < len && ing_is_start(text, p)) c++; }
+	const bool aligned = ((uintptr_t)text & 15) == 0;
+	const uint32_t c = p0 < len ? (uint32_t)__builtin_popcount(ing_start_mask(ing_load_chunk(text, len, p0, aligned), p0, len)) : 0u;
 	uint32_t tot;
 	ing_block_scan(c, &tot);
 	if (threadIdx.x == 0) block_lines[blockIdx.x] = tot;
@@ -66,16 +108,16 @@ void ingest_count_lines(const uint8_t *text, uint64_t len, uint32_t *block_lines
 __global__ __launch_bounds__(ING_THREADS)
 void ingest_index_lines(const uint8_t *text, uint64_t len, const uint64_t *block_base, uint64_t *line_start, uint32_t *line_len, uint32_t *err) {
 	const uint64_t p0 = ((uint64_t)blockIdx.x * ING_THREADS + threadIdx.x) * ING_BYTES;
-	uint32_t c = 0;
-	for (int j = 0; j < ING_BYTES; j++) { const uint64_t p = p0 + j; if (p < len && ing_is_start(text, p)) c++; }
+	const bool aligned = ((uintptr_t)text & 15) == 0;
+	const uint32_t mask = p0 < len ? ing_start_mask(ing_load_chunk(text, len, p0, aligned), p0, len) : 0u;
+	const uint32_t c = (uint32_t)__builtin_popcount(mask);
 	uint32_t tot;
 	uint64_t idx = block_base[blockIdx.x] + ing_block_scan(c, &tot);
 	if (!c) return;
 	for (int j = 0; j < ING_BYTES; j++) {
 		const uint64_t p = p0 + j;
-		if (p < len && ing_is_start(text, p)) {
-			uint64_t e = p;
-			while (e < len && text[e] != '\n') e++;
+		if (mask & (1u << j)) {
+			uint64_t e = ing_line_end(text, len, p, aligned);
 			if (e - p > 0xffffffffull) { atomicOr(err, (uint32_t)ING_ERR_LEN); e = p; }
 			line_start[idx] = p; line_len[idx] = (uint32_t)(e - p);
 			idx++;
