@@ -1,18 +1,21 @@
 /*
- * kmr_partition.hpp -- streaming build path: hash-partition the k-mer records twice,
- * then count every final partition inside LDS.
+ * kmr_partition.hpp -- streaming build path: hash-partition the k-mer records (twice, or as often as
+ * the input needs), then count every final partition inside LDS.
  *
  * Why: the open-addressed table of kmr_kernels.hpp touches HBM randomly (one 32-byte
  * sector and three device-scope atomics per k-mer occurrence) and runs at the chip's
  * scattered-atomic rate, ~3 % of the HBM roofline.  Here every HBM access is a
  * streaming one and all atomics are LDS atomics:
  *
- *   extract_kernel<LinearOp>      reads -> compacted 16-byte records {key, signed weight, ordinal}
- *   partition_direct_kernel<1>   records -> P1 chunked lists      (bits 63.. of a mix of the key)
- *   partition_direct_kernel<2>   each list -> P2 sub-lists        (next bits)
- *   count_kernel                  each final list -> LDS hash table -> (key,count,fwd,weight,first)
- *                                 -> kept entries + per-bucket counts
- *   scan / entry_scatter / sort   entries -> bucketed sorted maps (same layout as the table path)
+ *   extract_kernel<LinearOp>        reads -> compacted records {key, signed weight, ordinal | packet + ordinal}
+ *   partition_direct_kernel<..,1>  records (linear buffer, or wire records of the owner exchange) -> chunked lists
+ *                                   by the top bits of the rotated lookup3 hash; its per-block state survives launches
+ *   partition_direct_kernel<..,2>  each list -> sub-lists by the next bits, into the same pool (fresh chunks, or
+ *                                   the chunks it has just read); repeated while lists are too long to count
+ *   count_kernel                    each final list -> LDS hash table -> (key,count,fwd,weight,first[,tallies])
+ *                                   -> kept entries + per-bucket counts
+ *   scan / entry_scatter / sort     entries -> bucketed sorted maps (same layout as the table path)
+ *   owner_scatter_kernel            sender side of the owner exchange: linear records -> owner segments
  *
  * It replaces the same reference functions as InsertOp (KmerSpectrum::append + track(),
  * src/KmerSpectrum.h:1578-1668, src/KmerTrackingData.h:427,517,641) and purgeMinDepth
