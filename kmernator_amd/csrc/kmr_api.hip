@@ -84,6 +84,7 @@ struct kmr_handle {
 	 * cursor, so a finalize neither allocates nor frees device memory once the handle has seen one build */
 	uint8_t *arena = nullptr; size_t arena_cap = 0, arena_used = 0, arena_want = 0; std::vector<void *> arena_overflow;
 	unsigned long long *scan_sums = nullptr; uint64_t scan_sums_n = 0;
+	uint8_t *score_buf = nullptr; size_t score_buf_bytes = 0;        /* temporaries of kmr_score_reads*, grow-only */
 	void *linear = nullptr; uint64_t linear_cap = 0;         /* records */
 	uint32_t *tile_count = nullptr; uint64_t tile_cap = 0;
 	uint32_t *kcap = nullptr; uint64_t *koff = nullptr; uint64_t kcap_n = 0, koff_n = 0;
@@ -1217,6 +1218,7 @@ void kmr_destroy(kmr_handle *h) {
 	free_map(h->weak); free_map(h->sing);
 	free_partition_state(h);
 	if (h->scan_sums) hipFree(h->scan_sums);
+	if (h->score_buf) hipFree(h->score_buf);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -1360,31 +1362,52 @@ int kmr_lookup_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, 
 
 /* ReadSelector::scoreAndTrimReads (src/ReadSelector.h:1182-1207) on the weak map; s_b / s_o: device bases and offsets,
  * offsets: the same offsets on the host */
-static int score_reads_core(kmr_handle *h, const uint8_t *s_b, const uint64_t *s_o, const uint64_t *offsets, uint64_t n_reads, double minimum_kmer_score, int scoring_type,
+static int score_reads_core(kmr_handle *h, const uint8_t *s_b, const uint64_t *s_o, uint64_t n_reads, double minimum_kmer_score, int scoring_type,
                             uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed) {
-	struct { const uint8_t *b; const uint64_t *o; void release() {} } s = {s_b, s_o};
 	int rc = 0;
-	std::vector<uint64_t> coff(n_reads + 1, 0);
-	for (uint64_t r = 0; r < n_reads; r++) { const uint64_t L = offsets[r + 1] - offsets[r]; coff[r + 1] = coff[r] + (L >= h->k ? L - h->k + 1 : 0); }
-	const uint64_t outN = coff[n_reads];
-	uint32_t *dcounts, *dto, *dtl; uint64_t *dcoff; float *dsc; uint8_t *dwt;
-	HIPCHK(h, hipMalloc((void **)&dcounts, std::max<uint64_t>(8, 4 * outN))); HIPCHK(h, hipMalloc((void **)&dcoff, 8 * (n_reads + 1)));
-	HIPCHK(h, hipMalloc((void **)&dto, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dtl, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dsc, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dwt, n_reads));
+	ReadsView rv; rv.bases = s_b; rv.quals = nullptr; rv.offsets = s_o; rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0; rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
+	/* per-read k-mer counts and their exclusive scan on the device (no host pass over the reads); one grow-only block for
+	 * every temporary (a hipFree of the ~GB count array costs more than the scoring) */
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t fixed = al(4 * (n_reads + 1)) + al(8 * (n_reads + 1)) + 3 * al(4 * n_reads) + al(n_reads);
+	if (h->score_buf_bytes < fixed) {
+		if (h->score_buf) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->score_buf); h->score_buf = nullptr; h->score_buf_bytes = 0; }
+		HIPCHK(h, hipMalloc((void **)&h->score_buf, fixed + fixed / 4)); h->score_buf_bytes = fixed + fixed / 4;
+	}
+	uint8_t *p = h->score_buf;
+	uint32_t *dkc = (uint32_t *)p; p += al(4 * (n_reads + 1));
+	uint64_t *dcoff = (uint64_t *)p;
+	hipLaunchKernelGGL(kmer_capacity_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, rv, h->k, dkc);
+	HIPCHK(h, hipGetLastError());
+	rc = exclusive_scan(h, dkc, n_reads, dcoff); if (rc) return rc;
+	uint64_t outN = 0;
+	HIPCHK(h, hipMemcpy(&outN, dcoff + n_reads, 8, hipMemcpyDeviceToHost));
+	const size_t need = fixed + al(std::max<uint64_t>(8, 4 * outN));
+	if (h->score_buf_bytes < need) {         /* grow, keeping the scan */
+		uint8_t *nbuf; HIPCHK(h, hipMalloc((void **)&nbuf, need + need / 8));
+		HIPCHK(h, hipMemcpy(nbuf, h->score_buf, al(4 * (n_reads + 1)) + al(8 * (n_reads + 1)), hipMemcpyDeviceToDevice));
+		HIPCHK(h, hipDeviceSynchronize());
+		hipFree(h->score_buf); h->score_buf = nbuf; h->score_buf_bytes = need + need / 8;
+	}
+	p = h->score_buf + al(4 * (n_reads + 1));
+	dcoff = (uint64_t *)p; p += al(8 * (n_reads + 1));
+	uint32_t *dto = (uint32_t *)p; p += al(4 * n_reads);
+	uint32_t *dtl = (uint32_t *)p; p += al(4 * n_reads);
+	float *dsc = (float *)p; p += al(4 * n_reads);
+	uint8_t *dwt = p; p += al(n_reads);
+	uint32_t *dcounts = (uint32_t *)p;
 	HIPCHK(h, hipMemsetAsync(dcounts, 0, 4 * outN, h->stream));
-	HIPCHK(h, hipMemcpyAsync(dcoff, coff.data(), 8 * (n_reads + 1), hipMemcpyHostToDevice, h->stream));
-	ReadsView rv; rv.bases = s.b; rv.quals = nullptr; rv.offsets = s.o; rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0; rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
-	{ int urc = prepare_units(h, rv); if (urc) { s.release(); return urc; } }
+	{ int urc = prepare_units(h, rv); if (urc) return urc; }
 	switch (h->W) { case 1: rc = lookup_reads_t<1>(h, rv, dcounts, dcoff, true); break; case 2: rc = lookup_reads_t<2>(h, rv, dcounts, dcoff, true); break;
 	case 3: rc = lookup_reads_t<3>(h, rv, dcounts, dcoff, true); break; default: rc = lookup_reads_t<4>(h, rv, dcounts, dcoff, true); }
 	if (!rc) {
-		hipLaunchKernelGGL(score_reads_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, s.b, s.o, n_reads, h->k, dcounts, dcoff,
+		hipLaunchKernelGGL(score_reads_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, s_b, s_o, n_reads, h->k, dcounts, dcoff,
 		                   (float)minimum_kmer_score, scoring_type, dto, dtl, dsc, dwt);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipMemcpyAsync(trim_offset, dto, 4 * n_reads, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(trim_length, dtl, 4 * n_reads, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(h, hipMemcpyAsync(score, dsc, 4 * n_reads, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(was_trimmed, dwt, n_reads, hipMemcpyDeviceToHost, h->stream));
 		rc = sync_state(h);
 	} else hipStreamSynchronize(h->stream);
-	hipFree(dcounts); hipFree(dcoff); hipFree(dto); hipFree(dtl); hipFree(dsc); hipFree(dwt);
 	return rc;
 }
 int kmr_score_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads, double minimum_kmer_score, int scoring_type,
@@ -1397,9 +1420,7 @@ int kmr_score_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, u
 	StagedReads s; uint64_t total = 0;
 	int rc = stage_reads(h, bases, nullptr, offsets, n_reads, nullptr, s, total);
 	if (!rc) {
-		std::vector<uint64_t> rel(n_reads + 1);
-		for (uint64_t i = 0; i <= n_reads; i++) rel[i] = offsets[i] - offsets[0];
-		rc = score_reads_core(h, s.b, s.o, rel.data(), n_reads, minimum_kmer_score, scoring_type, trim_offset, trim_length, score, was_trimmed);
+		rc = score_reads_core(h, s.b, s.o, n_reads, minimum_kmer_score, scoring_type, trim_offset, trim_length, score, was_trimmed);
 	}
 	s.release();
 	return rc;
@@ -1414,9 +1435,7 @@ int kmr_score_read_batch(kmr_handle *h, const kmr_reads *r, double minimum_kmer_
 	if (r->device != h->device) return fail(h, KMR_ERR_INVALID_ARG, "read batch lives on another device");
 	if (r->n == 0) return KMR_OK;
 	hipSetDevice(h->device);
-	std::vector<uint64_t> off(r->n + 1);
-	HIPCHK(h, hipMemcpy(off.data(), r->offsets, 8 * (r->n + 1), hipMemcpyDeviceToHost));
-	return score_reads_core(h, r->bases, r->offsets, off.data(), r->n, minimum_kmer_score, scoring_type, trim_offset, trim_length, score, was_trimmed);
+	return score_reads_core(h, r->bases, r->offsets, r->n, minimum_kmer_score, scoring_type, trim_offset, trim_length, score, was_trimmed);
 }
 
 static DevMap *map_of(kmr_handle *h, int which) {

@@ -715,7 +715,8 @@ __global__ void score_reads_kernel(const uint8_t *bases, const uint64_t *offsets
 			if (scoring == SCORE_MEDIAN) {
 				/* sorted[n/2]: the smallest v with #(x <= v) > n/2, found by bisection on the 16-bit count */
 				const uint32_t t = bestLen / 2;
-				uint32_t lo = 0, hi = 65535;
+				uint32_t lo = 65535, hi = 0;          /* the bisection starts from the run's own range, not from 16 bits */
+				for (uint32_t i = 0; i < bestLen; i++) { const uint32_t v = run[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
 				while (lo < hi) {
 					const uint32_t mid = (lo + hi) >> 1;
 					uint32_t le = 0;

@@ -1,6 +1,7 @@
 """development tool: throughput of kmr_ingest_fastq (FASTQ text already in HBM) and parity of the result at scale"""
-import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, ctypes as C
 import kmernator_amd as ka
 from helpers import synth_reads
@@ -24,3 +25,12 @@ for rep in range(3):
 b = np.zeros(tot.value, np.uint8); q = np.zeros(tot.value, np.uint8)
 lib.kmr_reads_copy(r, b.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), None, None, None)
 print("bases identical:", np.array_equal(b, rb.bases), "quals identical:", np.array_equal(q, rb.quals))
+# the rest of the FilterReads flow on the same device-resident reads: spectrum, then scoreAndTrimReads
+t0 = time.time(); rc = lib.kmr_add_read_batch(sp.h, r, 0); assert rc == 0; sp.finalize(2); torch.cuda.synchronize(); t1 = time.time()
+to = np.zeros(n, np.uint32); tl = np.zeros(n, np.uint32); sc = np.zeros(n, np.float32); wt = np.zeros(n, np.uint8)
+for rep in range(2):
+    t2 = time.time()
+    rc = lib.kmr_score_read_batch(sp.h, r, 2.0, 1, to.ctypes.data_as(C.POINTER(C.c_uint32)), tl.ctypes.data_as(C.POINTER(C.c_uint32)), sc.ctypes.data_as(C.POINTER(C.c_float)), wt.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert rc == 0; t3 = time.time()
+print("build %.1f ms; scoreAndTrimReads of %d reads (%d k-mer lookups) %.1f ms -> %.2f G lookups/s; trimmed %d, median of medians %.0f" % (
+    (t1 - t0) * 1e3, n, n * 120, (t3 - t2) * 1e3, n * 120 / (t3 - t2) / 1e9, int(wt.sum()), float(np.median(sc))))
