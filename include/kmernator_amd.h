@@ -312,6 +312,53 @@ void kmr_reads_free(kmr_reads *r);
 int kmr_score_read_batch(kmr_handle *h, const kmr_reads *r, double minimum_kmer_score, int scoring_type,
                          uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed);
 
+/* ---- f4: artifact filter (FilterKnownOddities, src/FilterKnownOddities.h) ------------------
+ * The screen FilterReads runs over every read before the spectrum build (apps/FilterReads.cpp:107-118):
+ * (1) the longest run of bases with quality >= start + min_quality ("best"; the runner-up may be rescued as a
+ * remnant read), (2) every 4th match_length-mer inside it looked up (canonical form) in a set made of all
+ * match_length-mers of the artifact sequences, circularised, plus their substitution neighbours, (3) keep the
+ * longer side of the read next to the hits, then discard or trim (recordAffectedRead :551-640).
+ *
+ * The artifact sequences are handed in as FASTA text (multi-line records allowed; the reference's are
+ * FilterKnownOddities::getArtifactFasta/getSimpleRepeatFasta/getPhiX and --artifact-reference-file). Sequence
+ * indices are 1-based in file order (0 is the reference's empty "no match" read); value n_sequences marks a
+ * read that only lost bases to the quality screen ("MinQualityTrim"). */
+typedef struct kmr_artifact_config {
+	uint32_t match_length;          /* --artifact-match-length (24): multiple of 4, <= 28                             */
+	uint32_t edit_distance;         /* --artifact-edit-distance (2)                                                   */
+	uint32_t build_edits;           /* --build-artifact-edits-in-filter (2): 0 never, 1 always, 2 while < 750 000 keys */
+	uint32_t simple_repeat_begin;   /* [begin, end) = the simple-repeat sequences (--mask-simple-repeats); 0,0 = none */
+	uint32_t simple_repeat_end;
+	uint32_t phix_idx;              /* the PhiX sequence (--phix-output); 0 = none                                    */
+	uint32_t reference_begin;       /* first --artifact-reference-file sequence (not circularised); 0 = none          */
+	uint32_t min_quality;           /* --min-quality-score                                                            */
+	uint32_t fastq_start_char;      /* Read::FASTQ_START_CHAR the reads are scaled to                                 */
+	float    min_read_length;       /* --min-read-length (fraction of the read if <= 1, bases otherwise)              */
+} kmr_artifact_config;
+void kmr_artifact_config_init(kmr_artifact_config *c);      /* the reference's defaults, start char 33, min quality 3, min length 0.40 */
+
+typedef struct kmr_artifact_filter kmr_artifact_filter;
+/* constructor + prepareMaps (:205-287); the key set lives in device memory */
+int kmr_artifact_filter_create(kmr_handle *h, const kmr_artifact_config *cfg, const char *fasta, uint64_t len,
+                               kmr_artifact_filter **out);
+/* sequences.getSize(), filter.size(), and the edits left for query time (numErrors after prepareMaps) */
+int kmr_artifact_filter_info(const kmr_artifact_filter *f, uint64_t *n_sequences, uint64_t *n_filter_kmers,
+                             uint32_t *remaining_edits);
+/* copies the (key, sequence index) pairs out in ascending key order (key = 2-bit packed match_length-mer,
+ * first base most significant); returns KMR_ERR_CAPACITY if cap is too small */
+int kmr_artifact_filter_entries(const kmr_artifact_filter *f, uint64_t *keys, uint32_t *values, uint64_t cap);
+void kmr_artifact_filter_free(kmr_artifact_filter *f);
+/* applyFilter (:663-733) over a device-resident read batch.  mate (host, n entries, may be NULL) = index of the
+ * paired read or -1 (applyFilterToPair :355-386).  Per read (host arrays, each may be NULL):
+ * value (matched sequence, n_sequences = quality trim only, 0 = clean), [min_pass, max_pass) the part to keep,
+ * action 0 = untouched / 1 = trimmed ("AFTrim:<min_pass>+<max_pass-min_pass>") / 2 = discarded, and
+ * [remnant_off, +remnant_len) the second-best quality run rescued as an extra read (len 0 = none).
+ * *out (may be NULL) receives a new batch: read i trimmed or emptied in place, the remnants appended in read
+ * order (the reference appends them per OpenMP thread). */
+int kmr_artifact_filter_apply(kmr_handle *h, const kmr_artifact_filter *f, const kmr_reads *in, const int64_t *mate,
+                              uint32_t *value, uint32_t *min_pass, uint32_t *max_pass, uint8_t *action,
+                              uint32_t *remnant_off, uint32_t *remnant_len, kmr_reads **out);
+
 /* Raw HIP stream of the handle (hipStream_t) so callers can order their own
  * work (torch.cuda.ExternalStream) against it. */
 void *kmr_stream(kmr_handle *h);

@@ -47,6 +47,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unordered_map>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -1114,6 +1115,241 @@ int64_t orc_parse_fastq(const char *text, uint64_t len, uint32_t start_char, uin
 	}
 	if (final_input_base) *final_input_base = inBase;
 	return (int64_t)n;
+}
+
+}  // extern "C"
+
+/* ====================================================================== */
+/* f4: FilterKnownOddities (src/FilterKnownOddities.h).  The filter is a set of canonical match_length-mers
+ * (all windows of every artifact sequence, circularised, plus their built-in substitution neighbours) and the
+ * per-read screen of applyFilterToRead (:389-541) with recordAffectedRead's discard / trim decision (:551-640). */
+namespace orc {
+
+struct ArtifactFilter {
+	kmr_artifact_config cfg;
+	uint32_t length = 0, twoBitLength = 0;
+	int numErrors = 0;                     /* edits left for query time after prepareMaps() */
+	uint32_t nSeq = 0;                     /* sequences.getSize(), index 0 = the empty read */
+	std::unordered_map<uint64_t, uint32_t> filter;
+	std::vector<std::string> names;
+
+	static uint64_t packWindow(const char *s, uint32_t len) {      /* compressSequence: non-ACGT packs as A */
+		uint64_t v = 0;
+		for (uint32_t i = 0; i < len; i++) {
+			uint64_t c;
+			switch (s[i]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: c = 0; }
+			v = (v << 2) | c;
+		}
+		return v;
+	}
+	uint64_t revComp(uint64_t v) const {
+		uint64_t r = 0;
+		for (uint32_t i = 0; i < length; i++) { r = (r << 2) | (3 - (v & 3)); v >>= 2; }
+		return r;
+	}
+	uint64_t least(uint64_t v) const { uint64_t r = revComp(v); return r < v ? r : v; }      /* Kmer::buildLeastComplement :356-364 */
+	uint64_t bucketOf(uint64_t v, uint64_t mask) const {                                      /* key bytes big-endian, as stored */
+		uint8_t b[8];
+		for (uint32_t i = 0; i < twoBitLength; i++) b[i] = (uint8_t)(v >> (8 * (twoBitLength - 1 - i)));
+		return getHash(b, (int)twoBitLength) & mask;
+	}
+	bool isPhiX(uint32_t v) const { return cfg.phix_idx != 0 && v == cfg.phix_idx; }
+	bool isSimpleRepeat(uint32_t v) const { return cfg.simple_repeat_end != 0 && v >= cfg.simple_repeat_begin && v < cfg.simple_repeat_end; }
+	bool isReference(uint32_t v) const { return cfg.reference_begin != 0 && cfg.reference_begin <= v; }
+
+	/* ctor :205-232 + prepareMaps :242-287 */
+	bool build(const char *fasta, uint64_t len) {
+		length = cfg.match_length;
+		if (length == 0 || length > 28 || (length & 3)) return false;
+		twoBitLength = length / 4;
+		numErrors = (int)cfg.edit_distance;
+		std::vector<std::string> seqs(1);
+		names.assign(1, "");
+		uint64_t i = 0;
+		while (i < len) {
+			uint64_t e = i; while (e < len && fasta[e] != '\n') e++;
+			uint64_t le = e; if (le > i && fasta[le - 1] == '\r') le--;
+			if (le > i) {
+				if (fasta[i] == '>') {
+					uint64_t ne = i + 1; while (ne < le && fasta[ne] != ' ' && fasta[ne] != '\t') ne++;
+					names.push_back(std::string(fasta + i + 1, fasta + ne)); seqs.push_back("");
+				} else if (seqs.size() > 1) {
+					for (uint64_t j = i; j < le; j++) seqs.back().push_back((char)toupper((unsigned char)fasta[j]));
+				}
+			}
+			i = e + 1;
+		}
+		nSeq = (uint32_t)seqs.size();
+		for (uint32_t s = 1; s < nSeq; s++)                            /* ReadSet::circularize(length), src/ReadSet.cpp:120-130 */
+			if (cfg.reference_begin == 0 || s < cfg.reference_begin) seqs[s] += seqs[s].substr(0, length);
+		for (uint32_t s = 0; s < nSeq; s++) {
+			const std::string &q = seqs[s];
+			if (q.size() < length) continue;
+			for (size_t j = 0; j + length <= q.size(); j++) filter.emplace(least(packWindow(q.data() + j, length)), s);   /* getOrSetElement */
+		}
+		const int maxErrors = numErrors;
+		const uint64_t mask = resizeBuckets(512 * 1024 / 32 + 1) - 1;    /* KmerMap(512*1024): buckets of 32 (src/Kmer.h:2837) */
+		for (int error = 0; error < maxErrors; error++) {
+			if (cfg.build_edits == 1 || (cfg.build_edits == 2 && filter.size() < 750000)) {
+				numErrors--;
+				std::vector<std::pair<std::pair<uint64_t, uint64_t>, uint32_t> > snap;     /* map iteration: bucket by bucket, keys sorted */
+				snap.reserve(filter.size());
+				for (auto &kv : filter) snap.push_back(std::make_pair(std::make_pair(bucketOf(kv.first, mask), kv.first), kv.second));
+				std::sort(snap.begin(), snap.end());
+				std::vector<std::pair<uint64_t, uint32_t> > add;
+				add.reserve(snap.size() * 3 * length);
+				for (auto &e : snap) {                                                       /* permuteBases(key, value, true) :1434-1459 */
+					const uint64_t key = e.first.second;
+					for (uint32_t b = 0; b < length; b++) {
+						const uint32_t sh = 2 * (length - 1 - b);
+						const uint64_t cur = (key >> sh) & 3;
+						for (uint64_t nb = 0; nb < 4; nb++) if (nb != cur) add.push_back(std::make_pair(least((key & ~(3ull << sh)) | (nb << sh)), e.second));
+					}
+				}
+				for (auto &a : add) filter.emplace(a.first, a.second);
+			}
+		}
+		return true;
+	}
+
+	struct Result { uint32_t value, minPass, maxPass; long second0, second1; bool remnant; };
+
+	/* applyFilterToRead :389-541 */
+	Result screen(const char *bases, const char *quals, uint32_t seqLen) const {
+		Result R; R.remnant = false;
+		uint32_t value = 0, minPass = 0, maxPass = seqLen;
+		std::pair<long, long> best(0, 0), secondBest(0, 0), test(0, 0);
+		const char minQual = (char)(cfg.fastq_start_char + cfg.min_quality);
+		for (uint32_t i = 0; i < seqLen; i++) {
+			test.second = i;
+			if (quals[i] < minQual) {
+				if (test.second - test.first > best.second - best.first) std::swap(best, test);
+				if (test.second - test.first > secondBest.second - secondBest.first) std::swap(secondBest, test);
+				test.first = test.second = i + 1;
+			}
+		}
+		test.second = seqLen;
+		if (test.second - test.first > best.second - best.first) std::swap(best, test);
+		if (test.second - test.first > secondBest.second - secondBest.first) std::swap(secondBest, test);
+		if (best.second > best.first) { minPass = (uint32_t)best.first; maxPass = (uint32_t)best.second; } else { minPass = 0; maxPass = 0; }
+
+		const long bytes = (seqLen + 3) / 4;
+		long byteHops = (long)((maxPass + 3) / 4) - (long)twoBitLength - ((seqLen & 3) == 0 ? 0 : 1);
+		if (byteHops < 0 || byteHops > bytes) byteHops = 0;
+		bool wasPhiX = false;
+		uint32_t minAffected = maxPass, maxAffected = minPass;
+		long w = 0;                                   /* the reference's ptr starts at the read's first byte whatever minPass is */
+		for (long byteHop = minPass / 4; byteHop <= byteHops; byteHop++, w++) {
+			uint64_t fwd = 0;
+			for (uint32_t j = 0; j < length; j++) {
+				const uint64_t p = (uint64_t)w * 4 + j;
+				uint64_t c = 0;
+				if (p < seqLen) switch (bases[p]) { case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: c = 0; }
+				fwd = (fwd << 2) | c;                   /* past the end of the read the reference reads whatever follows its buffer; zeros here */
+			}
+			const uint64_t lk = least(fwd);
+			const uint32_t pos = (uint32_t)(byteHop * 4);
+			auto hit = [&](uint64_t key) {
+				auto it = filter.find(key);
+				if (it == filter.end()) return;
+				value = it->second; wasPhiX |= isPhiX(value);
+				if (minAffected > pos) minAffected = pos;
+				if (maxAffected < pos + length) maxAffected = pos + length;
+			};
+			hit(lk);
+			if (numErrors > 0) permuteQuery(lk, 0, numErrors, hit);
+		}
+		if (wasPhiX) value = cfg.phix_idx;
+		else if (isSimpleRepeat(value)) {
+			bool isGoodMargin = true;
+			if ((long)(uint32_t)(minAffected - minPass) < (long)3 * length / 2) isGoodMargin = false;
+			if ((long)(uint32_t)(maxPass - maxAffected) < (long)3 * length / 2) isGoodMargin = false;
+			if (isGoodMargin) { value = 0; minAffected = maxPass; maxAffected = minPass; }
+		}
+		if (value > 0 && minAffected <= maxAffected) {
+			if ((uint32_t)(minAffected - minPass) >= (uint32_t)(maxPass - maxAffected)) maxPass = minAffected;
+			else minPass = maxAffected;
+		}
+		if (value == 0 && (uint32_t)(maxPass - minPass) != seqLen) {
+			value = nSeq;
+			if (passesLength((float)(secondBest.second - secondBest.first), seqLen, cfg.min_read_length)) R.remnant = true;
+		}
+		R.value = value; R.minPass = minPass; R.maxPass = maxPass; R.second0 = secondBest.first; R.second1 = secondBest.second;
+		return R;
+	}
+	/* Kmer.h:1409-1427 __permuteBases: every substitution pattern of up to editDistance bases at increasing positions,
+	 * NOT re-canonicalised (the leastComplement argument is ignored there) */
+	template <typename F> void permuteQuery(uint64_t key, uint32_t startIdx, int editDistance, F &hit) const {
+		if (editDistance == 0) return;
+		for (uint32_t b = startIdx; b < length; b++) {
+			const uint32_t sh = 2 * (length - 1 - b);
+			const uint64_t cur = (key >> sh) & 3;
+			for (uint64_t nb = 0; nb < 4; nb++) if (nb != cur) {
+				const uint64_t v = (key & ~(3ull << sh)) | (nb << sh);
+				hit(v);
+				if (editDistance > 1) permuteQuery(v, b + 1, editDistance - 1, hit);
+			}
+		}
+	}
+	static bool passesLength(float length, uint32_t readLength, float minimumLength) {      /* src/ReadSelector.h:219-228 */
+		if (length <= 1.0) return false;
+		if (minimumLength <= 1.0) return readLength * minimumLength <= length;
+		return minimumLength <= length;
+	}
+};
+
+}  // namespace orc
+
+extern "C" {
+
+struct orc_artifact { orc::ArtifactFilter f; };
+
+orc_artifact *orc_artifact_create(const kmr_artifact_config *cfg, const char *fasta, uint64_t len) {
+	initTables();
+	orc_artifact *a = new orc_artifact; a->f.cfg = *cfg;
+	if (!a->f.build(fasta, len)) { delete a; return NULL; }
+	return a;
+}
+void orc_artifact_free(orc_artifact *a) { delete a; }
+void orc_artifact_info(const orc_artifact *a, uint64_t *n_sequences, uint64_t *n_kmers, uint32_t *remaining_edits) {
+	*n_sequences = a->f.nSeq; *n_kmers = a->f.filter.size(); *remaining_edits = (uint32_t)a->f.numErrors;
+}
+/* sorted (key, value) pairs of the filter, for comparison with the product's table */
+uint64_t orc_artifact_entries(const orc_artifact *a, uint64_t *keys, uint32_t *values, uint64_t cap) {
+	std::vector<std::pair<uint64_t, uint32_t> > v(a->f.filter.begin(), a->f.filter.end());
+	std::sort(v.begin(), v.end());
+	for (uint64_t i = 0; i < v.size() && i < cap; i++) { keys[i] = v[i].first; values[i] = v[i].second; }
+	return v.size();
+}
+/* applyFilter :663-733 for single reads (mate == NULL) or pairs (mate[i] = index of the other read or -1):
+ * action 0 = untouched, 1 = trimmed to [min_pass, max_pass), 2 = discarded; rem_len > 0 = a remnant read
+ * [rem_off, rem_off + rem_len) is appended (:519-528) */
+int orc_artifact_apply(const orc_artifact *a, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n, const int64_t *mate,
+                       uint32_t *value, uint32_t *min_pass, uint32_t *max_pass, uint8_t *action, uint32_t *rem_off, uint32_t *rem_len) {
+	const orc::ArtifactFilter &f = a->f;
+	for (uint64_t i = 0; i < n; i++) {
+		const uint32_t L = (uint32_t)(offsets[i + 1] - offsets[i]);
+		orc::ArtifactFilter::Result r = f.screen(bases + offsets[i], quals + offsets[i], L);
+		value[i] = r.value; min_pass[i] = r.minPass; max_pass[i] = r.maxPass;
+		rem_off[i] = 0; rem_len[i] = 0;
+		if (r.remnant) { rem_off[i] = (uint32_t)r.second0; rem_len[i] = (uint32_t)(r.second1 - r.second0); }
+	}
+	for (uint64_t i = 0; i < n; i++) {                     /* recordAffectedRead :551-640 */
+		const int64_t m = mate ? mate[i] : -1;
+		const uint32_t v1 = value[i], v2 = m >= 0 ? value[m] : 0;
+		const bool wasPhiX = f.isPhiX(v1) || f.isPhiX(v2);
+		const bool wasReference = (v1 != f.nSeq && f.isReference(v1)) || (v2 != f.nSeq && f.isReference(v2));
+		const uint32_t L = (uint32_t)(offsets[i + 1] - offsets[i]);
+		action[i] = 0;
+		if (v1 == 0 && v2 == 0) continue;
+		if (wasPhiX) { action[i] = 2; continue; }
+		if (v1 != 0) {
+			const int passLength = (int)(max_pass[i] - min_pass[i]);
+			if (wasReference || passLength <= 0 || !orc::ArtifactFilter::passesLength((float)passLength, L, f.cfg.min_read_length)) action[i] = 2;
+			else action[i] = 1;
+		}
+	}
+	return 0;
 }
 
 }  // extern "C"

@@ -49,6 +49,20 @@ class KmrStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class KmrArtifactConfig(C.Structure):
+    """Mirror of kmr_artifact_config in include/kmernator_amd.h."""
+    _fields_ = [(n, C.c_uint32) for n in ("match_length", "edit_distance", "build_edits", "simple_repeat_begin", "simple_repeat_end",
+                                          "phix_idx", "reference_begin", "min_quality", "fastq_start_char")] + [("min_read_length", C.c_float)]
+
+
+def artifact_config(**kw):
+    """the reference's defaults (FilterKnownOdditiesOptions, src/FilterKnownOddities.h:72-74; ReadSelectorOptions min-read-length)"""
+    c = KmrArtifactConfig(24, 2, 2, 0, 0, 0, 0, 3, 33, 0.40)
+    for name, v in kw.items():
+        setattr(c, name, v)
+    return c
+
+
 def default_config(k, **kw):
     c = KmrConfig()
     c.struct_size = C.sizeof(KmrConfig)
@@ -135,6 +149,74 @@ def oracle_lib():
                                         C.c_uint64, C.c_uint64, u32p]
         _oracle = lib
     return _oracle
+
+
+class OracleArtifactFilter:
+    """oracle restatement of FilterKnownOddities (f4)"""
+
+    def __init__(self, cfg, fasta):
+        lib = oracle_lib()
+        lib.orc_artifact_create.restype = C.c_void_p
+        lib.orc_artifact_create.argtypes = [C.POINTER(KmrArtifactConfig), C.c_char_p, C.c_uint64]
+        lib.orc_artifact_free.argtypes = [C.c_void_p]
+        lib.orc_artifact_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        lib.orc_artifact_entries.restype = C.c_uint64
+        lib.orc_artifact_entries.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64]
+        lib.orc_artifact_apply.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_int64)] + \
+            [C.POINTER(C.c_uint32)] * 3 + [C.POINTER(C.c_uint8)] + [C.POINTER(C.c_uint32)] * 2
+        self.lib = lib
+        self.cfg = cfg
+        fasta = bytes(fasta)
+        self.h = lib.orc_artifact_create(C.byref(cfg), fasta, len(fasta))
+        assert self.h
+
+    def info(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        self.lib.orc_artifact_info(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def entries(self):
+        n = self.info()[1]
+        keys = np.zeros(n, dtype=np.uint64)
+        vals = np.zeros(n, dtype=np.uint32)
+        assert self.lib.orc_artifact_entries(self.h, _ptr(keys, C.c_uint64), _ptr(vals, C.c_uint32), n) == n
+        return keys, vals
+
+    def apply(self, rb, mate=None):
+        """dict of per-read arrays: value, min_pass, max_pass, action, remnant_off, remnant_len"""
+        n = rb.n
+        out = {k: np.zeros(n, dtype=np.uint32) for k in ("value", "min_pass", "max_pass", "remnant_off", "remnant_len")}
+        out["action"] = np.zeros(n, dtype=np.uint8)
+        m = None if mate is None else _ptr(np.ascontiguousarray(mate, dtype=np.int64), C.c_int64)
+        self.lib.orc_artifact_apply(self.h, rb.bases.ctypes.data_as(C.c_char_p), rb.quals.ctypes.data_as(C.c_char_p), _ptr(rb.offsets, C.c_uint64), n, m,
+                                    _ptr(out["value"], C.c_uint32), _ptr(out["min_pass"], C.c_uint32), _ptr(out["max_pass"], C.c_uint32),
+                                    _ptr(out["action"], C.c_uint8), _ptr(out["remnant_off"], C.c_uint32), _ptr(out["remnant_len"], C.c_uint32))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_artifact_free(self.h)
+            self.h = None
+
+
+def apply_artifact_result(rb, res):
+    """the read set after applyFilter: trimmed / emptied reads in place, remnants appended (host-side model for the tests)"""
+    seqs, quals = [], []
+    for i in range(rb.n):
+        s, q = rb.seq(i), rb.qual(i)
+        a = int(res["action"][i])
+        if a == 1:
+            s, q = s[int(res["min_pass"][i]):int(res["max_pass"][i])], q[int(res["min_pass"][i]):int(res["max_pass"][i])]
+        elif a == 2:
+            s, q = b"", b""
+        seqs.append(s)
+        quals.append(q)
+    for i in range(rb.n):
+        if res["remnant_len"][i]:
+            o, l = int(res["remnant_off"][i]), int(res["remnant_len"][i])
+            seqs.append(rb.seq(i)[o:o + l])
+            quals.append(rb.qual(i)[o:o + l])
+    return ReadBatch(seqs, quals)
 
 
 def _ptr(a, t):
