@@ -45,6 +45,12 @@ class KmrStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class KmrArtifactConfig(C.Structure):
+    """kmr_artifact_config"""
+    _fields_ = [(n, C.c_uint32) for n in ("match_length", "edit_distance", "build_edits", "simple_repeat_begin", "simple_repeat_end",
+                                          "phix_idx", "reference_begin", "min_quality", "fastq_start_char")] + [("min_read_length", C.c_float)]
+
+
 # every symbol include/kmernator_amd.h declares
 EXPORTS = [
     "kmr_abi_version", "kmr_config_init", "kmr_create", "kmr_destroy", "kmr_last_error", "kmr_num_buckets",
@@ -55,6 +61,8 @@ EXPORTS = [
     "kmr_insert_records_dev", "kmr_stream", "kmr_kernel_time", "kmr_kernel_time_reset", "kmr_reset", "kmr_release_table", "kmr_score_reads",
     "kmr_ingest_fastq", "kmr_ingest_fastq_dev", "kmr_reads_info", "kmr_reads_device_ptrs", "kmr_reads_copy",
     "kmr_add_read_batch", "kmr_reads_free", "kmr_histogram", "kmr_histogram_bins", "kmr_merge_image", "kmr_subtract_reference", "kmr_subtracted", "kmr_score_read_batch",
+    "kmr_artifact_config_init", "kmr_artifact_filter_create", "kmr_artifact_filter_info", "kmr_artifact_filter_entries",
+    "kmr_artifact_filter_free", "kmr_artifact_filter_apply",
 ]
 
 _lib = None
@@ -119,6 +127,14 @@ def load():
     lib.kmr_reads_free.argtypes = [vp]
     lib.kmr_reads_free.restype = None
     lib.kmr_score_read_batch.argtypes = [vp, vp, C.c_double, C.c_int, u32p, u32p, C.POINTER(C.c_float), u8p]
+    lib.kmr_artifact_config_init.argtypes = [C.POINTER(KmrArtifactConfig)]
+    lib.kmr_artifact_config_init.restype = None
+    lib.kmr_artifact_filter_create.argtypes = [vp, C.POINTER(KmrArtifactConfig), C.c_char_p, C.c_uint64, C.POINTER(vp)]
+    lib.kmr_artifact_filter_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.kmr_artifact_filter_entries.argtypes = [vp, C.POINTER(C.c_uint64), u32p, C.c_uint64]
+    lib.kmr_artifact_filter_free.argtypes = [vp]
+    lib.kmr_artifact_filter_free.restype = None
+    lib.kmr_artifact_filter_apply.argtypes = [vp, vp, vp, C.POINTER(C.c_int64), u32p, u32p, u32p, u8p, u32p, u32p, C.POINTER(vp)]
     lib.kmr_merge_image.argtypes = [vp, C.c_int, vp, C.c_uint64]
     lib.kmr_subtract_reference.argtypes = [vp, vp]
     lib.kmr_subtracted.argtypes = [vp, u64p]

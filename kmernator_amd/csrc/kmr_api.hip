@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -21,6 +23,7 @@
 #include "kmr_kernels.hpp"
 #include "kmr_partition.hpp"
 #include "kmr_ingest.hpp"
+#include "kmr_artifact.hpp"
 
 using namespace kmr;
 
@@ -1745,6 +1748,248 @@ int kmr_add_read_batch(kmr_handle *h, const kmr_reads *r, uint64_t first_global_
 	int rc = kmr_add_reads_dev(h, r->bases, r->quals, r->offsets, r->n, r->total, first_global_read_idx, nullptr);
 	if (!rc) rc = kmr_sync(h);
 	return rc;
+}
+
+/* ---- f4: artifact filter (FilterKnownOddities) --------------------------- */
+}  // extern "C"
+
+struct kmr_artifact_filter {
+	int device = 0;
+	kmr_artifact_config cfg;
+	uint32_t n_seq = 0, remaining_edits = 0, log2cap = 0;
+	uint64_t n_keys = 0;
+	uint64_t *d_keys = nullptr; uint32_t *d_vals = nullptr;      /* open-addressed lookup table */
+	std::vector<uint64_t> keys; std::vector<uint32_t> vals;        /* the same entries on the host, ascending keys */
+};
+
+namespace {
+
+uint32_t art_log2cap(uint64_t n) { uint32_t l = 10; while ((1ull << l) < 2 * n + 16) l++; return l; }
+
+struct ArtBuf {          /* device scratch of one call, released on every exit path */
+	std::vector<void *> p;
+	~ArtBuf() { for (void *q : p) if (q) hipFree(q); }
+	template <typename T> hipError_t get(T **out, size_t n) { void *q = nullptr; hipError_t e = hipMalloc(&q, std::max<size_t>(sizeof(T) * n, 256)); if (e == hipSuccess) p.push_back(q); *out = (T *)q; return e; }
+};
+
+uint64_t art_pack(const char *s, uint32_t len) {      /* TwoBitSequence::compressSequence: anything but ACGT packs as A */
+	uint64_t v = 0;
+	for (uint32_t i = 0; i < len; i++) { const char c = s[i]; v = (v << 2) | (uint64_t)((c == 'C') ? 1 : (c == 'G') ? 2 : (c == 'T') ? 3 : 0); }
+	return v;
+}
+uint64_t art_revcomp_host(uint64_t v, uint32_t len) { uint64_t r = 0; for (uint32_t i = 0; i < len; i++) { r = (r << 2) | (3 - (v & 3)); v >>= 2; } return r; }
+
+/* (re)build the lookup table of the filter from its host entries */
+int art_upload(kmr_handle *h, kmr_artifact_filter *f) {
+	if (f->d_keys) { hipFree(f->d_keys); f->d_keys = nullptr; } if (f->d_vals) { hipFree(f->d_vals); f->d_vals = nullptr; }
+	f->n_keys = f->keys.size();
+	f->log2cap = art_log2cap(f->n_keys);
+	const uint64_t cap = 1ull << f->log2cap;
+	HIPCHK(h, hipMalloc((void **)&f->d_keys, 8 * cap)); HIPCHK(h, hipMalloc((void **)&f->d_vals, 4 * cap));
+	ArtBuf tmp; uint64_t *dk; uint32_t *dv;
+	HIPCHK(h, tmp.get(&dk, f->n_keys)); HIPCHK(h, tmp.get(&dv, f->n_keys));
+	if (f->n_keys) { HIPCHK(h, hipMemcpyAsync(dk, f->keys.data(), 8 * f->n_keys, hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipMemcpyAsync(dv, f->vals.data(), 4 * f->n_keys, hipMemcpyHostToDevice, h->stream)); }
+	ArtifactTable t{f->d_keys, f->d_vals, nullptr, f->log2cap};
+	hipLaunchKernelGGL(artifact_fill, dim3(1024), dim3(256), 0, h->stream, f->d_keys, (uint32_t *)nullptr, cap);
+	if (f->n_keys) hipLaunchKernelGGL(artifact_insert, dim3((unsigned)std::min<uint64_t>((f->n_keys + 255) / 256, 4096)), dim3(256), 0, h->stream, t, dk, dv, f->n_keys);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	return KMR_OK;
+}
+
+/* one round of prepareMaps' edit loop (src/FilterKnownOddities.h:264-282) on the device */
+int art_build_round(kmr_handle *h, kmr_artifact_filter *f) {
+	const uint32_t L = f->cfg.match_length, kb = L / 4;
+	const uint64_t n = f->keys.size();
+	/* the map's iteration order: bucket by bucket (KmerMap(512*1024): 512*1024/32+1 buckets rounded up to 2^15), sorted inside */
+	const uint64_t mask = resize_buckets(512 * 1024 / 32 + 1) - 1;
+	std::vector<std::pair<uint64_t, uint64_t>> order(n);
+	for (uint64_t i = 0; i < n; i++) {
+		uint8_t b[8];
+		for (uint32_t j = 0; j < kb; j++) b[j] = (uint8_t)(f->keys[i] >> (8 * (kb - 1 - j)));
+		order[i] = std::make_pair(kmr_hash(b, kb) & mask, i);
+	}
+	std::sort(order.begin(), order.end());       /* ties inside a bucket: ascending index = ascending key */
+	std::vector<uint64_t> sk(n); std::vector<uint32_t> sv(n);
+	for (uint64_t i = 0; i < n; i++) { sk[i] = f->keys[order[i].second]; sv[i] = f->vals[order[i].second]; }
+	const uint64_t worst = n * (3ull * L + 1);
+	if (worst > (1ull << 32)) return fail(h, KMR_ERR_UNSUPPORTED, "artifact filter: an edit round over " + std::to_string(n) + " keys does not fit the build table");
+	const uint32_t log2cap = art_log2cap(worst);
+	const uint64_t cap = 1ull << log2cap;
+	ArtBuf tmp; uint64_t *tk, *dk, *ok; uint32_t *tv, *tr, *dv, *ov; unsigned long long *cnt;
+	HIPCHK(h, tmp.get(&tk, cap)); HIPCHK(h, tmp.get(&tv, cap)); HIPCHK(h, tmp.get(&tr, cap));
+	HIPCHK(h, tmp.get(&dk, n)); HIPCHK(h, tmp.get(&dv, n)); HIPCHK(h, tmp.get(&cnt, 1));
+	HIPCHK(h, hipMemcpyAsync(dk, sk.data(), 8 * n, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(h, hipMemcpyAsync(dv, sv.data(), 4 * n, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(h, hipMemsetAsync(cnt, 0, 8, h->stream));
+	ArtifactTable t{tk, tv, tr, log2cap};
+	hipLaunchKernelGGL(artifact_fill, dim3(2048), dim3(256), 0, h->stream, tk, tr, cap);
+	hipLaunchKernelGGL(artifact_insert, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream, t, dk, dv, n);
+	hipLaunchKernelGGL(artifact_neighbours, dim3((unsigned)std::min<uint64_t>((n * L + 255) / 256, 1u << 20)), dim3(256), 0, h->stream, t, dk, n, L);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	/* the table is sparse (<= 50 % by construction, a few % in practice): count first, then compact */
+	HIPCHK(h, tmp.get(&ok, worst)); HIPCHK(h, tmp.get(&ov, worst));
+	hipLaunchKernelGGL(artifact_compact, dim3(2048), dim3(256), 0, h->stream, t, dv, ok, ov, cnt);
+	HIPCHK(h, hipGetLastError());
+	unsigned long long m = 0;
+	HIPCHK(h, hipMemcpyAsync(&m, cnt, 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	std::vector<uint64_t> nk(m); std::vector<uint32_t> nv(m);
+	HIPCHK(h, hipMemcpy(nk.data(), ok, 8 * m, hipMemcpyDeviceToHost)); HIPCHK(h, hipMemcpy(nv.data(), ov, 4 * m, hipMemcpyDeviceToHost));
+	std::vector<uint64_t> idx(m);
+	for (uint64_t i = 0; i < m; i++) idx[i] = i;
+	std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) { return nk[a] < nk[b]; });
+	f->keys.resize(m); f->vals.resize(m);
+	for (uint64_t i = 0; i < m; i++) { f->keys[i] = nk[idx[i]]; f->vals[i] = nv[idx[i]]; }
+	return KMR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void kmr_artifact_config_init(kmr_artifact_config *c) {
+	if (!c) return;
+	memset(c, 0, sizeof(*c));
+	c->match_length = 24; c->edit_distance = 2; c->build_edits = 2;      /* _FilterKnownOdditiesOptions(), src/FilterKnownOddities.h:72-75 */
+	c->min_quality = 3; c->fastq_start_char = 33; c->min_read_length = 0.40f;
+}
+
+int kmr_artifact_filter_create(kmr_handle *h, const kmr_artifact_config *cfg, const char *fasta, uint64_t len, kmr_artifact_filter **out) {
+	if (!h || !cfg || !out || (len && !fasta)) return KMR_ERR_INVALID_ARG;
+	*out = nullptr;
+	if (cfg->match_length == 0 || cfg->match_length > 28 || (cfg->match_length & 3))
+		return fail(h, KMR_ERR_INVALID_ARG, "artifact match length must be a multiple of 4 and <= 28 (src/FilterKnownOddities.h:207-209,244)");
+	hipSetDevice(h->device);
+	std::unique_ptr<kmr_artifact_filter> f(new kmr_artifact_filter);
+	f->device = h->device; f->cfg = *cfg;
+	const uint32_t L = cfg->match_length;
+	/* sequences: read 0 is the empty "no match" read, then the FASTA records in file order (:213-231) */
+	std::vector<std::string> seqs(1);
+	for (uint64_t i = 0; i < len;) {
+		uint64_t e = i; while (e < len && fasta[e] != '\n') e++;
+		uint64_t le = e; if (le > i && fasta[le - 1] == '\r') le--;
+		if (le > i) {
+			if (fasta[i] == '>') seqs.push_back(std::string());
+			else if (seqs.size() > 1) for (uint64_t j = i; j < le; j++) seqs.back().push_back((char)toupper((unsigned char)fasta[j]));
+		}
+		i = e + 1;
+	}
+	f->n_seq = (uint32_t)seqs.size();
+	std::vector<std::pair<uint64_t, uint32_t>> kv;
+	for (uint32_t s = 1; s < f->n_seq; s++) {
+		std::string q = seqs[s];
+		if (cfg->reference_begin == 0 || s < cfg->reference_begin) q += seqs[s].substr(0, L);      /* ReadSet::circularize, src/ReadSet.cpp:120-130 */
+		for (size_t j = 0; j + L <= q.size(); j++) {
+			const uint64_t v = art_pack(q.data() + j, L), r = art_revcomp_host(v, L);
+			kv.push_back(std::make_pair(r < v ? r : v, s));
+		}
+	}
+	std::sort(kv.begin(), kv.end());                  /* getOrSetElement in sequence order: the lowest sequence index keeps a key */
+	for (size_t i = 0; i < kv.size(); i++) if (i == 0 || kv[i].first != kv[i - 1].first) { f->keys.push_back(kv[i].first); f->vals.push_back(kv[i].second); }
+	int edits = (int)cfg->edit_distance;
+	const int maxErrors = edits;
+	for (int error = 0; error < maxErrors; error++) {
+		if (cfg->build_edits == 1 || (cfg->build_edits == 2 && f->keys.size() < 750000)) {
+			edits--;
+			if (!f->keys.empty()) { const int rc = art_build_round(h, f.get()); if (rc) return rc; }
+		}
+	}
+	if (edits > 2) return fail(h, KMR_ERR_UNSUPPORTED, "artifact filter: more than two edits left for query time");
+	f->remaining_edits = (uint32_t)edits;
+	const int rc = art_upload(h, f.get());
+	if (rc) return rc;
+	*out = f.release();
+	return KMR_OK;
+}
+int kmr_artifact_filter_info(const kmr_artifact_filter *f, uint64_t *n_sequences, uint64_t *n_filter_kmers, uint32_t *remaining_edits) {
+	if (!f) return KMR_ERR_INVALID_ARG;
+	if (n_sequences) *n_sequences = f->n_seq; if (n_filter_kmers) *n_filter_kmers = f->n_keys; if (remaining_edits) *remaining_edits = f->remaining_edits;
+	return KMR_OK;
+}
+int kmr_artifact_filter_entries(const kmr_artifact_filter *f, uint64_t *keys, uint32_t *values, uint64_t cap) {
+	if (!f) return KMR_ERR_INVALID_ARG;
+	if (cap < f->keys.size()) return KMR_ERR_CAPACITY;
+	if (keys) memcpy(keys, f->keys.data(), 8 * f->keys.size());
+	if (values) memcpy(values, f->vals.data(), 4 * f->vals.size());
+	return KMR_OK;
+}
+void kmr_artifact_filter_free(kmr_artifact_filter *f) {
+	if (!f) return;
+	hipSetDevice(f->device);
+	if (f->d_keys) hipFree(f->d_keys); if (f->d_vals) hipFree(f->d_vals);
+	delete f;
+}
+
+int kmr_artifact_filter_apply(kmr_handle *h, const kmr_artifact_filter *f, const kmr_reads *in, const int64_t *mate,
+                              uint32_t *value, uint32_t *min_pass, uint32_t *max_pass, uint8_t *action,
+                              uint32_t *remnant_off, uint32_t *remnant_len, kmr_reads **out) {
+	if (!h || !f || !in) return KMR_ERR_INVALID_ARG;
+	if (out) *out = nullptr;
+	if (f->device != h->device || in->device != h->device) return fail(h, KMR_ERR_INVALID_ARG, "filter, reads and handle must live on one device");
+	hipSetDevice(h->device);
+	const uint64_t n = in->n;
+	ArtifactTable t{f->d_keys, f->d_vals, nullptr, f->log2cap};
+	ArtifactParams P;
+	P.length = f->cfg.match_length; P.nSeq = f->n_seq; P.numErrors = f->remaining_edits;
+	P.srBegin = f->cfg.simple_repeat_begin; P.srEnd = f->cfg.simple_repeat_end; P.phix = f->cfg.phix_idx; P.refBegin = f->cfg.reference_begin;
+	P.minQualChar = (int32_t)(int8_t)(uint8_t)(f->cfg.fastq_start_char + f->cfg.min_quality);
+	P.minReadLength = f->cfg.min_read_length;
+	ArtBuf tmp;
+	uint32_t *dval, *dmin, *dmax, *dro, *drl, *dlen, *dflag; uint8_t *dact; int64_t *dmate = nullptr; uint64_t *dridx, *dsrc;
+	HIPCHK(h, tmp.get(&dval, n)); HIPCHK(h, tmp.get(&dmin, n)); HIPCHK(h, tmp.get(&dmax, n)); HIPCHK(h, tmp.get(&dro, n)); HIPCHK(h, tmp.get(&drl, n));
+	HIPCHK(h, tmp.get(&dact, n)); HIPCHK(h, tmp.get(&dflag, n)); HIPCHK(h, tmp.get(&dridx, n + 1));
+	if (mate && n) { HIPCHK(h, tmp.get(&dmate, n)); HIPCHK(h, hipMemcpyAsync(dmate, mate, 8 * n, hipMemcpyHostToDevice, h->stream)); }
+	uint64_t n_rem = 0;
+	if (n) {
+		const unsigned blocks = (unsigned)((n + 255) / 256);
+		hipLaunchKernelGGL(artifact_screen, dim3(blocks), dim3(256), 0, h->stream, in->bases, in->quals, in->offsets, n, t, P, dval, dmin, dmax, dro, drl);
+		HIPCHK(h, hipGetLastError());
+	}
+	/* lengths after the filter: n reads, then the remnants */
+	HIPCHK(h, tmp.get(&dlen, 2 * n + 1));
+	if (n) {
+		const unsigned blocks = (unsigned)((n + 255) / 256);
+		hipLaunchKernelGGL(artifact_action, dim3(blocks), dim3(256), 0, h->stream, in->offsets, n, dmate, P, dval, dmin, dmax, drl, dact, dlen, dflag);
+		HIPCHK(h, hipGetLastError());
+		int rc = exclusive_scan(h, dflag, n, dridx); if (rc) return rc;
+		HIPCHK(h, hipMemcpy(&n_rem, dridx + n, 8, hipMemcpyDeviceToHost));
+	}
+	HIPCHK(h, tmp.get(&dsrc, n_rem));
+	if (n_rem) {
+		hipLaunchKernelGGL(artifact_remnants, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, drl, dridx, dlen, dsrc);
+		HIPCHK(h, hipGetLastError());
+	}
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipError_t e = hipSuccess;
+	if (n) {
+		if (value && e == hipSuccess) e = hipMemcpy(value, dval, 4 * n, hipMemcpyDeviceToHost);
+		if (min_pass && e == hipSuccess) e = hipMemcpy(min_pass, dmin, 4 * n, hipMemcpyDeviceToHost);
+		if (max_pass && e == hipSuccess) e = hipMemcpy(max_pass, dmax, 4 * n, hipMemcpyDeviceToHost);
+		if (action && e == hipSuccess) e = hipMemcpy(action, dact, n, hipMemcpyDeviceToHost);
+		if (remnant_off && e == hipSuccess) e = hipMemcpy(remnant_off, dro, 4 * n, hipMemcpyDeviceToHost);
+		if (remnant_len && e == hipSuccess) e = hipMemcpy(remnant_len, drl, 4 * n, hipMemcpyDeviceToHost);
+	}
+	HIPCHK(h, e);
+	if (!out) return KMR_OK;
+	const uint64_t n_out = n + n_rem;
+	std::unique_ptr<kmr_reads, void (*)(kmr_reads *)> r(new kmr_reads, kmr_reads_free);
+	r->device = h->device; r->n = n_out; r->input_base = in->input_base; r->filtered = in->filtered;
+	HIPCHK(h, hipMalloc((void **)&r->offsets, 8 * (n_out + 1)));
+	if (n_out) { int rc = exclusive_scan(h, dlen, n_out, r->offsets); if (rc) return rc; HIPCHK(h, hipMemcpy(&r->total, r->offsets + n_out, 8, hipMemcpyDeviceToHost)); }
+	else HIPCHK(h, hipMemset(r->offsets, 0, 8));
+	HIPCHK(h, hipMalloc((void **)&r->bases, r->total + 64)); HIPCHK(h, hipMalloc((void **)&r->quals, r->total + 64));
+	HIPCHK(h, hipMemsetAsync(r->bases + r->total, 0, 64, h->stream)); HIPCHK(h, hipMemsetAsync(r->quals + r->total, 0, 64, h->stream));
+	HIPCHK(h, hipMalloc((void **)&r->name_off, 8 * std::max<uint64_t>(n_out, 1))); HIPCHK(h, hipMalloc((void **)&r->name_len, 4 * std::max<uint64_t>(n_out, 1)));
+	if (n_out) {
+		hipLaunchKernelGGL(artifact_gather, dim3((unsigned)std::min<uint64_t>((n_out + 3) / 4, 1u << 16)), dim3(256), 0, h->stream,
+		                   in->bases, in->quals, in->offsets, in->name_off, in->name_len, n, n_out, dact, dmin, dro, dsrc, r->offsets, r->bases, r->quals, r->name_off, r->name_len);
+		HIPCHK(h, hipGetLastError());
+	}
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	*out = r.release();
+	return KMR_OK;
 }
 
 /* ---- stateless helpers ------------------------------------------------- */

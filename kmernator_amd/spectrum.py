@@ -322,6 +322,16 @@ class ReadSet:
         spectrum.lib.kmr_reads_info(self.r, C.byref(n), C.byref(tot), C.byref(qb), C.byref(nf))
         self.n, self.total_bases, self.input_quality_base, self.filtered = n.value, tot.value, qb.value, nf.value
 
+    @classmethod
+    def _adopt(cls, spectrum, text, handle):
+        """wrap a kmr_reads the library produced from another batch (names still point into `text`)"""
+        self = cls.__new__(cls)
+        self.sp, self.text, self.r = spectrum, text, handle
+        n, tot, qb, nf = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()
+        spectrum.lib.kmr_reads_info(self.r, C.byref(n), C.byref(tot), C.byref(qb), C.byref(nf))
+        self.n, self.total_bases, self.input_quality_base, self.filtered = n.value, tot.value, qb.value, nf.value
+        return self
+
     def getSize(self):
         return self.n
 
@@ -343,6 +353,71 @@ class ReadSet:
         if getattr(self, "r", None):
             self.sp.lib.kmr_reads_free(self.r)
             self.r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FilterKnownOddities:
+    """The artifact filter FilterReads runs before the spectrum build (src/FilterKnownOddities.h, apps/FilterReads.cpp:107-118):
+    quality-run trimming plus a screen of every 4th 24-mer of a read against the artifact sequences (and their substitution
+    neighbours), on the device.  `fasta` = the sequences as FASTA text (the reference embeds its own table); keyword
+    arguments are the fields of kmr_artifact_config (edit_distance, min_quality, fastq_start_char, min_read_length, ...)."""
+
+    def __init__(self, spectrum, fasta, **kw):
+        self.sp = spectrum
+        cfg = _lib.KmrArtifactConfig()
+        spectrum.lib.kmr_artifact_config_init(C.byref(cfg))
+        cfg.fastq_start_char = spectrum.cfg.fastq_start_char
+        cfg.min_quality = spectrum.cfg.min_quality_score
+        for name, v in kw.items():
+            if not hasattr(cfg, name):
+                raise TypeError("unknown artifact filter option %r" % name)
+            setattr(cfg, name, v)
+        self.cfg = cfg
+        fasta = bytes(fasta)
+        f = C.c_void_p()
+        spectrum._call("artifact_filter_create", spectrum.h, C.byref(cfg), fasta, len(fasta), C.byref(f))
+        self.f = f
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        spectrum.lib.kmr_artifact_filter_info(self.f, C.byref(a), C.byref(b), C.byref(c))
+        self.n_sequences, self.n_filter_kmers, self.remaining_edits = a.value, b.value, c.value
+
+    def entries(self):
+        keys = np.zeros(self.n_filter_kmers, dtype=np.uint64)
+        vals = np.zeros(self.n_filter_kmers, dtype=np.uint32)
+        rc = self.sp.lib.kmr_artifact_filter_entries(self.f, keys.ctypes.data_as(C.POINTER(C.c_uint64)), vals.ctypes.data_as(C.POINTER(C.c_uint32)), keys.size)
+        if rc != 0:
+            raise KmerSpectrumError("kmr_artifact_filter_entries: %s" % _lib.STATUS.get(rc, rc))
+        return keys, vals
+
+    def applyFilter(self, reads, mate=None, want_reads=True):
+        """applyFilter(ReadSet&) (:663-733).  Returns (results, filtered ReadSet): results = dict of per-read arrays value,
+        min_pass, max_pass, action (0 untouched / 1 trimmed / 2 discarded), remnant_off, remnant_len; the new ReadSet holds the
+        trimmed reads in place and the rescued remnants behind them."""
+        n = reads.n
+        res = {k: np.zeros(max(1, n), dtype=np.uint32) for k in ("value", "min_pass", "max_pass", "remnant_off", "remnant_len")}
+        res["action"] = np.zeros(max(1, n), dtype=np.uint8)
+        u32 = C.POINTER(C.c_uint32)
+        m = None
+        if mate is not None:
+            mate = np.ascontiguousarray(mate, dtype=np.int64)
+            assert mate.size == n
+            m = mate.ctypes.data_as(C.POINTER(C.c_int64))
+        out = C.c_void_p()
+        self.sp._call("artifact_filter_apply", self.sp.h, self.f, reads.r, m, res["value"].ctypes.data_as(u32), res["min_pass"].ctypes.data_as(u32),
+                      res["max_pass"].ctypes.data_as(u32), res["action"].ctypes.data_as(C.POINTER(C.c_uint8)), res["remnant_off"].ctypes.data_as(u32),
+                      res["remnant_len"].ctypes.data_as(u32), C.byref(out) if want_reads else None)
+        res = {k: v[:n] for k, v in res.items()}
+        return res, (ReadSet._adopt(self.sp, reads.text, out) if want_reads else None)
+
+    def close(self):
+        if getattr(self, "f", None):
+            self.sp.lib.kmr_artifact_filter_free(self.f)
+            self.f = None
 
     def __del__(self):
         try:

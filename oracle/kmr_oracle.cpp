@@ -1284,11 +1284,10 @@ struct ArtifactFilter {
 		for (uint32_t b = startIdx; b < length; b++) {
 			const uint32_t sh = 2 * (length - 1 - b);
 			const uint64_t cur = (key >> sh) & 3;
-			for (uint64_t nb = 0; nb < 4; nb++) if (nb != cur) {
-				const uint64_t v = (key & ~(3ull << sh)) | (nb << sh);
-				hit(v);
-				if (editDistance > 1) permuteQuery(v, b + 1, editDistance - 1, hit);
-			}
+			uint64_t v[3]; int n = 0;
+			for (uint64_t nb = 0; nb < 4; nb++) if (nb != cur) v[n++] = (key & ~(3ull << sh)) | (nb << sh);   /* permutations[] order, TwoBitSequence.cpp:187-201 */
+			for (int i = 0; i < 3; i++) hit(v[i]);                        /* the array holds v1 v2 v3, then their subtrees */
+			if (editDistance > 1) for (int i = 0; i < 3; i++) permuteQuery(v[i], b + 1, editDistance - 1, hit);
 		}
 	}
 	static bool passesLength(float length, uint32_t readLength, float minimumLength) {      /* src/ReadSelector.h:219-228 */

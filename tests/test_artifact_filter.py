@@ -90,3 +90,204 @@ def test_golden_filterreads_end_to_end():
         if m:
             seq = seq[int(m.group(1)):int(m.group(1)) + int(m.group(2))]
         assert seq == gold.seq(i), (i, gold.names[i])
+
+
+# ---------------------------------------------------------------- product (GPU) against the oracle, through the C-ABI
+
+def _fastq_text(rb, names=None):
+    out = []
+    for i in range(rb.n):
+        out.append(b"@" + (names[i] if names else b"r%d" % i) + b"\n" + rb.seq(i) + b"\n+\n" + rb.qual(i) + b"\n")
+    return b"".join(out)
+
+
+def _device_filter(cfg_kw, fasta_text, k=31):
+    import kmernator_amd as ka
+    sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=100000, device=0))
+    return sp, ka.FilterKnownOddities(sp, fasta_text, **cfg_kw)
+
+
+def _all_tables():
+    """artifact table + simple repeats + PhiX in the order the reference appends them (:213-229), with the class ranges"""
+    a, s, p = fasta("artifact_sequences.fa"), fasta("simple_repeats.fa"), fasta("phix.fa")
+    na, ns = a.count(b">"), s.count(b">")
+    return a + s + p, dict(simple_repeat_begin=1 + na, simple_repeat_end=1 + na + ns, phix_idx=1 + na + ns)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(edit_distance=0), dict(edit_distance=1), dict(), dict(edit_distance=3), dict(build_edits=0), dict(match_length=20, edit_distance=1)])
+def test_filter_set_matches_oracle(kw):
+    """prepareMaps on the device: same keys, same sequence index per key (first writer in the map's iteration order)"""
+    o = OracleArtifactFilter(artifact_config(**kw), fasta("artifact_sequences.fa"))
+    sp, f = _device_filter(kw, fasta("artifact_sequences.fa"))
+    assert (f.n_sequences, f.n_filter_kmers, f.remaining_edits) == o.info()
+    ko, vo = o.entries()
+    kd, vd = f.entries()
+    assert np.array_equal(kd, ko) and np.array_equal(vd, vo)
+
+
+@pytest.mark.gpu
+def test_filter_set_with_repeats_and_phix():
+    text, cls = _all_tables()
+    kw = dict(edit_distance=2, **cls)
+    o = OracleArtifactFilter(artifact_config(**kw), text)
+    sp, f = _device_filter(kw, text)
+    assert (f.n_sequences, f.n_filter_kmers, f.remaining_edits) == o.info()
+    assert f.n_filter_kmers > 100000
+    ko, vo = o.entries()
+    kd, vd = f.entries()
+    assert np.array_equal(kd, ko) and np.array_equal(vd, vo)
+
+
+def _check_apply(f, o, rs, rb, mate=None):
+    want = o.apply(rb, mate)
+    got, frs = f.applyFilter(rs, mate)
+    for key in ("value", "min_pass", "max_pass", "action", "remnant_off", "remnant_len"):
+        bad = np.nonzero(got[key] != want[key])[0]
+        assert bad.size == 0, (key, bad[:5], got[key][bad[:5]], want[key][bad[:5]])
+    fr = apply_artifact_result(rb, want)
+    b, q, off, names = frs.arrays()
+    assert frs.n == fr.n and np.array_equal(off, fr.offsets)
+    assert np.array_equal(b, fr.bases) and np.array_equal(q, fr.quals)
+    return want, frs, names
+
+
+@pytest.mark.gpu
+def test_golden_filterreads_end_to_end_on_the_device():
+    """FASTQ text -> device reads -> artifact filter -> spectrum of the filtered reads -> scoreAndTrimReads, everything on
+    the device: every label of all 1000 reads of test/1000-Filtered.fastq incl. the 51 AFTrim ones"""
+    import kmernator_amd as ka
+    gold = read_fastq(os.path.join(GOLDEN, "1000-Filtered.fastq"))
+    sp = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=46000, device=0))
+    rs = ka.ReadSet(sp, fasta("1000.fastq"))
+    assert rs.input_quality_base == 64
+    f = ka.FilterKnownOddities(sp, fasta("artifact_sequences.fa"), edit_distance=1, min_read_length=25.0)
+    res, frs = f.applyFilter(rs)
+    assert frs.n == 1000 and int((res["action"] == 1).sum()) == 51 and not (res["action"] == 2).any()
+    sp.buildKmerSpectrumFromReadSet(frs)
+    sp.finalize(2)
+    to, tl, sc, wt = sp.scoreAndTrimReadSet(frs, 2, "MEDIAN")
+    b, q, off, names = frs.arrays()
+    for i in range(1000):
+        label = b""
+        if res["action"][i] == 1:
+            label += b"AFTrim:%d+%d " % (res["min_pass"][i], res["max_pass"][i] - res["min_pass"][i])
+        if wt[i]:
+            label += b"Trim:%d+%d " % (to[i], tl[i])
+        label += b"MedianScore:%d" % int(sc[i] + 0.5)
+        assert names[i].split(b" ")[0] == gold.names[i].split(b" ")[0]
+        assert label == gold.names[i].split(b" ", 1)[1].replace(b"\t", b" "), (i, label, gold.names[i])
+        seq = bytes(b[int(off[i]):int(off[i + 1])])
+        if wt[i]:
+            seq = seq[int(to[i]):int(to[i]) + int(tl[i])]
+        assert seq == gold.seq(i), (i, gold.names[i])
+
+
+def _spiked_reads(n, seed, tables, read_len=(30, 160)):
+    """synthetic reads with what the filter reacts to: adapter / repeat / PhiX pieces (exact and with one or two substitutions)
+    at random places, runs of low quality, N's, reads shorter than the match length"""
+    rng = np.random.default_rng(seed)
+    seqs = []
+    cur = None
+    for line in tables.split(b"\n"):
+        if line.startswith(b">"):
+            cur = []
+            seqs.append(cur)
+        elif cur is not None and line:
+            cur.append(line)
+    seqs = [b"".join(s) for s in seqs]
+    out_s, out_q = [], []
+    for i in range(n):
+        L = int(rng.integers(read_len[0], read_len[1])) if rng.random() > 0.03 else int(rng.integers(1, 30))
+        s = bytearray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L).tobytes())
+        q = bytearray(rng.choice(np.frombuffer(b"5:?DI", dtype=np.uint8), size=L).tobytes())
+        r = rng.random()
+        if r < 0.5 and L >= 30:
+            a = seqs[int(rng.integers(0, len(seqs)))]
+            a = a + a
+            piece = bytearray(a[int(rng.integers(0, max(1, len(a) // 2))):][:int(rng.integers(20, 60))])
+            for _ in range(int(rng.integers(0, 3))):
+                if len(piece):
+                    piece[int(rng.integers(0, len(piece)))] = b"ACGT"[int(rng.integers(0, 4))]
+            at = int(rng.integers(0, L))
+            s[at:at + len(piece)] = piece
+            s = s[:L]
+        if rng.random() < 0.4 and L:
+            for _ in range(int(rng.integers(1, 4))):
+                at, ln = int(rng.integers(0, L)), int(rng.integers(1, 12))
+                q[at:at + ln] = b"#" * len(q[at:at + ln])
+        if rng.random() < 0.1 and L:
+            s[int(rng.integers(0, L))] = ord("N")
+        out_s.append(bytes(s))
+        out_q.append(bytes(q))
+    return ReadBatch(out_s, out_q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(edit_distance=1, min_read_length=25.0), dict(edit_distance=0, min_read_length=0.5),
+                                dict(edit_distance=3), dict(build_edits=0, edit_distance=1), dict(build_edits=0, edit_distance=2, min_read_length=0.0)])
+def test_screen_matches_oracle_on_spiked_reads(kw):
+    """applyFilterToRead / recordAffectedRead on reads with adapters (0-2 substitutions), low-quality runs, N's and short reads;
+    query-time edits 0, 1 and 2"""
+    import kmernator_amd as ka
+    table = fasta("artifact_sequences.fa")
+    rb = _spiked_reads(3000 if kw.get("build_edits", 2) else 600, 7, table)
+    o = OracleArtifactFilter(artifact_config(**kw), table)
+    sp, f = _device_filter(kw, table)
+    rs = ka.ReadSet(sp, _fastq_text(rb), input_quality_base=33)
+    assert rs.n == rb.n
+    want, frs, _ = _check_apply(f, o, rs, rb)
+    assert (want["action"] == 1).sum() > 50 and ((want["action"] == 2).sum() > 10 or kw.get("min_read_length") == 0.0)
+    assert kw.get("min_read_length") == 0.5 or (want["remnant_len"] > 0).sum() > 5      # two runs of half a read cannot both exist
+    assert ((want["value"] > 0) & (want["value"] < o.info()[0])).sum() > (100 if rb.n >= 3000 else 20)        # real artifact hits, not only quality trims
+
+
+@pytest.mark.gpu
+def test_pairs_repeats_phix_and_reference_sequences():
+    """applyFilterToPair: PhiX in one read discards the pair, a hit to an --artifact-reference-file sequence discards instead of
+    trimming, simple repeats in the middle of a read with good margins are let through"""
+    import kmernator_amd as ka
+    text, cls = _all_tables()
+    rng = np.random.default_rng(3)
+    ref = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=400).tobytes())
+    nseq = text.count(b">")
+    text = text + b">reference_1\n" + ref + b"\n"
+    kw = dict(edit_distance=1, min_read_length=0.3, reference_begin=1 + nseq, **cls)
+    spikes = fasta("phix.fa") + b">reference_1\n" + ref + b"\n"            # pieces come from PhiX, the reference sequence,
+    spikes = spikes * 8 + fasta("artifact_sequences.fa") + fasta("simple_repeats.fa")[:4000]      # the adapters and a few repeats
+    rb = _spiked_reads(4000, 11, spikes, read_len=(60, 200))
+    mate = np.arange(rb.n, dtype=np.int64) ^ 1
+    mate[-100:] = -1                                          # the last 100 reads are unpaired
+    o = OracleArtifactFilter(artifact_config(**kw), text)
+    sp, f = _device_filter(kw, text)
+    rs = ka.ReadSet(sp, _fastq_text(rb), input_quality_base=33)
+    want, frs, _ = _check_apply(f, o, rs, rb, mate)
+    n_all = o.info()[0]
+    assert (want["value"] == cls["phix_idx"]).sum() > 20
+    assert ((want["value"] >= cls["simple_repeat_begin"]) & (want["value"] < cls["simple_repeat_end"])).sum() > 20
+    assert ((want["value"] >= kw["reference_begin"]) & (want["value"] < n_all)).sum() > 5
+    # a clean read whose mate hit PhiX is discarded too
+    clean_discarded = (want["value"] == 0) & (want["action"] == 2)
+    assert clean_discarded.sum() > 5
+    # and without the mates it is not
+    want1, _, _ = _check_apply(f, o, rs, rb, None)
+    assert not ((want1["value"] == 0) & (want1["action"] != 0)).any()
+
+
+@pytest.mark.gpu
+def test_filter_errors_and_empty_batches():
+    import kmernator_amd as ka
+    sp = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=1000, device=0))
+    with pytest.raises(ka.KmerSpectrumError):
+        ka.FilterKnownOddities(sp, fasta("artifact_sequences.fa"), match_length=30)
+    with pytest.raises(ka.KmerSpectrumError):
+        ka.FilterKnownOddities(sp, fasta("artifact_sequences.fa"), match_length=22)
+    f = ka.FilterKnownOddities(sp, b"", edit_distance=1)                   # no sequences: only the quality screen acts
+    assert (f.n_sequences, f.n_filter_kmers) == (1, 0)
+    rs = ka.ReadSet(sp, b"@a\nACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIII#IIIIIIIIIIIIIII\n", input_quality_base=33)
+    res, frs = f.applyFilter(rs)
+    assert (res["value"][0], res["action"][0], res["min_pass"][0], res["max_pass"][0]) == (1, 1, 0, 16)
+    assert frs.n == 2 and (res["remnant_off"][0], res["remnant_len"][0]) == (17, 15)      # 15 of 32 >= 0.40: rescued
+    empty = ka.ReadSet(sp, b"")
+    res, frs = f.applyFilter(empty)
+    assert frs.n == 0 and res["action"].size == 0
