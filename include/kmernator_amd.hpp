@@ -27,6 +27,7 @@
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -87,6 +88,9 @@ public:
 	std::string getName(uint64_t i) const { return _text.substr(_nameOff[i], _nameLen[i]); }
 	const kmr_reads *raw() const { return _r; }
 private:
+	friend class FilterKnownOddities;
+	ReadSet(const std::string &text, kmr_reads *r) : _text(text), _r(r) { load(); }      /* a batch the library derived from another one */
+	void load();
 	std::string _text; kmr_reads *_r = nullptr; uint64_t _n = 0, _bases = 0, _filtered = 0; uint32_t _qbase = 0;
 	std::vector<uint64_t> _nameOff; std::vector<uint32_t> _nameLen;
 };
@@ -105,6 +109,7 @@ public:
 	uint32_t k() const { return _cfg.k; }
 	uint32_t keyBytes() const { return (_cfg.k + 3) / 4; }
 	kmr_handle *raw() { return _h; }
+	const kmr_config &config() const { return _cfg; }
 
 	void reset() { check(kmr_reset(_h), "kmr_reset"); }
 	void buildKmerSpectrum(const char *bases, const char *quals, const uint64_t *offsets, uint64_t nReads, uint64_t firstReadIdx = 0, const uint8_t *discarded = nullptr) {
@@ -172,14 +177,45 @@ private:
 	}
 	kmr_config _cfg; kmr_handle *_h = nullptr;
 	friend class ReadSet;
+	friend class FilterKnownOddities;
 };
 
 inline ReadSet::ReadSet(KmerSpectrum &sp, const std::string &fastqText, uint32_t inputQualityBase, bool storeComment) : _text(fastqText) {
 	sp.check(kmr_ingest_fastq(sp._h, _text.data(), _text.size(), inputQualityBase, storeComment ? 1 : 0, &_r), "kmr_ingest_fastq");
+	load();
+}
+inline void ReadSet::load() {
 	kmr_reads_info(_r, &_n, &_bases, &_qbase, &_filtered);
 	_nameOff.resize(_n ? _n : 1); _nameLen.resize(_n ? _n : 1);
 	if (kmr_reads_copy(_r, nullptr, nullptr, nullptr, _nameOff.data(), _nameLen.data()) != KMR_OK) throw KmerSpectrumError(KMR_ERR_HIP, "kmr_reads_copy");
 }
+
+/* FilterKnownOddities (src/FilterKnownOddities.h): the artifact screen FilterReads runs before the spectrum build */
+class FilterKnownOddities {
+public:
+	struct Results {                      /* per read, FilterResults (:289-296) + what recordAffectedRead did with it */
+		std::vector<uint32_t> value, minPass, maxPass, remnantOffset, remnantLength;
+		std::vector<uint8_t> action;      /* 0 untouched, 1 trimmed ("AFTrim:<minPass>+<maxPass-minPass>"), 2 discarded */
+	};
+	static kmr_artifact_config defaults(const kmr_config &sp) { kmr_artifact_config c; kmr_artifact_config_init(&c); c.fastq_start_char = sp.fastq_start_char; c.min_quality = sp.min_quality_score; return c; }
+	FilterKnownOddities(KmerSpectrum &sp, const std::string &artifactFasta, const kmr_artifact_config &cfg) : _sp(sp) {
+		sp.check(kmr_artifact_filter_create(sp.raw(), &cfg, artifactFasta.data(), artifactFasta.size(), &_f), "kmr_artifact_filter_create");
+	}
+	~FilterKnownOddities() { kmr_artifact_filter_free(_f); }
+	FilterKnownOddities(const FilterKnownOddities &) = delete; FilterKnownOddities &operator=(const FilterKnownOddities &) = delete;
+	uint64_t getFilterSize() const { uint64_t n = 0; kmr_artifact_filter_info(_f, nullptr, &n, nullptr); return n; }
+	/* applyFilter(ReadSet&) (:663-733): the reads afterwards (trimmed in place, remnants appended); mate = paired read or -1 */
+	std::unique_ptr<ReadSet> applyFilter(const ReadSet &reads, Results &res, const int64_t *mate = nullptr) {
+		const uint64_t n = reads.getSize(), m = n ? n : 1;
+		res.value.assign(m, 0); res.minPass.assign(m, 0); res.maxPass.assign(m, 0); res.remnantOffset.assign(m, 0); res.remnantLength.assign(m, 0); res.action.assign(m, 0);
+		kmr_reads *out = nullptr;
+		_sp.check(kmr_artifact_filter_apply(_sp.raw(), _f, reads.raw(), mate, res.value.data(), res.minPass.data(), res.maxPass.data(), res.action.data(),
+		                                    res.remnantOffset.data(), res.remnantLength.data(), &out), "kmr_artifact_filter_apply");
+		return std::unique_ptr<ReadSet>(new ReadSet(reads._text, out));
+	}
+private:
+	KmerSpectrum &_sp; kmr_artifact_filter *_f = nullptr;
+};
 
 }  // namespace kmernator
 #endif

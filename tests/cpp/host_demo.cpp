@@ -1,7 +1,7 @@
 // C++ host side above the C-ABI, driven the way the reference's apps drive KmerSpectrum:
 //   host_demo mercount <fastq> <out-prefix>      MeraculousCounter (apps/MeraculousCounter.cpp:110-151): k = 21,
 //                                                --min-kmer-quality 0 --min-quality-score 2, dumpCounts + dumpGraphs
-//   host_demo filter   <fastq> <out-file>        FilterReads (apps/FilterReads.cpp:83-215) up to scoreAndTrimReads:
+//   host_demo filter   <fastq> <out-file> [artifacts.fa]        FilterReads (apps/FilterReads.cpp:83-215) up to scoreAndTrimReads:
 //                                                k = 31, one line "<name> [Trim:o+l ]MedianScore:s" per read
 // Exit code 3 = no HIP device (the library has no CPU path).
 #include <cstdio>
@@ -16,7 +16,7 @@ using namespace kmernator;
 static std::string slurp(const char *path) { std::ifstream f(path, std::ios::binary); return std::string(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()); }
 
 int main(int argc, char **argv) {
-	if (argc < 4) { std::fprintf(stderr, "usage: host_demo mercount|filter <fastq> <out>\n"); return 2; }
+	if (argc < 4) { std::fprintf(stderr, "usage: host_demo mercount|filter <fastq> <out> [artifacts.fa]\n"); return 2; }
 	const std::string mode = argv[1], text = slurp(argv[2]), out = argv[3];
 	try {
 		if (mode == "mercount") {
@@ -33,7 +33,18 @@ int main(int argc, char **argv) {
 			            (unsigned long long)sp.getRawKmers(), (unsigned long long)sp.getUniqueKmers());
 		} else if (mode == "filter") {
 			KmerSpectrum sp(KmerSpectrum::defaults(31, 46000));
-			ReadSet reads(sp, text);
+			ReadSet input(sp, text);
+			/* with a 4th argument (FASTA of artifact sequences) the artifact filter runs first, as in FilterReads.cpp:107-118
+			 * with the settings of test/runFilterTests.sh (--artifact-edit-distance 1 --min-read-length 25) */
+			std::unique_ptr<ReadSet> filtered;
+			FilterKnownOddities::Results fr;
+			if (argc > 4) {
+				kmr_artifact_config ac = FilterKnownOddities::defaults(sp.config());
+				ac.edit_distance = 1; ac.min_read_length = 25.0f;
+				FilterKnownOddities filter(sp, slurp(argv[4]), ac);
+				filtered = filter.applyFilter(input, fr);
+			}
+			const ReadSet &reads = filtered ? *filtered : input;
 			sp.buildKmerSpectrum(reads);
 			sp.purgeMinDepth(2);
 			KmerSpectrum::TrimResult r = sp.scoreAndTrimReads(reads, 2, KmerSpectrum::KS_MEDIAN);
@@ -42,6 +53,7 @@ int main(int argc, char **argv) {
 				std::string name = reads.getName(i);
 				name = name.substr(0, name.find_first_of(" \t"));
 				o << name << " ";
+				if (filtered && i < input.getSize() && fr.action[i] == 1) o << "AFTrim:" << fr.minPass[i] << "+" << (fr.maxPass[i] - fr.minPass[i]) << " ";
 				if (r.wasTrimmed[i]) o << "Trim:" << r.trimOffset[i] << "+" << r.trimLength[i] << " ";
 				o << "MedianScore:" << (long)(r.score[i] + 0.5) << "\n";
 			}

@@ -67,3 +67,18 @@ def test_cpp_filterreads_labels(tmp_path):
         assert line.split(" ", 1)[1].encode() == gold.names[i].split(b" ", 1)[1], (i, line, gold.names[i])
         checked += 1
     assert checked == 949
+
+
+@pytest.mark.gpu
+def test_cpp_filterreads_with_artifact_filter(tmp_path):
+    """the same flow with FilterKnownOddities in front (C++ mirror class): all 1000 labels incl. the 51 AFTrim ones"""
+    demo = build_demo()
+    out = str(tmp_path / "labels")
+    p = subprocess.run([demo, "filter", os.path.join(GOLDEN, "1000.fastq"), out, os.path.join(GOLDEN, "artifact_sequences.fa")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    gold = read_fastq(os.path.join(GOLDEN, "1000-Filtered.fastq"))
+    lines = open(out).read().splitlines()
+    assert len(lines) == 1000
+    for i, line in enumerate(lines):
+        assert line.split(" ", 1)[1].encode() == gold.names[i].split(b" ", 1)[1].replace(b"\t", b" "), (i, line, gold.names[i])
+    assert sum("AFTrim" in line for line in lines) == 51

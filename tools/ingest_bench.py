@@ -34,3 +34,16 @@ for rep in range(2):
     assert rc == 0; t3 = time.time()
 print("build %.1f ms; scoreAndTrimReads of %d reads (%d k-mer lookups) %.1f ms -> %.2f G lookups/s; trimmed %d, median of medians %.0f" % (
     (t1 - t0) * 1e3, n, n * 120, (t3 - t2) * 1e3, n * 120 / (t3 - t2) / 1e9, int(wt.sum()), float(np.median(sc))))
+# the artifact filter in front of the build (FilterKnownOddities): the reference's table, default settings
+table = open(os.path.join(ROOT, "tests", "golden", "artifact_sequences.fa"), "rb").read()
+rs = ka.ReadSet._adopt(sp, text, r)
+for kw in (dict(), dict(edit_distance=3)):
+    t0 = time.time(); f = ka.FilterKnownOddities(sp, table, **kw); t1 = time.time()
+    for rep in range(2):
+        t2 = time.time(); res, _ = f.applyFilter(rs, want_reads=False); t3 = time.time()
+    t4 = time.time(); res, frs = f.applyFilter(rs); t5 = time.time()
+    print("artifact filter %s: %d keys built in %.0f ms, %d edits at query time; screen of %d reads %.1f ms (%.1f GB/s of bases+quals), with the filtered batch %.1f ms; trimmed %d, discarded %d, remnants %d" % (
+        kw, f.n_filter_kmers, (t1 - t0) * 1e3, f.remaining_edits, n, (t3 - t2) * 1e3, 2 * tot.value / (t3 - t2) / 1e9, (t5 - t4) * 1e3,
+        int((res["action"] == 1).sum()), int((res["action"] == 2).sum()), int((res["remnant_len"] > 0).sum())), flush=True)
+    frs.close(); f.close()
+rs.r = None
