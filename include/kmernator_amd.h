@@ -279,6 +279,29 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
 /* Insert n records (any owner mix that belongs to this handle) into the table. */
 int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n_records);
 
+/* ---- f1, distributed form: scoreAndTrimReads when the spectrum is partitioned by owner --------
+ * DistributedReadSelector::scoreAndTrimReads / _batchKmerLookup (src/DistributedFunctions.h:876-1045): every k-mer of a
+ * rank's reads is looked up at its owner (request = requestId + k-mer, response = requestId + score over
+ * MPI_Alltoallv).  Here a request is the key alone (8 * KMR_KEY_WORDS(k) bytes: the u64 key words, most significant
+ * first) and a response a u32 count: the answers come back in request order, so the requester keeps the position of
+ * each request instead of sending an id.
+ *
+ * kmr_lookup_requests_dev: every k-mer without markup of a device-resident read batch, binned by owner into world_size
+ * segments of dev_keys (segment s starts at key seg_capacity * s); dev_pos[seg_capacity * s + j] (u32) = position of
+ * request j's first base in dev_bases (offsets[r] + i; < 2^32), dev_seg_counts[world_size] (u64) the exact counts.
+ * kmr_lookup_keys_dev: owner side, weak-map count of n received keys (ReadSelector::getValue, src/ReadSelector.h:924-931).
+ * kmr_scatter_counts_dev: position_counts[pos[j]] = counts[j] for the answers of one owner segment.
+ * kmr_score_counts_dev: trimReadByMinimumKmerScore + scoring + setTrimHeaders (as kmr_score_reads) from counts indexed
+ * by base position (u32 position_counts[total_bases], zero where no answer was written).
+ * All asynchronous on the handle's stream except kmr_score_counts_dev, which returns host arrays. */
+int kmr_lookup_requests_dev(kmr_handle *h, const void *dev_bases, const void *dev_offsets, uint64_t n_reads, uint64_t total_bases,
+                            void *dev_keys, void *dev_pos, uint64_t seg_capacity, void *dev_seg_counts);
+int kmr_lookup_keys_dev(kmr_handle *h, const void *dev_keys, uint64_t n, void *dev_counts);
+int kmr_scatter_counts_dev(kmr_handle *h, const void *dev_counts, const void *dev_pos, uint64_t n, void *dev_position_counts);
+int kmr_score_counts_dev(kmr_handle *h, const void *dev_bases, const void *dev_offsets, uint64_t n_reads, const void *dev_position_counts,
+                         double minimum_kmer_score, int scoring_type, uint32_t *trim_offset, uint32_t *trim_length,
+                         float *score, uint8_t *was_trimmed);
+
 /* ---- f2: FASTQ ingest on the device -------------------------------------
  * Parses a whole in-memory FASTQ block into a device-resident read batch:
  * FastqStreamParser::readRecord (src/ReadFileReader.h:768-835) + ReadFileReader::nextRead

@@ -763,7 +763,7 @@ void choose_bits1(kmr_handle *h, uint64_t records_hint) {
 }
 
 /* sender side of the exchange: reads -> linear records (every owner's) -> owner segments */
-template <int W, bool EXT> int extract_by_owner_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases, void *dev_records, uint64_t seg_capacity, void *dev_seg_counts) {
+template <int W, bool EXT> int extract_by_owner_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases, void *dev_records, uint64_t seg_capacity, void *dev_seg_counts, uint32_t *dev_pos = nullptr) {
 	const uint64_t n = rvAll.n_reads;
 	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
 	const uint64_t chunk = std::max<uint64_t>(64, (SUB_BATCH_BASES / avg) & ~63ull);
@@ -789,8 +789,12 @@ template <int W, bool EXT> int extract_by_owner_t(kmr_handle *h, const ReadsView
 		rc = launch_extract<W, EXT>(h, rv, op); if (rc) return rc;
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 8, tiles);
-		hipLaunchKernelGGL((owner_scatter_kernel<W, EXT>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->kb,
-		                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr);
+		if (dev_pos)
+			hipLaunchKernelGGL((owner_scatter_kernel<W, EXT, true>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->kb,
+			                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr, dev_pos);
+		else
+			hipLaunchKernelGGL((owner_scatter_kernel<W, EXT>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->kb,
+			                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr, (uint32_t *)nullptr);
 		HIPCHK(h, hipGetLastError());
 	}
 	return 0;
@@ -2054,6 +2058,71 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
 #undef REC
 	h->stream_base += total_bases; h->reads += n_reads;
 	return rc;
+}
+
+/* ---- f1, distributed form: lookups of k-mers other ranks own (DistributedReadSelector, src/DistributedFunctions.h:809-1045) */
+int kmr_lookup_requests_dev(kmr_handle *h, const void *dev_bases, const void *dev_offsets, uint64_t n_reads, uint64_t total_bases,
+                            void *dev_keys, void *dev_pos, uint64_t seg_capacity, void *dev_seg_counts) {
+	if (!h || !dev_bases || !dev_offsets || !dev_keys || !dev_pos || !dev_seg_counts) return KMR_ERR_INVALID_ARG;
+	if (h->cfg.world_size > (uint32_t)OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "owner exchange supports up to 8 ranks per node");
+	if (total_bases >= (1ull << 32)) return fail(h, KMR_ERR_UNSUPPORTED, "kmr_lookup_requests_dev: positions are 32-bit, pass at most 2^32 - 1 bases per call");
+	hipSetDevice(h->device);
+	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = nullptr; rv.offsets = (const uint64_t *)dev_offsets;
+	rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0;
+	rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
+	HIPCHK(h, hipMemsetAsync(dev_seg_counts, 0, 8 * h->cfg.world_size, h->stream));
+	if (n_reads == 0) return KMR_OK;
+	int rc = 0;
+#define REC(Wv, E) rc = extract_by_owner_t<Wv, E>(h, rv, total_bases, dev_keys, seg_capacity, dev_seg_counts, (uint32_t *)dev_pos);
+	switch (h->W) {
+	case 1: if (h->ext) REC(1, true) else REC(1, false) break;
+	case 2: if (h->ext) REC(2, true) else REC(2, false) break;
+	case 3: if (h->ext) REC(3, true) else REC(3, false) break;
+	default: if (h->ext) REC(4, true) else REC(4, false)
+	}
+#undef REC
+	return rc;
+}
+int kmr_lookup_keys_dev(kmr_handle *h, const void *dev_keys, uint64_t n, void *dev_counts) {
+	if (!h || (n && (!dev_keys || !dev_counts))) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_lookup_keys_dev before kmr_finalize");
+	if (n == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	const uint32_t vw = h->ext ? 15 : 3;
+#define LK(Wv) hipLaunchKernelGGL(lookup_words_kernel<Wv>, dim3(grid_for(n)), dim3(256), 0, h->stream, view_of<Wv>(h->weak, vw), (const uint64_t *)dev_keys, n, h->kb, (uint32_t *)dev_counts)
+	switch (h->W) { case 1: LK(1); break; case 2: LK(2); break; case 3: LK(3); break; default: LK(4); }
+#undef LK
+	HIPCHK(h, hipGetLastError());
+	return KMR_OK;
+}
+int kmr_scatter_counts_dev(kmr_handle *h, const void *dev_counts, const void *dev_pos, uint64_t n, void *dev_position_counts) {
+	if (!h || (n && (!dev_counts || !dev_pos || !dev_position_counts))) return KMR_ERR_INVALID_ARG;
+	if (n == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	hipLaunchKernelGGL(scatter_counts_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, (const uint32_t *)dev_counts, (const uint32_t *)dev_pos, n, (uint32_t *)dev_position_counts);
+	HIPCHK(h, hipGetLastError());
+	return KMR_OK;
+}
+int kmr_score_counts_dev(kmr_handle *h, const void *dev_bases, const void *dev_offsets, uint64_t n_reads, const void *dev_position_counts,
+                         double minimum_kmer_score, int scoring_type, uint32_t *trim_offset, uint32_t *trim_length, float *score, uint8_t *was_trimmed) {
+	if (!h || !dev_bases || !dev_offsets || !dev_position_counts || !trim_offset || !trim_length || !score || !was_trimmed) return KMR_ERR_INVALID_ARG;
+	if (scoring_type < 0 || scoring_type > 4) return fail(h, KMR_ERR_INVALID_ARG, "bad scoring_type");
+	if (n_reads == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	uint32_t *dto, *dtl; float *dsc; uint8_t *dwt;
+	HIPCHK(h, hipMalloc((void **)&dto, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dtl, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dsc, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dwt, n_reads));
+	/* k-mer i of read r sits at position offsets[r] + i: the offsets are their own count offsets */
+	hipLaunchKernelGGL(score_reads_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, (const uint8_t *)dev_bases, (const uint64_t *)dev_offsets, n_reads, h->k,
+	                   (const uint32_t *)dev_position_counts, (const uint64_t *)dev_offsets, (float)minimum_kmer_score, scoring_type, dto, dtl, dsc, dwt);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(trim_offset, dto, 4 * n_reads, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(trim_length, dtl, 4 * n_reads, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(score, dsc, 4 * n_reads, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(was_trimmed, dwt, n_reads, hipMemcpyDeviceToHost, h->stream);
+	hipStreamSynchronize(h->stream);
+	hipFree(dto); hipFree(dtl); hipFree(dsc); hipFree(dwt);
+	HIPCHK(h, e);
+	return KMR_OK;
 }
 
 int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n) {

@@ -684,6 +684,23 @@ __global__ void lookup_keys_kernel(MapView<W> weak, MapView<W> sing, const uint8
 	}
 }
 
+/* owner side of a lookup request: key words as they travel (Key<W>::w), weak map only as ReadSelector::getValue
+ * (src/ReadSelector.h:924-931; processRequest, src/DistributedFunctions.h:857-866) */
+template <int W>
+__global__ void lookup_words_kernel(MapView<W> weak, const uint64_t *keys, uint64_t n, uint32_t kb, uint32_t *out) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		Key<W> key;
+#pragma unroll
+		for (int j = 0; j < W; j++) key.w[j] = keys[i * W + j];
+		const int64_t e = map_find<W>(weak, key, key_hash<W>(key, kb));
+		out[i] = e >= 0 ? (weak.vals[(uint64_t)e * weak.vw] & 0xffffu) : 0u;
+	}
+}
+/* processRespond (:848-854): the answer to request i belongs to the k-mer at position pos[i] of the read batch */
+__global__ void scatter_counts_kernel(const uint32_t *counts, const uint32_t *pos, uint64_t n, uint32_t *position_counts) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) position_counts[pos[i]] = counts[i];
+}
+
 /* ReadSelector::scoreAndTrimReads for one read per lane (src/ReadSelector.h:1182-1207): numKmers is cut at the
  * first N/X markup (_setNumKmers :1037-1047), the read is trimmed to the first longest run of k-mers whose count
  * is >= minScore (trimReadByMinimumKmerScore :949-1014, bimodal detection off), the run is scored

@@ -135,10 +135,13 @@ template <int W, bool EXT, bool STATS> __device__ __forceinline__ uint32_t op_fa
  * owner; one device atomic per owner reserves the piece's run in each segment; pass 2 reads the records again (L2 / MALL)
  * and stores them behind the runs in order, in the wire format.  No holes: seg_counts are exact record counts. */
 static const int OSEG = 2048, OWNER_THREADS = 256, OWNER_MAX = 8;
-template <int W, bool EXT>
+/* REQ: the same binning for lookup requests (the distributed form of scoreAndTrimReads, src/DistributedFunctions.h:876-900):
+ * the owner segment gets the key words only, the position of the k-mer in the requester's read batch stays behind in pos_out
+ * at the same index (the answers come back in request order, so no request id travels) */
+template <int W, bool EXT, bool REQ = false>
 __global__ __launch_bounds__(OWNER_THREADS)
 void owner_scatter_kernel(const typename PoolRec<W, EXT>::type *linear, const uint64_t *koff, const uint32_t *tile_count, uint64_t n_tiles, uint32_t kb, uint32_t world,
-                          uint32_t *out, uint64_t seg_capacity, unsigned long long *seg_counts, unsigned int *work_counter, uint32_t *err) {
+                          uint32_t *out, uint64_t seg_capacity, unsigned long long *seg_counts, unsigned int *work_counter, uint32_t *err, uint32_t *pos_out = nullptr) {
 	constexpr uint32_t RW = 2 * W + (EXT ? 2 : 1);      /* dwords of a wire record (KMR_RECORD_BYTES) */
 	/* One block per tile of the linear buffer, in pieces of OSEG records that are read from HBM once and held in
 	 * registers: every thread hashes its records and takes a rank per owner from an LDS counter, one thread per owner
@@ -193,11 +196,19 @@ void owner_scatter_kernel(const typename PoolRec<W, EXT>::type *linear, const ui
 				if (i < m) {
 					const unsigned long long b = s_base[ow[u]];
 					if (b != ~0ull) {
-						uint32_t *dst = out + ((uint64_t)ow[u] * seg_capacity + b + rank[u]) * RW;
+						const uint64_t at = (uint64_t)ow[u] * seg_capacity + b + rank[u];
+						if (REQ) {
+							uint64_t *dst = (uint64_t *)out + at * W;
 #pragma unroll
-						for (int j = 0; j < W; j++) { dst[2 * j] = (uint32_t)r[u].key[j]; dst[2 * j + 1] = (uint32_t)(r[u].key[j] >> 32); }
-						dst[2 * W] = __float_as_uint(r[u].w);
-						if (EXT) dst[2 * W + 1] = r[u].pkt;
+							for (int j = 0; j < W; j++) dst[j] = r[u].key[j];
+							pos_out[at] = rec_ordinal<W>(r[u]);
+						} else {
+							uint32_t *dst = out + at * RW;
+#pragma unroll
+							for (int j = 0; j < W; j++) { dst[2 * j] = (uint32_t)r[u].key[j]; dst[2 * j + 1] = (uint32_t)(r[u].key[j] >> 32); }
+							dst[2 * W] = __float_as_uint(r[u].w);
+							if (EXT) dst[2 * W + 1] = r[u].pkt;
+						}
 					}
 				}
 			}

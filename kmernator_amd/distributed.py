@@ -152,3 +152,75 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
     spectrum.sync()
     torch.cuda.synchronize(dev)
     return spectrum
+
+
+def _all_to_all_flat(send, send_split, recv_split, group=None):
+    """send: [sum(send_split), words] rows grouped by destination; returns [sum(recv_split), words] grouped by source"""
+    recv = torch.empty((sum(recv_split), send.shape[1]), dtype=send.dtype, device=send.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all(list(recv.split(recv_split)), list(send.split(send_split)), group=group)
+    else:
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_split, input_split_sizes=send_split, group=group)
+    return recv
+
+
+def score_partitioned(spectrum, bases, offsets, minimum_kmer_score, scoring_type="MEDIAN", chunk_reads=None, group=None, slack=1.25):
+    """scoreAndTrimReads over an owner-partitioned spectrum: DistributedReadSelector::scoreAndTrimReads
+    (src/DistributedFunctions.h:900-1045).  Every rank scores its own reads; a k-mer is looked up on the rank that owns it.
+    Per chunk of reads: the k-mers binned by owner (device) -> all-to-all of the keys (8 * words bytes each; the reference sends
+    requestId + k-mer) -> weak-map lookup at the owner (device) -> all-to-all of the u32 counts back, in request order -> scatter
+    to the k-mers' positions (device); then the usual trim + score kernel over the position-indexed counts.
+
+    `spectrum`: finalized, rank / world_size configured (anything with lookup_requests / lookup_keys / scatter_counts /
+    score_counts / sync and .k, as KmerSpectrum has).  bases: uint8 tensor, offsets: int64/uint64 tensor [n+1] starting at 0,
+    both on the spectrum's device.  Returns (trim_offset, trim_length, score, was_trimmed) host arrays for this rank's reads."""
+    world = dist.get_world_size(group)
+    dev = bases.device
+    n = offsets.numel() - 1
+    words = (((spectrum.k + 3) // 4) + 7) // 8
+    off_host = offsets.cpu().to(torch.int64)
+    total = int(off_host[n]) if n else 0
+    if total >= 1 << 32:
+        raise RuntimeError("score_partitioned: positions are 32-bit, pass at most 2^32 - 1 bases per call")
+    chunk_reads, n_chunks, max_kmers = _plan_chunks(off_host, n, 8 * words, chunk_reads) if n else (1, 0, 0)
+    total_chunks = all_ranks_chunk_count(n_chunks, group, dev)
+    seg_cap = max(1024, int(max_kmers / world * slack) + 1024)
+    keys = torch.empty((world, seg_cap, words), dtype=torch.int64, device=dev)
+    pos = torch.empty((world, seg_cap), dtype=torch.int32, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    position_counts = torch.zeros(max(total, 1), dtype=torch.int32, device=dev)
+
+    def fence():
+        spectrum.sync()
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    fence()
+    for c in range(total_chunks):
+        lo, hi = c * chunk_reads, min(n, (c + 1) * chunk_reads)
+        if lo < n:
+            spectrum.lookup_requests(bases, offsets, lo, hi, int(off_host[hi] - off_host[lo]), keys, pos, seg_cap, counts)
+        else:
+            counts.zero_()
+        fence()
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts, group=group)
+        sc = [int(x) for x in counts.cpu().tolist()]
+        rc = [int(x) for x in recv_counts.cpu().tolist()]
+        if max(sc) > seg_cap:
+            raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_cap))
+        asked = _all_to_all_rows(keys, sc, rc, group)                      # the k-mers other ranks want from this one
+        answers = torch.zeros((sum(rc), 1), dtype=torch.int32, device=dev)
+        if sum(rc):
+            fence()
+            spectrum.lookup_keys(asked, sum(rc), answers)
+            fence()
+        back = _all_to_all_flat(answers, rc, sc, group)                    # the counts of this rank's requests, owner by owner
+        fence()
+        at = 0
+        for s in range(world):
+            if sc[s]:
+                spectrum.scatter_counts(back[at:at + sc[s]], pos[s], sc[s], position_counts)
+            at += sc[s]
+        fence()
+    return spectrum.score_counts(bases, offsets, n, position_counts, minimum_kmer_score, scoring_type)

@@ -111,6 +111,29 @@ class KmerSpectrum:
     def insertRecordsDevice(self, records_ptr, n):
         self._call("insert_records_dev", self.h, records_ptr, n)
 
+    # the device steps of the distributed scoreAndTrimReads (kmernator_amd.distributed.score_partitioned); tensors are torch
+    # tensors on this handle's device
+    def lookup_requests(self, bases, offsets, lo, hi, total_bases, keys, pos, seg_capacity, seg_counts):
+        self._call("lookup_requests_dev", self.h, bases.data_ptr(), offsets.data_ptr() + 8 * lo, hi - lo, total_bases,
+                   keys.data_ptr(), pos.data_ptr(), seg_capacity, seg_counts.data_ptr())
+
+    def lookup_keys(self, keys, n, counts):
+        self._call("lookup_keys_dev", self.h, keys.data_ptr(), n, counts.data_ptr())
+
+    def scatter_counts(self, counts, pos, n, position_counts):
+        self._call("scatter_counts_dev", self.h, counts.data_ptr(), pos.data_ptr(), n, position_counts.data_ptr())
+
+    def score_counts(self, bases, offsets, n_reads, position_counts, minimum_kmer_score, scoring_type="MEDIAN"):
+        to = np.zeros(n_reads, dtype=np.uint32)
+        tl = np.zeros(n_reads, dtype=np.uint32)
+        sc = np.zeros(n_reads, dtype=np.float32)
+        wt = np.zeros(n_reads, dtype=np.uint8)
+        if n_reads:
+            self._call("score_counts_dev", self.h, bases.data_ptr(), offsets.data_ptr(), n_reads, position_counts.data_ptr(), float(minimum_kmer_score),
+                       self.SCORING[scoring_type], to.ctypes.data_as(C.POINTER(C.c_uint32)), tl.ctypes.data_as(C.POINTER(C.c_uint32)),
+                       sc.ctypes.data_as(C.POINTER(C.c_float)), wt.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return to, tl, sc, wt.astype(bool)
+
     def stream(self):
         return self.lib.kmr_stream(self.h)
 

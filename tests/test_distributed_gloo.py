@@ -80,3 +80,102 @@ def test_exchange_union_equals_single(world, k, ext):
             s.finalize(2)
             s.dump(os.path.join(tmp, "single"), 2, False)
             assert sorted(got) == sorted(open(os.path.join(tmp, "single")).read().splitlines())
+
+
+# ---------------------------------------------------------------- distributed scoreAndTrimReads (f1, request / response form)
+
+class _OracleScoringRank:
+    """Stands in for the four device steps of kmernator_amd.distributed.score_partitioned on the CPU; the exchange logic under
+    test is the product's.  Keys travel as the product sends them: KMR_KEY_WORDS u64 words, most significant first."""
+
+    def __init__(self, cfg, spec):
+        self.cfg, self.spec, self.k = cfg, spec, cfg.k
+        self.kb = (cfg.k + 3) // 4
+        self.words = (self.kb + 7) // 8
+        self.lib = oracle_lib()
+
+    def sync(self):
+        pass
+
+    def _words(self, keys):                              # [n, kb] bytes -> [n, words] int64
+        pad = np.zeros((keys.shape[0], 8 * self.words), dtype=np.uint8)
+        pad[:, :self.kb] = keys
+        return pad.view(">u8").astype(np.uint64).view(np.int64)
+
+    def lookup_requests(self, bases, offsets, lo, hi, total_bases, keys, pos, seg_capacity, seg_counts):
+        from helpers import oracle_weighted_kmers
+        b, off = bases.numpy(), offsets.numpy()
+        fill = [0] * keys.shape[0]
+        for r in range(lo, hi):
+            seq = b[int(off[r]):int(off[r + 1])].tobytes()
+            kk, w, _ = oracle_weighted_kmers(self.cfg, seq, None)
+            ww = self._words(kk)
+            for i in range(kk.shape[0]):
+                if w[i] == 0:                            # a k-mer over a markup: never asked for
+                    continue
+                o = self.lib.orc_distributed_thread_id(self.lib.orc_hash(kk[i].tobytes(), self.kb), keys.shape[0])
+                keys[o, fill[o]] = torch.from_numpy(ww[i].copy())
+                pos[o, fill[o]] = int(off[r]) + i
+                fill[o] += 1
+        seg_counts.copy_(torch.tensor(fill, dtype=torch.int64))
+
+    def lookup_keys(self, keys, n, counts):
+        kw = keys.numpy().reshape(n, self.words).view(np.uint64).astype(">u8").view(np.uint8).reshape(n, 8 * self.words)[:, :self.kb]
+        counts.copy_(torch.from_numpy(self.spec.lookup(np.ascontiguousarray(kw)).astype(np.int32)).reshape(n, 1))
+
+    def scatter_counts(self, counts, pos, n, position_counts):
+        position_counts[pos[:n].long()] = counts.reshape(-1)[:n]
+
+    def score_counts(self, bases, offsets, n_reads, position_counts, minimum_kmer_score, scoring_type="MEDIAN"):
+        from refsemantics import score_and_trim
+        b, off, pc = bases.numpy(), offsets.numpy(), position_counts.numpy()
+        out = []
+        for r in range(n_reads):
+            seq = b[int(off[r]):int(off[r + 1])].tobytes()
+            nk = max(0, len(seq) - self.k + 1)
+            out.append(score_and_trim(pc[int(off[r]):int(off[r]) + nk], seq, self.k, minimum_kmer_score, scoring_type))
+        return out
+
+
+def _score_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmernator_amd.distributed import score_partitioned
+        k = 31
+        rb_all = read_fastq(os.path.join(GOLDEN, "1000.fastq"))
+        cfg = default_config(k, fastq_start_char=64, estimated_raw_kmers=46000, rank=rank, world_size=world)
+        spec = OracleSpectrum(cfg)
+        spec.add_reads(rb_all)                               # the oracle keeps the k-mers this rank owns
+        spec.finalize(2)
+        per = (rb_all.n + world - 1) // world
+        lo, hi = rank * per, min(rb_all.n, (rank + 1) * per) if rank != world - 1 else rb_all.n - 7 * (world - 1)
+        lo = lo if rank == 0 else lo - 7 * rank                # uneven slices: different chunk counts per rank
+        mine = rb_all.slice(lo, hi)
+        res = score_partitioned(_OracleScoringRank(cfg, spec), torch.from_numpy(mine.bases), torch.from_numpy(mine.offsets.astype(np.int64)), 2, "MEDIAN",
+                                chunk_reads=90 + 40 * rank)
+        with open(os.path.join(tmp, "labels.%d" % rank), "w") as f:
+            for i, (to, tl, sc, wt) in enumerate(res):
+                f.write("%d %s%s\n" % (lo + i, "Trim:%d+%d " % (to, tl) if wt else "", "MedianScore:%d" % int(sc + 0.5)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_score_partitioned_reproduces_golden_labels(world):
+    """every rank scores its slice of test/1000.fastq against a spectrum split over `world` owners: the labels of the 949 reads
+    without AFTrim in test/1000-Filtered.fastq, as from one spectrum"""
+    port = 31500 + (os.getpid() % 2000) + world
+    gold = read_fastq(os.path.join(GOLDEN, "1000-Filtered.fastq"))
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_score_worker, args=(world, port, tmp), nprocs=world, join=True)
+        seen = set()
+        for r in range(world):
+            for line in open(os.path.join(tmp, "labels.%d" % r)).read().splitlines():
+                idx, label = line.split(" ", 1)
+                i = int(idx)
+                seen.add(i)
+                if b"AFTrim" not in gold.names[i]:
+                    assert label.encode() == gold.names[i].split(b" ", 1)[1], (i, label, gold.names[i])
+        assert len(seen) >= 1000 - 7 * world

@@ -677,3 +677,89 @@ def test_build_partitioned_driver_single_rank(pipeline):
         compare_weak_images(a.image(KMR_MAP_WEAK), b.image(KMR_MAP_WEAK), a.kb, False, dir_tol=1)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [31, 51])
+def test_distributed_scoring_halves_three_owners_on_one_gpu(k):
+    """f1, distributed form (DistributedReadSelector, src/DistributedFunctions.h:876-1045) without the collectives: three
+    handles own a third of the k-mers each; requests binned by owner -> lookup at the owner -> answers scattered back ->
+    trim + score must equal scoreAndTrimReads on one whole spectrum."""
+    import torch
+    world, n = 3, 60000
+    rb = synth_reads(n, read_len=120, genome_len=4 * n, seed=9, quality="noisy", n_rate=0.002)
+    dev = torch.device("cuda", 0)
+    tb = torch.from_numpy(np.concatenate([rb.bases, np.zeros(64, np.uint8)])).to(dev)
+    tq = torch.from_numpy(np.concatenate([rb.quals, np.zeros(64, np.uint8)])).to(dev)
+    to = torch.from_numpy(rb.offsets.astype(np.int64)).to(dev)
+    total = int(rb.offsets[-1])
+    whole = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * 100, device=0))
+    whole.buildKmerSpectrumDevice(tb.data_ptr(), tq.data_ptr(), to.data_ptr(), n, total, 0)
+    whole.finalize(2)
+    want = whole.scoreAndTrimReads(rb.bases, rb.offsets, 2, "MEDIAN")
+    owners = []
+    for r in range(world):
+        s = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * 100, device=0, rank=r, world_size=world))
+        s.buildKmerSpectrumDevice(tb.data_ptr(), tq.data_ptr(), to.data_ptr(), n, total, 0)
+        s.finalize(2)
+        owners.append(s)
+    assert sum(s.stats()["weak_entries"] for s in owners) == whole.stats()["weak_entries"]
+    words = (whole.kb + 7) // 8
+    seg_cap = n * 120 // 2
+    keys = torch.empty((world, seg_cap, words), dtype=torch.int64, device=dev)
+    pos = torch.empty((world, seg_cap), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(world, dtype=torch.int64, device=dev)
+    position_counts = torch.zeros(total, dtype=torch.int32, device=dev)
+    req = owners[1]                                   # the requesting rank; two calls, as the chunks of score_partitioned
+    half = n // 2 + 13
+    n_req = 0
+    for lo, hi in ((0, half), (half, n)):
+        torch.cuda.synchronize()
+        req.lookup_requests(tb, to, lo, hi, int(rb.offsets[hi] - rb.offsets[lo]), keys, pos, seg_cap, cnt)
+        req.sync()
+        sc = [int(x) for x in cnt.cpu().tolist()]
+        n_req += sum(sc)
+        assert min(sc) > 0.2 * sum(sc)
+        lib = ka.load()
+        hk = keys[2, :50].cpu().numpy().view(np.uint64).astype(">u8").view(np.uint8).reshape(50, 8 * words)[:, :whole.kb]
+        for kk in hk:                                  # what sits in owner 2's segment is owned by rank 2
+            assert lib.kmr_distributed_thread_id(lib.kmr_hash(kk.tobytes(), whole.kb), world) == 2
+        for s in range(world):
+            ans = torch.zeros(sc[s], dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            owners[s].lookup_keys(keys[s], sc[s], ans)
+            owners[s].sync()
+            req.scatter_counts(ans, pos[s], sc[s], position_counts)
+            req.sync()
+    no_n = sum(max(0, len(rb.seq(i)) - k + 1) for i in range(n) if b"N" not in rb.seq(i))
+    assert no_n <= n_req <= n * (120 - k + 1)
+    got = req.score_counts(tb, to, n, position_counts, 2, "MEDIAN")
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
+def test_score_partitioned_driver_single_rank():
+    """kmernator_amd.distributed.score_partitioned with a one-rank RCCL group (keys and answers through the all-to-alls, several
+    chunks) equals scoreAndTrimReads"""
+    import torch
+    import torch.distributed as dist
+    from kmernator_amd.distributed import score_partitioned
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29950 + (os.getpid() % 300))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n = 200000
+        rb = synth_reads(n, read_len=150, genome_len=5 * n, seed=4, quality="noisy", n_rate=0.001)
+        tb = torch.from_numpy(np.concatenate([rb.bases, np.zeros(64, np.uint8)])).to(dev)
+        tq = torch.from_numpy(np.concatenate([rb.quals, np.zeros(64, np.uint8)])).to(dev)
+        to = torch.from_numpy(rb.offsets.astype(np.int64)).to(dev)
+        sp = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0))
+        sp.buildKmerSpectrumDevice(tb.data_ptr(), tq.data_ptr(), to.data_ptr(), n, n * 150, 0)
+        sp.finalize(2)
+        want = sp.scoreAndTrimReads(rb.bases, rb.offsets, 2, "AVG")
+        got = score_partitioned(sp, tb, to, 2, "AVG", chunk_reads=70000)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    finally:
+        dist.destroy_process_group()
