@@ -12,6 +12,22 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(t, group=None):
+    """gloo moves host memory: a device tensor goes through the host there (CPU tests, and rehearsals of the N>1 code with
+    several ranks on ONE GPU, which RCCL refuses); RCCL takes device memory as it is"""
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def _exchange_counts(counts, group=None):
+    """counts: int64 tensor [world], records for each rank -> (sent, received) as Python lists"""
+    send = counts.to(torch.int64)
+    if _staged(send, group):
+        send = send.cpu()
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return [int(x) for x in send.cpu().tolist()], [int(x) for x in recv.cpu().tolist()]
+
+
 def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
     """records: uint8 tensor [world * seg_capacity * rec_bytes], segment s holds
     seg_counts[s] records for rank s.  Returns (recv uint8 tensor, n_records).
@@ -19,11 +35,7 @@ def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
     The payload travels as int32 rows of one record each, so the split sizes handed to the
     collective count records (a byte count overflows 32 bits at ~1.8e8 twelve-byte records)."""
     world = dist.get_world_size(group)
-    send_counts = seg_counts.to(torch.int64)
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
-    sc = [int(x) for x in send_counts.cpu().tolist()]
-    rc = [int(x) for x in recv_counts.cpu().tolist()]
+    sc, rc = _exchange_counts(seg_counts, group)
     if max(sc) > seg_capacity:
         raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_capacity))
     assert rec_bytes % 4 == 0
@@ -43,13 +55,18 @@ def _all_to_all_rows(rows, sc, rc, group=None):
         dist.all_to_all(list(recv.split(rc)), [rows[s, :sc[s]] for s in range(world)], group=group)
     else:
         send = torch.cat([rows[s, :sc[s]] for s in range(world)]) if world > 1 else rows[0, :sc[0]].contiguous()
-        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        if _staged(send, group):
+            got = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(got, send.cpu(), output_split_sizes=rc, input_split_sizes=sc, group=group)
+            recv.copy_(got)
+        else:
+            dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
     return recv
 
 
 def all_ranks_chunk_count(n_local_chunks, group=None, device="cpu"):
     """every rank must issue the same number of all-to-alls"""
-    t = torch.tensor([n_local_chunks], dtype=torch.int64, device=device)
+    t = torch.tensor([n_local_chunks], dtype=torch.int64, device=device if dist.get_backend(group) == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return int(t.item())
 
@@ -131,11 +148,7 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
             ev_extract[(c + 1) % nbuf].record(lib_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev_extract[b])
-            send_counts = counts[b].clone()
-            recv_counts = torch.empty_like(send_counts)
-            dist.all_to_all_single(recv_counts, send_counts, group=group)
-            sc = [int(x) for x in send_counts.cpu().tolist()]          # host waits for extract(c) and the counts exchange only
-            rc = [int(x) for x in recv_counts.cpu().tolist()]
+            sc, rc = _exchange_counts(counts[b].clone(), group)     # host waits for extract(c) and the counts exchange only
             if max(sc) > seg_cap:
                 raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_cap))
             rows = records[b].view(torch.int32).view(world, seg_cap, words)
@@ -159,6 +172,10 @@ def _all_to_all_flat(send, send_split, recv_split, group=None):
     recv = torch.empty((sum(recv_split), send.shape[1]), dtype=send.dtype, device=send.device)
     if dist.get_backend(group) == "nccl":
         dist.all_to_all(list(recv.split(recv_split)), list(send.split(send_split)), group=group)
+    elif _staged(send, group):
+        got = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(got, send.cpu().contiguous(), output_split_sizes=recv_split, input_split_sizes=send_split, group=group)
+        recv.copy_(got)
     else:
         dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_split, input_split_sizes=send_split, group=group)
     return recv
@@ -203,10 +220,7 @@ def score_partitioned(spectrum, bases, offsets, minimum_kmer_score, scoring_type
         else:
             counts.zero_()
         fence()
-        recv_counts = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts, counts, group=group)
-        sc = [int(x) for x in counts.cpu().tolist()]
-        rc = [int(x) for x in recv_counts.cpu().tolist()]
+        sc, rc = _exchange_counts(counts, group)
         if max(sc) > seg_cap:
             raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_cap))
         asked = _all_to_all_rows(keys, sc, rc, group)                      # the k-mers other ranks want from this one

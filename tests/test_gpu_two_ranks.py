@@ -1,0 +1,99 @@
+"""Rehearsal of the N>1 code path with several ranks on ONE GPU: one process per rank as under torch.distributed.run, gloo as
+the transport (RCCL refuses two ranks on one device; kmernator_amd.distributed stages device tensors through the host for
+gloo), everything else -- extract-by-owner, the chunked and pipelined exchange driver, wire-format inserts, finalize, the
+request / response scoring -- is the code bench.py --gpus N runs.  The union of the ranks' spectra must be the single-GPU
+spectrum, every k-mer on its lookup3 owner, and every rank's read scores those of the whole spectrum."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import KMR_MAP_WEAK, parse_image, synth_reads
+
+pytestmark = pytest.mark.gpu
+
+N_READS, READ_LEN, K = 90000, 150, 31
+
+
+def _reads():
+    return synth_reads(N_READS, read_len=READ_LEN, genome_len=6 * N_READS, seed=12, quality="noisy", n_rate=0.001)
+
+
+def _slice(rank, world):
+    per = (N_READS + world - 1) // world
+    lo = rank * per - (5000 * rank if rank else 0)            # uneven shares: the ranks run different numbers of chunks
+    hi = N_READS if rank == world - 1 else (rank + 1) * per - 5000 * (rank + 1)
+    return lo, hi
+
+
+def _worker(rank, world, port, tmp, pipeline):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kmernator_amd as ka
+        from kmernator_amd.distributed import build_partitioned, score_partitioned
+        dev = torch.device("cuda", 0)
+        lo, hi = _slice(rank, world)
+        rb = _reads().slice(lo, hi)
+        tb = torch.from_numpy(np.concatenate([rb.bases, np.zeros(64, np.uint8)])).to(dev)
+        tq = torch.from_numpy(np.concatenate([rb.quals, np.zeros(64, np.uint8)])).to(dev)
+        to = torch.from_numpy(rb.offsets.astype(np.int64)).to(dev)
+        sp = ka.KmerSpectrum(ka.default_config(K, estimated_raw_kmers=N_READS * (READ_LEN - K + 1), device=0, rank=rank, world_size=world))
+        build_partitioned(sp, tb, tq, to, first_read_idx=lo, chunk_reads=7000 + 2000 * rank, pipeline=pipeline)
+        sp.finalize(2)
+        np.save(os.path.join(tmp, "image.%d.npy" % rank), sp.image(KMR_MAP_WEAK))
+        st = sp.stats()
+        np.save(os.path.join(tmp, "stats.%d.npy" % rank), np.array([st["raw_kmers"], st["raw_good_kmers"], st["weak_entries"], st["unique_kmers"]], dtype=np.int64))
+        res = score_partitioned(sp, tb, to, 2, "MEDIAN", chunk_reads=9000 + 3000 * rank)
+        np.savez(os.path.join(tmp, "score.%d.npz" % rank), to=res[0], tl=res[1], sc=res[2], wt=res[3])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pipeline", [(2, True), (3, False)])
+def test_ranks_sharing_one_gpu(world, pipeline):
+    import kmernator_amd as ka
+    port = 30500 + (os.getpid() % 1500) + world
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(world, port, tmp, pipeline), nprocs=world, join=True)
+        rb = _reads()
+        whole = ka.KmerSpectrum(ka.default_config(K, estimated_raw_kmers=N_READS * (READ_LEN - K + 1), device=0))
+        whole.buildKmerSpectrum(rb.bases, rb.quals, rb.offsets)
+        whole.finalize(2)
+        ws = whole.stats()
+        stats = sum(np.load(os.path.join(tmp, "stats.%d.npy" % r)) for r in range(world))
+        # the reads overlap between neighbouring slices (uneven shares), so compare against a spectrum of the same multiset
+        both = []
+        for r in range(world):
+            lo, hi = _slice(r, world)
+            both.append(rb.slice(lo, hi))
+        multi = ka.KmerSpectrum(ka.default_config(K, estimated_raw_kmers=N_READS * (READ_LEN - K + 1), device=0))
+        for part in both:
+            multi.buildKmerSpectrum(part.bases, part.quals, part.offsets)
+        multi.finalize(2)
+        ms = multi.stats()
+        assert (int(stats[1]), int(stats[2]), int(stats[3])) == (ms["raw_good_kmers"], ms["weak_entries"], ms["unique_kmers"]), (stats, ms, ws)
+        lib = ka.load()
+        total = 0
+        for r in range(world):
+            nb, mask, buckets = parse_image(np.load(os.path.join(tmp, "image.%d.npy" % r)), multi.kb, 12)
+            keys = np.concatenate([k for k, _ in buckets if len(k)])
+            vals = np.concatenate([v for _, v in buckets if len(v)])
+            counts = np.ascontiguousarray(vals[:, :2]).view(np.uint16).reshape(-1).astype(np.uint32)
+            assert np.array_equal(multi.getCount(keys), counts)
+            for kk in keys[::997]:
+                assert lib.kmr_distributed_thread_id(lib.kmr_hash(kk.tobytes(), multi.kb), world) == r
+            total += len(keys)
+        assert total == ms["weak_entries"]
+        for r in range(world):
+            part = both[r]
+            want = multi.scoreAndTrimReads(part.bases, part.offsets, 2, "MEDIAN")
+            got = np.load(os.path.join(tmp, "score.%d.npz" % r))
+            for a, b in zip((got["to"], got["tl"], got["sc"], got["wt"]), want):
+                assert np.array_equal(a, b)
