@@ -100,16 +100,22 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=50_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="run the owner-exchange path even on one GPU (sanity/timing of the N>1 code)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="development: all ranks of a torch.distributed.run launch share GPU 0 and talk "
+                    "over gloo (RCCL refuses two ranks on one device); exercises the N>1 code, its timings mean nothing")
     ap.add_argument("--build-mode", type=int, default=0, help="kmr_config.build_mode: 0 auto (streaming partition), 1 device table")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if world > 1 or args.force_exchange:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        if world == 1:
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        elif world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -157,8 +163,9 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    red_dev = "cpu" if args.rehearse_on_one_gpu else dev      # gloo reduces host tensors
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -168,7 +175,7 @@ def main():
     raw_local = st["raw_kmers"]
     uniq_local = st["unique_kmers"]
     if dist is not None:
-        t = torch.tensor([raw_local, uniq_local], dtype=torch.int64, device=dev)
+        t = torch.tensor([raw_local, uniq_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t)
         raw_total, uniq_total = int(t[0].item()), int(t[1].item())
     else:
