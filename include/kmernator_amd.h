@@ -321,6 +321,10 @@ int kmr_ingest_fastq_dev(kmr_handle *h, const void *dev_text, uint64_t len, uint
 /* n_filtered = records dropped by the Casava filter; input_quality_base = the base after detection */
 int kmr_reads_info(const kmr_reads *r, uint64_t *n_reads, uint64_t *total_bases,
                    uint32_t *input_quality_base, uint64_t *n_filtered);
+/* the same kind of batch from reads the host has already parsed (arrays as for kmr_add_reads, qualities scaled to the
+ * handle's fastq_start_char); names are empty */
+int kmr_reads_from_host(kmr_handle *h, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n_reads,
+                        kmr_reads **out);
 /* device arrays in the layout kmr_add_reads_dev takes: bases[total], quals[total], u64 offsets[n+1] */
 int kmr_reads_device_ptrs(const kmr_reads *r, void **dev_bases, void **dev_quals, void **dev_offsets);
 /* copies to host; any pointer may be NULL.  name_off/name_len: span of each read's name line

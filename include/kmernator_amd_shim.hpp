@@ -105,6 +105,47 @@ private:
 		this->rawKmers = st.raw_kmers; this->rawGoodKmers = st.raw_good_kmers;
 		this->uniqueKmers = st.unique_kmers; this->singletonKmers = st.singleton_kmers;
 	}
+	// The artifact filter on the device, in place of FilterKnownOddities::applyFilter(reads) at apps/FilterReads.cpp:110-114:
+	//     spectrum.applyArtifactFilter(reads, FilterKnownOddities::getArtifactFasta() [+ repeat / PhiX tables], cfg);
+	// The screen runs on the GPU; trims, discards and remnant reads are applied to the reference's ReadSet exactly as
+	// Recorder::recordTrim / recordDiscard (src/FilterKnownOddities.h:310-334) and applyFilterToRead :519-528 do.
+	unsigned long applyArtifactFilter(ReadSet &reads, const std::string &artifactFasta, const kmr_artifact_config &cfg) {
+		std::string bases, quals;
+		std::vector<uint64_t> offsets(1, 0);
+		for (ReadSet::ReadSetSizeType i = 0; i < reads.getSize(); i++) {
+			const Read &read = reads.getRead(i);
+			bases += read.getFasta(); quals += read.getQuals();
+			offsets.push_back(bases.size());
+		}
+		std::vector<int64_t> mate;
+		if (reads.hasPairs()) {
+			mate.assign(reads.getSize(), -1);
+			for (ReadSet::ReadSetSizeType p = 0; p < reads.getPairSize(); p++) {
+				const ReadSet::Pair &pair = reads.getPair(p);
+				if (reads.isValidRead(pair.read1) && reads.isValidRead(pair.read2)) { mate[pair.read1] = pair.read2; mate[pair.read2] = pair.read1; }
+			}
+		}
+		kmr_reads *batch = NULL; kmr_artifact_filter *filter = NULL;
+		check(kmr_reads_from_host(_h, bases.data(), quals.data(), offsets.data(), reads.getSize(), &batch), "kmr_reads_from_host");
+		int rc = kmr_artifact_filter_create(_h, &cfg, artifactFasta.data(), artifactFasta.size(), &filter);
+		const size_t n = reads.getSize();
+		std::vector<uint32_t> value(n), minPass(n), maxPass(n), remOff(n), remLen(n); std::vector<uint8_t> action(n);
+		if (rc == KMR_OK) rc = kmr_artifact_filter_apply(_h, filter, batch, mate.empty() ? NULL : mate.data(), value.data(), minPass.data(), maxPass.data(),
+		                                                 action.data(), remOff.data(), remLen.data(), NULL);
+		kmr_artifact_filter_free(filter); kmr_reads_free(batch);
+		check(rc, "kmr_artifact_filter");
+		unsigned long affected = 0;
+		ReadSet remnants;
+		for (size_t i = 0; i < n; i++) {
+			Read &read = reads.getRead(i);
+			if (remLen[i]) remnants.append(read.getTrimRead(remOff[i], remLen[i], "AFTrim:" + boost::lexical_cast<std::string>(remOff[i]) + "+" + boost::lexical_cast<std::string>(remLen[i]), "-qtrim"));
+			if (action[i] == 1) { read = read.getTrimRead(minPass[i], maxPass[i] - minPass[i], "AFTrim:" + boost::lexical_cast<std::string>(minPass[i]) + "+" + boost::lexical_cast<std::string>(maxPass[i] - minPass[i])); affected++; }
+			else if (action[i] == 2) read.discard();
+		}
+		if (remnants.getSize() > 0) reads.append(remnants);
+		return affected;
+	}
+
 	void check(int rc, const char *what) {
 		if (rc != KMR_OK) throw std::runtime_error(std::string(what) + ": " + kmr_last_error(_h));
 	}

@@ -1717,6 +1717,26 @@ int kmr_ingest_fastq(kmr_handle *h, const char *text, uint64_t len, uint32_t inp
 	hipFree(d);
 	return rc;
 }
+/* a device-resident batch from reads the host already parsed (the reference's ReadSet flattened as for kmr_add_reads) */
+int kmr_reads_from_host(kmr_handle *h, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n_reads, kmr_reads **out) {
+	if (!h || !out || !offsets || (n_reads && (!bases || !quals))) return KMR_ERR_INVALID_ARG;
+	*out = nullptr;
+	hipSetDevice(h->device);
+	const uint64_t first = offsets[0], total = offsets[n_reads] - first;
+	std::unique_ptr<kmr_reads, void (*)(kmr_reads *)> r(new kmr_reads, kmr_reads_free);
+	r->device = h->device; r->n = n_reads; r->total = total; r->input_base = h->cfg.fastq_start_char;
+	HIPCHK(h, hipMalloc((void **)&r->bases, total + 64)); HIPCHK(h, hipMalloc((void **)&r->quals, total + 64));
+	HIPCHK(h, hipMalloc((void **)&r->offsets, 8 * (n_reads + 1)));
+	HIPCHK(h, hipMalloc((void **)&r->name_off, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, hipMalloc((void **)&r->name_len, 4 * std::max<uint64_t>(n_reads, 1)));
+	HIPCHK(h, hipMemset(r->bases + total, 0, 64)); HIPCHK(h, hipMemset(r->quals + total, 0, 64));
+	HIPCHK(h, hipMemset(r->name_off, 0, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, hipMemset(r->name_len, 0, 4 * std::max<uint64_t>(n_reads, 1)));
+	if (total) { HIPCHK(h, hipMemcpy(r->bases, bases + first, total, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(r->quals, quals + first, total, hipMemcpyHostToDevice)); }
+	std::vector<uint64_t> rel(n_reads + 1);
+	for (uint64_t i = 0; i <= n_reads; i++) rel[i] = offsets[i] - first;
+	HIPCHK(h, hipMemcpy(r->offsets, rel.data(), 8 * (n_reads + 1), hipMemcpyHostToDevice));
+	*out = r.release();
+	return KMR_OK;
+}
 void kmr_reads_free(kmr_reads *r) {
 	if (!r) return;
 	hipSetDevice(r->device);

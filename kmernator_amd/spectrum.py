@@ -355,6 +355,17 @@ class ReadSet:
         self.n, self.total_bases, self.input_quality_base, self.filtered = n.value, tot.value, qb.value, nf.value
         return self
 
+    @classmethod
+    def from_arrays(cls, spectrum, bases, quals, offsets):
+        """reads the host already holds (uint8 bases / quals scaled to the spectrum's quality base, uint64 offsets[n+1])"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        r = C.c_void_p()
+        spectrum._call("reads_from_host", spectrum.h, bases.ctypes.data_as(C.c_void_p), quals.ctypes.data_as(C.c_void_p),
+                       offsets.ctypes.data_as(C.POINTER(C.c_uint64)), offsets.size - 1, C.byref(r))
+        return cls._adopt(spectrum, b"", r)
+
     def getSize(self):
         return self.n
 

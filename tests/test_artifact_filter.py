@@ -291,3 +291,17 @@ def test_filter_errors_and_empty_batches():
     empty = ka.ReadSet(sp, b"")
     res, frs = f.applyFilter(empty)
     assert frs.n == 0 and res["action"].size == 0
+
+
+@pytest.mark.gpu
+def test_filter_on_reads_handed_over_as_host_arrays():
+    """kmr_reads_from_host: the route the reference-side shim takes (ReadSet flattened by the host, include/kmernator_amd_shim.hpp)"""
+    import kmernator_amd as ka
+    table = fasta("artifact_sequences.fa")
+    rb = _spiked_reads(2000, 21, table)
+    kw = dict(edit_distance=1, min_read_length=25.0)
+    o = OracleArtifactFilter(artifact_config(**kw), table)
+    sp, f = _device_filter(kw, table)
+    rs = ka.ReadSet.from_arrays(sp, rb.bases, rb.quals, rb.offsets)
+    assert rs.n == rb.n and rs.total_bases == rb.bases.size
+    _check_apply(f, o, rs, rb)
