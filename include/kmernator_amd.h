@@ -292,7 +292,8 @@ int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n_re
  * kmr_lookup_keys_dev: owner side, weak-map count of n received keys (ReadSelector::getValue, src/ReadSelector.h:924-931).
  * kmr_scatter_counts_dev: position_counts[pos[j]] = counts[j] for the answers of one owner segment.
  * kmr_score_counts_dev: trimReadByMinimumKmerScore + scoring + setTrimHeaders (as kmr_score_reads) from counts indexed
- * by base position (u32 position_counts[total_bases], zero where no answer was written).
+ * by base position (u32 position_counts[total_bases], zero where no answer was written); dev_bases 16-byte aligned and
+ * padded by 64 bytes as for kmr_add_reads_dev.
  * All asynchronous on the handle's stream except kmr_score_counts_dev, which returns host arrays. */
 int kmr_lookup_requests_dev(kmr_handle *h, const void *dev_bases, const void *dev_offsets, uint64_t n_reads, uint64_t total_bases,
                             void *dev_keys, void *dev_pos, uint64_t seg_capacity, void *dev_seg_counts);

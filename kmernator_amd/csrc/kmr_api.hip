@@ -88,6 +88,8 @@ struct kmr_handle {
 	uint8_t *arena = nullptr; size_t arena_cap = 0, arena_used = 0, arena_want = 0; std::vector<void *> arena_overflow;
 	unsigned long long *scan_sums = nullptr; uint64_t scan_sums_n = 0;
 	uint8_t *score_buf = nullptr; size_t score_buf_bytes = 0;        /* temporaries of kmr_score_reads*, grow-only */
+	uint64_t *lut = nullptr; size_t lut_bytes = 0; uint32_t lut_log2 = 0;      /* lookup accelerator over the weak map (LutView) */
+	uint64_t lut_gen = ~0ull, map_gen = 0;                           /* the table belongs to the maps of generation lut_gen */
 	void *linear = nullptr; uint64_t linear_cap = 0;         /* records */
 	uint32_t *tile_count = nullptr; uint64_t tile_cap = 0;
 	uint32_t *kcap = nullptr; uint64_t *koff = nullptr; uint64_t kcap_n = 0, koff_n = 0;
@@ -455,7 +457,7 @@ template <int W, bool EXT> int finalize_t(kmr_handle *h, uint32_t min_depth) {
 	h->has_singletons = keepSing;
 	if (!keepSing) { sm.n = 0; }
 	h->stats.weak_entries = wm.n; h->stats.singleton_entries = keepSing ? sm.n : 0;
-	h->finalized = true;
+	h->finalized = true; h->map_gen++;
 	return sync_state(h);
 }
 
@@ -567,8 +569,33 @@ template <int W> int lookup_t(kmr_handle *h, const uint8_t *packed, uint64_t n, 
 	return 0;
 }
 
+/* the lookup accelerator of the current weak map (built on first use after the map changed); slots == nullptr when it cannot
+ * be had (no memory): the callers then search the buckets */
+template <int W> LutView<W> lut_of(kmr_handle *h) {
+	LutView<W> v; v.slots = nullptr; v.mask = 0; v.shift = 0;
+	if (getenv("KMR_NO_LUT") || !h->weak.present || h->weak.n == 0) return v;
+	if (!(h->lut && h->lut_gen == h->map_gen)) {
+		uint32_t l2 = 10; while ((1ull << l2) < 2 * h->weak.n) l2++;
+		const size_t bytes = (size_t)(W + 1) * 8 << l2;
+		if (h->lut_bytes < bytes) {
+			if (h->lut) { hipStreamSynchronize(h->stream); hipFree(h->lut); h->lut = nullptr; h->lut_bytes = 0; }
+			size_t fr = 0, tot = 0;
+			if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + (1ull << 30) || hipMalloc((void **)&h->lut, bytes) != hipSuccess) { h->lut = nullptr; (void)hipGetLastError(); return v; }
+			h->lut_bytes = bytes;
+		}
+		const uint32_t vw = h->ext ? 15 : 3;
+		hipLaunchKernelGGL(lut_clear_kernel, dim3(4096), dim3(256), 0, h->stream, h->lut, 1ull << l2, (uint32_t)(W + 1));
+		hipLaunchKernelGGL(lut_build_kernel<W>, dim3(grid_for(h->weak.n)), dim3(256), 0, h->stream, view_of<W>(h->weak, vw), h->weak.n, h->lut, (1ull << l2) - 1, 64 - l2, h->kb);
+		if (hipGetLastError() != hipSuccess) return v;
+		h->lut_log2 = l2; h->lut_gen = h->map_gen;
+	}
+	v.slots = h->lut; v.mask = (1ull << h->lut_log2) - 1; v.shift = 64 - h->lut_log2;
+	return v;
+}
+
 template <int W> int lookup_reads_t(kmr_handle *h, const ReadsView &rv, uint32_t *dout, const uint64_t *dout_off, bool weak_only = false) {
 	LookupOp<W> op; const uint32_t vw = h->ext ? 15 : 3; op.weak_only = weak_only;
+	op.lut = weak_only ? lut_of<W>(h) : LutView<W>{nullptr, 0, 0};
 	op.weak = view_of<W>(h->weak, vw); op.sing = view_of<W>(h->sing, vw); op.out = dout; op.out_offsets = dout_off; op.first_read_idx = rv.first_read_idx;
 	return launch_extract<W, false>(h, rv, op);
 }
@@ -1065,7 +1092,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 	time_end(h, 1, ea, eb);
 	h->has_singletons = keepSing;
 	h->stats.weak_entries = h->weak.n; h->stats.singleton_entries = keepSing ? h->sing.n : 0;
-	h->finalized = true;
+	h->finalized = true; h->map_gen++;
 	rc = sync_state(h);
 	/* the temporaries are dead: if some of them had to be allocated on the side, the arena is brought to size now,
 	 * so that it is this build (a handle's first) that pays for it and not the next one */
@@ -1226,6 +1253,7 @@ void kmr_destroy(kmr_handle *h) {
 	free_partition_state(h);
 	if (h->scan_sums) hipFree(h->scan_sums);
 	if (h->score_buf) hipFree(h->score_buf);
+	if (h->lut) hipFree(h->lut);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -1264,7 +1292,7 @@ int kmr_reset(kmr_handle *h) {
 	HIPCHK(h, hipMemsetAsync(h->derr, 0, 4, h->stream));
 	memset(&h->stats, 0, sizeof(h->stats));
 	h->occupied = h->pending_kmers = 0; h->stream_base = 0; h->reads = 0; h->subtracted = 0;
-	h->finalized = false; h->has_singletons = h->cfg.separate_singletons != 0;
+	h->finalized = false; h->map_gen++; h->has_singletons = h->cfg.separate_singletons != 0;
 	return KMR_OK;
 }
 int kmr_release_table(kmr_handle *h) {
@@ -1408,7 +1436,7 @@ static int score_reads_core(kmr_handle *h, const uint8_t *s_b, const uint64_t *s
 	switch (h->W) { case 1: rc = lookup_reads_t<1>(h, rv, dcounts, dcoff, true); break; case 2: rc = lookup_reads_t<2>(h, rv, dcounts, dcoff, true); break;
 	case 3: rc = lookup_reads_t<3>(h, rv, dcounts, dcoff, true); break; default: rc = lookup_reads_t<4>(h, rv, dcounts, dcoff, true); }
 	if (!rc) {
-		hipLaunchKernelGGL(score_reads_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, s_b, s_o, n_reads, h->k, dcounts, dcoff,
+		hipLaunchKernelGGL(score_reads_kernel, dim3((unsigned)std::min<uint64_t>(((n_reads + 63) / 64 + SC_WAVES - 1) / SC_WAVES, 1u << 16)), dim3(SC_WAVES * 64), 0, h->stream, s_b, s_o, n_reads, h->k, dcounts, dcoff,
 		                   (float)minimum_kmer_score, scoring_type, dto, dtl, dsc, dwt);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipMemcpyAsync(trim_offset, dto, 4 * n_reads, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(trim_length, dtl, 4 * n_reads, hipMemcpyDeviceToHost, h->stream));
@@ -1493,7 +1521,7 @@ int kmr_load_image(kmr_handle *h, int which, const void *src, uint64_t len) {
 	if (h->slots) { hipFree(h->slots); h->slots = nullptr; if (h->extslots) { hipFree(h->extslots); h->extslots = nullptr; } }
 	if (which == KMR_MAP_WEAK) { h->nb_weak = m->nb; h->stats.weak_entries = m->n; if (!h->sing.present) { h->has_singletons = false; h->sing.nb = h->nb_sing; } }
 	else { h->nb_sing = m->nb; h->stats.singleton_entries = m->n; h->has_singletons = true; if (!h->weak.present) h->weak.nb = h->nb_weak; }
-	h->finalized = true;
+	h->finalized = true; h->map_gen++;
 	return KMR_OK;
 }
 
@@ -1550,6 +1578,7 @@ int kmr_merge_image(kmr_handle *h, int which, const void *src, uint64_t len) {
 	int rc;
 	switch (h->W) { case 1: rc = merge_image_t<1>(h, *m, weakMap, (const uint8_t *)src, len); break; case 2: rc = merge_image_t<2>(h, *m, weakMap, (const uint8_t *)src, len); break;
 	case 3: rc = merge_image_t<3>(h, *m, weakMap, (const uint8_t *)src, len); break; default: rc = merge_image_t<4>(h, *m, weakMap, (const uint8_t *)src, len); }
+	h->map_gen++;
 	if (rc) return rc;
 	if (weakMap) h->stats.weak_entries = m->n; else h->stats.singleton_entries = m->n;
 	return KMR_OK;
@@ -2109,7 +2138,7 @@ int kmr_lookup_keys_dev(kmr_handle *h, const void *dev_keys, uint64_t n, void *d
 	if (n == 0) return KMR_OK;
 	hipSetDevice(h->device);
 	const uint32_t vw = h->ext ? 15 : 3;
-#define LK(Wv) hipLaunchKernelGGL(lookup_words_kernel<Wv>, dim3(grid_for(n)), dim3(256), 0, h->stream, view_of<Wv>(h->weak, vw), (const uint64_t *)dev_keys, n, h->kb, (uint32_t *)dev_counts)
+#define LK(Wv) hipLaunchKernelGGL(lookup_words_kernel<Wv>, dim3(grid_for(n)), dim3(256), 0, h->stream, view_of<Wv>(h->weak, vw), lut_of<Wv>(h), (const uint64_t *)dev_keys, n, h->kb, (uint32_t *)dev_counts)
 	switch (h->W) { case 1: LK(1); break; case 2: LK(2); break; case 3: LK(3); break; default: LK(4); }
 #undef LK
 	HIPCHK(h, hipGetLastError());
@@ -2132,7 +2161,7 @@ int kmr_score_counts_dev(kmr_handle *h, const void *dev_bases, const void *dev_o
 	uint32_t *dto, *dtl; float *dsc; uint8_t *dwt;
 	HIPCHK(h, hipMalloc((void **)&dto, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dtl, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dsc, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dwt, n_reads));
 	/* k-mer i of read r sits at position offsets[r] + i: the offsets are their own count offsets */
-	hipLaunchKernelGGL(score_reads_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, (const uint8_t *)dev_bases, (const uint64_t *)dev_offsets, n_reads, h->k,
+	hipLaunchKernelGGL(score_reads_kernel, dim3((unsigned)std::min<uint64_t>(((n_reads + 63) / 64 + SC_WAVES - 1) / SC_WAVES, 1u << 16)), dim3(SC_WAVES * 64), 0, h->stream, (const uint8_t *)dev_bases, (const uint64_t *)dev_offsets, n_reads, h->k,
 	                   (const uint32_t *)dev_position_counts, (const uint64_t *)dev_offsets, (float)minimum_kmer_score, scoring_type, dto, dtl, dsc, dwt);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(trim_offset, dto, 4 * n_reads, hipMemcpyDeviceToHost, h->stream);

@@ -648,7 +648,56 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 template <int W, bool EXT> __device__ __forceinline__ bool op_keeps_all_owners(const InsertOp<W, EXT> &) { return false; }
 template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(const InsertOp<W, EXT> &) { return ERR_TABLE_FULL; }
 
+/* Lookup accelerator for read scoring: the weak map once more as an open-addressed table, slot = {key words, count}
+ * ((W + 1) u64), at most half full, slot index from the same lookup3 hash.  A sorted bucket costs ~7 dependent loads per
+ * k-mer (two bucket bounds, the binary search, the value); a slot of this table is one 16-byte load at k <= 32.  Built on the
+ * first scoring call after a finalize (lut_build_kernel), dropped when the map changes. */
+template <int W> struct LutView { const uint64_t *slots; uint64_t mask; uint32_t shift; };
+__host__ __device__ __forceinline__ uint64_t lut_slot(uint64_t hash, uint32_t shift) { return (hash * 0x9E3779B97F4A7C15ull) >> shift; }
+template <int W> __device__ __forceinline__ uint32_t lut_count(const LutView<W> &t, const Key<W> &key, uint64_t hash) {
+	uint64_t s = lut_slot(hash, t.shift);
+	for (;;) {
+		const uint64_t *p = t.slots + s * (W + 1);
+		if (W == 1) {
+			const ulonglong2 v = *(const ulonglong2 *)p;
+			if (v.x == key.w[0]) return (uint32_t)v.y;
+			if (v.x == EMPTY_KEY) return 0u;
+		} else {
+			const uint64_t k0 = p[0];
+			if (k0 == EMPTY_KEY) return 0u;
+			bool eq = k0 == key.w[0];
+#pragma unroll
+			for (int i = 1; i < W; i++) eq = eq && p[i] == key.w[i];
+			if (eq) return (uint32_t)p[W];
+		}
+		s = (s + 1) & t.mask;
+	}
+}
+template <int W>
+__global__ void lut_build_kernel(MapView<W> weak, uint64_t n, uint64_t *slots, uint64_t mask, uint32_t shift, uint32_t kb) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		Key<W> key;
+#pragma unroll
+		for (int j = 0; j < W; j++) key.w[j] = weak.keys[i * W + j];
+		uint64_t s = lut_slot(key_hash<W>(key, kb), shift);
+		for (;;) {           /* the keys of a map are distinct: a slot is taken by whoever swaps its first word in */
+			unsigned long long *p = (unsigned long long *)(slots + s * (W + 1));
+			if (atomicCAS(p, (unsigned long long)EMPTY_KEY, (unsigned long long)key.w[0]) == (unsigned long long)EMPTY_KEY) {
+#pragma unroll
+				for (int j = 1; j < W; j++) p[j] = key.w[j];
+				p[W] = weak.vals[i * weak.vw] & 0xffffu;
+				break;
+			}
+			s = (s + 1) & mask;
+		}
+	}
+}
+__global__ void lut_clear_kernel(uint64_t *slots, uint64_t n_slots, uint32_t stride) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) slots[i * stride] = EMPTY_KEY;
+}
+
 template <int W> struct LookupOp {
+	LutView<W> lut;                /* slots == nullptr: search the sorted buckets */
 	MapView<W> weak, sing;
 	uint32_t *out;
 	const uint64_t *out_offsets;   /* per read, indexed by global read index - first_read_idx */
@@ -666,7 +715,8 @@ template <int W> struct LookupOp {
 	                                     uint64_t readIdx, uint32_t pos, unsigned &, bool &) const {
 		if (valid) {
 			uint32_t c;
-			if (weak_only) { const int64_t i = map_find<W>(weak, key, hash); c = i >= 0 ? (weak.vals[(uint64_t)i * weak.vw] & 0xffffu) : 0u; }
+			if (weak_only && lut.slots) c = lut_count<W>(lut, key, hash);
+			else if (weak_only) { const int64_t i = map_find<W>(weak, key, hash); c = i >= 0 ? (weak.vals[(uint64_t)i * weak.vw] & 0xffffu) : 0u; }
 			else c = maps_count<W>(weak, sing, key, hash);
 			out[out_offsets[readIdx - first_read_idx] + pos] = c;
 		}
@@ -687,12 +737,14 @@ __global__ void lookup_keys_kernel(MapView<W> weak, MapView<W> sing, const uint8
 /* owner side of a lookup request: key words as they travel (Key<W>::w), weak map only as ReadSelector::getValue
  * (src/ReadSelector.h:924-931; processRequest, src/DistributedFunctions.h:857-866) */
 template <int W>
-__global__ void lookup_words_kernel(MapView<W> weak, const uint64_t *keys, uint64_t n, uint32_t kb, uint32_t *out) {
+__global__ void lookup_words_kernel(MapView<W> weak, LutView<W> lut, const uint64_t *keys, uint64_t n, uint32_t kb, uint32_t *out) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		Key<W> key;
 #pragma unroll
 		for (int j = 0; j < W; j++) key.w[j] = keys[i * W + j];
-		const int64_t e = map_find<W>(weak, key, key_hash<W>(key, kb));
+		const uint64_t hash = key_hash<W>(key, kb);
+		if (lut.slots) { out[i] = lut_count<W>(lut, key, hash); continue; }
+		const int64_t e = map_find<W>(weak, key, hash);
 		out[i] = e >= 0 ? (weak.vals[(uint64_t)e * weak.vw] & 0xffffu) : 0u;
 	}
 }
@@ -706,54 +758,98 @@ __global__ void scatter_counts_kernel(const uint32_t *counts, const uint32_t *po
  * is >= minScore (trimReadByMinimumKmerScore :949-1014, bimodal detection off), the run is scored
  * (scoreReadByScoringType :1094-1180) and setTrimHeaders (:1015-1036) converts the run to bases. */
 enum { SCORE_SUM = 0, SCORE_MEDIAN = 1, SCORE_MIN = 2, SCORE_MAX = 3, SCORE_AVG = 4 };
-__global__ void score_reads_kernel(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, uint32_t k, const uint32_t *counts,
-                                   const uint64_t *count_off, float minScore, int scoring, uint32_t *trimOffset, uint32_t *trimLength,
-                                   float *score, uint8_t *wasTrimmed) {
-	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
-		const uint64_t b0 = offsets[r], L = offsets[r + 1] - b0;
-		uint32_t numKmers = L >= k ? (uint32_t)(L - k + 1) : 0;
-		for (uint64_t i = 0; i < L; i++) {                      /* TwoBitSequence::firstMarkupNorX */
-			uint8_t c = bases[b0 + i];
-			if (c == '.') c = 'N';
-			if (c == 'N' || c == 'X') { const uint32_t m = (uint32_t)i + 1; numKmers = m > k ? (m - k < numKmers ? m - k : numKmers) : 0; break; }
-		}
-		const uint32_t *cv = counts + count_off[r];
-		uint32_t bestOff = 0, bestLen = 0, off = 0, len = 0;
-		for (uint32_t i = 0; i < numKmers; i++) {
-			const float v = (float)cv[i];
-			if (v >= minScore) len++;
-			else { if (len > bestLen) { bestLen = len; bestOff = off; } off += len + 1; len = 0; }
-		}
-		if (len > bestLen) { bestLen = len; bestOff = off; }
-		const bool trimmed = bestLen < numKmers;
-		float sc = -1.0f;
-		if (bestLen > 0) {
-			const uint32_t *run = cv + bestOff;
-			if (scoring == SCORE_MEDIAN) {
-				/* sorted[n/2]: the smallest v with #(x <= v) > n/2, found by bisection on the 16-bit count */
-				const uint32_t t = bestLen / 2;
-				uint32_t lo = 65535, hi = 0;          /* the bisection starts from the run's own range, not from 16 bits */
-				for (uint32_t i = 0; i < bestLen; i++) { const uint32_t v = run[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-				while (lo < hi) {
-					const uint32_t mid = (lo + hi) >> 1;
-					uint32_t le = 0;
-					for (uint32_t i = 0; i < bestLen; i++) le += run[i] <= mid ? 1u : 0u;
-					if (le > t) hi = mid; else lo = mid + 1;
+/* one read: numKmers is already cut at the first markup; cv = its counts (LDS copy as u16, or global u32) */
+template <typename T>
+__device__ __forceinline__ void score_one_read(const T *cv, uint32_t numKmers, uint32_t k, float minScore, int scoring,
+                                               uint32_t &tOff, uint32_t &tLen, float &scOut, bool &trimmedOut) {
+	uint32_t bestOff = 0, bestLen = 0, off = 0, len = 0;
+	for (uint32_t i = 0; i < numKmers; i++) {
+		const float v = (float)(uint32_t)cv[i];
+		if (v >= minScore) len++;
+		else { if (len > bestLen) { bestLen = len; bestOff = off; } off += len + 1; len = 0; }
+	}
+	if (len > bestLen) { bestLen = len; bestOff = off; }
+	trimmedOut = bestLen < numKmers;
+	float sc = -1.0f;
+	if (bestLen > 0) {
+		const T *run = cv + bestOff;
+		if (scoring == SCORE_MEDIAN) {
+			/* sorted[n/2]: the smallest v with #(x <= v) > n/2, found by bisection on the 16-bit count */
+			const uint32_t t = bestLen / 2;
+			uint32_t lo = 65535, hi = 0;          /* the bisection starts from the run's own range, not from 16 bits */
+			for (uint32_t i = 0; i < bestLen; i++) { const uint32_t v = run[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				uint32_t le = 0;
+				for (uint32_t i = 0; i < bestLen; i++) le += (uint32_t)run[i] <= mid ? 1u : 0u;
+				if (le > t) hi = mid; else lo = mid + 1;
+			}
+			sc = (float)lo;
+		} else if (scoring == SCORE_AVG) {
+			double sum = 0.0; for (uint32_t i = 0; i < bestLen; i++) sum += (float)(uint32_t)run[i];
+			sc = (float)(sum / (double)bestLen);
+		} else if (scoring == SCORE_MIN || scoring == SCORE_MAX) {
+			uint32_t m = run[0];
+			for (uint32_t i = 1; i < bestLen; i++) { const uint32_t v = run[i]; m = scoring == SCORE_MAX ? (v > m ? v : m) : (v < m ? v : m); }
+			sc = (float)m;
+		} else sc = 0.0f;     /* KS_SUM: scoreReadBySumKmer only assigns the score when byAvg (:1149-1162) */
+	}
+	tOff = bestLen > 0 ? bestOff : 0u;
+	tLen = bestLen > 0 ? bestLen + k - 1 : 0u;
+	scOut = sc;
+}
+
+/* A wavefront takes 64 consecutive reads: their bases are one contiguous range, searched for markups with coalesced 16-byte
+ * loads (a hit finds its read by bisection over the 65 offsets in LDS -- hits are rare), their counts are one contiguous
+ * range too (count_off is an exclusive scan, or the base offsets themselves), copied into LDS as u16; then every lane walks
+ * its own read in LDS.  Groups whose counts do not fit the LDS window (long reads) walk them in global memory. */
+static const int SC_WAVES = 3, SC_CAP = 10240;
+__global__ __launch_bounds__(SC_WAVES * 64)
+void score_reads_kernel(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, uint32_t k, const uint32_t *counts,
+                        const uint64_t *count_off, float minScore, int scoring, uint32_t *trimOffset, uint32_t *trimLength,
+                        float *score, uint8_t *wasTrimmed) {
+	__shared__ uint16_t s_cnt[SC_WAVES][SC_CAP];
+	__shared__ uint64_t s_off[SC_WAVES][65], s_coff[SC_WAVES][65];
+	__shared__ uint32_t s_first[SC_WAVES][64];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint64_t groups = (n_reads + 63) / 64;
+	for (uint64_t g = (uint64_t)blockIdx.x * SC_WAVES + wave; g < groups; g += (uint64_t)gridDim.x * SC_WAVES) {
+		const uint64_t r0 = g * 64;
+		const uint32_t nr = (uint32_t)(n_reads - r0 < 64 ? n_reads - r0 : 64);
+		__builtin_amdgcn_wave_barrier();
+		for (uint32_t i = lane; i <= nr; i += 64) { s_off[wave][i] = offsets[r0 + i]; s_coff[wave][i] = count_off[r0 + i]; }
+		s_first[wave][lane] = 0xffffffffu;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+		const uint64_t b0 = s_off[wave][0], b1 = s_off[wave][nr];
+		for (uint64_t q = (b0 & ~15ull) + (uint64_t)lane * 16; q < b1; q += 1024) {        /* TwoBitSequence::firstMarkupNorX */
+			const uint4 v = *(const uint4 *)(bases + q);
+			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int j = 0; j < 16; j++) {
+				const uint8_t c = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+				const uint64_t pp = q + j;
+				if ((c == 'N' || c == 'X' || c == '.') && pp >= b0 && pp < b1) {
+					uint32_t lo = 0, hi = nr;                     /* the read with off[l] <= pp < off[l+1] */
+					while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[wave][mid] <= pp) lo = mid; else hi = mid; }
+					atomicMin(&s_first[wave][lo], (uint32_t)(pp - s_off[wave][lo]));
 				}
-				sc = (float)lo;
-			} else if (scoring == SCORE_AVG) {
-				double sum = 0.0; for (uint32_t i = 0; i < bestLen; i++) sum += (float)run[i];
-				sc = (float)(sum / (double)bestLen);
-			} else if (scoring == SCORE_MIN || scoring == SCORE_MAX) {
-				uint32_t m = run[0];
-				for (uint32_t i = 1; i < bestLen; i++) m = scoring == SCORE_MAX ? (run[i] > m ? run[i] : m) : (run[i] < m ? run[i] : m);
-				sc = (float)m;
-			} else sc = 0.0f;     /* KS_SUM: scoreReadBySumKmer only assigns the score when byAvg (:1149-1162) */
+			}
 		}
-		trimOffset[r] = bestLen > 0 ? bestOff : 0u;
-		trimLength[r] = bestLen > 0 ? bestLen + k - 1 : 0u;
-		score[r] = sc;
-		wasTrimmed[r] = trimmed ? 1 : 0;
+		const uint64_t c0 = s_coff[wave][0], cn = s_coff[wave][nr] - c0;
+		const bool staged = cn <= (uint64_t)SC_CAP;
+		if (staged) for (uint64_t i = lane; i < cn; i += 64) s_cnt[wave][i] = (uint16_t)counts[c0 + i];
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+		if ((uint32_t)lane < nr) {
+			const uint64_t L = s_off[wave][lane + 1] - s_off[wave][lane];
+			uint32_t numKmers = L >= k ? (uint32_t)(L - k + 1) : 0;
+			const uint32_t first = s_first[wave][lane];
+			if (first != 0xffffffffu) { const uint32_t m = first + 1; numKmers = m > k ? (m - k < numKmers ? m - k : numKmers) : 0; }
+			uint32_t tOff, tLen; float sc; bool trimmed;
+			if (staged) score_one_read<uint16_t>(&s_cnt[wave][s_coff[wave][lane] - c0], numKmers, k, minScore, scoring, tOff, tLen, sc, trimmed);
+			else score_one_read<uint32_t>(counts + s_coff[wave][lane], numKmers, k, minScore, scoring, tOff, tLen, sc, trimmed);
+			const uint64_t r = r0 + lane;
+			trimOffset[r] = tOff; trimLength[r] = tLen; score[r] = sc; wasTrimmed[r] = trimmed ? 1 : 0;
+		}
 	}
 }
 
