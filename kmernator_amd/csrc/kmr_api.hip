@@ -1812,6 +1812,7 @@ struct kmr_artifact_filter {
 	uint32_t n_seq = 0, remaining_edits = 0, log2cap = 0;
 	uint64_t n_keys = 0;
 	uint64_t *d_keys = nullptr; uint32_t *d_vals = nullptr;      /* open-addressed lookup table */
+	uint32_t *d_bits = nullptr;                                    /* presence filter in front of it (ART_FILTER_LOG2 bits) */
 	std::vector<uint64_t> keys; std::vector<uint32_t> vals;        /* the same entries on the host, ascending keys */
 };
 
@@ -1839,10 +1840,12 @@ int art_upload(kmr_handle *h, kmr_artifact_filter *f) {
 	f->log2cap = art_log2cap(f->n_keys);
 	const uint64_t cap = 1ull << f->log2cap;
 	HIPCHK(h, hipMalloc((void **)&f->d_keys, 8 * cap)); HIPCHK(h, hipMalloc((void **)&f->d_vals, 4 * cap));
+	if (!f->d_bits) HIPCHK(h, hipMalloc((void **)&f->d_bits, (1u << ART_FILTER_LOG2) / 8));
+	HIPCHK(h, hipMemsetAsync(f->d_bits, 0, (1u << ART_FILTER_LOG2) / 8, h->stream));
 	ArtBuf tmp; uint64_t *dk; uint32_t *dv;
 	HIPCHK(h, tmp.get(&dk, f->n_keys)); HIPCHK(h, tmp.get(&dv, f->n_keys));
 	if (f->n_keys) { HIPCHK(h, hipMemcpyAsync(dk, f->keys.data(), 8 * f->n_keys, hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipMemcpyAsync(dv, f->vals.data(), 4 * f->n_keys, hipMemcpyHostToDevice, h->stream)); }
-	ArtifactTable t{f->d_keys, f->d_vals, nullptr, f->log2cap};
+	ArtifactTable t{f->d_keys, f->d_vals, nullptr, f->log2cap, f->d_bits};
 	hipLaunchKernelGGL(artifact_fill, dim3(1024), dim3(256), 0, h->stream, f->d_keys, (uint32_t *)nullptr, cap);
 	if (f->n_keys) hipLaunchKernelGGL(artifact_insert, dim3((unsigned)std::min<uint64_t>((f->n_keys + 255) / 256, 4096)), dim3(256), 0, h->stream, t, dk, dv, f->n_keys);
 	HIPCHK(h, hipGetLastError());
@@ -1875,7 +1878,7 @@ int art_build_round(kmr_handle *h, kmr_artifact_filter *f) {
 	HIPCHK(h, hipMemcpyAsync(dk, sk.data(), 8 * n, hipMemcpyHostToDevice, h->stream));
 	HIPCHK(h, hipMemcpyAsync(dv, sv.data(), 4 * n, hipMemcpyHostToDevice, h->stream));
 	HIPCHK(h, hipMemsetAsync(cnt, 0, 8, h->stream));
-	ArtifactTable t{tk, tv, tr, log2cap};
+	ArtifactTable t{tk, tv, tr, log2cap, nullptr};
 	hipLaunchKernelGGL(artifact_fill, dim3(2048), dim3(256), 0, h->stream, tk, tr, cap);
 	hipLaunchKernelGGL(artifact_insert, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream, t, dk, dv, n);
 	hipLaunchKernelGGL(artifact_neighbours, dim3((unsigned)std::min<uint64_t>((n * L + 255) / 256, 1u << 20)), dim3(256), 0, h->stream, t, dk, n, L);
@@ -1971,7 +1974,7 @@ int kmr_artifact_filter_entries(const kmr_artifact_filter *f, uint64_t *keys, ui
 void kmr_artifact_filter_free(kmr_artifact_filter *f) {
 	if (!f) return;
 	hipSetDevice(f->device);
-	if (f->d_keys) hipFree(f->d_keys); if (f->d_vals) hipFree(f->d_vals);
+	if (f->d_keys) hipFree(f->d_keys); if (f->d_vals) hipFree(f->d_vals); if (f->d_bits) hipFree(f->d_bits);
 	delete f;
 }
 
@@ -1983,7 +1986,7 @@ int kmr_artifact_filter_apply(kmr_handle *h, const kmr_artifact_filter *f, const
 	if (f->device != h->device || in->device != h->device) return fail(h, KMR_ERR_INVALID_ARG, "filter, reads and handle must live on one device");
 	hipSetDevice(h->device);
 	const uint64_t n = in->n;
-	ArtifactTable t{f->d_keys, f->d_vals, nullptr, f->log2cap};
+	ArtifactTable t{f->d_keys, f->d_vals, nullptr, f->log2cap, f->d_bits};
 	ArtifactParams P;
 	P.length = f->cfg.match_length; P.nSeq = f->n_seq; P.numErrors = f->remaining_edits;
 	P.srBegin = f->cfg.simple_repeat_begin; P.srEnd = f->cfg.simple_repeat_end; P.phix = f->cfg.phix_idx; P.refBegin = f->cfg.reference_begin;

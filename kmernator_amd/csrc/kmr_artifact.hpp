@@ -2,7 +2,7 @@
  *
  * The filter is a set of canonical match_length-mers (<= 28 bases, one 64-bit word, first base most significant in the
  * low 2*length bits) with the index of the artifact sequence each one came from, kept as an open-addressed table in HBM
- * (a few MB: it lives in L2).  Kernels:
+ * behind a 2 MB presence filter that stays in L2.  Kernels:
  *   artifact_insert / artifact_neighbours / artifact_compact   prepareMaps (:242-287): the substitution neighbours of
  *       every key, first writer in the reference's map order wins (atomicMin on the writer's rank)
  *   artifact_screen     applyFilterToRead (:389-541), one read per thread: best / second-best quality run, every 4th
@@ -20,7 +20,11 @@ namespace kmr {
 
 static const uint64_t ART_EMPTY = ~0ull;
 
-struct ArtifactTable { uint64_t *keys; uint32_t *vals; uint32_t *rank; uint32_t log2cap; };
+/* bits: a 2^24-bit presence filter in front of the lookup table (2 MB: it stays in L2 while the table of the reference's
+ * default filter, 1.2 M keys, does not): nearly every window of a clean read is turned away by one bit test */
+static const uint32_t ART_FILTER_LOG2 = 24;
+struct ArtifactTable { uint64_t *keys; uint32_t *vals; uint32_t *rank; uint32_t log2cap; uint32_t *bits; };
+__host__ __device__ __forceinline__ uint32_t art_filter_bit(uint64_t key) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - ART_FILTER_LOG2)); }
 struct ArtifactParams {
 	uint32_t length, nSeq, numErrors, srBegin, srEnd, phix, refBegin;
 	int32_t minQualChar;              /* (char)(FASTQ_START_CHAR + min quality), compared as signed chars (:410-413) */
@@ -48,6 +52,7 @@ __device__ __forceinline__ uint64_t art_claim(const ArtifactTable &t, uint64_t k
 	}
 }
 __device__ __forceinline__ uint32_t art_find(const ArtifactTable &t, uint64_t key) {          /* sequence index, 0 = absent */
+	if (t.bits) { const uint32_t b = art_filter_bit(key); if (!((t.bits[b >> 5] >> (b & 31)) & 1u)) return 0; }
 	const uint64_t mask = (1ull << t.log2cap) - 1;
 	uint64_t s = art_slot(key, t.log2cap);
 	for (;;) {
@@ -67,6 +72,7 @@ __global__ void artifact_insert(ArtifactTable t, const uint64_t *keys, const uin
 		const uint64_t s = art_claim(t, keys[i]);
 		t.vals[s] = vals[i];
 		if (t.rank) t.rank[s] = 0;
+		if (t.bits) { const uint32_t b = art_filter_bit(keys[i]); atomicOr(&t.bits[b >> 5], 1u << (b & 31)); }
 	}
 }
 /* KmerArrayPair::permuteBases(key, value, true) (src/Kmer.h:1434-1459) for entry e = the e-th of the map's iteration:
