@@ -305,3 +305,16 @@ def test_filter_on_reads_handed_over_as_host_arrays():
     rs = ka.ReadSet.from_arrays(sp, rb.bases, rb.quals, rb.offsets)
     assert rs.n == rb.n and rs.total_bases == rb.bases.size
     _check_apply(f, o, rs, rb)
+
+
+@pytest.mark.gpu
+def test_screen_matches_oracle_at_scale():
+    """200 000 spiked reads of 30-300 bases through the reference's default settings (both substitution rounds built in)"""
+    import kmernator_amd as ka
+    table = fasta("artifact_sequences.fa")
+    rb = _spiked_reads(200000, 31, table, read_len=(30, 300))
+    o = OracleArtifactFilter(artifact_config(), table)
+    sp, f = _device_filter({}, table)
+    rs = ka.ReadSet.from_arrays(sp, rb.bases, rb.quals, rb.offsets)
+    want, frs, _ = _check_apply(f, o, rs, rb)
+    assert (want["action"] == 1).sum() > 50000 and (want["remnant_len"] > 0).sum() > 5000
