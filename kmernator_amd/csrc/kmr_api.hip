@@ -1681,7 +1681,8 @@ static int ingest_dev(kmr_handle *h, const uint8_t *text, uint64_t len, uint32_t
 	uint64_t n_kept = 0, total = 0;
 	if (nrec) {
 		ING(hipMalloc((void **)&lstart, 8 * n_lines)); ING(hipMalloc((void **)&llen, 4 * n_lines));
-		hipLaunchKernelGGL(ingest_index_lines, dim3((unsigned)nblk), dim3(ING_THREADS), 0, h->stream, text, len, bbase, lstart, llen, derr);
+		hipLaunchKernelGGL(ingest_index_lines, dim3((unsigned)nblk), dim3(ING_THREADS), 0, h->stream, text, len, bbase, lstart);
+		hipLaunchKernelGGL(ingest_line_lengths, dim3(grid_for(n_lines)), dim3(256), 0, h->stream, text, len, lstart, n_lines, llen, derr);
 		ING(hipMalloc((void **)&keep, 4 * nrec)); ING(hipMalloc((void **)&klen, 4 * nrec));
 		ING(hipMalloc((void **)&kidx, 8 * (nrec + 1))); ING(hipMalloc((void **)&boff, 8 * (nrec + 1)));
 		hipLaunchKernelGGL(ingest_records, dim3(grid_for(nrec)), dim3(256), 0, h->stream, text, lstart, llen, nrec, store_comment, keep, klen, derr);

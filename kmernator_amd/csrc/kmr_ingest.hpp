@@ -11,7 +11,8 @@
  * The reference walks the text line by line; here every byte is looked at once, in parallel:
  *   ingest_count_lines   per 4 KB block: number of non-empty line starts
  *   (exclusive scan)
- *   ingest_index_lines   line_start[i], line_len[i] for the i-th non-empty line
+ *   ingest_index_lines   line_start[i] for the i-th non-empty line
+ *   ingest_line_lengths  line_len[i], from the start of the next line
  *   ingest_records       record r = lines 4r..4r+3: markers, lengths, Casava filter -> keep[r], len[r]
  *   (two exclusive scans: kept index, base offset)
  *   ingest_copy          one wavefront per record: upper-cased bases, rescaled quals, offsets, name
@@ -106,7 +107,7 @@ void ingest_count_lines(const uint8_t *text, uint64_t len, uint32_t *block_lines
 }
 
 __global__ __launch_bounds__(ING_THREADS)
-void ingest_index_lines(const uint8_t *text, uint64_t len, const uint64_t *block_base, uint64_t *line_start, uint32_t *line_len, uint32_t *err) {
+void ingest_index_lines(const uint8_t *text, uint64_t len, const uint64_t *block_base, uint64_t *line_start) {
 	const uint64_t p0 = ((uint64_t)blockIdx.x * ING_THREADS + threadIdx.x) * ING_BYTES;
 	const bool aligned = ((uintptr_t)text & 15) == 0;
 	const uint32_t mask = p0 < len ? ing_start_mask(ing_load_chunk(text, len, p0, aligned), p0, len) : 0u;
@@ -115,13 +116,21 @@ void ingest_index_lines(const uint8_t *text, uint64_t len, const uint64_t *block
 	uint64_t idx = block_base[blockIdx.x] + ing_block_scan(c, &tot);
 	if (!c) return;
 	for (int j = 0; j < ING_BYTES; j++) {
-		const uint64_t p = p0 + j;
-		if (mask & (1u << j)) {
-			uint64_t e = ing_line_end(text, len, p, aligned);
-			if (e - p > 0xffffffffull) { atomicOr(err, (uint32_t)ING_ERR_LEN); e = p; }
-			line_start[idx] = p; line_len[idx] = (uint32_t)(e - p);
-			idx++;
-		}
+		if (mask & (1u << j)) line_start[idx++] = p0 + j;
+	}
+}
+/* one thread per line: the line ends at the first '\n' at or after its start, and everything between that and the next
+ * non-empty line's start is '\n' -- so the end is found from the next start (one byte looked at when no blank lines
+ * intervene) instead of by reading the line; only the last line is read to its end */
+__global__ void ingest_line_lengths(const uint8_t *text, uint64_t len, const uint64_t *line_start, uint64_t n_lines, uint32_t *line_len, uint32_t *err) {
+	const bool aligned = ((uintptr_t)text & 15) == 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_lines; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t p = line_start[i];
+		uint64_t e;
+		if (i + 1 < n_lines) { e = line_start[i + 1] - 1; while (e > p && text[e - 1] == '\n') e--; }
+		else e = ing_line_end(text, len, p, aligned);
+		if (e - p > 0xffffffffull) { atomicOr(err, (uint32_t)ING_ERR_LEN); e = p; }
+		line_len[i] = (uint32_t)(e - p);
 	}
 }
 
