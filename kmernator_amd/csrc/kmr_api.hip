@@ -1709,7 +1709,7 @@ static int ingest_dev(kmr_handle *h, const uint8_t *text, uint64_t len, uint32_t
 	ING(hipMemcpyAsync(R->offsets + n_kept, &total, 8, hipMemcpyHostToDevice, h->stream));
 	if (nrec) {
 		/* appendFasta rescales every read from the input base to Read::FASTQ_START_CHAR as it is read (src/ReadSet.cpp:324,336) */
-		hipLaunchKernelGGL(ingest_copy, dim3(grid_for(nrec, 4, 1 << 16)), dim3(256), 0, h->stream, text, lstart, llen, nrec, keep, kidx, boff,
+		hipLaunchKernelGGL(ingest_copy, dim3(grid_for(nrec, 4, 1 << 16)), dim3(256), 0, h->stream, text, len, lstart, llen, nrec, keep, kidx, boff,
 		                   (int)start - (int)input_base, start, R->bases, R->quals, R->offsets, R->name_off, R->name_len, derr + 1);
 		ING(hipGetLastError());
 		uint32_t flip = 0;

@@ -165,12 +165,28 @@ __global__ void ingest_records(const uint8_t *text, const uint64_t *line_start, 
 	}
 }
 
-/* one wavefront per record */
+/* four output bytes [a, a + 4) of a record's bases or quals (a 4-byte aligned in the output array): the source bytes sit at
+ * text + sa .. sa + 3 at any alignment -- two aligned dword loads and a byte funnel shift when the text is 4-byte aligned and
+ * the second dword is inside it, single bytes otherwise */
+__device__ __forceinline__ uint32_t ing_src_dword(const uint8_t *text, uint64_t len, int64_t sa, bool aligned) {
+	if (aligned && sa >= 0 && (uint64_t)sa + 8 <= len) {
+		const uint32_t *w = (const uint32_t *)(text + ((uint64_t)sa & ~3ull));
+		const uint64_t both = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+		return (uint32_t)(both >> (8 * ((uint64_t)sa & 3)));
+	}
+	uint32_t v = 0;
+#pragma unroll
+	for (int b = 0; b < 4; b++) { const int64_t q = sa + b; if (q >= 0 && (uint64_t)q < len) v |= (uint32_t)text[q] << (8 * b); }
+	return v;
+}
+
+/* one wavefront per record, one lane per aligned output dword */
 __global__ __launch_bounds__(256)
-void ingest_copy(const uint8_t *text, const uint64_t *line_start, const uint32_t *line_len, uint64_t n_records, const uint32_t *keep,
+void ingest_copy(const uint8_t *text, uint64_t len, const uint64_t *line_start, const uint32_t *line_len, uint64_t n_records, const uint32_t *keep,
                  const uint64_t *kept_idx, const uint64_t *base_off, int qdelta, uint32_t start_char,
                  uint8_t *bases, uint8_t *quals, uint64_t *offsets, uint64_t *name_off, uint32_t *name_len, uint32_t *flip) {
 	const int lane = threadIdx.x & 63;
+	const bool aligned = ((uintptr_t)text & 3) == 0;
 	const uint64_t wavesPerGrid = (uint64_t)gridDim.x * (blockDim.x >> 6);
 	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_records; r += wavesPerGrid) {
 		if (!keep[r]) continue;
@@ -178,13 +194,29 @@ void ingest_copy(const uint8_t *text, const uint64_t *line_start, const uint32_t
 		const uint64_t sb = line_start[4 * r + 1], sq = line_start[4 * r + 3];
 		const uint32_t L = line_len[4 * r + 1];
 		uint32_t mn = 255;
-		for (uint32_t i = lane; i < L; i += 64) {
-			uint8_t c = text[sb + i];
-			if (c >= 'a' && c <= 'z') c -= 32;                       /* std::toupper, src/ReadFileReader.h:311 */
-			bases[o + i] = c;
-			const uint8_t q = (uint8_t)(text[sq + i] + qdelta);      /* Read::rescaleQuality, src/Sequence.h:443-447 */
-			quals[o + i] = q;
-			mn = q < mn ? q : mn;
+		const uint64_t a0 = o & ~3ull, nd = (((o + L + 3) & ~3ull) - a0) >> 2;
+		const int64_t shift = (int64_t)(o - a0);
+		for (uint64_t d = lane; d < nd; d += 64) {
+			const uint64_t a = a0 + 4 * d;                                   /* output bytes [a, a + 4) */
+			const uint32_t vb = ing_src_dword(text, len, (int64_t)sb - shift + (int64_t)(4 * d), aligned);
+			const uint32_t vq = ing_src_dword(text, len, (int64_t)sq - shift + (int64_t)(4 * d), aligned);
+			uint32_t ob = 0, oq = 0, valid = 0;
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const uint64_t pos = a + b;
+				if (pos < o || pos >= o + L) continue;
+				valid |= 1u << b;
+				uint8_t c = (uint8_t)(vb >> (8 * b));
+				if (c >= 'a' && c <= 'z') c -= 32;                           /* std::toupper, src/ReadFileReader.h:311 */
+				const uint8_t q = (uint8_t)((uint8_t)(vq >> (8 * b)) + qdelta);  /* Read::rescaleQuality, src/Sequence.h:443-447 */
+				ob |= (uint32_t)c << (8 * b); oq |= (uint32_t)q << (8 * b);
+				mn = q < mn ? q : mn;
+			}
+			if (valid == 0xfu) { *(uint32_t *)(bases + a) = ob; *(uint32_t *)(quals + a) = oq; }
+			else {
+#pragma unroll
+				for (int b = 0; b < 4; b++) if (valid & (1u << b)) { bases[a + b] = (uint8_t)(ob >> (8 * b)); quals[a + b] = (uint8_t)(oq >> (8 * b)); }
+			}
 		}
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1) { const uint32_t x = __shfl_xor(mn, off, 64); mn = x < mn ? x : mn; }
