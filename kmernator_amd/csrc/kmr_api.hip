@@ -1061,12 +1061,25 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 			auto kern = count_kernel<W, EXT, 11>;
 			const size_t smem = count_smem_bytes<W, EXT, 11>();
 			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter);
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter, 0);
+		} else if (EXT && W == 1 && !getenv("KMR_NO_NARROW")) {
+			/* extension values at k <= 32: 16-bit tallies for every list of at most 65 535 records (two blocks per CU), then
+			 * the wide table for whatever is longer */
+			auto kn = count_kernel<W, EXT, COUNT_LOG2S, true>;
+			const size_t sn = count_smem_bytes<W, EXT, COUNT_LOG2S, true>();
+			HIPCHK(h, hipFuncSetAttribute((const void *)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn));
+			hipLaunchKernelGGL(kn, dim3(grid), dim3(COUNT_THREADS), sn, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter, 1);
+			HIPCHK(h, hipGetLastError());
+			rc = zero_work_counter(h); if (rc) return rc;
+			auto kern = count_kernel<W, EXT, COUNT_LOG2S>;
+			const size_t smem = count_smem_bytes<W, EXT, COUNT_LOG2S>();
+			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+			hipLaunchKernelGGL(kern, dim3(std::min(grid, part_grid(h))), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter, 2);
 		} else {
 			auto kern = count_kernel<W, EXT, COUNT_LOG2S>;
 			const size_t smem = count_smem_bytes<W, EXT, COUNT_LOG2S>();
 			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter);
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter, 0);
 		}
 		HIPCHK(h, hipGetLastError());
 	}
@@ -1919,7 +1932,7 @@ int kmr_artifact_filter_create(kmr_handle *h, const kmr_artifact_config *cfg, co
 	if (cfg->match_length == 0 || cfg->match_length > 28 || (cfg->match_length & 3))
 		return fail(h, KMR_ERR_INVALID_ARG, "artifact match length must be a multiple of 4 and <= 28 (src/FilterKnownOddities.h:207-209,244)");
 	hipSetDevice(h->device);
-	std::unique_ptr<kmr_artifact_filter> f(new kmr_artifact_filter);
+	std::unique_ptr<kmr_artifact_filter, void (*)(kmr_artifact_filter *)> f(new kmr_artifact_filter, kmr_artifact_filter_free);
 	f->device = h->device; f->cfg = *cfg;
 	const uint32_t L = cfg->match_length;
 	/* sequences: read 0 is the empty "no match" read, then the FASTA records in file order (:213-231) */

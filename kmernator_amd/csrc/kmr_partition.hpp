@@ -757,16 +757,24 @@ struct CountOut {
 	uint32_t *err;
 };
 
-template <int W, bool EXT, int LOG2S>
-__host__ __device__ constexpr size_t count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (EXT ? 52 : 0)); }
+/* NARROW (extension values only): the 12 tallies of a slot are kept as 16-bit halves of six words, which is exact for a
+ * list of at most 65 535 records -- 60 instead of 84 bytes per slot, two blocks per CU instead of one.  COUNT_NARROW_CHUNKS
+ * is the longest list (in chunks of CH records) the narrow instantiation takes; the few longer ones (a k-mer that repeats
+ * 10^5 times) go through the wide one in a second launch (list_filter). */
+static const uint64_t COUNT_NARROW_CHUNKS = 65535 / CH;
+template <int W, bool EXT, int LOG2S, bool NARROW = false>
+__host__ __device__ constexpr size_t count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (EXT ? (NARROW ? 28 : 52) : 0)); }
 
 /* One block per final list.  LDS table: keys, count|fwd<<32, f64 weight sum, first
  * (ordinal<<1|fwd).  If the table would overflow the list is split by further hash bits
  * and done in sub-passes (a tiny LDS stack), so any input is handled. */
-template <int W, bool EXT, int LOG2S>
-__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && !EXT && LOG2S <= 10) ? 4 : 1)      /* W == 1: four blocks per CU (<= 128 VGPRs, < 40 KB LDS each) */
+template <int W, bool EXT, int LOG2S, bool NARROW = false>
+__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && !EXT && LOG2S <= 10) ? 4 : (NARROW ? 2 : 1))      /* W == 1: four blocks per CU (<= 128 VGPRs, < 40 KB LDS each) */
 void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists,
-                  CountOut out, FinalizeParams f, unsigned int *work_counter) {
+                  CountOut out, FinalizeParams f, unsigned int *work_counter, int list_filter = 0) {
+	constexpr int TW = NARROW ? 6 : 12;          /* tally words per slot */
+	/* list_filter 1: only lists of at most COUNT_NARROW_CHUNKS chunks, 2: only the longer ones, 0: all */
+	auto skipped = [&](uint64_t a, uint64_t b) -> bool { return list_filter == 1 ? b - a > COUNT_NARROW_CHUNKS : (list_filter == 2 ? b - a <= COUNT_NARROW_CHUNKS : false); };
 	constexpr int S = 1 << LOG2S;
 	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
 	typedef typename PoolRec<W, EXT>::type Rec;
@@ -777,7 +785,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 	unsigned long long *tfirst = (unsigned long long *)(twsum + S);
 	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
 	uint32_t *ttally = tstate + (W > 1 ? S : 0);                       /* EXT: [S][12] extension tallies, then [S] one packet */
-	uint32_t *tpkt = ttally + (EXT ? 12 * S : 0);
+	uint32_t *tpkt = ttally + (EXT ? TW * S : 0);
 	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns;
 	__shared__ unsigned long long s_wbase, s_sbase;
 	/* output space is taken from the global cursors one slab at a time (a per-list atomic on one word would
@@ -835,13 +843,13 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 				if ((uint32_t)(t & 63) < (uint32_t)(d[u] >> 32)) dst[u] = ((const Rec *)(pool.base + (size_t)(uint32_t)d[u] * CH * sizeof(Rec)))[t & 63];
 			}
 		};
-		load_round(s_ls[0], s_ls[1], rn);
+		if (!skipped(s_ls[0], s_ls[1])) load_round(s_ls[0], s_ls[1], rn);
 		for (uint32_t j = 0; j < nl; j++) {
 		const uint64_t c0 = s_ls[j], c1 = s_ls[j + 1];
 #pragma unroll
 		for (int u = 0; u < UNR; u++) rr[u] = rn[u];
-		if (j + 1 < nl) load_round(s_ls[j + 1], s_ls[j + 2], rn);
-		if (c0 == c1) continue;
+		if (j + 1 < nl && !skipped(s_ls[j + 1], s_ls[j + 2])) load_round(s_ls[j + 1], s_ls[j + 2], rn);
+		if (c0 == c1 || skipped(c0, c1)) continue;
 		bool head_in_regs = true;       /* rr holds chunks [c0, c0 + HEAD) until a later round or sub-pass reloads it */
 		lds_barrier();       /* every thread has left the previous list's while (s_sp > 0) before s_sp is re-armed */
 		if (t == 0) { s_sp = 1; s_stackBits[0] = 0; s_stackVal[0] = 0; }
@@ -851,7 +859,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 			lds_barrier();
 			if (t == 0) { s_sp--; s_claimed = 0; s_overflow = 0; s_nw = 0; s_ns = 0; }
 			for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; }
-			if (EXT) for (int i = t; i < 12 * S; i += COUNT_THREADS) ttally[i] = 0;
+			if (EXT) for (int i = t; i < TW * S; i += COUNT_THREADS) ttally[i] = 0;
 			lds_barrier();
 			const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
 			/* insert: wave w takes chunks cb + w, + waves, ...; lane = record */
@@ -942,8 +950,13 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 				if constexpr (EXT) {      /* ExtensionTracking::trackExtension (src/KmerTrackingData.h:195-201) */
 					const int lc = ext_tally_index(r.pkt & 0xff), rc_ = ext_tally_index((r.pkt >> 8) & 0xff);
 					const uint32_t lq = (r.pkt >> 16) & 0xff, rq_ = r.pkt >> 24;
-					if (lq >= f.ext_min_q || lc > 3) atomicAdd(&ttally[(size_t)s * 12 + lc], 1u);
-					if (rq_ >= f.ext_min_q || rc_ > 3) atomicAdd(&ttally[(size_t)s * 12 + 6 + rc_], 1u);
+					if (NARROW) {
+						if (lq >= f.ext_min_q || lc > 3) atomicAdd(&ttally[(size_t)s * TW + (lc >> 1)], 1u << (16 * (lc & 1)));
+						if (rq_ >= f.ext_min_q || rc_ > 3) atomicAdd(&ttally[(size_t)s * TW + ((6 + rc_) >> 1)], 1u << (16 * ((6 + rc_) & 1)));
+					} else {
+						if (lq >= f.ext_min_q || lc > 3) atomicAdd(&ttally[(size_t)s * 12 + lc], 1u);
+						if (rq_ >= f.ext_min_q || rc_ > 3) atomicAdd(&ttally[(size_t)s * 12 + 6 + rc_], 1u);
+					}
 					tpkt[s] = r.pkt;      /* exact whenever the key ends with one occurrence, the only case it is read */
 				}
 				}
@@ -1037,7 +1050,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 						v[0] = cnt; v[1] = __float_as_uint((float)twsum[s]); v[2] = fwd;
 						if (EXT) {
 #pragma unroll
-							for (int j = 0; j < 12; j++) v[3 + j] = ttally[(size_t)s * 12 + j];
+							for (int j = 0; j < 12; j++) v[3 + j] = NARROW ? ((ttally[(size_t)s * TW + (j >> 1)] >> (16 * (j & 1))) & 0xffffu) : ttally[(size_t)s * 12 + j];
 						}
 					}
 					bucket_count_add(out.weakCount, bucket, live);

@@ -1,6 +1,6 @@
 """development tool: extension values (Meraculous) at scale, streaming vs device-table mode"""
 import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, numpy as np
 import bench, kmernator_amd as ka
 from helpers import KMR_MAP_WEAK, KMR_VALUE_EXT
