@@ -1121,13 +1121,26 @@ __global__ void entry_scatter_kernel(const uint64_t *ukeys, const uint32_t *uval
 			if (mine) { rank = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1)); done = true; }
 		}
 		if (live && !done) rank = atomicAdd(&cursor[b], 1u);
-		if (!live) continue;
-		const uint64_t pos = start[b] + rank;
+		const uint64_t pos = live ? start[b] + rank : 0;
+		if (live) {
 #pragma unroll
-		for (int j = 0; j < W; j++) keys[pos * W + j] = key.w[j];
-		if (uvals) for (uint32_t j = 0; j < vw; j++) vals[pos * vw + j] = uvals[e * vw + j];
-		if (ub8) b8[pos] = ub8[e];
-		if (upkt) pkt[pos] = upkt[e];
+			for (int j = 0; j < W; j++) keys[pos * W + j] = key.w[j];
+			if (ub8) b8[pos] = ub8[e];
+			if (upkt) pkt[pos] = upkt[e];
+		}
+		if (uvals && vw <= 4) {
+			if (live) for (uint32_t j = 0; j < vw; j++) vals[pos * vw + j] = uvals[e * vw + j];
+		} else if (uvals) {
+			/* wide values (15 words with extension tallies): a lane copying its own entry word by word touches 64 lines per
+			 * instruction; instead 16 lanes share an entry, four entries per step, so a step reads 4 x 60 contiguous bytes */
+			for (int i0 = 0; i0 < 64; i0 += 4) {
+				const int src = i0 + (lane >> 4);
+				const uint32_t word = (uint32_t)(lane & 15);
+				const int sl = __shfl(live ? 1 : 0, src);
+				const uint64_t sp = ((uint64_t)(uint32_t)__shfl((int)(pos >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)pos, src);
+				if (sl && word < vw) vals[sp * vw + word] = uvals[(e0 + src) * vw + word];
+			}
+		}
 	}
 }
 
