@@ -1070,11 +1070,19 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 			HIPCHK(h, hipFuncSetAttribute((const void *)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn));
 			hipLaunchKernelGGL(kn, dim3(grid), dim3(COUNT_THREADS), sn, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter, 1);
 			HIPCHK(h, hipGetLastError());
+			/* is any list longer than the narrow tallies can take?  (the work counter word doubles as the maximum) */
 			rc = zero_work_counter(h); if (rc) return rc;
-			auto kern = count_kernel<W, EXT, COUNT_LOG2S>;
-			const size_t smem = count_smem_bytes<W, EXT, COUNT_LOG2S>();
-			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-			hipLaunchKernelGGL(kern, dim3(std::min(grid, part_grid(h))), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter, 2);
+			hipLaunchKernelGGL(max_list_chunks_kernel, dim3(grid_for(nl2)), dim3(256), 0, h->stream, ls2, nl2, h->work_counter);
+			unsigned int longest = 0;
+			HIPCHK(h, hipMemcpyAsync(&longest, h->work_counter, 4, hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(h, hipStreamSynchronize(h->stream));
+			rc = zero_work_counter(h); if (rc) return rc;
+			if (longest > COUNT_NARROW_CHUNKS) {
+				auto kern = count_kernel<W, EXT, COUNT_LOG2S>;
+				const size_t smem = count_smem_bytes<W, EXT, COUNT_LOG2S>();
+				HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+				hipLaunchKernelGGL(kern, dim3(std::min(grid, part_grid(h))), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter, 2);
+			}
 		} else {
 			auto kern = count_kernel<W, EXT, COUNT_LOG2S>;
 			const size_t smem = count_smem_bytes<W, EXT, COUNT_LOG2S>();

@@ -762,6 +762,17 @@ struct CountOut {
  * is the longest list (in chunks of CH records) the narrow instantiation takes; the few longer ones (a k-mer that repeats
  * 10^5 times) go through the wide one in a second launch (list_filter). */
 static const uint64_t COUNT_NARROW_CHUNKS = 65535 / CH;
+__global__ void max_list_chunks_kernel(const uint64_t *list_start, uint64_t n_lists, unsigned int *out) {
+	unsigned int m = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_lists; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t n = list_start[i + 1] - list_start[i];
+		const unsigned int c = n > 0xffffffffull ? 0xffffffffu : (unsigned int)n;
+		m = c > m ? c : m;
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) { const unsigned int x = (unsigned int)__shfl_xor((int)m, off, 64); m = x > m ? x : m; }
+	if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
 template <int W, bool EXT, int LOG2S, bool NARROW = false>
 __host__ __device__ constexpr size_t count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (EXT ? (NARROW ? 28 : 52) : 0)); }
 
