@@ -18,3 +18,7 @@ for rep in range(3):
     sp.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0); sp.sync(); t2 = time.time()
     sp.finalize(2); t3 = time.time()
     print("build %d: reset %.1f ms, add_reads %.1f ms, finalize %.1f ms" % (rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3), flush=True)
+from kmernator_amd import KMR_MAP_WEAK
+for rep in range(2):
+    t0 = time.time(); img = sp.image(KMR_MAP_WEAK); t1 = time.time()
+    print("weak image export %d: %.1f MB in %.1f ms (device pack + copy to pageable host memory)" % (rep, img.size / 1e6, (t1 - t0) * 1e3), flush=True)
