@@ -97,3 +97,22 @@ def test_ranks_sharing_one_gpu(world, pipeline):
             got = np.load(os.path.join(tmp, "score.%d.npz" % r))
             for a, b in zip((got["to"], got["tl"], got["sc"], got["wt"]), want):
                 assert np.array_equal(a, b)
+
+
+def test_bench_n2_code_path_on_one_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), both ranks on this GPU over
+    gloo: the JSON line must come out and account for every k-mer of both ranks"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 31800 + (os.getpid() % 1000)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--reads", "300000", "--no-cpu", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["total_kmers"] == 2 * 300000 * 120
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
