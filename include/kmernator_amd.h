@@ -332,6 +332,15 @@ int kmr_reads_device_ptrs(const kmr_reads *r, void **dev_bases, void **dev_quals
  * (after '@') in the input text, for the host-side Read names */
 int kmr_reads_copy(const kmr_reads *r, char *bases, char *quals, uint64_t *offsets,
                    uint64_t *name_off, uint32_t *name_len);
+/* The batch in the form the reference's Read keeps its bases (src/Sequence.h: 2-bit packed + markups):
+ * TwoBitSequence::compressSequence (src/TwoBitSequence.cpp:242-269) over every read on the device.  Read i's packed bases are
+ * twobit[twobit_offsets[i] .. twobit_offsets[i+1]) (ceil(L/4) bytes, first base in bits 7-6, last byte zero padded), its markups
+ * (any character but ACGTacgt; '.' recorded as 'N') are entries markup_offsets[i] .. markup_offsets[i+1] of markup_pos /
+ * markup_char, in ascending offset.  *twobit_bytes and *n_markups always receive the sizes; with every array NULL that is all
+ * the call does, and KMR_ERR_CAPACITY means an array was too small for them.  All arrays are host memory. */
+int kmr_reads_twobit(kmr_handle *h, const kmr_reads *r, uint8_t *twobit, uint64_t twobit_capacity, uint64_t *twobit_offsets,
+                     uint32_t *markup_pos, char *markup_char, uint64_t markup_capacity, uint64_t *markup_offsets,
+                     uint64_t *twobit_bytes, uint64_t *n_markups);
 /* kmr_add_reads_dev on the batch, then kmr_sync */
 int kmr_add_read_batch(kmr_handle *h, const kmr_reads *r, uint64_t first_global_read_idx);
 void kmr_reads_free(kmr_reads *r);

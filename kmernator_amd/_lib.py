@@ -63,7 +63,7 @@ EXPORTS = [
     "kmr_add_read_batch", "kmr_reads_free", "kmr_histogram", "kmr_histogram_bins", "kmr_merge_image", "kmr_subtract_reference", "kmr_subtracted", "kmr_score_read_batch",
     "kmr_artifact_config_init", "kmr_artifact_filter_create", "kmr_artifact_filter_info", "kmr_artifact_filter_entries",
     "kmr_artifact_filter_free", "kmr_artifact_filter_apply",
-    "kmr_reads_from_host", "kmr_lookup_requests_dev", "kmr_lookup_keys_dev", "kmr_scatter_counts_dev", "kmr_score_counts_dev",
+    "kmr_reads_from_host", "kmr_reads_twobit", "kmr_lookup_requests_dev", "kmr_lookup_keys_dev", "kmr_scatter_counts_dev", "kmr_score_counts_dev",
 ]
 
 _lib = None
@@ -128,6 +128,7 @@ def load():
     lib.kmr_reads_free.argtypes = [vp]
     lib.kmr_reads_free.restype = None
     lib.kmr_score_read_batch.argtypes = [vp, vp, C.c_double, C.c_int, u32p, u32p, C.POINTER(C.c_float), u8p]
+    lib.kmr_reads_twobit.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), u32p, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.kmr_reads_from_host.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(vp)]
     lib.kmr_lookup_requests_dev.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint64, vp]
     lib.kmr_lookup_keys_dev.argtypes = [vp, vp, C.c_uint64, vp]

@@ -2070,6 +2070,44 @@ int kmr_artifact_filter_apply(kmr_handle *h, const kmr_artifact_filter *f, const
 	return KMR_OK;
 }
 
+/* ---- f2: the batch as 2-bit packed reads + markups -------------------------- */
+int kmr_reads_twobit(kmr_handle *h, const kmr_reads *r, uint8_t *twobit, uint64_t twobit_capacity, uint64_t *twobit_offsets,
+                     uint32_t *markup_pos, char *markup_char, uint64_t markup_capacity, uint64_t *markup_offsets,
+                     uint64_t *twobit_bytes, uint64_t *n_markups) {
+	if (!h || !r) return KMR_ERR_INVALID_ARG;
+	if (r->device != h->device) return fail(h, KMR_ERR_INVALID_ARG, "read batch lives on another device");
+	hipSetDevice(h->device);
+	const uint64_t n = r->n;
+	ArtBuf tmp; uint32_t *dlen, *dcnt; uint64_t *dtb, *dmk;
+	HIPCHK(h, tmp.get(&dlen, n + 1)); HIPCHK(h, tmp.get(&dcnt, n + 1)); HIPCHK(h, tmp.get(&dtb, n + 1)); HIPCHK(h, tmp.get(&dmk, n + 1));
+	uint64_t tb_total = 0, mk_total = 0;
+	if (n) {
+		hipLaunchKernelGGL(twobit_count_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, r->bases, r->offsets, n, dlen, dcnt);
+		HIPCHK(h, hipGetLastError());
+		int rc = exclusive_scan(h, dlen, n, dtb); if (rc) return rc;
+		rc = exclusive_scan(h, dcnt, n, dmk); if (rc) return rc;
+		HIPCHK(h, hipMemcpy(&tb_total, dtb + n, 8, hipMemcpyDeviceToHost)); HIPCHK(h, hipMemcpy(&mk_total, dmk + n, 8, hipMemcpyDeviceToHost));
+	} else { HIPCHK(h, hipMemset(dtb, 0, 8)); HIPCHK(h, hipMemset(dmk, 0, 8)); }
+	if (twobit_bytes) *twobit_bytes = tb_total; if (n_markups) *n_markups = mk_total;
+	if (!twobit && !markup_pos && !markup_char && !twobit_offsets && !markup_offsets) return KMR_OK;      /* sizes only */
+	if ((twobit && twobit_capacity < tb_total) || ((markup_pos || markup_char) && markup_capacity < mk_total)) return KMR_ERR_CAPACITY;
+	uint8_t *dtw, *dmc; uint32_t *dmp;
+	HIPCHK(h, tmp.get(&dtw, tb_total)); HIPCHK(h, tmp.get(&dmp, mk_total)); HIPCHK(h, tmp.get(&dmc, mk_total));
+	if (n) {
+		hipLaunchKernelGGL(twobit_pack_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, r->bases, r->offsets, n, dtb, dmk, dtw, dmp, dmc);
+		HIPCHK(h, hipGetLastError());
+	}
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipError_t e = hipSuccess;
+	if (twobit && tb_total) e = hipMemcpy(twobit, dtw, tb_total, hipMemcpyDeviceToHost);
+	if (e == hipSuccess && twobit_offsets) e = hipMemcpy(twobit_offsets, dtb, 8 * (n + 1), hipMemcpyDeviceToHost);
+	if (e == hipSuccess && markup_pos && mk_total) e = hipMemcpy(markup_pos, dmp, 4 * mk_total, hipMemcpyDeviceToHost);
+	if (e == hipSuccess && markup_char && mk_total) e = hipMemcpy(markup_char, dmc, mk_total, hipMemcpyDeviceToHost);
+	if (e == hipSuccess && markup_offsets) e = hipMemcpy(markup_offsets, dmk, 8 * (n + 1), hipMemcpyDeviceToHost);
+	HIPCHK(h, e);
+	return KMR_OK;
+}
+
 /* ---- stateless helpers ------------------------------------------------- */
 uint64_t kmr_hash(const uint8_t *key, uint32_t len) {
 	if (!key || len == 0 || len > 32) return 0;

@@ -229,6 +229,45 @@ void ingest_copy(const uint8_t *text, uint64_t len, const uint64_t *line_start, 
 	}
 }
 
+/* ---- 2-bit pack of a read batch: TwoBitSequence::compressSequence (src/TwoBitSequence.cpp:242-269, compressBase :114-147) ----
+ * four bases per byte, first base in bits 7-6, A/a = 0 C/c = 1 G/g = 2 T/t = 3; anything else packs as 0 and is recorded as a
+ * markup (char, offset), '.' recorded as 'N'.  One read per thread, bases through aligned 8-byte loads. */
+struct IngBytes {
+	const uint8_t *p; uint64_t w;
+	__device__ __forceinline__ void init(const uint8_t *q) { p = q; w = *(const uint64_t *)((uintptr_t)q & ~(uintptr_t)7); }
+	__device__ __forceinline__ uint8_t next() { const uint32_t o = (uint32_t)((uintptr_t)p & 7); if (o == 0) w = *(const uint64_t *)p; p++; return (uint8_t)(w >> (8 * o)); }
+};
+__device__ __forceinline__ uint32_t ing_base_code(uint8_t c) {      /* 4 = markup */
+	switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+__global__ void twobit_count_kernel(const uint8_t *bases, const uint64_t *offsets, uint64_t n, uint32_t *packed_len, uint32_t *markups) {
+	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t o = offsets[r], L = offsets[r + 1] - o;
+		IngBytes b; b.init(bases + o);
+		uint32_t m = 0;
+		for (uint64_t i = 0; i < L; i++) m += ing_base_code(b.next()) == 4 ? 1u : 0u;
+		packed_len[r] = (uint32_t)((L + 3) / 4); markups[r] = m;
+	}
+}
+__global__ void twobit_pack_kernel(const uint8_t *bases, const uint64_t *offsets, uint64_t n, const uint64_t *tb_off, const uint64_t *mk_off,
+                                   uint8_t *twobit, uint32_t *mk_pos, uint8_t *mk_char) {
+	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t o = offsets[r], L = offsets[r + 1] - o;
+		IngBytes b; b.init(bases + o);
+		uint8_t *out = twobit + tb_off[r];
+		uint64_t m = mk_off[r];
+		uint32_t acc = 0;
+		for (uint64_t i = 0; i < L; i++) {
+			const uint8_t c = b.next();
+			uint32_t code = ing_base_code(c);
+			if (code == 4) { mk_pos[m] = (uint32_t)i; mk_char[m] = c == '.' ? (uint8_t)'N' : c; m++; code = 0; }
+			acc |= code << (6 - 2 * (uint32_t)(i & 3));
+			if ((i & 3) == 3) { *out++ = (uint8_t)acc; acc = 0; }
+		}
+		if (L & 3) *out = (uint8_t)acc;              /* the partial last byte is zero padded */
+	}
+}
+
 __global__ void ingest_shift_quals(uint8_t *quals, uint64_t n, int delta) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) quals[i] = (uint8_t)(quals[i] + delta);
 }

@@ -366,6 +366,21 @@ class ReadSet:
                        offsets.ctypes.data_as(C.POINTER(C.c_uint64)), offsets.size - 1, C.byref(r))
         return cls._adopt(spectrum, b"", r)
 
+    def twobit(self):
+        """(packed bases, offsets[n+1], markup positions, markup chars, markup offsets[n+1]): every read as
+        TwoBitSequence::compressSequence packs it (src/TwoBitSequence.cpp:242-269), on the device"""
+        nb, nm = C.c_uint64(), C.c_uint64()
+        u64 = C.POINTER(C.c_uint64)
+        self.sp._call("reads_twobit", self.sp.h, self.r, None, 0, None, None, None, 0, None, C.byref(nb), C.byref(nm))
+        tw = np.zeros(max(1, nb.value), dtype=np.uint8)
+        to = np.zeros(self.n + 1, dtype=np.uint64)
+        mp = np.zeros(max(1, nm.value), dtype=np.uint32)
+        mc = np.zeros(max(1, nm.value), dtype=np.uint8)
+        mo = np.zeros(self.n + 1, dtype=np.uint64)
+        self.sp._call("reads_twobit", self.sp.h, self.r, tw.ctypes.data_as(C.c_void_p), tw.size, to.ctypes.data_as(u64), mp.ctypes.data_as(C.POINTER(C.c_uint32)),
+                      mc.ctypes.data_as(C.c_void_p), mp.size, mo.ctypes.data_as(u64), C.byref(nb), C.byref(nm))
+        return tw[:nb.value], to, mp[:nm.value], mc[:nm.value], mo
+
     def getSize(self):
         return self.n
 

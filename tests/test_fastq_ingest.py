@@ -182,3 +182,32 @@ def test_filterreads_from_fastq_text_on_the_device():
         assert label == gold.names[i].split(b" ", 1)[1], (i, label, gold.names[i])
         checked += 1
     assert checked == 949
+
+
+@pytest.mark.gpu
+def test_twobit_pack_of_a_batch_matches_compress_sequence():
+    """f2: TwoBitSequence::compressSequence over a device-resident batch (packed bytes + markup list per read) against the
+    oracle restatement (test/TwoBitSequenceTest.cpp's cases are in tests/test_oracle_kat.py), incl. '.', 'X', IUPAC codes, lower
+    case, reads of 0-3 bases and lengths that are not multiples of 4"""
+    import ctypes as C
+    import kmernator_amd as ka
+    from helpers import oracle_lib, ReadBatch
+    rng = np.random.default_rng(23)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtN.XRY", dtype=np.uint8)
+    seqs = [bytes(rng.choice(alphabet, size=int(L)).tobytes()) for L in list(rng.integers(1, 300, 4000)) + [1, 2, 3, 4, 5, 8]]
+    rb = ReadBatch(seqs, [b"I" * len(s) for s in seqs])
+    sp = ka.KmerSpectrum(ka.default_config(21, estimated_raw_kmers=100000, device=0))
+    rs = ka.ReadSet.from_arrays(sp, rb.bases, rb.quals, rb.offsets)
+    tw, to, mp, mc, mo = rs.twobit()
+    lib = oracle_lib()
+    assert int(to[-1]) == tw.size == sum((len(s) + 3) // 4 for s in seqs)
+    for i, s in enumerate(seqs):
+        out = np.zeros((len(s) + 3) // 4 + 1, dtype=np.uint8)
+        pos = np.zeros(len(s) + 1, dtype=np.uint32)
+        ch = C.create_string_buffer(len(s) + 1)
+        nm = lib.orc_compress_sequence(s, len(s), out.ctypes.data_as(C.POINTER(C.c_uint8)), pos.ctypes.data_as(C.POINTER(C.c_uint32)), ch, len(s) + 1)
+        assert np.array_equal(tw[int(to[i]):int(to[i + 1])], out[:(len(s) + 3) // 4]), i
+        assert int(mo[i + 1] - mo[i]) == nm, i
+        assert np.array_equal(mp[int(mo[i]):int(mo[i + 1])], pos[:nm]), i
+        assert mc[int(mo[i]):int(mo[i + 1])].tobytes() == ch.raw[:nm], i
+    assert int(mo[-1]) > 1000
