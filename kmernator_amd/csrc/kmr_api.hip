@@ -857,6 +857,13 @@ template <int W, bool EXT> int add_reads_partition_t(kmr_handle *h, const ReadsV
 		time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
 		rc = launch_extract<W, EXT>(h, rv, op);
 		time_end(h, KMR_TIME_EXTRACT, a2, b2);
+		if (!rc && getenv("KMR_DEBUG_SAME_TILE")) {
+			/* measurement aid (tools/l1_write_side.py): every tile of the level-1 pass reads the records of one of the first N tiles again, i.e. its
+			 * input comes out of L2 and only the scatter writes go to HBM -- what the pass would cost if extract fed it from
+			 * registers.  The result is not a spectrum. */
+			const uint64_t distinct = std::max<uint64_t>(1, strtoull(getenv("KMR_DEBUG_SAME_TILE"), nullptr, 10));
+			hipLaunchKernelGGL(same_tile_kernel, dim3(grid_for(tiles)), dim3(256), 0, h->stream, h->koff, tiles, distinct, total_cap / std::max<uint64_t>(tiles, 1));
+		}
 		if (!rc) rc = partition_level1<W, EXT>(h, h->linear, h->koff, h->tile_count, tiles, 64, 0, 0, total_cap);
 		time_end(h, KMR_TIME_BUILD, a, b);
 		if (rc) return rc;

@@ -216,6 +216,11 @@ void owner_scatter_kernel(const typename PoolRec<W, EXT>::type *linear, const ui
 	}
 }
 
+/* measurement aid: point every tile at the records of one of the first `distinct` tiles (KMR_DEBUG_SAME_TILE = distinct;
+ * equal-length reads only: a tile's region is tile_records long) */
+__global__ void same_tile_kernel(uint64_t *koff, uint64_t n_tiles, uint64_t distinct, uint64_t tile_records) {
+	for (uint64_t t = distinct + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * blockDim.x) koff[t * 64] = (t % distinct) * tile_records;
+}
 /* k-mer capacity of every work unit (a read, or a segment of a long read) */
 __global__ void kmer_capacity_kernel(ReadsView rv, uint32_t k, uint32_t *cap) {
 	const uint64_t n = rv.u_start ? rv.n_units : rv.n_reads;
