@@ -319,7 +319,11 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 	uint32_t *stage_n = xoff + P;                    /* G: records waiting in the list's write-combining line  */
 	uint32_t *stage_plan = stage_n + (G ? P : 0);    /* G: per batch, (records that go out << 8) | waiting before */
 	uint32_t *extra = stage_plan + (G ? P : 0);
-	Rec *stage = (Rec *)(((uintptr_t)(extra + BATCH / CH + P + 8) + 15) & ~(uintptr_t)15);
+	/* 16-byte aligned behind the words above; the alignment is done by pointer arithmetic, not through an integer, so that the
+	 * compiler keeps seeing an LDS pointer (an inttoptr makes it a generic one and every line access a flat_* instruction) */
+	uint8_t *stage_raw = (uint8_t *)(extra + BATCH / CH + P + 8);
+	stage_raw += (16u - ((uint32_t)(uintptr_t)stage_raw & 15u)) & 15u;
+	Rec *stage = (Rec *)stage_raw;
 	__shared__ uint32_t s_item;
 	__shared__ uint32_t s_nextra;
 	constexpr uint32_t SLAB = 64, RING = 128;
