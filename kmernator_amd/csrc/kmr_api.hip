@@ -1145,7 +1145,9 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 	rc = reserve_bytes(h, (void **)&sm.sweight, sm.c_sw, sm.n); if (rc) return rc;
 	if (h->ext) { rc = reserve_bytes(h, (void **)&sm.spkt, sm.c_pkt, 4 * sm.n); if (rc) return rc; }
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * sm.nb, h->stream));
-	if (wm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
+	if (wm.n && vw > 4) hipLaunchKernelGGL((entry_scatter_kernel<W, true>), dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
+	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->kb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
+	else if (wm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
 	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->kb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
 	if (sm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(sslots)), dim3(256), 0, h->stream, (const uint64_t *)h->us_keys, (const uint32_t *)nullptr,
 	                            (const uint8_t *)h->us_b8, (const uint32_t *)h->us_pkt, sslots, 0u, h->kb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, h->ext ? sm.spkt : (uint32_t *)nullptr);

@@ -1111,7 +1111,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
  * from one or two final lists and with the partition cut along the bucket index (part_order) they fall into a
  * handful of neighbouring buckets: lanes with the same bucket share one cursor update (a few rounds of
  * ballot-and-elect) instead of serialising on it; what is left after the rounds takes its own atomic. */
-template <int W>
+template <int W, bool WIDE = false>
 __global__ void entry_scatter_kernel(const uint64_t *ukeys, const uint32_t *uvals, const uint8_t *ub8, const uint32_t *upkt, uint64_t n,
                                      uint32_t vw, uint32_t kb, uint64_t nb, const uint64_t *start, uint32_t *cursor,
                                      uint64_t *keys, uint32_t *vals, uint8_t *b8, uint32_t *pkt) {
@@ -1141,6 +1141,16 @@ __global__ void entry_scatter_kernel(const uint64_t *ukeys, const uint32_t *uval
 			if (mine) { rank = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1)); done = true; }
 		}
 		if (live && !done) rank = atomicAdd(&cursor[b], 1u);
+		if (!WIDE) {
+			if (!live) continue;
+			const uint64_t pos = start[b] + rank;
+#pragma unroll
+			for (int j = 0; j < W; j++) keys[pos * W + j] = key.w[j];
+			if (uvals) for (uint32_t j = 0; j < vw; j++) vals[pos * vw + j] = uvals[e * vw + j];
+			if (ub8) b8[pos] = ub8[e];
+			if (upkt) pkt[pos] = upkt[e];
+			continue;
+		}
 		const uint64_t pos = live ? start[b] + rank : 0;
 		if (live) {
 #pragma unroll
@@ -1148,9 +1158,7 @@ __global__ void entry_scatter_kernel(const uint64_t *ukeys, const uint32_t *uval
 			if (ub8) b8[pos] = ub8[e];
 			if (upkt) pkt[pos] = upkt[e];
 		}
-		if (uvals && vw <= 4) {
-			if (live) for (uint32_t j = 0; j < vw; j++) vals[pos * vw + j] = uvals[e * vw + j];
-		} else if (uvals) {
+		if (uvals) {
 			/* wide values (15 words with extension tallies): a lane copying its own entry word by word touches 64 lines per
 			 * instruction; instead 16 lanes share an entry, four entries per step, so a step reads 4 x 60 contiguous bytes */
 			for (int i0 = 0; i0 < 64; i0 += 4) {
