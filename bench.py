@@ -104,6 +104,11 @@ def main():
                     "over gloo (RCCL refuses two ranks on one device); exercises the N>1 code, its timings mean nothing")
     ap.add_argument("--build-mode", type=int, default=0, help="kmr_config.build_mode: 0 auto (streaming partition), 1 device table")
     args = ap.parse_args()
+    # stdout carries exactly one JSON line: libraries that print there (RCCL writes a version banner when its first communicator
+    # comes up) are pointed at stderr, and the line goes out through the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -250,7 +255,7 @@ def main():
             pass
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(bases, quals, min(args.cpu_sample, n_reads))
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
