@@ -279,6 +279,15 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
 /* Insert n records (any owner mix that belongs to this handle) into the table. */
 int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n_records);
 
+/* Host-buffer forms of the two halves for a host whose exchange is MPI_Alltoallv over host memory (the reference's own,
+ * src/MPIBuffer.h:588-600; include/kmernator_amd_shim.hpp, GpuDistributedKmerSpectrum).  kmr_extract_by_owner_host: the records
+ * of a device-resident batch, owner after owner without gaps; seg_counts[world_size] always receives the counts, and with
+ * records == NULL that is all the call does (the segments wait on the device for the call that fetches them). */
+struct kmr_reads;      /* a device-resident read batch, see "FASTQ ingest" below */
+int kmr_extract_by_owner_host(kmr_handle *h, const struct kmr_reads *batch, uint64_t first_global_read_idx,
+                              uint64_t *seg_counts, void *records, uint64_t capacity_bytes);
+int kmr_insert_records(kmr_handle *h, const void *host_records, uint64_t n_records);
+
 /* ---- f1, distributed form: scoreAndTrimReads when the spectrum is partitioned by owner --------
  * DistributedReadSelector::scoreAndTrimReads / _batchKmerLookup (src/DistributedFunctions.h:876-1045): every k-mer of a
  * rank's reads is looked up at its owner (request = requestId + k-mer, response = requestId + score over
@@ -399,6 +408,15 @@ int kmr_artifact_filter_apply(kmr_handle *h, const kmr_artifact_filter *f, const
 /* Raw HIP stream of the handle (hipStream_t) so callers can order their own
  * work (torch.cuda.ExternalStream) against it. */
 void *kmr_stream(kmr_handle *h);
+
+/* Implementation knobs of one handle; none of them changes a result.  They exist so that tests reach the multi-level,
+ * retry and sub-batch code with small inputs and measurement tools can sweep a parameter; the library reads no
+ * environment variable.  Knobs (value): "target_list_records" (records per final list the partition bits aim for, 2048),
+ * "sub_batch_bases" (bases per extract launch, 0 = default), "recycle_chunks" (-1 auto, 0, 1), "partition_blocks"
+ * (0 = one per CU), "entry_share" (initial entry-buffer share of the count pass, < 0 = from the probe), "lookup_table",
+ * "narrow_tallies", "keep_level1_state" (1 / 0), "superkmer_minimizer" (minimizer length of build_mode 3, 0 = default).  Call before
+ * the first kmr_add_reads* of a build.  KMR_ERR_INVALID_ARG for an unknown knob. */
+int kmr_tune(kmr_handle *h, const char *knob, double value);
 
 /* Timing of the hot path measured with HIP events on the handle's stream
  * (used by bench.py for the roofline object).  Returns the accumulated

@@ -1,29 +1,68 @@
 /*
  * kmernator_amd_shim.hpp -- the reference-side binding a Kmernator maintainer adds.
  *
- * Include AFTER Kmernator's own "KmerSpectrum.h" (it needs ReadSet, KmerSizer, the map
- * types and the option singletons; it is therefore not compiled inside this repository,
- * where Boost and the reference headers are absent -- see INTEGRATION.md).
+ * Include AFTER Kmernator's own "KmerSpectrum.h" (and, for the -P tools, "DistributedFunctions.h"): it needs ReadSet, Read,
+ * KmerSizer, the map types and the option singletons.  Written in the reference's dialect (C++03, no Boost needed by
+ * the shim itself).  The reference's headers cannot be compiled in this repository (Boost 1.53 / sparsehash are absent),
+ * so tests/test_shim_compile.py compiles this header against tests/cpp/mock_kmernator.h -- a mock that DECLARES the handful
+ * of reference names used here with the signatures they have in the reference (each cites its file:line).  That test catches
+ * syntax, access and ownership mistakes; it pins no behaviour of the reference.
  *
- *   typedef KmerSpectrum<DataType, DataType, SingletonDataType> KS;       // apps/FilterReads.h:246
- *   typedef GpuKmerSpectrum<KS> GKS;
- *   GKS spectrum(rawKmers);                                               // apps/FilterReads.cpp:136
- *   spectrum.buildKmerSpectrum(reads);                                    // apps/FilterReads.cpp:139
+ * The whole patch, against the reference as it is:
  *
- * buildKmerSpectrum() flattens the ReadSet into the arrays kmr_add_reads takes, runs the
- * build on the MI355X, and materialises weak (and singleton) as the reference's OWN map
- * objects by KmerMapByKmerArrayPair::restore() (src/Kmer.h:3160-3173) over the images the
- * library writes in the store() layout (src/Kmer.h:3143-3159).  Everything downstream
- * (ReadSelector, histogram, storeMmap) then runs unchanged on the reference types.
+ *   src/KmerSpectrum.h:404     -private:                       (rawKmers ... subtracted, :405-409)
+ *                              +protected:                      so that a derived spectrum can set the counters it computed
+ *   apps/FilterReads.h:246     (after `typedef KmerSpectrum<DataType, DataType, SingletonDataType> KS;`)
+ *                              +#include "kmernator_amd_shim.hpp"
+ *                              +typedef GpuKmerSpectrum<KS> GKS;
+ *   apps/FilterReads.cpp:126   -KS spectrum(0);                 +GKS spectrum(0);            (no device handle yet: it is made by the first build)
+ *   apps/FilterReads.cpp:136   -spectrum = KS(rawKmers);        +spectrum = GKS(rawKmers);   (value semantics: the handle is shared and counted)
+ *   apps/FilterReads.cpp:139   unchanged: buildKmerSpectrumInParts(reads, parts, ...) calls the virtual buildKmerSpectrum(store, isSolid)
+ *                              (src/KmerSpectrum.h:1822), which GpuKmerSpectrum overrides; with --build-partitions > 1 the
+ *                              reference's own loop (:1831-1902) runs and calls the 4-argument non-virtual overload, i.e. the CPU path.
+ *   apps/MeraculousCounter.cpp:126  KS -> GpuDistributedKmerSpectrum<KS> with KMR_VALUE_EXT (maps are ExtensionTrackingData, src/Meraculous.h:79-80)
+ *   apps/FilterReads-P.cpp:110      KS spectrum(world, rawKmers) -> GpuDistributedKmerSpectrum<KS> spectrum(world, rawKmers)
+ *   apps/CMakeLists.txt        target_link_libraries(<tool> kmernator_amd), -I<this repo>/include, -DKMERNATOR_AMD_SHIM_MPI for the -P tools
+ *
+ * buildKmerSpectrum() flattens the ReadSet into the arrays kmr_add_reads takes, runs the build on the MI355X and fills weak
+ * (and singleton) -- the reference's OWN map objects -- from the images the library writes in the store() layout
+ * (src/Kmer.h:3143-3159) through the copying constructor KmerMapByKmerArrayPair(const void *) (src/Kmer.h:3124-3135), exactly
+ * as KmerSpectrum::restoreMmap does (src/KmerSpectrum.h:489-518).  Everything downstream (optimize, trackSpectrum, histogram,
+ * ReadSelector, storeMmap) then runs unchanged on the reference types.
+ *
+ * One process drives ONE device (kmr_config.device).  The reference's unit of distribution is the MPI rank
+ * (apps/FilterReads-P.cpp:263-325), so "N GPUs" is N ranks with one handle each -- GpuDistributedKmerSpectrum below, or
+ * kmr_exchange_* of the C-ABI over RCCL for hosts without MPI; that is why kmr_config has no num_devices.
  */
 #ifndef KMERNATOR_AMD_SHIM_HPP_
 #define KMERNATOR_AMD_SHIM_HPP_
 
 #include <stdexcept>
 #include <string>
+#include <sstream>
 #include <vector>
 
 #include "kmernator_amd.h"
+
+/* counted owner of a kmr_handle: the reference copies and assigns spectra by value (apps/FilterReads.cpp:126,136) */
+class KmrSharedHandle {
+public:
+	KmrSharedHandle() : _p(NULL) {}
+	KmrSharedHandle(const KmrSharedHandle &o) : _p(o._p) { if (_p) _p->refs++; }
+	KmrSharedHandle &operator=(const KmrSharedHandle &o) {
+		if (o._p) o._p->refs++;
+		release();
+		_p = o._p;
+		return *this;
+	}
+	~KmrSharedHandle() { release(); }
+	kmr_handle *get() const { return _p ? _p->h : NULL; }
+	void adopt(kmr_handle *h) { release(); _p = new Box(); _p->h = h; _p->refs = 1; }
+private:
+	struct Box { kmr_handle *h; long refs; };
+	void release() { if (_p && --_p->refs == 0) { kmr_destroy(_p->h); delete _p; } _p = NULL; }
+	Box *_p;
+};
 
 template <typename KS>
 class GpuKmerSpectrum : public KS {
@@ -31,92 +70,43 @@ public:
 	typedef typename KS::WeakMapType WeakMapType;
 	typedef typename KS::SingletonMapType SingletonMapType;
 
-	GpuKmerSpectrum(unsigned long estimatedRawKmers, bool separateSingletons = true, int valueKind = KMR_VALUE_COUNT_DIR)
-	    : KS(estimatedRawKmers, separateSingletons), _h(NULL) {
-		kmr_config c;
-		kmr_config_init(&c);
-		c.k = KmerSizer::getSequenceLength();                                   // src/Kmer.h:115
-		c.num_buckets_weak = this->weak.getNumBuckets();                        // the ctor already sized them
-		c.num_buckets_singleton = this->singleton.getNumBuckets();
-		c.estimated_raw_kmers = estimatedRawKmers;
-		c.value_kind = valueKind;
-		c.min_weight = TrackingData::getMinimumWeight();                        // src/KmerTrackingData.h:377
-		c.min_quality_score = GeneralOptions::getOptions().getMinQuality();     // src/Options.h
-		c.fastq_start_char = Read::FASTQ_START_CHAR;                            // reads are already rescaled to it
-		c.ext_min_quality = ExtensionTracking::getMinQuality();
-		c.separate_singletons = separateSingletons ? 1 : 0;
-		c.kmer_subsample = KS::getKmerSubsample();
-		check(kmr_create(&c, &_h), "kmr_create");
-	}
-	virtual ~GpuKmerSpectrum() { kmr_destroy(_h); }
+	/* KmerSpectrum(estimatedRawKmers, separateSingletons), src/KmerSpectrum.h:414-421.  No device work happens here: the
+	 * reference constructs `KS spectrum(0)` first and assigns the real one later */
+	GpuKmerSpectrum(unsigned long estimatedRawKmers = 0, bool separateSingletons = true, int valueKind = KMR_VALUE_COUNT_DIR, int device = -1)
+	    : KS(estimatedRawKmers, separateSingletons), _estimatedRawKmers(estimatedRawKmers), _separateSingletons(separateSingletons),
+	      _valueKind(valueKind), _device(device), _rank(0), _worldSize(1) {}
+	virtual ~GpuKmerSpectrum() {}
+	/* copy construction and assignment: KS copies its maps (src/KmerSpectrum.h:423-440), the device handle is shared */
 
-	// replaces KmerSpectrum::buildKmerSpectrum(const ReadSet&, bool) (src/KmerSpectrum.h:2085-2115)
+	/* replaces KmerSpectrum::buildKmerSpectrum(const ReadSet &[, bool]) (src/KmerSpectrum.h:2081-2086) */
 	virtual void buildKmerSpectrum(const ReadSet &store) { buildKmerSpectrum(store, false); }
 	virtual void buildKmerSpectrum(const ReadSet &store, bool isSolid) {
-		if (isSolid) { KS::buildKmerSpectrum(store, isSolid); return; }       // solid map: not on this path
-		std::string bases, quals;
-		std::vector<uint64_t> offsets(1, 0);
-		std::vector<uint8_t> discarded;
-		bool anyQuals = false;
-		for (ReadSet::ReadSetSizeType i = 0; i < store.getSize(); i++) {
-			const Read &read = store.getRead(i);
-			discarded.push_back(read.isDiscarded() ? 1 : 0);
-			if (!read.isDiscarded()) {
-				std::string f = read.getFasta();                                    // markups applied: N/X become non-ACGT chars
-				std::string q = read.getQuals();                                    // REF_QUAL string for reads without quals
-				bases += f; quals += q; anyQuals = true;
-			}
-			offsets.push_back(bases.size());
-		}
-		check(kmr_reset(_h), "kmr_reset");
-		check(kmr_add_reads(_h, bases.data(), anyQuals ? quals.data() : NULL, offsets.data(), store.getSize(), 0, discarded.data()), "kmr_add_reads");
+		if (isSolid) { KS::buildKmerSpectrum(store, isSolid); return; }       /* solid map: not on this path */
+		FlatReads fr;
+		flatten(store, fr, true);
+		ensureHandle();
+		check(kmr_reset(_handle.get()), "kmr_reset");
+		check(kmr_add_reads(_handle.get(), fr.bases.data(), fr.anyQuals ? fr.quals.data() : NULL, &fr.offsets[0], store.getSize(), 0,
+		                    fr.discarded.empty() ? NULL : &fr.discarded[0]), "kmr_add_reads");
 		pull(KmerSpectrumOptions::getOptions().getMinDepth());
 	}
 
-	// per-k-mer lookups stay on the restored reference maps; batch form for ReadSelector-style consumers:
+	/* per-k-mer lookups stay on the restored reference maps; batch form for ReadSelector-style consumers */
 	void getCounts(const std::vector<uint8_t> &packedCanonicalKmers, std::vector<uint32_t> &counts) {
-		size_t kb = KmerSizer::getByteSize();
+		const size_t kb = KmerSizer::getByteSize();
 		counts.resize(packedCanonicalKmers.size() / kb);
-		check(kmr_lookup(_h, packedCanonicalKmers.data(), counts.size(), counts.data()), "kmr_lookup");
+		if (counts.empty()) return;
+		requireHandle();
+		check(kmr_lookup(_handle.get(), &packedCanonicalKmers[0], counts.size(), &counts[0]), "kmr_lookup");
 	}
 
-private:
-	// purgeMinDepth + materialise: the images must outlive the maps that alias them (src/KmerSpectrum.h:1817)
-	void pull(unsigned int minDepth) {
-		check(kmr_finalize(_h, minDepth), "kmr_finalize");
-		uint64_t n = 0;
-		check(kmr_image_size(_h, KMR_MAP_WEAK, &n), "kmr_image_size");
-		_weakImage.resize(n);
-		check(kmr_write_image(_h, KMR_MAP_WEAK, _weakImage.data(), n), "kmr_write_image");
-		WeakMapType w = WeakMapType::restore(_weakImage.data());
-		this->weak.swap(w);
-		if (minDepth <= 1 && this->hasSingletons) {
-			check(kmr_image_size(_h, KMR_MAP_SINGLETON, &n), "kmr_image_size");
-			_singletonImage.resize(n);
-			check(kmr_write_image(_h, KMR_MAP_SINGLETON, _singletonImage.data(), n), "kmr_write_image");
-			SingletonMapType s = SingletonMapType::restore(_singletonImage.data());
-			this->singleton.swap(s);
-		} else {
-			this->singleton.clear(false);
-			this->hasSingletons = false;
-		}
-		kmr_stats st;
-		check(kmr_get_stats(_h, &st), "kmr_get_stats");
-		this->rawKmers = st.raw_kmers; this->rawGoodKmers = st.raw_good_kmers;
-		this->uniqueKmers = st.unique_kmers; this->singletonKmers = st.singleton_kmers;
-	}
-	// The artifact filter on the device, in place of FilterKnownOddities::applyFilter(reads) at apps/FilterReads.cpp:110-114:
-	//     spectrum.applyArtifactFilter(reads, FilterKnownOddities::getArtifactFasta() [+ repeat / PhiX tables], cfg);
-	// The screen runs on the GPU; trims, discards and remnant reads are applied to the reference's ReadSet exactly as
-	// Recorder::recordTrim / recordDiscard (src/FilterKnownOddities.h:310-334) and applyFilterToRead :519-528 do.
+	/* The artifact filter on the device, in place of FilterKnownOddities::applyFilter(reads) at apps/FilterReads.cpp:110-114:
+	 *     spectrum.applyArtifactFilter(reads, FilterKnownOddities::getArtifactFasta() [+ repeat / PhiX tables], cfg);
+	 * The screen runs on the GPU; trims, discards and remnant reads are applied to the reference's ReadSet exactly as
+	 * Recorder::recordTrim / recordDiscard (src/FilterKnownOddities.h:310-334) and applyFilterToRead :519-528 do. */
 	unsigned long applyArtifactFilter(ReadSet &reads, const std::string &artifactFasta, const kmr_artifact_config &cfg) {
-		std::string bases, quals;
-		std::vector<uint64_t> offsets(1, 0);
-		for (ReadSet::ReadSetSizeType i = 0; i < reads.getSize(); i++) {
-			const Read &read = reads.getRead(i);
-			bases += read.getFasta(); quals += read.getQuals();
-			offsets.push_back(bases.size());
-		}
+		FlatReads fr;
+		flatten(reads, fr, false);
 		std::vector<int64_t> mate;
 		if (reads.hasPairs()) {
 			mate.assign(reads.getSize(), -1);
@@ -125,32 +115,182 @@ private:
 				if (reads.isValidRead(pair.read1) && reads.isValidRead(pair.read2)) { mate[pair.read1] = pair.read2; mate[pair.read2] = pair.read1; }
 			}
 		}
+		ensureHandle();
+		kmr_handle *h = _handle.get();
 		kmr_reads *batch = NULL; kmr_artifact_filter *filter = NULL;
-		check(kmr_reads_from_host(_h, bases.data(), quals.data(), offsets.data(), reads.getSize(), &batch), "kmr_reads_from_host");
-		int rc = kmr_artifact_filter_create(_h, &cfg, artifactFasta.data(), artifactFasta.size(), &filter);
+		check(kmr_reads_from_host(h, fr.bases.data(), fr.quals.data(), &fr.offsets[0], reads.getSize(), &batch), "kmr_reads_from_host");
+		int rc = kmr_artifact_filter_create(h, &cfg, artifactFasta.data(), artifactFasta.size(), &filter);
 		const size_t n = reads.getSize();
-		std::vector<uint32_t> value(n), minPass(n), maxPass(n), remOff(n), remLen(n); std::vector<uint8_t> action(n);
-		if (rc == KMR_OK) rc = kmr_artifact_filter_apply(_h, filter, batch, mate.empty() ? NULL : mate.data(), value.data(), minPass.data(), maxPass.data(),
-		                                                 action.data(), remOff.data(), remLen.data(), NULL);
+		std::vector<uint32_t> value(n + 1), minPass(n + 1), maxPass(n + 1), remOff(n + 1), remLen(n + 1); std::vector<uint8_t> action(n + 1);
+		if (rc == KMR_OK) rc = kmr_artifact_filter_apply(h, filter, batch, mate.empty() ? NULL : &mate[0], &value[0], &minPass[0], &maxPass[0],
+		                                                 &action[0], &remOff[0], &remLen[0], NULL);
 		kmr_artifact_filter_free(filter); kmr_reads_free(batch);
 		check(rc, "kmr_artifact_filter");
 		unsigned long affected = 0;
 		ReadSet remnants;
 		for (size_t i = 0; i < n; i++) {
 			Read &read = reads.getRead(i);
-			if (remLen[i]) remnants.append(read.getTrimRead(remOff[i], remLen[i], "AFTrim:" + boost::lexical_cast<std::string>(remOff[i]) + "+" + boost::lexical_cast<std::string>(remLen[i]), "-qtrim"));
-			if (action[i] == 1) { read = read.getTrimRead(minPass[i], maxPass[i] - minPass[i], "AFTrim:" + boost::lexical_cast<std::string>(minPass[i]) + "+" + boost::lexical_cast<std::string>(maxPass[i] - minPass[i])); affected++; }
+			if (remLen[i]) remnants.append(read.getTrimRead(remOff[i], remLen[i], trimLabel(remOff[i], remLen[i]), "-qtrim"));
+			if (action[i] == 1) { read = read.getTrimRead(minPass[i], maxPass[i] - minPass[i], trimLabel(minPass[i], maxPass[i] - minPass[i])); affected++; }
 			else if (action[i] == 2) read.discard();
 		}
 		if (remnants.getSize() > 0) reads.append(remnants);
 		return affected;
 	}
 
-	void check(int rc, const char *what) {
-		if (rc != KMR_OK) throw std::runtime_error(std::string(what) + ": " + kmr_last_error(_h));
+	kmr_handle *handle() { return _handle.get(); }
+
+protected:
+	/* for spectra whose constructor takes the communicator first (DistributedKmerSpectrum, src/DistributedFunctions.h:124);
+	 * the tag keeps this template from ever being chosen for a copy */
+	struct WorldTag {};
+	template <typename World>
+	GpuKmerSpectrum(WorldTag, World &world, unsigned long estimatedRawKmers, bool separateSingletons, int valueKind, int device)
+	    : KS(world, estimatedRawKmers, separateSingletons), _estimatedRawKmers(estimatedRawKmers), _separateSingletons(separateSingletons),
+	      _valueKind(valueKind), _device(device), _rank(0), _worldSize(1) {}
+
+	struct FlatReads {
+		std::string bases, quals;
+		std::vector<uint64_t> offsets;
+		std::vector<uint8_t> discarded;
+		bool anyQuals;
+		FlatReads() : offsets(1, 0), anyQuals(false) {}
+	};
+	/* the arrays kmr_add_reads takes: sequence characters with markups applied (N / X), quality characters scaled to
+	 * Read::FASTQ_START_CHAR (REF_QUAL strings for reads without quals), byte offsets per read */
+	static void flatten(const ReadSet &store, FlatReads &fr, bool skipDiscarded) {
+		for (ReadSet::ReadSetSizeType i = 0; i < store.getSize(); i++) {
+			const Read &read = store.getRead(i);
+			const bool dis = read.isDiscarded();
+			if (skipDiscarded) fr.discarded.push_back(dis ? 1 : 0);
+			if (!(skipDiscarded && dis)) { fr.bases += read.getFasta(); fr.quals += read.getQuals(); fr.anyQuals = true; }
+			fr.offsets.push_back(fr.bases.size());
+		}
 	}
-	kmr_handle *_h;
-	std::vector<char> _weakImage, _singletonImage;
+	static std::string trimLabel(uint32_t off, uint32_t len) { std::ostringstream ss; ss << "AFTrim:" << off << "+" << len; return ss.str(); }
+
+	kmr_config makeConfig() {
+		kmr_config c;
+		kmr_config_init(&c);
+		c.k = KmerSizer::getSequenceLength();                                   /* src/Kmer.h:115 */
+		c.num_buckets_weak = this->weak.getNumBuckets();                        /* the KS ctor already sized them */
+		c.num_buckets_singleton = this->singleton.getNumBuckets();
+		c.estimated_raw_kmers = _estimatedRawKmers;
+		c.value_kind = (uint32_t)_valueKind;
+		c.min_weight = TrackingData::getMinimumWeight();                        /* src/KmerTrackingData.h:377 */
+		c.min_quality_score = GeneralOptions::getOptions().getMinQuality();     /* src/Options.h:327 */
+		c.fastq_start_char = Read::FASTQ_START_CHAR;                            /* reads are already rescaled to it */
+		c.ext_min_quality = ExtensionTracking::getMinQuality();                 /* src/KmerTrackingData.h:157-163 */
+		c.separate_singletons = _separateSingletons ? 1 : 0;
+		c.kmer_subsample = (uint32_t)KS::getKmerSubsample();                    /* src/KmerSpectrum.h:461 */
+		c.device = _device;
+		c.rank = (uint32_t)_rank; c.world_size = (uint32_t)_worldSize;
+		return c;
+	}
+	/* the device handle is made by the first build (or by whoever asks for it first) and shared by copies of this object */
+	void ensureHandle() {
+		if (_handle.get()) return;
+		kmr_config c = makeConfig();
+		kmr_handle *h = NULL;
+		const int rc = kmr_create(&c, &h);
+		if (rc != KMR_OK) throw std::runtime_error(std::string("kmr_create: ") + kmr_last_error(NULL));
+		_handle.adopt(h);
+	}
+	void requireHandle() { if (!_handle.get()) throw std::runtime_error("GpuKmerSpectrum: no spectrum has been built on the device yet"); }
+
+	/* purgeMinDepth + materialise.  The maps copy out of the images (KmerMapByKmerArrayPair(const void *), src/Kmer.h:3124),
+	 * so the image buffers die here. */
+	void pull(unsigned int minDepth) {
+		kmr_handle *h = _handle.get();
+		check(kmr_finalize(h, minDepth), "kmr_finalize");
+		std::vector<char> image;
+		uint64_t n = 0;
+		check(kmr_image_size(h, KMR_MAP_WEAK, &n), "kmr_image_size");
+		image.resize(n);
+		check(kmr_write_image(h, KMR_MAP_WEAK, &image[0], n), "kmr_write_image");
+		{ WeakMapType tmp(&image[0]); this->weak.swap(tmp); }
+		if (minDepth <= 1 && this->hasSingletons) {
+			check(kmr_image_size(h, KMR_MAP_SINGLETON, &n), "kmr_image_size");
+			image.resize(n);
+			check(kmr_write_image(h, KMR_MAP_SINGLETON, &image[0], n), "kmr_write_image");
+			SingletonMapType tmp(&image[0]); this->singleton.swap(tmp);
+		} else {
+			this->singleton.clear(false);         /* purgeMinDepth, src/KmerSpectrum.h:1805-1815 */
+			this->hasSingletons = false;
+		}
+		kmr_stats st;
+		check(kmr_get_stats(h, &st), "kmr_get_stats");
+		/* private in the reference (src/KmerSpectrum.h:404-409): the patch at the top of this file makes them protected */
+		this->rawKmers = (long)st.raw_kmers; this->rawGoodKmers = (long)st.raw_good_kmers;
+		this->uniqueKmers = (long)st.unique_kmers; this->singletonKmers = (long)st.singleton_kmers;
+	}
+
+	void check(int rc, const char *what) {
+		if (rc != KMR_OK) throw std::runtime_error(std::string(what) + ": " + kmr_last_error(_handle.get()));
+	}
+
+	KmrSharedHandle _handle;
+	unsigned long _estimatedRawKmers;
+	bool _separateSingletons;
+	int _valueKind, _device, _rank, _worldSize;
 };
+
+#ifdef KMERNATOR_AMD_SHIM_MPI
+#include <mpi.h>
+/*
+ * The -P tools: DKS = DistributedKmerSpectrum<...> or MeraculousDistributedKmerSpectrum (src/DistributedFunctions.h:100-131,
+ * src/Meraculous.h:82-105), one MPI rank per GPU.  buildKmerSpectrum(store) replaces _buildKmerSpectrumMPI
+ * (src/DistributedFunctions.h:340-458): the rank's reads -> owner segments on the device (kmr_extract_by_owner_dev) ->
+ * MPI_Alltoall of the counts, MPI_Alltoallv of the records (as src/MPIBuffer.h:588-600, but KMR_RECORD_BYTES per k-mer instead of
+ * 24 + kb) -> kmr_insert_records_dev at the owner, then the post-steps of buildKmerSpectrum (:560-569).  The owner of a k-mer is
+ * getDistributedThreadId (src/Kmer.h:2284-2295), unchanged.  Hosts without MPI use kmr_exchange_* (RCCL over xGMI) instead.
+ */
+template <typename DKS>
+class GpuDistributedKmerSpectrum : public GpuKmerSpectrum<DKS> {
+public:
+	typedef GpuKmerSpectrum<DKS> Base;
+	/* DistributedKmerSpectrum(mpi::communicator &, estimatedRawKmers, separateSingletons), src/DistributedFunctions.h:124-131
+	 * (mpi = boost::mpi there; the communicator converts to MPI_Comm) */
+	GpuDistributedKmerSpectrum(mpi::communicator &world, unsigned long estimatedRawKmers = 0, bool separateSingletons = true, int valueKind = KMR_VALUE_COUNT_DIR, int device = -1)
+	    : Base(typename Base::WorldTag(), world, estimatedRawKmers, separateSingletons, valueKind, device), _comm((MPI_Comm)world) {
+		MPI_Comm_rank(_comm, &this->_rank); MPI_Comm_size(_comm, &this->_worldSize);
+		this->_estimatedRawKmers = estimatedRawKmers * (unsigned long)this->_worldSize;      /* kmr_config takes the whole job's figure */
+	}
+	virtual void buildKmerSpectrum(const ReadSet &store) { buildKmerSpectrum(store, false); }
+	virtual void buildKmerSpectrum(const ReadSet &store, bool isSolid) {
+		if (isSolid) throw std::runtime_error("GpuDistributedKmerSpectrum: the solid map is not built on this path");
+		typename Base::FlatReads fr;
+		Base::flatten(store, fr, true);
+		this->ensureHandle();
+		kmr_handle *h = this->handle();
+		const int R = this->_worldSize;
+		this->check(kmr_reset(h), "kmr_reset");
+		kmr_reads *batch = NULL;
+		this->check(kmr_reads_from_host(h, fr.bases.data(), fr.anyQuals ? fr.quals.data() : NULL, &fr.offsets[0], store.getSize(), &batch), "kmr_reads_from_host");
+		uint64_t nReads = 0, totalBases = 0;
+		kmr_reads_info(batch, &nReads, &totalBases, NULL, NULL);
+		const uint32_t recBytes = KMR_RECORD_BYTES(KmerSizer::getSequenceLength(), (uint32_t)this->_valueKind);
+		std::vector<char> sendBuf, recvBuf;
+		std::vector<uint64_t> segCounts(R, 0);
+		int rc = kmr_extract_by_owner_host(h, batch, store.getGlobalOffset(this->_rank), &segCounts[0], NULL, 0);      /* sizes first */
+		uint64_t total = 0; for (int r = 0; r < R; r++) total += segCounts[r];
+		sendBuf.resize((size_t)total * recBytes + 1);
+		if (rc == KMR_OK) rc = kmr_extract_by_owner_host(h, batch, store.getGlobalOffset(this->_rank), &segCounts[0], &sendBuf[0], sendBuf.size());
+		kmr_reads_free(batch);
+		this->check(rc, "kmr_extract_by_owner_host");
+		std::vector<int> sc(R), sd(R), rcnt(R), rd(R);
+		std::vector<uint64_t> recvCounts(R, 0);
+		MPI_Alltoall(&segCounts[0], 1, MPI_UINT64_T, &recvCounts[0], 1, MPI_UINT64_T, _comm);
+		uint64_t so = 0, ro = 0;
+		for (int r = 0; r < R; r++) { sc[r] = (int)(segCounts[r] * recBytes); sd[r] = (int)so; so += sc[r]; rcnt[r] = (int)(recvCounts[r] * recBytes); rd[r] = (int)ro; ro += rcnt[r]; }
+		recvBuf.resize((size_t)ro + 1);
+		MPI_Alltoallv(&sendBuf[0], &sc[0], &sd[0], MPI_BYTE, &recvBuf[0], &rcnt[0], &rd[0], MPI_BYTE, _comm);
+		this->check(kmr_insert_records(h, &recvBuf[0], ro / recBytes), "kmr_insert_records");
+		this->pull(KmerSpectrumOptions::getOptions().getMinDepth());
+	}
+private:
+	MPI_Comm _comm;
+};
+#endif /* KMERNATOR_AMD_SHIM_MPI */
 
 #endif

@@ -53,8 +53,20 @@ struct HostPool {                    /* owner of one chunk pool */
 
 }  // namespace
 
+/* per-handle knobs of kmr_tune(): sizes the tests shrink to reach the multi-level / retry / sub-batch code with small inputs, and
+ * switches the measurement tools flip.  None of them changes a result. */
+struct Tuning {
+	uint64_t target_list = 2048;      /* records per final list the partition bits aim for */
+	uint64_t sub_batch_bases = 0;     /* 0 = SUB_BATCH_BASES */
+	int recycle = -1;                 /* -1 auto, 0 fresh chunks, 1 recycle the chunks a pass has just read */
+	int part_blocks = 0;              /* 0 = one partition block per CU */
+	double entry_share = -1.0;        /* >= 0: initial size of the count pass's entry buffers as a share of the records */
+	bool no_lut = false, no_narrow = false, no_l1_state = false;
+};
+
 struct kmr_handle {
 	kmr_config cfg;
+	Tuning tune;
 	uint32_t k = 0, kb = 0, W = 0;
 	bool ext = false;
 	int device = 0, ncu = 0;
@@ -78,6 +90,7 @@ struct kmr_handle {
 	kmr_stats stats;
 	/* streaming (partition) build path */
 	bool partition_mode = false;
+	bool superkmer_mode = false;       /* build_mode 3: super-k-mer lists (kmr_superkmer.hpp); implies partition_mode */
 	HostPool l1;                       /* the record pool of every partition level */
 	int bits1 = 0;
 	uint64_t inserted_records = 0;     /* records fed through kmr_insert_records_dev (counted on the host) */
@@ -97,6 +110,8 @@ struct kmr_handle {
 	uint32_t *ucnt = nullptr; uint64_t *ufirst = nullptr, *u_start = nullptr, *u_end = nullptr, *u_read = nullptr;
 	uint64_t ucnt_n = 0, ufirst_n = 0, units_n = 0; unsigned int *umax = nullptr;
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr, *us_pkt = nullptr; uint64_t uw_cap = 0, us_cap = 0;
+	/* kmr_extract_by_owner_host: owner segments of one batch kept on the device between the sizing call and the copy-out */
+	void *xo_dev = nullptr; uint64_t xo_segcap = 0; std::vector<uint64_t> xo_counts; const void *xo_batch = nullptr; uint64_t xo_first = 0;
 	/* timing */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	double ms[KMR_TIME_GROUPS] = {0};
@@ -119,6 +134,14 @@ namespace {
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
 	(h)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
 	return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+
+/* diagnostics on stderr and the measurement-only hooks exist in a -DKMR_DEBUG_HOOKS build alone: the shipped library reads no
+ * environment variable */
+#ifdef KMR_DEBUG_HOOKS
+bool dbg() { static const bool d = getenv("KMR_DEBUG") != nullptr; return d; }
+#else
+constexpr bool dbg() { return false; }
+#endif
 
 int fail(kmr_handle *h, int code, const std::string &msg) { if (h) h->err = msg; else g_create_error = msg; return code; }
 
@@ -293,7 +316,7 @@ template <int W, bool EXT, class Op> int launch_extract(kmr_handle *h, const Rea
 	const bool sub = Op::NEEDS_WEIGHT && (dp.sub_wnb | dp.sub_snb) != 0;      /* lookups ignore the subtracting reference */
 	auto kern = sub ? extract_kernel<W, EXT, Op, true> : extract_kernel<W, EXT, Op, false>;
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXTRACT_SMEM));
-	if (getenv("KMR_DEBUG")) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, WAVES_PER_BLOCK * 64, EXTRACT_SMEM); fprintf(stderr, "extract: %d blocks of %d waves per CU (dynamic LDS %zu)\n", nb, WAVES_PER_BLOCK, EXTRACT_SMEM);
+	if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, WAVES_PER_BLOCK * 64, EXTRACT_SMEM); fprintf(stderr, "extract: %d blocks of %d waves per CU (dynamic LDS %zu)\n", nb, WAVES_PER_BLOCK, EXTRACT_SMEM);
 		for (size_t tr : {(size_t)79872, (size_t)65536, (size_t)52000, (size_t)38000}) { hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, WAVES_PER_BLOCK * 64, tr); fprintf(stderr, "   with %zu bytes: %d blocks\n", tr, nb); } }
 	const uint64_t tiles = ((rv.u_start ? rv.n_units : rv.n_reads) + 63) / 64;
 	uint64_t blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -573,7 +596,7 @@ template <int W> int lookup_t(kmr_handle *h, const uint8_t *packed, uint64_t n, 
  * be had (no memory): the callers then search the buckets */
 template <int W> LutView<W> lut_of(kmr_handle *h) {
 	LutView<W> v; v.slots = nullptr; v.mask = 0; v.shift = 0;
-	if (getenv("KMR_NO_LUT") || !h->weak.present || h->weak.n == 0) return v;
+	if (h->tune.no_lut || !h->weak.present || h->weak.n == 0) return v;
 	if (!(h->lut && h->lut_gen == h->map_gen)) {
 		uint32_t l2 = 10; while ((1ull << l2) < 2 * h->weak.n) l2++;
 		const size_t bytes = (size_t)(W + 1) * 8 << l2;
@@ -619,8 +642,7 @@ int stage_reads(kmr_handle *h, const char *bases, const char *quals, const uint6
 /* ---------------------------------------------------------------------- */
 /* streaming build path (kmr_partition.hpp)                                  */
 const int COUNT_LOG2S = 10;                  /* 1024-slot LDS table per final list (expected ~350 distinct keys) */
-static uint64_t target_list_records() { const char *e = getenv("KMR_TARGET_LIST"); return e ? strtoull(e, nullptr, 10) : 2048; }   /* records per final list the partition bits aim for */
-#define TARGET_LIST_RECORDS (target_list_records())
+#define TARGET_LIST_RECORDS (h->tune.target_list)      /* records per final list the partition bits aim for (kmr_tune "target_list_records") */
 const double MAX_LIST_DISTINCT = 600.0;       /* distinct keys per final list the 1024-slot table takes comfortably (limit 819) */
 const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
 const uint64_t SUB_BATCH_BASES = 1ull << 30;      /* linear records of one sub-batch: <= 17 GB at 16 bytes; 2^28 cost 2 ms per C2 step in launch tails */
@@ -637,7 +659,7 @@ uint32_t part_rot(kmr_handle *h) { uint32_t r = 0; while ((1ull << (r + 1)) <= h
 template <int W, bool EXT, int LEVEL> int launch_partition(kmr_handle *h, const PartSource<W> &S, HostPool &pool, int grid, int bits, int shift) {
 	auto kern = partition_direct_kernel<W, EXT, LEVEL, PD_THREADS, PD_RPT, PD_LINE>;
 	const size_t smem = partition_direct_smem_bytes<W, EXT, PD_THREADS, PD_RPT, PD_LINE>(bits);
-	if (getenv("KMR_DEBUG")) fprintf(stderr, "partition level %d W=%d bits=%d shift=%d smem=%zu grid=%d\n", LEVEL, W, bits, shift, smem, grid);
+	if (dbg()) fprintf(stderr, "partition level %d W=%d bits=%d shift=%d smem=%zu grid=%d\n", LEVEL, W, bits, shift, smem, grid);
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
 	                              (int)partition_direct_smem_bytes<W, EXT, PD_THREADS, PD_RPT, PD_LINE>(max_part_bits(h))));
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), smem, h->stream, S, pool_view(h, pool), h->work_counter, bits, shift);
@@ -708,7 +730,7 @@ int num_cus(kmr_handle *h) {
 int part_grid(kmr_handle *h) { return num_cus(h) * 2; }
 /* the partition kernel wants a compute unit to itself: every (block, list) pair is a write stream, and the fewer of
  * those there are the longer the runs each batch appends */
-int partition_blocks(kmr_handle *h) { return getenv("KMR_PART_BLOCKS") ? atoi(getenv("KMR_PART_BLOCKS")) : num_cus(h); }
+int partition_blocks(kmr_handle *h) { return h->tune.part_blocks > 0 ? h->tune.part_blocks : num_cus(h); }
 
 /* per-block level-1 state, allocated (and emptied) on first use */
 template <int W, bool EXT> int ensure_l1_state(kmr_handle *h) {
@@ -768,8 +790,7 @@ template <int W, bool EXT> int partition_level1(kmr_handle *h, const void *linea
 	PartSource<W> S; memset(&S, 0, sizeof(S));
 	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
 	S.valid_counter = valid_counter; S.kb = h->kb; S.rot = part_rot(h); S.packed_words = packed_words; S.ordinal_base = ordinal_base;
-	static const bool keep_state = !getenv("KMR_NO_L1_STATE");
-	if (keep_state) {
+	if (!h->tune.no_l1_state) {
 		rc = ensure_l1_state<W, EXT>(h); if (rc) return rc;
 		S.state = h->l1_state; S.state_final = 0; h->l1_state_dirty = true;
 	}
@@ -831,7 +852,7 @@ template <int W, bool EXT> int add_reads_partition_t(kmr_handle *h, const ReadsV
 	const uint64_t n = rvAll.n_reads;
 	if (!h->l1.head) choose_bits1(h, total_bases);
 	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
-	const uint64_t sub_bases = getenv("KMR_SUB_BATCH_BASES") ? strtoull(getenv("KMR_SUB_BATCH_BASES"), nullptr, 10) : SUB_BATCH_BASES;
+	const uint64_t sub_bases = h->tune.sub_batch_bases ? h->tune.sub_batch_bases : SUB_BATCH_BASES;
 	const uint64_t chunk = std::max<uint64_t>(64, (sub_bases / avg) & ~63ull);
 	for (uint64_t r = 0; r < n; r += chunk) {
 		const uint64_t m = std::min(chunk, n - r);
@@ -857,6 +878,7 @@ template <int W, bool EXT> int add_reads_partition_t(kmr_handle *h, const ReadsV
 		time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
 		rc = launch_extract<W, EXT>(h, rv, op);
 		time_end(h, KMR_TIME_EXTRACT, a2, b2);
+#ifdef KMR_DEBUG_HOOKS
 		if (!rc && getenv("KMR_DEBUG_SAME_TILE")) {
 			/* measurement aid (tools/l1_write_side.py): every tile of the level-1 pass reads the records of one of the first N tiles again, i.e. its
 			 * input comes out of L2 and only the scatter writes go to HBM -- what the pass would cost if extract fed it from
@@ -864,6 +886,7 @@ template <int W, bool EXT> int add_reads_partition_t(kmr_handle *h, const ReadsV
 			const uint64_t distinct = std::max<uint64_t>(1, strtoull(getenv("KMR_DEBUG_SAME_TILE"), nullptr, 10));
 			hipLaunchKernelGGL(same_tile_kernel, dim3(grid_for(tiles)), dim3(256), 0, h->stream, h->koff, tiles, distinct, total_cap / std::max<uint64_t>(tiles, 1));
 		}
+#endif
 		if (!rc) rc = partition_level1<W, EXT>(h, h->linear, h->koff, h->tile_count, tiles, 64, 0, 0, total_cap);
 		time_end(h, KMR_TIME_BUILD, a, b);
 		if (rc) return rc;
@@ -894,7 +917,7 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint32_t first, uint64_t 
 	if (used) hipLaunchKernelGGL(chunk_scatter_kernel, dim3(csr_grid), dim3(CSR_THREADS), 0, h->stream, p.chunk_list + first, p.chunk_count + first, used, first, *list_start, cnt, *list_chunks, (uint32_t)nl);
 	HIPCHK(h, hipGetLastError());
 	*n_chunks_out = used;
-	if (getenv("KMR_DEBUG")) {
+	if (dbg()) {
 		unsigned long long *d, hv[2] = {0, 0};
 		HIPCHK(h, hipMalloc((void **)&d, 16)); HIPCHK(h, hipMemset(d, 0, 16));
 		if (used) hipLaunchKernelGGL(pool_records_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, p.chunk_count, used, d, d + 1);
@@ -952,7 +975,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipMemcpyAsync(hpr, dpr, 32, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
 		if (hpr[0] >= 256) { distinct_share = std::min(1.0, std::max(0.01, (double)hpr[1] / (double)hpr[0])); repeated_share = std::min(0.5, (double)hpr[2] / (double)hpr[0]); }
-		if (getenv("KMR_DEBUG")) fprintf(stderr, "distinct probe: %llu records, %llu distinct (%llu repeated) -> shares %.3f %.3f\n", hpr[0], hpr[1], hpr[2], distinct_share, repeated_share);
+		if (dbg()) fprintf(stderr, "distinct probe: %llu records, %llu distinct (%llu repeated) -> shares %.3f %.3f\n", hpr[0], hpr[1], hpr[2], distinct_share, repeated_share);
 	}
 	const int mb = max_part_bits(h);
 	int T = 0; while (T < 40 && ((G >> T) > TARGET_LIST_RECORDS || (double)(G >> T) * distinct_share > MAX_LIST_DISTINCT)) T++;
@@ -980,7 +1003,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 		const uint64_t partials = ib.size() * (1ull << nbits) + (uint64_t)part_grid(h) * 512 + 64;
 		unsigned int head_before = 0;
 		HIPCHK(h, hipMemcpy(&head_before, h->l1.head, 4, hipMemcpyDeviceToHost));
-		const bool recycle = getenv("KMR_RECYCLE") ? atoi(getenv("KMR_RECYCLE")) != 0 : (uint64_t)head_before + G / CH + partials + 64 > h->l1.cap;
+		const bool recycle = h->tune.recycle >= 0 ? h->tune.recycle != 0 : (uint64_t)head_before + G / CH + partials + 64 > h->l1.cap;
 		h->l1.used_ub = head_before;
 		rc = pool_reserve(h, h->l1, (recycle ? 0 : G / CH) + partials, true); if (rc) return rc;
 		uint64_t *dib, *die; uint32_t *dil;
@@ -992,7 +1015,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 		S.src = pool_view(h, h->l1); S.list_chunks = lc2; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size(); S.kb = h->kb; S.rot = part_rot(h);
 		S.recycle = recycle ? 1 : 0;
 		const int grid = (int)std::min<uint64_t>(partition_blocks(h), ib.size());
-		if (getenv("KMR_DEBUG")) fprintf(stderr, "level %d: %d bits after %d, %zu items, %s\n", level, nbits, cur_bits, ib.size(), recycle ? "recycling chunks" : "fresh chunks");
+		if (dbg()) fprintf(stderr, "level %d: %d bits after %d, %zu items, %s\n", level, nbits, cur_bits, ib.size(), recycle ? "recycling chunks" : "fresh chunks");
 		hipEvent_t ta, tb; time_begin(h, KMR_TIME_PARTITION2, &ta, &tb);
 		rc = launch_partition<W, EXT, 2>(h, S, h->l1, grid, nbits, cur_bits);
 		time_end(h, KMR_TIME_PARTITION2, ta, tb);
@@ -1006,17 +1029,20 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 	}
 	const uint64_t nl2 = 1ull << cur_bits;
 	const int count_log2s = (!EXT && (double)(G >> cur_bits) * distinct_share > MAX_LIST_DISTINCT) ? 11 : COUNT_LOG2S;      /* with extension tallies 2048 slots do not fit LDS */
-	if (getenv("KMR_DEBUG")) fprintf(stderr, "count pass: %llu lists of ~%llu records, table 2^%d\n", (unsigned long long)nl2, (unsigned long long)(G >> cur_bits), count_log2s);
+	if (dbg()) fprintf(stderr, "count pass: %llu lists of ~%llu records, table 2^%d\n", (unsigned long long)nl2, (unsigned long long)(G >> cur_bits), count_log2s);
 	const uint32_t vw = EXT ? 15 : 3;
 	const uint64_t slack = (uint64_t)part_grid(h) * 8 * 8192 + 16;     /* one partly used output slab per block */
 	/* entry buffers: the worst case (every second record a weak entry, or every record a singleton) is 5-10 x what
 	 * sequencing data produces, and at C4 size it is 70 GB; they are sized from the probe's shares with 50 % headroom and
 	 * the count pass is simply run again with larger ones if that was not enough */
-	const uint64_t wmax = (f.has_singletons ? G / 2 : G) + slack, smax = keepSing ? G + slack : 16;
+	/* upper bounds of the kept entries; the count pass retires an output slab that cannot take a list's entries whole, so up to
+	 * (entries of one list - 1) of every 8192-slot slab stay unused: an eighth on top */
+	const uint64_t wbound = f.has_singletons ? G / 2 : G, sbound = keepSing ? G : 0;
+	const uint64_t wmax = wbound + wbound / 8 + slack, smax = keepSing ? sbound + sbound / 8 + slack : 16;
 	uint64_t wcap = std::min<uint64_t>(wmax, (uint64_t)((double)G * (f.has_singletons ? repeated_share : distinct_share) * 1.5) + G / 64 + slack);
 	uint64_t scap = keepSing ? std::min<uint64_t>(smax, (uint64_t)((double)G * std::max(0.0, distinct_share - repeated_share) * 1.5) + G / 64 + slack) : 16;
-	if (getenv("KMR_ENTRY_SHARE")) {       /* test hook: start from a hopeless estimate so that the retry below has to run */
-		const double sh = atof(getenv("KMR_ENTRY_SHARE"));
+	if (h->tune.entry_share >= 0) {       /* kmr_tune "entry_share": start from a given (e.g. hopeless) estimate so that the retry below has to run */
+		const double sh = h->tune.entry_share;
 		wcap = std::min<uint64_t>(wmax, (uint64_t)((double)G * sh) + 16384); if (keepSing) scap = std::min<uint64_t>(smax, (uint64_t)((double)G * sh) + 16384);
 		if (h->uw_keys) { hipFree(h->uw_keys); hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0; }
 		if (h->us_keys) { hipFree(h->us_keys); hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0; }
@@ -1051,7 +1077,11 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 	out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = (uint32_t *)h->us_pkt; out.scursor = cursors + 1; out.scap = h->us_cap;
 	out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
 	rc = zero_work_counter(h); if (rc) return rc;
+	#ifdef KMR_DEBUG_HOOKS
 	const int count_reps = getenv("KMR_COUNT_CHECK") ? atoi(getenv("KMR_COUNT_CHECK")) : 0;
+#else
+	const int count_reps = 0;
+#endif
 	for (int cr = 0; cr <= count_reps; cr++) {
 		if (cr) {      /* debugging aid: the count pass is repeated on the same input and must report the same numbers */
 			FinalizeCounters c0; unsigned long long cur0[2];
@@ -1069,7 +1099,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 			const size_t smem = count_smem_bytes<W, EXT, 11>();
 			HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 			hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls2, lc2, nl2, out, f, h->work_counter, 0);
-		} else if (EXT && W == 1 && !getenv("KMR_NO_NARROW")) {
+		} else if (EXT && W == 1 && !h->tune.no_narrow) {
 			/* extension values at k <= 32: 16-bit tallies for every list of at most 65 535 records (two blocks per CU), then
 			 * the wide table for whatever is longer */
 			auto kn = count_kernel<W, EXT, COUNT_LOG2S, true>;
@@ -1107,9 +1137,15 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 	cerr &= ~(uint32_t)ERR_ENTRIES_FULL;
 	HIPCHK(h, hipMemcpy(h->derr, &cerr, 4, hipMemcpyHostToDevice));
 	wcap = std::min<uint64_t>(wmax, wcap * 2); if (keepSing) scap = std::min<uint64_t>(smax, scap * 2);
-	if (getenv("KMR_DEBUG")) fprintf(stderr, "count pass: entry buffers too small, retrying with %llu / %llu\n", (unsigned long long)wcap, (unsigned long long)scap);
+	if (dbg()) fprintf(stderr, "count pass: entry buffers too small, retrying with %llu / %llu\n", (unsigned long long)wcap, (unsigned long long)scap);
 	}
 	time_end(h, KMR_TIME_COUNT, tca, tcb);
+	{	/* still full with the buffers at their bounds (or after the last retry): the cursors point past the buffers, nothing
+		 * downstream may use them */
+		uint32_t cerr2 = 0;
+		HIPCHK(h, hipMemcpy(&cerr2, h->derr, 4, hipMemcpyDeviceToHost));
+		if (cerr2 & ERR_ENTRIES_FULL) { time_end(h, 1, ea, eb); return fail(h, KMR_ERR_CAPACITY, "entry buffers of the count pass overflowed at their upper bound (internal sizing error)"); }
+	}
 
 	h->stats.unique_kmers = c.unique;
 	h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
@@ -1284,6 +1320,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->scan_sums) hipFree(h->scan_sums);
 	if (h->score_buf) hipFree(h->score_buf);
 	if (h->lut) hipFree(h->lut);
+	if (h->xo_dev) hipFree(h->xo_dev);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -1337,6 +1374,22 @@ int kmr_release_table(kmr_handle *h) {
 
 void *kmr_stream(kmr_handle *h) { return h ? (void *)h->stream : nullptr; }
 
+/* knobs of one handle (see struct Tuning); set before the first kmr_add_reads* of a build */
+int kmr_tune(kmr_handle *h, const char *knob, double value) {
+	if (!h || !knob) return KMR_ERR_INVALID_ARG;
+	const std::string k(knob);
+	if (k == "target_list_records") h->tune.target_list = value >= 1 ? (uint64_t)value : 2048;
+	else if (k == "sub_batch_bases") h->tune.sub_batch_bases = value >= 1 ? (uint64_t)value : 0;
+	else if (k == "recycle_chunks") h->tune.recycle = value < 0 ? -1 : (value != 0 ? 1 : 0);
+	else if (k == "partition_blocks") h->tune.part_blocks = value >= 1 ? (int)value : 0;
+	else if (k == "entry_share") h->tune.entry_share = value;
+	else if (k == "lookup_table") h->tune.no_lut = value == 0;
+	else if (k == "narrow_tallies") h->tune.no_narrow = value == 0;
+	else if (k == "keep_level1_state") h->tune.no_l1_state = value == 0;
+	else return fail(h, KMR_ERR_INVALID_ARG, "unknown tuning knob '" + k + "'");
+	return KMR_OK;
+}
+
 int kmr_sync(kmr_handle *h) { if (!h) return KMR_ERR_INVALID_ARG; hipSetDevice(h->device); return sync_state(h); }
 
 int kmr_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals, const void *dev_offsets, uint64_t n_reads,
@@ -1349,6 +1402,11 @@ int kmr_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_qual
 	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
 	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
 	rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
+	/* the stream ordinal of an occurrence decides which sighting of a k-mer was its first (directionBias, the quantised first
+	 * weight): 40 bits in the table slots, and the 16-byte records of build_mode 2 without extension values carry 32 of them */
+	if (h->stream_base + total_bases > MAX_STREAM_ORDINAL) return fail(h, KMR_ERR_CAPACITY, "more than 2^40 input bases on one handle");
+	if (h->partition_mode && !h->superkmer_mode && !h->ext && h->stream_base + total_bases > (1ull << 32))
+		return fail(h, KMR_ERR_CAPACITY, "build_mode 2 orders occurrences by a 32-bit stream ordinal: at most 2^32 input bases per handle without extension values (use build_mode 0 / 3 or 1)");
 	int rc = h->partition_mode ? add_reads_partition(h, rv, total_bases) : add_reads_dev_any(h, rv, total_bases);
 	h->stream_base += total_bases; h->reads += n_reads; h->stats.reads = h->reads;
 	return rc;
@@ -2266,6 +2324,67 @@ int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n) {
 	HIPCHK(h, hipGetLastError());
 	h->stream_base += n;
 	return KMR_OK;
+}
+
+/* Host-buffer forms of the two halves, for a host whose exchange is MPI_Alltoallv over host memory (the shim's
+ * GpuDistributedKmerSpectrum): records of a device-resident batch binned by owner and copied out owner after owner, and records
+ * received from the other ranks staged in and inserted. */
+int kmr_extract_by_owner_host(kmr_handle *h, const kmr_reads *batch, uint64_t first_global_read_idx, uint64_t *seg_counts, void *records, uint64_t capacity_bytes) {
+	if (!h || !batch || !seg_counts) return KMR_ERR_INVALID_ARG;
+	if (batch->device != h->device) return fail(h, KMR_ERR_INVALID_ARG, "read batch lives on another device");
+	hipSetDevice(h->device);
+	const uint32_t world = h->cfg.world_size, rb = KMR_RECORD_BYTES(h->k, h->cfg.value_kind);
+	if (!(h->xo_dev && h->xo_batch == (const void *)batch && h->xo_first == first_global_read_idx)) {
+		if (h->xo_dev) { hipFree(h->xo_dev); h->xo_dev = nullptr; }
+		h->xo_counts.assign(world, 0); h->xo_batch = nullptr;
+		unsigned long long *dcounts = nullptr;
+		HIPCHK(h, hipMalloc((void **)&dcounts, 8 * world));
+		const uint64_t upper = batch->total + 64;          /* k-mers <= bases */
+		uint64_t segcap = std::min<uint64_t>(upper, upper / world + upper / (4 * world) + 4096);
+		const uint64_t sb = h->stream_base, rd = h->reads;
+		for (;;) {
+			if (hipMalloc(&h->xo_dev, (size_t)world * segcap * rb) != hipSuccess) { hipFree(dcounts); h->xo_dev = nullptr; return fail(h, KMR_ERR_OOM, "owner segments"); }
+			h->stream_base = sb; h->reads = rd;             /* a repeated attempt stamps the same ordinals */
+			int rc = kmr_extract_by_owner_dev(h, batch->bases, batch->quals, batch->offsets, batch->n, batch->total, first_global_read_idx, nullptr, h->xo_dev, segcap, dcounts);
+			if (!rc) rc = sync_state(h);
+			if (rc == KMR_ERR_CAPACITY && segcap < upper) {      /* a skewed batch: one owner takes more than its share */
+				uint32_t e = 0; hipMemcpy(&e, h->derr, 4, hipMemcpyDeviceToHost); e &= ~(uint32_t)ERR_SEGMENT_OVERFLOW; hipMemcpy(h->derr, &e, 4, hipMemcpyHostToDevice);
+				hipFree(h->xo_dev); h->xo_dev = nullptr;
+				segcap = std::min<uint64_t>(upper, segcap * 2);
+				continue;
+			}
+			if (rc) { hipFree(dcounts); hipFree(h->xo_dev); h->xo_dev = nullptr; return rc; }
+			break;
+		}
+		hipError_t e = hipMemcpy(h->xo_counts.data(), dcounts, 8 * world, hipMemcpyDeviceToHost);
+		hipFree(dcounts);
+		HIPCHK(h, e);
+		h->xo_segcap = segcap; h->xo_batch = batch; h->xo_first = first_global_read_idx;
+	}
+	uint64_t total = 0;
+	for (uint32_t r = 0; r < world; r++) { seg_counts[r] = h->xo_counts[r]; total += h->xo_counts[r]; }
+	if (!records) return KMR_OK;                           /* sizing call: the segments wait on the device */
+	if (capacity_bytes < total * rb) return fail(h, KMR_ERR_CAPACITY, "record buffer too small");
+	uint8_t *dst = (uint8_t *)records;
+	for (uint32_t r = 0; r < world; r++) {
+		if (h->xo_counts[r]) HIPCHK(h, hipMemcpy(dst, (const uint8_t *)h->xo_dev + (size_t)r * h->xo_segcap * rb, (size_t)h->xo_counts[r] * rb, hipMemcpyDeviceToHost));
+		dst += (size_t)h->xo_counts[r] * rb;
+	}
+	hipFree(h->xo_dev); h->xo_dev = nullptr; h->xo_batch = nullptr;
+	return KMR_OK;
+}
+int kmr_insert_records(kmr_handle *h, const void *host_records, uint64_t n) {
+	if (!h || (n && !host_records)) return KMR_ERR_INVALID_ARG;
+	if (n == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	const size_t bytes = (size_t)n * KMR_RECORD_BYTES(h->k, h->cfg.value_kind);
+	void *d = nullptr;
+	HIPCHK(h, hipMalloc(&d, bytes));
+	hipError_t e = hipMemcpy(d, host_records, bytes, hipMemcpyHostToDevice);
+	int rc = e == hipSuccess ? kmr_insert_records_dev(h, d, n) : KMR_ERR_HIP;
+	if (!rc) rc = sync_state(h); else hipStreamSynchronize(h->stream);
+	hipFree(d);
+	return rc;
 }
 
 int kmr_kernel_time(kmr_handle *h, int which, double *ms, uint64_t *launches) {

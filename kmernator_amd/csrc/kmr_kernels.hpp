@@ -40,6 +40,30 @@ namespace kmr {
 
 static const uint64_t EMPTY_KEY = ~0ull;
 static const uint64_t NO_FIRST = ~0ull;
+
+/* "First sighting" word of a table slot: the minimum, over the occurrences of a key, of
+ *     ordinal (40 bits) << 24 | forward << 23 | q8 << 15 | r15
+ * so the occurrence with the smallest stream ordinal wins and brings along what the reference knows about a k-mer's
+ * first sighting, which lives in the singleton map until the second one arrives: no direction
+ * (TrackingDataSingleton::getDirectionBias() == 0, src/KmerTrackingData.h:654) and its weight as the byte
+ * q8 = (unsigned char)(w * 254) (:646); r15 = 15 more bits of w * 254, enough to take the exact weight out of the f64 sum
+ * again (error <= 6e-8).  weightedCount of a promoted key is then (float)(q8 / 254.0) + the other weights (:658, :540-547). */
+static const int FIRST_ORD_SHIFT = 24;
+static const uint64_t MAX_STREAM_ORDINAL = (1ull << 40) - 1;
+__host__ __device__ __forceinline__ unsigned long long first_pack(uint64_t ordinal, bool forward, float w) {
+	const double x = (double)w * 254.0;
+	const uint32_t q8 = (uint32_t)(unsigned char)x;
+	uint32_t r15 = (uint32_t)((x - (double)q8) * 32768.0);
+	if (r15 > 32767u) r15 = 32767u;
+	return ((unsigned long long)ordinal << FIRST_ORD_SHIFT) | ((unsigned long long)(forward ? 1u : 0u) << 23) | ((unsigned long long)q8 << 15) | r15;
+}
+__host__ __device__ __forceinline__ bool first_forward(unsigned long long f) { return ((f >> 23) & 1ull) != 0; }
+/* what promotion from the singleton map does to the weight sum: (float)(q8 / 254.0) - w of the first sighting */
+__host__ __device__ __forceinline__ double first_weight_shift(unsigned long long f) {
+	const uint32_t q8 = (uint32_t)(f >> 15) & 0xffu, r15 = (uint32_t)f & 0x7fffu;
+	const double w1 = ((double)q8 + ((double)r15 + 0.5) / 32768.0) / 254.0;
+	return (double)(float)((double)q8 / 254.0) - w1;
+}
 static const int WAVES_PER_BLOCK = 4;
 /* LDS bytes per wave for bases (same again for quals).  Two 4-wave blocks must fit the 160 KiB of a CU:
  * 2 * (8 * TILE_BUF + 2064 static) <= 163840, i.e. TILE_BUF <= 9982 -- 9984 left room for ONE block per CU (one wave
@@ -121,7 +145,7 @@ template <> struct Slot<1> {
 	uint64_t key;              /* EMPTY_KEY when free                                 */
 	unsigned long long cntfwd; /* low 32: occurrences, high 32: forward occurrences   */
 	double wsum;               /* sum of weights                                      */
-	unsigned long long first;  /* min over occurrences of (ordinal << 1 | forward)    */
+	unsigned long long first;  /* min over occurrences of first_pack(ordinal, forward, w) */
 };
 template <int W> struct Slot {
 	uint64_t key[W];
@@ -256,7 +280,7 @@ __device__ __forceinline__ bool table_add(const Table<W> &t, const Key<W> &key, 
 	Slot<W> *sl = &t.slots[s];
 	atomicAdd(&sl->cntfwd, 1ull | ((unsigned long long)(o.forward ? 1 : 0) << 32));
 	atomicAdd(&sl->wsum, (double)o.w);
-	atomicMin(&sl->first, (unsigned long long)((o.ordinal << 1) | (o.forward ? 1ull : 0ull)));
+	atomicMin(&sl->first, first_pack(o.ordinal, o.forward, o.w));
 	if constexpr (EXT) {
 		ExtSlot *e = &t.ext[s];
 		if (o.ltally >= 0) atomicAdd(&e->tally[o.ltally], 1u);
@@ -300,10 +324,12 @@ template <int W> struct RecordX {
 };
 template <int W, bool EXT> struct PoolRec { typedef Record<W> type; };
 template <int W> struct PoolRec<W, true> { typedef RecordX<W> type; };
-template <int W> __device__ __forceinline__ uint32_t rec_ordinal(const Record<W> &r) { return r.pkt; }
-template <int W> __device__ __forceinline__ uint32_t rec_ordinal(const RecordX<W> &r) { return r.ord; }
-template <int W> __device__ __forceinline__ void rec_set(Record<W> &r, uint32_t pkt, uint32_t ord) { r.pkt = ord; (void)pkt; }
-template <int W> __device__ __forceinline__ void rec_set(RecordX<W> &r, uint32_t pkt, uint32_t ord) { r.pkt = pkt; r.ord = ord; r.pad = 0; }
+/* Record<W> carries the low 32 bits of the stream ordinal (the host refuses more than 2^32 input bases on that path),
+ * RecordX<W> 40 bits (the high byte in its pad word) */
+template <int W> __device__ __forceinline__ uint64_t rec_ordinal(const Record<W> &r) { return r.pkt; }
+template <int W> __device__ __forceinline__ uint64_t rec_ordinal(const RecordX<W> &r) { return (uint64_t)r.ord | ((uint64_t)r.pad << 32); }
+template <int W> __device__ __forceinline__ void rec_set(Record<W> &r, uint32_t pkt, uint64_t ord) { r.pkt = (uint32_t)ord; (void)pkt; }
+template <int W> __device__ __forceinline__ void rec_set(RecordX<W> &r, uint32_t pkt, uint64_t ord) { r.pkt = pkt; r.ord = (uint32_t)ord; r.pad = (uint32_t)(ord >> 32); }
 /* ExtensionTracking::trackExtension on a packet (src/KmerTrackingData.h:195-201): tally index 0..11 or -1 */
 __device__ __forceinline__ int ext_tally_index(uint32_t ch) { switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'X': return 5; default: return 4; } }
 
@@ -654,6 +680,10 @@ template <int W, bool EXT> __device__ __forceinline__ uint32_t op_fail_code(cons
  * first scoring call after a finalize (lut_build_kernel), dropped when the map changes. */
 template <int W> struct LutView { const uint64_t *slots; uint64_t mask; uint32_t shift; };
 __host__ __device__ __forceinline__ uint64_t lut_slot(uint64_t hash, uint32_t shift) { return (hash * 0x9E3779B97F4A7C15ull) >> shift; }
+/* The table marks a free slot by EMPTY_KEY in its first word.  A one-word canonical key is never all ones (all-T is not
+ * canonical), but the first word of a longer key can be (k >= 64: T^32...A^32 is its own reverse complement): such keys
+ * are not put into the table, lookups of them search the sorted buckets. */
+template <int W> __device__ __forceinline__ bool lut_holds(const Key<W> &key) { return W == 1 || key.w[0] != EMPTY_KEY; }
 template <int W> __device__ __forceinline__ uint32_t lut_count(const LutView<W> &t, const Key<W> &key, uint64_t hash) {
 	uint64_t s = lut_slot(hash, t.shift);
 	for (;;) {
@@ -679,6 +709,7 @@ __global__ void lut_build_kernel(MapView<W> weak, uint64_t n, uint64_t *slots, u
 		Key<W> key;
 #pragma unroll
 		for (int j = 0; j < W; j++) key.w[j] = weak.keys[i * W + j];
+		if (!lut_holds<W>(key)) continue;
 		uint64_t s = lut_slot(key_hash<W>(key, kb), shift);
 		for (;;) {           /* the keys of a map are distinct: a slot is taken by whoever swaps its first word in */
 			unsigned long long *p = (unsigned long long *)(slots + s * (W + 1));
@@ -715,7 +746,7 @@ template <int W> struct LookupOp {
 	                                     uint64_t readIdx, uint32_t pos, unsigned &, bool &) const {
 		if (valid) {
 			uint32_t c;
-			if (weak_only && lut.slots) c = lut_count<W>(lut, key, hash);
+			if (weak_only && lut.slots && lut_holds<W>(key)) c = lut_count<W>(lut, key, hash);
 			else if (weak_only) { const int64_t i = map_find<W>(weak, key, hash); c = i >= 0 ? (weak.vals[(uint64_t)i * weak.vw] & 0xffffu) : 0u; }
 			else c = maps_count<W>(weak, sing, key, hash);
 			out[out_offsets[readIdx - first_read_idx] + pos] = c;
@@ -743,7 +774,7 @@ __global__ void lookup_words_kernel(MapView<W> weak, LutView<W> lut, const uint6
 #pragma unroll
 		for (int j = 0; j < W; j++) key.w[j] = keys[i * W + j];
 		const uint64_t hash = key_hash<W>(key, kb);
-		if (lut.slots) { out[i] = lut_count<W>(lut, key, hash); continue; }
+		if (lut.slots && lut_holds<W>(key)) { out[i] = lut_count<W>(lut, key, hash); continue; }
 		const int64_t e = map_find<W>(weak, key, hash);
 		out[i] = e >= 0 ? (weak.vals[(uint64_t)e * weak.vw] & 0xffffu) : 0u;
 	}
@@ -977,12 +1008,12 @@ __global__ void scatter_kernel(Table<W> t, FinalizeParams f, const uint64_t *wea
 			uint32_t cnt = count;
 			/* the first sighting lived in the singleton map, which keeps no direction
 			 * (TrackingDataSingleton::getDirectionBias, src/KmerTrackingData.h:654) */
-			if (f.has_singletons && (s.first & 1ull)) fwd -= 1;
+			if (f.has_singletons && first_forward(s.first)) fwd -= 1;
 			if (cnt > 65535u) { cnt = 65535u; if (fwd > 65534u) fwd = 65534u; }   /* MAX_COUNT, :434 */
 			if (fwd > 65535u) fwd = 65535u;
 			uint32_t *v = weakVals + pos * vw;
 			v[0] = cnt;
-			v[1] = __float_as_uint((float)s.wsum);
+			v[1] = __float_as_uint((float)(f.has_singletons ? s.wsum + first_weight_shift(s.first) : s.wsum));
 			v[2] = fwd;
 			if (EXT) {
 #pragma unroll
@@ -1041,7 +1072,9 @@ void sort_buckets_kernel(SortView<W> v, const uint64_t *start, uint64_t nb) {
 				Key<W> other;
 #pragma unroll
 				for (int j = 0; j < W; j++) other.w[j] = __shfl(key.w[j], (int)i, 64);
-				rank += key_lt<W>(other, key) ? 1u : 0u;
+				/* ties are broken by lane, so the output is a permutation even when a bucket holds a key twice (a merge of
+				 * overlapping maps, a loaded image with a repeated key): duplicate_keys_kernel then finds the pair side by side */
+				rank += (key_lt<W>(other, key) || (key_eq<W>(other, key) && i < (uint32_t)lane)) ? 1u : 0u;
 			}
 			if (have) {
 #pragma unroll

@@ -118,7 +118,7 @@ template <int W, bool EXT, bool STATS = true> struct LinearOp {
 #pragma unroll
 			for (int i = 0; i < W; i++) r.key[i] = key.w[i];
 			r.w = o.forward ? o.w : -o.w;
-			rec_set<W>(r, o.pkt, (uint32_t)o.ordinal);
+			rec_set<W>(r, o.pkt, o.ordinal);
 			(records + (st.base + st.n))[rank] = r;
 		}
 		st.n += (uint32_t)__builtin_popcountll(mask);
@@ -201,7 +201,7 @@ void owner_scatter_kernel(const typename PoolRec<W, EXT>::type *linear, const ui
 							uint64_t *dst = (uint64_t *)out + at * W;
 #pragma unroll
 							for (int j = 0; j < W; j++) dst[j] = r[u].key[j];
-							pos_out[at] = rec_ordinal<W>(r[u]);
+							pos_out[at] = (uint32_t)rec_ordinal<W>(r[u]);
 						} else {
 							uint32_t *dst = out + at * RW;
 #pragma unroll
@@ -489,7 +489,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
 #pragma unroll
 							for (int j = 0; j < W; j++) rr[i].key[j] = (uint64_t)p32[2 * j] | ((uint64_t)p32[2 * j + 1] << 32);
 							rr[i].w = __uint_as_float(p32[2 * W]);
-							rec_set<W>(rr[i], S.packed_words > 2u * W + 1u ? p32[2 * W + 1] : 0u, (uint32_t)(S.ordinal_base + ri));      /* arrival ordinal */
+							rec_set<W>(rr[i], S.packed_words > 2u * W + 1u ? p32[2 * W + 1] : 0u, S.ordinal_base + ri);      /* arrival ordinal */
 						} else rr[i] = ((const Rec *)S.linear)[ri];
 						if (rr[i].w != 0.0f) { pp[i] = pid_of(rr[i]); nvalid++; }
 					}
@@ -966,7 +966,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 				const float wa = fwd ? r.w : -r.w;
 				atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(fwd ? 1 : 0) << 32));
 				atomicAdd(&twsum[s], (double)wa);
-				atomicMin(&tfirst[s], ((unsigned long long)rec_ordinal<W>(r) << 1) | (fwd ? 1ull : 0ull));
+				atomicMin(&tfirst[s], first_pack(rec_ordinal<W>(r), fwd, wa));
 				if constexpr (EXT) {      /* ExtensionTracking::trackExtension (src/KmerTrackingData.h:195-201) */
 					const int lc = ext_tally_index(r.pkt & 0xff), rc_ = ext_tally_index((r.pkt >> 8) & 0xff);
 					const uint32_t lq = (r.pkt >> 16) & 0xff, rq_ = r.pkt >> 24;
@@ -1063,11 +1063,12 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 #pragma unroll
 						for (int j = 0; j < W; j++) out.wkeys[pos * W + j] = key.w[j];
 						uint32_t fwd = (uint32_t)(cf >> 32), cnt = (uint32_t)cf;
-						if (f.has_singletons && (tfirst[s] & 1ull)) fwd -= 1;
+						const unsigned long long fst = tfirst[s];
+						if (f.has_singletons && first_forward(fst)) fwd -= 1;
 						if (cnt > 65535u) { cnt = 65535u; if (fwd > 65534u) fwd = 65534u; }
 						if (fwd > 65535u) fwd = 65535u;
 						uint32_t *v = out.wvals + pos * vw;
-						v[0] = cnt; v[1] = __float_as_uint((float)twsum[s]); v[2] = fwd;
+						v[0] = cnt; v[1] = __float_as_uint((float)(f.has_singletons ? twsum[s] + first_weight_shift(fst) : twsum[s])); v[2] = fwd;
 						if (EXT) {
 #pragma unroll
 							for (int j = 0; j < 12; j++) v[3 + j] = NARROW ? ((ttally[(size_t)s * TW + (j >> 1)] >> (16 * (j & 1))) & 0xffffu) : ttally[(size_t)s * 12 + j];

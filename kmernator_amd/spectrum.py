@@ -56,6 +56,12 @@ class KmerSpectrum:
         except Exception:
             pass
 
+    def tune(self, **knobs):
+        """kmr_tune: implementation knobs of this handle (none changes a result)"""
+        for name, v in knobs.items():
+            self._call("tune", self.h, name.encode(), float(v))
+        return self
+
     # -- build
     def buildKmerSpectrum(self, bases, quals, offsets, first_read_idx=0, discarded=None):
         """KmerSpectrum::buildKmerSpectrum(const ReadSet&) on flat host arrays."""
