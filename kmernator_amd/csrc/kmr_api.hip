@@ -24,6 +24,7 @@
 #include "kmr_partition.hpp"
 #include "kmr_ingest.hpp"
 #include "kmr_artifact.hpp"
+#include "kmr_superkmer.hpp"
 
 using namespace kmr;
 
@@ -110,6 +111,9 @@ struct kmr_handle {
 	uint32_t *ucnt = nullptr; uint64_t *ufirst = nullptr, *u_start = nullptr, *u_end = nullptr, *u_read = nullptr;
 	uint64_t ucnt_n = 0, ufirst_n = 0, units_n = 0; unsigned int *umax = nullptr;
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr, *us_pkt = nullptr; uint64_t uw_cap = 0, us_cap = 0;
+	/* build_mode 3 (kmr_superkmer.hpp): list words, minimizer geometry, table of k-fold quality products */
+	unsigned long long *sk_state = nullptr; uint32_t sk_bits = 0, sk_m = 0, sk_off = 0, sk_win = 0; double *dPk = nullptr;
+	uint32_t sk_min_override = 0;
 	/* kmr_extract_by_owner_host: owner segments of one batch kept on the device between the sizing call and the copy-out */
 	void *xo_dev = nullptr; uint64_t xo_segcap = 0; std::vector<uint64_t> xo_counts; const void *xo_batch = nullptr; uint64_t xo_first = 0;
 	/* timing */
@@ -647,7 +651,7 @@ const double MAX_LIST_DISTINCT = 600.0;       /* distinct keys per final list th
 const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
 const uint64_t SUB_BATCH_BASES = 1ull << 30;      /* linear records of one sub-batch: <= 17 GB at 16 bytes; 2^28 cost 2 ms per C2 step in launch tails */
 
-size_t rec_bytes(kmr_handle *h) { return 8 * h->W + (h->ext ? 16 : 8); }      /* Record<W> / RecordX<W> */
+size_t rec_bytes(kmr_handle *h) { return h->superkmer_mode ? 16 : 8 * h->W + (h->ext ? 16 : 8); }      /* Record<W> / RecordX<W>; a 16-byte granule of a super-k-mer record */
 /* partition kernel shape: one 1024-thread block per compute unit, 8 records per thread per batch, a
  * 4-record write-combining line per list in LDS (see partition_direct_kernel) */
 const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
@@ -1222,7 +1226,165 @@ int insert_records_partition(kmr_handle *h, const void *recs, uint64_t n) {
 	switch (h->W) { case 1: return IRP(1); case 2: return IRP(2); case 3: return IRP(3); default: return IRP(4); }
 #undef IRP
 }
+/* ---------------------------------------------------------------------- */
+/* build_mode 3: super-k-mer lists (kmr_superkmer.hpp)                        */
+/* Minimizer geometry for k: the window of WIN m-mer offsets sits in the middle of the k-mer (2 * off + WIN = k - m + 1), m is
+ * the largest length <= 16 (one 32-bit word) of the right parity, WIN the largest of 16 / 8 / 4 that leaves m >= 10. */
+bool sk_geometry(uint32_t k, uint32_t m_wish, uint32_t &win, uint32_t &m, uint32_t &off) {
+	for (uint32_t w : {16u, 8u, 4u}) {
+		if (k < w + 9) continue;
+		uint32_t mm = std::min<uint32_t>(m_wish ? m_wish : 16u, k - w + 1);
+		if (mm > 16) mm = 16;
+		if (((k - mm + 1 - w) & 1u) != 0) mm--;                 /* k - m + 1 - WIN must be even */
+		if (mm < 10 && !m_wish) continue;
+		if (mm < 4) continue;
+		win = w; m = mm; off = (k - mm + 1 - w) / 2;
+		return true;
+	}
+	return false;
+}
+template <int W, int WIN, bool FILT> int launch_sk_extract(kmr_handle *h, const ReadsView &rv, const SkParams &sp) {
+	auto kern = sk_extract_kernel<W, WIN, FILT>;
+	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_EXTRACT_SMEM));
+	const uint64_t tiles = ((rv.u_start ? rv.n_units : rv.n_reads) + 63) / 64;
+	uint64_t blocks = (tiles + SK_WAVES - 1) / SK_WAVES;
+	if (blocks == 0) return 0;
+	blocks = std::min<uint64_t>(blocks, (uint64_t)num_cus(h) * 2);      /* resident grid: a wavefront walks tiles tile0, tile0 + stride, ... */
+	if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, SK_WAVES * 64, SK_EXTRACT_SMEM); fprintf(stderr, "sk_extract<W=%d,WIN=%d>: %d blocks of %d waves per CU (LDS %zu), grid %llu, m=%u off=%u bits=%u\n", W, WIN, nb, SK_WAVES, SK_EXTRACT_SMEM, (unsigned long long)blocks, sp.m, sp.off, sp.list_bits); }
+	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SK_WAVES * 64), SK_EXTRACT_SMEM, h->stream, rv, dev_params(h), sp, pool_view(h, h->l1));
+	HIPCHK(h, hipGetLastError());
+	return 0;
+}
+SkParams sk_params(kmr_handle *h) { SkParams sp; sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; return sp; }
+template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
+	const uint64_t n = rvAll.n_reads;
+	if (!h->sk_state) {
+		/* lists: about 1100 k-mers each, as the final lists of the two-level partition */
+		const uint64_t est = std::max<uint64_t>(total_bases, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
+		uint32_t bits = 6; while (bits < 24 && (est >> bits) > h->tune.target_list / 2 + 76) bits++;
+		h->sk_bits = bits;
+		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8ull << bits));
+		hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(1ull << bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << bits);
+		HIPCHK(h, hipGetLastError());
+	}
+	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
+	const uint64_t sub_bases = h->tune.sub_batch_bases ? h->tune.sub_batch_bases : (1ull << 31);
+	const uint64_t chunk = std::max<uint64_t>(64, (sub_bases / avg) & ~63ull);
+	const DevParams dp = dev_params(h);
+	const bool filt = dp.subsample > 1 || dp.world > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0;
+	for (uint64_t r = 0; r < n; r += chunk) {
+		const uint64_t m = std::min(chunk, n - r);
+		ReadsView rv = rvAll;
+		rv.offsets = rvAll.offsets + r; rv.n_reads = m;
+		rv.discarded = rvAll.discarded ? rvAll.discarded + r : nullptr;
+		rv.first_read_idx = rvAll.first_read_idx + r;
+		int rc = prepare_units(h, rv); if (rc) return rc;
+		/* room for this launch: a granule per k-mer is more than any input takes (flat qualities: a quarter of that), one open
+		 * chunk per list and two slabs of 64 chunks per wavefront */
+		const uint64_t bases = m * avg + avg;
+		rc = pool_reserve(h, h->l1, bases / SK_CHUNK_G + (h->l1.base ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * 2 * SK_WAVES * 130 + 64, true); if (rc) return rc;
+		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b); time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
+		const SkParams sp = sk_params(h);
+#define SKX(WINv) (filt ? launch_sk_extract<W, WINv, true>(h, rv, sp) : launch_sk_extract<W, WINv, false>(h, rv, sp))
+		rc = h->sk_win == 16 ? SKX(16) : (h->sk_win == 8 ? SKX(8) : SKX(4));
+#undef SKX
+		time_end(h, KMR_TIME_EXTRACT, a2, b2); time_end(h, KMR_TIME_BUILD, a, b);
+		if (rc) return rc;
+	}
+	return 0;
+}
+int add_reads_superkmer(kmr_handle *h, const ReadsView &rv, uint64_t total_bases) {
+	switch (h->W) { case 1: return add_reads_superkmer_t<1>(h, rv, total_bases); case 2: return add_reads_superkmer_t<2>(h, rv, total_bases);
+	case 3: return add_reads_superkmer_t<3>(h, rv, total_bases); default: return add_reads_superkmer_t<4>(h, rv, total_bases); }
+}
+template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
+	int rc = sync_state(h);
+	if (rc) return rc;
+	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
+	const uint64_t G = h->stats.raw_good_kmers;
+	FinalizeParams f; f.kb = h->kb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	const bool keepSing = f.has_singletons && min_depth <= 1;
+	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
+	rc = arena_reset(h); if (rc) return rc;
+	const uint64_t nl = h->sk_state ? 1ull << h->sk_bits : 1;
+	if (h->sk_state) {
+		hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);
+		HIPCHK(h, hipGetLastError());
+	}
+	uint64_t *ls = nullptr, *lc = nullptr; uint32_t nch = 0;
+	rc = build_csr(h, h->l1, nl, 0, &ls, &lc, &nch); if (rc) return rc;
+	const uint32_t vw = 3;
+	const uint64_t slack = (uint64_t)num_cus(h) * 4 * 8192 + 16;
+	const uint64_t wbound = f.has_singletons ? G / 2 : G, sbound = keepSing ? G : 0;
+	const uint64_t wmax = wbound + wbound / 8 + slack, smax = keepSing ? sbound + sbound / 8 + slack : 16;
+	/* entry buffers: sequencing data keeps a few per cent of its k-mers as weak entries; the pass is run again with larger
+	 * buffers when that was not enough */
+	uint64_t wcap = std::min<uint64_t>(wmax, G / (f.has_singletons ? 8 : 3) + slack), scap = keepSing ? std::min<uint64_t>(smax, G / 3 + slack) : 16;
+	if (h->tune.entry_share >= 0) { wcap = std::min<uint64_t>(wmax, (uint64_t)((double)G * h->tune.entry_share) + 16384); if (keepSing) scap = std::min<uint64_t>(smax, (uint64_t)((double)G * h->tune.entry_share) + 16384);
+		if (h->uw_keys) { hipFree(h->uw_keys); hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0; }
+		if (h->us_keys) { hipFree(h->us_keys); hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0; } }
+	if (h->uw_keys && h->uw_cap >= wcap) wcap = h->uw_cap;
+	if (h->us_keys && h->us_cap >= scap) scap = h->us_cap;
+	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr; unsigned long long *cursors = nullptr;
+	rc = arena_get(h, &wc, h->nb_weak); if (rc) return rc; rc = arena_get(h, &sc, h->nb_sing); if (rc) return rc;
+	rc = arena_get(h, &fc, 1); if (rc) return rc; rc = arena_get(h, &cursors, 2); if (rc) return rc;
+	FinalizeCounters c; unsigned long long cur[2];
+	hipEvent_t tca, tcb; time_begin(h, KMR_TIME_COUNT, &tca, &tcb);
+	for (int attempt = 0; ; attempt++) {
+		if (!h->uw_keys || h->uw_cap < wcap) {
+			if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
+			HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, hipMalloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
+		}
+		if (!h->us_keys || h->us_cap < scap) {
+			if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0;
+			HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); h->us_cap = scap;
+		}
+		HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
+		HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
+		CountOut out; out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wcursor = cursors; out.wcap = h->uw_cap;
+		out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = nullptr; out.scursor = cursors + 1; out.scap = h->us_cap;
+		out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
+		rc = zero_work_counter(h); if (rc) return rc;
+		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (nl + SK_LBATCH - 1) / SK_LBATCH);
+		auto kern = sk_count_kernel<W, COUNT_LOG2S>;
+		const size_t smem = sk_count_smem_bytes<W, COUNT_LOG2S>();
+		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+		if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, COUNT_THREADS, smem); fprintf(stderr, "sk_count<W=%d>: %d blocks per CU (LDS %zu), %llu lists, %u chunks\n", W, nb, smem, (unsigned long long)nl, nch); }
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter);
+		HIPCHK(h, hipGetLastError());
+		uint32_t cerr = 0;
+		HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(cur, cursors, 16, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(h, hipMemcpyAsync(&cerr, h->derr, 4, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+		if (!(cerr & ERR_ENTRIES_FULL)) break;
+		if ((wcap >= wmax && scap >= smax) || attempt >= 8) { time_end(h, KMR_TIME_COUNT, tca, tcb); time_end(h, 1, ea, eb); return fail(h, KMR_ERR_CAPACITY, "entry buffers of the count pass overflowed at their upper bound (internal sizing error)"); }
+		cerr &= ~(uint32_t)ERR_ENTRIES_FULL;
+		HIPCHK(h, hipMemcpy(h->derr, &cerr, 4, hipMemcpyHostToDevice));
+		wcap = std::min<uint64_t>(wmax, wcap * 2); if (keepSing) scap = std::min<uint64_t>(smax, scap * 2);
+		if (dbg()) fprintf(stderr, "sk count pass: entry buffers too small, retrying with %llu / %llu\n", (unsigned long long)wcap, (unsigned long long)scap);
+	}
+	time_end(h, KMR_TIME_COUNT, tca, tcb);
+	h->stats.unique_kmers = c.unique;
+	h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
+	hipEvent_t tma, tmb; time_begin(h, KMR_TIME_BUCKETS, &tma, &tmb);
+	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing);
+	time_end(h, KMR_TIME_BUCKETS, tma, tmb);
+	if (rc) return rc;
+	time_end(h, 1, ea, eb);
+	h->has_singletons = keepSing;
+	h->stats.weak_entries = h->weak.n; h->stats.singleton_entries = keepSing ? h->sing.n : 0;
+	h->finalized = true; h->map_gen++;
+	rc = sync_state(h);
+	if (!rc && !h->arena_overflow.empty()) rc = arena_reset(h);
+	return rc;
+}
+int finalize_superkmer(kmr_handle *h, uint32_t min_depth) {
+	switch (h->W) { case 1: return finalize_superkmer_t<1>(h, min_depth); case 2: return finalize_superkmer_t<2>(h, min_depth);
+	case 3: return finalize_superkmer_t<3>(h, min_depth); default: return finalize_superkmer_t<4>(h, min_depth); }
+}
+
 void free_partition_state(kmr_handle *h) {
+	if (h->sk_state) hipFree(h->sk_state); h->sk_state = nullptr;
 	pool_free(h->l1);
 	if (h->l1_state) hipFree(h->l1_state); h->l1_state = nullptr; h->l1_state_bytes = 0; h->l1_state_dirty = false;
 	for (void *p : h->arena_overflow) hipFree(p);
@@ -1296,8 +1458,17 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 		if (hipMalloc((void **)&h->dP, sizeof(P)) != hipSuccess || hipMalloc((void **)&h->dstats, sizeof(DevStats)) != hipSuccess || hipMalloc((void **)&h->derr, 4) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
 		hipMemcpy(h->dP, P, sizeof(P), hipMemcpyHostToDevice); hipMemset(h->dstats, 0, sizeof(DevStats)); hipMemset(h->derr, 0, 4);
 		/* build_mode: 0 auto (streaming partition path unless EXT values), 1 table, 2 partition */
-		if (cfg->build_mode > 2) { rc = fail(nullptr, KMR_ERR_INVALID_ARG, "bad build_mode"); break; }
+		if (cfg->build_mode > 3) { rc = fail(nullptr, KMR_ERR_INVALID_ARG, "bad build_mode"); break; }
 		h->partition_mode = cfg->build_mode != 1;
+		if (cfg->build_mode == 3) {
+			if (h->ext) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) builds KMR_VALUE_COUNT_DIR values only"); break; }
+			if (!sk_geometry(h->k, 0, h->sk_win, h->sk_m, h->sk_off)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) needs k >= 13"); break; }
+			h->superkmer_mode = true;
+			double Pk[256];
+			for (int cidx = 0; cidx < 256; cidx++) { double wv = 1.0; for (uint32_t jj = 0; jj < h->k; jj++) wv *= P[cidx]; Pk[cidx] = wv; }      /* the loop of buildWeightedKmers, src/KmerReadUtils.h:205-208 */
+			if (hipMalloc((void **)&h->dPk, sizeof(Pk)) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
+			hipMemcpy(h->dPk, Pk, sizeof(Pk), hipMemcpyHostToDevice);
+		}
 		if (!h->partition_mode) {
 			rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
 			if (rc) { g_create_error = h->err; break; }
@@ -1314,7 +1485,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->stream) hipStreamSynchronize(h->stream);
 	for (int which = 0; which < KMR_TIME_GROUPS; which++) for (auto &pr : h->pending_events[which]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 	if (h->slots) hipFree(h->slots); if (h->extslots) hipFree(h->extslots);
-	if (h->dP) hipFree(h->dP); if (h->dstats) hipFree(h->dstats); if (h->derr) hipFree(h->derr);
+	if (h->dP) hipFree(h->dP); if (h->dPk) hipFree(h->dPk); if (h->dstats) hipFree(h->dstats); if (h->derr) hipFree(h->derr);
 	free_map(h->weak); free_map(h->sing);
 	free_partition_state(h);
 	if (h->scan_sums) hipFree(h->scan_sums);
@@ -1345,6 +1516,7 @@ int kmr_reset(kmr_handle *h) {
 		if (h->l1.head) HIPCHK(h, hipMemsetAsync(h->l1.head, 0, 4, h->stream));
 		h->l1.used_ub = 0;
 		h->inserted_records = 0;
+		if (h->sk_state) hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(1ull << h->sk_bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << h->sk_bits);
 		if (h->l1_state) {      /* what an unfinished build kept back is dropped with its pool */
 			hipLaunchKernelGGL(partition_state_init_kernel, dim3(partition_blocks(h)), dim3(256), 0, h->stream, h->l1_state,
 			                   h->l1_state_bytes / (size_t)partition_blocks(h), h->bits1, (uint32_t)partition_blocks(h));
@@ -1386,6 +1558,9 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "lookup_table") h->tune.no_lut = value == 0;
 	else if (k == "narrow_tallies") h->tune.no_narrow = value == 0;
 	else if (k == "keep_level1_state") h->tune.no_l1_state = value == 0;
+	else if (k == "superkmer_minimizer") {
+		if (h->superkmer_mode && !h->sk_state) { uint32_t w, m, o; if (!sk_geometry(h->k, (uint32_t)value, w, m, o)) return fail(h, KMR_ERR_INVALID_ARG, "no minimizer geometry for that length"); h->sk_win = w; h->sk_m = m; h->sk_off = o; }
+	}
 	else return fail(h, KMR_ERR_INVALID_ARG, "unknown tuning knob '" + k + "'");
 	return KMR_OK;
 }
@@ -1407,7 +1582,7 @@ int kmr_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_qual
 	if (h->stream_base + total_bases > MAX_STREAM_ORDINAL) return fail(h, KMR_ERR_CAPACITY, "more than 2^40 input bases on one handle");
 	if (h->partition_mode && !h->superkmer_mode && !h->ext && h->stream_base + total_bases > (1ull << 32))
 		return fail(h, KMR_ERR_CAPACITY, "build_mode 2 orders occurrences by a 32-bit stream ordinal: at most 2^32 input bases per handle without extension values (use build_mode 0 / 3 or 1)");
-	int rc = h->partition_mode ? add_reads_partition(h, rv, total_bases) : add_reads_dev_any(h, rv, total_bases);
+	int rc = h->superkmer_mode ? add_reads_superkmer(h, rv, total_bases) : (h->partition_mode ? add_reads_partition(h, rv, total_bases) : add_reads_dev_any(h, rv, total_bases));
 	h->stream_base += total_bases; h->reads += n_reads; h->stats.reads = h->reads;
 	return rc;
 }
@@ -1434,6 +1609,7 @@ int kmr_finalize(kmr_handle *h, uint32_t min_depth) {
 	hipSetDevice(h->device);
 	{ int src_ = sync_state(h); if (src_) return src_; }
 	h->subtract = nullptr;                             /* optimize(): subtractingReference.reset() */
+	if (h->superkmer_mode) return finalize_superkmer(h, min_depth);
 	if (h->partition_mode) return finalize_partition(h, min_depth);
 #define FIN(Wv) (h->ext ? finalize_t<Wv, true>(h, min_depth) : finalize_t<Wv, false>(h, min_depth))
 	switch (h->W) { case 1: return FIN(1); case 2: return FIN(2); case 3: return FIN(3); default: return FIN(4); }
@@ -2221,6 +2397,7 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
                              void *dev_records, uint64_t seg_capacity, void *dev_seg_counts) {
 	if (!h || !dev_bases || !dev_offsets || !dev_records || !dev_seg_counts) return KMR_ERR_INVALID_ARG;
 	if (h->cfg.world_size > (uint32_t)OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "owner exchange supports up to 8 ranks per node");
+	if (h->superkmer_mode) return fail(h, KMR_ERR_UNSUPPORTED, "k-mer records by owner are a build_mode 1 / 2 path; build_mode 3 exchanges super-k-mers (kmr_exchange_*)");
 	hipSetDevice(h->device);
 	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
 	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
@@ -2309,6 +2486,7 @@ int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n) {
 	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_insert_records_dev after kmr_finalize");
 	if (n == 0) return KMR_OK;
 	hipSetDevice(h->device);
+	if (h->superkmer_mode) return fail(h, KMR_ERR_UNSUPPORTED, "k-mer records are inserted by build_mode 1 / 2; build_mode 3 exchanges super-k-mers");
 	if (h->partition_mode) { int prc = insert_records_partition(h, dev_records, n); h->stream_base += n; return prc; }
 	int rc = ensure_capacity(h, n); if (rc) return rc;
 	hipEvent_t a, b; time_begin(h, 0, &a, &b);

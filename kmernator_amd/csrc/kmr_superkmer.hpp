@@ -1,0 +1,758 @@
+/*
+ * kmr_superkmer.hpp -- build_mode 3: the streaming build over SUPER-K-MERS instead of k-mer records.
+ *
+ * The two partition passes of kmr_partition.hpp move every k-mer occurrence as a 16-byte record five times through HBM
+ * (140 GB per 1.2e9 k-mers, 3.2 x the algorithmic bytes).  Consecutive k-mers of a read overlap in k-1 bases, so here a
+ * record is a RUN of consecutive good k-mers of one read that share a minimizer -- a super-k-mer: one 16-byte header, the
+ * run's n + k - 1 bases packed to 2 bits, and one weight (or n of them when the qualities differ inside the run) --
+ * 32 bytes for ~8 k-mers.  All occurrences of a k-mer, on either strand, have the same minimizer, so hashing the minimizer
+ * into 2^list_bits lists puts them into one list in a SINGLE scatter pass fused into the extraction; the count pass
+ * expands each list inside LDS (lane per k-mer: bases -> forward / reverse-complement word -> canonical key) and counts it
+ * in the same LDS hash table as count_kernel.  HBM sees the reads once, the super-k-mers once written and once read, and
+ * the kept entries.
+ *
+ *   sk_extract_kernel   reads -> (exact fp64 weight chain, minimizer, runs) -> records appended to chunked lists
+ *   sk_close_kernel     fill counts of the lists' open chunks (before the chunk CSR is built)
+ *   sk_count_kernel     list -> LDS: records expanded to k-mers -> LDS table -> kept entries + per-bucket counts
+ *
+ * Replaces the same reference functions as extract_kernel + InsertOp: KmerReadUtils::buildWeightedKmers
+ * (src/KmerReadUtils.h:176-248), KmerSpectrum::append + track() (src/KmerSpectrum.h:1578-1668,
+ * src/KmerTrackingData.h:427,517,641) and purgeMinDepth (:1805-1815).  The minimizer, the list function and the record
+ * format are private: no result depends on them (tests hold the maps byte-identical to the other build modes and to the
+ * oracle).  Values: TrackingDataWithDirection / TrackingDataSingleton (KMR_VALUE_COUNT_DIR) only.
+ *
+ * Minimizer of a k-mer: the smallest hash among the canonical m-mers at WIN consecutive offsets placed symmetrically inside
+ * the k-mer ([off, off + WIN) with 2 * off + WIN = k - m + 1), so a k-mer and its reverse complement see the same set of
+ * canonical m-mers.  WIN is a compile-time 4, 8 or 16: the sliding minimum is kept in registers (block decomposition: suffix
+ * minima of the previous block of WIN values, prefix minimum of the current one) with static register indices because the
+ * position loop is unrolled by 16.
+ */
+#ifndef KMR_SUPERKMER_HPP_
+#define KMR_SUPERKMER_HPP_
+
+#include "kmr_partition.hpp"
+
+namespace kmr {
+
+static const uint32_t SK_CHUNK_G = 64;        /* 16-byte granules per chunk: 1 KB, the CH * 16 of PoolView           */
+static const uint32_t SK_MAX_N = 128;         /* k-mers per record                                                    */
+static const int SK_WAVES = 3;                /* wavefronts per block of sk_extract_kernel (two blocks per CU by LDS) */
+static const int SK_WINDOW = 16;              /* positions between two gathers = the unroll of the position loop      */
+
+struct SkParams {
+	uint32_t m;            /* minimizer length in bases, <= 16                                        */
+	uint32_t off;          /* offset inside the k-mer of the first m-mer the minimizer looks at       */
+	uint32_t list_bits;    /* lists = 2^list_bits                                                     */
+	unsigned long long *state;     /* per list: open chunk << 32 | granules used (SK_CHUNK_G and NO_CHUNK: none) */
+	const double *Pk;      /* 256 entries: P[c] multiplied k times in sequence, the weight of a window of k equal qualities */
+};
+
+/* murmur3 finaliser: a bijection of 32-bit words */
+__host__ __device__ __forceinline__ uint32_t sk_fmix(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+/* order of the canonical m-mers (the minimizer is the smallest) */
+__host__ __device__ __forceinline__ uint32_t sk_mmer_hash(uint32_t canon) { return sk_fmix(canon ^ 0x9e3779b9u); }
+/* list of a minimizer: minima crowd near zero, so the list is cut from a second scramble of the hash, not from its top bits */
+__host__ __device__ __forceinline__ uint32_t sk_list_of(uint32_t mh, uint32_t list_bits) { return list_bits ? sk_fmix(mh * 0x2545f491u + 0x7f4a7c15u) >> (32 - list_bits) : 0u; }
+
+/* Record, in 16-byte granules:
+ *   granule 0   { ordinal low 32 | ordinal bits 32..39, n << 8, uniform << 16, granules << 17 | minimizer hash | weight (f32 bits) }
+ *   granules    the run's n + k - 1 bases, 64 per granule, first base in the top two bits of the first dword
+ *   granules    n f32 weights, 4 per granule -- only when the run's weights are not all equal (uniform == 0)
+ * ordinal = stream ordinal of the run's first k-mer; the others follow by +1. */
+__host__ __device__ __forceinline__ uint32_t sk_base_granules(uint32_t n, uint32_t k) { return (n + k - 1 + 63) / 64; }
+
+__global__ void sk_state_init_kernel(unsigned long long *state, uint64_t n) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) state[i] = ((unsigned long long)NO_CHUNK << 32) | SK_CHUNK_G;
+}
+/* the open chunk of every list gets its fill count (chunks closed by an append already have theirs) */
+__global__ void sk_close_kernel(const unsigned long long *state, uint64_t n, uint32_t *chunk_count, uint32_t cap) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const unsigned long long s = state[i];
+		const uint32_t c = (uint32_t)(s >> 32), f = (uint32_t)s;
+		if (c != NO_CHUNK && c < cap) chunk_count[c] = f < SK_CHUNK_G ? f : SK_CHUNK_G;
+	}
+}
+
+/* Reserve g granules in list `list`: lock-free append to a chain of fixed chunks.  The list's word is open chunk << 32 |
+ * fill; an atomic add books [fill, fill + g).  The ONE adder that crosses the end of the chunk closes it (its fill count is
+ * the value it saw), takes a new chunk from its wavefront's slab and publishes it with its own g already booked; adders that
+ * arrive in between see a fill beyond the end and try again.  Records never straddle chunks.  Returns the granule index
+ * in the pool (chunk * SK_CHUNK_G + offset) or ~0 when the pool is exhausted (error flagged). */
+struct SkSlab { uint32_t base[2]; uint32_t next; uint32_t pad; };       /* per wavefront, in LDS: two slabs of 64 chunks */
+__device__ __forceinline__ uint32_t sk_alloc_chunk(SkSlab *slab, const PoolView &pool) {
+	const uint32_t idx = atomicAdd(&slab->next, 1u);
+	uint32_t c;
+	if (idx < 128u) c = slab->base[idx >> 6] + (idx & 63u);
+	else c = atomicAdd(pool.head, 1u);
+	if (c >= pool.cap) { atomicOr(pool.err, (uint32_t)ERR_POOL_FULL); return NO_CHUNK; }
+	return c;
+}
+__device__ __forceinline__ uint64_t sk_append(unsigned long long *state, uint32_t list, uint32_t g, SkSlab *slab, const PoolView &pool) {
+	unsigned long long *word = state + list;
+	for (int spin = 0; spin < 1024; spin++) {
+		const unsigned long long old = atomicAdd(word, (unsigned long long)g);
+		const uint32_t c = (uint32_t)(old >> 32), f = (uint32_t)old;
+		if (f + g <= SK_CHUNK_G) return (uint64_t)c * SK_CHUNK_G + f;
+		if (f <= SK_CHUNK_G) {                     /* this add crossed the end: replace the chunk */
+			if (c != NO_CHUNK) pool.chunk_count[c] = f;
+			const uint32_t c2 = sk_alloc_chunk(slab, pool);
+			if (c2 == NO_CHUNK) {                  /* pool exhausted: leave the list closed for good, the build is void */
+				atomicExch(word, ((unsigned long long)NO_CHUNK << 32) | (SK_CHUNK_G + 1));
+				return ~0ull;
+			}
+			pool.chunk_list[c2] = list;
+			atomicExch(word, ((unsigned long long)c2 << 32) | g);
+			return (uint64_t)c2 * SK_CHUNK_G;
+		}
+		/* somebody else is replacing the chunk: wait until the word names another chunk */
+		for (int w = 0; w < 256; w++) {
+			const unsigned long long now = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((uint32_t)(now >> 32) != c || (uint32_t)now <= SK_CHUNK_G) break;
+			__builtin_amdgcn_s_sleep(2);
+		}
+		if (__hip_atomic_load(pool.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ERR_POOL_FULL) return ~0ull;
+	}
+	atomicOr(pool.err, (uint32_t)ERR_POOL_FULL);
+	return ~0ull;
+}
+
+/* 16 bases starting at base index x of a 2-bit packed array (16 bases per dword, first base in the top bits) */
+__device__ __forceinline__ uint32_t sk_bases16(const uint32_t *pk, uint32_t x) {
+	const uint32_t g = x >> 4, s = 2u * (x & 15u);
+	const uint64_t two = ((uint64_t)pk[g] << 32) | pk[g + 1];
+	return (uint32_t)((two << s) >> 32);
+}
+/* 16 flags starting at index x of a bit array kept as one u16 per 16 positions (bit b = position 16 g + b) */
+__device__ __forceinline__ uint32_t sk_flags16(const uint16_t *a, uint32_t x) {
+	const uint32_t g = x >> 4, s = x & 15u;
+	return (((uint32_t)a[g] | ((uint32_t)a[g + 1] << 16)) >> s) & 0xffffu;
+}
+
+template <int W> struct SkRoll { Roller<W> r; };
+
+/* LDS of one wavefront: quality chars of the tile, bases packed to 2 bits, N flags, (quality below the floor | quality equal
+ * to the one before) flags, and per position of the current window the minimizer hash and the f32 weight of its k-mer */
+static const int SK_Q_BYTES = TILE_BUF;                       /* 9856 */
+static const int SK_GROUPS = TILE_BUF / 16 + 8;               /* 16-base groups incl. padding: 624 */
+static const int SK_WAVE_LDS = (SK_Q_BYTES + SK_GROUPS * 4 + SK_GROUPS * 2 + SK_GROUPS * 4 + 2 * SK_WINDOW * 64 * 4 + 64 + 15) & ~15;
+static const size_t SK_EXTRACT_SMEM = (size_t)SK_WAVES * SK_WAVE_LDS;
+
+template <int W, int WIN, bool FILT>
+__global__ __launch_bounds__(SK_WAVES * 64, 1)
+void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	__shared__ double sP[256], sPk[256];
+	__shared__ SkSlab s_slab[SK_WAVES];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int i = threadIdx.x; i < 256; i += blockDim.x) { sP[i] = p.P[i]; sPk[i] = sp.Pk[i]; }
+	uint8_t *wb = smem + (size_t)wave * SK_WAVE_LDS;
+	uint8_t *tq = wb;                                                   /* quality chars                          */
+	uint32_t *pk = (uint32_t *)(wb + SK_Q_BYTES);                       /* [SK_GROUPS] packed bases               */
+	uint32_t *qe = pk + SK_GROUPS;                                      /* [SK_GROUPS] low: q < floor, high: q == previous q */
+	uint16_t *nm = (uint16_t *)(qe + SK_GROUPS);                        /* [SK_GROUPS] N flags                    */
+	uint32_t *mhr = (uint32_t *)(wb + SK_Q_BYTES + SK_GROUPS * 10 + 8);   /* [SK_WINDOW][64] minimizer hash         */
+	float *wtr = (float *)(mhr + SK_WINDOW * 64);                       /* [SK_WINDOW][64] weight                 */
+	SkSlab *slab = &s_slab[wave];
+	if (lane == 0) { slab->base[0] = atomicAdd(pool.head, 64u); slab->base[1] = atomicAdd(pool.head, 64u); slab->next = 0; }
+	__syncthreads();                       /* the only block-wide barrier; waves are independent below */
+
+	const uint32_t k = p.k, m = sp.m;
+	const uint32_t mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+	const uint32_t mtop = 2 * (m - 1);
+	unsigned long long nRaw = 0, nGood = 0, nSub = 0;
+	const uint64_t n_items = rv.u_start ? rv.n_units : rv.n_reads;
+	const uint64_t n_tiles = (n_items + 63) / 64;
+	for (uint64_t tile = (uint64_t)blockIdx.x * SK_WAVES + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * SK_WAVES) {
+	const uint64_t r0 = tile * 64;
+	const uint32_t nr = (uint32_t)((n_items - r0) < 64 ? (n_items - r0) : 64);
+	const bool have = (uint32_t)lane < nr;
+	uint64_t myStart = 0, myEnd = 0, myRead = 0;
+	bool myDiscard = true, myRefQual = false;
+	if (have) {
+		if (rv.u_start) {
+			myStart = rv.u_start[r0 + lane]; myEnd = rv.u_end[r0 + lane]; myRead = rv.u_read[r0 + lane];
+			const uint64_t rs = rv.offsets[myRead];
+			myRefQual = rv.quals && rv.offsets[myRead + 1] > rs && rv.quals[rs] == 127;
+		} else {
+			myRead = r0 + lane;
+			myStart = rv.offsets[myRead];
+			myEnd = rv.offsets[myRead + 1];
+		}
+		myDiscard = rv.discarded ? (rv.discarded[myRead] != 0) : false;
+	}
+	uint32_t tRaw = 0, tGood = 0;
+
+	uint32_t done = 0;
+	while (done < nr) {
+		const uint64_t B0 = __shfl(myStart, (int)done, 64);
+		const bool fits = have && (uint32_t)lane >= done && (myEnd - B0 <= (uint64_t)TILE_SPAN);
+		unsigned long long fm = __ballot(fits) >> done;
+		uint32_t n = (uint32_t)__builtin_ctzll(~fm);          /* run of fitting reads starting at 'done' */
+		if (n > nr - done) n = nr - done;
+		if (n == 0) {                                        /* read longer than a tile */
+			if (lane == 0) atomicOr(p.err, (uint32_t)ERR_READ_TOO_LONG);
+			done += 1;
+			continue;
+		}
+		const uint64_t B1 = __shfl(myEnd, (int)(done + n - 1), 64);
+		const uintptr_t gb = (uintptr_t)rv.bases + B0, gq = (uintptr_t)rv.quals + B0;
+		const uintptr_t ab = gb & ~(uintptr_t)15, aq = gq & ~(uintptr_t)15;
+		const uint32_t nb16 = (uint32_t)(((uintptr_t)rv.bases + B1 - ab + 15) >> 4);
+		const bool haveQuals = rv.quals != nullptr;
+		const uint32_t nq16 = haveQuals ? (uint32_t)(((uintptr_t)rv.quals + B1 - aq + 15) >> 4) : 0u;
+		/* stage the tile: 16 bytes per lane and round, coalesced.  Bases leave as 2 bits each plus an N flag, qualities are
+		 * kept as they are (the weight chain multiplies by table entries of them) plus two flags per position */
+		{
+			const uint4 *gbp = (const uint4 *)(rv.bases + (ptrdiff_t)(ab - (uintptr_t)rv.bases));
+			const uint4 *gqp = (const uint4 *)(rv.quals + (ptrdiff_t)(aq - (uintptr_t)rv.quals));
+			constexpr int STG = (TILE_BUF / 16 + 63) / 64;
+			uint32_t carryq = 0x100;           /* last quality of the previous round's last lane: no match at the very start */
+#pragma unroll 2
+			for (int c = 0; c < STG; c++) {
+				if (64u * c >= nb16 && 64u * c >= nq16) break;
+				const uint32_t idx = (uint32_t)lane + 64u * c;
+				uint4 vb = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
+				if (idx < nb16) vb = gbp[idx];
+				if (idx < nq16) vq = gqp[idx];
+				{
+					const uint32_t w4[4] = {vb.x, vb.y, vb.z, vb.w};
+					uint32_t packed = 0, nflags = 0;
+#pragma unroll
+					for (int b = 0; b < 16; b++) {
+						const uint32_t code = base_code((uint8_t)(w4[b >> 2] >> (8 * (b & 3))));
+						packed |= (code & 3u) << (30 - 2 * b);          /* markup packs as A */
+						nflags |= (code >> 2) << b;
+					}
+					if (idx < (uint32_t)SK_GROUPS) { pk[idx] = packed; nm[idx] = (uint16_t)nflags; }
+				}
+				if (haveQuals) {
+					const uint32_t w4[4] = {vq.x, vq.y, vq.z, vq.w};
+					uint32_t prevq = (uint32_t)__shfl_up((int)(vq.w >> 24), 1, 64);
+					if (lane == 0) prevq = carryq;
+					uint32_t low = 0, eq = 0;
+#pragma unroll
+					for (int b = 0; b < 16; b++) {
+						const uint32_t q = (w4[b >> 2] >> (8 * (b & 3))) & 0xffu;
+						low |= (q < p.qzero ? 1u : 0u) << b;
+						eq |= (q == prevq ? 1u : 0u) << b;
+						prevq = q;
+					}
+					if (idx < (uint32_t)SK_GROUPS) qe[idx] = low | (eq << 16);
+					if (idx < nq16) *(uint4 *)(tq + 16u * idx) = vq;
+					carryq = (uint32_t)__builtin_amdgcn_readlane((int)(vq.w >> 24), 63);
+				}
+			}
+			/* two groups of padding behind the data so that window reads of the last positions stay defined */
+			if (lane < 4) { const uint32_t g = nb16 + (uint32_t)lane; if (g < (uint32_t)SK_GROUPS) { pk[g] = 0; nm[g] = 0; } const uint32_t g2 = nq16 + (uint32_t)lane; if (g2 < (uint32_t)SK_GROUPS) qe[g2] = 0; }
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+		const bool active = have && (uint32_t)lane >= done && (uint32_t)lane < done + n && !myDiscard;
+		const uint32_t L = active ? (uint32_t)(myEnd - myStart) : 0;
+		const uint32_t rbOff = active ? (uint32_t)(gb - ab) + (uint32_t)(myStart - B0) : 0u;
+		const uint32_t rqOff = active ? (uint32_t)(gq - aq) + (uint32_t)(myStart - B0) : 0u;
+		const uint8_t *rq = tq + rqOff;
+		uint32_t Lmax = L;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { uint32_t x = __shfl_xor(Lmax, o, 64); Lmax = x > Lmax ? x : Lmax; }
+
+		const bool isRef = !haveQuals || (rv.u_start ? myRefQual : (L > 0 && rq[0] == 127));
+		const uint64_t ord0 = rv.stream_base + myStart;      /* + k-mer index = stream ordinal of the occurrence */
+		/* weight chain */
+		double w = 0.0;
+		uint32_t zc = 0;
+		uint64_t zbits[3] = {0, 0, 0};
+		uint32_t qrun = 0;
+		/* minimizer pipeline: runs sp.off positions behind the k-mer pipeline */
+		uint32_t mf = 0, mr = 0;
+		uint32_t hs[WIN];
+#pragma unroll
+		for (int i = 0; i < WIN; i++) hs[i] = 0xffffffffu;
+		uint32_t pref = 0xffffffffu;
+		/* the run in progress */
+		bool runOpen = false, runUniform = true, runInWin = false;
+		uint32_t runStart = 0, runN = 0, runMh = 0, runW0 = 0;
+		SkRoll<FILT ? W : 1> fr;           /* forward / reverse-complement words: only the filters need the k-mer itself */
+		if (FILT) fr.r.init(k);
+
+		for (uint32_t jb = 0; jb < Lmax || __any(runOpen); jb += SK_WINDOW) {
+			/* the window's 16 positions of this lane's read: bases, N flags, quality flags; and the bases sp.off positions back */
+			const uint32_t pkw = sk_bases16(pk, rbOff + jb);
+			const uint32_t nmw = sk_flags16(nm, rbOff + jb);
+			uint32_t qlow = 0, qeq = 0xffffu;
+			if (haveQuals) {
+				const uint32_t xq = rqOff + jb, g = xq >> 4, s = xq & 15u;
+				const uint32_t a = qe[g], b = qe[g + 1];
+				qlow = (((a & 0xffffu) | (b << 16)) >> s) & 0xffffu;
+				qeq = (((a >> 16) | (b & 0xffff0000u)) >> s) & 0xffffu;
+			}
+			/* (the very first positions of a tile have nothing sp.off bases back: zeros, they end no m-mer a k-mer looks at) */
+			const int32_t xm = (int32_t)(rbOff + jb) - (int32_t)sp.off;
+			const uint32_t mpkw = xm >= 0 ? sk_bases16(pk, (uint32_t)xm) : (xm > -16 ? sk_bases16(pk, 0u) >> (2 * (uint32_t)(-xm)) : 0u);
+			/* the run carried into this window (always uniform) */
+			const bool cinOpen = runOpen; const uint32_t cinStart = runStart, cinN = runN, cinMh = runMh, cinW0 = runW0;
+			uint32_t Sm = 0, Vm = 0, Cm = 0;
+			runInWin = false;
+#pragma unroll
+			for (int t = 0; t < SK_WINDOW; t++) {
+				const uint32_t j = jb + t;
+				const bool in = j < L;
+				const uint32_t code = (pkw >> (30 - 2 * t)) & 3u;
+				const bool z = in && ((((nmw >> t) & 1u) != 0) || (!isRef && ((qlow >> t) & 1u) != 0));
+				zbits[2] = (zbits[2] << 1) | (zbits[1] >> 63); zbits[1] = (zbits[1] << 1) | (zbits[0] >> 63); zbits[0] = (zbits[0] << 1) | (z ? 1ull : 0ull);
+				zc += z ? 1u : 0u;
+				zc -= (uint32_t)((zbits[k >> 6] >> (k & 63)) & 1ull);   /* position j-k leaves the window (0 while j < k) */
+				qrun = (j > 0 && (isRef || ((qeq >> t) & 1u))) ? qrun + 1 : 0;
+				if (FILT) fr.r.push(code);
+				/* minimizer: m-mer ending sp.off positions back, canonical, hashed; minimum of the last WIN of them */
+				{
+					const uint32_t mc = (mpkw >> (30 - 2 * t)) & 3u;
+					mf = ((mf << 2) | mc) & mmask;
+					mr = (mr >> 2) | ((3u - mc) << mtop);
+					const uint32_t x = sk_mmer_hash(mf < mr ? mf : mr);
+					const int r = t % WIN;
+					pref = r == 0 ? x : (x < pref ? x : pref);
+					hs[r] = x;
+				}
+				uint32_t M = pref;
+				{
+					const int r = t % WIN;
+					if (r < WIN - 1) { const uint32_t sfx = hs[r + 1 < WIN ? r + 1 : 0]; M = sfx < M ? sfx : M; }
+					else {
+#pragma unroll
+						for (int u = WIN - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
+					}
+				}
+				bool valid = false;
+				float wf = 0.0f;
+				if (in && j + 1 >= k) {
+					const uint32_t i = j + 1 - k;
+					if (zc > 0) w = 0.0;
+					else if (isRef) w = 1.0;
+					else if ((i & 1023u) == 0 || w == 0.0) {
+						if (qrun + 1 >= k) w = sPk[rq[j]];                 /* k equal qualities: the table holds the same sequence of products */
+						else { w = 1.0; for (uint32_t jj = 0; jj < k; jj++) w *= sP[rq[i + jj]]; }
+					} else if (qrun < k) {
+						/* x / x == 1.0 exactly, so equal qualities leave w unchanged; a run of k+1 equal chars proves that without a load */
+						const uint32_t q = rq[j], qo = rq[i - 1];
+						if (qo != q) { const double change = sP[q] / sP[qo]; w *= change; }
+					}
+					wf = (float)w;
+					bool mine = true;
+					if (FILT) {
+						const Key<FILT ? W : 1> kf = fr.r.getFwd(), kr = fr.r.getRc();
+						const Key<FILT ? W : 1> canon = key_le<FILT ? W : 1>(kf, kr) ? kf : kr;
+						const uint64_t hash = key_hash<FILT ? W : 1>(canon, p.kb);
+						if (p.subsample > 1 && hash % p.subsample != 0) mine = false;
+						if (p.world > 1 && distributed_thread_id(hash, p.world) != p.rank) mine = false;
+						if (p.num_parts > 1 && distributed_thread_id(hash, p.num_parts) != p.part_idx) mine = false;
+						if (mine && (p.sub_wnb | p.sub_snb)) {       /* subtractingReference->exists(least): skipped before rawKmers++ */
+							MapView<FILT ? W : 1> sw, ss;
+							sw.start = p.sub_wstart; sw.keys = p.sub_wkeys; sw.vals = p.sub_wvals; sw.sweight = nullptr; sw.nb = p.sub_wnb; sw.vw = p.sub_vw;
+							ss.start = p.sub_sstart; ss.keys = p.sub_skeys; ss.vals = nullptr; ss.sweight = p.sub_sweight; ss.nb = p.sub_snb; ss.vw = 0;
+							if (maps_count<FILT ? W : 1>(sw, ss, canon, hash) > 0) { mine = false; nSub++; }
+						}
+					}
+					if (mine) {
+						tRaw++;
+						valid = wf > p.min_weight;
+						if (valid) tGood++;
+					}
+					/* run logic: the k-mer continues the run in progress if it is good, has the same minimizer and -- for a run that
+					 * began before this window, whose earlier weights are no longer at hand -- the same weight */
+					const uint32_t wbits = __float_as_uint(wf);
+					if (valid) {
+						const bool wsame = wbits == runW0;
+						const bool cont = runOpen && M == runMh && runN < SK_MAX_N && (wsame || runInWin);
+						if (cont) { runN++; if (!wsame) { runUniform = false; Cm |= 1u << t; } }
+						else { Sm |= 1u << t; runOpen = true; runStart = i; runN = 1; runMh = M; runW0 = wbits; runUniform = true; runInWin = true; }
+						Vm |= 1u << t;
+					} else runOpen = false;
+				} else if (!in) runOpen = false;
+				mhr[t * 64 + lane] = M;
+				wtr[t * 64 + lane] = wf;
+			}
+			/* a run with unequal weights ends with its window (its weights live in this window's ring) */
+			const bool openEnd = runOpen && runUniform;
+			if (runOpen && !runUniform) runOpen = false;
+			/* gather: every run that ended in this window becomes a record of its list */
+			const uint32_t brk = (~Vm | Sm) & 0xffffu;
+			bool pendC = false; uint32_t lead = 16;
+			if (cinOpen) { lead = (uint32_t)__builtin_ctz(brk | 0x10000u); pendC = lead < 16; }
+			uint32_t Srem = Sm;
+			if (openEnd && runInWin && Sm) Srem &= ~(1u << (31 - __builtin_clz(Sm)));      /* the run still open is the last one begun */
+			while (__any(pendC || Srem)) {
+				bool emit = false; uint32_t eStart = 0, eN = 0, eMh = 0, eW0 = 0, pos = 0; bool eUni = true;
+				if (pendC) { pendC = false; emit = true; eStart = cinStart; eN = cinN + lead; eMh = cinMh; eW0 = cinW0; }
+				else if (Srem) {
+					pos = (uint32_t)__builtin_ctz(Srem); Srem &= Srem - 1;
+					const uint32_t end = pos + 1 + (uint32_t)__builtin_ctz((brk >> (pos + 1)) | (1u << (15 - pos)));
+					emit = true; eN = end - pos; eStart = jb + pos + 1 - k; eMh = mhr[pos * 64 + lane]; eW0 = __float_as_uint(wtr[pos * 64 + lane]);
+					eUni = ((Cm >> (pos + 1)) & ((1u << (eN - 1)) - 1u)) == 0;
+				}
+				if (emit) {
+					const uint32_t nbg = sk_base_granules(eN, k), nwg = eUni ? 0u : (eN + 3) / 4, g = 1 + nbg + nwg;
+					const uint64_t at = sk_append(sp.state, sk_list_of(eMh, sp.list_bits), g, slab, pool);
+					if (at != ~0ull) {
+						uint4 *dst = (uint4 *)pool.base + at;
+						const uint64_t ord = ord0 + eStart;
+						dst[0] = make_uint4((uint32_t)ord, (uint32_t)(ord >> 32) | (eN << 8) | ((eUni ? 1u : 0u) << 16) | (g << 17), eMh, eW0);
+						const uint32_t xb = rbOff + eStart;
+						for (uint32_t b = 0; b < nbg; b++)
+							dst[1 + b] = make_uint4(sk_bases16(pk, xb + 64 * b), sk_bases16(pk, xb + 64 * b + 16), sk_bases16(pk, xb + 64 * b + 32), sk_bases16(pk, xb + 64 * b + 48));
+						for (uint32_t b = 0; b < nwg; b++) {
+							uint32_t v[4];
+#pragma unroll
+							for (int u = 0; u < 4; u++) { const uint32_t tt = pos + 4 * b + u; v[u] = tt < 16 ? __float_as_uint(wtr[tt * 64 + lane]) : 0u; }
+							dst[1 + nbg + b] = make_uint4(v[0], v[1], v[2], v[3]);
+						}
+					}
+				}
+			}
+			/* refill the slab cache of the wavefront (uniform) */
+			if (slab->next >= 64u) {
+				__builtin_amdgcn_wave_barrier();
+				if (lane == 0) { const uint32_t used = slab->next; slab->base[0] = slab->base[1]; slab->base[1] = atomicAdd(pool.head, 64u); slab->next = used >= 128u ? 64u : used - 64u; }
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+		done += n;
+		__builtin_amdgcn_wave_barrier();   /* all lanes are done reading the tile before it is overwritten */
+	}
+	nRaw += tRaw; nGood += tGood;
+	}
+	/* chunks of the slabs nobody took belong to no list */
+	__builtin_amdgcn_wave_barrier();
+	{
+		const uint32_t used = slab->next < 128u ? slab->next : 128u;
+		for (uint32_t idx = used + (uint32_t)lane; idx < 128u; idx += 64) { const uint32_t c = slab->base[idx >> 6] + (idx & 63u); if (c < pool.cap) { pool.chunk_list[c] = NO_CHUNK; pool.chunk_count[c] = 0; } }
+	}
+	nRaw = wave_sum(nRaw); nGood = wave_sum(nGood);
+	if (lane == 0) { atomicAdd(&p.stats->raw, nRaw); atomicAdd(&p.stats->good, nGood); }
+	if (FILT) { nSub = wave_sum(nSub); if (lane == 0 && nSub) atomicAdd(&p.stats->subtracted, nSub); }
+}
+
+/* reverse complement of a left-justified k-mer of W words, left-justified again */
+template <int W> __device__ __forceinline__ Key<W> key_revcomp(const Key<W> &f, uint32_t k) {
+	Key<W> r;
+#pragma unroll
+	for (int i = 0; i < W; i++) {
+		uint64_t x = f.w[W - 1 - i];
+		x = ((uint64_t)__builtin_bitreverse32((uint32_t)x) << 32) | __builtin_bitreverse32((uint32_t)(x >> 32));      /* bit reversal of 64 bits */
+		x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);                                  /* bits of a base back in order */
+		r.w[i] = ~x;
+	}
+	/* the string now ends with the complement of the pad: shift it out */
+	const uint32_t sh = 64u * W - 2u * k;
+	const uint32_t ws = sh >> 6, bs = sh & 63u;
+	Key<W> o;
+#pragma unroll
+	for (int i = 0; i < W; i++) {
+		const int a = i + (int)ws;
+		const uint64_t hi = a < W ? r.w[a < W ? a : 0] : 0ull, lo = a + 1 < W ? r.w[a + 1 < W ? a + 1 : 0] : 0ull;
+		o.w[i] = bs ? (hi << bs) | (lo >> (64 - bs)) : hi;
+	}
+	return o;
+}
+
+/* ------------------------------------------------------------------ count over super-k-mer lists */
+/* One block per list, lists taken SK_LBATCH at a time.  The list's chunks are staged SK_STAGE_CHUNKS at a time (the next group
+ * is held in registers meanwhile), every wavefront finds the record starts of one chunk by following the granule counts in
+ * the headers, the records' k-mer counts are scanned, and then every thread expands and inserts k-mers t, t + 256, ... of the
+ * group: the record's bases give the forward word, key_revcomp the other strand, the smaller one is the key.  Table, sub-pass
+ * splitting and the emission of kept entries are those of count_kernel (COUNT_DIR values). */
+static const int SK_STAGE_CHUNKS = 4;                          /* = wavefronts of the block */
+static const int SK_STAGE_G = SK_STAGE_CHUNKS * SK_CHUNK_G;    /* 256 granules = one per thread */
+static const int SK_EXPAND_CAP = 2048;                         /* k-mers of one staged group handled per pass */
+static const uint32_t SK_LBATCH = 8;
+
+template <int W, int LOG2S>
+__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0)) + (size_t)SK_STAGE_G * 16 + SK_EXPAND_CAP + SK_STAGE_G * 2 + 64; }
+
+template <int W, int LOG2S>
+__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10) ? 3 : 1)
+void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
+                     CountOut out, FinalizeParams f, unsigned int *work_counter) {
+	constexpr int S = 1 << LOG2S;
+	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
+	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
+	uint64_t *tkeys = (uint64_t *)csm;                                 /* [S][W] */
+	unsigned long long *tcnt = (unsigned long long *)(tkeys + (size_t)S * W);
+	double *twsum = (double *)(tcnt + S);
+	unsigned long long *tfirst = (unsigned long long *)(twsum + S);
+	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
+	uint4 *stage = (uint4 *)(tstate + (W > 1 ? S : 0));                /* 16-byte aligned: every table array is a multiple of 16 bytes */
+	uint8_t *owner = (uint8_t *)(stage + SK_STAGE_G);                  /* [SK_EXPAND_CAP] staged granule of the record a k-mer belongs to */
+	uint16_t *roff = (uint16_t *)(owner + SK_EXPAND_CAP);              /* [SK_STAGE_G] first k-mer slot of the record starting at a granule */
+	uint16_t *s_kept = (uint16_t *)stage;                              /* emission only: aliases the staging area (S <= 2048 entries) */
+	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns, s_nk;
+	__shared__ unsigned long long s_wbase, s_sbase;
+	__shared__ unsigned long long s_wpos, s_wend, s_spos, s_send;
+	__shared__ unsigned long long s_holeW0, s_holeW1, s_holeS0, s_holeS1;
+	__shared__ uint32_t s_stackBits[40], s_stackVal[40];
+	__shared__ unsigned long long s_ls[SK_LBATCH + 1];
+	__shared__ uint32_t s_wtot[SK_STAGE_CHUNKS];
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const uint32_t vw = 3;
+	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;
+	constexpr unsigned long long OSLAB = 8192;
+	if (t == 0) { s_wpos = s_wend = 0; s_spos = s_send = 0; }
+	lds_barrier();
+	const uint4 *poolg = (const uint4 *)pool.base;
+
+	for (;;) {
+		if (t == 0) s_list = atomicAdd(work_counter, SK_LBATCH);
+		lds_barrier();
+		const uint64_t lfirst = s_list;
+		if (lfirst >= n_lists) break;
+		const uint32_t nl = (uint32_t)(n_lists - lfirst < (uint64_t)SK_LBATCH ? n_lists - lfirst : (uint64_t)SK_LBATCH);
+		if ((uint32_t)t <= nl) s_ls[t] = list_start[lfirst + t];
+		lds_barrier();
+		for (uint32_t lj = 0; lj < nl; lj++) {
+			const uint64_t c0 = s_ls[lj], c1 = s_ls[lj + 1];
+			if (c0 == c1) continue;
+			lds_barrier();
+			if (t == 0) { s_sp = 1; s_stackBits[0] = 0; s_stackVal[0] = 0; }
+			lds_barrier();
+			while (s_sp > 0) {
+				const uint32_t bits = s_stackBits[s_sp - 1], val = s_stackVal[s_sp - 1];
+				lds_barrier();
+				if (t == 0) { s_sp--; s_claimed = 0; s_overflow = 0; s_nw = 0; s_ns = 0; }
+				for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; }
+				lds_barrier();
+				const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
+				/* the first group of the list: requested now, landed in `nxt` */
+				auto load_group = [&](uint64_t cb) -> uint4 {
+					const uint64_t ci = cb + (uint64_t)wv;
+					uint4 v = make_uint4(0, 0, 0, 0);
+					if (ci < c1) { const uint64_t d = list_chunks[ci]; if ((uint32_t)lane < (uint32_t)(d >> 32)) v = poolg[(size_t)(uint32_t)d * SK_CHUNK_G + lane]; }
+					return v;
+				};
+				auto group_count = [&](uint64_t cb) -> uint32_t { const uint64_t ci = cb + (uint64_t)wv; return ci < c1 ? (uint32_t)(list_chunks[ci] >> 32) : 0u; };
+				uint4 nxt = load_group(c0);
+				uint32_t nxtCount = group_count(c0);
+				for (uint64_t cb = c0; cb < c1 && !s_overflow && s_claimed <= LIMIT; cb += SK_STAGE_CHUNKS) {
+					const uint4 cur = nxt; const uint32_t curCount = nxtCount;
+					stage[t] = cur;
+					if (cb + SK_STAGE_CHUNKS < c1) { nxt = load_group(cb + SK_STAGE_CHUNKS); nxtCount = group_count(cb + SK_STAGE_CHUNKS); }
+					/* record starts of this wavefront's chunk: follow the granule counts from granule 0 */
+					const uint32_t glen = (cur.y >> 17) & 0x7fu;
+					unsigned long long starts = 0;
+					for (uint32_t pos = 0; pos < curCount; ) {
+						starts |= 1ull << pos;
+						const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos);
+						pos += step ? step : SK_CHUNK_G;        /* a zero would never end: a corrupt chunk is dropped */
+					}
+					const bool isStart = (starts >> lane) & 1ull;
+					const uint32_t myN = isStart ? (cur.y >> 8) & 0xffu : 0u;
+					/* exclusive scan of the k-mer counts over the wavefront, then over the four wavefronts */
+					uint32_t incl = myN;
+#pragma unroll
+					for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += x; }
+					if (lane == 63) s_wtot[wv] = incl;
+					lds_barrier();
+					uint32_t wbase = 0, total = 0;
+#pragma unroll
+					for (int i = 0; i < SK_STAGE_CHUNKS; i++) { const uint32_t x = s_wtot[i]; if (i < wv) wbase += x; total += x; }
+					const uint32_t myOff = wbase + incl - myN;
+					/* groups with more k-mers than the expansion table holds are done in passes over [base, base + SK_EXPAND_CAP) */
+					for (uint32_t base = 0; base < total; base += SK_EXPAND_CAP) {
+						if (isStart) {
+							roff[t] = (uint16_t)(myOff - base);      /* may wrap for records that begin before this pass: only the difference is used */
+							for (uint32_t q = 0; q < myN; q++) { const uint32_t slot = myOff + q; if (slot >= base && slot < base + SK_EXPAND_CAP) owner[slot - base] = (uint8_t)t; }
+						}
+						lds_barrier();
+						const uint32_t cnt = total - base < (uint32_t)SK_EXPAND_CAP ? total - base : (uint32_t)SK_EXPAND_CAP;
+						uint32_t claimedHere = 0;
+						for (uint32_t e = (uint32_t)t; e < cnt; e += COUNT_THREADS) {
+							const uint32_t g0 = owner[e];
+							const uint32_t j = (uint32_t)(uint16_t)((uint16_t)e - roff[g0]);           /* k-mer index inside its record */
+							const uint4 hd = stage[g0];
+							const uint32_t n = (hd.y >> 8) & 0xffu;
+							const uint32_t nbg = sk_base_granules(n, k);
+							const uint32_t *bw = (const uint32_t *)(stage + g0 + 1);                     /* the record's bases, 16 per dword */
+							/* forward word(s): 32 * W bases from base j on, cut to k */
+							Key<W> kf;
+							{
+								const uint32_t d0 = j >> 4, sft = 2u * (j & 15u);
+#pragma unroll
+								for (int wi = 0; wi < W; wi++) {
+									const uint32_t a = bw[d0 + 2 * wi], b = bw[d0 + 2 * wi + 1], c = bw[d0 + 2 * wi + 2];
+									const uint64_t hi = ((uint64_t)a << 32) | b;
+									kf.w[wi] = sft ? (hi << sft) | ((uint64_t)c >> (32 - sft)) : hi;
+								}
+								const uint32_t kbits = 2u * k;
+#pragma unroll
+								for (int wi = 0; wi < W; wi++) {
+									const uint32_t lo = 64u * wi;
+									if (kbits <= lo) kf.w[wi] = 0;
+									else if (kbits < lo + 64u) kf.w[wi] &= ~0ull << (lo + 64u - kbits);
+								}
+							}
+							const Key<W> kr = key_revcomp<W>(kf, k);
+							const bool fwd = key_le<W>(kf, kr);
+							const Key<W> key = fwd ? kf : kr;
+							const uint64_t h = slot_hash<W>(key.w);
+							if (((uint32_t)(h >> 20) & subMask) != val) continue;
+							const float wa = (hd.y >> 16) & 1u ? __uint_as_float(hd.w) : __uint_as_float(((const uint32_t *)(stage + g0 + 1 + nbg))[j]);
+							const uint64_t ordinal = ((uint64_t)hd.x | ((uint64_t)(hd.y & 0xffu) << 32)) + j;
+							uint32_t s = (uint32_t)(h >> (64 - LOG2S));
+							bool placed = false;
+							for (int probe = 0; probe < S && !placed; probe++) {
+								if constexpr (W == 1) {
+									uint64_t curk = tkeys[s];
+									if (curk == EMPTY_KEY) {
+										const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key.w[0]);
+										if (old == EMPTY_KEY) { claimedHere++; placed = true; break; }
+										curk = old;
+									}
+									if (curk == key.w[0]) { placed = true; break; }
+								} else {
+									uint32_t st = __hip_atomic_load(&tstate[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+									if (st == 0) {
+										const uint32_t old = atomicCAS(&tstate[s], 0u, 1u);
+										if (old == 0) {
+#pragma unroll
+											for (int q = 0; q < W; q++) tkeys[(size_t)s * W + q] = key.w[q];
+											__hip_atomic_store(&tstate[s], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+											claimedHere++;
+											placed = true; break;
+										}
+										st = old;
+									}
+									if (st == 1) { probe--; continue; }      /* writer publishes unconditionally: re-poll the same slot */
+									bool eq = true;
+#pragma unroll
+									for (int q = 0; q < W; q++) eq = eq && (tkeys[(size_t)s * W + q] == key.w[q]);
+									if (eq) { placed = true; break; }
+								}
+								s = (s + 1) & (S - 1);
+							}
+							if (!placed) { s_overflow = 1; continue; }      /* table full */
+							atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(fwd ? 1 : 0) << 32));
+							atomicAdd(&twsum[s], (double)wa);
+							atomicMin(&tfirst[s], first_pack(ordinal, fwd, wa));
+						}
+						claimedHere = (uint32_t)wave_sum((unsigned long long)claimedHere);
+						if (lane == 0 && claimedHere) atomicAdd(&s_claimed, claimedHere);
+						lds_barrier();
+					}
+					lds_barrier();
+				}
+				lds_barrier();
+				if (s_overflow || s_claimed > LIMIT) {       /* split this sub-pass in two by one more hash bit */
+					if (t == 0) {
+						if (bits >= 20) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
+						else {
+							s_stackBits[s_sp] = bits + 1; s_stackVal[s_sp] = val; s_sp++;
+							s_stackBits[s_sp] = bits + 1; s_stackVal[s_sp] = val | (1u << bits); s_sp++;
+						}
+					}
+					lds_barrier();
+					continue;
+				}
+				/* emit: as count_kernel (weak entries from the front of s_kept, singletons from its back) */
+				const uint32_t singC = f.has_singletons ? (f.min_depth > 1 ? 0u : 2u) : 3u;
+				const uint32_t weakMin = ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1) ? f.min_depth : 0u;
+				uint32_t cls[S / COUNT_THREADS];
+#pragma unroll
+				for (int i = 0; i < S / COUNT_THREADS; i++) {
+					const int s = i * COUNT_THREADS + t;
+					const bool used = W == 1 ? tkeys[s] != EMPTY_KEY : tstate[s] == 2;
+					const uint32_t count = (uint32_t)tcnt[s];
+					uniq += used ? 1u : 0u;
+					single += (used && count == 1) ? 1u : 0u;
+					cls[i] = !used ? 0u : ((count == 1 && singC != 3u) ? singC : (count < weakMin ? 0u : 1u));
+				}
+				const unsigned long long below = (1ull << lane) - 1;
+#pragma unroll
+				for (int i = 0; i < S / COUNT_THREADS; i++) {
+					const int s = i * COUNT_THREADS + t;
+					const uint32_t c = cls[i];
+					const unsigned long long mw = __ballot(c == 1), ms = __ballot(c == 2);
+					if ((mw | ms) == 0) continue;
+					uint32_t bw = 0, bs = 0;
+					if (lane == 0) { if (mw) bw = atomicAdd(&s_nw, (uint32_t)__builtin_popcountll(mw)); if (ms) bs = atomicAdd(&s_ns, (uint32_t)__builtin_popcountll(ms)); }
+					bw = (uint32_t)__shfl((int)bw, 0, 64); bs = (uint32_t)__shfl((int)bs, 0, 64);
+					if (c == 1) s_kept[bw + (uint32_t)__builtin_popcountll(mw & below)] = (uint16_t)s;
+					else if (c == 2) s_kept[S - 1 - (bs + (uint32_t)__builtin_popcountll(ms & below))] = (uint16_t)s;
+				}
+				lds_barrier();
+				if (t == 0) {
+					s_holeW0 = s_holeW1 = 0; s_holeS0 = s_holeS1 = 0;
+					if (s_nw && s_wpos + s_nw > s_wend) {
+						s_holeW0 = s_wpos; s_holeW1 = s_wend < out.wcap ? s_wend : out.wcap;
+						const unsigned long long g = s_nw > OSLAB ? s_nw : OSLAB; s_wpos = atomicAdd(out.wcursor, g); s_wend = s_wpos + g;
+					}
+					if (s_ns && s_spos + s_ns > s_send) {
+						s_holeS0 = s_spos; s_holeS1 = s_send < out.scap ? s_send : out.scap;
+						const unsigned long long g = s_ns > OSLAB ? s_ns : OSLAB; s_spos = atomicAdd(out.scursor, g); s_send = s_spos + g;
+					}
+					s_wbase = s_wpos; s_wpos += s_nw; keptW += s_nw;
+					s_sbase = s_spos; s_spos += s_ns; keptS += s_ns;
+					if (s_wend > out.wcap || s_send > out.scap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); s_nw = 0xffffffffu; }
+				}
+				lds_barrier();
+				for (unsigned long long e = s_holeW0 + t; e < s_holeW1; e += COUNT_THREADS) out.wvals[e * vw] = 0;
+				for (unsigned long long e = s_holeS0 + t; e < s_holeS1; e += COUNT_THREADS) out.sweight[e] = 0;
+				if (s_nw != 0xffffffffu) {
+					for (uint32_t e0 = (uint32_t)t & ~63u; e0 < s_nw; e0 += COUNT_THREADS) {
+						const uint32_t e = e0 + (uint32_t)lane;
+						const bool live = e < s_nw;
+						uint64_t bucket = 0;
+						if (live) {
+							const uint32_t s = s_kept[e];
+							Key<W> key;
+#pragma unroll
+							for (int q = 0; q < W; q++) key.w[q] = tkeys[(size_t)s * W + q];
+							bucket = key_hash<W>(key, f.kb) & (f.nb_weak - 1);
+							const unsigned long long cf = tcnt[s];
+							const uint64_t pos = s_wbase + e;
+#pragma unroll
+							for (int q = 0; q < W; q++) out.wkeys[pos * W + q] = key.w[q];
+							uint32_t fwdc = (uint32_t)(cf >> 32), cnt = (uint32_t)cf;
+							const unsigned long long fst = tfirst[s];
+							if (f.has_singletons && first_forward(fst)) fwdc -= 1;
+							if (cnt > 65535u) { cnt = 65535u; if (fwdc > 65534u) fwdc = 65534u; }
+							if (fwdc > 65535u) fwdc = 65535u;
+							uint32_t *v = out.wvals + pos * vw;
+							v[0] = cnt; v[1] = __float_as_uint((float)(f.has_singletons ? twsum[s] + first_weight_shift(fst) : twsum[s])); v[2] = fwdc;
+						}
+						bucket_count_add(out.weakCount, bucket, live);
+					}
+					for (uint32_t e0 = (uint32_t)t & ~63u; e0 < s_ns; e0 += COUNT_THREADS) {
+						const uint32_t e = e0 + (uint32_t)lane;
+						const bool live = e < s_ns;
+						uint64_t bucket = 0;
+						if (live) {
+							const uint32_t s = s_kept[S - 1 - e];
+							Key<W> key;
+#pragma unroll
+							for (int q = 0; q < W; q++) key.w[q] = tkeys[(size_t)s * W + q];
+							bucket = key_hash<W>(key, f.kb) & (f.nb_sing - 1);
+							const uint64_t pos = s_sbase + e;
+#pragma unroll
+							for (int q = 0; q < W; q++) out.skeys[pos * W + q] = key.w[q];
+							const float wf = (float)twsum[s];
+							out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
+						}
+						bucket_count_add(out.singCount, bucket, live);
+					}
+				}
+				lds_barrier();
+			}
+		}
+	}
+	lds_barrier();
+	for (unsigned long long e = s_wpos + t; e < s_wend && e < out.wcap; e += COUNT_THREADS) out.wvals[e * vw] = 0;
+	for (unsigned long long e = s_spos + t; e < s_send && e < out.scap; e += COUNT_THREADS) out.sweight[e] = 0;
+	uniq = wave_sum(uniq); single = wave_sum(single);
+	if (lane == 0) { if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single); }
+	if (t == 0) { if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS); }
+}
+
+}  // namespace kmr
+#endif

@@ -16,7 +16,7 @@ from refsemantics import median_trim_label, score_and_trim
 pytestmark = pytest.mark.gpu
 
 
-MODES = [1, 2]      # kmr_config.build_mode: 1 = open-addressed device table, 2 = streaming partition + LDS counting
+MODES = [1, 2, 3]   # kmr_config.build_mode: 1 = open-addressed device table, 2 = streaming partition + LDS counting, 3 = super-k-mer lists
 
 
 def product(cfg, mode=0, **tune):
@@ -24,6 +24,8 @@ def product(cfg, mode=0, **tune):
     for name, _ in cfg._fields_:
         setattr(c, name, getattr(cfg, name))
     c.build_mode = mode
+    if mode == 3 and (cfg.value_kind == KMR_VALUE_EXT or cfg.k < 13):
+        pytest.skip("build_mode 3 builds count / direction values at k >= 13")
     return ka.KmerSpectrum(c).tune(**tune)
 
 
