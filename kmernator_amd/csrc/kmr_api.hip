@@ -227,6 +227,9 @@ int sync_state(kmr_handle *h) {
 	uint32_t e = 0; DevStats s;
 	HIPCHK(h, hipMemcpy(&e, h->derr, sizeof(e), hipMemcpyDeviceToHost));
 	HIPCHK(h, hipMemcpy(&s, h->dstats, sizeof(s), hipMemcpyDeviceToHost));
+#ifdef KMR_DEBUG_HOOKS
+	if (h->superkmer_mode) { if (dbg()) fprintf(stderr, "sk_extract windows: %llu general, %llu fast\n", s.claimed, s.inserted); s.claimed = 0; s.inserted = 0; }
+#endif
 	h->stats.raw_kmers = s.raw + s.inserted; h->stats.raw_good_kmers = s.good + s.inserted; h->stats.discarded = s.raw - s.good;
 	h->occupied = s.claimed; h->pending_kmers = 0; h->subtracted = s.subtracted;
 	if (e & ERR_READ_TOO_LONG) return fail(h, KMR_ERR_UNSUPPORTED, "a read is longer than the per-wavefront LDS tile (" + std::to_string(TILE_SPAN) + " bases)");
@@ -1255,13 +1258,21 @@ template <int W, int WIN, bool FILT> int launch_sk_extract(kmr_handle *h, const 
 	HIPCHK(h, hipGetLastError());
 	return 0;
 }
-SkParams sk_params(kmr_handle *h) { SkParams sp; sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; return sp; }
+uint32_t sk_dbg_flags(const char *name) {
+#ifdef KMR_DEBUG_HOOKS
+	const char *e = getenv(name); return e ? (uint32_t)atoi(e) : 0u;
+#else
+	(void)name; return 0u;
+#endif
+}
+SkParams sk_params(kmr_handle *h) { SkParams sp; sp.dbg = sk_dbg_flags("KMR_SK_EXTRACT_DBG"); sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; return sp; }
 template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
 	const uint64_t n = rvAll.n_reads;
 	if (!h->sk_state) {
 		/* lists: about 1100 k-mers each, as the final lists of the two-level partition */
-		const uint64_t est = std::max<uint64_t>(total_bases, h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size));
-		uint32_t bits = 6; while (bits < 24 && (est >> bits) > h->tune.target_list / 2 + 76) bits++;
+		const uint64_t share = h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size);
+		const uint64_t est = share ? share : total_bases;         /* the caller's estimate of the k-mers (estimateRawKmers), else this call's bases */
+		uint32_t bits = 6; while (bits < 24 && (est >> bits) > h->tune.target_list / 2 + 200) bits++;
 		h->sk_bits = bits;
 		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8ull << bits));
 		hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(1ull << bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << bits);
@@ -1350,7 +1361,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		const size_t smem = sk_count_smem_bytes<W, COUNT_LOG2S>();
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 		if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, COUNT_THREADS, smem); fprintf(stderr, "sk_count<W=%d>: %d blocks per CU (LDS %zu), %llu lists, %u chunks\n", W, nb, smem, (unsigned long long)nl, nch); }
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"));
 		HIPCHK(h, hipGetLastError());
 		uint32_t cerr = 0;
 		HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(cur, cursors, 16, hipMemcpyDeviceToHost, h->stream));

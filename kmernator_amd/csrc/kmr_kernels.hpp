@@ -33,6 +33,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "kmr_key.hpp"
 
@@ -50,12 +51,22 @@ static const uint64_t NO_FIRST = ~0ull;
  * again (error <= 6e-8).  weightedCount of a promoted key is then (float)(q8 / 254.0) + the other weights (:658, :540-547). */
 static const int FIRST_ORD_SHIFT = 24;
 static const uint64_t MAX_STREAM_ORDINAL = (1ull << 40) - 1;
+/* q8 << 15 | r15 = floor(w * 254 * 2^15) for 0 < w <= 1, in integers: w * 254 is exact in 32 bits (24-bit mantissa x 8 bits),
+ * so this is the (unsigned char)(w * 254.0) of the reference's double arithmetic bit for bit, without fp64 instructions */
+__host__ __device__ __forceinline__ uint32_t first_weight_bits(float w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t bits = __float_as_uint(w);
+#else
+	uint32_t bits; memcpy(&bits, &w, 4);
+#endif
+	const uint32_t ex = (bits >> 23) & 0xffu;
+	if (ex == 0 || ex > 127u) return ex > 127u ? (254u << 15) : 0u;      /* 0 and denormals; nothing above 1.0 reaches a spectrum */
+	const uint32_t prod = ((bits & 0x7fffffu) | 0x800000u) * 254u;        /* mantissa * 254 < 2^32 */
+	const uint32_t sh = 8u + (127u - ex);                                  /* w * 254 * 2^15 = prod * 2^(ex - 127 - 23 + 15) */
+	return sh < 32u ? prod >> sh : 0u;
+}
 __host__ __device__ __forceinline__ unsigned long long first_pack(uint64_t ordinal, bool forward, float w) {
-	const double x = (double)w * 254.0;
-	const uint32_t q8 = (uint32_t)(unsigned char)x;
-	uint32_t r15 = (uint32_t)((x - (double)q8) * 32768.0);
-	if (r15 > 32767u) r15 = 32767u;
-	return ((unsigned long long)ordinal << FIRST_ORD_SHIFT) | ((unsigned long long)(forward ? 1u : 0u) << 23) | ((unsigned long long)q8 << 15) | r15;
+	return ((unsigned long long)ordinal << FIRST_ORD_SHIFT) | ((unsigned long long)(forward ? 1u : 0u) << 23) | (unsigned long long)(first_weight_bits(w) & 0x7fffffu);
 }
 __host__ __device__ __forceinline__ bool first_forward(unsigned long long f) { return ((f >> 23) & 1ull) != 0; }
 /* what promotion from the singleton map does to the weight sum: (float)(q8 / 254.0) - w of the first sighting */
@@ -439,7 +450,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		const uint64_t B0 = __shfl(myStart, (int)done, 64);
 		const bool fits = have && (uint32_t)lane >= done && (myEnd - B0 <= (uint64_t)TILE_SPAN);
 		unsigned long long m = __ballot(fits) >> done;
-		uint32_t n = (uint32_t)__builtin_ctzll(~m);          /* run of fitting reads starting at 'done' */
+		uint32_t n = ~m ? (uint32_t)__builtin_ctzll(~m) : 64u;          /* run of fitting reads starting at 'done' (ctz of 0 is undefined) */
 		if (n > nr - done) n = nr - done;
 		if (n == 0) {                                        /* read longer than a tile */
 			if (lane == 0) atomicOr(p.err, (uint32_t)ERR_READ_TOO_LONG);

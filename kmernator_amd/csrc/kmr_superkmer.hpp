@@ -38,8 +38,15 @@ static const uint32_t SK_CHUNK_G = 64;        /* 16-byte granules per chunk: 1 K
 static const uint32_t SK_MAX_N = 128;         /* k-mers per record                                                    */
 static const int SK_WAVES = 3;                /* wavefronts per block of sk_extract_kernel (two blocks per CU by LDS) */
 static const int SK_WINDOW = 16;              /* positions between two gathers = the unroll of the position loop      */
+static const int SK_RR = 4;                   /* records a lane books per gather round                                */
 
+#ifdef KMR_DEBUG_HOOKS
+#define SK_DBG(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define SK_DBG(flags, bit) false
+#endif
 struct SkParams {
+	uint32_t dbg;          /* measurement switches of a -DKMR_DEBUG_HOOKS build (they void the result): extract 1 = no list appends, 2 = no gather; count 1 = no table, 2 = no emit, 4 = no insert loop */
 	uint32_t m;            /* minimizer length in bases, <= 16                                        */
 	uint32_t off;          /* offset inside the k-mer of the first m-mer the minimizer looks at       */
 	uint32_t list_bits;    /* lists = 2^list_bits                                                     */
@@ -86,6 +93,22 @@ __device__ __forceinline__ uint32_t sk_alloc_chunk(SkSlab *slab, const PoolView 
 	else c = atomicAdd(pool.head, 1u);
 	if (c >= pool.cap) { atomicOr(pool.err, (uint32_t)ERR_POOL_FULL); return NO_CHUNK; }
 	return c;
+}
+/* the part of sk_append after the add, for adds issued ahead: a fit or a crossing is settled here; an add that landed behind
+ * somebody else's crossing is void and reported through `waits` (the caller books again with sk_append) */
+__device__ __forceinline__ uint64_t sk_append_settle(unsigned long long *state, uint32_t list, uint32_t g, unsigned long long old, SkSlab *slab, const PoolView &pool, bool &waits) {
+	const uint32_t c = (uint32_t)(old >> 32), f = (uint32_t)old;
+	if (f + g <= SK_CHUNK_G) return (uint64_t)c * SK_CHUNK_G + f;
+	if (f <= SK_CHUNK_G) {
+		if (c != NO_CHUNK) pool.chunk_count[c] = f;
+		const uint32_t c2 = sk_alloc_chunk(slab, pool);
+		if (c2 == NO_CHUNK) { atomicExch(state + list, ((unsigned long long)NO_CHUNK << 32) | (SK_CHUNK_G + 1)); return ~0ull; }
+		pool.chunk_list[c2] = list;
+		atomicExch(state + list, ((unsigned long long)c2 << 32) | g);
+		return (uint64_t)c2 * SK_CHUNK_G;
+	}
+	waits = true;
+	return ~0ull;
 }
 __device__ __forceinline__ uint64_t sk_append(unsigned long long *state, uint32_t list, uint32_t g, SkSlab *slab, const PoolView &pool) {
 	unsigned long long *word = state + list;
@@ -138,7 +161,7 @@ static const int SK_WAVE_LDS = (SK_Q_BYTES + SK_GROUPS * 4 + SK_GROUPS * 2 + SK_
 static const size_t SK_EXTRACT_SMEM = (size_t)SK_WAVES * SK_WAVE_LDS;
 
 template <int W, int WIN, bool FILT>
-__global__ __launch_bounds__(SK_WAVES * 64, 1)
+__global__ __launch_bounds__(SK_WAVES * 64, 2)
 void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	__shared__ double sP[256], sPk[256];
@@ -160,6 +183,9 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 	const uint32_t mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
 	const uint32_t mtop = 2 * (m - 1);
 	unsigned long long nRaw = 0, nGood = 0, nSub = 0;
+#ifdef KMR_DEBUG_HOOKS
+	unsigned long long nFlatBlk = 0, nGenBlk = 0;
+#endif
 	const uint64_t n_items = rv.u_start ? rv.n_units : rv.n_reads;
 	const uint64_t n_tiles = (n_items + 63) / 64;
 	for (uint64_t tile = (uint64_t)blockIdx.x * SK_WAVES + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * SK_WAVES) {
@@ -187,7 +213,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 		const uint64_t B0 = __shfl(myStart, (int)done, 64);
 		const bool fits = have && (uint32_t)lane >= done && (myEnd - B0 <= (uint64_t)TILE_SPAN);
 		unsigned long long fm = __ballot(fits) >> done;
-		uint32_t n = (uint32_t)__builtin_ctzll(~fm);          /* run of fitting reads starting at 'done' */
+		uint32_t n = ~fm ? (uint32_t)__builtin_ctzll(~fm) : 64u;          /* run of fitting reads starting at 'done' (ctz of 0 is undefined: it came out as 32 and halved every tile) */
 		if (n > nr - done) n = nr - done;
 		if (n == 0) {                                        /* read longer than a tile */
 			if (lane == 0) atomicOr(p.err, (uint32_t)ERR_READ_TOO_LONG);
@@ -195,6 +221,9 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 			continue;
 		}
 		const uint64_t B1 = __shfl(myEnd, (int)(done + n - 1), 64);
+#ifdef KMR_DEBUG_HOOKS
+		if (lane == 0) nGenBlk += 1000000ull + n;
+#endif
 		const uintptr_t gb = (uintptr_t)rv.bases + B0, gq = (uintptr_t)rv.quals + B0;
 		const uintptr_t ab = gb & ~(uintptr_t)15, aq = gq & ~(uintptr_t)15;
 		const uint32_t nb16 = (uint32_t)(((uintptr_t)rv.bases + B1 - ab + 15) >> 4);
@@ -263,6 +292,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 		/* weight chain */
 		double w = 0.0;
 		uint32_t zc = 0;
+		constexpr int ZN = W == 1 ? 1 : (W == 2 ? 2 : 3);      /* history of zero flags, one bit per position: k + 1 bits */
 		uint64_t zbits[3] = {0, 0, 0};
 		uint32_t qrun = 0;
 		/* minimizer pipeline: runs sp.off positions behind the k-mer pipeline */
@@ -277,6 +307,47 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 		SkRoll<FILT ? W : 1> fr;           /* forward / reverse-complement words: only the filters need the k-mer itself */
 		if (FILT) fr.r.init(k);
 
+		/* records booked but not yet written (see the gather below): start | n << 16 | uniform << 24 | window position << 25 | 1 << 31,
+		 * minimizer hash, weight bits, and what the booking add returned */
+		uint32_t q_info[SK_RR], q_mh[SK_RR], q_w0[SK_RR]; unsigned long long q_booked[SK_RR];
+#pragma unroll
+		for (int r = 0; r < SK_RR; r++) { q_info[r] = 0; q_mh[r] = 0; q_w0[r] = 0; q_booked[r] = 0; }
+		auto flush_pending = [&]() {
+			uint64_t at[SK_RR]; bool waits[SK_RR];
+#pragma unroll
+			for (int r = 0; r < SK_RR; r++) {
+				waits[r] = false; at[r] = ~0ull;
+				if ((q_info[r] >> 31) && !SK_DBG(sp.dbg, 1)) {
+					const uint32_t n = (q_info[r] >> 16) & 0xffu; const bool uni = (q_info[r] >> 24) & 1u;
+					at[r] = sk_append_settle(sp.state, sk_list_of(q_mh[r], sp.list_bits), 1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4), q_booked[r], slab, pool, waits[r]);
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < SK_RR; r++) if (waits[r]) {
+				const uint32_t n = (q_info[r] >> 16) & 0xffu; const bool uni = (q_info[r] >> 24) & 1u;
+				at[r] = sk_append(sp.state, sk_list_of(q_mh[r], sp.list_bits), 1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4), slab, pool);
+			}
+#pragma unroll
+			for (int r = 0; r < SK_RR; r++) {
+				if ((q_info[r] >> 31) && at[r] != ~0ull && !SK_DBG(sp.dbg, 4)) {
+					const uint32_t start = q_info[r] & 0xffffu, n = (q_info[r] >> 16) & 0xffu, pos = (q_info[r] >> 25) & 15u; const bool uni = (q_info[r] >> 24) & 1u;
+					const uint32_t nbg = sk_base_granules(n, k), nwg = uni ? 0u : (n + 3) / 4;
+					uint4 *dst = (uint4 *)pool.base + at[r];
+					const uint64_t ord = ord0 + start;
+					dst[0] = make_uint4((uint32_t)ord, (uint32_t)(ord >> 32) | (n << 8) | ((uni ? 1u : 0u) << 16) | ((1 + nbg + nwg) << 17), q_mh[r], q_w0[r]);
+					const uint32_t xb = rbOff + start;
+					for (uint32_t b = 0; b < nbg; b++)
+						dst[1 + b] = make_uint4(sk_bases16(pk, xb + 64 * b), sk_bases16(pk, xb + 64 * b + 16), sk_bases16(pk, xb + 64 * b + 32), sk_bases16(pk, xb + 64 * b + 48));
+					for (uint32_t b = 0; b < nwg; b++) {
+						uint32_t v[4];
+#pragma unroll
+						for (int u = 0; u < 4; u++) { const uint32_t tt = pos + 4 * b + u; v[u] = tt < 16 ? __float_as_uint(wtr[tt * 64 + lane]) : 0u; }
+						dst[1 + nbg + b] = make_uint4(v[0], v[1], v[2], v[3]);
+					}
+				}
+				q_info[r] = 0;
+			}
+		};
 		for (uint32_t jb = 0; jb < Lmax || __any(runOpen); jb += SK_WINDOW) {
 			/* the window's 16 positions of this lane's read: bases, N flags, quality flags; and the bases sp.off positions back */
 			const uint32_t pkw = sk_bases16(pk, rbOff + jb);
@@ -295,36 +366,116 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 			const bool cinOpen = runOpen; const uint32_t cinStart = runStart, cinN = runN, cinMh = runMh, cinW0 = runW0;
 			uint32_t Sm = 0, Vm = 0, Cm = 0;
 			runInWin = false;
+			/* minimizer of the k-mer that ends at position jb + t: m-mer ending sp.off positions back, canonical, hashed; minimum of
+			 * the last WIN of them (t is a constant after unrolling, so hs[] stays in registers) */
+			auto minimizer_step = [&](const int t) -> uint32_t {
+				const uint32_t mc = (mpkw >> (30 - 2 * t)) & 3u;
+				mf = ((mf << 2) | mc) & mmask;
+				mr = (mr >> 2) | ((3u - mc) << mtop);
+				const uint32_t x = sk_mmer_hash(mf < mr ? mf : mr);
+				const int r = t % WIN;
+				pref = r == 0 ? x : (x < pref ? x : pref);
+				hs[r] = x;
+				uint32_t M = pref;
+				if (r < WIN - 1) { const uint32_t sfx = hs[r + 1 < WIN ? r + 1 : 0]; M = sfx < M ? sfx : M; }
+				else {
+#pragma unroll
+					for (int u = WIN - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
+				}
+				return M;
+			};
+			/* Flat window: no lane sees an N or a quality below the floor (in the window or in the k positions before it), and the
+			 * qualities around every k-mer of the window are all equal -- a run of k + 1 equal chars behind each k-mer that continues
+			 * the weight chain (x / x == 1.0: the chain does not move), k equal chars where the product starts afresh (then it is
+			 * the table entry Pk[q]).  A fresh start is only allowed at the window's first k-mer: the first k-mer of a read, a lane
+			 * whose chain is at zero, or -- the same for every lane -- a k-mer index that is a multiple of 1024.  Then the weight is one
+			 * number per lane for the whole window and the positions need no case analysis: the same arithmetic as below without
+			 * the branches (the general path spends more scalar exec-mask instructions than vector ones).  Windows a read ends in
+			 * and the window its first k-mer falls into are covered (positions without a k-mer only move the minimizer on). */
+			bool flatBlk = false; uint32_t flatWbits = 0;
+			if (!FILT && jb + SK_WINDOW >= k) {
+				const bool live = jb < L;
+				const uint32_t tk = jb + 1 >= k ? 0u : k - 1 - jb;            /* first position of the window that ends a k-mer */
+				const uint32_t i0 = jb + tk + 1 - k;                           /* its k-mer index */
+				const uint32_t nin = live ? (L - jb < (uint32_t)SK_WINDOW ? L - jb : (uint32_t)SK_WINDOW) : 0u;
+				const uint32_t inmask = (1u << nin) - 1u;
+				/* fresh starts other than at tk send the window down the general path */
+				const uint32_t ph = i0 & 1023u;
+				const bool noLaterRestart = ph == 0 ? (SK_WINDOW - tk <= 1024u) : (ph + (SK_WINDOW - 1 - tk) < 1024u);
+				const bool fresh = ph == 0 || w == 0.0;
+				const uint32_t eqm = (isRef ? 0xffffu : qeq) | (jb == 0 ? 1u : 0u);       /* position 0 has no predecessor: not looked at */
+				const uint32_t qAtTk = jb == 0 ? tk : qrun + tk + 1;           /* qrun as it will stand at position tk if the window's qualities are equal */
+				const bool ok = !live || nin <= tk ||
+				                ((nmw & inmask) == 0 && zc == 0 && (isRef || ((qlow & inmask) == 0 && (eqm & inmask) == inmask && qAtTk >= (fresh ? k - 1 : k))));
+				if (noLaterRestart && __all(ok)) {
+					flatBlk = true;
+					const bool kmers = live && nin > tk;
+					if (kmers) { if (isRef) w = 1.0; else if (fresh) w = sPk[rq[jb + tk]]; }
+					const float wf = (float)w;
+					flatWbits = __float_as_uint(wf);
+					const uint32_t kmask = kmers ? inmask & ~((1u << tk) - 1u) : 0u;      /* positions with a k-mer */
+					const bool good = wf > p.min_weight;
+					Vm = good ? kmask : 0u;
+					tRaw += (uint32_t)__builtin_popcount(kmask); tGood += (uint32_t)__builtin_popcount(Vm);
+					if (live) {
+						if (ZN > 2) zbits[2] = (zbits[2] << 16) | (zbits[1] >> 48);
+						if (ZN > 1) zbits[1] = (zbits[1] << 16) | (zbits[0] >> 48);
+						zbits[0] <<= 16;
+						qrun = jb == 0 ? SK_WINDOW - 1 : qrun + SK_WINDOW;
+					}
+#pragma unroll
+					for (int t = 0; t < SK_WINDOW; t++) {
+						const uint32_t M = minimizer_step(t);
+						const bool valid = ((Vm >> t) & 1u) != 0;
+						const bool cont = runOpen && M == runMh && runN < SK_MAX_N && flatWbits == runW0;
+						const bool nw = valid && !cont;
+						Sm |= nw ? (1u << t) : 0u;
+						runStart = nw ? jb + (uint32_t)t + 1 - k : runStart;
+						runN = nw ? 1u : runN + ((valid && cont) ? 1u : 0u);
+						runMh = nw ? M : runMh; runW0 = nw ? flatWbits : runW0;
+						runUniform = runUniform || nw; runInWin = runInWin || nw;
+						runOpen = valid || (runOpen && (uint32_t)t < tk);
+						mhr[t * 64 + lane] = M;
+					}
+				}
+			}
+			/* Lead-in window: no position of it ends a k-mer yet (and every lane has all 16): only the histories move */
+			if (!flatBlk && !FILT) {
+				const bool live = jb < L;
+				if (__all(!live || (jb + SK_WINDOW <= L && jb + SK_WINDOW < k))) {
+					flatBlk = true;
+					if (live) {
+						const uint32_t zm = nmw | (isRef ? 0u : qlow);
+						zc += (uint32_t)__builtin_popcount(zm);
+						if (ZN > 2) zbits[2] = (zbits[2] << 16) | (zbits[1] >> 48);
+						if (ZN > 1) zbits[1] = (zbits[1] << 16) | (zbits[0] >> 48);
+						zbits[0] = (zbits[0] << 16) | (uint64_t)(__builtin_bitreverse32(zm) >> 16);      /* the newest position in bit 0 */
+						const uint32_t eq = (isRef ? 0xffffu : qeq) & (jb == 0 ? 0xfffeu : 0xffffu);       /* position 0 has no predecessor */
+						qrun = eq == 0xffffu ? qrun + SK_WINDOW : (uint32_t)__builtin_clz(~(eq << 16));      /* equal qualities counted back from the window's end */
+					}
+#pragma unroll
+					for (int t = 0; t < SK_WINDOW; t++) mhr[t * 64 + lane] = minimizer_step(t);
+					if (!live) runOpen = false;
+				}
+			}
+#ifdef KMR_DEBUG_HOOKS
+			if (lane == 0) { if (flatBlk) nFlatBlk++; else nGenBlk++; }
+#endif
+			if (!flatBlk) {
 #pragma unroll
 			for (int t = 0; t < SK_WINDOW; t++) {
 				const uint32_t j = jb + t;
 				const bool in = j < L;
 				const uint32_t code = (pkw >> (30 - 2 * t)) & 3u;
 				const bool z = in && ((((nmw >> t) & 1u) != 0) || (!isRef && ((qlow >> t) & 1u) != 0));
-				zbits[2] = (zbits[2] << 1) | (zbits[1] >> 63); zbits[1] = (zbits[1] << 1) | (zbits[0] >> 63); zbits[0] = (zbits[0] << 1) | (z ? 1ull : 0ull);
+				if (ZN > 2) zbits[2] = (zbits[2] << 1) | (zbits[1] >> 63);
+				if (ZN > 1) zbits[1] = (zbits[1] << 1) | (zbits[0] >> 63);
+				zbits[0] = (zbits[0] << 1) | (z ? 1ull : 0ull);
 				zc += z ? 1u : 0u;
-				zc -= (uint32_t)((zbits[k >> 6] >> (k & 63)) & 1ull);   /* position j-k leaves the window (0 while j < k) */
+				zc -= (uint32_t)((zbits[ZN == 1 ? 0 : (k >> 6)] >> (k & 63)) & 1ull);   /* position j-k leaves the window (0 while j < k) */
 				qrun = (j > 0 && (isRef || ((qeq >> t) & 1u))) ? qrun + 1 : 0;
 				if (FILT) fr.r.push(code);
-				/* minimizer: m-mer ending sp.off positions back, canonical, hashed; minimum of the last WIN of them */
-				{
-					const uint32_t mc = (mpkw >> (30 - 2 * t)) & 3u;
-					mf = ((mf << 2) | mc) & mmask;
-					mr = (mr >> 2) | ((3u - mc) << mtop);
-					const uint32_t x = sk_mmer_hash(mf < mr ? mf : mr);
-					const int r = t % WIN;
-					pref = r == 0 ? x : (x < pref ? x : pref);
-					hs[r] = x;
-				}
-				uint32_t M = pref;
-				{
-					const int r = t % WIN;
-					if (r < WIN - 1) { const uint32_t sfx = hs[r + 1 < WIN ? r + 1 : 0]; M = sfx < M ? sfx : M; }
-					else {
-#pragma unroll
-						for (int u = WIN - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
-					}
-				}
+				const uint32_t M = minimizer_step(t);
 				bool valid = false;
 				float wf = 0.0f;
 				if (in && j + 1 >= k) {
@@ -374,6 +525,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				mhr[t * 64 + lane] = M;
 				wtr[t * 64 + lane] = wf;
 			}
+			}
 			/* a run with unequal weights ends with its window (its weights live in this window's ring) */
 			const bool openEnd = runOpen && runUniform;
 			if (runOpen && !runUniform) runOpen = false;
@@ -383,33 +535,38 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 			if (cinOpen) { lead = (uint32_t)__builtin_ctz(brk | 0x10000u); pendC = lead < 16; }
 			uint32_t Srem = Sm;
 			if (openEnd && runInWin && Sm) Srem &= ~(1u << (31 - __builtin_clz(Sm)));      /* the run still open is the last one begun */
+			if (SK_DBG(sp.dbg, 2)) { pendC = false; Srem = 0; }
+			/* Four records per lane and round: their list words are bumped back to back, and the bookings of a round are settled
+			 * and the records written at the NEXT window's gather (or at the end of the tile): scattered device atomics run at
+			 * ~2 x 10^10 per second chip-wide and take tens of microseconds under that load -- time the wavefront now spends
+			 * walking the next 16 positions.  Settling goes in two steps: first everything that does not wait (a fit, or the one
+			 * add that crossed a chunk's end and replaces it), only then the adds that have to wait for somebody else's new chunk
+			 * -- a lane of this wavefront may be that somebody.  Records with a weight per k-mer are settled at once (their
+			 * weights live in this window's ring). */
+			flush_pending();
+			bool firstRound = true;
 			while (__any(pendC || Srem)) {
-				bool emit = false; uint32_t eStart = 0, eN = 0, eMh = 0, eW0 = 0, pos = 0; bool eUni = true;
-				if (pendC) { pendC = false; emit = true; eStart = cinStart; eN = cinN + lead; eMh = cinMh; eW0 = cinW0; }
-				else if (Srem) {
-					pos = (uint32_t)__builtin_ctz(Srem); Srem &= Srem - 1;
-					const uint32_t end = pos + 1 + (uint32_t)__builtin_ctz((brk >> (pos + 1)) | (1u << (15 - pos)));
-					emit = true; eN = end - pos; eStart = jb + pos + 1 - k; eMh = mhr[pos * 64 + lane]; eW0 = __float_as_uint(wtr[pos * 64 + lane]);
-					eUni = ((Cm >> (pos + 1)) & ((1u << (eN - 1)) - 1u)) == 0;
-				}
-				if (emit) {
-					const uint32_t nbg = sk_base_granules(eN, k), nwg = eUni ? 0u : (eN + 3) / 4, g = 1 + nbg + nwg;
-					const uint64_t at = sk_append(sp.state, sk_list_of(eMh, sp.list_bits), g, slab, pool);
-					if (at != ~0ull) {
-						uint4 *dst = (uint4 *)pool.base + at;
-						const uint64_t ord = ord0 + eStart;
-						dst[0] = make_uint4((uint32_t)ord, (uint32_t)(ord >> 32) | (eN << 8) | ((eUni ? 1u : 0u) << 16) | (g << 17), eMh, eW0);
-						const uint32_t xb = rbOff + eStart;
-						for (uint32_t b = 0; b < nbg; b++)
-							dst[1 + b] = make_uint4(sk_bases16(pk, xb + 64 * b), sk_bases16(pk, xb + 64 * b + 16), sk_bases16(pk, xb + 64 * b + 32), sk_bases16(pk, xb + 64 * b + 48));
-						for (uint32_t b = 0; b < nwg; b++) {
-							uint32_t v[4];
+				bool anyNow = false;
 #pragma unroll
-							for (int u = 0; u < 4; u++) { const uint32_t tt = pos + 4 * b + u; v[u] = tt < 16 ? __float_as_uint(wtr[tt * 64 + lane]) : 0u; }
-							dst[1 + nbg + b] = make_uint4(v[0], v[1], v[2], v[3]);
-						}
+				for (int r = 0; r < SK_RR; r++) {
+					q_info[r] = 0;
+					if (pendC) { pendC = false; q_info[r] = (1u << 31) | (1u << 24) | ((cinN + lead) << 16) | cinStart; q_mh[r] = cinMh; q_w0[r] = cinW0; }
+					else if (Srem) {
+						const uint32_t pos = (uint32_t)__builtin_ctz(Srem); Srem &= Srem - 1;
+						const uint32_t end = pos + 1 + (uint32_t)__builtin_ctz((brk >> (pos + 1)) | (1u << (15 - pos)));
+						const uint32_t n = end - pos;
+						const bool uni = ((Cm >> (pos + 1)) & ((1u << (n - 1)) - 1u)) == 0;
+						q_info[r] = (1u << 31) | (pos << 25) | ((uni ? 1u : 0u) << 24) | (n << 16) | (jb + pos + 1 - k);
+						q_mh[r] = mhr[pos * 64 + lane]; q_w0[r] = flatBlk ? flatWbits : __float_as_uint(wtr[pos * 64 + lane]);
+						anyNow = anyNow || !uni;
+					}
+					if ((q_info[r] >> 31) && !SK_DBG(sp.dbg, 1)) {
+						const uint32_t n = (q_info[r] >> 16) & 0xffu; const bool uni = (q_info[r] >> 24) & 1u;
+						q_booked[r] = atomicAdd(sp.state + sk_list_of(q_mh[r], sp.list_bits), (unsigned long long)(1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4)));
 					}
 				}
+				if (!firstRound || __any(anyNow) || __any(pendC || Srem)) flush_pending();      /* more rounds to come, or weights in the ring: settle now */
+				firstRound = false;
 			}
 			/* refill the slab cache of the wavefront (uniform) */
 			if (slab->next >= 64u) {
@@ -419,6 +576,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				__builtin_amdgcn_wave_barrier();
 			}
 		}
+		flush_pending();                   /* the last window's records: their bases are read from this tile */
 		done += n;
 		__builtin_amdgcn_wave_barrier();   /* all lanes are done reading the tile before it is overwritten */
 	}
@@ -432,6 +590,9 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 	}
 	nRaw = wave_sum(nRaw); nGood = wave_sum(nGood);
 	if (lane == 0) { atomicAdd(&p.stats->raw, nRaw); atomicAdd(&p.stats->good, nGood); }
+#ifdef KMR_DEBUG_HOOKS
+	if (lane == 0) { atomicAdd(&p.stats->claimed, nGenBlk); atomicAdd(&p.stats->inserted, nFlatBlk); }      /* windows down the general / the fast paths */
+#endif
 	if (FILT) { nSub = wave_sum(nSub); if (lane == 0 && nSub) atomicAdd(&p.stats->subtracted, nSub); }
 }
 
@@ -466,16 +627,15 @@ template <int W> __device__ __forceinline__ Key<W> key_revcomp(const Key<W> &f, 
  * splitting and the emission of kept entries are those of count_kernel (COUNT_DIR values). */
 static const int SK_STAGE_CHUNKS = 4;                          /* = wavefronts of the block */
 static const int SK_STAGE_G = SK_STAGE_CHUNKS * SK_CHUNK_G;    /* 256 granules = one per thread */
-static const int SK_EXPAND_CAP = 2048;                         /* k-mers of one staged group handled per pass */
 static const uint32_t SK_LBATCH = 8;
 
 template <int W, int LOG2S>
-__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0)) + (size_t)SK_STAGE_G * 16 + SK_EXPAND_CAP + SK_STAGE_G * 2 + 64; }
+__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + 2) + (size_t)SK_STAGE_G * 16 + 64; }
 
 template <int W, int LOG2S>
 __global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10) ? 3 : 1)
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
-                     CountOut out, FinalizeParams f, unsigned int *work_counter) {
+                     CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags) {
 	constexpr int S = 1 << LOG2S;
 	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
 	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
@@ -485,23 +645,28 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	unsigned long long *tfirst = (unsigned long long *)(twsum + S);
 	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
 	uint4 *stage = (uint4 *)(tstate + (W > 1 ? S : 0));                /* 16-byte aligned: every table array is a multiple of 16 bytes */
-	uint8_t *owner = (uint8_t *)(stage + SK_STAGE_G);                  /* [SK_EXPAND_CAP] staged granule of the record a k-mer belongs to */
-	uint16_t *roff = (uint16_t *)(owner + SK_EXPAND_CAP);              /* [SK_STAGE_G] first k-mer slot of the record starting at a granule */
-	uint16_t *s_kept = (uint16_t *)stage;                              /* emission only: aliases the staging area (S <= 2048 entries) */
-	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns, s_nk;
+	uint16_t *s_kept = (uint16_t *)(stage + SK_STAGE_G);               /* [S] table slots of the entries to write out */
+	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns, s_n2;
 	__shared__ unsigned long long s_wbase, s_sbase;
 	__shared__ unsigned long long s_wpos, s_wend, s_spos, s_send;
 	__shared__ unsigned long long s_holeW0, s_holeW1, s_holeS0, s_holeS1;
 	__shared__ uint32_t s_stackBits[40], s_stackVal[40];
 	__shared__ unsigned long long s_ls[SK_LBATCH + 1];
-	__shared__ uint32_t s_wtot[SK_STAGE_CHUNKS];
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const uint32_t vw = 3;
 	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;
 	constexpr unsigned long long OSLAB = 8192;
 	if (t == 0) { s_wpos = s_wend = 0; s_spos = s_send = 0; }
 	lds_barrier();
+	/* classify() of kmr_kernels.hpp folded into launch-wide scalars: a count of one goes to class singC when singletons are separate,
+	 * any other count below weakMin is dropped.  When no singleton is written out and the kept entries are exactly the keys seen at
+	 * least keepFrom >= 2 times (FilterReads' defaults: 2), the insert loop files them itself and the table is never scanned. */
+	const uint32_t singC = f.has_singletons ? (f.min_depth > 1 ? 0u : 2u) : 3u;
+	const uint32_t weakMin = ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1) ? f.min_depth : 0u;
+	const uint32_t keepFrom = singC == 0u ? (weakMin > 2u ? weakMin : 2u) : weakMin;
+	const bool fastEmit = singC != 2u && keepFrom >= 2u;
 	const uint4 *poolg = (const uint4 *)pool.base;
+	uint4 pre = make_uint4(0, 0, 0, 0); uint32_t preCount = 0; uint64_t preList = ~0ull;      /* this wavefront's first chunk of the list named */
 
 	for (;;) {
 		if (t == 0) s_list = atomicAdd(work_counter, SK_LBATCH);
@@ -517,131 +682,163 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 			lds_barrier();
 			if (t == 0) { s_sp = 1; s_stackBits[0] = 0; s_stackVal[0] = 0; }
 			lds_barrier();
+			bool firstPass = true;        /* sub-passes of a split list load their chunks themselves */
 			while (s_sp > 0) {
 				const uint32_t bits = s_stackBits[s_sp - 1], val = s_stackVal[s_sp - 1];
 				lds_barrier();
-				if (t == 0) { s_sp--; s_claimed = 0; s_overflow = 0; s_nw = 0; s_ns = 0; }
+				if (t == 0) { s_sp--; s_claimed = 0; s_overflow = 0; s_nw = 0; s_ns = 0; s_n2 = 0; }
 				for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; }
 				lds_barrier();
 				const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
-				/* the first group of the list: requested now, landed in `nxt` */
-				auto load_group = [&](uint64_t cb) -> uint4 {
-					const uint64_t ci = cb + (uint64_t)wv;
-					uint4 v = make_uint4(0, 0, 0, 0);
-					if (ci < c1) { const uint64_t d = list_chunks[ci]; if ((uint32_t)lane < (uint32_t)(d >> 32)) v = poolg[(size_t)(uint32_t)d * SK_CHUNK_G + lane]; }
-					return v;
-				};
-				auto group_count = [&](uint64_t cb) -> uint32_t { const uint64_t ci = cb + (uint64_t)wv; return ci < c1 ? (uint32_t)(list_chunks[ci] >> 32) : 0u; };
-				uint4 nxt = load_group(c0);
-				uint32_t nxtCount = group_count(c0);
-				for (uint64_t cb = c0; cb < c1 && !s_overflow && s_claimed <= LIMIT; cb += SK_STAGE_CHUNKS) {
-					const uint4 cur = nxt; const uint32_t curCount = nxtCount;
-					stage[t] = cur;
-					if (cb + SK_STAGE_CHUNKS < c1) { nxt = load_group(cb + SK_STAGE_CHUNKS); nxtCount = group_count(cb + SK_STAGE_CHUNKS); }
-					/* record starts of this wavefront's chunk: follow the granule counts from granule 0 */
+				/* insert: wavefront w takes chunks c0 + w, c0 + w + 4, ... of the list, each one on its own: it stages the chunk in its
+				 * quarter of the staging area, finds the record starts, maps k-mer slots to records and inserts -- no block-wide
+				 * barrier until all four are through (the table is shared through LDS atomics) */
+				uint4 *wstage = stage + wv * SK_CHUNK_G;
+				uint4 cur = make_uint4(0, 0, 0, 0); uint32_t curCount = 0;
+				if (firstPass && preList == lfirst + lj) { cur = pre; curCount = preCount; }        /* requested while the list before was counted */
+				else if (c0 + wv < c1) { const uint64_t d = list_chunks[c0 + wv]; curCount = (uint32_t)(d >> 32); if ((uint32_t)lane < curCount) cur = poolg[(size_t)(uint32_t)d * SK_CHUNK_G + lane]; }
+				/* descriptor of this wavefront's first chunk of the next list (its records are requested after the insert loop) */
+				uint64_t dnext = 0; bool haveNext = false;
+				if (firstPass && lj + 1 < nl) { const uint64_t n0 = s_ls[lj + 1], n1 = s_ls[lj + 2]; if (n0 + wv < n1) { dnext = list_chunks[n0 + wv]; haveNext = true; } }
+				for (uint64_t ci = c0 + wv; ci < c1 && !s_overflow && s_claimed <= LIMIT; ci += SK_STAGE_CHUNKS) {
+					uint4 nxt = make_uint4(0, 0, 0, 0); uint32_t nxtCount = 0;
+					if (ci + SK_STAGE_CHUNKS < c1) { const uint64_t d = list_chunks[ci + SK_STAGE_CHUNKS]; nxtCount = (uint32_t)(d >> 32); if ((uint32_t)lane < nxtCount) nxt = poolg[(size_t)(uint32_t)d * SK_CHUNK_G + lane]; }
+					wstage[lane] = cur;
+					/* record starts: follow the granule counts from granule 0 */
 					const uint32_t glen = (cur.y >> 17) & 0x7fu;
+					uint32_t claimedHere = 0;
 					unsigned long long starts = 0;
 					for (uint32_t pos = 0; pos < curCount; ) {
 						starts |= 1ull << pos;
 						const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos);
 						pos += step ? step : SK_CHUNK_G;        /* a zero would never end: a corrupt chunk is dropped */
 					}
-					const bool isStart = (starts >> lane) & 1ull;
-					const uint32_t myN = isStart ? (cur.y >> 8) & 0xffu : 0u;
-					/* exclusive scan of the k-mer counts over the wavefront, then over the four wavefronts */
-					uint32_t incl = myN;
+					/* Every granule's lane works: lane rs + q of a record of g granules (rs = its header's lane) takes k-mers
+					 * [q n / g, (q + 1) n / g).  The first of them is cut out of the record's bases and reverse-complemented once,
+					 * the others follow by rolling one base in -- and the table slot of the next k-mer is read while the current
+					 * one is being added. */
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					const unsigned long long below = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+					const bool inRec = (uint32_t)lane < curCount && below != 0;
+					const int rs = inRec ? 63 - __builtin_clzll(below) : 0;
+					const uint32_t hx = (uint32_t)__shfl((int)cur.x, rs, 64), hy = (uint32_t)__shfl((int)cur.y, rs, 64), hw = (uint32_t)__shfl((int)cur.w, rs, 64);
+					const uint32_t n = (hy >> 8) & 0xffu, g = (hy >> 17) & 0x7fu, q = (uint32_t)(lane - rs);
+					uint32_t j = 0, j1 = 0;
+					if (inRec && g) { j = (uint32_t)(((float)(q * n) + 0.5f) / (float)g); j1 = (uint32_t)(((float)((q + 1) * n) + 0.5f) / (float)g); }
+					const uint32_t nbg = sk_base_granules(n, k);
+					const uint32_t *bw = (const uint32_t *)(wstage + rs + 1);                    /* the record's bases, 16 per dword */
+					const uint32_t *ww = (const uint32_t *)(wstage + rs + 1 + nbg);             /* its weights when they differ */
+					const bool uniformW = ((hy >> 16) & 1u) != 0;
+					const uint64_t ord0 = (uint64_t)hx | ((uint64_t)(hy & 0xffu) << 32);
+					Roller<W> roll; roll.init(k);
+					if (j < j1) {
+						Key<W> kf;
+						const uint32_t d0 = j >> 4, sft = 2u * (j & 15u);
 #pragma unroll
-					for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += x; }
-					if (lane == 63) s_wtot[wv] = incl;
-					lds_barrier();
-					uint32_t wbase = 0, total = 0;
-#pragma unroll
-					for (int i = 0; i < SK_STAGE_CHUNKS; i++) { const uint32_t x = s_wtot[i]; if (i < wv) wbase += x; total += x; }
-					const uint32_t myOff = wbase + incl - myN;
-					/* groups with more k-mers than the expansion table holds are done in passes over [base, base + SK_EXPAND_CAP) */
-					for (uint32_t base = 0; base < total; base += SK_EXPAND_CAP) {
-						if (isStart) {
-							roff[t] = (uint16_t)(myOff - base);      /* may wrap for records that begin before this pass: only the difference is used */
-							for (uint32_t q = 0; q < myN; q++) { const uint32_t slot = myOff + q; if (slot >= base && slot < base + SK_EXPAND_CAP) owner[slot - base] = (uint8_t)t; }
+						for (int wi = 0; wi < W; wi++) {
+							const uint32_t a = bw[d0 + 2 * wi], b = bw[d0 + 2 * wi + 1], c = bw[d0 + 2 * wi + 2];
+							const uint64_t hi = ((uint64_t)a << 32) | b;
+							kf.w[wi] = sft ? (hi << sft) | ((uint64_t)c >> (32 - sft)) : hi;
 						}
-						lds_barrier();
-						const uint32_t cnt = total - base < (uint32_t)SK_EXPAND_CAP ? total - base : (uint32_t)SK_EXPAND_CAP;
-						uint32_t claimedHere = 0;
-						for (uint32_t e = (uint32_t)t; e < cnt; e += COUNT_THREADS) {
-							const uint32_t g0 = owner[e];
-							const uint32_t j = (uint32_t)(uint16_t)((uint16_t)e - roff[g0]);           /* k-mer index inside its record */
-							const uint4 hd = stage[g0];
-							const uint32_t n = (hd.y >> 8) & 0xffu;
-							const uint32_t nbg = sk_base_granules(n, k);
-							const uint32_t *bw = (const uint32_t *)(stage + g0 + 1);                     /* the record's bases, 16 per dword */
-							/* forward word(s): 32 * W bases from base j on, cut to k */
-							Key<W> kf;
-							{
-								const uint32_t d0 = j >> 4, sft = 2u * (j & 15u);
+						const uint32_t kbits = 2u * k;
 #pragma unroll
-								for (int wi = 0; wi < W; wi++) {
-									const uint32_t a = bw[d0 + 2 * wi], b = bw[d0 + 2 * wi + 1], c = bw[d0 + 2 * wi + 2];
-									const uint64_t hi = ((uint64_t)a << 32) | b;
-									kf.w[wi] = sft ? (hi << sft) | ((uint64_t)c >> (32 - sft)) : hi;
-								}
-								const uint32_t kbits = 2u * k;
+						for (int wi = 0; wi < W; wi++) {
+							const uint32_t lo = 64u * wi;
+							if (kbits <= lo) kf.w[wi] = 0;
+							else if (kbits < lo + 64u) kf.w[wi] &= ~0ull << (lo + 64u - kbits);
+						}
+						const Key<W> kr = key_revcomp<W>(kf, k);
+						if constexpr (W == 1) { roll.fh = (uint32_t)(kf.w[0] >> 32); roll.fl = (uint32_t)kf.w[0]; roll.rh = (uint32_t)(kr.w[0] >> 32); roll.rl = (uint32_t)kr.w[0]; }
+						else { roll.fwd = kf; roll.rc = kr; }
+					}
+					/* current k-mer: canonical key, strand, table slot and what its home slot holds */
+					Key<W> key; bool fwd = true; uint64_t h = 0; uint32_t slot = 0; uint64_t seen = 0; bool mine = false;
 #pragma unroll
-								for (int wi = 0; wi < W; wi++) {
-									const uint32_t lo = 64u * wi;
-									if (kbits <= lo) kf.w[wi] = 0;
-									else if (kbits < lo + 64u) kf.w[wi] &= ~0ull << (lo + 64u - kbits);
-								}
-							}
-							const Key<W> kr = key_revcomp<W>(kf, k);
-							const bool fwd = key_le<W>(kf, kr);
-							const Key<W> key = fwd ? kf : kr;
-							const uint64_t h = slot_hash<W>(key.w);
-							if (((uint32_t)(h >> 20) & subMask) != val) continue;
-							const float wa = (hd.y >> 16) & 1u ? __uint_as_float(hd.w) : __uint_as_float(((const uint32_t *)(stage + g0 + 1 + nbg))[j]);
-							const uint64_t ordinal = ((uint64_t)hd.x | ((uint64_t)(hd.y & 0xffu) << 32)) + j;
-							uint32_t s = (uint32_t)(h >> (64 - LOG2S));
-							bool placed = false;
-							for (int probe = 0; probe < S && !placed; probe++) {
+					for (int wi = 0; wi < W; wi++) key.w[wi] = 0;
+					auto prepare = [&]() {
+						const Key<W> kf = roll.getFwd(), kr = roll.getRc();
+						fwd = key_le<W>(kf, kr);
+						key = fwd ? kf : kr;
+						h = slot_hash<W>(key.w);
+						slot = (uint32_t)(h >> (64 - LOG2S));
+						mine = ((uint32_t)(h >> 20) & subMask) == val;
+						if constexpr (W == 1) seen = tkeys[slot];
+					};
+					if (j < j1) prepare();
+					if (SK_DBG(dbgFlags, 4)) j1 = j;
+					uint32_t dbgSink = 0;
+					while (__any(j < j1)) {
+						if (j < j1) {
+							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot; const uint64_t cseen = seen; const uint32_t cj = j;
+							/* the next k-mer of this lane: one base in, and its home slot requested */
+							j++;
+							if (j < j1) { const uint32_t nb = j + k - 1; roll.push((bw[nb >> 4] >> (30 - 2 * (nb & 15u))) & 3u); prepare(); }
+							if (SK_DBG(dbgFlags, 1)) { dbgSink ^= (uint32_t)ckey.w[0] ^ s ^ (uint32_t)cseen; }
+							else if (cmine) {
+								const float wa = uniformW ? __uint_as_float(hw) : __uint_as_float(ww[cj]);
+								bool placed = false;
 								if constexpr (W == 1) {
-									uint64_t curk = tkeys[s];
+									uint64_t curk = cseen;
 									if (curk == EMPTY_KEY) {
-										const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key.w[0]);
-										if (old == EMPTY_KEY) { claimedHere++; placed = true; break; }
+										const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)ckey.w[0]);
+										if (old == EMPTY_KEY) { claimedHere++; placed = true; }
 										curk = old;
 									}
-									if (curk == key.w[0]) { placed = true; break; }
-								} else {
-									uint32_t st = __hip_atomic_load(&tstate[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-									if (st == 0) {
-										const uint32_t old = atomicCAS(&tstate[s], 0u, 1u);
-										if (old == 0) {
-#pragma unroll
-											for (int q = 0; q < W; q++) tkeys[(size_t)s * W + q] = key.w[q];
-											__hip_atomic_store(&tstate[s], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-											claimedHere++;
-											placed = true; break;
-										}
-										st = old;
-									}
-									if (st == 1) { probe--; continue; }      /* writer publishes unconditionally: re-poll the same slot */
-									bool eq = true;
-#pragma unroll
-									for (int q = 0; q < W; q++) eq = eq && (tkeys[(size_t)s * W + q] == key.w[q]);
-									if (eq) { placed = true; break; }
+									if (!placed && curk == ckey.w[0]) placed = true;
+									if (!placed) s = (s + 1) & (S - 1);
 								}
-								s = (s + 1) & (S - 1);
+								for (int probe = 0; probe < S && !placed; probe++) {
+									if constexpr (W == 1) {
+										uint64_t curk = tkeys[s];
+										if (curk == EMPTY_KEY) {
+											const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)ckey.w[0]);
+											if (old == EMPTY_KEY) { claimedHere++; placed = true; break; }
+											curk = old;
+										}
+										if (curk == ckey.w[0]) { placed = true; break; }
+									} else {
+										uint32_t st = __hip_atomic_load(&tstate[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+										if (st == 0) {
+											const uint32_t old = atomicCAS(&tstate[s], 0u, 1u);
+											if (old == 0) {
+#pragma unroll
+												for (int qq = 0; qq < W; qq++) tkeys[(size_t)s * W + qq] = ckey.w[qq];
+												__hip_atomic_store(&tstate[s], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+												claimedHere++;
+												placed = true; break;
+											}
+											st = old;
+										}
+										if (st == 1) { probe--; continue; }      /* writer publishes unconditionally: re-poll the same slot */
+										bool eq = true;
+#pragma unroll
+										for (int qq = 0; qq < W; qq++) eq = eq && (tkeys[(size_t)s * W + qq] == ckey.w[qq]);
+										if (eq) { placed = true; break; }
+									}
+									s = (s + 1) & (S - 1);
+								}
+								if (!placed) s_overflow = 1;      /* table full */
+								else {
+									const uint32_t before = (uint32_t)atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(cfwd ? 1 : 0) << 32));
+									if (fastEmit) {      /* the sighting that makes the key a kept entry files its slot; a table never holds more keys than s_kept slots */
+										if (before == 1u && keepFrom != 2u) atomicAdd(&s_n2, 1u);
+										if (before + 1u == keepFrom) s_kept[atomicAdd(&s_nw, 1u)] = (uint16_t)s;
+									}
+									atomicAdd(&twsum[s], (double)wa);
+									atomicMin(&tfirst[s], first_pack(ord0 + cj, cfwd, wa));
+								}
 							}
-							if (!placed) { s_overflow = 1; continue; }      /* table full */
-							atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(fwd ? 1 : 0) << 32));
-							atomicAdd(&twsum[s], (double)wa);
-							atomicMin(&tfirst[s], first_pack(ordinal, fwd, wa));
 						}
-						claimedHere = (uint32_t)wave_sum((unsigned long long)claimedHere);
-						if (lane == 0 && claimedHere) atomicAdd(&s_claimed, claimedHere);
-						lds_barrier();
 					}
-					lds_barrier();
+					if (SK_DBG(dbgFlags, 1) && dbgSink == 0x12345u) s_overflow = 2;
+					claimedHere = (uint32_t)wave_sum((unsigned long long)claimedHere);
+					if (lane == 0 && claimedHere) atomicAdd(&s_claimed, claimedHere);
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					cur = nxt; curCount = nxtCount;
 				}
+				/* the next list's first chunk travels while this one is emitted */
+				if (firstPass) { preList = ~0ull; if (haveNext) { pre = make_uint4(0, 0, 0, 0); preCount = (uint32_t)(dnext >> 32); if ((uint32_t)lane < preCount) pre = poolg[(size_t)(uint32_t)dnext * SK_CHUNK_G + lane]; preList = lfirst + lj + 1; } }
+				firstPass = false;
 				lds_barrier();
 				if (s_overflow || s_claimed > LIMIT) {       /* split this sub-pass in two by one more hash bit */
 					if (t == 0) {
@@ -655,8 +852,10 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					continue;
 				}
 				/* emit: as count_kernel (weak entries from the front of s_kept, singletons from its back) */
-				const uint32_t singC = f.has_singletons ? (f.min_depth > 1 ? 0u : 2u) : 3u;
-				const uint32_t weakMin = ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1) ? f.min_depth : 0u;
+				if (SK_DBG(dbgFlags, 2)) { lds_barrier(); continue; }
+				if (fastEmit) {       /* the kept slots were filed as their counts reached keepFrom; the statistics follow from the counters */
+					if (t == 0) { uniq += s_claimed; single += s_claimed - (keepFrom == 2u ? s_nw : s_n2); }
+				} else {
 				uint32_t cls[S / COUNT_THREADS];
 #pragma unroll
 				for (int i = 0; i < S / COUNT_THREADS; i++) {
@@ -679,6 +878,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					bw = (uint32_t)__shfl((int)bw, 0, 64); bs = (uint32_t)__shfl((int)bs, 0, 64);
 					if (c == 1) s_kept[bw + (uint32_t)__builtin_popcountll(mw & below)] = (uint16_t)s;
 					else if (c == 2) s_kept[S - 1 - (bs + (uint32_t)__builtin_popcountll(ms & below))] = (uint16_t)s;
+				}
 				}
 				lds_barrier();
 				if (t == 0) {
