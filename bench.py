@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--force-exchange", action="store_true", help="run the owner-exchange path even on one GPU (sanity/timing of the N>1 code)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="development: all ranks of a torch.distributed.run launch share GPU 0 and talk "
                     "over gloo (RCCL refuses two ranks on one device); exercises the N>1 code, its timings mean nothing")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="kmr_tune knob of the handle (measurement sweeps), e.g. partition_blocks=192")
     ap.add_argument("--no-check", action="store_true", help="development: skip the conservation assert (ablation runs of a debug build)")
     ap.add_argument("--build-mode", type=int, default=0, help="kmr_config.build_mode: 0 auto (streaming partition), 1 device table")
     args = ap.parse_args()
@@ -145,6 +146,7 @@ def main():
     cfg = ka.default_config(K, estimated_raw_kmers=n_reads * kmers_per_read * world, device=dev.index,
                             rank=rank, world_size=world, build_mode=args.build_mode)
     sp = ka.KmerSpectrum(cfg)
+    sp.tune(**{kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.tune})
 
     def barrier():
         torch.cuda.synchronize()

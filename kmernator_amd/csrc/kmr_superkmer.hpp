@@ -34,8 +34,11 @@
 
 namespace kmr {
 
+#ifndef KMR_SK_MAX_N
+#define KMR_SK_MAX_N 128
+#endif
 static const uint32_t SK_CHUNK_G = 64;        /* 16-byte granules per chunk: 1 KB, the CH * 16 of PoolView           */
-static const uint32_t SK_MAX_N = 128;         /* k-mers per record                                                    */
+static const uint32_t SK_MAX_N = KMR_SK_MAX_N;         /* k-mers per record                                                    */
 static const int SK_WAVES = 3;                /* wavefronts per block of sk_extract_kernel (two blocks per CU by LDS) */
 static const int SK_WINDOW = 16;              /* positions between two gathers = the unroll of the position loop      */
 static const int SK_RR = 4;                   /* records a lane books per gather round                                */
@@ -630,7 +633,7 @@ static const int SK_STAGE_G = SK_STAGE_CHUNKS * SK_CHUNK_G;    /* 256 granules =
 static const uint32_t SK_LBATCH = 8;
 
 template <int W, int LOG2S>
-__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + 2) + (size_t)SK_STAGE_G * 16 + 64; }
+__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + 2) + (size_t)SK_STAGE_G * 16 + 256 + 64; }
 
 template <int W, int LOG2S>
 __global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10) ? 3 : 1)
@@ -646,6 +649,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
 	uint4 *stage = (uint4 *)(tstate + (W > 1 ? S : 0));                /* 16-byte aligned: every table array is a multiple of 16 bytes */
 	uint16_t *s_kept = (uint16_t *)(stage + SK_STAGE_G);               /* [S] table slots of the entries to write out */
+	uint8_t *recOf = (uint8_t *)(s_kept + S);                          /* [4][64] per wavefront: header lane of the record a lane's first k-mer lies in */
 	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns, s_n2;
 	__shared__ unsigned long long s_wbase, s_sbase;
 	__shared__ unsigned long long s_wpos, s_wend, s_spos, s_send;
@@ -694,6 +698,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				 * quarter of the staging area, finds the record starts, maps k-mer slots to records and inserts -- no block-wide
 				 * barrier until all four are through (the table is shared through LDS atomics) */
 				uint4 *wstage = stage + wv * SK_CHUNK_G;
+				uint8_t *wrecOf = recOf + wv * 64;
 				uint4 cur = make_uint4(0, 0, 0, 0); uint32_t curCount = 0;
 				if (firstPass && preList == lfirst + lj) { cur = pre; curCount = preCount; }        /* requested while the list before was counted */
 				else if (c0 + wv < c1) { const uint64_t d = list_chunks[c0 + wv]; curCount = (uint32_t)(d >> 32); if ((uint32_t)lane < curCount) cur = poolg[(size_t)(uint32_t)d * SK_CHUNK_G + lane]; }
@@ -713,25 +718,42 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos);
 						pos += step ? step : SK_CHUNK_G;        /* a zero would never end: a corrupt chunk is dropped */
 					}
-					/* Every granule's lane works: lane rs + q of a record of g granules (rs = its header's lane) takes k-mers
-					 * [q n / g, (q + 1) n / g).  The first of them is cut out of the record's bases and reverse-complemented once,
-					 * the others follow by rolling one base in -- and the table slot of the next k-mer is read while the current
-					 * one is being added. */
+					/* The chunk's k-mers are dealt out evenly: with T of them, lane l takes slots [l Lk, (l + 1) Lk), Lk = ceil(T / 64),
+					 * in the order the records lie in the chunk.  The record a lane starts in is told to it by that record's header
+					 * lane (which knows the slots it covers from a prefix sum of the n's); the lane cuts its first k-mer out of the
+					 * record's bases and reverse-complements it once, the others follow by rolling one base in, and when a record
+					 * runs out the lane starts the next one the same way.  The table slot of the next k-mer is read while the
+					 * current one is being added. */
+					const bool isStart = (starts >> lane) & 1ull;
+					const uint32_t myN = isStart ? (cur.y >> 8) & 0xffu : 0u;
+					uint32_t incl = myN;
+#pragma unroll
+					for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += x; }
+					const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+					const uint32_t myOff = incl - myN;
+					const uint32_t Lk = (T + 63u) >> 6;
+					if (myN) {
+						const float Lf = (float)Lk;
+						const uint32_t l0 = (uint32_t)((float)(myOff + Lk - 1) / Lf), l1 = (uint32_t)((float)(myOff + myN - 1) / Lf);      /* exact: small integers */
+						for (uint32_t l = l0; l <= l1 && l < 64u; l++) wrecOf[l] = (uint8_t)lane;
+					}
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-					const unsigned long long below = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-					const bool inRec = (uint32_t)lane < curCount && below != 0;
-					const int rs = inRec ? 63 - __builtin_clzll(below) : 0;
-					const uint32_t hx = (uint32_t)__shfl((int)cur.x, rs, 64), hy = (uint32_t)__shfl((int)cur.y, rs, 64), hw = (uint32_t)__shfl((int)cur.w, rs, 64);
-					const uint32_t n = (hy >> 8) & 0xffu, g = (hy >> 17) & 0x7fu, q = (uint32_t)(lane - rs);
-					uint32_t j = 0, j1 = 0;
-					if (inRec && g) { j = (uint32_t)(((float)(q * n) + 0.5f) / (float)g); j1 = (uint32_t)(((float)((q + 1) * n) + 0.5f) / (float)g); }
-					const uint32_t nbg = sk_base_granules(n, k);
-					const uint32_t *bw = (const uint32_t *)(wstage + rs + 1);                    /* the record's bases, 16 per dword */
-					const uint32_t *ww = (const uint32_t *)(wstage + rs + 1 + nbg);             /* its weights when they differ */
-					const bool uniformW = ((hy >> 16) & 1u) != 0;
-					const uint64_t ord0 = (uint64_t)hx | ((uint64_t)(hy & 0xffu) << 32);
+					const uint32_t e0 = (uint32_t)lane * Lk;
+					uint32_t left = e0 < T ? (T - e0 < Lk ? T - e0 : Lk) : 0u;      /* k-mers this lane still has to do */
+					uint32_t rs = left ? wrecOf[lane] : 0u;
+					uint32_t j = e0 - (uint32_t)__shfl((int)myOff, (int)rs, 64);
+					uint32_t hx = (uint32_t)__shfl((int)cur.x, (int)rs, 64), hy = (uint32_t)__shfl((int)cur.y, (int)rs, 64), hw = (uint32_t)__shfl((int)cur.w, (int)rs, 64);
+					if (SK_DBG(dbgFlags, 4)) left = 0;
 					Roller<W> roll; roll.init(k);
-					if (j < j1) {
+					/* the record the lane is in: its k-mer count, bases, weights, first ordinal */
+					uint32_t n = 0; const uint32_t *bw = nullptr, *ww = nullptr; bool uniformW = true; uint64_t ord0 = 0;
+					auto enter_record = [&]() {      /* header in hx, hy, hw; first k-mer j */
+						n = (hy >> 8) & 0xffu;
+						const uint32_t nbg = sk_base_granules(n, k);
+						bw = (const uint32_t *)(wstage + rs + 1);
+						ww = (const uint32_t *)(wstage + rs + 1 + nbg);
+						uniformW = ((hy >> 16) & 1u) != 0;
+						ord0 = (uint64_t)hx | ((uint64_t)(hy & 0xffu) << 32);
 						Key<W> kf;
 						const uint32_t d0 = j >> 4, sft = 2u * (j & 15u);
 #pragma unroll
@@ -750,7 +772,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						const Key<W> kr = key_revcomp<W>(kf, k);
 						if constexpr (W == 1) { roll.fh = (uint32_t)(kf.w[0] >> 32); roll.fl = (uint32_t)kf.w[0]; roll.rh = (uint32_t)(kr.w[0] >> 32); roll.rl = (uint32_t)kr.w[0]; }
 						else { roll.fwd = kf; roll.rc = kr; }
-					}
+					};
 					/* current k-mer: canonical key, strand, table slot and what its home slot holds */
 					Key<W> key; bool fwd = true; uint64_t h = 0; uint32_t slot = 0; uint64_t seen = 0; bool mine = false;
 #pragma unroll
@@ -764,18 +786,22 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						mine = ((uint32_t)(h >> 20) & subMask) == val;
 						if constexpr (W == 1) seen = tkeys[slot];
 					};
-					if (j < j1) prepare();
-					if (SK_DBG(dbgFlags, 4)) j1 = j;
+					if (left) { enter_record(); prepare(); }
 					uint32_t dbgSink = 0;
-					while (__any(j < j1)) {
-						if (j < j1) {
-							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot; const uint64_t cseen = seen; const uint32_t cj = j;
-							/* the next k-mer of this lane: one base in, and its home slot requested */
-							j++;
-							if (j < j1) { const uint32_t nb = j + k - 1; roll.push((bw[nb >> 4] >> (30 - 2 * (nb & 15u))) & 3u); prepare(); }
+					for (uint32_t it = 0; it < Lk; it++) {
+						if (left) {
+							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot; const uint64_t cseen = seen;
+							const float wa = uniformW ? __uint_as_float(hw) : __uint_as_float(ww[j]);
+							const uint64_t cord = ord0 + j;
+							/* the next k-mer of this lane: one base in (or the next record's first k-mer), and its home slot requested */
+							j++; left--;
+							if (left) {
+								if (j < n) { const uint32_t nb = j + k - 1; roll.push((bw[nb >> 4] >> (30 - 2 * (nb & 15u))) & 3u); }
+								else { rs += (hy >> 17) & 0x7fu; const uint4 hd = wstage[rs]; hx = hd.x; hy = hd.y; hw = hd.w; j = 0; enter_record(); }
+								prepare();
+							}
 							if (SK_DBG(dbgFlags, 1)) { dbgSink ^= (uint32_t)ckey.w[0] ^ s ^ (uint32_t)cseen; }
 							else if (cmine) {
-								const float wa = uniformW ? __uint_as_float(hw) : __uint_as_float(ww[cj]);
 								bool placed = false;
 								if constexpr (W == 1) {
 									uint64_t curk = cseen;
@@ -825,7 +851,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 										if (before + 1u == keepFrom) s_kept[atomicAdd(&s_nw, 1u)] = (uint16_t)s;
 									}
 									atomicAdd(&twsum[s], (double)wa);
-									atomicMin(&tfirst[s], first_pack(ord0 + cj, cfwd, wa));
+									atomicMin(&tfirst[s], first_pack(cord, cfwd, wa));
 								}
 							}
 						}
