@@ -92,6 +92,7 @@ struct kmr_handle {
 	/* streaming (partition) build path */
 	bool partition_mode = false;
 	bool superkmer_mode = false;       /* build_mode 3: super-k-mer lists (kmr_superkmer.hpp); implies partition_mode */
+	bool auto_mode = false;            /* build_mode 0: a handle that is fed k-mer records (the owner exchange) before any reads falls back to mode 2 */
 	HostPool l1;                       /* the record pool of every partition level */
 	int bits1 = 0;
 	uint64_t inserted_records = 0;     /* records fed through kmr_insert_records_dev (counted on the host) */
@@ -1471,7 +1472,11 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 		/* build_mode: 0 auto (streaming partition path unless EXT values), 1 table, 2 partition */
 		if (cfg->build_mode > 3) { rc = fail(nullptr, KMR_ERR_INVALID_ARG, "bad build_mode"); break; }
 		h->partition_mode = cfg->build_mode != 1;
-		if (cfg->build_mode == 3) {
+		/* auto: super-k-mer lists where they apply (count / direction values, one partition, k >= 13), else the two-level k-mer partition */
+		uint32_t wish_w = 0, wish_m = 0, wish_o = 0;
+		const bool sk_auto = cfg->build_mode == 0 && !h->ext && cfg->world_size <= 1 && sk_geometry(h->k, 0, wish_w, wish_m, wish_o);
+		h->auto_mode = cfg->build_mode == 0;
+		if (cfg->build_mode == 3 || sk_auto) {
 			if (h->ext) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) builds KMR_VALUE_COUNT_DIR values only"); break; }
 			if (!sk_geometry(h->k, 0, h->sk_win, h->sk_m, h->sk_off)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) needs k >= 13"); break; }
 			h->superkmer_mode = true;
@@ -2408,7 +2413,8 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
                              void *dev_records, uint64_t seg_capacity, void *dev_seg_counts) {
 	if (!h || !dev_bases || !dev_offsets || !dev_records || !dev_seg_counts) return KMR_ERR_INVALID_ARG;
 	if (h->cfg.world_size > (uint32_t)OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "owner exchange supports up to 8 ranks per node");
-	if (h->superkmer_mode) return fail(h, KMR_ERR_UNSUPPORTED, "k-mer records by owner are a build_mode 1 / 2 path; build_mode 3 exchanges super-k-mers (kmr_exchange_*)");
+	if (h->superkmer_mode && h->auto_mode && !h->sk_state) h->superkmer_mode = false;      /* auto: the k-mer record exchange runs on the two-level partition */
+	if (h->superkmer_mode) return fail(h, KMR_ERR_UNSUPPORTED, "k-mer records by owner are a build_mode 1 / 2 path");
 	hipSetDevice(h->device);
 	ReadsView rv; rv.bases = (const uint8_t *)dev_bases; rv.quals = (const uint8_t *)dev_quals; rv.offsets = (const uint64_t *)dev_offsets;
 	rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads; rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx;
@@ -2497,7 +2503,8 @@ int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n) {
 	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_insert_records_dev after kmr_finalize");
 	if (n == 0) return KMR_OK;
 	hipSetDevice(h->device);
-	if (h->superkmer_mode) return fail(h, KMR_ERR_UNSUPPORTED, "k-mer records are inserted by build_mode 1 / 2; build_mode 3 exchanges super-k-mers");
+	if (h->superkmer_mode && h->auto_mode && !h->sk_state) h->superkmer_mode = false;
+	if (h->superkmer_mode) return fail(h, KMR_ERR_UNSUPPORTED, "k-mer records are inserted by build_mode 1 / 2");
 	if (h->partition_mode) { int prc = insert_records_partition(h, dev_records, n); h->stream_base += n; return prc; }
 	int rc = ensure_capacity(h, n); if (rc) return rc;
 	hipEvent_t a, b; time_begin(h, 0, &a, &b);

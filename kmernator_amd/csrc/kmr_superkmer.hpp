@@ -630,13 +630,14 @@ template <int W> __device__ __forceinline__ Key<W> key_revcomp(const Key<W> &f, 
  * splitting and the emission of kept entries are those of count_kernel (COUNT_DIR values). */
 static const int SK_STAGE_CHUNKS = 4;                          /* = wavefronts of the block */
 static const int SK_STAGE_G = SK_STAGE_CHUNKS * SK_CHUNK_G;    /* 256 granules = one per thread */
-static const uint32_t SK_LBATCH = 8;
+static const uint32_t SK_LBATCH = 24;
+static const uint32_t SK_DESC_CAP = 160;                       /* chunk descriptors of a batch of lists kept in LDS */
 
 template <int W, int LOG2S>
 __host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + 2) + (size_t)SK_STAGE_G * 16 + 256 + 64; }
 
 template <int W, int LOG2S>
-__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10) ? 3 : 1)
+__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10) ? 4 : 1)
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
                      CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags) {
 	constexpr int S = 1 << LOG2S;
@@ -656,6 +657,8 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	__shared__ unsigned long long s_holeW0, s_holeW1, s_holeS0, s_holeS1;
 	__shared__ uint32_t s_stackBits[40], s_stackVal[40];
 	__shared__ unsigned long long s_ls[SK_LBATCH + 1];
+	__shared__ uint32_t s_dchunk[SK_DESC_CAP];
+	__shared__ uint8_t s_dcount[SK_DESC_CAP];
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const uint32_t vw = 3;
 	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;
@@ -680,6 +683,19 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 		const uint32_t nl = (uint32_t)(n_lists - lfirst < (uint64_t)SK_LBATCH ? n_lists - lfirst : (uint64_t)SK_LBATCH);
 		if ((uint32_t)t <= nl) s_ls[t] = list_start[lfirst + t];
 		lds_barrier();
+		/* the batch's chunk descriptors are contiguous in list_chunks: the first SK_DESC_CAP of them wait in LDS, so that a chunk can be
+		 * requested a whole list ahead without a descriptor load in front of it */
+		const uint64_t dbase = s_ls[0], dend = s_ls[nl];
+		if ((uint64_t)t < dend - dbase && (uint32_t)t < SK_DESC_CAP) { const uint64_t d = list_chunks[dbase + t]; s_dchunk[t] = (uint32_t)d; s_dcount[t] = (uint8_t)(d >> 32); }
+		lds_barrier();
+		/* this wavefront's chunk ci: granule `lane` of it (zeros past its fill count) and the fill count */
+		auto fetch = [&](uint64_t ci, uint4 &v, uint32_t &count) {
+			uint32_t chunk;
+			if (ci - dbase < (uint64_t)SK_DESC_CAP) { chunk = s_dchunk[ci - dbase]; count = s_dcount[ci - dbase]; }
+			else { const uint64_t d = list_chunks[ci]; chunk = (uint32_t)d; count = (uint32_t)(d >> 32); }
+			v = make_uint4(0, 0, 0, 0);
+			if ((uint32_t)lane < count) v = poolg[(size_t)chunk * SK_CHUNK_G + lane];
+		};
 		for (uint32_t lj = 0; lj < nl; lj++) {
 			const uint64_t c0 = s_ls[lj], c1 = s_ls[lj + 1];
 			if (c0 == c1) continue;
@@ -701,19 +717,24 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				uint8_t *wrecOf = recOf + wv * 64;
 				uint4 cur = make_uint4(0, 0, 0, 0); uint32_t curCount = 0;
 				if (firstPass && preList == lfirst + lj) { cur = pre; curCount = preCount; }        /* requested while the list before was counted */
-				else if (c0 + wv < c1) { const uint64_t d = list_chunks[c0 + wv]; curCount = (uint32_t)(d >> 32); if ((uint32_t)lane < curCount) cur = poolg[(size_t)(uint32_t)d * SK_CHUNK_G + lane]; }
-				/* descriptor of this wavefront's first chunk of the next list (its records are requested after the insert loop) */
-				uint64_t dnext = 0; bool haveNext = false;
-				if (firstPass && lj + 1 < nl) { const uint64_t n0 = s_ls[lj + 1], n1 = s_ls[lj + 2]; if (n0 + wv < n1) { dnext = list_chunks[n0 + wv]; haveNext = true; } }
+				else if (c0 + wv < c1) fetch(c0 + wv, cur, curCount);
+				/* this wavefront's first chunk of the next list travels while this list is counted */
+				if (firstPass) {
+					preList = ~0ull;
+					if (lj + 1 < nl) { const uint64_t n0 = s_ls[lj + 1], n1 = s_ls[lj + 2]; if (n0 + wv < n1) { fetch(n0 + wv, pre, preCount); preList = lfirst + lj + 1; } }
+				}
 				for (uint64_t ci = c0 + wv; ci < c1 && !s_overflow && s_claimed <= LIMIT; ci += SK_STAGE_CHUNKS) {
 					uint4 nxt = make_uint4(0, 0, 0, 0); uint32_t nxtCount = 0;
-					if (ci + SK_STAGE_CHUNKS < c1) { const uint64_t d = list_chunks[ci + SK_STAGE_CHUNKS]; nxtCount = (uint32_t)(d >> 32); if ((uint32_t)lane < nxtCount) nxt = poolg[(size_t)(uint32_t)d * SK_CHUNK_G + lane]; }
+					if (ci + SK_STAGE_CHUNKS < c1) fetch(ci + SK_STAGE_CHUNKS, nxt, nxtCount);
 					wstage[lane] = cur;
 					/* record starts: follow the granule counts from granule 0 */
 					const uint32_t glen = (cur.y >> 17) & 0x7fu;
 					uint32_t claimedHere = 0;
 					unsigned long long starts = 0;
-					for (uint32_t pos = 0; pos < curCount; ) {
+					/* the usual chunk holds two-granule records only (a header and up to 64 bases): if every even granule says "2" where a
+					 * header keeps its granule count, every even granule is a header (granule 0 is one, and each one vouches for the next) */
+					if (__all((lane & 1) != 0 || (uint32_t)lane >= curCount || glen == 2u)) starts = 0x5555555555555555ull & (curCount >= 64u ? ~0ull : ((1ull << curCount) - 1ull));
+					else for (uint32_t pos = 0; pos < curCount; ) {
 						starts |= 1ull << pos;
 						const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos);
 						pos += step ? step : SK_CHUNK_G;        /* a zero would never end: a corrupt chunk is dropped */
@@ -744,16 +765,22 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					uint32_t j = e0 - (uint32_t)__shfl((int)myOff, (int)rs, 64);
 					uint32_t hx = (uint32_t)__shfl((int)cur.x, (int)rs, 64), hy = (uint32_t)__shfl((int)cur.y, (int)rs, 64), hw = (uint32_t)__shfl((int)cur.w, (int)rs, 64);
 					if (SK_DBG(dbgFlags, 4)) left = 0;
-					Roller<W> roll; roll.init(k);
 					/* the record the lane is in: its k-mer count, bases, weights, first ordinal */
 					uint32_t n = 0; const uint32_t *bw = nullptr, *ww = nullptr; bool uniformW = true; uint64_t ord0 = 0;
-					auto enter_record = [&]() {      /* header in hx, hy, hw; first k-mer j */
+					auto enter_record = [&]() {      /* header in hx, hy, hw */
 						n = (hy >> 8) & 0xffu;
-						const uint32_t nbg = sk_base_granules(n, k);
 						bw = (const uint32_t *)(wstage + rs + 1);
-						ww = (const uint32_t *)(wstage + rs + 1 + nbg);
+						ww = bw + 4 * sk_base_granules(n, k);
 						uniformW = ((hy >> 16) & 1u) != 0;
 						ord0 = (uint64_t)hx | ((uint64_t)(hy & 0xffu) << 32);
+					};
+					/* current k-mer: canonical key, strand, table slot and what its home slot holds.  Every k-mer is cut out of its record's
+					 * bases and reverse-complemented on its own (~30 instructions): rolling one base in would be cheaper per k-mer, but
+					 * lanes change records at different times and the wavefront would pay for both paths at nearly every step. */
+					Key<W> key; bool fwd = true; uint64_t h = 0; uint32_t slot = 0; uint64_t seen = 0, seenFirst = 0; bool mine = false;
+#pragma unroll
+					for (int wi = 0; wi < W; wi++) key.w[wi] = 0;
+					auto prepare = [&]() {
 						Key<W> kf;
 						const uint32_t d0 = j >> 4, sft = 2u * (j & 15u);
 #pragma unroll
@@ -770,34 +797,24 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 							else if (kbits < lo + 64u) kf.w[wi] &= ~0ull << (lo + 64u - kbits);
 						}
 						const Key<W> kr = key_revcomp<W>(kf, k);
-						if constexpr (W == 1) { roll.fh = (uint32_t)(kf.w[0] >> 32); roll.fl = (uint32_t)kf.w[0]; roll.rh = (uint32_t)(kr.w[0] >> 32); roll.rl = (uint32_t)kr.w[0]; }
-						else { roll.fwd = kf; roll.rc = kr; }
-					};
-					/* current k-mer: canonical key, strand, table slot and what its home slot holds */
-					Key<W> key; bool fwd = true; uint64_t h = 0; uint32_t slot = 0; uint64_t seen = 0; bool mine = false;
-#pragma unroll
-					for (int wi = 0; wi < W; wi++) key.w[wi] = 0;
-					auto prepare = [&]() {
-						const Key<W> kf = roll.getFwd(), kr = roll.getRc();
 						fwd = key_le<W>(kf, kr);
 						key = fwd ? kf : kr;
 						h = slot_hash<W>(key.w);
 						slot = (uint32_t)(h >> (64 - LOG2S));
 						mine = ((uint32_t)(h >> 20) & subMask) == val;
-						if constexpr (W == 1) seen = tkeys[slot];
+						if constexpr (W == 1) { seen = tkeys[slot]; seenFirst = tfirst[slot]; }
 					};
 					if (left) { enter_record(); prepare(); }
 					uint32_t dbgSink = 0;
 					for (uint32_t it = 0; it < Lk; it++) {
 						if (left) {
-							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot; const uint64_t cseen = seen;
+							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot; const uint64_t cseen = seen; uint64_t cfirst = seenFirst;
 							const float wa = uniformW ? __uint_as_float(hw) : __uint_as_float(ww[j]);
 							const uint64_t cord = ord0 + j;
-							/* the next k-mer of this lane: one base in (or the next record's first k-mer), and its home slot requested */
+							/* the next k-mer of this lane (the next record's first one when this record is through), and its home slot requested */
 							j++; left--;
 							if (left) {
-								if (j < n) { const uint32_t nb = j + k - 1; roll.push((bw[nb >> 4] >> (30 - 2 * (nb & 15u))) & 3u); }
-								else { rs += (hy >> 17) & 0x7fu; const uint4 hd = wstage[rs]; hx = hd.x; hy = hd.y; hw = hd.w; j = 0; enter_record(); }
+								if (j >= n) { rs += (hy >> 17) & 0x7fu; const uint4 hd = wstage[rs]; hx = hd.x; hy = hd.y; hw = hd.w; j = 0; enter_record(); }
 								prepare();
 							}
 							if (SK_DBG(dbgFlags, 1)) { dbgSink ^= (uint32_t)ckey.w[0] ^ s ^ (uint32_t)cseen; }
@@ -811,7 +828,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 										curk = old;
 									}
 									if (!placed && curk == ckey.w[0]) placed = true;
-									if (!placed) s = (s + 1) & (S - 1);
+									if (!placed) { s = (s + 1) & (S - 1); cfirst = 0; }      /* another slot: its first-sighting word has not been read */
 								}
 								for (int probe = 0; probe < S && !placed; probe++) {
 									if constexpr (W == 1) {
@@ -845,13 +862,12 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 								}
 								if (!placed) s_overflow = 1;      /* table full */
 								else {
-									const uint32_t before = (uint32_t)atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(cfwd ? 1 : 0) << 32));
-									if (fastEmit) {      /* the sighting that makes the key a kept entry files its slot; a table never holds more keys than s_kept slots */
-										if (before == 1u && keepFrom != 2u) atomicAdd(&s_n2, 1u);
-										if (before + 1u == keepFrom) s_kept[atomicAdd(&s_nw, 1u)] = (uint16_t)s;
-									}
+									atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(cfwd ? 1 : 0) << 32));
 									atomicAdd(&twsum[s], (double)wa);
-									atomicMin(&tfirst[s], first_pack(cord, cfwd, wa));
+									/* the first-sighting word only ever goes down: an occurrence that does not undercut the value read together
+									 * with the key (cfirst; 0 = not read) cannot be the first one and skips the 64-bit LDS atomic */
+									const unsigned long long fp = first_pack(cord, cfwd, wa);
+									if (W > 1 || cfirst == 0 || fp < cfirst) atomicMin(&tfirst[s], fp);
 								}
 							}
 						}
@@ -862,8 +878,6 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 					cur = nxt; curCount = nxtCount;
 				}
-				/* the next list's first chunk travels while this one is emitted */
-				if (firstPass) { preList = ~0ull; if (haveNext) { pre = make_uint4(0, 0, 0, 0); preCount = (uint32_t)(dnext >> 32); if ((uint32_t)lane < preCount) pre = poolg[(size_t)(uint32_t)dnext * SK_CHUNK_G + lane]; preList = lfirst + lj + 1; } }
 				firstPass = false;
 				lds_barrier();
 				if (s_overflow || s_claimed > LIMIT) {       /* split this sub-pass in two by one more hash bit */
@@ -879,8 +893,20 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				}
 				/* emit: as count_kernel (weak entries from the front of s_kept, singletons from its back) */
 				if (SK_DBG(dbgFlags, 2)) { lds_barrier(); continue; }
-				if (fastEmit) {       /* the kept slots were filed as their counts reached keepFrom; the statistics follow from the counters */
-					if (t == 0) { uniq += s_claimed; single += s_claimed - (keepFrom == 2u ? s_nw : s_n2); }
+				if (fastEmit) {       /* only the counts are looked at: a slot is kept from keepFrom sightings on, nothing goes to the singleton map */
+					if (t == 0) uniq += s_claimed;
+#pragma unroll
+					for (int i = 0; i < S / COUNT_THREADS; i++) {
+						const int s = i * COUNT_THREADS + t;
+						const uint32_t count = (uint32_t)tcnt[s];
+						const unsigned long long mk = __ballot(count >= keepFrom), m1 = __ballot(count == 1u);
+						if (lane == 0) single += (unsigned long long)__builtin_popcountll(m1);
+						if (mk == 0) continue;
+						uint32_t bw = 0;
+						if (lane == 0) bw = atomicAdd(&s_nw, (uint32_t)__builtin_popcountll(mk));
+						bw = (uint32_t)__shfl((int)bw, 0, 64);
+						if (count >= keepFrom) s_kept[bw + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1))] = (uint16_t)s;
+					}
 				} else {
 				uint32_t cls[S / COUNT_THREADS];
 #pragma unroll
