@@ -2,19 +2,22 @@
 """bench.py -- k-mer spectrum build throughput on MI355X.
 
 A step = one full pass of the hot path over one batch of synthetic reads that is already
-resident in HBM: reset (empty table) -> extract + canonicalise + weight + lookup3 + insert
--> finalize (purge, bucket, sort: the queryable spectrum in the reference's map layout).
+resident in HBM: reset (empty maps) -> extract + canonicalise + weight + count -> finalize
+(purge, bucket, sort: the queryable spectrum in the reference's map layout).
 
 N=1 runs BASELINE.json configs[1] ("C2": k=31, 10M synthetic 150 bp reads, 1 GPU, single hash
-partition).  N>1 (launched by torch.distributed.run, one rank per GPU) is weak scaling: every
-rank brings its own 10M reads of one shared genome and k-mers are exchanged to their
-lookup3 owner with an RCCL all-to-all.
+partition).  N>1 is weak scaling, one rank per GPU: every rank brings its own 10M reads of one
+shared genome and the k-mers travel to their owner over RCCL.  `python bench.py --gpus N` starts
+the N ranks itself (python -m torch.distributed.run as a child process, before this process has
+touched a GPU); under an external launcher (WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -22,26 +25,66 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np
-import torch
-
 K = 31
 READ_LEN = 150
 ERR = 0.01
 HBM_PEAK = 8.0e12      # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def gen_reads(n_reads, genome_len, seed, rank, dev, chunk=1 << 20):
-    """SURVEY.md 8(d) generator on the GPU: uniform genome, uniform starts, random strand,
-    1 % substitutions, flat Q40 ('I'), no N.  The genome depends on `seed` only, the reads on
-    (seed, rank)."""
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (C2 = 10M)")
+    ap.add_argument("--quality", choices=["flat", "noisy"], default="flat", help="SURVEY 8(d): flat Q40 (the headline), or noisy "
+                    "(Q in {40,30,20,10,2} with p = {.80,.10,.05,.04,.01}, errors at Q10: the divide chain and the discard path are live)")
+    ap.add_argument("--cpu-reads", type=int, default=1_000_000, help="reads of the CPU baseline's sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--force-exchange", action="store_true", help="run the owner-exchange path even on one GPU (sanity/timing of the N>1 code)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="development: all ranks share GPU 0 and talk over gloo (RCCL refuses two "
+                    "ranks on one device); exercises the N>1 code, its timings mean nothing")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="kmr_tune knob of the handle (measurement sweeps), e.g. partition_blocks=192")
+    ap.add_argument("--no-check", action="store_true", help="development: skip the conservation assert (ablation runs of a debug build)")
+    ap.add_argument("--build-mode", type=int, default=0, help="kmr_config.build_mode: 0 auto, 1 device table, 2 two-level k-mer partition, 3 super-k-mer lists")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` without a launcher: start N ranks as a child job and pass its JSON line through.  Nothing in this
+    process has touched a GPU (torch is not even imported yet)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    sys.exit(p.returncode if p.returncode else (0 if lines else 1))
+
+
+def gen_reads(torch, n_reads, genome_len, seed, rank, dev, quality="flat", chunk=1 << 20):
+    """SURVEY.md 8(d) generator on the GPU: uniform genome, uniform starts, random strand, 1 % substitutions, no N.
+    The genome depends on `seed` only, the reads on (seed, rank)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     genome = torch.randint(0, 4, (genome_len,), generator=g, device=dev, dtype=torch.uint8)
     g.manual_seed(seed * 1000003 + 17 * (rank + 1))
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    bases = torch.empty(n_reads * READ_LEN, dtype=torch.uint8, device=dev)
+    bases = torch.empty(n_reads * READ_LEN + 64, dtype=torch.uint8, device=dev)
+    quals = torch.empty(n_reads * READ_LEN + 64, dtype=torch.uint8, device=dev)
+    bases[n_reads * READ_LEN:] = 0
+    quals[n_reads * READ_LEN:] = 0
     ar = torch.arange(READ_LEN, device=dev, dtype=torch.int64)
+    qchars = torch.tensor([33 + 40, 33 + 30, 33 + 20, 33 + 10, 33 + 2], dtype=torch.uint8, device=dev)
+    qcum = torch.tensor([0.80, 0.90, 0.95, 0.99], device=dev)
     for lo in range(0, n_reads, chunk):
         m = min(chunk, n_reads - lo)
         starts = torch.randint(0, genome_len - READ_LEN + 1, (m,), generator=g, device=dev, dtype=torch.int64)
@@ -53,71 +96,88 @@ def gen_reads(n_reads, genome_len, seed, rank, dev, chunk=1 << 20):
         shift = torch.randint(1, 4, (m, READ_LEN), generator=g, device=dev, dtype=torch.uint8)
         codes = torch.where(errs, (codes + shift) & 3, codes)
         bases[lo * READ_LEN:(lo + m) * READ_LEN] = lut[codes.long()].reshape(-1)
-    quals = torch.full((n_reads * READ_LEN,), ord("I"), dtype=torch.uint8, device=dev)
+        if quality == "noisy":
+            u = torch.rand((m, READ_LEN), generator=g, device=dev)
+            q = qchars[torch.bucketize(u, qcum)]
+            q = torch.where(errs, qchars[3], q)
+            quals[lo * READ_LEN:(lo + m) * READ_LEN] = q.reshape(-1)
+    if quality == "flat":
+        quals[:n_reads * READ_LEN] = ord("I")
     offsets = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * READ_LEN
     return bases, quals, offsets
 
 
-def cpu_baseline(bases, quals, n_sample):
-    """The oracle (CPU restatement of _buildKmerSpectrumParallel, kind 'port') on a bounded
-    sample of the same workload, all host cores."""
+def cpu_baseline(torch, n_reads, quality, dev):
+    """The oracle (CPU restatement of _buildKmerSpectrumParallel, kind 'port') on a sample at the SAME coverage as the GPU
+    workload (its own genome of 5 bases per read: 30x): the thread count is picked on a 100 000-read sweep (the reference's
+    build takes global atomics per occurrence, src/KmerSpectrum.h:1589-1603, and does not scale to many cores), then the full
+    sample is built three times at that count and the median reported."""
+    import numpy as np
     from helpers import OracleSpectrum, ReadBatch, default_config, oracle_lib
     lib = oracle_lib()
     cores = lib.orc_max_threads()
-    b = bases[:n_sample * READ_LEN].cpu().numpy()
-    q = quals[:n_sample * READ_LEN].cpu().numpy()
-    off = (np.arange(n_sample + 1, dtype=np.uint64) * np.uint64(READ_LEN))
-    rb = ReadBatch.from_arrays(b, q, off)
-    cfg = default_config(K, estimated_raw_kmers=n_sample * (READ_LEN - K + 1))
-    # the reference's build takes global atomics per occurrence (src/KmerSpectrum.h:1589-1603) and does
-    # not scale to many cores, so the thread count is swept and the fastest one is reported
-    best, best_t, sweep = None, 1, {}
-    for t in sorted(set([1, 4, 8, 16, 32, cores])):
-        if t > cores:
-            continue
-        s = OracleSpectrum(cfg)
+    bases, quals, _ = gen_reads(torch, n_reads, 5 * n_reads, 7, 0, dev, quality)
+    b = bases[:n_reads * READ_LEN].cpu().numpy()
+    q = quals[:n_reads * READ_LEN].cpu().numpy()
+    del bases, quals
+
+    def run(n, threads):
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(READ_LEN)
+        rb = ReadBatch.from_arrays(b[:n * READ_LEN], q[:n * READ_LEN], off)
+        s = OracleSpectrum(default_config(K, estimated_raw_kmers=n * (READ_LEN - K + 1)))
         t0 = time.perf_counter()
-        s.add_reads(rb, threads=t)
+        s.add_reads(rb, threads=threads)
         s.finalize(2)
         dt = time.perf_counter() - t0
-        st = s.stats()
+        raw = s.stats()["raw_kmers"]
         s.close()
-        sweep[t] = st["raw_kmers"] / dt
-        if best is None or dt < best:
-            best, best_t = dt, t
-    return {"value": st["raw_kmers"] / best, "unit": "kmers/s", "cores": best_t, "kind": "port",
-            "sample": "first %d reads of the same synthetic batch (%d k-mers), OpenMP T x T bucket-ownership build + purge; "
-                      "fastest of a thread sweep on a %d-thread host" % (n_sample, st["raw_kmers"], cores),
-            "seconds": best, "kmers_per_s_by_threads": sweep}
+        return raw, dt
+
+    sweep = {}
+    n_sweep = min(100_000, n_reads)
+    for t in sorted(set([1, 4, 8, 16, 32, cores])):
+        if t <= cores:
+            raw, dt = run(n_sweep, t)
+            sweep[t] = raw / dt
+    best_t = max(sweep, key=sweep.get)
+    runs = [run(n_reads, best_t) for _ in range(3)]
+    raw = runs[0][0]
+    secs = statistics.median(r[1] for r in runs)
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": raw / secs, "unit": "kmers/s", "cores": best_t, "kind": "port",
+            "sample": "%d synthetic reads (%d k-mers) of a %d bp genome -- the GPU workload's 30x coverage, error rate and quality mode -- "
+                      "through the OpenMP T x T bucket-ownership build + purge of the oracle; %d threads (best of a sweep on %d reads), "
+                      "median of 3 runs" % (n_reads, raw, 5 * n_reads, best_t, n_sweep),
+            "seconds": secs, "run_seconds": [r[1] for r in runs], "kmers_per_s_by_threads_on_sweep": sweep,
+            "host": {"nproc": os.cpu_count(), "threads_available": cores, "cpu_model": model}}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (C2 = 10M)")
-    ap.add_argument("--cpu-sample", type=int, default=50_000)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--force-exchange", action="store_true", help="run the owner-exchange path even on one GPU (sanity/timing of the N>1 code)")
-    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="development: all ranks of a torch.distributed.run launch share GPU 0 and talk "
-                    "over gloo (RCCL refuses two ranks on one device); exercises the N>1 code, its timings mean nothing")
-    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="kmr_tune knob of the handle (measurement sweeps), e.g. partition_blocks=192")
-    ap.add_argument("--no-check", action="store_true", help="development: skip the conservation assert (ablation runs of a debug build)")
-    ap.add_argument("--build-mode", type=int, default=0, help="kmr_config.build_mode: 0 auto (streaming partition), 1 device table")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     # stdout carries exactly one JSON line: libraries that print there (RCCL writes a version banner when its first communicator
     # comes up) are pointed at stderr, and the line goes out through the saved descriptor
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    import torch
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.rehearse_on_one_gpu:
         local_rank = 0
-    if world > 1 or args.force_exchange:
+    exchange = world > 1 or args.force_exchange
+    if exchange:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if args.rehearse_on_one_gpu:
@@ -139,7 +199,7 @@ def main():
     n_reads = args.reads
     kmers_per_read = READ_LEN - K + 1
     genome_len = 5 * n_reads * world               # 30x coverage
-    bases, quals, offsets = gen_reads(n_reads, genome_len, 1, rank, dev)
+    bases, quals, offsets = gen_reads(torch, n_reads, genome_len, 1, rank, dev, args.quality)
     total_bases = n_reads * READ_LEN
     torch.cuda.synchronize()
 
@@ -147,6 +207,7 @@ def main():
                             rank=rank, world_size=world, build_mode=args.build_mode)
     sp = ka.KmerSpectrum(cfg)
     sp.tune(**{kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.tune})
+    xstats = {}
 
     def barrier():
         torch.cuda.synchronize()
@@ -156,16 +217,17 @@ def main():
 
     def step():
         sp.reset()
-        if world == 1 and not args.force_exchange:
+        if not exchange:
             sp.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n_reads, total_bases, 0)
         else:
-            build_partitioned(sp, bases, quals, offsets, first_read_idx=rank * n_reads)
+            build_partitioned(sp, bases, quals, offsets, first_read_idx=rank * n_reads, stats=xstats)
         sp.finalize(2)
 
     for _ in range(args.warmup):
         step()
     barrier()
     sp.kernel_time_reset()
+    xstats.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -178,10 +240,8 @@ def main():
         dt = float(t.item())
 
     st = sp.stats()
-    build_ms, build_launches = sp.kernel_time(0)
-    fin_ms, fin_launches = sp.kernel_time(1)
-    raw_local = st["raw_kmers"]
-    uniq_local = st["unique_kmers"]
+    ktimes = {g: sp.kernel_time(g) for g in range(7)}       # HIP-event times of the timed steps (the PCIe leg below runs more builds)
+    raw_local, uniq_local = st["raw_kmers"], st["unique_kmers"]
     if dist is not None:
         t = torch.tensor([raw_local, uniq_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t)
@@ -189,55 +249,107 @@ def main():
     else:
         raw_total, uniq_total = raw_local, uniq_local
     total_kmers = n_reads * kmers_per_read * world
-    assert args.no_check or raw_total == total_kmers, (raw_total, total_kmers)
+    # conservation: every k-mer of every rank's reads is accounted for somewhere (through the exchange the owners count the good
+    # ones they receive, so the flat-quality case -- nothing discarded -- is the one that can be checked there)
+    assert args.no_check or raw_total == total_kmers or (exchange and args.quality != "flat"), (raw_total, total_kmers)
+
+    # PCIe-inclusive leg (t_build from "first byte of in-memory reads available"): the reads start in pinned host memory
+    # and go to the device in eight pieces on a copy stream while the library's stream builds the pieces that have arrived
+    h2d = None
+    if not args.no_h2d and not exchange and rank == 0:
+        hb = torch.empty(total_bases, dtype=torch.uint8).pin_memory()
+        hq = torch.empty(total_bases, dtype=torch.uint8).pin_memory()
+        hb.copy_(bases[:total_bases])
+        hq.copy_(quals[:total_bases])
+        db = torch.empty_like(bases)
+        dq = torch.empty_like(quals)
+        db[total_bases:] = 0
+        dq[total_bases:] = 0
+        pieces = 8
+        per = (n_reads + pieces - 1) // pieces
+        lib_stream = torch.cuda.ExternalStream(sp.stream(), device=dev)
+        copy_stream = torch.cuda.Stream(device=dev)
+
+        def h2d_step(copy_only=False):
+            sp.reset()
+            torch.cuda.synchronize()
+            evs = []
+            with torch.cuda.stream(copy_stream):
+                for c in range(pieces):
+                    lo, hi = c * per * READ_LEN, min(n_reads, (c + 1) * per) * READ_LEN
+                    db[lo:hi].copy_(hb[lo:hi], non_blocking=True)
+                    dq[lo:hi].copy_(hq[lo:hi], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                    evs.append(ev)
+            if not copy_only:
+                for c in range(pieces):
+                    r0, r1 = c * per, min(n_reads, (c + 1) * per)
+                    lib_stream.wait_event(evs[c])
+                    sp.buildKmerSpectrumDevice(db.data_ptr(), dq.data_ptr(), offsets.data_ptr() + 8 * r0, r1 - r0, (r1 - r0) * READ_LEN, r0)
+                sp.finalize(2)
+            torch.cuda.synchronize()
+
+        h2d_step()
+        t1 = time.perf_counter()
+        for _ in range(max(1, args.steps)):
+            h2d_step()
+        t_incl = (time.perf_counter() - t1) / max(1, args.steps)
+        assert args.no_check or sp.stats()["raw_kmers"] == n_reads * kmers_per_read
+        t1 = time.perf_counter()
+        h2d_step(copy_only=True)
+        t_copy = time.perf_counter() - t1
+        h2d = {"value_incl_h2d": n_reads * kmers_per_read / t_incl, "ms_per_step_incl_h2d": t_incl * 1e3, "h2d_ms": t_copy * 1e3,
+               "h2d_GBps": 2.0 * total_bases / t_copy / 1e9,
+               "how": "bases + quals (%.1f GB) from pinned host memory in %d pieces on a copy stream, each piece built as it arrives" % (2.0 * total_bases / 1e9, pieces)}
+        del hb, hq, db, dq
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_kmers / (dt / args.steps)
         kb = (K + 3) // 4
-        # algorithmic bytes: K * (2L/(L-k+1) + kb + 24) + D * kb for the k-mers rank 0 handled.
-        # The hot path of one step is a short chain of launches (extract, partition x2, count, bucket/sort),
-        # all timed with HIP events on the handle's stream; achieved = algorithmic bytes of the step / their sum.
-        k_local = raw_local
-        alg_bytes = k_local * (2.0 * READ_LEN / kmers_per_read + kb + 24) + uniq_local * kb
-        hot_ms = (build_ms + fin_ms) / max(1, args.steps)
-        achieved = alg_bytes / (hot_ms / 1e3) if hot_ms > 0 else 0.0
-        mode = "device-table" if args.build_mode == 1 else "streaming-partition"
+        # algorithmic bytes: K * (2L/(L-k+1) + kb + 24) + D * kb for the k-mers this rank handled; achieved = those
+        # bytes / the WHOLE step (wall clock between the barriers: exchange, host gaps and finalize included)
+        alg_bytes = raw_local * (2.0 * READ_LEN / kmers_per_read + kb + 24) + uniq_local * kb
+        achieved = alg_bytes / (ms_per_step / 1e3)
+        build_ms, fin_ms = ktimes[0][0], ktimes[1][0]
+        mode = {1: "device-table", 2: "two-level k-mer partition", 3: "super-k-mer lists"}[args.build_mode or (2 if exchange else 3)]
         out = {
             "metric": "total k-mers/sec at k=31, 150 bp reads (spectrum build, inputs resident in HBM)",
             "value": value, "unit": "kmers/s",
             "distinct_kmers_per_sec": uniq_total / (dt / args.steps),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: k=31, %d synthetic 150 bp reads per GPU, genome %d bp (30x), 1%% substitutions, flat Q40, "
-                                   "min-depth 2, %s" % (n_reads, genome_len, "single hash partition" if world == 1 else
-                                                        "owner-partitioned (lookup3) RCCL all-to-all over %d GPUs" % world),
-                       "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "total_kmers": total_kmers,
-                       "distinct_kmers": uniq_total, "build_mode": mode,
+            "config": {"workload": "C2: k=31, %d synthetic 150 bp reads per GPU, genome %d bp (30x), 1%% substitutions, %s, "
+                                   "min-depth 2, %s" % (n_reads, genome_len, "flat Q40" if args.quality == "flat" else "noisy qualities (SURVEY 8d)",
+                                                        "single hash partition" if world == 1 else "owner-partitioned RCCL all-to-all over %d GPUs" % world),
+                       "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "total_kmers": total_kmers, "good_kmers_rank0": st["raw_good_kmers"],
+                       "distinct_kmers": uniq_total, "build_mode": mode, "quality": args.quality,
                        "parallelism": "1 process per GPU, owner partition x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": ("extract_kernel<1,false,InsertOp>" if args.build_mode == 1 else
-                                    "hot path of one step: extract_kernel<LinearOp> + partition_direct_kernel<1,1> per sub-batch, "
-                                    "then partition_direct_kernel<1,2> + count_kernel + entry_scatter/sort_buckets"),
-                         "algorithmic_bytes_per_step": alg_bytes, "hot_path_ms_per_step": hot_ms,
-                         "build_ms_per_step": build_ms / max(1, args.steps), "build_launch_groups_per_step": build_launches // max(1, args.steps),
-                         "finalize_ms_per_step": fin_ms / max(1, args.steps)},
+                         "algorithmic_bytes_per_step": alg_bytes, "step_ms": ms_per_step,
+                         "hip_event_ms_per_step": {"build": build_ms / max(1, args.steps), "finalize": fin_ms / max(1, args.steps)}},
         }
         if args.build_mode != 1:
-            # per-kernel view of the same step: every kernel against the bytes its own role has to move (16-byte
-            # records at k=31; weak entries are 8-byte key + 12-byte value), each timed with HIP events on the handle's
-            # stream; rocprofv3 averages of the same command are in profiles/ (kernel_stats csv)
-            rec = 8 * ((kb + 7) // 8) + 8
+            # per-kernel view of the same step: every kernel against the bytes its own role has to move, each timed with HIP
+            # events on the handle's stream; rocprofv3 averages of the same command are in profiles/ (kernel_stats csv)
             weak = st["weak_entries"]
-            per = [("extract_kernel<LinearOp>", 2, k_local * (2.0 * READ_LEN / kmers_per_read + rec)),
-                   ("partition_direct_kernel<level 1>", 3, k_local * 2.0 * rec),
-                   ("partition_direct_kernel<level 2>", 4, k_local * 2.0 * rec),
-                   ("count_kernel", 5, k_local * rec + weak * 20.0),
-                   ("bucket scan + entry_scatter_kernel + sort_buckets_kernel", 6, weak * 60.0)]
+            if mode == "super-k-mer lists":
+                sk_bytes = (3.8 if args.quality == "flat" else 9.4) * raw_local      # a 32-byte record per ~8.5 k-mers (+ 4 bytes per k-mer when the weights differ)
+                per = [("sk_extract_kernel (extract + weight chain + minimizer + list scatter)", 2, raw_local * 2.0 * READ_LEN / kmers_per_read + sk_bytes),
+                       ("sk_count_kernel (expand + count in LDS)", 5, sk_bytes + weak * 20.0),
+                       ("bucket scan + entry_scatter_kernel + sort_buckets_kernel", 6, weak * 60.0)]
+            else:
+                rec = 8 * ((kb + 7) // 8) + 8
+                per = [("extract_kernel<LinearOp>", 2, raw_local * (2.0 * READ_LEN / kmers_per_read + rec)),
+                       ("partition_direct_kernel<level 1>", 3, raw_local * 2.0 * rec),
+                       ("partition_direct_kernel<level 2>", 4, raw_local * 2.0 * rec),
+                       ("count_kernel", 5, raw_local * rec + weak * 20.0),
+                       ("bucket scan + entry_scatter_kernel + sort_buckets_kernel", 6, weak * 60.0)]
             kernels = []
             for name, grp, nbytes in per:
-                ms, launches = sp.kernel_time(grp)
+                ms, launches = ktimes[grp]
                 if launches == 0:
                     continue
                 ms_step = ms / max(1, args.steps)
@@ -246,18 +358,26 @@ def main():
                                 "achieved_GBps": nbytes / (ms_step / 1e3) / 1e9, "frac": nbytes / (ms_step / 1e3) / HBM_PEAK})
             out["roofline"]["kernels"] = kernels
             if kernels:
-                out["roofline"]["dominant_kernel"] = max(kernels, key=lambda k: k["ms_per_step"])["name"]
-        # HBM bytes from the PMC counters: bench.py cannot run rocprofv3 on itself, so the committed summary of
-        # the same command (profiles/r01_pmc_traffic.json, tools/pmc.sh) is quoted when it describes this workload
+                dom = max(kernels, key=lambda k: k["ms_per_step"])
+                out["roofline"]["dominant_kernel"] = {"name": dom["name"], "ms_per_launch": dom["ms_per_launch"],
+                                                      "bytes_per_launch": dom["bytes_per_step"] / max(1, dom["launches_per_step"]),
+                                                      "achieved_GBps": dom["achieved_GBps"], "frac": dom["frac"]}
+        if exchange:
+            out["exchange"] = {k: (v / max(1, args.steps) if isinstance(v, (int, float)) else v) for k, v in xstats.items()}
+        # HBM bytes from the PMC counters: bench.py cannot run rocprofv3 on itself, so the committed summary of the same command
+        # (tools/pmc.sh -> profiles/r02_pmc_traffic.json) is quoted when it describes this workload and build mode
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if args.build_mode != 1 and n_reads == 10_000_000 and world == 1:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            if tj.get("build_mode") == mode and n_reads == 10_000_000 and world == 1 and args.quality == tj.get("quality", "flat"):
                 out["roofline"]["traffic"] = tj["hot_path_total_GB_per_step"] * 1e9
-                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (bytes per step, FETCH_SIZE x2 corrected)"
+                out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic.json (bytes per step, FETCH_SIZE x2 corrected)"
         except Exception:
             pass
+        if h2d:
+            out.update({"value_incl_h2d": h2d["value_incl_h2d"], "h2d_ms": h2d["h2d_ms"]})
+            out["h2d"] = h2d
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(bases, quals, min(args.cpu_sample, n_reads))
+            out["cpu_baseline"] = cpu_baseline(torch, min(args.cpu_reads, n_reads), args.quality, dev)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

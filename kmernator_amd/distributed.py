@@ -28,6 +28,15 @@ def _exchange_counts(counts, group=None):
     return [int(x) for x in send.cpu().tolist()], [int(x) for x in recv.cpu().tolist()]
 
 
+def _check_overflow(sc, seg_capacity, group, device):
+    """An owner segment that overflowed has lost records on THAT rank only: the decision to stop is taken by everybody (a MAX
+    all-reduce of the flag), otherwise the other ranks would walk into the records all-to-all and wait for the one that raised."""
+    flag = torch.tensor([1 if max(sc) > seg_capacity else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        raise RuntimeError("owner segment overflow on some rank (this rank: %d of %d records): raise `slack` or lower `chunk_reads`" % (max(sc), seg_capacity))
+
+
 def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
     """records: uint8 tensor [world * seg_capacity * rec_bytes], segment s holds
     seg_counts[s] records for rank s.  Returns (recv uint8 tensor, n_records).
@@ -36,8 +45,7 @@ def exchange_records(records, seg_counts, seg_capacity, rec_bytes, group=None):
     collective count records (a byte count overflows 32 bits at ~1.8e8 twelve-byte records)."""
     world = dist.get_world_size(group)
     sc, rc = _exchange_counts(seg_counts, group)
-    if max(sc) > seg_capacity:
-        raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_capacity))
+    _check_overflow(sc, seg_capacity, group, records.device)
     assert rec_bytes % 4 == 0
     words = rec_bytes // 4
     rows = records.view(torch.int32).view(world, seg_capacity, words)
@@ -88,13 +96,16 @@ def _plan_chunks(offsets_host, n, rb, chunk_reads):
     return chunk_reads, n_chunks, max_kmers
 
 
-def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_reads=None, group=None, slack=1.25, pipeline=True):
+def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_reads=None, group=None, slack=1.25, pipeline=True, stats=None):
     """Device tensors in, spectrum (rank/world_size configured) built in place.
     bases/quals: uint8 cuda tensors, offsets: int64/uint64 cuda tensor [n+1].
 
     pipeline=True overlaps the all-to-all of chunk c with the extraction of chunk c+1: the library's stream S
     runs extract(0), extract(1), [wait comm 0] insert(0), extract(2), [wait comm 1] insert(1), ... while a second
-    stream compacts the owner segments and runs the collectives; two record buffers alternate."""
+    stream compacts the owner segments and runs the collectives; two record buffers alternate.
+
+    stats (a dict, optional) accumulates over calls: "chunks", "records_sent", "bytes_to_peers" (what leaves this GPU over xGMI:
+    the records of other owners), "alltoall_ms" (device time of the record all-to-alls, by events on their stream)."""
     from . import record_bytes
     world = dist.get_world_size(group)
     n = offsets.numel() - 1
@@ -138,6 +149,8 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
     torch.cuda.synchronize(dev)
     ev_extract = [torch.cuda.Event() for _ in range(nbuf)]
     keep_alive = []
+    timed = []
+    my_rank = dist.get_rank(group)
     words = rb // 4
     submit_extract(0)
     ev_extract[0].record(lib_stream)
@@ -149,12 +162,18 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev_extract[b])
             sc, rc = _exchange_counts(counts[b].clone(), group)     # host waits for extract(c) and the counts exchange only
-            if max(sc) > seg_cap:
-                raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_cap))
+            _check_overflow(sc, seg_cap, group, dev)
             rows = records[b].view(torch.int32).view(world, seg_cap, words)
+            ev_a = torch.cuda.Event(enable_timing=True)
+            ev_a.record(comm_stream)
             recv = _all_to_all_rows(rows, sc, rc, group)
-            ev_comm = torch.cuda.Event()
+            ev_comm = torch.cuda.Event(enable_timing=True)
             ev_comm.record(comm_stream)
+            timed.append((ev_a, ev_comm))
+            if stats is not None:
+                stats["chunks"] = stats.get("chunks", 0) + 1
+                stats["records_sent"] = stats.get("records_sent", 0) + sum(sc)
+                stats["bytes_to_peers"] = stats.get("bytes_to_peers", 0) + (sum(sc) - sc[my_rank]) * rb
         recv.record_stream(lib_stream)
         keep_alive.append(recv)
         if len(keep_alive) > 3:
@@ -164,6 +183,8 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
             spectrum.insertRecordsDevice(recv.data_ptr(), sum(rc))
     spectrum.sync()
     torch.cuda.synchronize(dev)
+    if stats is not None:
+        stats["alltoall_ms"] = stats.get("alltoall_ms", 0.0) + sum(a.elapsed_time(b) for a, b in timed)
     return spectrum
 
 
@@ -221,8 +242,7 @@ def score_partitioned(spectrum, bases, offsets, minimum_kmer_score, scoring_type
             counts.zero_()
         fence()
         sc, rc = _exchange_counts(counts, group)
-        if max(sc) > seg_cap:
-            raise RuntimeError("owner segment overflow: %d > %d" % (max(sc), seg_cap))
+        _check_overflow(sc, seg_cap, group, dev)
         asked = _all_to_all_rows(keys, sc, rc, group)                      # the k-mers other ranks want from this one
         answers = torch.zeros((sum(rc), 1), dtype=torch.int32, device=dev)
         if sum(rc):

@@ -99,20 +99,29 @@ def test_ranks_sharing_one_gpu(world, pipeline):
                 assert np.array_equal(a, b)
 
 
-def test_bench_n2_code_path_on_one_gpu():
-    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), both ranks on this GPU over
-    gloo: the JSON line must come out and account for every k-mer of both ranks"""
+@pytest.mark.parametrize("how", ["external launcher", "bench.py --gpus 2"])
+def test_bench_n2_code_path_on_one_gpu(how):
+    """bench.py for N = 2, both ranks on this GPU over gloo (RCCL refuses two ranks on one device): once under
+    torch.distributed.run as the driver launches it, once as plain `bench.py --gpus 2`, which has to start its two ranks itself.
+    One JSON line must come out, say n_gpus 2, and account for every k-mer of both ranks; its roofline is priced on the whole
+    step (exchange included) and the exchange's bytes and time are reported."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 31800 + (os.getpid() % 1000)
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                        "--reads", "300000", "--no-cpu", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=600, cwd=root)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "300000", "--no-cpu", "--rehearse-on-one-gpu"]
+    if how == "external launcher":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["total_kmers"] == 2 * 300000 * 120
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert abs(d["roofline"]["achieved"] * 1e9 - d["roofline"]["algorithmic_bytes_per_step"] / (d["ms_per_step"] / 1e3)) < 1e-3 * d["roofline"]["achieved"] * 1e9
+    assert d["exchange"]["bytes_to_peers"] > 0 and d["exchange"]["alltoall_ms"] > 0
