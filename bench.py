@@ -70,9 +70,10 @@ def launch_ranks(args):
     sys.exit(p.returncode if p.returncode else (0 if lines else 1))
 
 
-def gen_reads(torch, n_reads, genome_len, seed, rank, dev, quality="flat", chunk=1 << 20):
+def gen_reads(torch, n_reads, genome_len, seed, rank, dev, quality="flat", chunk=1 << 20, read_len=READ_LEN):
     """SURVEY.md 8(d) generator on the GPU: uniform genome, uniform starts, random strand, 1 % substitutions, no N.
     The genome depends on `seed` only, the reads on (seed, rank)."""
+    READ_LEN = read_len
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     genome = torch.randint(0, 4, (genome_len,), generator=g, device=dev, dtype=torch.uint8)

@@ -558,7 +558,7 @@ def test_c2_full_size_properties():
     import bench
     n = 10_000_000
     dev = torch.device("cuda", 0)
-    bases, quals, offsets = bench.gen_reads(n, 5 * n, 1, 0, dev)
+    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev)
     torch.cuda.synchronize()
     c = ka.default_config(31, estimated_raw_kmers=n * 120, device=0)
     p = ka.KmerSpectrum(c)
@@ -792,3 +792,72 @@ def test_ext_hot_kmer_takes_the_wide_tally_table():
     assert n > 1000
     hot = np.zeros((1, p.kb), dtype=np.uint8)          # A^21 packed
     assert p.getCount(hot)[0] == 65535 == o.lookup(hot)[0]
+
+
+def _image_digest(sp, which=KMR_MAP_WEAK):
+    import hashlib
+    img = sp.image(which)
+    return img.size, hashlib.blake2b(memoryview(img), digest_size=16).hexdigest()
+
+
+def test_c4_full_size_k51():
+    """BASELINE.json configs[3] at full size: k = 51 (two-word keys), 50 M synthetic 100 bp reads = 2.5e9 k-mers over 5e9 input
+    bases -- more than 2^32, so the stream ordinal that decides which sighting of a k-mer was its first (directionBias, the
+    quantised first weight) has to be wider than 32 bits.  The default build (super-k-mer lists) must conserve the k-mers, be
+    consistent with its own histogram and lookups, and give the weak map of the device-table build (build_mode 1, 40-bit
+    ordinals in the slots) BYTE FOR BYTE -- counts, weights and direction biases; build_mode 2's 16-byte records carry 32
+    ordinal bits and must refuse the input instead of being quietly wrong."""
+    import torch
+    import bench
+    n, rl, k = 50_000_000, 100, 51
+    dev = torch.device("cuda", 0)
+    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev, read_len=rl)
+    torch.cuda.synchronize()
+    per = rl - k + 1
+    digests, stats = {}, {}
+    for mode in (0, 1):
+        p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per, device=0, build_mode=mode))
+        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * rl, 0)
+        p.finalize(2)
+        st = p.stats()
+        assert st["raw_kmers"] == n * per == st["raw_good_kmers"]
+        assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
+        if mode == 0:
+            hist = p.histogram(4096)[0]
+            assert int(hist.sum()) == st["weak_entries"]
+            assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
+            # lookups of k-mers cut out of the reads
+            host = bases[:200 * rl].cpu().numpy().tobytes()
+            lib = ka.load()
+            import ctypes as C
+            keys = np.zeros((200, p.kb), dtype=np.uint8)
+            for r in range(200):
+                packed = np.zeros(p.kb, dtype=np.uint8)
+                lib.kmr_compress_sequence(host[r * rl + 7:r * rl + 7 + k], k, packed.ctypes.data_as(C.POINTER(C.c_uint8)), None, None, 0)
+                lib.kmr_least_complement(packed.ctypes.data_as(C.POINTER(C.c_uint8)), k, keys[r].ctypes.data_as(C.POINTER(C.c_uint8)))
+            got = p.getCount(keys)
+            assert (got >= 1).sum() > 100 and got.max() < 200      # ~20x coverage of a random genome
+        stats[mode] = st
+        digests[mode] = _image_digest(p)
+        p.close()
+        del p
+    assert stats[0] == stats[1]
+    assert digests[0] == digests[1]
+    p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per, device=0, build_mode=2))
+    with pytest.raises(ka.KmerSpectrumError, match="32-bit stream ordinal"):
+        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * rl, 0)
+    p.close()
+
+
+@pytest.mark.parametrize("k", [31, 51])
+def test_million_noisy_reads_against_the_oracle(k):
+    """1 M reads x 100 bp with noisy qualities (the discard path and the divide chain are live) against the SERIAL
+    oracle: statistics, the weak image byte for byte in keys, counts, direction biases, weightedCount within 1e-5 * count --
+    an order of magnitude above the other oracle comparisons, to catch offset arithmetic and seams that only show at size."""
+    n, rl = 1_000_000, 100
+    rb = synth_reads(n, read_len=rl, genome_len=3 * n, seed=100 + k, quality="noisy", n_rate=0.0005)
+    cfg = default_config(k, estimated_raw_kmers=n * (rl - k + 1))
+    o, p = run_both(cfg, rb, min_depth=2, mode=0)
+    nkept = compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    assert nkept == o.stats()["weak_entries"] and nkept > 1_000_000
+    o.close()
