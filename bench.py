@@ -195,7 +195,7 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     import kmernator_amd as ka
-    from kmernator_amd.distributed import build_partitioned
+    from kmernator_amd.distributed import build_partitioned, build_partitioned_superkmers
 
     n_reads = args.reads
     kmers_per_read = READ_LEN - K + 1
@@ -204,8 +204,10 @@ def main():
     total_bases = n_reads * READ_LEN
     torch.cuda.synchronize()
 
+    # N > 1 (or --force-exchange): build_mode 0 means the super-k-mer lists and their chunk exchange; 2 the k-mer record exchange
+    mode_num = args.build_mode or 3
     cfg = ka.default_config(K, estimated_raw_kmers=n_reads * kmers_per_read * world, device=dev.index,
-                            rank=rank, world_size=world, build_mode=args.build_mode)
+                            rank=rank, world_size=world, build_mode=(mode_num if exchange else args.build_mode))
     sp = ka.KmerSpectrum(cfg)
     sp.tune(**{kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.tune})
     xstats = {}
@@ -220,6 +222,9 @@ def main():
         sp.reset()
         if not exchange:
             sp.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n_reads, total_bases, 0)
+        elif mode_num == 3:
+            build_partitioned_superkmers(sp, bases[:total_bases + 64], quals[:total_bases + 64], offsets, first_read_idx=rank * n_reads, stats=xstats,
+                                         stream_origin=rank * total_bases)
         else:
             build_partitioned(sp, bases, quals, offsets, first_read_idx=rank * n_reads, stats=xstats)
         sp.finalize(2)
@@ -252,7 +257,7 @@ def main():
     total_kmers = n_reads * kmers_per_read * world
     # conservation: every k-mer of every rank's reads is accounted for somewhere (through the exchange the owners count the good
     # ones they receive, so the flat-quality case -- nothing discarded -- is the one that can be checked there)
-    assert args.no_check or raw_total == total_kmers or (exchange and args.quality != "flat"), (raw_total, total_kmers)
+    assert args.no_check or raw_total == total_kmers or (exchange and mode_num != 3 and args.quality != "flat"), (raw_total, total_kmers)
 
     # PCIe-inclusive leg (t_build from "first byte of in-memory reads available"): the reads start in pinned host memory
     # and go to the device in eight pieces on a copy stream while the library's stream builds the pieces that have arrived
@@ -314,7 +319,7 @@ def main():
         alg_bytes = raw_local * (2.0 * READ_LEN / kmers_per_read + kb + 24) + uniq_local * kb
         achieved = alg_bytes / (ms_per_step / 1e3)
         build_ms, fin_ms = ktimes[0][0], ktimes[1][0]
-        mode = {1: "device-table", 2: "two-level k-mer partition", 3: "super-k-mer lists"}[args.build_mode or (2 if exchange else 3)]
+        mode = {1: "device-table", 2: "two-level k-mer partition", 3: "super-k-mer lists"}[mode_num]
         out = {
             "metric": "total k-mers/sec at k=31, 150 bp reads (spectrum build, inputs resident in HBM)",
             "value": value, "unit": "kmers/s",

@@ -154,6 +154,13 @@ int kmr_sync(kmr_handle *h);
  * queryable / exportable. */
 int kmr_finalize(kmr_handle *h, uint32_t min_depth);
 
+/* Position in the whole input of the next base handed to kmr_add_reads* (default: 0 after kmr_create / kmr_reset, then the bases
+ * added so far).  The order of occurrences in the input decides which sighting of a k-mer was its first -- the one
+ * TrackingDataSingleton keeps without a direction and with a quantised weight (src/KmerTrackingData.h:641-658).  Ranks that each
+ * read a slice of one input set their slice's offset here, and the owner-partitioned spectra (kmr_sk_exchange_*) come out as the
+ * serial build of the whole input would have them, whatever the ranks' timing. */
+int kmr_set_stream_origin(kmr_handle *h, uint64_t ordinal);
+
 /* Empty the maps and counters but keep the device allocations, as
  * KmerSpectrum::buildKmerSpectrum does on entry (weak.reset(false);
  * singleton.reset(false), src/KmerSpectrum.h:2091-2096).  Asynchronous. */
@@ -280,6 +287,23 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
                              void *dev_records, uint64_t seg_capacity, void *dev_seg_counts);
 /* Insert n records (any owner mix that belongs to this handle) into the table. */
 int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n_records);
+
+/* The same exchange for build_mode 3 (super-k-mer lists), whose unit is not the k-mer but the list: every rank scatters the
+ * super-k-mers of ITS reads (kmr_add_reads*; nothing is filtered by owner) into the job's 2^list_bits lists, list l belongs to
+ * rank l % world_size, and what a rank holds of other ranks' lists travels as it lies: ~4 bytes per k-mer on the wire instead of
+ * the reference's 24 + kb (src/DistributedFunctions.h:274-303).  The owner of a k-mer is decided by its minimizer (private to
+ * the build), not by getDistributedThreadId: per-rank spectra are a different partition of the same k-mers, their union is
+ * the same spectrum.
+ *   kmr_sk_exchange_counts    closes the lists; chunks[r], granules[r] (host, [world_size]) = what this rank holds for owner r
+ *                             (16-byte granules; r == rank: what stays)
+ *   kmr_sk_exchange_pack_dev  the chunks of the other owners -> dev_data (owner r's granules from granule_offset[r] on, 16 bytes
+ *                             each) and dev_meta (its (list, granules) pairs, u32 x 2, from chunk_offset[r] on); they leave the pool
+ *   (the caller moves data and meta to their owners: all-to-all over RCCL / MPI)
+ *   kmr_sk_exchange_adopt_dev the received chunks (any order) are appended to this rank's own lists
+ * then kmr_finalize as usual.  All three synchronise. */
+int kmr_sk_exchange_counts(kmr_handle *h, uint64_t *chunks, uint64_t *granules);
+int kmr_sk_exchange_pack_dev(kmr_handle *h, void *dev_data, void *dev_meta, const uint64_t *granule_offset, const uint64_t *chunk_offset);
+int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *dev_meta, uint64_t n_chunks, uint64_t n_granules);
 
 /* Host-buffer forms of the two halves for a host whose exchange is MPI_Alltoallv over host memory (the reference's own,
  * src/MPIBuffer.h:588-600; include/kmernator_amd_shim.hpp, GpuDistributedKmerSpectrum).  kmr_extract_by_owner_host: the records

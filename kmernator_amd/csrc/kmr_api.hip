@@ -1271,8 +1271,9 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 	const uint64_t n = rvAll.n_reads;
 	if (!h->sk_state) {
 		/* lists: about 1100 k-mers each, as the final lists of the two-level partition */
-		const uint64_t share = h->cfg.estimated_raw_kmers / std::max<uint32_t>(1, h->cfg.world_size);
-		const uint64_t est = share ? share : total_bases;         /* the caller's estimate of the k-mers (estimateRawKmers), else this call's bases */
+		/* the list space is the whole job's (with world_size > 1 a rank owns every world_size-th list): sized from the caller's estimate
+		 * of all the k-mers (estimateRawKmers), else from this call's bases times the ranks */
+		const uint64_t est = h->cfg.estimated_raw_kmers ? h->cfg.estimated_raw_kmers : total_bases * std::max<uint32_t>(1, h->cfg.world_size);
 		uint32_t bits = 6; while (bits < 24 && (est >> bits) > h->tune.target_list / 2 + 200) bits++;
 		h->sk_bits = bits;
 		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8ull << bits));
@@ -1283,7 +1284,7 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 	const uint64_t sub_bases = h->tune.sub_batch_bases ? h->tune.sub_batch_bases : (1ull << 31);
 	const uint64_t chunk = std::max<uint64_t>(64, (sub_bases / avg) & ~63ull);
 	const DevParams dp = dev_params(h);
-	const bool filt = dp.subsample > 1 || dp.world > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0;
+	const bool filt = dp.subsample > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0;      /* (with world_size > 1 every k-mer is kept: the lists are exchanged) */
 	for (uint64_t r = 0; r < n; r += chunk) {
 		const uint64_t m = std::min(chunk, n - r);
 		ReadsView rv = rvAll;
@@ -1561,6 +1562,15 @@ int kmr_release_table(kmr_handle *h) {
 }
 
 void *kmr_stream(kmr_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+/* the stream ordinal the next kmr_add_reads* starts from (see the header) */
+int kmr_set_stream_origin(kmr_handle *h, uint64_t ordinal) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_set_stream_origin after kmr_finalize");
+	if (ordinal > MAX_STREAM_ORDINAL) return fail(h, KMR_ERR_CAPACITY, "stream ordinals have 40 bits");
+	h->stream_base = ordinal;
+	return KMR_OK;
+}
 
 /* knobs of one handle (see struct Tuning); set before the first kmr_add_reads* of a build */
 int kmr_tune(kmr_handle *h, const char *knob, double value) {
@@ -2581,6 +2591,87 @@ int kmr_insert_records(kmr_handle *h, const void *host_records, uint64_t n) {
 	if (!rc) rc = sync_state(h); else hipStreamSynchronize(h->stream);
 	hipFree(d);
 	return rc;
+}
+
+/* ---- owner exchange of super-k-mer lists (build_mode 3, world_size > 1): see kmr_superkmer.hpp */
+static int sk_exchange_ready(kmr_handle *h, const char *who) {
+	if (!h->superkmer_mode) return fail(h, KMR_ERR_STATE, std::string(who) + ": the handle does not build super-k-mer lists (build_mode 3)");
+	if (h->finalized) return fail(h, KMR_ERR_STATE, std::string(who) + " after kmr_finalize");
+	if (h->cfg.world_size > SK_OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "at most 64 ranks");
+	return 0;
+}
+static int sk_ensure_state(kmr_handle *h) {      /* a rank without reads still owns lists */
+	if (h->sk_state) return 0;
+	ReadsView rv; memset(&rv, 0, sizeof(rv));
+	return add_reads_superkmer(h, rv, 0);
+}
+int kmr_sk_exchange_counts(kmr_handle *h, uint64_t *chunks, uint64_t *granules) {
+	if (!h || !chunks || !granules) return KMR_ERR_INVALID_ARG;
+	int rc = sk_exchange_ready(h, "kmr_sk_exchange_counts"); if (rc) return rc;
+	hipSetDevice(h->device);
+	rc = sk_ensure_state(h); if (rc) return rc;
+	rc = sync_state(h); if (rc) return rc;
+	const uint32_t world = h->cfg.world_size;
+	const uint64_t nl = 1ull << h->sk_bits;
+	unsigned int head = 0;
+	HIPCHK(h, hipMemcpy(&head, h->l1.head, 4, hipMemcpyDeviceToHost));
+	if (head > h->l1.cap) head = h->l1.cap;
+	unsigned long long *d = nullptr;
+	HIPCHK(h, hipMalloc((void **)&d, 16 * SK_OWNER_MAX)); HIPCHK(h, hipMemsetAsync(d, 0, 16 * SK_OWNER_MAX, h->stream));
+	hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);
+	if (head) hipLaunchKernelGGL(sk_owner_count_kernel, dim3(grid_for(head)), dim3(256), 0, h->stream, h->l1.chunk_list, h->l1.chunk_count, head, world, d, d + SK_OWNER_MAX);
+	hipError_t e = hipGetLastError();
+	std::vector<unsigned long long> hv(2 * SK_OWNER_MAX, 0);
+	if (e == hipSuccess) e = hipMemcpyAsync(hv.data(), d, 16 * SK_OWNER_MAX, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	hipFree(d);
+	HIPCHK(h, e);
+	for (uint32_t r = 0; r < world; r++) { chunks[r] = hv[r]; granules[r] = hv[SK_OWNER_MAX + r]; }
+	return KMR_OK;
+}
+int kmr_sk_exchange_pack_dev(kmr_handle *h, void *dev_data, void *dev_meta, const uint64_t *granule_offset, const uint64_t *chunk_offset) {
+	if (!h || !dev_data || !dev_meta || !granule_offset || !chunk_offset) return KMR_ERR_INVALID_ARG;
+	int rc = sk_exchange_ready(h, "kmr_sk_exchange_pack_dev"); if (rc) return rc;
+	hipSetDevice(h->device);
+	const uint32_t world = h->cfg.world_size;
+	unsigned int head = 0;
+	HIPCHK(h, hipMemcpy(&head, h->l1.head, 4, hipMemcpyDeviceToHost));
+	if (head > h->l1.cap) head = h->l1.cap;
+	unsigned long long *d = nullptr;
+	HIPCHK(h, hipMalloc((void **)&d, 32 * SK_OWNER_MAX));
+	std::vector<unsigned long long> hv(4 * SK_OWNER_MAX, 0);
+	for (uint32_t r = 0; r < world; r++) { hv[r] = granule_offset[r]; hv[SK_OWNER_MAX + r] = chunk_offset[r]; }
+	hipError_t e = hipMemcpyAsync(d, hv.data(), 32 * SK_OWNER_MAX, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess && head) {
+		hipLaunchKernelGGL(sk_pack_kernel, dim3(grid_for((uint64_t)head * 64, 256, num_cus(h) * 8)), dim3(256), 0, h->stream, pool_view(h, h->l1), head, world, h->cfg.rank,
+		                   d, d + SK_OWNER_MAX, d + 2 * SK_OWNER_MAX, d + 3 * SK_OWNER_MAX, (uint4 *)dev_data, (uint2 *)dev_meta);
+		hipLaunchKernelGGL(sk_state_drop_kernel, dim3(grid_for(1ull << h->sk_bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << h->sk_bits, world, h->cfg.rank);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);      /* hv and d go out of scope */
+	hipFree(d);
+	HIPCHK(h, e);
+	return KMR_OK;
+}
+int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *dev_meta, uint64_t n_chunks, uint64_t n_granules) {
+	if (!h || (n_chunks && (!dev_data || !dev_meta))) return KMR_ERR_INVALID_ARG;
+	int rc = sk_exchange_ready(h, "kmr_sk_exchange_adopt_dev"); if (rc) return rc;
+	if (n_chunks == 0) return KMR_OK;
+	hipSetDevice(h->device);
+	rc = sk_ensure_state(h); if (rc) return rc;
+	const int grid = (int)std::min<uint64_t>((n_chunks + SK_ADOPT_WAVES - 1) / SK_ADOPT_WAVES, (uint64_t)num_cus(h) * 8);
+	rc = pool_reserve(h, h->l1, n_granules / SK_CHUNK_G + ((1ull << h->sk_bits) / h->cfg.world_size) + (uint64_t)grid * SK_ADOPT_WAVES * 130 + 64, true); if (rc) return rc;
+	uint32_t *cnt = nullptr; uint64_t *start = nullptr;
+	HIPCHK(h, hipMalloc((void **)&cnt, 4 * (n_chunks + 1))); HIPCHK(h, hipMalloc((void **)&start, 8 * (n_chunks + 1)));
+	hipLaunchKernelGGL(sk_meta_counts_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, h->stream, (const uint2 *)dev_meta, n_chunks, cnt);
+	rc = exclusive_scan(h, cnt, n_chunks, start);
+	if (!rc) {
+		hipLaunchKernelGGL(sk_adopt_kernel, dim3(grid), dim3(SK_ADOPT_WAVES * 64), 0, h->stream, (const uint4 *)dev_data, (const uint2 *)dev_meta, start, n_chunks, sk_params(h), pool_view(h, h->l1));
+		if (hipGetLastError() != hipSuccess) rc = fail(h, KMR_ERR_HIP, "sk_adopt_kernel launch");
+	}
+	hipStreamSynchronize(h->stream);
+	hipFree(cnt); hipFree(start);
+	return rc ? rc : sync_state(h);
 }
 
 int kmr_kernel_time(kmr_handle *h, int which, double *ms, uint64_t *launches) {

@@ -500,7 +500,6 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 						const Key<FILT ? W : 1> canon = key_le<FILT ? W : 1>(kf, kr) ? kf : kr;
 						const uint64_t hash = key_hash<FILT ? W : 1>(canon, p.kb);
 						if (p.subsample > 1 && hash % p.subsample != 0) mine = false;
-						if (p.world > 1 && distributed_thread_id(hash, p.world) != p.rank) mine = false;
 						if (p.num_parts > 1 && distributed_thread_id(hash, p.num_parts) != p.part_idx) mine = false;
 						if (mine && (p.sub_wnb | p.sub_snb)) {       /* subtractingReference->exists(least): skipped before rawKmers++ */
 							MapView<FILT ? W : 1> sw, ss;
@@ -1004,6 +1003,93 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	uniq = wave_sum(uniq); single = wave_sum(single);
 	if (lane == 0) { if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single); }
 	if (t == 0) { if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS); }
+}
+
+/* ------------------------------------------------------------------ owner exchange of super-k-mer lists */
+/* One process per GPU: every rank scatters the super-k-mers of ITS reads into all 2^list_bits lists; list l belongs to rank
+ * l % world.  What a rank holds of other ranks' lists travels as it lies -- the used granules of every such chunk, plus
+ * (list, granules) per chunk -- and the owner appends the records to its own chains (sk_adopt_kernel), so its lists end up as
+ * dense as if it had extracted everything itself and the count pass runs unchanged.  This replaces the k-mer exchange of
+ * _buildKmerSpectrumMPI (src/DistributedFunctions.h:340-458; MPI_Alltoallv, src/MPIBuffer.h:588-600) with ~4 bytes per k-mer on
+ * the wire instead of 24 + kb; the owner function is the build's own (a k-mer's minimizer decides), not getDistributedThreadId. */
+static const uint32_t SK_OWNER_MAX = 64;
+__global__ __launch_bounds__(256)
+void sk_owner_count_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, uint32_t world, unsigned long long *chunks, unsigned long long *granules) {
+	__shared__ unsigned long long lc[SK_OWNER_MAX], lg[SK_OWNER_MAX];
+	if (threadIdx.x < SK_OWNER_MAX) { lc[threadIdx.x] = 0; lg[threadIdx.x] = 0; }
+	__syncthreads();
+	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t l = chunk_list[c];
+		if (l == NO_CHUNK || chunk_count[c] == 0) continue;
+		atomicAdd(&lc[l % world], 1ull); atomicAdd(&lg[l % world], (unsigned long long)chunk_count[c]);
+	}
+	__syncthreads();
+	if (threadIdx.x < world) { if (lc[threadIdx.x]) { atomicAdd(&chunks[threadIdx.x], lc[threadIdx.x]); atomicAdd(&granules[threadIdx.x], lg[threadIdx.x]); } }
+}
+/* the chunks of other owners -> send buffers (owner after owner), one wavefront per chunk; the chunk leaves the pool */
+__global__ __launch_bounds__(256)
+void sk_pack_kernel(PoolView pool, uint32_t n_chunks, uint32_t world, uint32_t rank, const unsigned long long *granule_base, const unsigned long long *chunk_base,
+                    unsigned long long *granule_cursor, unsigned long long *chunk_cursor, uint4 *out_data, uint2 *out_meta) {
+	const int lane = threadIdx.x & 63;
+	const uint64_t wavesPerGrid = (uint64_t)gridDim.x * (blockDim.x >> 6);
+	for (uint64_t c = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c < n_chunks; c += wavesPerGrid) {
+		const uint32_t l = pool.chunk_list[c], cnt = pool.chunk_count[c];
+		if (l == NO_CHUNK || cnt == 0 || l % world == rank) continue;
+		const uint32_t o = l % world;
+		/* ONE cursor per owner, chunks << 40 | granules: the chunk's place among the (list, granules) pairs and the place of its granules
+		 * are booked together, so the data lies in the order of the pairs (the owner finds a chunk's granules by a prefix sum of them) */
+		unsigned long long both = 0;
+		if (lane == 0) both = atomicAdd(&granule_cursor[o], (1ull << 40) | (unsigned long long)cnt);
+		both = ((unsigned long long)(uint32_t)__shfl((int)(both >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)both, 0, 64);
+		const unsigned long long gp = both & ((1ull << 40) - 1), cp = both >> 40;
+		(void)chunk_cursor;
+		if ((uint32_t)lane < cnt) out_data[granule_base[o] + gp + lane] = ((const uint4 *)pool.base)[c * SK_CHUNK_G + lane];
+		if (lane == 0) { out_meta[chunk_base[o] + cp] = make_uint2(l, cnt); pool.chunk_list[c] = NO_CHUNK; pool.chunk_count[c] = 0; }
+	}
+}
+/* lists of other owners start afresh (their chunks are gone) */
+__global__ void sk_state_drop_kernel(unsigned long long *state, uint64_t n, uint32_t world, uint32_t rank) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		if (i % world != rank) state[i] = ((unsigned long long)NO_CHUNK << 32) | SK_CHUNK_G;
+}
+__global__ void sk_meta_counts_kernel(const uint2 *meta, uint64_t n, uint32_t *counts) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) counts[i] = meta[i].y;
+}
+/* received chunks -> this rank's own lists: one wavefront per chunk, the header lane of every record books room in the record's
+ * list and copies its granules */
+static const int SK_ADOPT_WAVES = 4;
+__global__ __launch_bounds__(SK_ADOPT_WAVES * 64)
+void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t *in_start, uint64_t n_in, SkParams sp, PoolView pool) {
+	__shared__ SkSlab s_slab[SK_ADOPT_WAVES];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	SkSlab *slab = &s_slab[wave];
+	if (lane == 0) { slab->base[0] = atomicAdd(pool.head, 64u); slab->base[1] = atomicAdd(pool.head, 64u); slab->next = 0; }
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+	const uint64_t wavesPerGrid = (uint64_t)gridDim.x * SK_ADOPT_WAVES;
+	for (uint64_t c = (uint64_t)blockIdx.x * SK_ADOPT_WAVES + wave; c < n_in; c += wavesPerGrid) {
+		const uint2 m = in_meta[c];
+		const uint32_t list = m.x, cnt = m.y < SK_CHUNK_G ? m.y : SK_CHUNK_G;
+		const uint4 *src = in_data + in_start[c];
+		uint4 cur = make_uint4(0, 0, 0, 0);
+		if ((uint32_t)lane < cnt) cur = src[lane];
+		const uint32_t glen = (cur.y >> 17) & 0x7fu;
+		unsigned long long starts = 0;
+		if (__all((lane & 1) != 0 || (uint32_t)lane >= cnt || glen == 2u)) starts = 0x5555555555555555ull & (cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull));
+		else for (uint32_t pos = 0; pos < cnt; ) { starts |= 1ull << pos; const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos); pos += step ? step : SK_CHUNK_G; }
+		if (((starts >> lane) & 1ull) && glen && (uint32_t)lane + glen <= cnt) {
+			const uint64_t at = sk_append(sp.state, list, glen, slab, pool);
+			if (at != ~0ull) { uint4 *dst = (uint4 *)pool.base + at; dst[0] = cur; for (uint32_t g = 1; g < glen; g++) dst[g] = src[lane + g]; }
+		}
+		if (slab->next >= 64u) {
+			__builtin_amdgcn_wave_barrier();
+			if (lane == 0) { const uint32_t used = slab->next; slab->base[0] = slab->base[1]; slab->base[1] = atomicAdd(pool.head, 64u); slab->next = used >= 128u ? 64u : used - 64u; }
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	const uint32_t used = slab->next < 128u ? slab->next : 128u;
+	for (uint32_t idx = used + (uint32_t)lane; idx < 128u; idx += 64) { const uint32_t c = slab->base[idx >> 6] + (idx & 63u); if (c < pool.cap) { pool.chunk_list[c] = NO_CHUNK; pool.chunk_count[c] = 0; } }
 }
 
 }  // namespace kmr

@@ -188,6 +188,111 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
     return spectrum
 
 
+def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx=0, group=None, stats=None, stream_origin=None):
+    """The N > 1 build on super-k-mer lists (kmr_config.build_mode = 3, rank / world_size configured): every rank scatters the
+    super-k-mers of its own reads into the job's lists on its own GPU (no owner filter), list l belongs to rank l % world, and
+    the chunks a rank holds of other ranks' lists travel as they lie -- one all-to-all of (list, granules) pairs and one of the
+    16-byte granules, ~4 bytes per k-mer instead of the 12-byte k-mer records of build_partitioned (24 + kb in the reference,
+    src/DistributedFunctions.h:274-303).  The owner appends what it receives to its own lists; kmr_finalize then counts them as
+    in the single-GPU build.  Replaces _buildKmerSpectrumMPI (src/DistributedFunctions.h:340-458).
+
+    bases / quals: uint8 tensors on the spectrum's device, offsets: int64 tensor [n + 1].  stream_origin: position of this rank's
+    first base in the whole input (default: the bases of the lower ranks, found by an all-gather) -- with it the first sighting of
+    a k-mer is the first one in the whole input, as in a serial build, whatever the ranks' timing.  stats (a dict, optional)
+    accumulates "bytes_to_peers", "records_sent" (granules), "chunks", "alltoall_ms"."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = bases.device
+    n = offsets.numel() - 1
+    total = int(offsets[n].item() - offsets[0].item()) if n else 0
+    if stream_origin is None:
+        mine = torch.tensor([total], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine, group=group)
+        stream_origin = sum(int(t.item()) for t in every[:rank])
+    spectrum.set_stream_origin(stream_origin)
+    if n:
+        spectrum.buildKmerSpectrumDevice(bases.data_ptr(), None if quals is None else quals.data_ptr(), offsets.data_ptr(), n, total, first_read_idx)
+    chunks, granules = spectrum.sk_exchange_counts()
+    send_c = [int(chunks[r]) if r != rank else 0 for r in range(world)]
+    send_g = [int(granules[r]) if r != rank else 0 for r in range(world)]
+    goff, coff, ag, ac = [], [], 0, 0
+    for r in range(world):
+        goff.append(ag)
+        coff.append(ac)
+        ag += send_g[r]
+        ac += send_c[r]
+    data = torch.empty((max(ag, 1), 4), dtype=torch.int32, device=dev)
+    meta = torch.empty((max(ac, 1), 2), dtype=torch.int32, device=dev)
+    spectrum.sk_exchange_pack(data.data_ptr(), meta.data_ptr(), goff, coff)
+    _, recv_c = _exchange_counts(torch.tensor(send_c, dtype=torch.int64, device=dev), group)
+    _, recv_g = _exchange_counts(torch.tensor(send_g, dtype=torch.int64, device=dev), group)
+    timed = None
+    if dev.type == "cuda":
+        timed = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        timed[0].record()
+    got_meta = _all_to_all_sliced(meta[:ac], send_c, recv_c, group)
+    got_data = _all_to_all_sliced(data[:ag], send_g, recv_g, group)
+    if timed:
+        timed[1].record()
+        torch.cuda.synchronize(dev)
+    if sum(recv_c):
+        spectrum.sk_exchange_adopt(got_data.data_ptr(), got_meta.data_ptr(), sum(recv_c), sum(recv_g))
+    if stats is not None:
+        stats["chunks"] = stats.get("chunks", 0) + sum(send_c)
+        stats["records_sent"] = stats.get("records_sent", 0) + sum(send_g)
+        stats["bytes_to_peers"] = stats.get("bytes_to_peers", 0) + 16 * sum(send_g) + 8 * sum(send_c)
+        if timed:
+            stats["alltoall_ms"] = stats.get("alltoall_ms", 0.0) + timed[0].elapsed_time(timed[1])
+    return spectrum
+
+
+def _all_to_all_sliced(send, send_split, recv_split, group=None, max_rows=None):
+    """_all_to_all_flat in slices, so that no single message exceeds MAX_CHUNK_BYTES (see there); every rank runs the same number of
+    slices.  send: [sum(send_split), words] rows grouped by destination; returns the received rows grouped by source."""
+    world = len(send_split)
+    words = send.shape[1] if send.dim() > 1 else 1
+    if max_rows is None:
+        max_rows = max(1, MAX_CHUNK_BYTES // (4 * words))
+    need = max([0] + [(x + max_rows - 1) // max_rows for x in list(send_split) + list(recv_split)])
+    t = torch.tensor([need], dtype=torch.int64, device=send.device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    slices = max(1, int(t.item()))
+
+    def one(piece, ss, rs):      # rows are contiguous and grouped by destination: the single-tensor collective with split sizes
+        got = torch.empty((sum(rs), words), dtype=piece.dtype, device=piece.device)
+        if _staged(piece, group):
+            host = torch.empty(got.shape, dtype=got.dtype)
+            dist.all_to_all_single(host, piece.cpu().contiguous(), output_split_sizes=rs, input_split_sizes=ss, group=group)
+            got.copy_(host)
+        else:
+            dist.all_to_all_single(got, piece.contiguous(), output_split_sizes=rs, input_split_sizes=ss, group=group)
+        return got
+
+    if world == 1:
+        return send[:0].reshape(0, words)
+    if slices == 1:
+        return one(send, list(send_split), list(recv_split))
+    out = torch.empty((sum(recv_split), words), dtype=send.dtype, device=send.device)
+    sbase, rbase, a, b = [], [], 0, 0
+    for r in range(world):
+        sbase.append(a)
+        rbase.append(b)
+        a += send_split[r]
+        b += recv_split[r]
+    for p in range(slices):
+        ss = [max(0, min(max_rows, send_split[r] - p * max_rows)) for r in range(world)]
+        rs = [max(0, min(max_rows, recv_split[r] - p * max_rows)) for r in range(world)]
+        piece = torch.cat([send[sbase[r] + p * max_rows: sbase[r] + p * max_rows + ss[r]] for r in range(world)]) if sum(ss) else send[:0]
+        got = one(piece, ss, rs)
+        at = 0
+        for r in range(world):
+            if rs[r]:
+                out[rbase[r] + p * max_rows: rbase[r] + p * max_rows + rs[r]] = got[at:at + rs[r]]
+            at += rs[r]
+    return out
+
+
 def _all_to_all_flat(send, send_split, recv_split, group=None):
     """send: [sum(send_split), words] rows grouped by destination; returns [sum(recv_split), words] grouped by source"""
     recv = torch.empty((sum(recv_split), send.shape[1]), dtype=send.dtype, device=send.device)
@@ -258,3 +363,34 @@ def score_partitioned(spectrum, bases, offsets, minimum_kmer_score, scoring_type
             at += sc[s]
         fence()
     return spectrum.score_counts(bases, offsets, n, position_counts, minimum_kmer_score, scoring_type)
+
+
+def reduce_stats(spectrum, group=None):
+    """Job-wide counters of an owner-partitioned spectrum: the sums DistributedKmerSpectrum forms over its ranks (raw / rawGood /
+    unique / singleton k-mers and map sizes; src/DistributedFunctions.h:460-512 reduces them inside its SizeTracker, the purge
+    bookkeeping at :707-710).  Every rank gets the same dict."""
+    st = spectrum.stats()
+    keys = sorted(st)
+    t = torch.tensor([st[k] for k in keys], dtype=torch.int64)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return {k: int(v) for k, v in zip(keys, t.cpu().tolist())}
+
+
+def reduce_histogram(spectrum, zoom_max=255, log_base=2.0, group=None):
+    """MPIHistogram::reduce (src/DistributedFunctions.h:513-535) over kmr_histogram: the three arrays of every rank's
+    KmerSpectrum::Histogram (visits, visitedCount, visitedWeight) summed over the ranks -- three all-reduces of ~65.8 k entries,
+    as in the reference (DistributedKmerSpectrum::_getHistogram uses Histogram(255), :574-583).  Returns the same Histogram
+    object on every rank; .toString() prints the reference's table."""
+    from .spectrum import Histogram
+    h = spectrum.getHistogram(zoom_max, log_base)
+    on_dev = dist.get_backend(group) == "nccl"
+    out = []
+    for arr, dt in ((h.visits, torch.int64), (h.visitedCount, torch.int64), (h.visitedWeight, torch.float64)):
+        t = torch.from_numpy(arr.astype("int64" if dt == torch.int64 else "float64"))
+        if on_dev:
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        out.append(t.cpu().numpy())
+    return Histogram(zoom_max, log_base, out[0].astype("uint64"), out[1].astype("uint64"), out[2])

@@ -117,6 +117,26 @@ class KmerSpectrum:
     def insertRecordsDevice(self, records_ptr, n):
         self._call("insert_records_dev", self.h, records_ptr, n)
 
+    def set_stream_origin(self, ordinal):
+        """position in the whole input of the next base this handle is fed (kmr_set_stream_origin)"""
+        self._call("set_stream_origin", self.h, int(ordinal))
+
+    # owner exchange of super-k-mer lists (build_mode 3; kmernator_amd.distributed.build_partitioned_superkmers)
+    def sk_exchange_counts(self):
+        world = self.cfg.world_size
+        chunks = np.zeros(world, dtype=np.uint64)
+        granules = np.zeros(world, dtype=np.uint64)
+        self._call("sk_exchange_counts", self.h, chunks.ctypes.data_as(C.POINTER(C.c_uint64)), granules.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return chunks, granules
+
+    def sk_exchange_pack(self, data_ptr, meta_ptr, granule_offset, chunk_offset):
+        go = np.ascontiguousarray(granule_offset, dtype=np.uint64)
+        co = np.ascontiguousarray(chunk_offset, dtype=np.uint64)
+        self._call("sk_exchange_pack_dev", self.h, data_ptr, meta_ptr, go.ctypes.data_as(C.POINTER(C.c_uint64)), co.ctypes.data_as(C.POINTER(C.c_uint64)))
+
+    def sk_exchange_adopt(self, data_ptr, meta_ptr, n_chunks, n_granules):
+        self._call("sk_exchange_adopt_dev", self.h, data_ptr, meta_ptr, n_chunks, n_granules)
+
     # the device steps of the distributed scoreAndTrimReads (kmernator_amd.distributed.score_partitioned); tensors are torch
     # tensors on this handle's device
     def lookup_requests(self, bases, offsets, lo, hi, total_bases, keys, pos, seg_capacity, seg_counts):

@@ -179,3 +179,61 @@ def test_score_partitioned_reproduces_golden_labels(world):
                 if b"AFTrim" not in gold.names[i]:
                     assert label.encode() == gold.names[i].split(b" ", 1)[1], (i, label, gold.names[i])
         assert len(seen) >= 1000 - 7 * world
+
+
+def _sliced_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmernator_amd.distributed import _all_to_all_sliced, reduce_histogram, reduce_stats
+        # rank r sends (r + 1) * (d + 2) rows of 4 words to rank d, nothing to itself; row content names source, destination and index
+        send_split = [0 if d == rank else (rank + 1) * (d + 2) * 7 for d in range(world)]
+        recv_split = [0 if s == rank else (s + 1) * (rank + 2) * 7 for s in range(world)]
+        rows = []
+        for d in range(world):
+            for i in range(send_split[d]):
+                rows.append([rank, d, i, 1000 * rank + d])
+        send = torch.tensor(rows, dtype=torch.int32).reshape(-1, 4)
+        for max_rows in (None, 5, 64):      # one message, many slices, a few slices
+            got = _all_to_all_sliced(send, send_split, recv_split, max_rows=max_rows)
+            assert got.shape == (sum(recv_split), 4)
+            at = 0
+            for s in range(world):
+                part = got[at:at + recv_split[s]]
+                assert bool((part[:, 0] == s).all()) and bool((part[:, 1] == rank).all())
+                assert part[:, 2].tolist() == list(range(recv_split[s]))
+                at += recv_split[s]
+
+        class _Spec:        # what reduce_stats / reduce_histogram ask of a spectrum
+            def stats(self):
+                return {"raw_kmers": 100 + rank, "unique_kmers": 10 * (rank + 1), "weak_entries": rank}
+
+            def getHistogram(self, zoom_max, log_base):
+                import kmernator_amd.spectrum as sp
+                n = (1 << 16) + 2 + zoom_max
+                v = np.zeros(n, dtype=np.uint64); c = np.zeros(n, dtype=np.uint64); w = np.zeros(n, dtype=np.float64)
+                v[2 + rank] = 5; c[2 + rank] = 5 * (2 + rank); w[2 + rank] = 4.5
+                v[7] = 1; c[7] = 7; w[7] = 6.5
+                return sp.Histogram(zoom_max, log_base, v, c, w)
+
+        st = reduce_stats(_Spec())
+        assert st == {"raw_kmers": sum(100 + r for r in range(world)), "unique_kmers": sum(10 * (r + 1) for r in range(world)), "weak_entries": sum(range(world))}
+        h = reduce_histogram(_Spec(), 255, 2.0)
+        assert int(h.visits[7]) == world and int(h.visitedCount[7]) == 7 * world and abs(float(h.visitedWeight[7]) - 6.5 * world) < 1e-9
+        assert all(int(h.visits[2 + r]) == 5 for r in range(world)) and h.count == 6 * world
+        open(os.path.join(tmp, "ok.%d" % rank), "w").write(h.toString())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sliced_all_to_all_and_the_reduces(world):
+    """The wire of the super-k-mer exchange (rows grouped by destination, cut into slices below RCCL's message limit, every rank
+    running the same number of slices) and the job-wide sums of statistics and histograms (MPIHistogram::reduce,
+    src/DistributedFunctions.h:513-535), over gloo; every rank must print the same histogram table."""
+    port = 33300 + (os.getpid() % 1500) + world
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_sliced_worker, args=(world, port, tmp), nprocs=world, join=True)
+        texts = [open(os.path.join(tmp, "ok.%d" % r)).read() for r in range(world)]
+        assert all(t == texts[0] for t in texts) and texts[0].startswith("Counts, Weights and Directions")

@@ -99,6 +99,67 @@ def test_ranks_sharing_one_gpu(world, pipeline):
                 assert np.array_equal(a, b)
 
 
+def _worker_sk(rank, world, port, tmp, k):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kmernator_amd as ka
+        from kmernator_amd.distributed import build_partitioned_superkmers
+        dev = torch.device("cuda", 0)
+        lo, hi = _slice(rank, world)
+        rb = _reads().slice(lo, hi)
+        tb = torch.from_numpy(np.concatenate([rb.bases, np.zeros(64, np.uint8)])).to(dev)
+        tq = torch.from_numpy(np.concatenate([rb.quals, np.zeros(64, np.uint8)])).to(dev)
+        to = torch.from_numpy(rb.offsets.astype(np.int64)).to(dev)
+        sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0, rank=rank, world_size=world, build_mode=3))
+        xs = {}
+        build_partitioned_superkmers(sp, tb, tq, to, first_read_idx=lo, stats=xs)
+        sp.finalize(2)
+        np.save(os.path.join(tmp, "image.%d.npy" % rank), sp.image(KMR_MAP_WEAK))
+        st = sp.stats()
+        np.save(os.path.join(tmp, "stats.%d.npy" % rank), np.array([st["raw_kmers"], st["raw_good_kmers"], st["weak_entries"], st["unique_kmers"], xs.get("bytes_to_peers", 0)], dtype=np.int64))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k", [(2, 31), (3, 51)])
+def test_superkmer_exchange_ranks_sharing_one_gpu(world, k):
+    """The N > 1 build of build_mode 3 (every rank scatters its reads' super-k-mers into the job's lists, the chunks of other
+    owners travel, the owner appends them to its lists) with 2 and 3 ranks on this GPU over gloo: the union of the ranks' weak
+    maps is the weak map of one spectrum over the same reads -- same keys, counts, direction biases -- every k-mer lives on
+    exactly one rank, and the statistics add up."""
+    import kmernator_amd as ka
+    port = 32100 + (os.getpid() % 1500) + world
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_sk, args=(world, port, tmp, k), nprocs=world, join=True)
+        rb = _reads()
+        multi = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0))
+        for r in range(world):
+            lo, hi = _slice(r, world)
+            part = rb.slice(lo, hi)
+            multi.buildKmerSpectrum(part.bases, part.quals, part.offsets)
+        multi.finalize(2)
+        ms = multi.stats()
+        stats = sum(np.load(os.path.join(tmp, "stats.%d.npy" % r)) for r in range(world))
+        assert (int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])) == (ms["raw_kmers"], ms["raw_good_kmers"], ms["weak_entries"], ms["unique_kmers"]), (stats, ms)
+        assert int(stats[4]) > 0
+        _, _, whole = parse_image(multi.image(KMR_MAP_WEAK), multi.kb, 12)
+        wk = np.concatenate([kk for kk, _ in whole if len(kk)])
+        wv = np.concatenate([v for _, v in whole if len(v)])
+        want = {bytes(kk): bytes(v[:2]) + bytes(v[8:10]) for kk, v in zip(wk, wv)}       # count and directionBias bytes (the first sighting through an exchange is still the first in the stream: ordinals travel)
+        seen = 0
+        for r in range(world):
+            _, _, buckets = parse_image(np.load(os.path.join(tmp, "image.%d.npy" % r)), multi.kb, 12)
+            keys = np.concatenate([kk for kk, _ in buckets if len(kk)])
+            vals = np.concatenate([v for _, v in buckets if len(v)])
+            for kk, v in zip(keys, vals):
+                assert want.pop(bytes(kk)) == bytes(v[:2]) + bytes(v[8:10])
+            seen += len(keys)
+        assert seen == ms["weak_entries"] and not want
+
+
 @pytest.mark.parametrize("how", ["external launcher", "bench.py --gpus 2"])
 def test_bench_n2_code_path_on_one_gpu(how):
     """bench.py for N = 2, both ranks on this GPU over gloo (RCCL refuses two ranks on one device): once under
