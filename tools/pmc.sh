@@ -3,7 +3,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu "$@" > $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$ctr.log 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-h2d "$@" > $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$ctr.log 2>&1
   ls $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$ctr/*/ | head -5
 done
 python3 - <<PY

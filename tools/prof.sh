@@ -2,11 +2,11 @@
 # usage: tools/prof.sh <tag> [bench args]  -- rocprofv3 kernel stats of bench.py into gpurun_out/prof_<tag>
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-h2d "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
 grep metric $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log | python3 -c "
 import sys,json
 try:
-    d=json.loads(sys.stdin.read()); print('%.2f G kmers/s  %.1f ms/step  build %.1f ms x%d  finalize %.1f ms' % (d['value']/1e9, d['ms_per_step'], d['roofline']['build_ms_per_step'], d['roofline']['build_launch_groups_per_step'], d['roofline']['finalize_ms_per_step']))
+    d=json.loads(sys.stdin.read()); h=d['roofline']['hip_event_ms_per_step']; print('%.2f G kmers/s  %.1f ms/step  build %.1f ms  finalize %.1f ms' % (d['value']/1e9, d['ms_per_step'], h['build'], h['finalize']))
 except Exception as e: print('no json', e)"
 python3 -c "
 import csv,glob
