@@ -289,11 +289,14 @@ int kmr_extract_by_owner_dev(kmr_handle *h, const void *dev_bases, const void *d
 int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n_records);
 
 /* The same exchange for build_mode 3 (super-k-mer lists), whose unit is not the k-mer but the list: every rank scatters the
- * super-k-mers of ITS reads (kmr_add_reads*; nothing is filtered by owner) into the job's 2^list_bits lists, list l belongs to
+ * super-k-mers of ITS reads (kmr_add_reads* after kmr_sk_exchange_begin: nothing is filtered by owner; without that call a
+ * handle with world_size > 1 keeps what getDistributedThreadId gives its rank, as in the other build modes, and has nothing to
+ * exchange) into the job's 2^list_bits lists, list l belongs to
  * rank l % world_size, and what a rank holds of other ranks' lists travels as it lies: ~4 bytes per k-mer on the wire instead of
  * the reference's 24 + kb (src/DistributedFunctions.h:274-303).  The owner of a k-mer is decided by its minimizer (private to
  * the build), not by getDistributedThreadId: per-rank spectra are a different partition of the same k-mers, their union is
  * the same spectrum.
+ *   kmr_sk_exchange_begin     the handle's reads are meant for the exchange (sticky; before the first kmr_add_reads*)
  *   kmr_sk_exchange_counts    closes the lists; chunks[r], granules[r] (host, [world_size]) = what this rank holds for owner r
  *                             (16-byte granules; r == rank: what stays)
  *   kmr_sk_exchange_pack_dev  the chunks of the other owners -> dev_data (owner r's granules from granule_offset[r] on, 16 bytes
@@ -301,9 +304,31 @@ int kmr_insert_records_dev(kmr_handle *h, const void *dev_records, uint64_t n_re
  *   (the caller moves data and meta to their owners: all-to-all over RCCL / MPI)
  *   kmr_sk_exchange_adopt_dev the received chunks (any order) are appended to this rank's own lists
  * then kmr_finalize as usual.  All three synchronise. */
+int kmr_sk_exchange_begin(kmr_handle *h);      /* before the first reads of the handle */
 int kmr_sk_exchange_counts(kmr_handle *h, uint64_t *chunks, uint64_t *granules);
 int kmr_sk_exchange_pack_dev(kmr_handle *h, void *dev_data, void *dev_meta, const uint64_t *granule_offset, const uint64_t *chunk_offset);
 int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *dev_meta, uint64_t n_chunks, uint64_t n_granules);
+
+/* The whole exchange inside the library, RCCL called directly (librccl is dlopen'ed on first use: no link-time dependency): what a
+ * C / C++ host -- one process or thread per GPU of a node, no MPI, no Python -- calls instead of
+ * DistributedKmerSpectrum::_buildKmerSpectrumMPI (src/DistributedFunctions.h:340-458; the MPI_Alltoallv of src/MPIBuffer.h:588-600
+ * becomes grouped ncclSend / ncclRecv over xGMI, one message of <= 1 GiB per peer and slice; the local share never moves).
+ *   kmr_exchange_unique_id      rank 0 makes the job's id; the host hands the KMR_EXCHANGE_ID_BYTES to every rank (file, pipe, socket)
+ *   kmr_exchange_init           collective: ncclCommInitRank(cfg.world_size, id, cfg.rank) on the handle's device.  A build_mode 0
+ *                               handle that can build super-k-mer lists moves to them here (build_mode 3 semantics, see above)
+ *   kmr_exchange_add_reads_dev  collective, one batch of THIS rank's reads (device pointers as kmr_add_reads_dev; n_reads may be 0):
+ *                               build_mode 3: global stream ordinals (an all-gather of the batch sizes), extract into the job's
+ *                               lists, counts, chunks of other owners out, received chunks appended; other modes: the batch's
+ *                               k-mer records binned by getDistributedThreadId (segments grown and re-extracted if one owner takes
+ *                               more than its share), counts, records out, kmr_insert_records_dev of what arrived
+ *   kmr_exchange_stats          bytes sent to other ranks and the time of the all-to-alls (HIP events on the handle's stream)
+ * then kmr_finalize on every rank.  kmr_destroy frees the communicator.  Every rank must make the same sequence of calls. */
+#define KMR_EXCHANGE_ID_BYTES 128
+int kmr_exchange_unique_id(void *id);
+int kmr_exchange_init(kmr_handle *h, const void *id);
+int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals, const void *dev_offsets, uint64_t n_reads,
+                               uint64_t total_bases, uint64_t first_global_read_idx, const void *dev_discarded);
+int kmr_exchange_stats(kmr_handle *h, uint64_t *bytes_to_peers, double *alltoall_ms);
 
 /* Host-buffer forms of the two halves for a host whose exchange is MPI_Alltoallv over host memory (the reference's own,
  * src/MPIBuffer.h:588-600; include/kmernator_amd_shim.hpp, GpuDistributedKmerSpectrum).  kmr_extract_by_owner_host: the records
@@ -457,7 +482,8 @@ enum kmr_time_group {
 	KMR_TIME_PARTITION2 = 4,  /* level-2 partition launch                                            */
 	KMR_TIME_COUNT = 5,       /* count pass                                                          */
 	KMR_TIME_BUCKETS = 6,     /* bucket scan + entry scatter + bucket sort                           */
-	KMR_TIME_GROUPS = 7
+	KMR_TIME_EXCHANGE = 7,    /* kmr_exchange_add_reads_dev: the all-to-all of list chunks / k-mer records (RCCL)   */
+	KMR_TIME_GROUPS = 8
 };
 int kmr_kernel_time(kmr_handle *h, int which, double *ms, uint64_t *launches);
 int kmr_kernel_time_reset(kmr_handle *h);

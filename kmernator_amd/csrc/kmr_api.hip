@@ -8,6 +8,8 @@
  * KMR_ERR_NO_DEVICE otherwise.
  */
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -92,6 +94,7 @@ struct kmr_handle {
 	/* streaming (partition) build path */
 	bool partition_mode = false;
 	bool superkmer_mode = false;       /* build_mode 3: super-k-mer lists (kmr_superkmer.hpp); implies partition_mode */
+	bool sk_exchange = false;          /* kmr_sk_exchange_begin: the lists are the whole job's, every owner's k-mers are kept until the exchange */
 	bool auto_mode = false;            /* build_mode 0: a handle that is fed k-mer records (the owner exchange) before any reads falls back to mode 2 */
 	HostPool l1;                       /* the record pool of every partition level */
 	int bits1 = 0;
@@ -116,6 +119,10 @@ struct kmr_handle {
 	unsigned long long *sk_state = nullptr; uint32_t sk_bits = 0, sk_m = 0, sk_off = 0, sk_win = 0; double *dPk = nullptr;
 	uint32_t sk_min_override = 0;
 	/* kmr_extract_by_owner_host: owner segments of one batch kept on the device between the sizing call and the copy-out */
+	/* kmr_exchange_* (kmr_exchange_rccl.hpp): communicator, gather scratch, grow-only send / receive buffers, what the job was fed so far */
+	void *xc_comm = nullptr; unsigned long long *xc_small = nullptr;
+	void *xc_send = nullptr, *xc_send2 = nullptr, *xc_recv = nullptr, *xc_recv2 = nullptr;
+	uint64_t xc_send_cap = 0, xc_send2_cap = 0, xc_recv_cap = 0, xc_recv2_cap = 0, xc_job_bases = 0, xc_bytes_to_peers = 0;
 	void *xo_dev = nullptr; uint64_t xo_segcap = 0; std::vector<uint64_t> xo_counts; const void *xo_batch = nullptr; uint64_t xo_first = 0;
 	/* timing */
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -839,18 +846,21 @@ template <int W, bool EXT> int extract_by_owner_t(kmr_handle *h, const ReadsView
 		uint64_t total_cap = 0;
 		HIPCHK(h, hipMemcpy(&total_cap, h->koff + nu, 8, hipMemcpyDeviceToHost));
 		const uint64_t tiles = (nu + 63) / 64;
-		rc = ensure_buf(h, h->linear, h->linear_cap, total_cap, rec_bytes(h)); if (rc) return rc;
+		rc = ensure_buf(h, h->linear, h->linear_cap, total_cap, sizeof(typename PoolRec<W, EXT>::type)); if (rc) return rc;      /* (rec_bytes() is the granule size on a super-k-mer handle) */
 		rc = ensure_buf(h, h->tile_count, h->tile_cap, tiles, 4); if (rc) return rc;
 		LinearOp<W, EXT, false> op; op.records = (typename PoolRec<W, EXT>::type *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
 		rc = launch_extract<W, EXT>(h, rv, op); if (rc) return rc;
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 8, tiles);
+		/* who owns a k-mer: getDistributedThreadId, or -- a spectrum that was built through the list exchange -- the list of its minimizer */
+		OwnerFn of; of.m = 0; of.off = of.win = of.list_bits = 0;
+		if (h->superkmer_mode && h->sk_exchange) { of.m = h->sk_m; of.off = h->sk_off; of.win = h->sk_win; of.list_bits = h->sk_bits; }
 		if (dev_pos)
 			hipLaunchKernelGGL((owner_scatter_kernel<W, EXT, true>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->kb,
-			                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr, dev_pos);
+			                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr, dev_pos, of);
 		else
 			hipLaunchKernelGGL((owner_scatter_kernel<W, EXT>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->kb,
-			                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr, (uint32_t *)nullptr);
+			                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr, (uint32_t *)nullptr, of);
 		HIPCHK(h, hipGetLastError());
 	}
 	return 0;
@@ -1266,7 +1276,7 @@ uint32_t sk_dbg_flags(const char *name) {
 	(void)name; return 0u;
 #endif
 }
-SkParams sk_params(kmr_handle *h) { SkParams sp; sp.dbg = sk_dbg_flags("KMR_SK_EXTRACT_DBG"); sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; return sp; }
+SkParams sk_params(kmr_handle *h) { SkParams sp; sp.dbg = sk_dbg_flags("KMR_SK_EXTRACT_DBG"); sp.keep_all_owners = h->sk_exchange ? 1u : 0u; sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; return sp; }
 template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
 	const uint64_t n = rvAll.n_reads;
 	if (!h->sk_state) {
@@ -1284,7 +1294,9 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 	const uint64_t sub_bases = h->tune.sub_batch_bases ? h->tune.sub_batch_bases : (1ull << 31);
 	const uint64_t chunk = std::max<uint64_t>(64, (sub_bases / avg) & ~63ull);
 	const DevParams dp = dev_params(h);
-	const bool filt = dp.subsample > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0;      /* (with world_size > 1 every k-mer is kept: the lists are exchanged) */
+	/* world_size > 1: without the exchange a rank keeps the k-mers the reference's owner function gives it (getDistributedThreadId,
+	 * as the other build modes do); inside an exchange (kmr_sk_exchange_begin) every k-mer is kept, the lists decide the owner */
+	const bool filt = dp.subsample > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0 || (dp.world > 1 && !h->sk_exchange);
 	for (uint64_t r = 0; r < n; r += chunk) {
 		const uint64_t m = std::min(chunk, n - r);
 		ReadsView rv = rvAll;
@@ -1477,10 +1489,13 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 		uint32_t wish_w = 0, wish_m = 0, wish_o = 0;
 		const bool sk_auto = cfg->build_mode == 0 && !h->ext && cfg->world_size <= 1 && sk_geometry(h->k, 0, wish_w, wish_m, wish_o);
 		h->auto_mode = cfg->build_mode == 0;
-		if (cfg->build_mode == 3 || sk_auto) {
+		/* (an auto handle of a multi-rank job starts on the k-mer partition -- plain kmr_add_reads* there means the getDistributedThreadId
+		 * filter -- but is made ready for the lists: kmr_exchange_init moves it over) */
+		const bool sk_ready = cfg->build_mode == 0 && !h->ext && sk_geometry(h->k, 0, wish_w, wish_m, wish_o);
+		if (cfg->build_mode == 3 || sk_auto || sk_ready) {
 			if (h->ext) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) builds KMR_VALUE_COUNT_DIR values only"); break; }
 			if (!sk_geometry(h->k, 0, h->sk_win, h->sk_m, h->sk_off)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) needs k >= 13"); break; }
-			h->superkmer_mode = true;
+			h->superkmer_mode = cfg->build_mode == 3 || sk_auto;
 			double Pk[256];
 			for (int cidx = 0; cidx < 256; cidx++) { double wv = 1.0; for (uint32_t jj = 0; jj < h->k; jj++) wv *= P[cidx]; Pk[cidx] = wv; }      /* the loop of buildWeightedKmers, src/KmerReadUtils.h:205-208 */
 			if (hipMalloc((void **)&h->dPk, sizeof(Pk)) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
@@ -1497,6 +1512,7 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 	return KMR_OK;
 }
 
+static void exchange_free(kmr_handle *h);
 void kmr_destroy(kmr_handle *h) {
 	if (!h) return;
 	if (h->stream) hipStreamSynchronize(h->stream);
@@ -1509,6 +1525,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->score_buf) hipFree(h->score_buf);
 	if (h->lut) hipFree(h->lut);
 	if (h->xo_dev) hipFree(h->xo_dev);
+	exchange_free(h);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -1547,7 +1564,7 @@ int kmr_reset(kmr_handle *h) {
 	HIPCHK(h, hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream));
 	HIPCHK(h, hipMemsetAsync(h->derr, 0, 4, h->stream));
 	memset(&h->stats, 0, sizeof(h->stats));
-	h->occupied = h->pending_kmers = 0; h->stream_base = 0; h->reads = 0; h->subtracted = 0;
+	h->occupied = h->pending_kmers = 0; h->stream_base = 0; h->reads = 0; h->subtracted = 0; h->xc_job_bases = 0; h->xc_bytes_to_peers = 0;
 	h->finalized = false; h->map_gen++; h->has_singletons = h->cfg.separate_singletons != 0;
 	return KMR_OK;
 }
@@ -2598,7 +2615,16 @@ static int sk_exchange_ready(kmr_handle *h, const char *who) {
 	if (!h->superkmer_mode) return fail(h, KMR_ERR_STATE, std::string(who) + ": the handle does not build super-k-mer lists (build_mode 3)");
 	if (h->finalized) return fail(h, KMR_ERR_STATE, std::string(who) + " after kmr_finalize");
 	if (h->cfg.world_size > SK_OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "at most 64 ranks");
+	if (!h->sk_exchange) return fail(h, KMR_ERR_STATE, std::string(who) + " without kmr_sk_exchange_begin (the reads of this handle were filtered by getDistributedThreadId)");
 	return 0;
+}
+int kmr_sk_exchange_begin(kmr_handle *h) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (!h->superkmer_mode) return fail(h, KMR_ERR_STATE, "kmr_sk_exchange_begin: the handle does not build super-k-mer lists (build_mode 3)");
+	if (h->cfg.world_size > SK_OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "at most 64 ranks");
+	if (h->sk_state && !h->sk_exchange && h->reads) return fail(h, KMR_ERR_STATE, "kmr_sk_exchange_begin after reads were added");
+	h->sk_exchange = true;
+	return KMR_OK;
 }
 static int sk_ensure_state(kmr_handle *h) {      /* a rank without reads still owns lists */
 	if (h->sk_state) return 0;
@@ -2673,6 +2699,8 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
 	hipFree(cnt); hipFree(start);
 	return rc ? rc : sync_state(h);
 }
+
+#include "kmr_exchange_rccl.hpp"
 
 int kmr_kernel_time(kmr_handle *h, int which, double *ms, uint64_t *launches) {
 	if (!h || which < 0 || which >= KMR_TIME_GROUPS) return KMR_ERR_INVALID_ARG;

@@ -83,6 +83,30 @@ template <int W> __host__ __device__ __forceinline__ uint64_t part_order(const u
 	return rot ? (h >> rot) | (h << (64 - rot)) : h;
 }
 
+/* murmur3 finaliser: a bijection of 32-bit words */
+__host__ __device__ __forceinline__ uint32_t sk_fmix(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+/* order of the canonical m-mers (the minimizer is the smallest) */
+__host__ __device__ __forceinline__ uint32_t sk_mmer_hash(uint32_t canon) { return sk_fmix(canon ^ 0x9e3779b9u); }
+/* list of a minimizer: minima crowd near zero, so the list is cut from a second scramble of the hash, not from its top bits */
+__host__ __device__ __forceinline__ uint32_t sk_list_of(uint32_t mh, uint32_t list_bits) { return list_bits ? sk_fmix(mh * 0x2545f491u + 0x7f4a7c15u) >> (32 - list_bits) : 0u; }
+
+/* Owner of a k-mer in a job built on super-k-mer lists (build_mode 3 + exchange): the list of its canonical minimizer, modulo the
+ * ranks.  OwnerFn.m == 0: the reference's getDistributedThreadId (lookup3).  sk_key_minimizer recomputes, from the packed k-mer,
+ * what sk_extract_kernel found while walking the read: the smallest hash among the canonical m-mers at offsets off .. off + win - 1
+ * (the window is symmetric, so both strands of a k-mer give the same value). */
+struct OwnerFn { uint32_t m, off, win, list_bits; };
+template <int W> __host__ __device__ __forceinline__ uint32_t sk_key_minimizer(const uint64_t *key, uint32_t m, uint32_t off, uint32_t win) {
+	const uint32_t mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u), mtop = 2 * (m - 1);
+	uint32_t mf = 0, mr = 0, best = 0xffffffffu;
+	for (uint32_t i = off; i < off + m + win - 1; i++) {
+		const uint32_t c = (uint32_t)(key[(i >> 5) < (uint32_t)W ? (i >> 5) : W - 1] >> (62 - 2 * (i & 31u))) & 3u;
+		mf = ((mf << 2) | c) & mmask;
+		mr = (mr >> 2) | ((3u - c) << mtop);
+		if (i + 1 >= off + m) { const uint32_t x = sk_mmer_hash(mf < mr ? mf : mr); best = x < best ? x : best; }
+	}
+	return best;
+}
+
 /* ------------------------------------------------------------------ LinearOp */
 /* extract -> compacted linear records.  Each wavefront owns the region
  * [koff[r0], koff[r0+nr)) of the record buffer (koff = exclusive scan of the per-read
@@ -141,7 +165,7 @@ static const int OSEG = 2048, OWNER_THREADS = 256, OWNER_MAX = 8;
 template <int W, bool EXT, bool REQ = false>
 __global__ __launch_bounds__(OWNER_THREADS)
 void owner_scatter_kernel(const typename PoolRec<W, EXT>::type *linear, const uint64_t *koff, const uint32_t *tile_count, uint64_t n_tiles, uint32_t kb, uint32_t world,
-                          uint32_t *out, uint64_t seg_capacity, unsigned long long *seg_counts, unsigned int *work_counter, uint32_t *err, uint32_t *pos_out = nullptr) {
+                          uint32_t *out, uint64_t seg_capacity, unsigned long long *seg_counts, unsigned int *work_counter, uint32_t *err, uint32_t *pos_out, OwnerFn of) {
 	constexpr uint32_t RW = 2 * W + (EXT ? 2 : 1);      /* dwords of a wire record (KMR_RECORD_BYTES) */
 	/* One block per tile of the linear buffer, in pieces of OSEG records that are read from HBM once and held in
 	 * registers: every thread hashes its records and takes a rank per owner from an LDS counter, one thread per owner
@@ -178,7 +202,7 @@ void owner_scatter_kernel(const typename PoolRec<W, EXT>::type *linear, const ui
 					Key<W> key;
 #pragma unroll
 					for (int j = 0; j < W; j++) key.w[j] = r[u].key[j];
-					ow[u] = distributed_thread_id(key_hash<W>(key, kb), world);
+					ow[u] = of.m ? sk_list_of(sk_key_minimizer<W>(key.w, of.m, of.off, of.win), of.list_bits) % world : distributed_thread_id(key_hash<W>(key, kb), world);
 					rank[u] = atomicAdd(&s_cnt[ow[u]], 1u);
 				}
 			}

@@ -53,16 +53,10 @@ struct SkParams {
 	uint32_t m;            /* minimizer length in bases, <= 16                                        */
 	uint32_t off;          /* offset inside the k-mer of the first m-mer the minimizer looks at       */
 	uint32_t list_bits;    /* lists = 2^list_bits                                                     */
+	uint32_t keep_all_owners;      /* world_size > 1: 1 inside an owner exchange (the list decides the owner), 0 = keep what getDistributedThreadId gives this rank */
 	unsigned long long *state;     /* per list: open chunk << 32 | granules used (SK_CHUNK_G and NO_CHUNK: none) */
 	const double *Pk;      /* 256 entries: P[c] multiplied k times in sequence, the weight of a window of k equal qualities */
 };
-
-/* murmur3 finaliser: a bijection of 32-bit words */
-__host__ __device__ __forceinline__ uint32_t sk_fmix(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
-/* order of the canonical m-mers (the minimizer is the smallest) */
-__host__ __device__ __forceinline__ uint32_t sk_mmer_hash(uint32_t canon) { return sk_fmix(canon ^ 0x9e3779b9u); }
-/* list of a minimizer: minima crowd near zero, so the list is cut from a second scramble of the hash, not from its top bits */
-__host__ __device__ __forceinline__ uint32_t sk_list_of(uint32_t mh, uint32_t list_bits) { return list_bits ? sk_fmix(mh * 0x2545f491u + 0x7f4a7c15u) >> (32 - list_bits) : 0u; }
 
 /* Record, in 16-byte granules:
  *   granule 0   { ordinal low 32 | ordinal bits 32..39, n << 8, uniform << 16, granules << 17 | minimizer hash | weight (f32 bits) }
@@ -465,8 +459,14 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 			if (lane == 0) { if (flatBlk) nFlatBlk++; else nGenBlk++; }
 #endif
 			if (!flatBlk) {
+			/* General path, in two sweeps over the window: the minimizers first (unrolled: their block decomposition wants the position in
+			 * the window as a constant) into the ring, then the case analysis of the weight chain and the runs as ONE loop body -- unrolled
+			 * 16 times it was 70 KB of code and ran out of the instruction cache (24 ms per C2 batch of noisy reads against 7 ms for the walk
+			 * of flat ones) */
 #pragma unroll
-			for (int t = 0; t < SK_WINDOW; t++) {
+			for (int t = 0; t < SK_WINDOW; t++) mhr[t * 64 + lane] = minimizer_step(t);
+#pragma nounroll
+			for (uint32_t t = 0; t < (uint32_t)SK_WINDOW; t++) {
 				const uint32_t j = jb + t;
 				const bool in = j < L;
 				const uint32_t code = (pkw >> (30 - 2 * t)) & 3u;
@@ -478,7 +478,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				zc -= (uint32_t)((zbits[ZN == 1 ? 0 : (k >> 6)] >> (k & 63)) & 1ull);   /* position j-k leaves the window (0 while j < k) */
 				qrun = (j > 0 && (isRef || ((qeq >> t) & 1u))) ? qrun + 1 : 0;
 				if (FILT) fr.r.push(code);
-				const uint32_t M = minimizer_step(t);
+				const uint32_t M = mhr[t * 64 + lane];
 				bool valid = false;
 				float wf = 0.0f;
 				if (in && j + 1 >= k) {
@@ -500,6 +500,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 						const Key<FILT ? W : 1> canon = key_le<FILT ? W : 1>(kf, kr) ? kf : kr;
 						const uint64_t hash = key_hash<FILT ? W : 1>(canon, p.kb);
 						if (p.subsample > 1 && hash % p.subsample != 0) mine = false;
+						if (p.world > 1 && !sp.keep_all_owners && distributed_thread_id(hash, p.world) != p.rank) mine = false;
 						if (p.num_parts > 1 && distributed_thread_id(hash, p.num_parts) != p.part_idx) mine = false;
 						if (mine && (p.sub_wnb | p.sub_snb)) {       /* subtractingReference->exists(least): skipped before rawKmers++ */
 							MapView<FILT ? W : 1> sw, ss;
@@ -524,7 +525,6 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 						Vm |= 1u << t;
 					} else runOpen = false;
 				} else if (!in) runOpen = false;
-				mhr[t * 64 + lane] = M;
 				wtr[t * 64 + lane] = wf;
 			}
 			}

@@ -210,6 +210,7 @@ def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine, group=group)
         stream_origin = sum(int(t.item()) for t in every[:rank])
+    spectrum.sk_exchange_begin()
     spectrum.set_stream_origin(stream_origin)
     if n:
         spectrum.buildKmerSpectrumDevice(bases.data_ptr(), None if quals is None else quals.data_ptr(), offsets.data_ptr(), n, total, first_read_idx)

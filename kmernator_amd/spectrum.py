@@ -122,6 +122,10 @@ class KmerSpectrum:
         self._call("set_stream_origin", self.h, int(ordinal))
 
     # owner exchange of super-k-mer lists (build_mode 3; kmernator_amd.distributed.build_partitioned_superkmers)
+    def sk_exchange_begin(self):
+        """from here on the handle's reads go through the list exchange: every owner's k-mers are kept (kmr_sk_exchange_begin)"""
+        self._call("sk_exchange_begin", self.h)
+
     def sk_exchange_counts(self):
         world = self.cfg.world_size
         chunks = np.zeros(world, dtype=np.uint64)

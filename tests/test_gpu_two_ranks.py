@@ -106,7 +106,7 @@ def _worker_sk(rank, world, port, tmp, k):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import kmernator_amd as ka
-        from kmernator_amd.distributed import build_partitioned_superkmers
+        from kmernator_amd.distributed import build_partitioned_superkmers, score_partitioned
         dev = torch.device("cuda", 0)
         lo, hi = _slice(rank, world)
         rb = _reads().slice(lo, hi)
@@ -120,6 +120,8 @@ def _worker_sk(rank, world, port, tmp, k):
         np.save(os.path.join(tmp, "image.%d.npy" % rank), sp.image(KMR_MAP_WEAK))
         st = sp.stats()
         np.save(os.path.join(tmp, "stats.%d.npy" % rank), np.array([st["raw_kmers"], st["raw_good_kmers"], st["weak_entries"], st["unique_kmers"], xs.get("bytes_to_peers", 0)], dtype=np.int64))
+        res = score_partitioned(sp, tb, to, 2, "MEDIAN", chunk_reads=9000 + 3000 * rank)      # requests go to the owner of the k-mer's list
+        np.savez(os.path.join(tmp, "score.%d.npz" % rank), to=res[0], tl=res[1], sc=res[2], wt=res[3])
     finally:
         dist.destroy_process_group()
 
@@ -129,7 +131,8 @@ def test_superkmer_exchange_ranks_sharing_one_gpu(world, k):
     """The N > 1 build of build_mode 3 (every rank scatters its reads' super-k-mers into the job's lists, the chunks of other
     owners travel, the owner appends them to its lists) with 2 and 3 ranks on this GPU over gloo: the union of the ranks' weak
     maps is the weak map of one spectrum over the same reads -- same keys, counts, direction biases -- every k-mer lives on
-    exactly one rank, and the statistics add up."""
+    exactly one rank, the statistics add up, and every rank's reads score as on the whole spectrum (a lookup goes to the owner of
+    the k-mer's list, not to its lookup3 owner)."""
     import kmernator_amd as ka
     port = 32100 + (os.getpid() % 1500) + world
     with tempfile.TemporaryDirectory() as tmp:
@@ -158,6 +161,13 @@ def test_superkmer_exchange_ranks_sharing_one_gpu(world, k):
                 assert want.pop(bytes(kk)) == bytes(v[:2]) + bytes(v[8:10])
             seen += len(keys)
         assert seen == ms["weak_entries"] and not want
+        for r in range(world):
+            lo, hi = _slice(r, world)
+            part = rb.slice(lo, hi)
+            wanted = multi.scoreAndTrimReads(part.bases, part.offsets, 2, "MEDIAN")
+            got = np.load(os.path.join(tmp, "score.%d.npz" % r))
+            for a, b in zip((got["to"], got["tl"], got["sc"], got["wt"]), wanted):
+                assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("how", ["external launcher", "bench.py --gpus 2"])
