@@ -314,7 +314,8 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
  * DistributedKmerSpectrum::_buildKmerSpectrumMPI (src/DistributedFunctions.h:340-458; the MPI_Alltoallv of src/MPIBuffer.h:588-600
  * becomes grouped ncclSend / ncclRecv over xGMI, one message of <= 1 GiB per peer and slice; the local share never moves).
  *   kmr_exchange_unique_id      rank 0 makes the job's id; the host hands the KMR_EXCHANGE_ID_BYTES to every rank (file, pipe, socket)
- *   kmr_exchange_init           collective: ncclCommInitRank(cfg.world_size, id, cfg.rank) on the handle's device.  A build_mode 0
+ *   kmr_exchange_init           collective: ncclCommInitRank(cfg.world_size, id, cfg.rank) on the handle's device (or
+ *                               kmr_exchange_init_transport below: the host's own collectives).  A build_mode 0
  *                               handle that can build super-k-mer lists moves to them here (build_mode 3 semantics, see above)
  *   kmr_exchange_add_reads_dev  collective, one batch of THIS rank's reads (device pointers as kmr_add_reads_dev; n_reads may be 0):
  *                               build_mode 3: global stream ordinals (an all-gather of the batch sizes), extract into the job's
@@ -324,10 +325,25 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
  *   kmr_exchange_stats          bytes sent to other ranks and the time of the all-to-alls (HIP events on the handle's stream)
  * then kmr_finalize on every rank.  kmr_destroy frees the communicator.  Every rank must make the same sequence of calls. */
 #define KMR_EXCHANGE_ID_BYTES 128
+struct kmr_reads;      /* a device-resident read batch, see "FASTQ ingest" below */
 int kmr_exchange_unique_id(void *id);
 int kmr_exchange_init(kmr_handle *h, const void *id);
+/* The same driver over the host's own collectives instead of RCCL (an MPI job: MPI_Allgather and a device-aware MPI_Alltoallv, or one
+ * staged through host memory; the tests plug in gloo).  Both are collective and return 0 or a KMR_ERR_* code.
+ *   allgather_u64   every rank contributes n values (host memory); all[r * n + j] = value j of rank r
+ *   alltoallv_dev   DEVICE buffers: send_bytes[r] bytes at send + send_off[r] go to rank r, recv_bytes[r] bytes from rank r land at
+ *                   recv + recv_off[r]; the entries of the calling rank are 0; hip_stream = the handle's stream (the buffers were
+ *                   written on it; the call returns when the received bytes are visible to it).  No message exceeds 1 GiB. */
+typedef struct kmr_transport {
+	void *user;
+	int (*allgather_u64)(void *user, const uint64_t *mine, uint64_t n, uint64_t *all);
+	int (*alltoallv_dev)(void *user, const void *send, const uint64_t *send_off, const uint64_t *send_bytes,
+	                     void *recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *hip_stream);
+} kmr_transport;
+int kmr_exchange_init_transport(kmr_handle *h, const kmr_transport *t);
 int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals, const void *dev_offsets, uint64_t n_reads,
                                uint64_t total_bases, uint64_t first_global_read_idx, const void *dev_discarded);
+int kmr_exchange_add_read_batch(kmr_handle *h, const struct kmr_reads *batch, uint64_t first_global_read_idx);      /* the same for a device-resident read batch ("FASTQ ingest" below); NULL = no reads this round */
 int kmr_exchange_stats(kmr_handle *h, uint64_t *bytes_to_peers, double *alltoall_ms);
 
 /* Host-buffer forms of the two halves for a host whose exchange is MPI_Alltoallv over host memory (the reference's own,

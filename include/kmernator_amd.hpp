@@ -116,6 +116,20 @@ public:
 		check(kmr_add_reads(_h, bases, quals, offsets, nReads, firstReadIdx, discarded), "kmr_add_reads");
 	}
 	void buildKmerSpectrum(const ReadSet &reads, uint64_t firstReadIdx = 0) { check(kmr_add_read_batch(_h, reads.raw(), firstReadIdx), "kmr_add_read_batch"); }
+	/* N GPUs, one process (or thread) per GPU, no MPI: DistributedKmerSpectrum::buildKmerSpectrum (src/DistributedFunctions.h:340-458)
+	 * over RCCL inside the library.  Rank 0 makes the id and the host hands it to the others; config.rank / world_size say who is who;
+	 * every rank calls buildKmerSpectrumExchange the same number of times (nullptr: no reads this round), then purgeMinDepth. */
+	static std::vector<uint8_t> exchangeUniqueId() {
+		std::vector<uint8_t> id(KMR_EXCHANGE_ID_BYTES);
+		const int rc = kmr_exchange_unique_id(id.data());
+		if (rc != KMR_OK) throw KmerSpectrumError(rc, std::string("kmr_exchange_unique_id: ") + kmr_last_error(nullptr));
+		return id;
+	}
+	void exchangeInit(const std::vector<uint8_t> &id) {
+		if (id.size() != KMR_EXCHANGE_ID_BYTES) throw KmerSpectrumError(KMR_ERR_INVALID_ARG, "exchangeInit: the id has KMR_EXCHANGE_ID_BYTES bytes");
+		check(kmr_exchange_init(_h, id.data()), "kmr_exchange_init");
+	}
+	void buildKmerSpectrumExchange(const ReadSet *reads, uint64_t firstReadIdx = 0) { check(kmr_exchange_add_read_batch(_h, reads ? reads->raw() : nullptr, firstReadIdx), "kmr_exchange_add_read_batch"); }
 	void subtractReference(KmerSpectrum *other) { check(kmr_subtract_reference(_h, other ? other->_h : nullptr), "kmr_subtract_reference"); }
 	void purgeMinDepth(uint32_t minDepth) { check(kmr_finalize(_h, minDepth), "kmr_finalize"); }
 

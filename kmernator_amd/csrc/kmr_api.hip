@@ -94,6 +94,7 @@ struct kmr_handle {
 	/* streaming (partition) build path */
 	bool partition_mode = false;
 	bool superkmer_mode = false;       /* build_mode 3: super-k-mer lists (kmr_superkmer.hpp); implies partition_mode */
+	bool sender_launch = false;        /* extract_by_owner_t, build (not request) mode: dev_params tells the kernel to count what it does not send */
 	bool sk_exchange = false;          /* kmr_sk_exchange_begin: the lists are the whole job's, every owner's k-mers are kept until the exchange */
 	bool auto_mode = false;            /* build_mode 0: a handle that is fed k-mer records (the owner exchange) before any reads falls back to mode 2 */
 	HostPool l1;                       /* the record pool of every partition level */
@@ -120,7 +121,7 @@ struct kmr_handle {
 	uint32_t sk_min_override = 0;
 	/* kmr_extract_by_owner_host: owner segments of one batch kept on the device between the sizing call and the copy-out */
 	/* kmr_exchange_* (kmr_exchange_rccl.hpp): communicator, gather scratch, grow-only send / receive buffers, what the job was fed so far */
-	void *xc_comm = nullptr; unsigned long long *xc_small = nullptr;
+	void *xc_comm = nullptr; unsigned long long *xc_small = nullptr, *xc_dcounts = nullptr; kmr_transport xc_tr = {nullptr, nullptr, nullptr};
 	void *xc_send = nullptr, *xc_send2 = nullptr, *xc_recv = nullptr, *xc_recv2 = nullptr;
 	uint64_t xc_send_cap = 0, xc_send2_cap = 0, xc_recv_cap = 0, xc_recv2_cap = 0, xc_job_bases = 0, xc_bytes_to_peers = 0;
 	void *xo_dev = nullptr; uint64_t xo_segcap = 0; std::vector<uint64_t> xo_counts; const void *xo_batch = nullptr; uint64_t xo_first = 0;
@@ -185,6 +186,7 @@ DevParams dev_params(kmr_handle *h) {
 	p.k = h->k; p.kb = h->kb; p.min_weight = h->cfg.min_weight; p.fastq_start = h->cfg.fastq_start_char; p.ext_min_q = h->cfg.ext_min_quality;
 	p.qzero = h->cfg.fastq_start_char + std::max<uint32_t>(1u, h->cfg.min_quality_score);   /* Q0 has probability 0 too */
 	p.subsample = h->cfg.kmer_subsample; p.rank = h->cfg.rank; p.world = h->cfg.world_size; p.num_parts = h->cfg.num_parts; p.part_idx = h->cfg.part_idx;
+	p.count_sender_bad = h->sender_launch ? 1u : 0u;
 	p.P = h->dP; p.stats = h->dstats; p.err = h->derr;
 	p.sub_wstart = p.sub_wkeys = p.sub_sstart = p.sub_skeys = nullptr; p.sub_wvals = nullptr; p.sub_sweight = nullptr; p.sub_wnb = p.sub_snb = 0; p.sub_vw = 0;
 	if (h->subtract) {
@@ -238,7 +240,8 @@ int sync_state(kmr_handle *h) {
 #ifdef KMR_DEBUG_HOOKS
 	if (h->superkmer_mode) { if (dbg()) fprintf(stderr, "sk_extract windows: %llu general, %llu fast\n", s.claimed, s.inserted); s.claimed = 0; s.inserted = 0; }
 #endif
-	h->stats.raw_kmers = s.raw + s.inserted; h->stats.raw_good_kmers = s.good + s.inserted; h->stats.discarded = s.raw - s.good;
+	/* (through the k-mer record exchange: good k-mers are counted where they arrive, bad ones where they were read) */
+	h->stats.raw_kmers = s.raw + s.inserted + s.sender_bad; h->stats.raw_good_kmers = s.good + s.inserted; h->stats.discarded = s.raw - s.good + s.sender_bad;
 	h->occupied = s.claimed; h->pending_kmers = 0; h->subtracted = s.subtracted;
 	if (e & ERR_READ_TOO_LONG) return fail(h, KMR_ERR_UNSUPPORTED, "a read is longer than the per-wavefront LDS tile (" + std::to_string(TILE_SPAN) + " bases)");
 	if (e & ERR_TABLE_FULL) return fail(h, KMR_ERR_CAPACITY, "device k-mer table is full; raise kmr_config.max_table_entries / estimated_raw_kmers");
@@ -849,7 +852,10 @@ template <int W, bool EXT> int extract_by_owner_t(kmr_handle *h, const ReadsView
 		rc = ensure_buf(h, h->linear, h->linear_cap, total_cap, sizeof(typename PoolRec<W, EXT>::type)); if (rc) return rc;      /* (rec_bytes() is the granule size on a super-k-mer handle) */
 		rc = ensure_buf(h, h->tile_count, h->tile_cap, tiles, 4); if (rc) return rc;
 		LinearOp<W, EXT, false> op; op.records = (typename PoolRec<W, EXT>::type *)h->linear; op.koff = h->koff; op.tile_count = h->tile_count; op.first_read_idx = rv.first_read_idx;
-		rc = launch_extract<W, EXT>(h, rv, op); if (rc) return rc;
+		h->sender_launch = dev_pos == nullptr;
+		rc = launch_extract<W, EXT>(h, rv, op);
+		h->sender_launch = false;
+		if (rc) return rc;
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 8, tiles);
 		/* who owns a k-mer: getDistributedThreadId, or -- a spectrum that was built through the list exchange -- the list of its minimizer */
@@ -2565,13 +2571,14 @@ int kmr_extract_by_owner_host(kmr_handle *h, const kmr_reads *batch, uint64_t fi
 		const uint64_t upper = batch->total + 64;          /* k-mers <= bases */
 		uint64_t segcap = std::min<uint64_t>(upper, upper / world + upper / (4 * world) + 4096);
 		const uint64_t sb = h->stream_base, rd = h->reads;
+		unsigned long long bad0 = 0; hipMemcpy(&bad0, &h->dstats->sender_bad, 8, hipMemcpyDeviceToHost);      /* a repeated attempt must not count the dropped k-mers twice */
 		for (;;) {
 			if (hipMalloc(&h->xo_dev, (size_t)world * segcap * rb) != hipSuccess) { hipFree(dcounts); h->xo_dev = nullptr; return fail(h, KMR_ERR_OOM, "owner segments"); }
 			h->stream_base = sb; h->reads = rd;             /* a repeated attempt stamps the same ordinals */
 			int rc = kmr_extract_by_owner_dev(h, batch->bases, batch->quals, batch->offsets, batch->n, batch->total, first_global_read_idx, nullptr, h->xo_dev, segcap, dcounts);
 			if (!rc) rc = sync_state(h);
 			if (rc == KMR_ERR_CAPACITY && segcap < upper) {      /* a skewed batch: one owner takes more than its share */
-				uint32_t e = 0; hipMemcpy(&e, h->derr, 4, hipMemcpyDeviceToHost); e &= ~(uint32_t)ERR_SEGMENT_OVERFLOW; hipMemcpy(h->derr, &e, 4, hipMemcpyHostToDevice);
+				uint32_t e = 0; hipMemcpy(&e, h->derr, 4, hipMemcpyDeviceToHost); e &= ~(uint32_t)ERR_SEGMENT_OVERFLOW; hipMemcpy(h->derr, &e, 4, hipMemcpyHostToDevice); hipMemcpy(&h->dstats->sender_bad, &bad0, 8, hipMemcpyHostToDevice);
 				hipFree(h->xo_dev); h->xo_dev = nullptr;
 				segcap = std::min<uint64_t>(upper, segcap * 2);
 				continue;

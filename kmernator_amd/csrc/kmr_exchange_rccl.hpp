@@ -5,6 +5,7 @@
  *
  *   rank 0:      kmr_exchange_unique_id(id)            -> hand the 128 bytes to every rank (a file, a pipe, MPI_Bcast ...)
  *   every rank:  kmr_exchange_init(h, id)              collective: ncclCommInitRank(world_size, id, rank) on the handle's device
+ *                (or kmr_exchange_init_transport(h, t): the host's own all-gather / all-to-all, e.g. MPI, instead of RCCL)
  *   per batch:   kmr_exchange_add_reads_dev(h, ...)    collective: extract -> counts -> all-to-all -> insert at the owner
  *   then:        kmr_finalize(h, ...) as on one GPU
  *
@@ -54,9 +55,19 @@ int kmr_exchange_unique_id(void *id) {
 	memcpy(id, &u, sizeof(u));
 	return KMR_OK;
 }
+static int exchange_ready(kmr_handle *h) {      /* common tail of the two inits */
+	if (h->cfg.world_size > SK_OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "at most 64 ranks");
+	/* build_mode 0: a job that exchanges through the library runs on the lists when the handle can (direction-counting values, a
+	 * minimizer geometry for k) and nothing has been fed to it yet */
+	if (h->auto_mode && !h->superkmer_mode && h->dPk && !h->reads && !h->inserted_records && !h->sk_state) h->superkmer_mode = true;
+	if (h->superkmer_mode) return kmr_sk_exchange_begin(h);
+	return KMR_OK;
+}
+static int rccl_allgather_u64(void *user, const uint64_t *mine, uint64_t n, uint64_t *all);
+static int rccl_alltoallv_dev(void *user, const void *send, const uint64_t *send_off, const uint64_t *send_bytes, void *recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream);
 int kmr_exchange_init(kmr_handle *h, const void *id) {
 	if (!h || !id) return KMR_ERR_INVALID_ARG;
-	if (h->xc_comm) return fail(h, KMR_ERR_STATE, "kmr_exchange_init: the handle already has a communicator");
+	if (h->xc_tr.allgather_u64) return fail(h, KMR_ERR_STATE, "kmr_exchange_init: the handle already has a transport");
 	if (const char *e = rccl_load()) return fail(h, KMR_ERR_UNSUPPORTED, e);
 	if (h->cfg.world_size > SK_OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "at most 64 ranks");
 	hipSetDevice(h->device);
@@ -64,19 +75,23 @@ int kmr_exchange_init(kmr_handle *h, const void *id) {
 	ncclComm_t comm = nullptr;
 	RCCLCHK(h, g_rccl.CommInitRank(&comm, (int)h->cfg.world_size, u, (int)h->cfg.rank));
 	h->xc_comm = comm;
-	HIPCHK(h, hipMalloc((void **)&h->xc_small, 8ull * ((2 * SK_OWNER_MAX) * (SK_OWNER_MAX + 1) + SK_OWNER_MAX)));
-	/* build_mode 0: a job that exchanges through the library runs on the lists when the handle can (direction-counting values, a
-	 * minimizer geometry for k) and nothing has been fed to it yet */
-	if (h->auto_mode && !h->superkmer_mode && h->dPk && !h->reads && !h->inserted_records && !h->sk_state) h->superkmer_mode = true;
-	if (h->superkmer_mode) return kmr_sk_exchange_begin(h);
-	return KMR_OK;
+	HIPCHK(h, hipMalloc((void **)&h->xc_small, 8ull * (2 * SK_OWNER_MAX) * (SK_OWNER_MAX + 1)));
+	h->xc_tr.user = h; h->xc_tr.allgather_u64 = rccl_allgather_u64; h->xc_tr.alltoallv_dev = rccl_alltoallv_dev;
+	return exchange_ready(h);
+}
+int kmr_exchange_init_transport(kmr_handle *h, const kmr_transport *t) {
+	if (!h || !t || !t->allgather_u64 || !t->alltoallv_dev) return KMR_ERR_INVALID_ARG;
+	if (h->xc_tr.allgather_u64) return fail(h, KMR_ERR_STATE, "kmr_exchange_init_transport: the handle already has a transport");
+	h->xc_tr = *t;
+	return exchange_ready(h);
 }
 static void exchange_free(kmr_handle *h) {      /* kmr_destroy */
 	if (h->xc_comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)h->xc_comm);
 	h->xc_comm = nullptr;
 	for (void **p : {&h->xc_send, &h->xc_send2, &h->xc_recv, &h->xc_recv2}) { if (*p) hipFree(*p); *p = nullptr; }
 	if (h->xc_small) hipFree(h->xc_small);
-	h->xc_small = nullptr;
+	if (h->xc_dcounts) hipFree(h->xc_dcounts);
+	h->xc_small = nullptr; h->xc_dcounts = nullptr;
 }
 static int xc_reserve(kmr_handle *h, void **p, uint64_t &cap, uint64_t bytes) {
 	if (bytes <= cap && *p) return 0;
@@ -86,19 +101,42 @@ static int xc_reserve(kmr_handle *h, void **p, uint64_t &cap, uint64_t bytes) {
 	cap = bytes;
 	return 0;
 }
-/* every rank's row of 2 * world numbers -> all rows, on the host: m[r * 2 * world + j] */
-static int xc_allgather_rows(kmr_handle *h, const std::vector<uint64_t> &mine, std::vector<uint64_t> &all) {
-	const uint32_t world = h->cfg.world_size; const size_t row = mine.size();
-	all.assign(row * world, 0);
-	unsigned long long *d = h->xc_small;      /* [row] mine, then [world][row] */
-	HIPCHK(h, hipMemcpyAsync(d, mine.data(), 8 * row, hipMemcpyHostToDevice, h->stream));
-	RCCLCHK(h, g_rccl.AllGather(d, d + row, row, ncclUint64, (ncclComm_t)h->xc_comm, h->stream));
-	HIPCHK(h, hipMemcpyAsync(all.data(), d + row, 8 * row * world, hipMemcpyDeviceToHost, h->stream));
+/* ---- the built-in transport: RCCL on the handle's stream */
+static int rccl_allgather_u64(void *user, const uint64_t *mine, uint64_t n, uint64_t *all) {
+	kmr_handle *h = (kmr_handle *)user;
+	const uint32_t world = h->cfg.world_size;
+	if (n > 2 * SK_OWNER_MAX) return fail(h, KMR_ERR_INVALID_ARG, "allgather row too long");
+	unsigned long long *d = h->xc_small;      /* [n] mine, then [world][n] */
+	HIPCHK(h, hipMemcpyAsync(d, mine, 8 * n, hipMemcpyHostToDevice, h->stream));
+	RCCLCHK(h, g_rccl.AllGather(d, d + n, n, ncclUint64, (ncclComm_t)h->xc_comm, h->stream));
+	HIPCHK(h, hipMemcpyAsync(all, d + n, 8 * n * world, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	return 0;
 }
-/* all-to-all of byte segments: send[r] bytes from sbuf + soff[r] to rank r, recv[r] bytes from rank r to rbuf + roff[r]; slices keeps
- * every message <= XC_MAX_MESSAGE and is the same number on every rank (it comes from the gathered matrix) */
+static int rccl_alltoallv_dev(void *user, const void *send, const uint64_t *send_off, const uint64_t *send_bytes,
+                              void *recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream) {
+	kmr_handle *h = (kmr_handle *)user;
+	const uint32_t world = h->cfg.world_size, rank = h->cfg.rank;
+	RCCLCHK(h, g_rccl.GroupStart());
+	for (uint32_t r = 0; r < world; r++) {
+		if (r == rank) continue;
+		if (send_bytes[r]) RCCLCHK(h, g_rccl.Send((const uint8_t *)send + send_off[r], send_bytes[r], ncclUint8, (int)r, (ncclComm_t)h->xc_comm, (hipStream_t)stream));
+		if (recv_bytes[r]) RCCLCHK(h, g_rccl.Recv((uint8_t *)recv + recv_off[r], recv_bytes[r], ncclUint8, (int)r, (ncclComm_t)h->xc_comm, (hipStream_t)stream));
+	}
+	RCCLCHK(h, g_rccl.GroupEnd());
+	return 0;
+}
+
+/* every rank's row of numbers -> all rows, on the host: all[r * row + j] */
+static int xc_allgather_rows(kmr_handle *h, const std::vector<uint64_t> &mine, std::vector<uint64_t> &all) {
+	const uint32_t world = h->cfg.world_size; const size_t row = mine.size();
+	all.assign(row * world, 0);
+	const int rc = h->xc_tr.allgather_u64(h->xc_tr.user, mine.data(), row, all.data());
+	if (rc) return h->xc_tr.user == (void *)h ? rc : fail(h, rc, "transport: allgather_u64 failed");
+	return 0;
+}
+/* all-to-all of byte segments: send[r] bytes from sbuf + soff[r] to rank r, recv[r] bytes from rank r to rbuf + roff[r], in `slices`
+ * rounds so that no message exceeds XC_MAX_MESSAGE (the number of rounds comes from the gathered matrix: the same on every rank) */
 static int xc_alltoallv(kmr_handle *h, const uint8_t *sbuf, const std::vector<uint64_t> &soff, const std::vector<uint64_t> &send,
                         uint8_t *rbuf, const std::vector<uint64_t> &roff, const std::vector<uint64_t> &recv, uint64_t slices, uint64_t unit) {
 	const uint32_t world = h->cfg.world_size, rank = h->cfg.rank;
@@ -107,17 +145,15 @@ static int xc_alltoallv(kmr_handle *h, const uint8_t *sbuf, const std::vector<ui
 		const uint64_t a = std::min(units, s * per), b = std::min(units, (s + 1) * per);
 		lo = a * unit; n = (b - a) * unit;
 	};
+	std::vector<uint64_t> so(world), sn(world), ro(world), rn(world);
 	for (uint64_t s = 0; s < slices; s++) {
-		RCCLCHK(h, g_rccl.GroupStart());
 		for (uint32_t r = 0; r < world; r++) {
-			if (r == rank) continue;
 			uint64_t lo, n;
-			part(send[r], s, lo, n);
-			if (n) RCCLCHK(h, g_rccl.Send(sbuf + soff[r] + lo, n, ncclUint8, (int)r, (ncclComm_t)h->xc_comm, h->stream));
-			part(recv[r], s, lo, n);
-			if (n) RCCLCHK(h, g_rccl.Recv(rbuf + roff[r] + lo, n, ncclUint8, (int)r, (ncclComm_t)h->xc_comm, h->stream));
+			part(r == rank ? 0 : send[r], s, lo, n); so[r] = soff[r] + lo; sn[r] = n;
+			part(r == rank ? 0 : recv[r], s, lo, n); ro[r] = roff[r] + lo; rn[r] = n;
 		}
-		RCCLCHK(h, g_rccl.GroupEnd());
+		const int rc = h->xc_tr.alltoallv_dev(h->xc_tr.user, sbuf, so.data(), sn.data(), rbuf, ro.data(), rn.data(), (void *)h->stream);
+		if (rc) return h->xc_tr.user == (void *)h ? rc : fail(h, rc, "transport: alltoallv_dev failed");
 	}
 	return 0;
 }
@@ -125,7 +161,7 @@ static int xc_alltoallv(kmr_handle *h, const uint8_t *sbuf, const std::vector<ui
 int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals, const void *dev_offsets, uint64_t n_reads, uint64_t total_bases,
                                uint64_t first_global_read_idx, const void *dev_discarded) {
 	if (!h || (n_reads && (!dev_bases || !dev_offsets))) return KMR_ERR_INVALID_ARG;
-	if (!h->xc_comm) return fail(h, KMR_ERR_STATE, "kmr_exchange_add_reads_dev before kmr_exchange_init");
+	if (!h->xc_tr.allgather_u64) return fail(h, KMR_ERR_STATE, "kmr_exchange_add_reads_dev before kmr_exchange_init / kmr_exchange_init_transport");
 	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_exchange_add_reads_dev after kmr_finalize (kmr_reset first)");
 	hipSetDevice(h->device);
 	const uint32_t world = h->cfg.world_size, rank = h->cfg.rank;
@@ -180,7 +216,9 @@ int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void 
 	const uint64_t upper = total_bases + 64;
 	uint64_t segcap = std::min<uint64_t>(upper, upper / world + upper / (4 * world) + 4096);
 	const uint64_t sb = h->stream_base, rd = h->reads;
-	unsigned long long *dcounts = h->xc_small + (2 * SK_OWNER_MAX) * (SK_OWNER_MAX + 1);      /* behind the gather rows */
+	unsigned long long bad0 = 0; hipMemcpy(&bad0, &h->dstats->sender_bad, 8, hipMemcpyDeviceToHost);      /* a repeated attempt must not count the dropped k-mers twice */
+	if (!h->xc_dcounts) HIPCHK(h, hipMalloc((void **)&h->xc_dcounts, 8 * SK_OWNER_MAX));
+	unsigned long long *dcounts = h->xc_dcounts;
 	std::vector<uint64_t> counts(world, 0);
 	for (;;) {      /* a skewed batch (one owner takes more than its share) is extracted again into larger segments */
 		rc = xc_reserve(h, &h->xc_send, h->xc_send_cap, (uint64_t)world * segcap * rb); if (rc) return rc;
@@ -189,7 +227,7 @@ int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void 
 		else HIPCHK(h, hipMemsetAsync(dcounts, 0, 8 * world, h->stream));
 		if (!rc) rc = sync_state(h);
 		if (rc == KMR_ERR_CAPACITY && segcap < upper) {
-			uint32_t e = 0; hipMemcpy(&e, h->derr, 4, hipMemcpyDeviceToHost); e &= ~(uint32_t)ERR_SEGMENT_OVERFLOW; hipMemcpy(h->derr, &e, 4, hipMemcpyHostToDevice);
+			uint32_t e = 0; hipMemcpy(&e, h->derr, 4, hipMemcpyDeviceToHost); e &= ~(uint32_t)ERR_SEGMENT_OVERFLOW; hipMemcpy(h->derr, &e, 4, hipMemcpyHostToDevice); hipMemcpy(&h->dstats->sender_bad, &bad0, 8, hipMemcpyHostToDevice);
 			segcap = std::min<uint64_t>(upper, segcap * 2);
 			continue;
 		}
@@ -217,6 +255,14 @@ int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void 
 	if (counts[rank]) { rc = kmr_insert_records_dev(h, (const uint8_t *)h->xc_send + (uint64_t)rank * segcap * rb, counts[rank]); if (rc) return rc; }
 	if (got) { rc = kmr_insert_records_dev(h, h->xc_recv, got / rb); if (rc) return rc; }
 	return sync_state(h);
+}
+int kmr_exchange_add_read_batch(kmr_handle *h, const kmr_reads *r, uint64_t first_global_read_idx) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (r && r->device != h->device) return fail(h, KMR_ERR_INVALID_ARG, "read batch lives on another device");
+	int rc = r ? kmr_exchange_add_reads_dev(h, r->bases, r->quals, r->offsets, r->n, r->total, first_global_read_idx, nullptr)
+	           : kmr_exchange_add_reads_dev(h, nullptr, nullptr, nullptr, 0, 0, first_global_read_idx, nullptr);
+	if (!rc) rc = kmr_sync(h);
+	return rc;
 }
 int kmr_exchange_stats(kmr_handle *h, uint64_t *bytes_to_peers, double *alltoall_ms) {
 	if (!h) return KMR_ERR_INVALID_ARG;

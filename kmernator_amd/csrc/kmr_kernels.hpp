@@ -91,6 +91,7 @@ struct DevStats {
 	unsigned long long raw, good, claimed;   /* claimed = new keys inserted */
 	unsigned long long inserted;             /* records received through the owner exchange (holes excluded) */
 	unsigned long long subtracted;           /* occurrences found in the subtracting reference spectrum */
+	unsigned long long sender_bad;           /* sender side of the k-mer record exchange: k-mers of this rank's reads that were not good enough to send */
 };
 
 struct DevParams {
@@ -99,6 +100,7 @@ struct DevParams {
 	uint32_t fastq_start, ext_min_q;
 	uint32_t qzero;            /* raw quality chars below this have probability 0 (fastq_start + min_quality_score) */
 	uint32_t subsample, rank, world, num_parts, part_idx;
+	uint32_t count_sender_bad; /* the launch is the sender side of the k-mer record exchange (the owner counts what it receives, the sender what it drops) */
 	const double *P;       /* 256 entries, device */
 	DevStats *stats;
 	uint32_t *err;
@@ -678,6 +680,7 @@ void extract_kernel(ReadsView rv, DevParams p, Op op) {
 		atomicAdd(&p.stats->good, nGood);
 		if (nc) atomicAdd(&p.stats->claimed, nc);
 	}
+	if (lane == 0 && !Op::COUNTS_STATS && p.count_sender_bad && nRaw > nGood) atomicAdd(&p.stats->sender_bad, nRaw - nGood);
 	if (haveSub) { nSub = wave_sum(nSub); if (lane == 0 && nSub) atomicAdd(&p.stats->subtracted, nSub); }
 	if (__any(fail) && lane == 0) atomicOr(p.err, op_fail_code(op));
 }

@@ -117,6 +117,67 @@ class KmerSpectrum:
     def insertRecordsDevice(self, records_ptr, n):
         self._call("insert_records_dev", self.h, records_ptr, n)
 
+    # the whole owner exchange inside the library (kmr_exchange_*): RCCL called from C++, or a transport the host supplies
+    @staticmethod
+    def exchange_unique_id():
+        """rank 0: the job's RCCL id (KMR_EXCHANGE_ID_BYTES bytes) to hand to every rank"""
+        buf = (C.c_uint8 * 128)()
+        lib = _lib.load()
+        rc = lib.kmr_exchange_unique_id(C.cast(buf, C.c_void_p))
+        if rc:
+            raise KmerSpectrumError("kmr_exchange_unique_id failed (%d): %s" % (rc, lib.kmr_last_error(None).decode()))
+        return bytes(buf)
+
+    def exchange_init(self, unique_id):
+        """collective: ncclCommInitRank(world_size, id, rank) on the handle's device (kmr_exchange_init)"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._call("exchange_init", self.h, C.cast(buf, C.c_void_p))
+
+    def exchange_init_transport(self, allgather_u64, alltoallv_dev):
+        """kmr_exchange_init_transport with Python callables (tests: gloo).  allgather_u64(mine: list[int]) -> list of world rows;
+        alltoallv_dev(send_ptr, send_off, send_bytes, recv_ptr, recv_off, recv_bytes, stream) with lists of world ints."""
+        world = self.cfg.world_size
+        u64p = C.POINTER(C.c_uint64)
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, C.c_uint64, u64p)
+        AV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, C.c_void_p)
+
+        def ag(user, mine, n, out):
+            try:
+                rows = allgather_u64([int(mine[i]) for i in range(n)])
+                for r in range(world):
+                    for j in range(n):
+                        out[r * n + j] = int(rows[r][j])
+                return 0
+            except Exception:          # noqa: BLE001 -- the exception cannot cross the C frame
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        def av(user, send, soff, sbytes, recv, roff, rbytes, stream):
+            try:
+                alltoallv_dev(send, [int(soff[r]) for r in range(world)], [int(sbytes[r]) for r in range(world)],
+                              recv, [int(roff[r]) for r in range(world)], [int(rbytes[r]) for r in range(world)], stream)
+                return 0
+            except Exception:          # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        class Transport(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("allgather_u64", AG), ("alltoallv_dev", AV)]
+        self._transport = Transport(None, AG(ag), AV(av))          # keeps the callbacks alive as long as the handle
+        self._call("exchange_init_transport", self.h, C.cast(C.pointer(self._transport), C.c_void_p))
+
+    def exchange_add_reads(self, bases_ptr, quals_ptr, offsets_ptr, n_reads, total_bases, first_read_idx=0, discarded_ptr=None):
+        """collective: one batch of this rank's reads through extract -> all-to-all -> insert at the owner (kmr_exchange_add_reads_dev)"""
+        self._call("exchange_add_reads_dev", self.h, bases_ptr, quals_ptr, offsets_ptr, n_reads, total_bases, first_read_idx, discarded_ptr)
+
+    def exchange_stats(self):
+        b = C.c_uint64()
+        ms = C.c_double()
+        self._call("exchange_stats", self.h, C.byref(b), C.byref(ms))
+        return {"bytes_to_peers": b.value, "alltoall_ms": ms.value}
+
     def set_stream_origin(self, ordinal):
         """position in the whole input of the next base this handle is fed (kmr_set_stream_origin)"""
         self._call("set_stream_origin", self.h, int(ordinal))

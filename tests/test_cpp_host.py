@@ -82,3 +82,20 @@ def test_cpp_filterreads_with_artifact_filter(tmp_path):
     for i, line in enumerate(lines):
         assert line.split(" ", 1)[1].encode() == gold.names[i].split(b" ", 1)[1].replace(b"\t", b" "), (i, line, gold.names[i])
     assert sum("AFTrim" in line for line in lines) == 51
+
+
+@pytest.mark.gpu
+def test_cpp_meraculous_counter_through_the_library_exchange(tmp_path):
+    """MeraculousCounter as the one-process-per-GPU job a C++ host runs (host_demo mercount-ranks): communicator, counts, all-to-all
+    and inserts all happen inside the library over RCCL.  This box has one GPU, so the job has one rank (RCCL refuses two ranks
+    on a device; the N-rank logic of the same driver runs over a host transport in tests/test_gpu_exchange_library.py): its dumps
+    must be the reference's goldens."""
+    demo = build_demo()
+    out = str(tmp_path / "phix")
+    p = subprocess.run([demo, "mercount-ranks", os.path.join(GOLDEN, "1000.fastq"), out, "0", "1", str(tmp_path / "id")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "rank 0 of 1: reads 1000 raw 56000" in p.stdout and "bytes-to-peers 0" in p.stdout
+    for ext, gold in ((".mercount.0", "phix.mercount.m21"), (".mergraph.0", "phix.mergraph.m21.D2")):
+        got = sorted(open(out + ext).read().splitlines())
+        exp = sorted(open(os.path.join(GOLDEN, gold)).read().splitlines())
+        assert got == exp
