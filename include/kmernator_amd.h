@@ -94,7 +94,15 @@ typedef struct kmr_config {
 	                                    values, k >= 13, single partition) */
 	uint64_t max_table_entries;      /* 0 = size from estimated_raw_kmers; else distinct-key
 	                                    capacity of the device table                           */
+	uint32_t hash_kind;              /* kmr_hash_kind: which hash places a k-mer in its bucket / owner / part / subsample.
+	                                    0 = KmerHasher::getHash as it is today: lookup3 hashlittle2 (src/Kmer.h:207-230);
+	                                    1 = lookup8 hash() with level 0xDEADBEEF (src/lookup8.h:90-160; what getHash used
+	                                    before, src/Kmer.h:210-212 -- the reference no longer calls it).  Images written with
+	                                    one kind cannot be loaded into a handle of the other (the bucket of a key differs) */
+	uint32_t size_tracker;           /* 1 = keep KmerSpectrum::SizeTracker snapshots (src/KmerSpectrum.h:812-900), see
+	                                    kmr_size_tracker below                                                          */
 } kmr_config;
+enum kmr_hash_kind { KMR_HASH_LOOKUP3 = 0, KMR_HASH_LOOKUP8 = 1 };
 
 typedef struct kmr_handle kmr_handle;
 
@@ -244,6 +252,7 @@ int kmr_dump_mergraph(kmr_handle *h, const char *path, uint32_t min_depth);
 /* KmerHasher::getHash (src/Kmer.h:207-230) = Lookup3::hashlittle2
  * (src/lookup3.h:470-641) with pc=0xDEADBEEF, pb=0, result c | b<<32. */
 uint64_t kmr_hash(const uint8_t *key, uint32_t len);
+uint64_t kmr_hash_of_kind(const uint8_t *key, uint32_t len, uint32_t hash_kind);      /* the same for either kmr_hash_kind (len <= 32) */
 /* BucketExposedMapLogic::getBucketIdx / getLocalThreadId / getDistributedThreadId
  * (src/Kmer.h:2329-2333, 2269-2280, 2284-2295). */
 uint64_t kmr_bucket_idx(uint64_t hash, uint64_t num_buckets_pow2);

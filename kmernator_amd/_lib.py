@@ -32,6 +32,7 @@ class KmrConfig(C.Structure):
         ("kmers_per_bucket", C.c_uint32), ("num_parts", C.c_uint32),
         ("part_idx", C.c_uint32), ("build_mode", C.c_uint32),
         ("max_table_entries", C.c_uint64),
+        ("hash_kind", C.c_uint32), ("size_tracker", C.c_uint32),
     ]
 
 
@@ -56,7 +57,7 @@ EXPORTS = [
     "kmr_abi_version", "kmr_config_init", "kmr_create", "kmr_destroy", "kmr_last_error", "kmr_num_buckets",
     "kmr_add_reads", "kmr_add_reads_dev", "kmr_sync", "kmr_finalize", "kmr_get_stats", "kmr_lookup",
     "kmr_lookup_reads", "kmr_image_size", "kmr_write_image", "kmr_load_image", "kmr_count_histogram",
-    "kmr_dump_mercount", "kmr_dump_mergraph", "kmr_hash", "kmr_bucket_idx", "kmr_local_thread_id",
+    "kmr_dump_mercount", "kmr_dump_mergraph", "kmr_hash", "kmr_hash_of_kind", "kmr_bucket_idx", "kmr_local_thread_id",
     "kmr_distributed_thread_id", "kmr_compress_sequence", "kmr_least_complement", "kmr_extract_by_owner_dev",
     "kmr_insert_records_dev", "kmr_stream", "kmr_kernel_time", "kmr_kernel_time_reset", "kmr_reset", "kmr_release_table", "kmr_score_reads",
     "kmr_ingest_fastq", "kmr_ingest_fastq_dev", "kmr_reads_info", "kmr_reads_device_ptrs", "kmr_reads_copy",

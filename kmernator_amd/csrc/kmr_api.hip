@@ -70,7 +70,7 @@ struct Tuning {
 struct kmr_handle {
 	kmr_config cfg;
 	Tuning tune;
-	uint32_t k = 0, kb = 0, W = 0;
+	uint32_t k = 0, kb = 0, hkb = 0, W = 0;
 	bool ext = false;
 	int device = 0, ncu = 0;
 	hipStream_t stream = nullptr;
@@ -183,7 +183,7 @@ size_t slot_bytes(uint32_t W) {
 
 DevParams dev_params(kmr_handle *h) {
 	DevParams p;
-	p.k = h->k; p.kb = h->kb; p.min_weight = h->cfg.min_weight; p.fastq_start = h->cfg.fastq_start_char; p.ext_min_q = h->cfg.ext_min_quality;
+	p.k = h->k; p.kb = h->hkb; p.min_weight = h->cfg.min_weight; p.fastq_start = h->cfg.fastq_start_char; p.ext_min_q = h->cfg.ext_min_quality;
 	p.qzero = h->cfg.fastq_start_char + std::max<uint32_t>(1u, h->cfg.min_quality_score);   /* Q0 has probability 0 too */
 	p.subsample = h->cfg.kmer_subsample; p.rank = h->cfg.rank; p.world = h->cfg.world_size; p.num_parts = h->cfg.num_parts; p.part_idx = h->cfg.part_idx;
 	p.count_sender_bad = h->sender_launch ? 1u : 0u;
@@ -256,7 +256,7 @@ template <int W, bool EXT> int grow_table_t(kmr_handle *h, uint32_t newlog) {
 	int rc = alloc_table(h, newlog, &ns, &ne);
 	if (rc) return rc;
 	Table<W> src = table_of<W>(h), dst; dst.slots = (Slot<W> *)ns; dst.ext = ne; dst.log2cap = newlog;
-	hipLaunchKernelGGL((rehash_kernel<W, EXT>), dim3(grid_for(1ull << h->log2cap)), dim3(256), 0, h->stream, src, dst, h->kb, h->derr);
+	hipLaunchKernelGGL((rehash_kernel<W, EXT>), dim3(grid_for(1ull << h->log2cap)), dim3(256), 0, h->stream, src, dst, h->hkb, h->derr);
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(h->slots); if (h->extslots) hipFree(h->extslots);
@@ -455,7 +455,7 @@ template <int W, bool EXT> int finalize_t(kmr_handle *h, uint32_t min_depth) {
 	int rc = sync_state(h);
 	if (rc) return rc;
 	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
-	FinalizeParams f; f.kb = h->kb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	FinalizeParams f; f.kb = h->hkb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr;
 	HIPCHK(h, hipMalloc((void **)&wc, 4 * h->nb_weak)); HIPCHK(h, hipMalloc((void **)&sc, 4 * h->nb_sing)); HIPCHK(h, hipMalloc((void **)&fc, sizeof(FinalizeCounters)));
@@ -602,7 +602,7 @@ template <int W> int lookup_t(kmr_handle *h, const uint8_t *packed, uint64_t n, 
 	HIPCHK(h, hipMalloc((void **)&dk, std::max<uint64_t>(8, n * h->kb))); HIPCHK(h, hipMalloc((void **)&dc, std::max<uint64_t>(8, 4 * n)));
 	HIPCHK(h, hipMemcpyAsync(dk, packed, n * h->kb, hipMemcpyHostToDevice, h->stream));
 	const uint32_t vw = h->ext ? 15 : 3;
-	hipLaunchKernelGGL(lookup_keys_kernel<W>, dim3(grid_for(n)), dim3(256), 0, h->stream, view_of<W>(h->weak, vw), view_of<W>(h->sing, vw), dk, n, h->kb, dc);
+	hipLaunchKernelGGL(lookup_keys_kernel<W>, dim3(grid_for(n)), dim3(256), 0, h->stream, view_of<W>(h->weak, vw), view_of<W>(h->sing, vw), dk, n, h->hkb, dc);
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipMemcpyAsync(counts, dc, 4 * n, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -626,7 +626,7 @@ template <int W> LutView<W> lut_of(kmr_handle *h) {
 		}
 		const uint32_t vw = h->ext ? 15 : 3;
 		hipLaunchKernelGGL(lut_clear_kernel, dim3(4096), dim3(256), 0, h->stream, h->lut, 1ull << l2, (uint32_t)(W + 1));
-		hipLaunchKernelGGL(lut_build_kernel<W>, dim3(grid_for(h->weak.n)), dim3(256), 0, h->stream, view_of<W>(h->weak, vw), h->weak.n, h->lut, (1ull << l2) - 1, 64 - l2, h->kb);
+		hipLaunchKernelGGL(lut_build_kernel<W>, dim3(grid_for(h->weak.n)), dim3(256), 0, h->stream, view_of<W>(h->weak, vw), h->weak.n, h->lut, (1ull << l2) - 1, 64 - l2, h->hkb);
 		if (hipGetLastError() != hipSuccess) return v;
 		h->lut_log2 = l2; h->lut_gen = h->map_gen;
 	}
@@ -767,7 +767,7 @@ template <int W, bool EXT> int flush_l1_state(kmr_handle *h) {
 	int rc = pool_reserve(h, h->l1, (uint64_t)partition_blocks(h) * ((1ull << h->bits1) + 512) + 64, true); if (rc) return rc;
 	rc = zero_work_counter(h); if (rc) return rc;
 	PartSource<W> S; memset(&S, 0, sizeof(S));
-	S.kb = h->kb; S.rot = part_rot(h); S.state = h->l1_state; S.state_final = 1;
+	S.kb = h->hkb; S.rot = part_rot(h); S.state = h->l1_state; S.state_final = 1;
 	rc = launch_partition<W, EXT, 1>(h, S, h->l1, partition_blocks(h), h->bits1, 0);
 	h->l1_state_dirty = false;
 	return rc;
@@ -807,7 +807,7 @@ template <int W, bool EXT> int partition_level1(kmr_handle *h, const void *linea
 	rc = zero_work_counter(h); if (rc) return rc;
 	PartSource<W> S; memset(&S, 0, sizeof(S));
 	S.linear = linear; S.ext_start = ext_start; S.ext_count = ext_count; S.n_ext = n_ext; S.ext_stride = ext_stride; S.ext_len = ext_len; S.total = total;
-	S.valid_counter = valid_counter; S.kb = h->kb; S.rot = part_rot(h); S.packed_words = packed_words; S.ordinal_base = ordinal_base;
+	S.valid_counter = valid_counter; S.kb = h->hkb; S.rot = part_rot(h); S.packed_words = packed_words; S.ordinal_base = ordinal_base;
 	if (!h->tune.no_l1_state) {
 		rc = ensure_l1_state<W, EXT>(h); if (rc) return rc;
 		S.state = h->l1_state; S.state_final = 0; h->l1_state_dirty = true;
@@ -862,10 +862,10 @@ template <int W, bool EXT> int extract_by_owner_t(kmr_handle *h, const ReadsView
 		OwnerFn of; of.m = 0; of.off = of.win = of.list_bits = 0;
 		if (h->superkmer_mode && h->sk_exchange) { of.m = h->sk_m; of.off = h->sk_off; of.win = h->sk_win; of.list_bits = h->sk_bits; }
 		if (dev_pos)
-			hipLaunchKernelGGL((owner_scatter_kernel<W, EXT, true>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->kb,
+			hipLaunchKernelGGL((owner_scatter_kernel<W, EXT, true>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->hkb,
 			                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr, dev_pos, of);
 		else
-			hipLaunchKernelGGL((owner_scatter_kernel<W, EXT>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->kb,
+			hipLaunchKernelGGL((owner_scatter_kernel<W, EXT>), dim3(grid), dim3(OWNER_THREADS), 0, h->stream, (const typename PoolRec<W, EXT>::type *)h->linear, h->koff, h->tile_count, tiles, h->hkb,
 			                   h->cfg.world_size, (uint32_t *)dev_records, seg_capacity, (unsigned long long *)dev_seg_counts, h->work_counter, h->derr, (uint32_t *)nullptr, of);
 		HIPCHK(h, hipGetLastError());
 	}
@@ -952,7 +952,7 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint32_t first, uint64_t 
 		int bits = 0; while ((1ull << bits) < nl) bits++;
 		HIPCHK(h, hipMalloc((void **)&v, 24)); HIPCHK(h, hipMemset(v, 0, 24));
 		PoolView pvw = pool_view(h, p);
-#define VLK(Wv, E) hipLaunchKernelGGL((verify_lists_kernel<Wv, E>), dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->kb, part_rot(h), v, v + 1, v + 2)
+#define VLK(Wv, E) hipLaunchKernelGGL((verify_lists_kernel<Wv, E>), dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->hkb, part_rot(h), v, v + 1, v + 2)
 		switch (h->W) {
 		case 1: if (h->ext) VLK(1, true); else VLK(1, false); break;
 		case 2: if (h->ext) VLK(2, true); else VLK(2, false); break;
@@ -974,7 +974,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 	if (rc) return rc;
 	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
 	const uint64_t G = h->stats.raw_good_kmers;     /* records in the level-1 pool */
-	FinalizeParams f; f.kb = h->kb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	FinalizeParams f; f.kb = h->hkb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
 	rc = arena_reset(h); if (rc) return rc;
@@ -994,7 +994,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 		const size_t tbytes = 8 * ((size_t)n_probes * PROBE_SLOTS + 4);
 		rc = arena_alloc(h, (void **)&dpr, tbytes); if (rc) return rc;
 		HIPCHK(h, hipMemsetAsync(dpr, 0, tbytes, h->stream));
-		hipLaunchKernelGGL((distinct_probe_kernel<W, EXT>), dim3(n_probes * PROBE_SPLIT), dim3(256), 0, h->stream, pool_view(h, h->l1), ls1, lc1, nl1, h->kb, part_rot(h),
+		hipLaunchKernelGGL((distinct_probe_kernel<W, EXT>), dim3(n_probes * PROBE_SPLIT), dim3(256), 0, h->stream, pool_view(h, h->l1), ls1, lc1, nl1, h->hkb, part_rot(h),
 		                   (int)h->bits1, n_probes, dpr + 4, dpr);
 		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipMemcpyAsync(hpr, dpr, 32, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1036,7 +1036,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 		HIPCHK(h, hipMemcpyAsync(dil, il.data(), 4 * il.size(), hipMemcpyHostToDevice, h->stream));
 		rc = zero_work_counter(h); if (rc) return rc;
 		PartSource<W> S; memset(&S, 0, sizeof(S));
-		S.src = pool_view(h, h->l1); S.list_chunks = lc2; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size(); S.kb = h->kb; S.rot = part_rot(h);
+		S.src = pool_view(h, h->l1); S.list_chunks = lc2; S.item_begin = dib; S.item_end = die; S.item_list = dil; S.n_items = ib.size(); S.kb = h->hkb; S.rot = part_rot(h);
 		S.recycle = recycle ? 1 : 0;
 		const int grid = (int)std::min<uint64_t>(partition_blocks(h), ib.size());
 		if (dbg()) fprintf(stderr, "level %d: %d bits after %d, %zu items, %s\n", level, nbits, cur_bits, ib.size(), recycle ? "recycling chunks" : "fresh chunks");
@@ -1206,11 +1206,11 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 	if (h->ext) { rc = reserve_bytes(h, (void **)&sm.spkt, sm.c_pkt, 4 * sm.n); if (rc) return rc; }
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * sm.nb, h->stream));
 	if (wm.n && vw > 4) hipLaunchKernelGGL((entry_scatter_kernel<W, true>), dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
-	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->kb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
+	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->hkb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
 	else if (wm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
-	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->kb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
+	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->hkb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
 	if (sm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(sslots)), dim3(256), 0, h->stream, (const uint64_t *)h->us_keys, (const uint32_t *)nullptr,
-	                            (const uint8_t *)h->us_b8, (const uint32_t *)h->us_pkt, sslots, 0u, h->kb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, h->ext ? sm.spkt : (uint32_t *)nullptr);
+	                            (const uint8_t *)h->us_b8, (const uint32_t *)h->us_pkt, sslots, 0u, h->hkb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, h->ext ? sm.spkt : (uint32_t *)nullptr);
 	HIPCHK(h, hipGetLastError());
 	SortView<W> sv; sv.keys = wm.keys; sv.vals = wm.vals; sv.b8 = nullptr; sv.pkt = nullptr; sv.vw = vw;
 	if (h->ext) hipLaunchKernelGGL((sort_buckets_kernel<W, 15>), dim3(grid_for(wm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, wm.start, wm.nb);
@@ -1333,7 +1333,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	if (rc) return rc;
 	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
 	const uint64_t G = h->stats.raw_good_kmers;
-	FinalizeParams f; f.kb = h->kb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	FinalizeParams f; f.kb = h->hkb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
 	rc = arena_reset(h); if (rc) return rc;
@@ -1456,6 +1456,7 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 	if (cfg->k < 1 || cfg->k > 128) return fail(nullptr, KMR_ERR_INVALID_ARG, "k must be in 1..128");
 	if (cfg->world_size < 1 || cfg->rank >= cfg->world_size) return fail(nullptr, KMR_ERR_INVALID_ARG, "bad rank/world_size");
 	if (cfg->value_kind > KMR_VALUE_EXT) return fail(nullptr, KMR_ERR_INVALID_ARG, "bad value_kind");
+	if (cfg->hash_kind > KMR_HASH_LOOKUP8) return fail(nullptr, KMR_ERR_INVALID_ARG, "bad hash_kind");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, KMR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
 	kmr_handle *h = new kmr_handle();
@@ -1463,6 +1464,7 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 	if (h->cfg.kmer_subsample == 0) h->cfg.kmer_subsample = 1;
 	if (h->cfg.num_parts == 0) h->cfg.num_parts = 1;
 	h->k = cfg->k; h->kb = (cfg->k + 3) / 4; h->W = (h->kb + 7) / 8; h->ext = cfg->value_kind == KMR_VALUE_EXT;
+	h->hkb = h->kb | (cfg->hash_kind << 16);      /* what the kernels' hash sees: key bytes and the hash kind (kmr_key.hpp, key_hash) */
 	memset(&h->stats, 0, sizeof(h->stats));
 	int rc = 0;
 	do {
@@ -2406,6 +2408,11 @@ uint64_t kmr_hash(const uint8_t *key, uint32_t len) {
 	Key<4> k; key_from_bytes<4>(k, key, len);
 	return key_hash<4>(k, len);
 }
+uint64_t kmr_hash_of_kind(const uint8_t *key, uint32_t len, uint32_t hash_kind) {
+	if (!key || len == 0 || len > 32 || hash_kind > KMR_HASH_LOOKUP8) return 0;
+	Key<4> k; key_from_bytes<4>(k, key, len);
+	return key_hash<4>(k, len | (hash_kind << 16));
+}
 uint64_t kmr_bucket_idx(uint64_t hash, uint64_t nb) { return hash & (nb - 1); }
 uint32_t kmr_local_thread_id(uint64_t hash, uint64_t nb, uint32_t t) { return (nb > 1 && t > 1) ? (uint32_t)((hash & (nb - 1)) % t) : 0; }
 uint32_t kmr_distributed_thread_id(uint64_t hash, uint32_t n) { return distributed_thread_id(hash, n); }
@@ -2495,7 +2502,7 @@ int kmr_lookup_keys_dev(kmr_handle *h, const void *dev_keys, uint64_t n, void *d
 	if (n == 0) return KMR_OK;
 	hipSetDevice(h->device);
 	const uint32_t vw = h->ext ? 15 : 3;
-#define LK(Wv) hipLaunchKernelGGL(lookup_words_kernel<Wv>, dim3(grid_for(n)), dim3(256), 0, h->stream, view_of<Wv>(h->weak, vw), lut_of<Wv>(h), (const uint64_t *)dev_keys, n, h->kb, (uint32_t *)dev_counts)
+#define LK(Wv) hipLaunchKernelGGL(lookup_words_kernel<Wv>, dim3(grid_for(n)), dim3(256), 0, h->stream, view_of<Wv>(h->weak, vw), lut_of<Wv>(h), (const uint64_t *)dev_keys, n, h->hkb, (uint32_t *)dev_counts)
 	switch (h->W) { case 1: LK(1); break; case 2: LK(2); break; case 3: LK(3); break; default: LK(4); }
 #undef LK
 	HIPCHK(h, hipGetLastError());

@@ -774,7 +774,7 @@ template <int W>
 __global__ void lookup_keys_kernel(MapView<W> weak, MapView<W> sing, const uint8_t *packed, uint64_t n, uint32_t kb, uint32_t *out) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		Key<W> key;
-		key_from_bytes<W>(key, packed + i * kb, kb);
+		key_from_bytes<W>(key, packed + i * (kb & 0xffffu), kb & 0xffffu);      /* (kb carries the hash kind above bit 16) */
 		out[i] = maps_count<W>(weak, sing, key, key_hash<W>(key, kb));
 	}
 }

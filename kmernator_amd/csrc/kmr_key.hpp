@@ -141,7 +141,45 @@ template <int W> KMR_HD uint32_t key_le32(const Key<W> &key, int m) {
 /* KmerHasher::getHash over kb bytes.  Pad bytes inside the last 12-byte block
  * are zero in our representation, so adding whole words equals the reference's
  * masked tail reads (src/lookup3.h:527-541). */
-template <int W> KMR_HD uint64_t key_hash(const Key<W> &key, uint32_t kb) {
+/* lookup8 (Bob Jenkins, lookup8.c 1997, public domain; src/lookup8.h:90-160 hash(), = hash3() on a little-endian machine) over the
+ * kb key bytes with level 0xDEADBEEF, the initial value KmerHasher::getHash used with it before it moved to lookup3
+ * (src/Kmer.h:210-212).  The reference no longer calls it: selectable (kmr_config.hash_kind), parity unpinned.
+ * Little-endian 8-byte words of the byte string = byte-swapped words of the key; pad bytes are zero, so whole words can be added
+ * where the reference adds the remaining bytes one by one. */
+#define KMR_MIX64(a, b, c) { \
+	a -= b; a -= c; a ^= (c >> 43); b -= c; b -= a; b ^= (a << 9);  c -= a; c -= b; c ^= (b >> 8); \
+	a -= b; a -= c; a ^= (c >> 38); b -= c; b -= a; b ^= (a << 23); c -= a; c -= b; c ^= (b >> 5); \
+	a -= b; a -= c; a ^= (c >> 35); b -= c; b -= a; b ^= (a << 49); c -= a; c -= b; c ^= (b >> 11); \
+	a -= b; a -= c; a ^= (c >> 12); b -= c; b -= a; b ^= (a << 18); c -= a; c -= b; c ^= (b >> 22); }
+KMR_HD uint64_t kmr_bswap64(uint64_t x) {
+	x = ((x & 0x00ff00ff00ff00ffull) << 8) | ((x >> 8) & 0x00ff00ff00ff00ffull);
+	x = ((x & 0x0000ffff0000ffffull) << 16) | ((x >> 16) & 0x0000ffff0000ffffull);
+	return (x << 32) | (x >> 32);
+}
+template <int W> KMR_HD uint64_t key_hash8(const Key<W> &key, uint32_t kb) {
+	uint64_t a, b, c;
+	a = b = 0xDEADBEEFull;
+	c = 0x9e3779b97f4a7c13ull;
+	uint32_t len = kb; int m = 0;
+	if (W >= 3 && len >= 24) {      /* one full block of 24 bytes (kb <= 32) */
+		a += kmr_bswap64(key.w[0]); b += kmr_bswap64(key.w[1]); c += kmr_bswap64(key.w[2]);
+		KMR_MIX64(a, b, c);
+		len -= 24; m = 3;
+	}
+	c += kb;
+	/* the last 0..23 bytes: bytes 0-7 into a, 8-15 into b, 16-22 into c above its first byte (reserved for the length) */
+	if (len > 0) a += kmr_bswap64(key.w[m < W ? m : W - 1]);
+	if (len > 8) b += kmr_bswap64(key.w[m + 1 < W ? m + 1 : W - 1]);
+	if (len > 16) c += kmr_bswap64(key.w[m + 2 < W ? m + 2 : W - 1]) << 8;
+	KMR_MIX64(a, b, c);
+	return c;
+}
+
+/* kb: the key bytes in the low 16 bits, the hash kind (kmr_config.hash_kind) above them -- one argument, so that every kernel
+ * that already hands "kb" to the hash serves both kinds */
+template <int W> KMR_HD uint64_t key_hash(const Key<W> &key, uint32_t kbAndKind) {
+	const uint32_t kb = kbAndKind & 0xffffu;
+	if (kbAndKind >> 16) return key_hash8<W>(key, kb);
 	uint32_t a, b, c;
 	a = b = c = 0xdeadbeefu + kb + 0xDEADBEEFu;
 	int m = 0;

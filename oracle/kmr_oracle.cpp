@@ -206,6 +206,46 @@ static inline uint64_t getHash(const void *ptr, int length) {
 	return (uint64_t)pc | ((uint64_t)pb << 32);
 }
 
+/* lookup8 hash() (Bob Jenkins, lookup8.c, January 4 1997, public domain; the reference carries it as src/lookup8.h:90-160 and used
+ * it in getHash with level 0xDEADBEEF before lookup3, src/Kmer.h:210-212; nothing calls it today).  Restated from the published
+ * algorithm byte by byte; PARITY UNPINNED: src/lookup8.h cannot be compiled here (its <config.h> wants Boost) and no test or
+ * fixture of the reference holds a lookup8 value.  What is checked is the file's own claim hash2(words) == hash(bytes) on a
+ * little-endian machine and agreement of the device code with this restatement. */
+#define ORC_MIX64(a, b, c) { \
+	a -= b; a -= c; a ^= (c >> 43); b -= c; b -= a; b ^= (a << 9);  c -= a; c -= b; c ^= (b >> 8); \
+	a -= b; a -= c; a ^= (c >> 38); b -= c; b -= a; b ^= (a << 23); c -= a; c -= b; c ^= (b >> 5); \
+	a -= b; a -= c; a ^= (c >> 35); b -= c; b -= a; b ^= (a << 49); c -= a; c -= b; c ^= (b >> 11); \
+	a -= b; a -= c; a ^= (c >> 12); b -= c; b -= a; b ^= (a << 18); c -= a; c -= b; c ^= (b >> 22); }
+static uint64_t lookup8_hash(const uint8_t *k, uint64_t length, uint64_t level) {
+	uint64_t a, b, c, len = length;
+	a = b = level;
+	c = 0x9e3779b97f4a7c13ull;
+	auto le = [](const uint8_t *p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v += (uint64_t)p[i] << (8 * i); return v; };
+	while (len >= 24) { a += le(k); b += le(k + 8); c += le(k + 16); ORC_MIX64(a, b, c); k += 24; len -= 24; }
+	c += length;
+	for (uint64_t i = len; i > 16; i--) c += (uint64_t)k[i - 1] << (8 * (i - 16));      /* the first byte of c is reserved for the length */
+	for (uint64_t i = len < 16 ? len : 16; i > 8; i--) b += (uint64_t)k[i - 1] << (8 * (i - 9));
+	for (uint64_t i = len < 8 ? len : 8; i > 0; i--) a += (uint64_t)k[i - 1] << (8 * (i - 1));
+	ORC_MIX64(a, b, c);
+	return c;
+}
+/* hash2(): the same over whole 64-bit words (src/lookup8.h:170-201) */
+static uint64_t lookup8_hash2(const uint64_t *k, uint64_t length, uint64_t level) {
+	uint64_t a, b, c, len = length;
+	a = b = level;
+	c = 0x9e3779b97f4a7c13ull;
+	while (len >= 3) { a += k[0]; b += k[1]; c += k[2]; ORC_MIX64(a, b, c); k += 3; len -= 3; }
+	c += length << 3;
+	if (len == 2) b += k[1];
+	if (len >= 1) a += k[0];
+	ORC_MIX64(a, b, c);
+	return c;
+}
+/* kmr_config.hash_kind */
+static inline uint64_t hashOf(uint32_t kind, const void *ptr, int length) {
+	return kind == KMR_HASH_LOOKUP8 ? lookup8_hash((const uint8_t *)ptr, (uint64_t)length, 0xDEADBEEFull) : getHash(ptr, length);
+}
+
 /* ---------------------------------------------------------------- a8 --- */
 static const int DMP_HASH_SHIFT = 24;
 static const uint64_t DMP_HASH_MASK = 0x7ffff;
@@ -627,7 +667,7 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 		if (isDiscard(g, weight)) return;
 #pragma omp atomic
 		rawGoodKmers++;
-		uint64_t hash = getHash(least, kb);
+		uint64_t hash = hashOf(cfg.hash_kind, least, kb);
 		WV *w = weak.getIfExists(least, hash);
 		if (w) {
 			trackWeak(g, *w, weight, keepDirection);
@@ -666,7 +706,7 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 	/* sender-side filters of _buildKmerSpectrumMPI, DistributedFunctions.h:418-433,
 	 * and the part filter of append(KmerWeightedExtensions...), KmerSpectrum.h:1680 */
 	inline bool mine(const uint8_t *key, uint64_t &hash) {
-		hash = getHash(key, kb);
+		hash = hashOf(cfg.hash_kind, key, kb);
 		if (cfg.kmer_subsample > 1 && hash % cfg.kmer_subsample != 0) return false;
 		if (cfg.world_size > 1 && (uint32_t)getDistributedThreadId(hash, cfg.world_size) != cfg.rank) return false;
 		if (cfg.num_parts > 1 && (uint32_t)getDistributedThreadId(hash, cfg.num_parts) != cfg.part_idx) return false;
@@ -774,7 +814,7 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 	}
 	/* DataPointers::getCount(false), KmerSpectrum.h:642-695 */
 	uint32_t lookup(const uint8_t *key) {
-		uint64_t hash = getHash(key, kb);
+		uint64_t hash = hashOf(cfg.hash_kind, key, kb);
 		WV *w = weak.getIfExists(key, hash);
 		if (w) return w->count;
 		if (hasSingletons) { SV *s = singleton.getIfExists(key, hash); if (s) return s->_weight == 0 ? 0 : 1; }
@@ -938,6 +978,8 @@ void orc_quality_table(unsigned minQ, unsigned startChar, double *P) { initializ
 
 /* stateless pieces, for the known-answer tests */
 uint64_t orc_hash(const uint8_t *key, uint32_t len) { return getHash(key, (int)len); }
+uint64_t orc_hash8(const uint8_t *key, uint64_t len, uint64_t level) { return lookup8_hash(key, len, level); }
+uint64_t orc_hash8_words(const uint64_t *words, uint64_t n, uint64_t level) { return lookup8_hash2(words, n, level); }
 void orc_hashlittle2(const void *key, uint64_t len, uint32_t *pc, uint32_t *pb) { hashlittle2(key, (size_t)len, pc, pb); }
 int64_t orc_compress_sequence(const char *bases, uint64_t len, uint8_t *out, uint32_t *mpos, char *mchar, uint64_t mcap) {
 	initTables();
@@ -988,7 +1030,7 @@ int64_t orc_extract_records_by_owner(const kmr_config *cfg, const char *bases, c
 			const uint8_t *key = wk.keys.data() + (size_t)i * b.kb;
 			float w = wk.weights[i];
 			if (!((w < 0 ? -w : w) > cfg->min_weight)) continue;
-			uint64_t h = getHash(key, b.kb);
+			uint64_t h = hashOf(cfg->hash_kind, key, b.kb);
 			if (cfg->kmer_subsample > 1 && h % cfg->kmer_subsample != 0) continue;
 			uint32_t owner = (uint32_t)getDistributedThreadId(h, cfg->world_size);
 			if (seg_counts[owner] >= seg_capacity) return -1;

@@ -19,6 +19,7 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_lookup3.so")
 PRODUCT_SO = os.path.join(ROOT, "kmernator_amd", "csrc", "libkmernator_amd.so")
 
 KMR_VALUE_COUNT_DIR, KMR_VALUE_EXT = 0, 1
+KMR_HASH_LOOKUP3, KMR_HASH_LOOKUP8 = 0, 1
 KMR_MAP_WEAK, KMR_MAP_SINGLETON, KMR_MAP_SOLID = 0, 1, 2
 
 
@@ -37,6 +38,7 @@ class KmrConfig(C.Structure):
         ("kmers_per_bucket", C.c_uint32), ("num_parts", C.c_uint32),
         ("part_idx", C.c_uint32), ("build_mode", C.c_uint32),
         ("max_table_entries", C.c_uint64),
+        ("hash_kind", C.c_uint32), ("size_tracker", C.c_uint32),
     ]
 
 
@@ -121,6 +123,10 @@ def oracle_lib():
         lib.orc_hash.restype = C.c_uint64
         lib.orc_hash.argtypes = [C.c_char_p, C.c_uint32]
         lib.orc_hashlittle2.argtypes = [C.c_char_p, C.c_uint64, u32p, u32p]
+        lib.orc_hash8.restype = C.c_uint64
+        lib.orc_hash8.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
+        lib.orc_hash8_words.restype = C.c_uint64
+        lib.orc_hash8_words.argtypes = [u64p, C.c_uint64, C.c_uint64]
         lib.orc_compress_sequence.restype = C.c_int64
         lib.orc_compress_sequence.argtypes = [C.c_char_p, C.c_uint64, u8p, u32p, C.c_char_p, C.c_uint64]
         lib.orc_reverse_complement.argtypes = [u8p, u8p, C.c_uint32]
