@@ -252,7 +252,7 @@ int kmr_dump_mergraph(kmr_handle *h, const char *path, uint32_t min_depth);
 /* KmerHasher::getHash (src/Kmer.h:207-230) = Lookup3::hashlittle2
  * (src/lookup3.h:470-641) with pc=0xDEADBEEF, pb=0, result c | b<<32. */
 uint64_t kmr_hash(const uint8_t *key, uint32_t len);
-uint64_t kmr_hash_of_kind(const uint8_t *key, uint32_t len, uint32_t hash_kind);      /* the same for either kmr_hash_kind (len <= 32) */
+uint64_t kmr_hash_of_kind(const uint8_t *key, uint32_t len, uint32_t hash_kind);      /* the same for either hash kind, len <= 32 */
 /* BucketExposedMapLogic::getBucketIdx / getLocalThreadId / getDistributedThreadId
  * (src/Kmer.h:2329-2333, 2269-2280, 2284-2295). */
 uint64_t kmr_bucket_idx(uint64_t hash, uint64_t num_buckets_pow2);
@@ -317,6 +317,18 @@ int kmr_sk_exchange_begin(kmr_handle *h);      /* before the first reads of the 
 int kmr_sk_exchange_counts(kmr_handle *h, uint64_t *chunks, uint64_t *granules);
 int kmr_sk_exchange_pack_dev(kmr_handle *h, void *dev_data, void *dev_meta, const uint64_t *granule_offset, const uint64_t *chunk_offset);
 int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *dev_meta, uint64_t n_chunks, uint64_t n_granules);
+
+/* KmerSpectrum::SizeTracker (src/KmerSpectrum.h:812-900): the history of (rawKmers, rawGoodKmers, uniqueKmers, singletonKmers) the
+ * apps write as --size-history-file (apps/FilterReads.cpp:141-147) and EstimateSize fits.  The reference calls track() before every
+ * k-mer it appends (trackSpectrum, :1574-1581: thread 0 only, so its parallel builds record an arbitrary subset); here the same
+ * rule -- an element whenever rawKmers has reached nextToTrack (128, then x 1.05 truncated to long) -- is applied after every READ,
+ * in input order: element i holds the four counters as they stand after the first read that brings rawKmers to the i-th threshold
+ * (counters of a serial build of exactly the reads up to there; what differs from the reference's serial history is only where
+ * inside a read the sample is taken).  Needs kmr_config.size_tracker = 1 (kept by the super-k-mer build of a single partition;
+ * kmr_create refuses other combinations) and a finalized handle.  elements: [capacity][4] u64, may be NULL to ask for the count;
+ * force_last = 1 appends the element trackSpectrum(true) adds after the build.  With kmer_subsample > 1 the stored values are
+ * scaled as track() does (:882-887). */
+int kmr_size_tracker(kmr_handle *h, int force_last, uint64_t *elements, uint64_t capacity, uint64_t *n_elements);
 
 /* The whole exchange inside the library, RCCL called directly (librccl is dlopen'ed on first use: no link-time dependency): what a
  * C / C++ host -- one process or thread per GPU of a node, no MPI, no Python -- calls instead of

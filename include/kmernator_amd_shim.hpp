@@ -185,6 +185,9 @@ protected:
 		c.kmer_subsample = (uint32_t)KS::getKmerSubsample();                    /* src/KmerSpectrum.h:461 */
 		c.device = _device;
 		c.rank = (uint32_t)_rank; c.world_size = (uint32_t)_worldSize;
+		/* the size history (--size-history-file, apps/FilterReads.cpp:141-147) is kept where the library keeps it: kmr_size_tracker */
+		c.size_tracker = (_valueKind == KMR_VALUE_COUNT_DIR && _worldSize == 1 && c.k >= 16) ? 1 : 0;
+		_sizeTracking = c.size_tracker != 0;
 		return c;
 	}
 	/* the device handle is made by the first build (or by whoever asks for it first) and shared by copies of this object */
@@ -223,6 +226,17 @@ protected:
 		/* private in the reference (src/KmerSpectrum.h:404-409): the patch at the top of this file makes them protected */
 		this->rawKmers = (long)st.raw_kmers; this->rawGoodKmers = (long)st.raw_good_kmers;
 		this->uniqueKmers = (long)st.unique_kmers; this->singletonKmers = (long)st.singleton_kmers;
+		if (_sizeTracking) {      /* KmerSpectrum::sizeTracker as the build would have left it (the app's trackSpectrum(true) adds the last element) */
+			uint64_t ne = 0;
+			check(kmr_size_tracker(h, 0, NULL, 0, &ne), "kmr_size_tracker");
+			std::vector<uint64_t> el(4 * ne + 4);
+			if (ne) check(kmr_size_tracker(h, 0, &el[0], ne, &ne), "kmr_size_tracker");
+			typename KS::SizeTracker tracker;
+			tracker.elements.clear();
+			for (uint64_t i = 0; i < ne; i++)
+				tracker.elements.push_back(typename KS::SizeTracker::SizeTrackerElement((long)el[4 * i], (long)el[4 * i + 1], (long)el[4 * i + 2], (long)el[4 * i + 3]));
+			this->setSizeTracker(tracker);
+		}
 	}
 
 	void check(int rc, const char *what) {
@@ -233,6 +247,7 @@ protected:
 	unsigned long _estimatedRawKmers;
 	bool _separateSingletons;
 	int _valueKind, _device, _rank, _worldSize;
+	bool _sizeTracking;
 };
 
 #ifdef KMERNATOR_AMD_SHIM_MPI

@@ -94,6 +94,8 @@ struct kmr_handle {
 	/* streaming (partition) build path */
 	bool partition_mode = false;
 	bool superkmer_mode = false;       /* build_mode 3: super-k-mer lists (kmr_superkmer.hpp); implies partition_mode */
+	/* size tracker (kmr_config.size_tracker): one record per read fed so far, and the elements made of them at kmr_finalize */
+	SkTrackRec *trk = nullptr; uint64_t trk_cap = 0, trk_n = 0; std::vector<uint64_t> trk_elems;
 	bool sender_launch = false;        /* extract_by_owner_t, build (not request) mode: dev_params tells the kernel to count what it does not send */
 	bool sk_exchange = false;          /* kmr_sk_exchange_begin: the lists are the whole job's, every owner's k-mers are kept until the exchange */
 	bool auto_mode = false;            /* build_mode 0: a handle that is fed k-mer records (the owner exchange) before any reads falls back to mode 2 */
@@ -1282,7 +1284,7 @@ uint32_t sk_dbg_flags(const char *name) {
 	(void)name; return 0u;
 #endif
 }
-SkParams sk_params(kmr_handle *h) { SkParams sp; sp.dbg = sk_dbg_flags("KMR_SK_EXTRACT_DBG"); sp.keep_all_owners = h->sk_exchange ? 1u : 0u; sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; return sp; }
+SkParams sk_params(kmr_handle *h) { SkParams sp; sp.dbg = sk_dbg_flags("KMR_SK_EXTRACT_DBG"); sp.keep_all_owners = h->sk_exchange ? 1u : 0u; sp.track = nullptr; sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; return sp; }
 template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
 	const uint64_t n = rvAll.n_reads;
 	if (!h->sk_state) {
@@ -1299,6 +1301,17 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
 	const uint64_t sub_bases = h->tune.sub_batch_bases ? h->tune.sub_batch_bases : (1ull << 31);
 	const uint64_t chunk = std::max<uint64_t>(64, (sub_bases / avg) & ~63ull);
+	if (h->cfg.size_tracker && n) {
+		if (h->trk_n + n > h->trk_cap) {
+			const uint64_t cap = std::max<uint64_t>(h->trk_n + n, h->trk_cap * 2);
+			SkTrackRec *bigger = nullptr;
+			HIPCHK(h, hipMalloc((void **)&bigger, cap * sizeof(SkTrackRec)));
+			if (h->trk_n) HIPCHK(h, hipMemcpyAsync(bigger, h->trk, h->trk_n * sizeof(SkTrackRec), hipMemcpyDeviceToDevice, h->stream));
+			if (h->trk) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->trk); }
+			h->trk = bigger; h->trk_cap = cap;
+		}
+		HIPCHK(h, hipMemsetAsync(h->trk + h->trk_n, 0, n * sizeof(SkTrackRec), h->stream));
+	}
 	const DevParams dp = dev_params(h);
 	/* world_size > 1: without the exchange a rank keeps the k-mers the reference's owner function gives it (getDistributedThreadId,
 	 * as the other build modes do); inside an exchange (kmr_sk_exchange_begin) every k-mer is kept, the lists decide the owner */
@@ -1315,13 +1328,15 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		const uint64_t bases = m * avg + avg;
 		rc = pool_reserve(h, h->l1, bases / SK_CHUNK_G + (h->l1.base ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * 2 * SK_WAVES * 130 + 64, true); if (rc) return rc;
 		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b); time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
-		const SkParams sp = sk_params(h);
+		SkParams sp = sk_params(h);
+		if (h->cfg.size_tracker) sp.track = h->trk + h->trk_n + r;
 #define SKX(WINv) (filt ? launch_sk_extract<W, WINv, true>(h, rv, sp) : launch_sk_extract<W, WINv, false>(h, rv, sp))
 		rc = h->sk_win == 16 ? SKX(16) : (h->sk_win == 8 ? SKX(8) : SKX(4));
 #undef SKX
 		time_end(h, KMR_TIME_EXTRACT, a2, b2); time_end(h, KMR_TIME_BUILD, a, b);
 		if (rc) return rc;
 	}
+	if (h->cfg.size_tracker) h->trk_n += n;
 	return 0;
 }
 int add_reads_superkmer(kmr_handle *h, const ReadsView &rv, uint64_t total_bases) {
@@ -1360,6 +1375,28 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	rc = arena_get(h, &wc, h->nb_weak); if (rc) return rc; rc = arena_get(h, &sc, h->nb_sing); if (rc) return rc;
 	rc = arena_get(h, &fc, 1); if (rc) return rc; rc = arena_get(h, &cursors, 2); if (rc) return rc;
 	FinalizeCounters c; unsigned long long cur[2];
+	/* size tracker: SizeTracker::track (src/KmerSpectrum.h:879-894) applied after every read, in stream order; what it pushes is known
+	 * from the per-read records alone except the unique / singleton counters, which the count pass fills in per boundary */
+	std::vector<unsigned long long> bounds; std::vector<uint64_t> snap_raw, snap_good;
+	SkTrackView tv; tv.bounds = nullptr; tv.n = 0; tv.d_unique = tv.d_single = nullptr;
+	const bool tracking = h->cfg.size_tracker != 0;
+	if (tracking) {
+		std::vector<SkTrackRec> recs(h->trk_n);
+		if (h->trk_n) HIPCHK(h, hipMemcpy(recs.data(), h->trk, h->trk_n * sizeof(SkTrackRec), hipMemcpyDeviceToHost));
+		long nextToTrack = 128; uint64_t raw = 0, good = 0; unsigned long long endmax = 0;
+		for (const SkTrackRec &r : recs) {
+			raw += r.raw; good += r.good; endmax = std::max(endmax, r.end_ordinal);
+			if ((long)raw < nextToTrack) continue;
+			bounds.push_back(endmax); snap_raw.push_back(raw); snap_good.push_back(good);
+			nextToTrack = (long)((double)nextToTrack * 1.05);
+		}
+		if (bounds.size() > SK_TRACK_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "size tracker: more than 512 elements");
+		unsigned long long *db = nullptr; unsigned int *dd = nullptr;
+		rc = arena_get(h, &db, bounds.size() + 1); if (rc) return rc;
+		rc = arena_get(h, &dd, 2 * (bounds.size() + 1)); if (rc) return rc;
+		if (!bounds.empty()) HIPCHK(h, hipMemcpyAsync(db, bounds.data(), 8 * bounds.size(), hipMemcpyHostToDevice, h->stream));
+		tv.bounds = db; tv.n = (uint32_t)bounds.size(); tv.d_unique = dd; tv.d_single = dd + bounds.size() + 1;
+	}
 	hipEvent_t tca, tcb; time_begin(h, KMR_TIME_COUNT, &tca, &tcb);
 	for (int attempt = 0; ; attempt++) {
 		if (!h->uw_keys || h->uw_cap < wcap) {
@@ -1377,11 +1414,12 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (nl + SK_LBATCH - 1) / SK_LBATCH);
-		auto kern = sk_count_kernel<W, COUNT_LOG2S>;
-		const size_t smem = sk_count_smem_bytes<W, COUNT_LOG2S>();
+		auto kern = tracking ? sk_count_kernel<W, COUNT_LOG2S, true> : sk_count_kernel<W, COUNT_LOG2S, false>;
+		const size_t smem = tracking ? sk_count_smem_bytes<W, COUNT_LOG2S, true>() : sk_count_smem_bytes<W, COUNT_LOG2S, false>();
+		if (tracking) HIPCHK(h, hipMemsetAsync(tv.d_unique, 0, 8 * (tv.n + 1), h->stream));
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 		if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, COUNT_THREADS, smem); fprintf(stderr, "sk_count<W=%d>: %d blocks per CU (LDS %zu), %llu lists, %u chunks\n", W, nb, smem, (unsigned long long)nl, nch); }
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"));
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv);
 		HIPCHK(h, hipGetLastError());
 		uint32_t cerr = 0;
 		HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(cur, cursors, 16, hipMemcpyDeviceToHost, h->stream));
@@ -1397,6 +1435,18 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	time_end(h, KMR_TIME_COUNT, tca, tcb);
 	h->stats.unique_kmers = c.unique;
 	h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
+	if (tracking) {
+		std::vector<unsigned int> dd(2 * (tv.n + 1), 0);
+		HIPCHK(h, hipMemcpy(dd.data(), tv.d_unique, 8 * (tv.n + 1), hipMemcpyDeviceToHost));
+		h->trk_elems.clear();
+		uint64_t uniq = 0; int64_t single = 0;
+		const uint64_t sub = h->cfg.kmer_subsample > 1 ? h->cfg.kmer_subsample : 1;      /* track() scales what it stores, :882-887 */
+		for (uint32_t i = 0; i < tv.n; i++) {
+			uniq += dd[i]; single += (int32_t)dd[tv.n + 1 + i];
+			h->trk_elems.push_back(snap_raw[i] * sub); h->trk_elems.push_back(snap_good[i] * sub);
+			h->trk_elems.push_back(uniq * sub); h->trk_elems.push_back(f.has_singletons ? (uint64_t)single * sub : 0);
+		}
+	}
 	hipEvent_t tma, tmb; time_begin(h, KMR_TIME_BUCKETS, &tma, &tmb);
 	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing);
 	time_end(h, KMR_TIME_BUCKETS, tma, tmb);
@@ -1509,6 +1559,7 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 			if (hipMalloc((void **)&h->dPk, sizeof(Pk)) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
 			hipMemcpy(h->dPk, Pk, sizeof(Pk), hipMemcpyHostToDevice);
 		}
+		if (cfg->size_tracker && (!h->superkmer_mode || cfg->world_size > 1)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "size_tracker: kept by the super-k-mer build (build_mode 0 / 3, direction-counting values, k >= 13) of a single partition"); break; }
 		if (!h->partition_mode) {
 			rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
 			if (rc) { g_create_error = h->err; break; }
@@ -1533,6 +1584,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->score_buf) hipFree(h->score_buf);
 	if (h->lut) hipFree(h->lut);
 	if (h->xo_dev) hipFree(h->xo_dev);
+	if (h->trk) hipFree(h->trk);
 	exchange_free(h);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
@@ -1573,6 +1625,7 @@ int kmr_reset(kmr_handle *h) {
 	HIPCHK(h, hipMemsetAsync(h->derr, 0, 4, h->stream));
 	memset(&h->stats, 0, sizeof(h->stats));
 	h->occupied = h->pending_kmers = 0; h->stream_base = 0; h->reads = 0; h->subtracted = 0; h->xc_job_bases = 0; h->xc_bytes_to_peers = 0;
+	h->trk_n = 0; h->trk_elems.clear();
 	h->finalized = false; h->map_gen++; h->has_singletons = h->cfg.separate_singletons != 0;
 	return KMR_OK;
 }
@@ -2712,6 +2765,24 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
 	hipStreamSynchronize(h->stream);
 	hipFree(cnt); hipFree(start);
 	return rc ? rc : sync_state(h);
+}
+
+/* ---- f3: KmerSpectrum::SizeTracker (src/KmerSpectrum.h:812-900) */
+int kmr_size_tracker(kmr_handle *h, int force_last, uint64_t *elements, uint64_t capacity, uint64_t *n_elements) {
+	if (!h || !n_elements) return KMR_ERR_INVALID_ARG;
+	if (!h->cfg.size_tracker) return fail(h, KMR_ERR_STATE, "kmr_size_tracker: kmr_config.size_tracker was not set");
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_size_tracker before kmr_finalize");
+	const uint64_t n = h->trk_elems.size() / 4 + (force_last ? 1 : 0);
+	*n_elements = n;
+	if (!elements) return KMR_OK;
+	if (capacity < n) return fail(h, KMR_ERR_CAPACITY, "kmr_size_tracker: element buffer too small");
+	if (!h->trk_elems.empty()) memcpy(elements, h->trk_elems.data(), 8 * h->trk_elems.size());
+	if (force_last) {      /* trackSpectrum(true), as the apps call it after the build (apps/FilterReads.cpp:141) */
+		const uint64_t sub = h->cfg.kmer_subsample > 1 ? h->cfg.kmer_subsample : 1;
+		uint64_t *e = elements + h->trk_elems.size();
+		e[0] = h->stats.raw_kmers * sub; e[1] = h->stats.raw_good_kmers * sub; e[2] = h->stats.unique_kmers * sub; e[3] = h->stats.singleton_kmers * sub;
+	}
+	return KMR_OK;
 }
 
 #include "kmr_exchange_rccl.hpp"

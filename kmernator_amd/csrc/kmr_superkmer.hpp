@@ -48,6 +48,15 @@ static const int SK_RR = 4;                   /* records a lane books per gather
 #else
 #define SK_DBG(flags, bit) false
 #endif
+/* KmerSpectrum::SizeTracker (src/KmerSpectrum.h:812-900).  The reference calls track() before every k-mer it appends; here the
+ * same rule is applied at READ boundaries: after a read, if the raw k-mers so far reach nextToTrack, the spectrum's four counters
+ * as they stand after that read become an element.  Extraction leaves per read what the rule needs (its raw and good k-mers and
+ * the stream ordinal its bases end at); the count pass, which keeps the two smallest stream ordinals of every key, then says for
+ * every boundary how many keys had been seen (first < boundary) and how many exactly once (first < boundary <= second). */
+struct SkTrackRec { uint32_t raw, good; unsigned long long end_ordinal; };
+static const uint32_t SK_TRACK_MAX = 512;       /* boundaries: 128 * 1.05^n reaches 10^12 k-mers at n = 467 */
+struct SkTrackView { const unsigned long long *bounds; uint32_t n; unsigned int *d_unique, *d_single; };      /* d_*: [n + 1] difference arrays */
+
 struct SkParams {
 	uint32_t dbg;          /* measurement switches of a -DKMR_DEBUG_HOOKS build (they void the result): extract 1 = no list appends, 2 = no gather; count 1 = no table, 2 = no emit, 4 = no insert loop */
 	uint32_t m;            /* minimizer length in bases, <= 16                                        */
@@ -55,6 +64,7 @@ struct SkParams {
 	uint32_t list_bits;    /* lists = 2^list_bits                                                     */
 	uint32_t keep_all_owners;      /* world_size > 1: 1 inside an owner exchange (the list decides the owner), 0 = keep what getDistributedThreadId gives this rank */
 	unsigned long long *state;     /* per list: open chunk << 32 | granules used (SK_CHUNK_G and NO_CHUNK: none) */
+	struct SkTrackRec *track;      /* size tracker (kmr_config.size_tracker): one record per read of this launch, or null */
 	const double *Pk;      /* 256 entries: P[c] multiplied k times in sequence, the weight of a window of k equal qualities */
 };
 
@@ -583,6 +593,11 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 		__builtin_amdgcn_wave_barrier();   /* all lanes are done reading the tile before it is overwritten */
 	}
 	nRaw += tRaw; nGood += tGood;
+	if (sp.track && have && !myDiscard) {      /* the lane's read (or its unit of a long read: the units of a read add up) */
+		SkTrackRec *tr = sp.track + myRead;
+		if (rv.u_start) { atomicAdd(&tr->raw, tRaw); atomicAdd(&tr->good, tGood); atomicMax(&tr->end_ordinal, (unsigned long long)(rv.stream_base + myEnd)); }
+		else { tr->raw = tRaw; tr->good = tGood; tr->end_ordinal = rv.stream_base + myEnd; }
+	}
 	}
 	/* chunks of the slabs nobody took belong to no list */
 	__builtin_amdgcn_wave_barrier();
@@ -632,13 +647,13 @@ static const int SK_STAGE_G = SK_STAGE_CHUNKS * SK_CHUNK_G;    /* 256 granules =
 static const uint32_t SK_LBATCH = 24;
 static const uint32_t SK_DESC_CAP = 160;                       /* chunk descriptors of a batch of lists kept in LDS */
 
-template <int W, int LOG2S>
-__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + 2) + (size_t)SK_STAGE_G * 16 + 256 + 64; }
+template <int W, int LOG2S, bool TRACK = false>
+__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + 2 + (TRACK ? 8 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
 
-template <int W, int LOG2S>
-__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10) ? 4 : 1)
+template <int W, int LOG2S, bool TRACK = false>
+__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10 && !TRACK) ? 4 : 1)
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
-                     CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags) {
+                     CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv) {
 	constexpr int S = 1 << LOG2S;
 	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
 	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
@@ -650,6 +665,9 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	uint4 *stage = (uint4 *)(tstate + (W > 1 ? S : 0));                /* 16-byte aligned: every table array is a multiple of 16 bytes */
 	uint16_t *s_kept = (uint16_t *)(stage + SK_STAGE_G);               /* [S] table slots of the entries to write out */
 	uint8_t *recOf = (uint8_t *)(s_kept + S);                          /* [4][64] per wavefront: header lane of the record a lane's first k-mer lies in */
+	/* size tracker: the second-smallest first-sighting word of every slot, and this block's share of the two difference arrays */
+	unsigned long long *tsecond = (unsigned long long *)(csm + (size_t)S * (8 * W + 24 + (W > 1 ? 4 : 0) + 2) + (size_t)SK_STAGE_G * 16 + 256 + 64);
+	unsigned int *trkU = (unsigned int *)(tsecond + (TRACK ? S : 0)), *trkS = trkU + (SK_TRACK_MAX + 1);
 	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns, s_n2;
 	__shared__ unsigned long long s_wbase, s_sbase;
 	__shared__ unsigned long long s_wpos, s_wend, s_spos, s_send;
@@ -659,6 +677,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	__shared__ uint32_t s_dchunk[SK_DESC_CAP];
 	__shared__ uint8_t s_dcount[SK_DESC_CAP];
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	if (TRACK) for (int i = t; i < 2 * (int)(SK_TRACK_MAX + 1); i += COUNT_THREADS) trkU[i] = 0;
 	const uint32_t vw = 3;
 	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;
 	constexpr unsigned long long OSLAB = 8192;
@@ -670,7 +689,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	const uint32_t singC = f.has_singletons ? (f.min_depth > 1 ? 0u : 2u) : 3u;
 	const uint32_t weakMin = ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1) ? f.min_depth : 0u;
 	const uint32_t keepFrom = singC == 0u ? (weakMin > 2u ? weakMin : 2u) : weakMin;
-	const bool fastEmit = singC != 2u && keepFrom >= 2u;
+	const bool fastEmit = !TRACK && singC != 2u && keepFrom >= 2u;      /* (the size tracker looks at every slot) */
 	const uint4 *poolg = (const uint4 *)pool.base;
 	uint4 pre = make_uint4(0, 0, 0, 0); uint32_t preCount = 0; uint64_t preList = ~0ull;      /* this wavefront's first chunk of the list named */
 
@@ -706,7 +725,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				const uint32_t bits = s_stackBits[s_sp - 1], val = s_stackVal[s_sp - 1];
 				lds_barrier();
 				if (t == 0) { s_sp--; s_claimed = 0; s_overflow = 0; s_nw = 0; s_ns = 0; s_n2 = 0; }
-				for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; }
+				for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
 				lds_barrier();
 				const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
 				/* insert: wavefront w takes chunks c0 + w, c0 + w + 4, ... of the list, each one on its own: it stages the chunk in its
@@ -866,7 +885,11 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 									/* the first-sighting word only ever goes down: an occurrence that does not undercut the value read together
 									 * with the key (cfirst; 0 = not read) cannot be the first one and skips the 64-bit LDS atomic */
 									const unsigned long long fp = first_pack(cord, cfwd, wa);
-									if (W > 1 || cfirst == 0 || fp < cfirst) atomicMin(&tfirst[s], fp);
+									if (TRACK) {      /* the two smallest: whichever of (old first, this one) is larger is a candidate for second */
+										const unsigned long long was = atomicMin(&tfirst[s], fp);
+										const unsigned long long cand = was > fp ? was : fp;
+										if (cand != NO_FIRST) atomicMin(&tsecond[s], cand);
+									} else if (W > 1 || cfirst == 0 || fp < cfirst) atomicMin(&tfirst[s], fp);
 								}
 							}
 						}
@@ -916,6 +939,20 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					uniq += used ? 1u : 0u;
 					single += (used && count == 1) ? 1u : 0u;
 					cls[i] = !used ? 0u : ((count == 1 && singC != 3u) ? singC : (count < weakMin ? 0u : 1u));
+					if (TRACK && used) {
+						/* the key counts as seen from the first boundary behind its first sighting on, and as a singleton until the
+						 * first boundary behind its second one: index = number of boundaries <= the ordinal */
+						auto behind = [&](unsigned long long ord) -> uint32_t {
+							uint32_t lo = 0, hi = tv.n;
+							while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (tv.bounds[mid] <= ord) lo = mid + 1; else hi = mid; }
+							return lo;
+						};
+						const uint32_t iu = behind(tfirst[s] >> 24);
+						atomicAdd(&trkU[iu], 1u);
+						atomicAdd(&trkS[iu], 1u);
+						const unsigned long long sec = tsecond[s];
+						if (sec != NO_FIRST) atomicAdd(&trkS[behind(sec >> 24)], 0xffffffffu);      /* -1 */
+					}
 				}
 				const unsigned long long below = (1ull << lane) - 1;
 #pragma unroll
@@ -1003,6 +1040,10 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	uniq = wave_sum(uniq); single = wave_sum(single);
 	if (lane == 0) { if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single); }
 	if (t == 0) { if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS); }
+	if (TRACK) {
+		lds_barrier();
+		for (uint32_t i = (uint32_t)t; i <= tv.n && i <= SK_TRACK_MAX; i += COUNT_THREADS) { if (trkU[i]) atomicAdd(&tv.d_unique[i], trkU[i]); if (trkS[i]) atomicAdd(&tv.d_single[i], trkS[i]); }
+	}
 }
 
 /* ------------------------------------------------------------------ owner exchange of super-k-mer lists */

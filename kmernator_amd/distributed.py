@@ -8,6 +8,7 @@ and one all-to-all per chunk moves each record to its owner (MPI_Alltoallv of
 src/MPIBuffer.h:588-600; the 'int dataSize' prefix becomes the counts all-to-all).
 Termination is implicit: every rank runs the same number of chunks.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -395,3 +396,26 @@ def reduce_histogram(spectrum, zoom_max=255, log_base=2.0, group=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         out.append(t.cpu().numpy())
     return Histogram(zoom_max, log_base, out[0].astype("uint64"), out[1].astype("uint64"), out[2])
+
+
+def reduce_size_tracker(tracker, group=None):
+    """DistributedKmerSpectrum::reduceSizeTracker (src/DistributedFunctions.h:460-491): the ranks' size histories summed element by
+    element; a rank with fewer elements than the longest repeats its last one.  `tracker`: this rank's kmernator_amd.spectrum
+    SizeTracker (a rank's own history comes from a single-partition handle: kmr_create refuses size_tracker with world_size > 1).
+    Every rank gets the same SizeTracker."""
+    from .spectrum import SizeTracker
+    nccl = dist.get_backend(group) == "nccl"
+    el = torch.from_numpy(np.ascontiguousarray(tracker.elements, dtype=np.uint64).astype(np.int64))
+    n = torch.tensor([el.shape[0]], dtype=torch.int64)
+    if nccl:
+        n = n.cuda()
+    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+    ct = int(n.item())
+    padded = torch.zeros((ct, 4), dtype=torch.int64)
+    if el.shape[0]:
+        padded[:el.shape[0]] = el
+        padded[el.shape[0]:] = el[-1]
+    if nccl:
+        padded = padded.cuda()
+    dist.all_reduce(padded, op=dist.ReduceOp.SUM, group=group)
+    return SizeTracker(padded.cpu().numpy().astype(np.uint64))

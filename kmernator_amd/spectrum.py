@@ -19,6 +19,20 @@ class KmerSpectrumError(RuntimeError):
     pass
 
 
+class SizeTracker:
+    """KmerSpectrum::SizeTracker (src/KmerSpectrum.h:812-900): elements[i] = (rawKmers, rawGoodKmers, uniqueKmers, singletonKmers)"""
+
+    def __init__(self, elements):
+        self.elements = np.asarray(elements, dtype=np.uint64).reshape(-1, 4)
+
+    def getLastElement(self):
+        return tuple(int(v) for v in self.elements[-1]) if len(self.elements) else (0, 0, 0, 0)
+
+    def toString(self):
+        """SizeTracker::toString (:873-878): the header, then one tab-separated line per element"""
+        return "rawKmers\trawGoodKmers\tuniqueKmers\tsingletonKmers\n" + "".join("%d\t%d\t%d\t%d\n" % tuple(int(v) for v in e) for e in self.elements)
+
+
 def _u8(a):
     return np.ascontiguousarray(a, dtype=np.uint8)
 
@@ -322,6 +336,16 @@ class KmerSpectrum:
         self._call("histogram", self.h, zoom_max, log_base, visits.ctypes.data_as(C.POINTER(C.c_uint64)),
                    vcount.ctypes.data_as(C.POINTER(C.c_uint64)), vweight.ctypes.data_as(C.POINTER(C.c_double)), nb)
         return Histogram(zoom_max, log_base, visits, vcount, vweight)
+
+    def getSizeTracker(self, force_last=True):
+        """KmerSpectrum::getSizeTracker (src/KmerSpectrum.h:902-904) after trackSpectrum(force_last): the size history, sampled at
+        read boundaries (kmr_size_tracker; needs kmr_config.size_tracker = 1)"""
+        n = C.c_uint64()
+        self._call("size_tracker", self.h, 1 if force_last else 0, None, 0, C.byref(n))
+        el = np.zeros((n.value, 4), dtype=np.uint64)
+        if n.value:
+            self._call("size_tracker", self.h, 1 if force_last else 0, el.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n))
+        return SizeTracker(el)
 
     # -- export / restore in the reference's mmap format
     def image(self, which=KMR_MAP_WEAK):

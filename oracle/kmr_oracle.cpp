@@ -621,8 +621,25 @@ struct KmerBuilder {
 	}
 };
 
+/* KmerSpectrum::SizeTracker, src/KmerSpectrum.h:812-900 */
+struct SizeTracker {
+	long nextToTrack;
+	std::vector<long> elements;      /* 4 per element: rawKmers, rawGoodKmers, uniqueKmers, singletonKmers */
+	unsigned int subsample = 1;
+	SizeTracker() { reset(); }
+	void track(long raw, long rawGood, long unique, long single, bool force = false) {      /* :879-894 */
+		if (raw < nextToTrack && !force) return;
+		if (subsample > 1) { raw *= subsample; rawGood *= subsample; unique *= subsample; single *= subsample; }
+		elements.push_back(raw); elements.push_back(rawGood); elements.push_back(unique); elements.push_back(single);
+		if (raw >= nextToTrack) nextToTrack *= 1.05;
+	}
+	void reset() { nextToTrack = 128; elements.clear(); track(0, 0, 0, 0); }      /* :895-899 */
+};
+
 /* ------------------------------------------------- spectrum (a10,a11) --- */
 struct SpectrumBase {
+	SizeTracker perKmer;      /* as the reference: track() at the top of every append() (trackSpectrum, :1574-1581; serial build) */
+	SizeTracker perRead;      /* the same rule applied after every read: what the product's read-boundary history is held to */
 	kmr_config cfg;
 	uint32_t k, kb;
 	Globals g;
@@ -655,6 +672,10 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 
 	/* KmerSpectrum::append, KmerSpectrum.h:1578-1668 (isSolid = false, no subtractingReference) */
 	inline void append(const uint8_t *least, float weight, const Extension &left, const Extension &right) {
+#ifdef _OPENMP
+		if (omp_get_thread_num() == 0)
+#endif
+			perKmer.track(rawKmers, rawGoodKmers, uniqueKmers, singletonKmers);      /* :1579-1580 */
 		if (subtractingReference && subtractingReference->lookup(least) > 0) {      /* :1582-1588 */
 #pragma omp atomic
 			subtracted++;
@@ -734,6 +755,7 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 					uint64_t h; if (!mine(key, h)) continue;
 					append(key, wk.weights[i], wk.exts[i].getLeft(), wk.exts[i].getRight());
 				}
+				perRead.track(rawKmers, rawGoodKmers, uniqueKmers, singletonKmers);
 			}
 			return;
 		}
@@ -944,6 +966,7 @@ orc_handle *orc_create(const kmr_config *cfg) {
 	s->g.minimumWeight = cfg->min_weight; s->g.extMinQuality = (uint8_t)cfg->ext_min_quality; s->g.discarded = 0;
 	s->hasSingletons = cfg->separate_singletons != 0; s->finalized = false;
 	s->rawKmers = s->rawGoodKmers = s->uniqueKmers = s->singletonKmers = 0; s->reads = 0;
+	s->perKmer.subsample = s->perRead.subsample = cfg->kmer_subsample;
 	initializeQualityToProbability(s->P, (unsigned char)cfg->min_quality_score, cfg->fastq_start_char);
 	orc_handle *h = new orc_handle; h->s = s; return h;
 }
@@ -953,6 +976,16 @@ int orc_add_reads(orc_handle *h, const char *bases, const char *quals, const uin
 	h->s->addReads(bases, quals, offsets, n, firstIdx, disc, threads); return 0;
 }
 int orc_finalize(orc_handle *h, uint32_t minDepth) { h->s->finalize(minDepth); return 0; }
+/* the size history: per_read = 0 the reference's own (track() before every k-mer, serial build), 1 = after every read; force_last as
+ * trackSpectrum(true) (apps/FilterReads.cpp:141).  Returns the number of elements; writes at most cap of them, 4 values each */
+uint64_t orc_size_tracker(orc_handle *h, int per_read, int force_last, uint64_t *elements, uint64_t cap) {
+	SpectrumBase *s = h->s;
+	SizeTracker t = per_read ? s->perRead : s->perKmer;
+	if (force_last) t.track(s->rawKmers, s->rawGoodKmers, s->uniqueKmers, s->singletonKmers, true);
+	const uint64_t n = t.elements.size() / 4;
+	for (uint64_t i = 0; i < n && i < cap; i++) for (int j = 0; j < 4; j++) elements[4 * i + j] = (uint64_t)t.elements[4 * i + j];
+	return n;
+}
 int orc_get_stats(orc_handle *h, kmr_stats *o) {
 	SpectrumBase *s = h->s;
 	o->raw_kmers = s->rawKmers; o->raw_good_kmers = s->rawGoodKmers; o->unique_kmers = s->uniqueKmers; o->singleton_kmers = s->singletonKmers;

@@ -142,6 +142,28 @@ public:
 	inline long getUniqueKmers() const { return uniqueKmers; }
 	inline long getSingletonKmers() const { return singletonKmers; }
 	static long &getKmerSubsample() { return KmerSpectrumOptions::getOptions().getKmerSubsample(); }   /* :461 */
+	class SizeTracker {                                   /* :812-900 (track() and reset() as there) */
+	public:
+		class SizeTrackerElement {
+		public:
+			long rawKmers, rawGoodKmers, uniqueKmers, singletonKmers;
+			SizeTrackerElement(long raw = 0, long rawGood = 0, long unique = 0, long single = 0) : rawKmers(raw), rawGoodKmers(rawGood), uniqueKmers(unique), singletonKmers(single) {}
+		};
+		typedef std::vector<SizeTrackerElement> Elements;
+		long nextToTrack;
+		Elements elements;
+		SizeTracker() { reset(); }
+		void track(long raw, long rawGood, long unique, long single, bool force = false) {
+			if (raw < nextToTrack && !force) return;
+			elements.push_back(SizeTrackerElement(raw, rawGood, unique, single));
+			if (raw >= nextToTrack) nextToTrack *= 1.05;
+		}
+		void reset() { nextToTrack = 128; elements.clear(); track(0, 0, 0, 0); }
+	};
+	SizeTracker sizeTracker;                              /* :901 */
+	SizeTracker getSizeTracker() const { return sizeTracker; }                    /* :902-907 */
+	void setSizeTracker(SizeTracker &st) { sizeTracker = st; }
+	void trackSpectrum(bool force = false) { sizeTracker.track(rawKmers, rawGoodKmers, uniqueKmers, singletonKmers, force); }   /* :1574-1576 */
 	static long estimateRawKmers(const ReadSet &store) {                          /* :573-584 */
 		long n = 0; for (ReadSet::ReadSetSizeType i = 0; i < store.getSize(); i++) { const long L = (long)store.getRead(i).getFasta().size(); if (L >= (long)KmerSizer::getSequenceLength()) n += L - KmerSizer::getSequenceLength() + 1; }
 		return n;

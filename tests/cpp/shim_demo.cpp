@@ -31,6 +31,12 @@ int main(int argc, char **argv) {
 		{ GKS copy(spectrum); GKS other(7); other = copy; }         /* copies share the (not yet made) handle and die quietly */
 		spectrum.buildKmerSpectrumInParts(reads, 0, "");           /* :139 -> virtual buildKmerSpectrum(store, false) */
 		spectrum.optimize();                                        /* :140 */
+		spectrum.trackSpectrum(true);                               /* :141; the history itself came with the build (kmr_size_tracker) */
+		{
+			const KS::SizeTracker hist = spectrum.getSizeTracker();
+			for (size_t i = 0; i < hist.elements.size(); i++)
+				fprintf(stderr, "history\t%ld\t%ld\t%ld\t%ld\n", hist.elements[i].rawKmers, hist.elements[i].rawGoodKmers, hist.elements[i].uniqueKmers, hist.elements[i].singletonKmers);
+		}
 		GKS again(spectrum);                                        /* the handle now exists and is shared */
 		fprintf(stderr, "raw %ld good %ld unique %ld singleton %ld weak %zu\n", spectrum.getRawKmers(), spectrum.getRawGoodKmers(), spectrum.getUniqueKmers(),
 		        spectrum.getSingletonKmers(), spectrum.weak.size());

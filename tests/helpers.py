@@ -123,6 +123,8 @@ def oracle_lib():
         lib.orc_hash.restype = C.c_uint64
         lib.orc_hash.argtypes = [C.c_char_p, C.c_uint32]
         lib.orc_hashlittle2.argtypes = [C.c_char_p, C.c_uint64, u32p, u32p]
+        lib.orc_size_tracker.restype = C.c_uint64
+        lib.orc_size_tracker.argtypes = [C.c_void_p, C.c_int, C.c_int, u64p, C.c_uint64]
         lib.orc_hash8.restype = C.c_uint64
         lib.orc_hash8.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
         lib.orc_hash8_words.restype = C.c_uint64
@@ -353,6 +355,15 @@ class OracleSpectrum(_SpectrumCommon):
     def insert_records(self, recs, n):
         recs = np.ascontiguousarray(recs, dtype=np.uint8)
         self._call("insert_records", self.h, _ptr(recs, C.c_uint8), n)
+
+    def size_tracker(self, per_read=True, force_last=True):
+        """the size history: the reference's own sampling (before every k-mer) or after every read; [n][4] uint64"""
+        lib = oracle_lib()
+        n = lib.orc_size_tracker(self.h, 1 if per_read else 0, 1 if force_last else 0, None, 0)
+        el = np.zeros((n, 4), dtype=np.uint64)
+        if n:
+            lib.orc_size_tracker(self.h, 1 if per_read else 0, 1 if force_last else 0, el.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        return el
 
     def ref_histogram(self, zoom_max=256, log_base=2.0):
         nb = (1 << 16) + 2 + zoom_max
