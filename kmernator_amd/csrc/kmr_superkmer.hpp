@@ -475,6 +475,82 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 			 * of flat ones) */
 #pragma unroll
 			for (int t = 0; t < SK_WINDOW; t++) mhr[t * 64 + lane] = minimizer_step(t);
+			if constexpr (!FILT) {
+			/* Without filters the case analysis is taken apart (noisy qualities: 215 vector + 147 scalar instructions per position
+			 * through the nested branches below, most of the scalar ones exec-mask bookkeeping, and a k-step product loop whenever ANY
+			 * lane's chain starts afresh -- with zero-probability bases sprinkled over the reads that is nearly every position):
+			 *   sweep A  flags only: zero history, equal-quality run, and where in the window this lane's chain will start afresh
+			 *            (the first k-mer, a multiple of 1024, or the k-mer behind a zero run: all known from the flags);
+			 *   once per window, all lanes together: the fresh product at that position (table entry or the k-step loop);
+			 *   sweep B  weights and runs with selects instead of branches: the chain's multiply / divide is applied where the quality
+			 *            that enters differs from the one that leaves (x / x == 1.0 otherwise: the same arithmetic as skipping it),
+			 *            the division is skipped only when no lane of the wavefront needs it.
+			 * Every decision still looks at the actual state (w == 0.0, not its prediction): a start the flags did not foresee -- a second
+			 * one in the same window -- takes the loop in place. */
+			uint32_t zcm = 0, tR = 16, qrunR = 0;
+			bool wz = w == 0.0;
+#pragma nounroll
+			for (uint32_t t = 0; t < (uint32_t)SK_WINDOW; t++) {
+				const uint32_t j = jb + t;
+				const bool in = j < L;
+				const bool z = in && ((((nmw >> t) & 1u) != 0) || (!isRef && ((qlow >> t) & 1u) != 0));
+				if (ZN > 2) zbits[2] = (zbits[2] << 1) | (zbits[1] >> 63);
+				if (ZN > 1) zbits[1] = (zbits[1] << 1) | (zbits[0] >> 63);
+				zbits[0] = (zbits[0] << 1) | (z ? 1ull : 0ull);
+				zc += z ? 1u : 0u;
+				zc -= (uint32_t)((zbits[ZN == 1 ? 0 : (k >> 6)] >> (k & 63)) & 1ull);
+				qrun = (j > 0 && (isRef || ((qeq >> t) & 1u))) ? qrun + 1 : 0;
+				const bool hasK = in && j + 1 >= k;
+				const bool zero = zc > 0;
+				zcm |= (hasK && zero) ? (1u << t) : 0u;
+				const bool fresh = hasK && !zero && !isRef && ((((j + 1 - k) & 1023u) == 0) || wz);
+				if (fresh && tR == 16) { tR = t; qrunR = qrun; }
+				wz = hasK ? zero : wz;
+			}
+			double wR = 0.0;
+			if (__any(tR < 16)) {
+				if (tR < 16) {
+					const uint32_t jR = jb + tR, iR = jR + 1 - k;
+					if (qrunR + 1 >= k) wR = sPk[rq[jR]];                 /* k equal qualities: the table holds the same sequence of products */
+					else { wR = 1.0; for (uint32_t jj = 0; jj < k; jj++) wR *= sP[rq[iR + jj]]; }
+				}
+			}
+#pragma nounroll
+			for (uint32_t t = 0; t < (uint32_t)SK_WINDOW; t++) {
+				const uint32_t j = jb + t;
+				const bool in = j < L;
+				const bool hasK = in && j + 1 >= k;
+				const uint32_t i = hasK ? j + 1 - k : 0u;
+				const bool zero = ((zcm >> t) & 1u) != 0;
+				const bool live = hasK && !zero && !isRef;
+				const bool fresh = live && ((i & 1023u) == 0 || w == 0.0);
+				if (__any(fresh && t != tR)) {
+					if (fresh && t != tR) { w = 1.0; for (uint32_t jj = 0; jj < k; jj++) w *= sP[rq[i + jj]]; }      /* (the table entry is this very product) */
+				}
+				w = (fresh && t == tR) ? wR : w;
+				const uint32_t q = rq[hasK ? j : 0u], qo = rq[(hasK && i > 0) ? i - 1 : 0u];
+				const bool moves = live && !fresh && q != qo;
+				if (__any(moves)) { const double change = sP[q] / sP[qo]; w = moves ? w * change : w; }
+				w = hasK ? (zero ? 0.0 : (isRef ? 1.0 : w)) : w;
+				const float wf = hasK ? (float)w : 0.0f;
+				const bool valid = hasK && wf > p.min_weight;
+				tRaw += hasK ? 1u : 0u; tGood += valid ? 1u : 0u;
+				const uint32_t M = mhr[t * 64 + lane];
+				const uint32_t wbits = __float_as_uint(wf);
+				const bool wsame = wbits == runW0;
+				const bool cont = valid && runOpen && M == runMh && runN < SK_MAX_N && (wsame || runInWin);
+				const bool nw = valid && !cont;
+				const bool uneven = cont && !wsame;
+				Cm |= uneven ? (1u << t) : 0u; Sm |= nw ? (1u << t) : 0u; Vm |= valid ? (1u << t) : 0u;
+				runUniform = nw || (runUniform && !uneven);
+				runStart = nw ? i : runStart;
+				runN = nw ? 1u : runN + (cont ? 1u : 0u);
+				runMh = nw ? M : runMh; runW0 = nw ? wbits : runW0;
+				runInWin = runInWin || nw;
+				runOpen = hasK ? valid : (in && runOpen);
+				wtr[t * 64 + lane] = wf;
+			}
+			} else {
 #pragma nounroll
 			for (uint32_t t = 0; t < (uint32_t)SK_WINDOW; t++) {
 				const uint32_t j = jb + t;
@@ -536,6 +612,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 					} else runOpen = false;
 				} else if (!in) runOpen = false;
 				wtr[t * 64 + lane] = wf;
+			}
 			}
 			}
 			/* a run with unequal weights ends with its window (its weights live in this window's ring) */
