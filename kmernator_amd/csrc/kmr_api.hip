@@ -64,7 +64,7 @@ struct Tuning {
 	int recycle = -1;                 /* -1 auto, 0 fresh chunks, 1 recycle the chunks a pass has just read */
 	int part_blocks = 0;              /* 0 = one partition block per CU */
 	double entry_share = -1.0;        /* >= 0: initial size of the count pass's entry buffers as a share of the records */
-	bool no_lut = false, no_narrow = false, no_l1_state = false;
+	bool no_lut = false, no_narrow = false, no_l1_state = false, no_stream_lookups = false;
 };
 
 struct kmr_handle {
@@ -94,6 +94,9 @@ struct kmr_handle {
 	/* streaming (partition) build path */
 	bool partition_mode = false;
 	bool superkmer_mode = false;       /* build_mode 3: super-k-mer lists (kmr_superkmer.hpp); implies partition_mode */
+	/* streaming lookups (sk_index_* / sk_lookup_kernel): the weak map's entries grouped by minimizer list, of map generation ix_gen */
+	uint64_t *ix_start = nullptr, *ix_keys = nullptr; uint32_t *ix_counts = nullptr; uint64_t ix_cap = 0, ix_lists = 0, ix_gen = ~0ull;
+	DevStats *scratch_stats = nullptr;
 	/* size tracker (kmr_config.size_tracker): one record per read fed so far, and the elements made of them at kmr_finalize */
 	SkTrackRec *trk = nullptr; uint64_t trk_cap = 0, trk_n = 0; std::vector<uint64_t> trk_elems;
 	bool sender_launch = false;        /* extract_by_owner_t, build (not request) mode: dev_params tells the kernel to count what it does not send */
@@ -1265,7 +1268,7 @@ bool sk_geometry(uint32_t k, uint32_t m_wish, uint32_t &win, uint32_t &m, uint32
 	}
 	return false;
 }
-template <int W, int WIN, bool FILT> int launch_sk_extract(kmr_handle *h, const ReadsView &rv, const SkParams &sp) {
+template <int W, int WIN, bool FILT> int launch_sk_extract(kmr_handle *h, const ReadsView &rv, const SkParams &sp, const DevParams *override_params = nullptr) {
 	auto kern = sk_extract_kernel<W, WIN, FILT>;
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_EXTRACT_SMEM));
 	const uint64_t tiles = ((rv.u_start ? rv.n_units : rv.n_reads) + 63) / 64;
@@ -1273,7 +1276,7 @@ template <int W, int WIN, bool FILT> int launch_sk_extract(kmr_handle *h, const 
 	if (blocks == 0) return 0;
 	blocks = std::min<uint64_t>(blocks, (uint64_t)num_cus(h) * 2);      /* resident grid: a wavefront walks tiles tile0, tile0 + stride, ... */
 	if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, SK_WAVES * 64, SK_EXTRACT_SMEM); fprintf(stderr, "sk_extract<W=%d,WIN=%d>: %d blocks of %d waves per CU (LDS %zu), grid %llu, m=%u off=%u bits=%u\n", W, WIN, nb, SK_WAVES, SK_EXTRACT_SMEM, (unsigned long long)blocks, sp.m, sp.off, sp.list_bits); }
-	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SK_WAVES * 64), SK_EXTRACT_SMEM, h->stream, rv, dev_params(h), sp, pool_view(h, h->l1));
+	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SK_WAVES * 64), SK_EXTRACT_SMEM, h->stream, rv, override_params ? *override_params : dev_params(h), sp, pool_view(h, h->l1));
 	HIPCHK(h, hipGetLastError());
 	return 0;
 }
@@ -1549,9 +1552,10 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 		h->auto_mode = cfg->build_mode == 0;
 		/* (an auto handle of a multi-rank job starts on the k-mer partition -- plain kmr_add_reads* there means the getDistributedThreadId
 		 * filter -- but is made ready for the lists: kmr_exchange_init moves it over) */
-		const bool sk_ready = cfg->build_mode == 0 && !h->ext && sk_geometry(h->k, 0, wish_w, wish_m, wish_o);
+		/* (and any handle whose k has a minimizer geometry can answer lookups as a streaming pass over the same lists) */
+		const bool sk_ready = sk_geometry(h->k, 0, wish_w, wish_m, wish_o);
 		if (cfg->build_mode == 3 || sk_auto || sk_ready) {
-			if (h->ext) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) builds KMR_VALUE_COUNT_DIR values only"); break; }
+			if (h->ext && cfg->build_mode == 3) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) builds KMR_VALUE_COUNT_DIR values only"); break; }
 			if (!sk_geometry(h->k, 0, h->sk_win, h->sk_m, h->sk_off)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) needs k >= 13"); break; }
 			h->superkmer_mode = cfg->build_mode == 3 || sk_auto;
 			double Pk[256];
@@ -1585,6 +1589,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->lut) hipFree(h->lut);
 	if (h->xo_dev) hipFree(h->xo_dev);
 	if (h->trk) hipFree(h->trk);
+	if (h->ix_start) hipFree(h->ix_start); if (h->ix_keys) hipFree(h->ix_keys); if (h->ix_counts) hipFree(h->ix_counts); if (h->scratch_stats) hipFree(h->scratch_stats);
 	exchange_free(h);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
@@ -1660,6 +1665,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "partition_blocks") h->tune.part_blocks = value >= 1 ? (int)value : 0;
 	else if (k == "entry_share") h->tune.entry_share = value;
 	else if (k == "lookup_table") h->tune.no_lut = value == 0;
+	else if (k == "stream_lookups") h->tune.no_stream_lookups = value == 0;
 	else if (k == "narrow_tallies") h->tune.no_narrow = value == 0;
 	else if (k == "keep_level1_state") h->tune.no_l1_state = value == 0;
 	else if (k == "superkmer_minimizer") {
@@ -1763,6 +1769,76 @@ int kmr_lookup_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, 
 	return rc;
 }
 
+}  // extern "C"
+/* ---- lookups as a streaming pass (kmr_superkmer.hpp, "lookups as a streaming pass"): position_counts[offsets[r] + i] = weak-map
+ * count of k-mer i of read r, zero where the k-mer is absent or holds an N.  The handle's list pool and list state are reused
+ * (after kmr_finalize the build's lists are dead). */
+bool stream_lookups_possible(kmr_handle *h) {
+	return h->dPk && !h->tune.no_stream_lookups && h->weak.present && h->weak.n > 0 && h->cfg.size_tracker == 0 && !h->sk_exchange;
+}
+template <int W> int sk_index_t(kmr_handle *h) {
+	if (h->ix_gen == h->map_gen && h->ix_start) return 0;
+	const uint64_t nl = 1ull << h->sk_bits, n = h->weak.n;
+	const uint32_t vw = h->ext ? 15 : 3;
+	if (h->ix_lists != nl) { if (h->ix_start) hipFree(h->ix_start); h->ix_start = nullptr; HIPCHK(h, hipMalloc((void **)&h->ix_start, 8 * (nl + 1))); h->ix_lists = nl; }
+	if (h->ix_cap < n) {
+		if (h->ix_keys) hipFree(h->ix_keys); if (h->ix_counts) hipFree(h->ix_counts); h->ix_keys = nullptr; h->ix_counts = nullptr; h->ix_cap = 0;
+		HIPCHK(h, hipMalloc((void **)&h->ix_keys, 8ull * W * n)); HIPCHK(h, hipMalloc((void **)&h->ix_counts, 4 * n)); h->ix_cap = n;
+	}
+	uint32_t *elist = nullptr, *hist = nullptr;
+	int rc = arena_get(h, &elist, n); if (rc) return rc;
+	rc = arena_get(h, &hist, nl); if (rc) return rc;
+	HIPCHK(h, hipMemsetAsync(hist, 0, 4 * nl, h->stream));
+	hipLaunchKernelGGL(sk_index_hist_kernel<W>, dim3(grid_for(n)), dim3(256), 0, h->stream, (const uint64_t *)h->weak.keys, n, h->sk_m, h->sk_off, h->sk_win, h->sk_bits, elist, hist);
+	HIPCHK(h, hipGetLastError());
+	rc = exclusive_scan(h, hist, nl, h->ix_start); if (rc) return rc;
+	HIPCHK(h, hipMemsetAsync(hist, 0, 4 * nl, h->stream));
+	hipLaunchKernelGGL(sk_index_scatter_kernel<W>, dim3(grid_for(n)), dim3(256), 0, h->stream, (const uint64_t *)h->weak.keys, (const uint32_t *)h->weak.vals, vw, n, elist, h->ix_start, hist, h->ix_keys, h->ix_counts);
+	HIPCHK(h, hipGetLastError());
+	h->ix_gen = h->map_gen;
+	return 0;
+}
+template <int W> int lookup_stream_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases, uint32_t *position_counts, uint64_t out_n) {
+	int rc = arena_reset(h); if (rc) return rc;
+	if (!h->sk_state) {      /* a handle that was not built on the lists (loaded image, other build mode): lists sized for this batch */
+		uint32_t bits = 6; while (bits < 24 && (total_bases >> bits) > h->tune.target_list / 2 + 200) bits++;
+		h->sk_bits = bits;
+		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8ull << bits));
+	}
+	if (!h->scratch_stats) HIPCHK(h, hipMalloc((void **)&h->scratch_stats, sizeof(DevStats)));
+	rc = sk_index_t<W>(h); if (rc) return rc;
+	const uint64_t nl = 1ull << h->sk_bits;
+	hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl);
+	if (h->l1.head) HIPCHK(h, hipMemsetAsync(h->l1.head, 0, 4, h->stream));
+	h->l1.used_ub = 0;
+	ReadsView rv = rvAll;
+	rc = prepare_units(h, rv); if (rc) return rc;
+	rc = pool_reserve(h, h->l1, total_bases / SK_CHUNK_G + nl + (uint64_t)num_cus(h) * 2 * SK_WAVES * 130 + 64, true); if (rc) return rc;
+	/* every k-mer without an N is asked for: no qualities (weight 1, or 0 with an N), no filters, nothing added to the handle's counters */
+	DevParams dp = dev_params(h);
+	dp.min_weight = 0.5f; dp.subsample = 1; dp.world = 1; dp.num_parts = 1; dp.sub_wnb = 0; dp.sub_snb = 0; dp.stats = h->scratch_stats;
+	SkParams sp = sk_params(h); sp.keep_all_owners = 1; sp.track = nullptr;
+	rc = h->sk_win == 16 ? launch_sk_extract<W, 16, false>(h, rv, sp, &dp) : (h->sk_win == 8 ? launch_sk_extract<W, 8, false>(h, rv, sp, &dp) : launch_sk_extract<W, 4, false>(h, rv, sp, &dp));
+	if (rc) return rc;
+	hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);
+	HIPCHK(h, hipGetLastError());
+	uint64_t *ls = nullptr, *lc = nullptr; uint32_t nch = 0;
+	rc = build_csr(h, h->l1, nl, 0, &ls, &lc, &nch); if (rc) return rc;
+	rc = zero_work_counter(h); if (rc) return rc;
+	const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (nl + SK_LBATCH - 1) / SK_LBATCH);
+	auto kern = sk_lookup_kernel<W>;
+	const size_t smem = sk_lookup_smem_bytes<W>();
+	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, h->ix_start, h->ix_keys, h->ix_counts, position_counts, out_n, h->work_counter);
+	HIPCHK(h, hipGetLastError());
+	return 0;
+}
+int lookup_stream(kmr_handle *h, const ReadsView &rv, uint64_t total_bases, uint32_t *position_counts, uint64_t out_n) {
+	switch (h->W) { case 1: return lookup_stream_t<1>(h, rv, total_bases, position_counts, out_n); case 2: return lookup_stream_t<2>(h, rv, total_bases, position_counts, out_n);
+	case 3: return lookup_stream_t<3>(h, rv, total_bases, position_counts, out_n); default: return lookup_stream_t<4>(h, rv, total_bases, position_counts, out_n); }
+}
+
+extern "C" {
 /* ReadSelector::scoreAndTrimReads (src/ReadSelector.h:1182-1207) on the weak map; s_b / s_o: device bases and offsets,
  * offsets: the same offsets on the host */
 static int score_reads_core(kmr_handle *h, const uint8_t *s_b, const uint64_t *s_o, uint64_t n_reads, double minimum_kmer_score, int scoring_type,
@@ -1780,11 +1856,18 @@ static int score_reads_core(kmr_handle *h, const uint8_t *s_b, const uint64_t *s
 	uint8_t *p = h->score_buf;
 	uint32_t *dkc = (uint32_t *)p; p += al(4 * (n_reads + 1));
 	uint64_t *dcoff = (uint64_t *)p;
-	hipLaunchKernelGGL(kmer_capacity_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, rv, h->k, dkc);
-	HIPCHK(h, hipGetLastError());
-	rc = exclusive_scan(h, dkc, n_reads, dcoff); if (rc) return rc;
-	uint64_t outN = 0;
-	HIPCHK(h, hipMemcpy(&outN, dcoff + n_reads, 8, hipMemcpyDeviceToHost));
+	/* counts per k-mer: as a streaming pass over minimizer lists (indexed by the k-mer's base position: the reads' own offsets are the
+	 * count offsets), or -- where the handle has no list geometry, or on request -- by probing the lookup table k-mer by k-mer */
+	const bool stream = stream_lookups_possible(h);
+	uint64_t outN = 0, first_off = 0;
+	if (stream) {
+		HIPCHK(h, hipMemcpy(&outN, s_o + n_reads, 8, hipMemcpyDeviceToHost)); HIPCHK(h, hipMemcpy(&first_off, s_o, 8, hipMemcpyDeviceToHost));
+	} else {
+		hipLaunchKernelGGL(kmer_capacity_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, rv, h->k, dkc);
+		HIPCHK(h, hipGetLastError());
+		rc = exclusive_scan(h, dkc, n_reads, dcoff); if (rc) return rc;
+		HIPCHK(h, hipMemcpy(&outN, dcoff + n_reads, 8, hipMemcpyDeviceToHost));
+	}
 	const size_t need = fixed + al(std::max<uint64_t>(8, 4 * outN));
 	if (h->score_buf_bytes < need) {         /* grow, keeping the scan */
 		uint8_t *nbuf; HIPCHK(h, hipMalloc((void **)&nbuf, need + need / 8));
@@ -1800,9 +1883,14 @@ static int score_reads_core(kmr_handle *h, const uint8_t *s_b, const uint64_t *s
 	uint8_t *dwt = p; p += al(n_reads);
 	uint32_t *dcounts = (uint32_t *)p;
 	HIPCHK(h, hipMemsetAsync(dcounts, 0, 4 * outN, h->stream));
-	{ int urc = prepare_units(h, rv); if (urc) return urc; }
-	switch (h->W) { case 1: rc = lookup_reads_t<1>(h, rv, dcounts, dcoff, true); break; case 2: rc = lookup_reads_t<2>(h, rv, dcounts, dcoff, true); break;
-	case 3: rc = lookup_reads_t<3>(h, rv, dcounts, dcoff, true); break; default: rc = lookup_reads_t<4>(h, rv, dcounts, dcoff, true); }
+	if (stream) {
+		rc = lookup_stream(h, rv, outN - first_off, dcounts, outN);
+		dcoff = (uint64_t *)s_o;
+	} else {
+		{ int urc = prepare_units(h, rv); if (urc) return urc; }
+		switch (h->W) { case 1: rc = lookup_reads_t<1>(h, rv, dcounts, dcoff, true); break; case 2: rc = lookup_reads_t<2>(h, rv, dcounts, dcoff, true); break;
+		case 3: rc = lookup_reads_t<3>(h, rv, dcounts, dcoff, true); break; default: rc = lookup_reads_t<4>(h, rv, dcounts, dcoff, true); }
+	}
 	if (!rc) {
 		hipLaunchKernelGGL(score_reads_kernel, dim3((unsigned)std::min<uint64_t>(((n_reads + 63) / 64 + SC_WAVES - 1) / SC_WAVES, 1u << 16)), dim3(SC_WAVES * 64), 0, h->stream, s_b, s_o, n_reads, h->k, dcounts, dcoff,
 		                   (float)minimum_kmer_score, scoring_type, dto, dtl, dsc, dwt);

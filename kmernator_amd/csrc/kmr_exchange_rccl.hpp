@@ -59,7 +59,7 @@ static int exchange_ready(kmr_handle *h) {      /* common tail of the two inits 
 	if (h->cfg.world_size > SK_OWNER_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "at most 64 ranks");
 	/* build_mode 0: a job that exchanges through the library runs on the lists when the handle can (direction-counting values, a
 	 * minimizer geometry for k) and nothing has been fed to it yet */
-	if (h->auto_mode && !h->superkmer_mode && h->dPk && !h->reads && !h->inserted_records && !h->sk_state) h->superkmer_mode = true;
+	if (h->auto_mode && !h->superkmer_mode && !h->ext && h->dPk && !h->reads && !h->inserted_records && !h->sk_state) h->superkmer_mode = true;
 	if (h->superkmer_mode) return kmr_sk_exchange_begin(h);
 	return KMR_OK;
 }

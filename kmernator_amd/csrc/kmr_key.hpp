@@ -161,10 +161,12 @@ template <int W> KMR_HD uint64_t key_hash8(const Key<W> &key, uint32_t kb) {
 	a = b = 0xDEADBEEFull;
 	c = 0x9e3779b97f4a7c13ull;
 	uint32_t len = kb; int m = 0;
-	if (W >= 3 && len >= 24) {      /* one full block of 24 bytes (kb <= 32) */
-		a += kmr_bswap64(key.w[0]); b += kmr_bswap64(key.w[1]); c += kmr_bswap64(key.w[2]);
-		KMR_MIX64(a, b, c);
-		len -= 24; m = 3;
+	if constexpr (W >= 3) {
+		if (len >= 24) {      /* one full block of 24 bytes (kb <= 32) */
+			a += kmr_bswap64(key.w[0]); b += kmr_bswap64(key.w[1]); c += kmr_bswap64(key.w[2]);
+			KMR_MIX64(a, b, c);
+			len -= 24; m = 3;
+		}
 	}
 	c += kb;
 	/* the last 0..23 bytes: bytes 0-7 into a, 8-15 into b, 16-22 into c above its first byte (reserved for the length) */

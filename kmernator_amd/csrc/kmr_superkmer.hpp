@@ -1123,6 +1123,171 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	}
 }
 
+/* ------------------------------------------------------------------ lookups as a streaming pass (f1) */
+/* ReadSelector::scoreAndTrimReads asks the weak map for the count of every k-mer of every read (getValue, src/ReadSelector.h:924-931;
+ * setKmerValues :1060-1090): 1.2 x 10^9 independent lookups per C2 batch, which as random probes of a 2 GB table run at the
+ * chip's random-access rate (72 ms).  The same lists that make the build stream make the lookups stream: the weak map's entries
+ * are grouped ONCE per finalized map by the list their minimizer selects (sk_index_*: key + count, 12 bytes per entry at k <= 32),
+ * the reads are cut into super-k-mers exactly as for the build (no qualities: every k-mer without an N is asked for), and one block
+ * per list puts the list's entries into an LDS table, expands the list's records and answers each k-mer from LDS, writing the
+ * count to the k-mer's position (its stream ordinal).  A k-mer that is not in the map, or holds an N, keeps the zero the output was
+ * cleared to. */
+template <int W>
+__global__ __launch_bounds__(256)
+void sk_index_hist_kernel(const uint64_t *keys, uint64_t n, uint32_t m, uint32_t off, uint32_t win, uint32_t list_bits, uint32_t *elist, uint32_t *hist) {
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t l = sk_list_of(sk_key_minimizer<W>(keys + e * W, m, off, win), list_bits);
+		elist[e] = l;
+		atomicAdd(&hist[l], 1u);
+	}
+}
+template <int W>
+__global__ __launch_bounds__(256)
+void sk_index_scatter_kernel(const uint64_t *keys, const uint32_t *vals, uint32_t vw, uint64_t n, const uint32_t *elist, const uint64_t *start, uint32_t *cursor,
+                             uint64_t *ikeys, uint32_t *icounts) {
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t l = elist[e];
+		const uint64_t pos = start[l] + atomicAdd(&cursor[l], 1u);
+#pragma unroll
+		for (int q = 0; q < W; q++) ikeys[pos * W + q] = keys[e * W + q];
+		icounts[pos] = vals[e * vw] & 0xffffu;       /* TrackingData::getCount: the u16 at the head of the value */
+	}
+}
+
+static const int SKL_LOG2S = 10;                       /* LDS table of a list's entries: 1024 slots, at most SKL_FILL per pass */
+static const uint32_t SKL_FILL = 704;
+template <int W> __host__ __device__ constexpr size_t sk_lookup_smem_bytes() { return (size_t)(1 << SKL_LOG2S) * (8 * W + 4 + 4) + (size_t)SK_STAGE_G * 16 + 256 + 64; }
+
+template <int W>
+__global__ __launch_bounds__(COUNT_THREADS, W == 1 ? 4 : 1)
+void sk_lookup_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
+                      const uint64_t *ix_start, const uint64_t *ix_keys, const uint32_t *ix_counts, uint32_t *out, uint64_t out_n, unsigned int *work_counter) {
+	constexpr int S = 1 << SKL_LOG2S;
+	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
+	uint64_t *tkeys = (uint64_t *)csm;                                 /* [S][W] */
+	uint32_t *tval = (uint32_t *)(tkeys + (size_t)S * W);
+	uint32_t *tstate = tval + S;                                       /* 0 empty, 1 filled (entries are put in before anybody looks) */
+	uint4 *stage = (uint4 *)(tstate + S);
+	uint8_t *recOf = (uint8_t *)(stage + SK_STAGE_G);
+	__shared__ uint32_t s_list;
+	__shared__ unsigned long long s_ls[SK_LBATCH + 1];
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const uint4 *poolg = (const uint4 *)pool.base;
+	for (;;) {
+		lds_barrier();
+		if (t == 0) s_list = atomicAdd(work_counter, SK_LBATCH);
+		lds_barrier();
+		const uint64_t lfirst = s_list;
+		if (lfirst >= n_lists) break;
+		const uint32_t nl = (uint32_t)(n_lists - lfirst < (uint64_t)SK_LBATCH ? n_lists - lfirst : (uint64_t)SK_LBATCH);
+		if ((uint32_t)t <= nl) s_ls[t] = list_start[lfirst + t];
+		lds_barrier();
+		for (uint32_t lj = 0; lj < nl; lj++) {
+			const uint64_t c0 = s_ls[lj], c1 = s_ls[lj + 1];
+			if (c0 == c1) continue;
+			const uint64_t e0 = ix_start[lfirst + lj], e1 = ix_start[lfirst + lj + 1];
+			/* a list with more entries than the table takes is answered in passes over its records, one table fill each (a key is in
+			 * exactly one of them) */
+			for (uint64_t eb = e0; eb < e1; eb += SKL_FILL) {
+				lds_barrier();
+				for (int i = t; i < S; i += COUNT_THREADS) tstate[i] = 0;
+				lds_barrier();
+				const uint64_t ee = eb + SKL_FILL < e1 ? eb + SKL_FILL : e1;
+				for (uint64_t e = eb + (uint64_t)t; e < ee; e += COUNT_THREADS) {
+					uint64_t kw[W];
+#pragma unroll
+					for (int q = 0; q < W; q++) kw[q] = ix_keys[e * W + q];
+					uint32_t sl = (uint32_t)(slot_hash<W>(kw) >> (64 - SKL_LOG2S));
+					while (atomicCAS(&tstate[sl], 0u, 1u) != 0u) sl = (sl + 1) & (S - 1);      /* keys are distinct: a taken slot is somebody else's */
+#pragma unroll
+					for (int q = 0; q < W; q++) tkeys[(size_t)sl * W + q] = kw[q];
+					tval[sl] = ix_counts[e];
+				}
+				lds_barrier();
+				uint4 *wstage = stage + wv * SK_CHUNK_G;
+				uint8_t *wrecOf = recOf + wv * 64;
+				for (uint64_t ci = c0 + wv; ci < c1; ci += SK_STAGE_CHUNKS) {
+					const uint64_t d = list_chunks[ci];
+					const uint32_t chunk = (uint32_t)d, curCount = (uint32_t)(d >> 32);
+					uint4 cur = make_uint4(0, 0, 0, 0);
+					if ((uint32_t)lane < curCount) cur = poolg[(size_t)chunk * SK_CHUNK_G + lane];
+					__builtin_amdgcn_wave_barrier();      /* the lanes are done with the chunk before */
+					wstage[lane] = cur;
+					const uint32_t glen = (cur.y >> 17) & 0x7fu;
+					unsigned long long starts = 0;
+					if (__all((lane & 1) != 0 || (uint32_t)lane >= curCount || glen == 2u)) starts = 0x5555555555555555ull & (curCount >= 64u ? ~0ull : ((1ull << curCount) - 1ull));
+					else for (uint32_t pos = 0; pos < curCount; ) {
+						starts |= 1ull << pos;
+						const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos);
+						pos += step ? step : SK_CHUNK_G;
+					}
+					/* the chunk's k-mers dealt evenly over the lanes, as in sk_count_kernel */
+					const bool isStart = (starts >> lane) & 1ull;
+					const uint32_t myN = isStart ? (cur.y >> 8) & 0xffu : 0u;
+					uint32_t incl = myN;
+#pragma unroll
+					for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += x; }
+					const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+					const uint32_t myOff = incl - myN;
+					const uint32_t Lk = (T + 63u) >> 6;
+					if (myN) {
+						const float Lf = (float)Lk;
+						const uint32_t l0 = (uint32_t)((float)(myOff + Lk - 1) / Lf), l1 = (uint32_t)((float)(myOff + myN - 1) / Lf);
+						for (uint32_t l = l0; l <= l1 && l < 64u; l++) wrecOf[l] = (uint8_t)lane;
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					const uint32_t k0 = (uint32_t)lane * Lk;
+					uint32_t left = k0 < T ? (T - k0 < Lk ? T - k0 : Lk) : 0u;
+					uint32_t rs = left ? wrecOf[lane] : 0u;
+					uint32_t j = k0 - (uint32_t)__shfl((int)myOff, (int)rs, 64);
+					uint32_t hx = (uint32_t)__shfl((int)cur.x, (int)rs, 64), hy = (uint32_t)__shfl((int)cur.y, (int)rs, 64);
+					uint32_t n = 0; const uint32_t *bw = nullptr; uint64_t ord0 = 0;
+					for (uint32_t it = 0; it < Lk; it++) {
+						if (left) {
+							if (it == 0 || j >= n) {
+								if (it != 0) { rs += (hy >> 17) & 0x7fu; const uint4 hd = wstage[rs]; hx = hd.x; hy = hd.y; j = 0; }
+								n = (hy >> 8) & 0xffu;
+								bw = (const uint32_t *)(wstage + rs + 1);
+								ord0 = (uint64_t)hx | ((uint64_t)(hy & 0xffu) << 32);
+							}
+							Key<W> kf;
+							const uint32_t d0 = j >> 4, sft = 2u * (j & 15u);
+#pragma unroll
+							for (int wi = 0; wi < W; wi++) {
+								const uint32_t a = bw[d0 + 2 * wi], b = bw[d0 + 2 * wi + 1], c = bw[d0 + 2 * wi + 2];
+								const uint64_t hi = ((uint64_t)a << 32) | b;
+								kf.w[wi] = sft ? (hi << sft) | ((uint64_t)c >> (32 - sft)) : hi;
+							}
+							const uint32_t kbits = 2u * k;
+#pragma unroll
+							for (int wi = 0; wi < W; wi++) {
+								const uint32_t lo = 64u * wi;
+								if (kbits <= lo) kf.w[wi] = 0;
+								else if (kbits < lo + 64u) kf.w[wi] &= ~0ull << (lo + 64u - kbits);
+							}
+							const Key<W> kr = key_revcomp<W>(kf, k);
+							const Key<W> key = key_le<W>(kf, kr) ? kf : kr;
+							uint32_t sl = (uint32_t)(slot_hash<W>(key.w) >> (64 - SKL_LOG2S));
+							uint32_t found = 0;
+							for (int probe = 0; probe < S; probe++) {
+								if (tstate[sl] == 0) break;
+								bool eq = true;
+#pragma unroll
+								for (int q = 0; q < W; q++) eq = eq && tkeys[(size_t)sl * W + q] == key.w[q];
+								if (eq) { found = tval[sl]; break; }
+								sl = (sl + 1) & (S - 1);
+							}
+							const uint64_t at = ord0 + j;
+							if (found && at < out_n) out[at] = found;
+							j++; left--;
+						}
+					}
+				}
+			}
+		}
+	}
+}
+
 /* ------------------------------------------------------------------ owner exchange of super-k-mer lists */
 /* One process per GPU: every rank scatters the super-k-mers of ITS reads into all 2^list_bits lists; list l belongs to rank
  * l % world.  What a rank holds of other ranks' lists travels as it lies -- the used granules of every such chunk, plus

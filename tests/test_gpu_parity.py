@@ -611,14 +611,16 @@ def test_long_reads_within_tile(mode):
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
 
 
-def test_score_and_trim_reads_golden_labels():
+@pytest.mark.parametrize("stream", [1, 0])
+def test_score_and_trim_reads_golden_labels(stream):
     """f1: ReadSelector::scoreAndTrimReads on the device against the reference's FilterReads golden
-    (test/1000-Filtered.fastq: MedianScore / Trim labels of the 949 reads without AFTrim)."""
+    (test/1000-Filtered.fastq: MedianScore / Trim labels of the 949 reads without AFTrim); the k-mer counts come from the
+    streaming pass over minimizer lists, or from the per-k-mer probes of the lookup table"""
     import re
     k = 31
     rb = read_fastq(os.path.join(GOLDEN, "1000.fastq"))
     gold = read_fastq(os.path.join(GOLDEN, "1000-Filtered.fastq"))
-    p = product(default_config(k, fastq_start_char=64, estimated_raw_kmers=46000))
+    p = product(default_config(k, fastq_start_char=64, estimated_raw_kmers=46000), stream_lookups=stream)
     add(p, rb)
     p.finalize(2)
     to, tl, sc, wt = p.scoreAndTrimReads(rb.bases, rb.offsets, 2, "MEDIAN")
@@ -635,12 +637,12 @@ def test_score_and_trim_reads_golden_labels():
     assert checked == 949
 
 
-@pytest.mark.parametrize("scoring", ["MEDIAN", "AVG", "MIN", "MAX", "SUM"])
-def test_score_and_trim_reads_all_types(scoring):
+@pytest.mark.parametrize("scoring,stream", [("MEDIAN", 1), ("AVG", 1), ("MIN", 0), ("MAX", 1), ("SUM", 0), ("MEDIAN", 0)])
+def test_score_and_trim_reads_all_types(scoring, stream):
     k = 25
     rb = synth_reads(1500, read_len=120, seed=6, quality="noisy", n_rate=0.004)
     cfg = default_config(k, num_buckets_weak=256, num_buckets_singleton=1024)
-    o, p = run_both(cfg, rb)
+    o, p = run_both(cfg, rb, stream_lookups=stream)
     to, tl, sc, wt = p.scoreAndTrimReads(rb.bases, rb.offsets, 3, scoring)
     counts, off = p.getCountsForReads(rb.bases, rb.offsets)
     for i in range(rb.n):
@@ -861,3 +863,26 @@ def test_million_noisy_reads_against_the_oracle(k):
     nkept = compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
     assert nkept == o.stats()["weak_entries"] and nkept > 1_000_000
     o.close()
+
+
+@pytest.mark.parametrize("k,mode", [(21, 2), (31, 3), (51, 3), (95, 1), (127, 3)])
+def test_streaming_lookups_equal_table_probes(k, mode):
+    """f1 as a streaming pass (reads -> super-k-mers -> minimizer lists, the weak map's entries grouped by the same lists, answers from
+    LDS) against the per-k-mer probes: same trims and scores, for reads with N's, reads shorter than k, reads longer than an LDS tile,
+    spectra built in any mode (a handle that never made lists sizes them for the batch) and a second batch against the same map."""
+    rb = synth_reads(4000, read_len=180, genome_len=60000, seed=k, quality="noisy", n_rate=0.003)
+    odd = synth_reads(12, read_len=12000, genome_len=60000, seed=k + 1, quality="noisy", n_rate=0.001)
+    short = synth_reads(50, read_len=k - 1, genome_len=60000, seed=k + 2)
+    cfg = default_config(k, estimated_raw_kmers=4000 * 180)
+    a, b = product(cfg, mode, stream_lookups=1), product(cfg, mode, stream_lookups=0)
+    for p in (a, b):
+        add(p, rb)
+        add(p, odd, first=rb.n)
+        p.finalize(2)
+    for batch in (rb, odd, short, rb.slice(100, 900)):
+        for scoring in ("MEDIAN", "SUM"):
+            ra = a.scoreAndTrimReads(batch.bases, batch.offsets, 2, scoring)
+            rb_ = b.scoreAndTrimReads(batch.bases, batch.offsets, 2, scoring)
+            for x, y in zip(ra, rb_):
+                assert np.array_equal(x, y)
+    assert a.stats() == b.stats()          # the lookup pass leaves the build's counters alone
