@@ -99,6 +99,7 @@ struct kmr_handle {
 	DevStats *scratch_stats = nullptr;
 	/* size tracker (kmr_config.size_tracker): one record per read fed so far, and the elements made of them at kmr_finalize */
 	SkTrackRec *trk = nullptr; uint64_t trk_cap = 0, trk_n = 0; std::vector<uint64_t> trk_elems;
+	bool sk_fast_div = false;          /* see kmr_create: the chain's divide as multiply-and-correct */
 	bool sender_launch = false;        /* extract_by_owner_t, build (not request) mode: dev_params tells the kernel to count what it does not send */
 	bool sk_exchange = false;          /* kmr_sk_exchange_begin: the lists are the whole job's, every owner's k-mers are kept until the exchange */
 	bool auto_mode = false;            /* build_mode 0: a handle that is fed k-mer records (the owner exchange) before any reads falls back to mode 2 */
@@ -1287,7 +1288,7 @@ uint32_t sk_dbg_flags(const char *name) {
 	(void)name; return 0u;
 #endif
 }
-SkParams sk_params(kmr_handle *h) { SkParams sp; sp.dbg = sk_dbg_flags("KMR_SK_EXTRACT_DBG"); sp.keep_all_owners = h->sk_exchange ? 1u : 0u; sp.track = nullptr; sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; return sp; }
+SkParams sk_params(kmr_handle *h) { SkParams sp; sp.dbg = sk_dbg_flags("KMR_SK_EXTRACT_DBG"); sp.keep_all_owners = h->sk_exchange ? 1u : 0u; sp.track = nullptr; sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; sp.Rp = h->dPk + 256; sp.fast_div = h->sk_fast_div ? 1u : 0u; return sp; }
 template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
 	const uint64_t n = rvAll.n_reads;
 	if (!h->sk_state) {
@@ -1560,8 +1561,19 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 			h->superkmer_mode = cfg->build_mode == 3 || sk_auto;
 			double Pk[256];
 			for (int cidx = 0; cidx < 256; cidx++) { double wv = 1.0; for (uint32_t jj = 0; jj < h->k; jj++) wv *= P[cidx]; Pk[cidx] = wv; }      /* the loop of buildWeightedKmers, src/KmerReadUtils.h:205-208 */
-			if (hipMalloc((void **)&h->dPk, sizeof(Pk)) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
+			if (hipMalloc((void **)&h->dPk, 2 * sizeof(Pk)) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
 			hipMemcpy(h->dPk, Pk, sizeof(Pk), hipMemcpyHostToDevice);
+			/* reciprocals for the chain's divide, usable only if multiply-and-correct reproduces the correctly rounded quotient of every
+			 * pair of table entries (all 256 x 256 are tried; the kernel divides otherwise) */
+			double Rp[256]; bool fast = true;
+			for (int cidx = 0; cidx < 256; cidx++) Rp[cidx] = P[cidx] != 0.0 ? 1.0 / P[cidx] : 0.0;
+			for (int a = 0; a < 256 && fast; a++) for (int b = 0; b < 256; b++) {
+				if (P[a] == 0.0 || P[b] == 0.0) continue;
+				const double q0 = P[a] * Rp[b];
+				if (std::fma(std::fma(-q0, P[b], P[a]), Rp[b], q0) != P[a] / P[b]) { fast = false; break; }
+			}
+			h->sk_fast_div = fast;
+			hipMemcpy(h->dPk + 256, Rp, sizeof(Rp), hipMemcpyHostToDevice);
 		}
 		if (cfg->size_tracker && (!h->superkmer_mode || cfg->world_size > 1)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "size_tracker: kept by the super-k-mer build (build_mode 0 / 3, direction-counting values, k >= 13) of a single partition"); break; }
 		if (!h->partition_mode) {

@@ -62,6 +62,8 @@ struct SkParams {
 	uint32_t m;            /* minimizer length in bases, <= 16                                        */
 	uint32_t off;          /* offset inside the k-mer of the first m-mer the minimizer looks at       */
 	uint32_t list_bits;    /* lists = 2^list_bits                                                     */
+	uint32_t fast_div;     /* 1: P[a] / P[b] may be formed as fma(fma(-q0, P[b], P[a]), R[b], q0), q0 = P[a] * R[b], R = 1 / P: the host has checked that this gives the correctly rounded quotient for every pair of table entries (kmr_create) */
+	const double *Rp;      /* 256 entries: 1 / P[c] (0 where P[c] == 0) */
 	uint32_t keep_all_owners;      /* world_size > 1: 1 inside an owner exchange (the list decides the owner), 0 = keep what getDistributedThreadId gives this rank */
 	unsigned long long *state;     /* per list: open chunk << 32 | granules used (SK_CHUNK_G and NO_CHUNK: none) */
 	struct SkTrackRec *track;      /* size tracker (kmr_config.size_tracker): one record per read of this launch, or null */
@@ -171,10 +173,10 @@ template <int W, int WIN, bool FILT>
 __global__ __launch_bounds__(SK_WAVES * 64, 2)
 void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	__shared__ double sP[256], sPk[256];
+	__shared__ double sP[256], sR[256];      /* P and 1 / P; the k-fold products Pk are read from global memory (once per read, or where a chain starts afresh) */
 	__shared__ SkSlab s_slab[SK_WAVES];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	for (int i = threadIdx.x; i < 256; i += blockDim.x) { sP[i] = p.P[i]; sPk[i] = sp.Pk[i]; }
+	for (int i = threadIdx.x; i < 256; i += blockDim.x) { sP[i] = p.P[i]; sR[i] = sp.Rp[i]; }
 	uint8_t *wb = smem + (size_t)wave * SK_WAVE_LDS;
 	uint8_t *tq = wb;                                                   /* quality chars                          */
 	uint32_t *pk = (uint32_t *)(wb + SK_Q_BYTES);                       /* [SK_GROUPS] packed bases               */
@@ -417,7 +419,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				if (noLaterRestart && __all(ok)) {
 					flatBlk = true;
 					const bool kmers = live && nin > tk;
-					if (kmers) { if (isRef) w = 1.0; else if (fresh) w = sPk[rq[jb + tk]]; }
+					if (kmers) { if (isRef) w = 1.0; else if (fresh) w = sp.Pk[rq[jb + tk]]; }
 					const float wf = (float)w;
 					flatWbits = __float_as_uint(wf);
 					const uint32_t kmask = kmers ? inmask & ~((1u << tk) - 1u) : 0u;      /* positions with a k-mer */
@@ -489,6 +491,44 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 			 * one in the same window -- takes the loop in place. */
 			uint32_t zcm = 0, tR = 16, qrunR = 0;
 			bool wz = w == 0.0;
+			if (k >= (uint32_t)SK_WINDOW) {
+				/* sweep A on whole 16-bit masks (k >= 16: what leaves the k-window during these 16 positions lies wholly in the history):
+				 * zero flags of the window, the flags that leave it, and from the two the positions where the window count is above
+				 * zero; k-mer positions; where the chain starts afresh */
+				const uint32_t nin = jb < L ? (L - jb < (uint32_t)SK_WINDOW ? L - jb : (uint32_t)SK_WINDOW) : 0u;
+				const uint32_t inmask = (1u << nin) - 1u;
+				const uint32_t tk = jb + 1 >= k ? 0u : k - 1 - jb;                     /* < 16 here: jb + 16 >= k was checked by the caller's paths */
+				const uint32_t km = tk < 16u ? (inmask & ~((1u << tk) - 1u)) : 0u;
+				const uint32_t zm = (nmw | (isRef ? 0u : qlow)) & inmask;
+				uint32_t field;                                                          /* history bits k-16 .. k-1 (bit b = position jb - 1 - b) */
+				{
+					const uint32_t lo = k - 16u, wi = lo >> 6, sh = lo & 63u;
+					uint64_t a = zbits[wi < (uint32_t)ZN ? wi : ZN - 1];
+					if (wi >= (uint32_t)ZN) a = 0;
+					uint64_t b = (wi + 1 < (uint32_t)ZN) ? zbits[wi + 1 < (uint32_t)ZN ? wi + 1 : ZN - 1] : 0ull;
+					field = (uint32_t)((sh ? (a >> sh) | (b << (64u - sh)) : a) & 0xffffu);
+				}
+				const uint32_t lm = __builtin_bitreverse32(field) >> 16;                 /* bit t: the flag that leaves at position jb + t */
+				uint32_t zcw = zc, zcpos = 0;
+#pragma unroll
+				for (int t = 0; t < SK_WINDOW; t++) { zcw += (zm >> t) & 1u; zcw -= (lm >> t) & 1u; zcpos |= (zcw != 0 ? 1u : 0u) << t; }
+				zc = zcw;
+				if (ZN > 2) zbits[2] = (zbits[2] << 16) | (zbits[1] >> 48);
+				if (ZN > 1) zbits[1] = (zbits[1] << 16) | (zbits[0] >> 48);
+				zbits[0] = (zbits[0] << 16) | (uint64_t)(__builtin_bitreverse32(zm) >> 16);
+				zcm = zcpos & km;
+				const uint32_t t1024 = (k - 1u - jb) & 1023u;                             /* position whose k-mer index is a multiple of 1024 */
+				const uint32_t p1024 = t1024 < 16u ? (1u << t1024) : 0u;
+				const uint32_t wzprev = ((zcm << 1) & 0xffffu) | ((wz && tk < 16u) ? (1u << tk) : 0u);
+				const uint32_t fm = isRef ? 0u : (km & ~zcpos & (p1024 | wzprev));
+				const uint32_t em = (isRef ? 0xffffu : qeq) & (jb == 0 ? 0xfffeu : 0xffffu);
+				if (fm) {
+					tR = (uint32_t)__builtin_ctz(fm);
+					const uint32_t x = ~em & ((2u << tR) - 1u);
+					qrunR = x ? tR - (31u - (uint32_t)__builtin_clz(x)) : qrun + tR + 1u;
+				}
+				{ const uint32_t x = ~em & 0xffffu; qrun = x ? 15u - (31u - (uint32_t)__builtin_clz(x)) : qrun + 16u; }
+			} else {
 #pragma nounroll
 			for (uint32_t t = 0; t < (uint32_t)SK_WINDOW; t++) {
 				const uint32_t j = jb + t;
@@ -507,11 +547,12 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				if (fresh && tR == 16) { tR = t; qrunR = qrun; }
 				wz = hasK ? zero : wz;
 			}
+			}
 			double wR = 0.0;
 			if (__any(tR < 16)) {
 				if (tR < 16) {
 					const uint32_t jR = jb + tR, iR = jR + 1 - k;
-					if (qrunR + 1 >= k) wR = sPk[rq[jR]];                 /* k equal qualities: the table holds the same sequence of products */
+					if (qrunR + 1 >= k) wR = sp.Pk[rq[jR]];                 /* k equal qualities: the table holds the same sequence of products */
 					else { wR = 1.0; for (uint32_t jj = 0; jj < k; jj++) wR *= sP[rq[iR + jj]]; }
 				}
 			}
@@ -530,7 +571,12 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				w = (fresh && t == tR) ? wR : w;
 				const uint32_t q = rq[hasK ? j : 0u], qo = rq[(hasK && i > 0) ? i - 1 : 0u];
 				const bool moves = live && !fresh && q != qo;
-				if (__any(moves)) { const double change = sP[q] / sP[qo]; w = moves ? w * change : w; }
+				if (__any(moves)) {
+					double change;
+					if (sp.fast_div) { const double a = sP[q], b = sP[qo], r = sR[qo]; const double q0 = a * r; change = fma(fma(-q0, b, a), r, q0); }
+					else change = sP[q] / sP[qo];
+					w = moves ? w * change : w;
+				}
 				w = hasK ? (zero ? 0.0 : (isRef ? 1.0 : w)) : w;
 				const float wf = hasK ? (float)w : 0.0f;
 				const bool valid = hasK && wf > p.min_weight;
@@ -572,7 +618,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 					if (zc > 0) w = 0.0;
 					else if (isRef) w = 1.0;
 					else if ((i & 1023u) == 0 || w == 0.0) {
-						if (qrun + 1 >= k) w = sPk[rq[j]];                 /* k equal qualities: the table holds the same sequence of products */
+						if (qrun + 1 >= k) w = sp.Pk[rq[j]];                 /* k equal qualities: the table holds the same sequence of products */
 						else { w = 1.0; for (uint32_t jj = 0; jj < k; jj++) w *= sP[rq[i + jj]]; }
 					} else if (qrun < k) {
 						/* x / x == 1.0 exactly, so equal qualities leave w unchanged; a run of k+1 equal chars proves that without a load */
