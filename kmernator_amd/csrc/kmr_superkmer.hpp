@@ -121,7 +121,10 @@ __device__ __forceinline__ uint64_t sk_append_settle(unsigned long long *state, 
 }
 __device__ __forceinline__ uint64_t sk_append(unsigned long long *state, uint32_t list, uint32_t g, SkSlab *slab, const PoolView &pool) {
 	unsigned long long *word = state + list;
-	for (int spin = 0; spin < 1024; spin++) {
+	/* (every round of a contended list lets a chunk's worth of adders through: with all the chip's lanes on ONE list -- reads that are
+	 * one long homopolymer -- a lane may lose some thousand rounds before it is its turn; the bound only has to end a build whose pool
+	 * is gone) */
+	for (int spin = 0; spin < (1 << 22); spin++) {
 		const unsigned long long old = atomicAdd(word, (unsigned long long)g);
 		const uint32_t c = (uint32_t)(old >> 32), f = (uint32_t)old;
 		if (f + g <= SK_CHUNK_G) return (uint64_t)c * SK_CHUNK_G + f;
@@ -142,6 +145,7 @@ __device__ __forceinline__ uint64_t sk_append(unsigned long long *state, uint32_
 			if ((uint32_t)(now >> 32) != c || (uint32_t)now <= SK_CHUNK_G) break;
 			__builtin_amdgcn_s_sleep(2);
 		}
+		if (spin > 64) __builtin_amdgcn_s_sleep(32);      /* a crowd: come back later rather than add to it */
 		if (__hip_atomic_load(pool.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ERR_POOL_FULL) return ~0ull;
 	}
 	atomicOr(pool.err, (uint32_t)ERR_POOL_FULL);

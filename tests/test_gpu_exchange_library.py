@@ -22,8 +22,20 @@ pytestmark = pytest.mark.gpu
 N_READS, READ_LEN = 60000, 150
 
 
-def _reads():
-    return synth_reads(N_READS, read_len=READ_LEN, genome_len=5 * N_READS, seed=21, quality="noisy", n_rate=0.001)
+SKEW = False          # set by the skewed-input test in the parent AND (through mp.spawn's pickled args) in the workers
+
+
+def _reads(skew=False):
+    rb = synth_reads(N_READS, read_len=READ_LEN, genome_len=5 * N_READS, seed=21, quality="noisy", n_rate=0.001)
+    if skew:
+        # half of the reads are poly-A: one k-mer, one owner, which then gets ~3/4 of every batch's records -- more than the
+        # segment a rank sets aside for an owner (its share + 25 %), so the sender has to grow its segments and extract again
+        bases = rb.bases.copy().reshape(N_READS, READ_LEN)
+        bases[::2] = ord("A")
+        quals = rb.quals.copy().reshape(N_READS, READ_LEN)
+        quals[::2] = ord("I")
+        rb = type(rb).from_arrays(bases.reshape(-1), quals.reshape(-1), rb.offsets)
+    return rb
 
 
 def _dev(rb, dev):
@@ -83,7 +95,7 @@ def _batches(rank, world):
     return list(zip(cuts[:-1], cuts[1:]))
 
 
-def _worker(rank, world, port, tmp, mode, k):
+def _worker(rank, world, port, tmp, mode, k, skew=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -125,7 +137,7 @@ def _worker(rank, world, port, tmp, mode, k):
                     assert hip.hipMemcpy(recv + roff[r], ins[r].numpy().ctypes.data, rbytes[r], 1) == 0
 
         lo, hi = _slice(rank, world)
-        rb = _reads().slice(lo, hi)
+        rb = _reads(skew).slice(lo, hi)
         sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0, rank=rank, world_size=world, build_mode=mode))
         sp.exchange_init_transport(allgather, alltoallv)
         for a, b in _batches(rank, world):
@@ -140,13 +152,16 @@ def _worker(rank, world, port, tmp, mode, k):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode,k", [(2, 0, 31), (3, 0, 51), (2, 2, 31)])
-def test_ranks_sharing_one_gpu_through_a_host_transport(world, mode, k):
+@pytest.mark.parametrize("world,mode,k,skew", [(2, 0, 31, False), (3, 0, 51, False), (2, 2, 31, False), (2, 2, 31, True), (2, 0, 31, True)])
+def test_ranks_sharing_one_gpu_through_a_host_transport(world, mode, k, skew):
+    """skew: half of the reads are poly-A, so one owner receives far more than its share of every batch -- the k-mer record path
+    has to grow its owner segments and extract again (no error, no hang: the decision is the sender's own), the lists take it as
+    it comes"""
     import kmernator_amd as ka
-    port = 33300 + (os.getpid() % 1500) + world + 7 * mode
+    port = 33300 + (os.getpid() % 1500) + world + 7 * mode + (13 if skew else 0)
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, port, tmp, mode, k), nprocs=world, join=True)
-        rb = _reads()
+        mp.spawn(_worker, args=(world, port, tmp, mode, k, skew), nprocs=world, join=True)
+        rb = _reads(skew)
         multi = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0))
         # the job's input order: round by round, and inside a round rank by rank (what kmr_exchange_add_reads_dev's ordinals say)
         for i in range(2):

@@ -886,3 +886,22 @@ def test_streaming_lookups_equal_table_probes(k, mode):
             for x, y in zip(ra, rb_):
                 assert np.array_equal(x, y)
     assert a.stats() == b.stats()          # the lookup pass leaves the build's counters alone
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_low_complexity_reads(mode):
+    """homopolymers and dinucleotide repeats: a handful of k-mers seen 10^5-10^6 times (counts saturate at 65 535), one list / one
+    table slot / one owner taking nearly everything -- the appends to ONE super-k-mer list from every lane of the chip at once must
+    neither starve nor give up"""
+    rb = synth_reads(24000, read_len=150, genome_len=20000, seed=77, quality="noisy")
+    bases = rb.bases.copy().reshape(rb.n, 150)
+    quals = rb.quals.copy().reshape(rb.n, 150)
+    bases[0::3] = ord("A")
+    bases[1::3, 0::2] = ord("A")
+    bases[1::3, 1::2] = ord("C")
+    quals[0::3] = ord("I")
+    quals[1::3] = ord("5")
+    rb = type(rb).from_arrays(bases.reshape(-1), quals.reshape(-1), rb.offsets)
+    cfg = default_config(31, estimated_raw_kmers=24000 * 120)
+    o, p = run_both(cfg, rb, mode=mode)
+    assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False, saturated_dir_free=True) == o.stats()["weak_entries"]
