@@ -94,7 +94,15 @@ __global__ void sk_close_kernel(const unsigned long long *state, uint64_t n, uin
  * the value it saw), takes a new chunk from its wavefront's slab and publishes it with its own g already booked; adders that
  * arrive in between see a fill beyond the end and try again.  Records never straddle chunks.  Returns the granule index
  * in the pool (chunk * SK_CHUNK_G + offset) or ~0 when the pool is exhausted (error flagged). */
-struct SkSlab { uint32_t base[2]; uint32_t next; uint32_t pad; };       /* per wavefront, in LDS: two slabs of 64 chunks */
+/* per wavefront, in LDS: two slabs of 64 chunks, and the wavefront's HOT LIST.  A list's word lets a chunk's worth of appends through
+ * per round trip (~10^7 records per second): a homopolymer or a repeat that sends more than that to one list (2 % poly-A reads in
+ * a C2 batch: 2 x 10^5 records in 10 ms, every lane of the chip retrying on one word, 700 ms) would stall the whole pass.  A lane
+ * whose booking has failed SK_HOT_AFTER times makes that list the hot list of its wavefront: from then on the wavefront appends
+ * its records for that list to a chain of chunks of its own through a word in LDS (64 contenders instead of 10^5) and hands the
+ * chunks to the list closed -- a list is the set of chunks that name it, only shared appends need its word. */
+struct SkSlab { uint32_t base[2]; uint32_t next; uint32_t hot_list; unsigned long long hot_state; };
+static const uint32_t SK_NO_LIST = 0xffffffffu, SK_LIST_LOCKED = 0xfffffffeu;
+static const int SK_HOT_AFTER = 3;
 __device__ __forceinline__ uint32_t sk_alloc_chunk(SkSlab *slab, const PoolView &pool) {
 	const uint32_t idx = atomicAdd(&slab->next, 1u);
 	uint32_t c;
@@ -119,12 +127,45 @@ __device__ __forceinline__ uint64_t sk_append_settle(unsigned long long *state, 
 	waits = true;
 	return ~0ull;
 }
+/* append to the wavefront's own chain for its hot list (the caller has seen slab->hot_list == list) */
+__device__ __forceinline__ uint64_t sk_append_hot(SkSlab *slab, uint32_t list, uint32_t g, const PoolView &pool) {
+	for (int spin = 0; spin < 4096; spin++) {
+		const unsigned long long old = atomicAdd(&slab->hot_state, (unsigned long long)g);
+		const uint32_t c = (uint32_t)(old >> 32), f = (uint32_t)old;
+		if (f + g <= SK_CHUNK_G) return (uint64_t)c * SK_CHUNK_G + f;
+		if (f <= SK_CHUNK_G) {                     /* crossed the end: close the chunk, open the next */
+			pool.chunk_count[c] = f;
+			const uint32_t c2 = sk_alloc_chunk(slab, pool);
+			if (c2 == NO_CHUNK) return ~0ull;
+			pool.chunk_list[c2] = list; pool.chunk_count[c2] = 0;
+			atomicExch(&slab->hot_state, ((unsigned long long)c2 << 32) | g);
+			return (uint64_t)c2 * SK_CHUNK_G;
+		}
+		/* a lane of this wavefront is replacing the chunk in this very iteration: again */
+	}
+	atomicOr(pool.err, (uint32_t)ERR_POOL_FULL);
+	return ~0ull;
+}
 __device__ __forceinline__ uint64_t sk_append(unsigned long long *state, uint32_t list, uint32_t g, SkSlab *slab, const PoolView &pool) {
 	unsigned long long *word = state + list;
 	/* (every round of a contended list lets a chunk's worth of adders through: with all the chip's lanes on ONE list -- reads that are
 	 * one long homopolymer -- a lane may lose some thousand rounds before it is its turn; the bound only has to end a build whose pool
 	 * is gone) */
 	for (int spin = 0; spin < (1 << 22); spin++) {
+		if (spin >= SK_HOT_AFTER) {
+			uint32_t hl = slab->hot_list;
+			if (hl == SK_NO_LIST && atomicCAS(&slab->hot_list, SK_NO_LIST, SK_LIST_LOCKED) == SK_NO_LIST) {
+				const uint32_t c2 = sk_alloc_chunk(slab, pool);
+				if (c2 == NO_CHUNK) { slab->hot_list = SK_NO_LIST; return ~0ull; }
+				pool.chunk_list[c2] = list; pool.chunk_count[c2] = 0;
+				slab->hot_state = ((unsigned long long)c2 << 32) | g;        /* this record first */
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__hip_atomic_store(&slab->hot_list, list, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				return (uint64_t)c2 * SK_CHUNK_G;
+			}
+			hl = __hip_atomic_load(&slab->hot_list, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (hl == list) return sk_append_hot(slab, list, g, pool);
+		}
 		const unsigned long long old = atomicAdd(word, (unsigned long long)g);
 		const uint32_t c = (uint32_t)(old >> 32), f = (uint32_t)old;
 		if (f + g <= SK_CHUNK_G) return (uint64_t)c * SK_CHUNK_G + f;
@@ -189,7 +230,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 	uint32_t *mhr = (uint32_t *)(wb + SK_Q_BYTES + SK_GROUPS * 10 + 8);   /* [SK_WINDOW][64] minimizer hash         */
 	float *wtr = (float *)(mhr + SK_WINDOW * 64);                       /* [SK_WINDOW][64] weight                 */
 	SkSlab *slab = &s_slab[wave];
-	if (lane == 0) { slab->base[0] = atomicAdd(pool.head, 64u); slab->base[1] = atomicAdd(pool.head, 64u); slab->next = 0; }
+	if (lane == 0) { slab->base[0] = atomicAdd(pool.head, 64u); slab->base[1] = atomicAdd(pool.head, 64u); slab->next = 0; slab->hot_list = SK_NO_LIST; slab->hot_state = 0; }
 	__syncthreads();                       /* the only block-wide barrier; waves are independent below */
 
 	const uint32_t k = p.k, m = sp.m;
@@ -332,7 +373,8 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				waits[r] = false; at[r] = ~0ull;
 				if ((q_info[r] >> 31) && !SK_DBG(sp.dbg, 1)) {
 					const uint32_t n = (q_info[r] >> 16) & 0xffu; const bool uni = (q_info[r] >> 24) & 1u;
-					at[r] = sk_append_settle(sp.state, sk_list_of(q_mh[r], sp.list_bits), 1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4), q_booked[r], slab, pool, waits[r]);
+					if ((q_info[r] >> 30) & 1u) at[r] = q_booked[r];
+					else at[r] = sk_append_settle(sp.state, sk_list_of(q_mh[r], sp.list_bits), 1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4), q_booked[r], slab, pool, waits[r]);
 				}
 			}
 #pragma unroll
@@ -684,6 +726,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 			 * weights live in this window's ring). */
 			flush_pending();
 			bool firstRound = true;
+			const uint32_t hotNow = slab->hot_list;      /* read once per window: a stale value only delays the switch to the wavefront's own chain */
 			while (__any(pendC || Srem)) {
 				bool anyNow = false;
 #pragma unroll
@@ -701,7 +744,9 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 					}
 					if ((q_info[r] >> 31) && !SK_DBG(sp.dbg, 1)) {
 						const uint32_t n = (q_info[r] >> 16) & 0xffu; const bool uni = (q_info[r] >> 24) & 1u;
-						q_booked[r] = atomicAdd(sp.state + sk_list_of(q_mh[r], sp.list_bits), (unsigned long long)(1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4)));
+						const uint32_t need = 1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4), myList = sk_list_of(q_mh[r], sp.list_bits);
+						if (myList == hotNow) { q_booked[r] = sk_append_hot(slab, myList, need, pool); q_info[r] |= 1u << 30; }      /* an address, not what a booking add returned */
+						else q_booked[r] = atomicAdd(sp.state + myList, (unsigned long long)need);
 					}
 				}
 				if (!firstRound || __any(anyNow) || __any(pendC || Srem)) flush_pending();      /* more rounds to come, or weights in the ring: settle now */
@@ -731,6 +776,10 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 	{
 		const uint32_t used = slab->next < 128u ? slab->next : 128u;
 		for (uint32_t idx = used + (uint32_t)lane; idx < 128u; idx += 64) { const uint32_t c = slab->base[idx >> 6] + (idx & 63u); if (c < pool.cap) { pool.chunk_list[c] = NO_CHUNK; pool.chunk_count[c] = 0; } }
+	if (lane == 0 && slab->hot_list < SK_LIST_LOCKED) {      /* the open chunk of the wavefront's hot chain */
+		const uint32_t hc = (uint32_t)(slab->hot_state >> 32), hf = (uint32_t)slab->hot_state;
+		if (hc < pool.cap) pool.chunk_count[hc] = hf < SK_CHUNK_G ? hf : SK_CHUNK_G;
+	}
 	}
 	nRaw = wave_sum(nRaw); nGood = wave_sum(nGood);
 	if (lane == 0) { atomicAdd(&p.stats->raw, nRaw); atomicAdd(&p.stats->good, nGood); }
@@ -1396,7 +1445,7 @@ void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t 
 	__shared__ SkSlab s_slab[SK_ADOPT_WAVES];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	SkSlab *slab = &s_slab[wave];
-	if (lane == 0) { slab->base[0] = atomicAdd(pool.head, 64u); slab->base[1] = atomicAdd(pool.head, 64u); slab->next = 0; }
+	if (lane == 0) { slab->base[0] = atomicAdd(pool.head, 64u); slab->base[1] = atomicAdd(pool.head, 64u); slab->next = 0; slab->hot_list = SK_NO_LIST; slab->hot_state = 0; }
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 	const uint64_t wavesPerGrid = (uint64_t)gridDim.x * SK_ADOPT_WAVES;
 	for (uint64_t c = (uint64_t)blockIdx.x * SK_ADOPT_WAVES + wave; c < n_in; c += wavesPerGrid) {
@@ -1423,6 +1472,10 @@ void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t 
 	__builtin_amdgcn_wave_barrier();
 	const uint32_t used = slab->next < 128u ? slab->next : 128u;
 	for (uint32_t idx = used + (uint32_t)lane; idx < 128u; idx += 64) { const uint32_t c = slab->base[idx >> 6] + (idx & 63u); if (c < pool.cap) { pool.chunk_list[c] = NO_CHUNK; pool.chunk_count[c] = 0; } }
+	if (lane == 0 && slab->hot_list < SK_LIST_LOCKED) {      /* the open chunk of the wavefront's hot chain */
+		const uint32_t hc = (uint32_t)(slab->hot_state >> 32), hf = (uint32_t)slab->hot_state;
+		if (hc < pool.cap) pool.chunk_count[hc] = hf < SK_CHUNK_G ? hf : SK_CHUNK_G;
+	}
 }
 
 }  // namespace kmr
