@@ -65,6 +65,7 @@ struct Tuning {
 	int part_blocks = 0;              /* 0 = one partition block per CU */
 	double entry_share = -1.0;        /* >= 0: initial size of the count pass's entry buffers as a share of the records */
 	bool no_lut = false, no_narrow = false, no_l1_state = false, no_stream_lookups = false;
+	uint64_t long_list_chunks = 0;     /* lists of more chunks are counted in pieces (0: 1024) */
 };
 
 struct kmr_handle {
@@ -1401,6 +1402,28 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		if (!bounds.empty()) HIPCHK(h, hipMemcpyAsync(db, bounds.data(), 8 * bounds.size(), hipMemcpyHostToDevice, h->stream));
 		tv.bounds = db; tv.n = (uint32_t)bounds.size(); tv.d_unique = dd; tv.d_single = dd + bounds.size() + 1;
 	}
+	/* long lists (SkLong in kmr_superkmer.hpp): found from the CSR, cut into work items, counted by a second launch into a merge table */
+	SkLong<W> lgMain; lgMain.item_c0 = lgMain.item_c1 = nullptr; lgMain.n_items = 0; lgMain.long_threshold = 0; lgMain.merge.slots = nullptr; lgMain.merge.ext = nullptr; lgMain.merge.log2cap = 0; lgMain.merge_used = nullptr;
+	SkLong<W> lgItems = lgMain;
+	uint64_t n_items = 0, long_chunks = 0;
+	const uint64_t LONG_CHUNKS = h->tune.long_list_chunks ? h->tune.long_list_chunks : 1024, PIECE = LONG_CHUNKS / 2;
+	if (!tracking && nch > LONG_CHUNKS) {
+		const uint64_t cap = (uint64_t)nch / PIECE + 2 * 1024 + 16;
+		uint64_t *ic0 = nullptr, *ic1 = nullptr; unsigned long long *dn = nullptr;
+		rc = arena_get(h, &ic0, cap); if (rc) return rc; rc = arena_get(h, &ic1, cap); if (rc) return rc; rc = arena_get(h, &dn, 1); if (rc) return rc;
+		HIPCHK(h, hipMemsetAsync(dn, 0, 8, h->stream));
+		hipLaunchKernelGGL(sk_long_items_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, ls, nl, LONG_CHUNKS, PIECE, ic0, ic1, cap, dn);
+		HIPCHK(h, hipGetLastError());
+		unsigned long long hn = 0;
+		HIPCHK(h, hipMemcpyAsync(&hn, dn, 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
+		if (hn > cap) return fail(h, KMR_ERR_CAPACITY, "long-list work items (internal sizing error)");
+		n_items = hn; long_chunks = n_items * PIECE;
+		if (n_items) {
+			lgMain.long_threshold = LONG_CHUNKS;
+			lgItems.item_c0 = ic0; lgItems.item_c1 = ic1; lgItems.n_items = n_items; lgItems.merge_used = dn;
+		}
+	}
+	uint32_t merge_log2 = 16;
 	hipEvent_t tca, tcb; time_begin(h, KMR_TIME_COUNT, &tca, &tcb);
 	for (int attempt = 0; ; attempt++) {
 		if (!h->uw_keys || h->uw_cap < wcap) {
@@ -1423,12 +1446,33 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		if (tracking) HIPCHK(h, hipMemsetAsync(tv.d_unique, 0, 8 * (tv.n + 1), h->stream));
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 		if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, COUNT_THREADS, smem); fprintf(stderr, "sk_count<W=%d>: %d blocks per CU (LDS %zu), %llu lists, %u chunks\n", W, nb, smem, (unsigned long long)nl, nch); }
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lgMain);
 		HIPCHK(h, hipGetLastError());
+		Slot<W> *mslots = nullptr;
+		if (n_items) {
+			/* the merge table holds the distinct keys of the long lists: few when a list is long because a k-mer repeats, at most the
+			 * k-mers of those lists; it starts small and the attempt is repeated with a larger one if it fills */
+			if (hipMalloc((void **)&mslots, sizeof(Slot<W>) << merge_log2) != hipSuccess) return fail(h, KMR_ERR_OOM, "merge table of the long lists");
+			hipLaunchKernelGGL(table_clear_kernel<W>, dim3(grid_for(1ull << merge_log2)), dim3(256), 0, h->stream, mslots, (ExtSlot *)nullptr, 1ull << merge_log2);
+			lgItems.merge.slots = mslots; lgItems.merge.ext = nullptr; lgItems.merge.log2cap = merge_log2;
+			HIPCHK(h, hipMemsetAsync(lgItems.merge_used, 0, 8, h->stream));
+			rc = zero_work_counter(h); if (rc) { hipFree(mslots); return rc; }
+			const int grid2 = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, n_items);
+			hipLaunchKernelGGL(kern, dim3(grid2), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lgItems);
+			hipLaunchKernelGGL(sk_merge_emit_kernel<W>, dim3(grid_for(1ull << merge_log2)), dim3(256), 0, h->stream, lgItems.merge, out, f);
+			if (hipGetLastError() != hipSuccess) { hipFree(mslots); return fail(h, KMR_ERR_HIP, "long-list launches"); }
+		}
 		uint32_t cerr = 0;
 		HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(cur, cursors, 16, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(h, hipMemcpyAsync(&cerr, h->derr, 4, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(h, hipStreamSynchronize(h->stream));
+		if (mslots) hipFree(mslots);
+		if (n_items && (cerr & ERR_TABLE_FULL) && merge_log2 < 30) {      /* the merge table filled: again with a larger one */
+			cerr &= ~(uint32_t)(ERR_TABLE_FULL | ERR_ENTRIES_FULL);
+			HIPCHK(h, hipMemcpy(h->derr, &cerr, 4, hipMemcpyHostToDevice));
+			merge_log2 += 3;
+			continue;
+		}
 		if (!(cerr & ERR_ENTRIES_FULL)) break;
 		if ((wcap >= wmax && scap >= smax) || attempt >= 8) { time_end(h, KMR_TIME_COUNT, tca, tcb); time_end(h, 1, ea, eb); return fail(h, KMR_ERR_CAPACITY, "entry buffers of the count pass overflowed at their upper bound (internal sizing error)"); }
 		cerr &= ~(uint32_t)ERR_ENTRIES_FULL;
@@ -1678,6 +1722,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "entry_share") h->tune.entry_share = value;
 	else if (k == "lookup_table") h->tune.no_lut = value == 0;
 	else if (k == "stream_lookups") h->tune.no_stream_lookups = value == 0;
+	else if (k == "long_list_chunks") h->tune.long_list_chunks = value < 2 ? 2 : (uint64_t)value;
 	else if (k == "narrow_tallies") h->tune.no_narrow = value == 0;
 	else if (k == "keep_level1_state") h->tune.no_l1_state = value == 0;
 	else if (k == "superkmer_minimizer") {
@@ -1841,8 +1886,30 @@ template <int W> int lookup_stream_t(kmr_handle *h, const ReadsView &rvAll, uint
 	auto kern = sk_lookup_kernel<W>;
 	const size_t smem = sk_lookup_smem_bytes<W>();
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-	hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, h->ix_start, h->ix_keys, h->ix_counts, position_counts, out_n, h->work_counter);
+	/* long lists in pieces (as in the count pass; here the pieces need no merge) */
+	const uint64_t LONG_CHUNKS = h->tune.long_list_chunks ? h->tune.long_list_chunks : 1024, PIECE = std::max<uint64_t>(1, LONG_CHUNKS / 2);
+	uint64_t n_items = 0; uint64_t *ic0 = nullptr, *ic1 = nullptr; uint32_t *il = nullptr;
+	if (nch > LONG_CHUNKS) {
+		const uint64_t cap = (uint64_t)nch / PIECE + 2 * 1024 + 16;
+		unsigned long long *dn = nullptr;
+		rc = arena_get(h, &ic0, cap); if (rc) return rc; rc = arena_get(h, &ic1, cap); if (rc) return rc; rc = arena_get(h, &il, cap); if (rc) return rc; rc = arena_get(h, &dn, 1); if (rc) return rc;
+		HIPCHK(h, hipMemsetAsync(dn, 0, 8, h->stream));
+		hipLaunchKernelGGL(sk_long_items_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, ls, nl, LONG_CHUNKS, PIECE, ic0, ic1, cap, dn, il);
+		HIPCHK(h, hipGetLastError());
+		unsigned long long hn = 0;
+		HIPCHK(h, hipMemcpyAsync(&hn, dn, 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
+		if (hn > cap) return fail(h, KMR_ERR_CAPACITY, "long-list work items (internal sizing error)");
+		n_items = hn;
+	}
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, h->ix_start, h->ix_keys, h->ix_counts, position_counts, out_n, h->work_counter,
+	                   (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (uint64_t)0, n_items ? LONG_CHUNKS : (uint64_t)0);
 	HIPCHK(h, hipGetLastError());
+	if (n_items) {
+		rc = zero_work_counter(h); if (rc) return rc;
+		hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>((uint64_t)num_cus(h) * 4, n_items)), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, h->ix_start, h->ix_keys, h->ix_counts,
+		                   position_counts, out_n, h->work_counter, (const uint64_t *)ic0, (const uint64_t *)ic1, (const uint32_t *)il, n_items, (uint64_t)0);
+		HIPCHK(h, hipGetLastError());
+	}
 	return 0;
 }
 int lookup_stream(kmr_handle *h, const ReadsView &rv, uint64_t total_bases, uint32_t *position_counts, uint64_t out_n) {

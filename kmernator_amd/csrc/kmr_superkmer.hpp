@@ -823,13 +823,28 @@ static const int SK_STAGE_G = SK_STAGE_CHUNKS * SK_CHUNK_G;    /* 256 granules =
 static const uint32_t SK_LBATCH = 24;
 static const uint32_t SK_DESC_CAP = 160;                       /* chunk descriptors of a batch of lists kept in LDS */
 
+/* Long lists.  A list is counted by one block, and a block gets through ~4 x 10^5 k-mers per millisecond: a minimizer that draws
+ * 10^7 k-mers (a homopolymer, a repeat family) would keep one block busy for tens of milliseconds after the rest of the chip is
+ * done.  Lists of more than long_threshold chunks are therefore left out of the main launch and counted in a second one whose work
+ * items are chunk RANGES of them: every block counts its range in LDS as usual, but instead of emitting entries it adds what its
+ * table holds into a device hash table (the open-addressed table of build_mode 1: count | forward, f64 weight sum, first-sighting
+ * word -- add, add, min), and sk_merge_emit_kernel turns that table into entries.  Ranges of one list share keys; the merge makes
+ * the result the same as if one block had seen the whole list (the f64 sum is formed in another order: within the tolerance). */
+template <int W> struct SkLong {
+	const uint64_t *item_c0, *item_c1;      /* item mode: chunk range of work item i (device); null = the lists of list_start */
+	uint64_t n_items;
+	uint64_t long_threshold;                /* list mode: lists of more chunks than this are skipped (0 = none) */
+	Table<W> merge;                         /* item mode: where the tables go */
+	unsigned long long *merge_used;         /* slots of it claimed so far: beyond 5/8 of the table the launch gives up (ERR_TABLE_FULL) and the host comes back with a larger one */
+};
+
 template <int W, int LOG2S, bool TRACK = false>
 __host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + 2 + (TRACK ? 8 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
 
 template <int W, int LOG2S, bool TRACK = false>
 __global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10 && !TRACK) ? 4 : 1)
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
-                     CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv) {
+                     CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv, SkLong<W> lg) {
 	constexpr int S = 1 << LOG2S;
 	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
 	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
@@ -849,7 +864,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	__shared__ unsigned long long s_wpos, s_wend, s_spos, s_send;
 	__shared__ unsigned long long s_holeW0, s_holeW1, s_holeS0, s_holeS1;
 	__shared__ uint32_t s_stackBits[40], s_stackVal[40];
-	__shared__ unsigned long long s_ls[SK_LBATCH + 1];
+	__shared__ unsigned long long s_c0[SK_LBATCH + 1], s_c1[SK_LBATCH + 1];      /* chunk range of every list (work item) of the batch */
 	__shared__ uint32_t s_dchunk[SK_DESC_CAP];
 	__shared__ uint8_t s_dcount[SK_DESC_CAP];
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -869,30 +884,40 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	const uint4 *poolg = (const uint4 *)pool.base;
 	uint4 pre = make_uint4(0, 0, 0, 0); uint32_t preCount = 0; uint64_t preList = ~0ull;      /* this wavefront's first chunk of the list named */
 
+	const bool itemMode = lg.item_c0 != nullptr;
+	const uint32_t grab = itemMode ? 1u : SK_LBATCH;      /* work items are large: one at a time */
 	for (;;) {
-		if (t == 0) s_list = atomicAdd(work_counter, SK_LBATCH);
+		if (t == 0) s_list = atomicAdd(work_counter, grab);
 		lds_barrier();
 		const uint64_t lfirst = s_list;
-		if (lfirst >= n_lists) break;
-		const uint32_t nl = (uint32_t)(n_lists - lfirst < (uint64_t)SK_LBATCH ? n_lists - lfirst : (uint64_t)SK_LBATCH);
-		if ((uint32_t)t <= nl) s_ls[t] = list_start[lfirst + t];
+		const uint64_t n_work = itemMode ? lg.n_items : n_lists;
+		if (lfirst >= n_work) break;
+		const uint32_t nl = (uint32_t)(n_work - lfirst < (uint64_t)grab ? n_work - lfirst : (uint64_t)grab);
+		if ((uint32_t)t < nl) {
+			uint64_t a, b;
+			if (itemMode) { a = lg.item_c0[lfirst + t]; b = lg.item_c1[lfirst + t]; }
+			else { a = list_start[lfirst + t]; b = list_start[lfirst + t + 1]; if (lg.long_threshold && b - a > lg.long_threshold) b = a; }      /* a long list: the second launch's */
+			s_c0[t] = a; s_c1[t] = b;
+		}
 		lds_barrier();
 		/* the batch's chunk descriptors are contiguous in list_chunks: the first SK_DESC_CAP of them wait in LDS, so that a chunk can be
 		 * requested a whole list ahead without a descriptor load in front of it */
-		const uint64_t dbase = s_ls[0], dend = s_ls[nl];
-		if ((uint64_t)t < dend - dbase && (uint32_t)t < SK_DESC_CAP) { const uint64_t d = list_chunks[dbase + t]; s_dchunk[t] = (uint32_t)d; s_dcount[t] = (uint8_t)(d >> 32); }
+		const uint64_t dbase = itemMode ? s_c0[0] : list_start[lfirst], dend = itemMode ? s_c1[0] : list_start[lfirst + nl];
+		const uint64_t dcached = dend - dbase < (uint64_t)SK_DESC_CAP ? dend - dbase : (uint64_t)SK_DESC_CAP;      /* descriptors [dbase, dbase + dcached) are in LDS (item mode: the first item's) */
+		if ((uint64_t)t < dcached) { const uint64_t d = list_chunks[dbase + t]; s_dchunk[t] = (uint32_t)d; s_dcount[t] = (uint8_t)(d >> 32); }
 		lds_barrier();
 		/* this wavefront's chunk ci: granule `lane` of it (zeros past its fill count) and the fill count */
 		auto fetch = [&](uint64_t ci, uint4 &v, uint32_t &count) {
 			uint32_t chunk;
-			if (ci - dbase < (uint64_t)SK_DESC_CAP) { chunk = s_dchunk[ci - dbase]; count = s_dcount[ci - dbase]; }
+			if (ci - dbase < dcached) { chunk = s_dchunk[ci - dbase]; count = s_dcount[ci - dbase]; }
 			else { const uint64_t d = list_chunks[ci]; chunk = (uint32_t)d; count = (uint32_t)(d >> 32); }
 			v = make_uint4(0, 0, 0, 0);
 			if ((uint32_t)lane < count) v = poolg[(size_t)chunk * SK_CHUNK_G + lane];
 		};
 		for (uint32_t lj = 0; lj < nl; lj++) {
-			const uint64_t c0 = s_ls[lj], c1 = s_ls[lj + 1];
+			const uint64_t c0 = s_c0[lj], c1 = s_c1[lj];
 			if (c0 == c1) continue;
+			if (itemMode && (__hip_atomic_load(out.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ERR_TABLE_FULL)) continue;      /* uniform enough: the launch is void anyway */
 			lds_barrier();
 			if (t == 0) { s_sp = 1; s_stackBits[0] = 0; s_stackVal[0] = 0; }
 			lds_barrier();
@@ -915,7 +940,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				/* this wavefront's first chunk of the next list travels while this list is counted */
 				if (firstPass) {
 					preList = ~0ull;
-					if (lj + 1 < nl) { const uint64_t n0 = s_ls[lj + 1], n1 = s_ls[lj + 2]; if (n0 + wv < n1) { fetch(n0 + wv, pre, preCount); preList = lfirst + lj + 1; } }
+					if (lj + 1 < nl) { const uint64_t n0 = s_c0[lj + 1], n1 = s_c1[lj + 1]; if (n0 + wv < n1) { fetch(n0 + wv, pre, preCount); preList = lfirst + lj + 1; } }
 				}
 				for (uint64_t ci = c0 + wv; ci < c1 && !s_overflow && s_claimed <= LIMIT; ci += SK_STAGE_CHUNKS) {
 					uint4 nxt = make_uint4(0, 0, 0, 0); uint32_t nxtCount = 0;
@@ -1091,6 +1116,34 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				}
 				/* emit: as count_kernel (weak entries from the front of s_kept, singletons from its back) */
 				if (SK_DBG(dbgFlags, 2)) { lds_barrier(); continue; }
+				if (itemMode) {      /* a range of a long list: the table goes into the merge table, entries come from there */
+					for (int i0 = t & ~63; i0 < S; i0 += COUNT_THREADS) {
+						const int i = i0 + lane;
+						const bool used = W == 1 ? tkeys[i] != EMPTY_KEY : tstate[i] == 2;
+						/* multi-word keys are claimed through a state word that a loser polls until the winner has written the key: two
+						 * lanes of one wavefront after the same empty slot would wait on each other forever, so there the lanes of a
+						 * wavefront go one after the other (a handful of keys per item; other wavefronts are no problem) */
+						for (int turn = 0; turn < (W == 1 ? 1 : 64); turn++) {
+							if (used && (W == 1 || lane == turn) && !(__hip_atomic_load(out.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ERR_TABLE_FULL)) {
+								Key<W> key;
+#pragma unroll
+								for (int q = 0; q < W; q++) key.w[q] = tkeys[(size_t)i * W + q];
+								bool claimed;
+								const uint64_t ms = table_find_or_insert<W>(lg.merge, key, part_hash<W>(key.w), claimed);
+								if (claimed && atomicAdd(lg.merge_used, 1ull) > (5ull << lg.merge.log2cap) / 8) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
+								if (ms == ~0ull) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
+								else {
+									Slot<W> *sl = &lg.merge.slots[ms];
+									atomicAdd(&sl->cntfwd, tcnt[i]);
+									atomicAdd(&sl->wsum, twsum[i]);
+									atomicMin(&sl->first, tfirst[i]);
+								}
+							}
+						}
+					}
+					lds_barrier();
+					continue;
+				}
 				if (fastEmit) {       /* only the counts are looked at: a slot is kept from keepFrom sightings on, nothing goes to the singleton map */
 					if (t == 0) uniq += s_claimed;
 #pragma unroll
@@ -1222,6 +1275,72 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	}
 }
 
+/* the merge table of the long lists -> entries, with count_kernel's rules (classify folded into scalars as in sk_count_kernel) */
+template <int W>
+__global__ __launch_bounds__(256)
+void sk_merge_emit_kernel(Table<W> tbl, CountOut out, FinalizeParams f) {
+	const uint32_t vw = 3;
+	const uint32_t singC = f.has_singletons ? (f.min_depth > 1 ? 0u : 2u) : 3u;
+	const uint32_t weakMin = ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1) ? f.min_depth : 0u;
+	const uint64_t cap = 1ull << tbl.log2cap;
+	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;
+	for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < cap; i0 += (uint64_t)gridDim.x * blockDim.x) {      /* whole wavefronts stay together (bucket_count_add) */
+		const uint64_t i = i0 + threadIdx.x;
+		const bool used = i < cap && slot_used<W>(tbl.slots[i]);
+		uint32_t cls = 0; uint64_t bucket = 0;
+		if (used) {
+			const Slot<W> sl = tbl.slots[i];
+			const Key<W> key = slot_key<W>(sl);
+			uint32_t cnt = (uint32_t)sl.cntfwd, fwdc = (uint32_t)(sl.cntfwd >> 32);
+			uniq++; if (cnt == 1) single++;
+			cls = (cnt == 1 && singC != 3u) ? singC : (cnt < weakMin ? 0u : 1u);
+			if (cls == 1) {
+				const unsigned long long pos = atomicAdd(out.wcursor, 1ull);
+				if (pos >= out.wcap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); cls = 0; }
+				else {
+					bucket = key_hash<W>(key, f.kb) & (f.nb_weak - 1);
+#pragma unroll
+					for (int q = 0; q < W; q++) out.wkeys[pos * W + q] = key.w[q];
+					if (f.has_singletons && first_forward(sl.first)) fwdc -= 1;
+					if (cnt > 65535u) { cnt = 65535u; if (fwdc > 65534u) fwdc = 65534u; }
+					if (fwdc > 65535u) fwdc = 65535u;
+					uint32_t *v = out.wvals + pos * vw;
+					v[0] = cnt; v[1] = __float_as_uint((float)(f.has_singletons ? sl.wsum + first_weight_shift(sl.first) : sl.wsum)); v[2] = fwdc;
+					keptW++;
+				}
+			} else if (cls == 2) {
+				const unsigned long long pos = atomicAdd(out.scursor, 1ull);
+				if (pos >= out.scap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); cls = 0; }
+				else {
+					bucket = key_hash<W>(key, f.kb) & (f.nb_sing - 1);
+#pragma unroll
+					for (int q = 0; q < W; q++) out.skeys[pos * W + q] = key.w[q];
+					const float wf = (float)sl.wsum;
+					out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
+					keptS++;
+				}
+			}
+		}
+		bucket_count_add(out.weakCount, bucket, cls == 1);
+		bucket_count_add(out.singCount, bucket, cls == 2);
+	}
+	uniq = wave_sum(uniq); single = wave_sum(single); keptW = wave_sum(keptW); keptS = wave_sum(keptS);
+	if ((threadIdx.x & 63) == 0) {
+		if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single);
+		if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS);
+	}
+}
+/* lists of more than `threshold` chunks -> work items of `piece` chunks each (their number through *n_items; nothing is written past cap) */
+__global__ void sk_long_items_kernel(const uint64_t *list_start, uint64_t n_lists, uint64_t threshold, uint64_t piece, uint64_t *item_c0, uint64_t *item_c1, uint64_t cap, unsigned long long *n_items, uint32_t *item_list = nullptr) {
+	for (uint64_t l = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; l < n_lists; l += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t a = list_start[l], b = list_start[l + 1];
+		if (b - a <= threshold) continue;
+		const uint64_t n = (b - a + piece - 1) / piece;
+		const unsigned long long at = atomicAdd(n_items, (unsigned long long)n);
+		for (uint64_t i = 0; i < n && at + i < cap; i++) { item_c0[at + i] = a + i * piece; item_c1[at + i] = a + (i + 1) * piece < b ? a + (i + 1) * piece : b; if (item_list) item_list[at + i] = (uint32_t)l; }
+	}
+}
+
 /* ------------------------------------------------------------------ lookups as a streaming pass (f1) */
 /* ReadSelector::scoreAndTrimReads asks the weak map for the count of every k-mer of every read (getValue, src/ReadSelector.h:924-931;
  * setKmerValues :1060-1090): 1.2 x 10^9 independent lookups per C2 batch, which as random probes of a 2 GB table run at the
@@ -1260,7 +1379,8 @@ template <int W> __host__ __device__ constexpr size_t sk_lookup_smem_bytes() { r
 template <int W>
 __global__ __launch_bounds__(COUNT_THREADS, W == 1 ? 4 : 1)
 void sk_lookup_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
-                      const uint64_t *ix_start, const uint64_t *ix_keys, const uint32_t *ix_counts, uint32_t *out, uint64_t out_n, unsigned int *work_counter) {
+                      const uint64_t *ix_start, const uint64_t *ix_keys, const uint32_t *ix_counts, uint32_t *out, uint64_t out_n, unsigned int *work_counter,
+                      const uint64_t *item_c0, const uint64_t *item_c1, const uint32_t *item_list, uint64_t n_items, uint64_t long_threshold) {
 	constexpr int S = 1 << SKL_LOG2S;
 	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
 	uint64_t *tkeys = (uint64_t *)csm;                                 /* [S][W] */
@@ -1269,22 +1389,33 @@ void sk_lookup_kernel(PoolView pool, const uint64_t *list_start, const uint64_t 
 	uint4 *stage = (uint4 *)(tstate + S);
 	uint8_t *recOf = (uint8_t *)(stage + SK_STAGE_G);
 	__shared__ uint32_t s_list;
-	__shared__ unsigned long long s_ls[SK_LBATCH + 1];
+	__shared__ unsigned long long s_c0[SK_LBATCH], s_c1[SK_LBATCH];
+	__shared__ uint32_t s_lid[SK_LBATCH];
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const uint4 *poolg = (const uint4 *)pool.base;
+	/* a list much longer than the others (a hot minimizer) is answered in pieces, each a work item of a second launch: lookups of
+	 * different records of a list do not depend on each other */
+	const bool itemMode = item_c0 != nullptr;
+	const uint32_t grab = itemMode ? 1u : SK_LBATCH;
+	const uint64_t n_work = itemMode ? n_items : n_lists;
 	for (;;) {
 		lds_barrier();
-		if (t == 0) s_list = atomicAdd(work_counter, SK_LBATCH);
+		if (t == 0) s_list = atomicAdd(work_counter, grab);
 		lds_barrier();
 		const uint64_t lfirst = s_list;
-		if (lfirst >= n_lists) break;
-		const uint32_t nl = (uint32_t)(n_lists - lfirst < (uint64_t)SK_LBATCH ? n_lists - lfirst : (uint64_t)SK_LBATCH);
-		if ((uint32_t)t <= nl) s_ls[t] = list_start[lfirst + t];
+		if (lfirst >= n_work) break;
+		const uint32_t nl = (uint32_t)(n_work - lfirst < (uint64_t)grab ? n_work - lfirst : (uint64_t)grab);
+		if ((uint32_t)t < nl) {
+			uint64_t a, b; uint32_t l;
+			if (itemMode) { a = item_c0[lfirst + t]; b = item_c1[lfirst + t]; l = item_list[lfirst + t]; }
+			else { a = list_start[lfirst + t]; b = list_start[lfirst + t + 1]; l = (uint32_t)(lfirst + t); if (long_threshold && b - a > long_threshold) b = a; }
+			s_c0[t] = a; s_c1[t] = b; s_lid[t] = l;
+		}
 		lds_barrier();
 		for (uint32_t lj = 0; lj < nl; lj++) {
-			const uint64_t c0 = s_ls[lj], c1 = s_ls[lj + 1];
+			const uint64_t c0 = s_c0[lj], c1 = s_c1[lj];
 			if (c0 == c1) continue;
-			const uint64_t e0 = ix_start[lfirst + lj], e1 = ix_start[lfirst + lj + 1];
+			const uint64_t e0 = ix_start[s_lid[lj]], e1 = ix_start[s_lid[lj] + 1];
 			/* a list with more entries than the table takes is answered in passes over its records, one table fill each (a key is in
 			 * exactly one of them) */
 			for (uint64_t eb = e0; eb < e1; eb += SKL_FILL) {

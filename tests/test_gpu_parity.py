@@ -874,7 +874,7 @@ def test_streaming_lookups_equal_table_probes(k, mode):
     odd = synth_reads(12, read_len=12000, genome_len=60000, seed=k + 1, quality="noisy", n_rate=0.001)
     short = synth_reads(50, read_len=k - 1, genome_len=60000, seed=k + 2)
     cfg = default_config(k, estimated_raw_kmers=4000 * 180)
-    a, b = product(cfg, mode, stream_lookups=1), product(cfg, mode, stream_lookups=0)
+    a, b = product(cfg, mode, stream_lookups=1, long_list_chunks=(4 if k == 51 else 1024)), product(cfg, mode, stream_lookups=0)      # k = 51: most lists answered in pieces
     for p in (a, b):
         add(p, rb)
         add(p, odd, first=rb.n)
@@ -905,3 +905,19 @@ def test_low_complexity_reads(mode):
     cfg = default_config(31, estimated_raw_kmers=24000 * 120)
     o, p = run_both(cfg, rb, mode=mode)
     assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False, saturated_dir_free=True) == o.stats()["weak_entries"]
+
+
+@pytest.mark.parametrize("k,chunks", [(31, 2), (51, 3), (27, 16)])
+def test_long_lists_counted_in_pieces(k, chunks):
+    """build_mode 3: a list of more than `long_list_chunks` chunks is counted by several blocks, each over a range of its chunks,
+    whose tables are merged in a device hash table before entries are made.  With the threshold turned down to a few chunks nearly
+    every list of an ordinary input goes that way: the maps must still be the oracle's (the weight sum is formed in another order:
+    the usual tolerance), with and without a singleton map."""
+    rb = synth_reads(20000, read_len=150, genome_len=120000, seed=k, quality="noisy", n_rate=0.002)
+    for kw in (dict(), dict(separate_singletons=0)):
+        cfg = default_config(k, estimated_raw_kmers=20000 * 40, **kw)          # few lists, so that they are long
+        o, p = run_both(cfg, rb, mode=3, long_list_chunks=chunks)
+        assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False) == o.stats()["weak_entries"]
+    cfg = default_config(k, estimated_raw_kmers=20000 * 40)
+    o, p = run_both(cfg, rb, min_depth=1, mode=3, long_list_chunks=chunks)      # singleton map kept
+    assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
