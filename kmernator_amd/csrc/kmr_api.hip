@@ -1214,8 +1214,15 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * sm.nb, h->stream));
 	if (wm.n && vw > 4) hipLaunchKernelGGL((entry_scatter_kernel<W, true>), dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
 	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->hkb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
-	else if (wm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
-	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->hkb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
+	else if (wm.n) {
+		/* lists cut by minimizer (build_mode 3) scatter their entries over unrelated buckets: 64-bit cursors that start at the buckets'
+		 * first entries, one returning add per entry */
+		unsigned long long *cur64 = nullptr;
+		if (h->superkmer_mode && arena_get(h, &cur64, wm.nb) == 0) HIPCHK(h, hipMemcpyAsync(cur64, wm.start, 8 * wm.nb, hipMemcpyDeviceToDevice, h->stream));
+		else cur64 = nullptr;
+		hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
+		                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->hkb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr, cur64, 6);
+	}
 	if (sm.n) hipLaunchKernelGGL(entry_scatter_kernel<W>, dim3(grid_for(sslots)), dim3(256), 0, h->stream, (const uint64_t *)h->us_keys, (const uint32_t *)nullptr,
 	                            (const uint8_t *)h->us_b8, (const uint32_t *)h->us_pkt, sslots, 0u, h->hkb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, h->ext ? sm.spkt : (uint32_t *)nullptr);
 	HIPCHK(h, hipGetLastError());

@@ -1139,7 +1139,7 @@ void count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *lis
 template <int W, bool WIDE = false>
 __global__ void entry_scatter_kernel(const uint64_t *ukeys, const uint32_t *uvals, const uint8_t *ub8, const uint32_t *upkt, uint64_t n,
                                      uint32_t vw, uint32_t kb, uint64_t nb, const uint64_t *start, uint32_t *cursor,
-                                     uint64_t *keys, uint32_t *vals, uint8_t *b8, uint32_t *pkt) {
+                                     uint64_t *keys, uint32_t *vals, uint8_t *b8, uint32_t *pkt, unsigned long long *cursor64 = nullptr, int rounds = 6) {
 	const int lane = (int)(threadIdx.x & 63);
 	for (uint64_t e0 = blockIdx.x * (uint64_t)blockDim.x + (threadIdx.x & ~63u); e0 < n; e0 += (uint64_t)gridDim.x * blockDim.x) {
 		const uint64_t e = e0 + lane;
@@ -1153,7 +1153,21 @@ __global__ void entry_scatter_kernel(const uint64_t *ukeys, const uint32_t *uval
 		}
 		bool done = !live;
 		uint32_t rank = 0;
-		for (int round = 0; round < 6; round++) {
+		/* cursor64 (the entries of a wavefront fall into unrelated buckets: lists cut by minimizer): the cursor of a bucket starts at
+		 * the bucket's first entry, so one returning add gives the position -- no election rounds, no load of start[] */
+		if (cursor64) {
+			if (!WIDE) {
+				if (!live) continue;
+				const uint64_t pos = atomicAdd(&cursor64[b], 1ull);
+#pragma unroll
+				for (int j = 0; j < W; j++) keys[pos * W + j] = key.w[j];
+				if (uvals) for (uint32_t j = 0; j < vw; j++) vals[pos * vw + j] = uvals[e * vw + j];
+				if (ub8) b8[pos] = ub8[e];
+				if (upkt) pkt[pos] = upkt[e];
+				continue;
+			}
+		}
+		for (int round = 0; round < rounds; round++) {
 			const unsigned long long pending = __ballot(!done);
 			if (!pending) break;
 			const int leader = __ffsll((long long)pending) - 1;
