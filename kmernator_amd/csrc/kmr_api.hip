@@ -1304,7 +1304,12 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		/* the list space is the whole job's (with world_size > 1 a rank owns every world_size-th list): sized from the caller's estimate
 		 * of all the k-mers (estimateRawKmers), else from this call's bases times the ranks */
 		const uint64_t est = h->cfg.estimated_raw_kmers ? h->cfg.estimated_raw_kmers : total_bases * std::max<uint32_t>(1, h->cfg.world_size);
-		uint32_t bits = 6; while (bits < 24 && (est >> bits) > h->tune.target_list / 2 + 200) bits++;
+		/* k-mers per list: the list's distinct keys have to fit the 1024-slot table of the count pass (80 %), or the list is redone in
+		 * sub-passes.  At k <= 32 a list of ~1200 k-mers holds ~350 distinct ones in sequencing data; longer k-mers are hit by read
+		 * errors more often (k = 51, 1 % errors: 40 % of the k-mers hold one and are nearly all distinct), so their lists are cut
+		 * half as long (C4: count pass 133 -> 93 ms; another halving costs more in per-list work than it saves) */
+		const uint64_t per_list = (h->tune.target_list == 2048 && W > 1) ? 700 : h->tune.target_list / 2 + 200;
+		uint32_t bits = 6; while (bits < 24 && (est >> bits) > per_list) bits++;
 		h->sk_bits = bits;
 		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8ull << bits));
 		hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(1ull << bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << bits);

@@ -1,5 +1,5 @@
 """development tool: k = 51 (two-word keys) at scale: the default build (super-k-mer lists) and, for the image comparison, the
-device-table build.  usage: tools/c4_check.py [reads] [k] [read_len] [modes e.g. 3,2,1]"""
+device-table build.  usage: tools/c4_check.py [reads] [k] [read_len] [modes e.g. 3,2,1] [knob=value ...]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import torch, numpy as np
@@ -9,12 +9,13 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 51
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 modes = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [3, 1]
+tune = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in sys.argv[5:]}
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 bases, quals, offsets = bench.gen_reads(torch, n, n * L // 30, 3, 0, dev, "flat", read_len=L)
 torch.cuda.synchronize()
 imgs = {}
 for mode in modes:
-    sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (L - k + 1), device=0, build_mode=mode))
+    sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (L - k + 1), device=0, build_mode=mode)).tune(**tune)
     for rep in range(2):
         sp.reset(); sp.kernel_time_reset(); torch.cuda.synchronize(); t0 = time.time()
         sp.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * L, 0)
