@@ -65,6 +65,12 @@ typedef enum kmr_map { KMR_MAP_WEAK = 0, KMR_MAP_SINGLETON = 1, KMR_MAP_SOLID = 
  * GeneralOptions min-quality-score / fastq-base-quality (src/Options.h:327-331),
  * ExtensionTracking::setMinQuality (src/KmerTrackingData.h:157-163) and the bucket
  * sizing of the KmerSpectrum constructor (src/KmerSpectrum.h:414-421, src/Kmer.h:2837,2224). */
+/* Two fields SURVEY section 8(b) sketches are deliberately absent.  num_devices: one handle drives ONE device, as one MPI rank
+ * drives one share of the spectrum in the reference (DistributedKmerSpectrum, src/DistributedFunctions.h:126); a node's N GPUs are
+ * N handles with rank / world_size set (one process or thread each) joined by kmr_exchange_*.  deterministic: results do not
+ * depend on scheduling -- counts, direction biases (global stream ordinals decide the first sighting), singleton bytes and
+ * extension tallies are exact and repeatable; only weightedCount's low bits depend on the order of an f64 atomic sum, inside the
+ * 1e-5 * count the reference's own OpenMP / MPI builds vary by. */
 typedef struct kmr_config {
 	uint32_t struct_size;            /* = sizeof(kmr_config), ABI guard                       */
 	uint32_t k;                      /* k-mer length in bases, 1..128                          */
