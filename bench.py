@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--force-exchange", action="store_true", help="run the owner-exchange path even on one GPU (sanity/timing of the N>1 code)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="development: all ranks share GPU 0 and talk over gloo (RCCL refuses two "
                     "ranks on one device); exercises the N>1 code, its timings mean nothing")
+    ap.add_argument("--exchange-pieces", type=int, default=4, help="N > 1: the batch goes through the list exchange in this many pieces, the all-to-all of one "
+                    "running while the next is extracted")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="kmr_tune knob of the handle (measurement sweeps), e.g. partition_blocks=192")
     ap.add_argument("--no-check", action="store_true", help="development: skip the conservation assert (ablation runs of a debug build)")
     ap.add_argument("--build-mode", type=int, default=0, help="kmr_config.build_mode: 0 auto, 1 device table, 2 two-level k-mer partition, 3 super-k-mer lists")
@@ -224,7 +226,7 @@ def main():
             sp.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n_reads, total_bases, 0)
         elif mode_num == 3:
             build_partitioned_superkmers(sp, bases[:total_bases + 64], quals[:total_bases + 64], offsets, first_read_idx=rank * n_reads, stats=xstats,
-                                         stream_origin=rank * total_bases)
+                                         stream_origin=rank * total_bases, pieces=args.exchange_pieces if world > 1 else 1)
         else:
             build_partitioned(sp, bases, quals, offsets, first_read_idx=rank * n_reads, stats=xstats)
         sp.finalize(2)

@@ -189,7 +189,7 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
     return spectrum
 
 
-def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx=0, group=None, stats=None, stream_origin=None):
+def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx=0, group=None, stats=None, stream_origin=None, pieces=1):
     """The N > 1 build on super-k-mer lists (kmr_config.build_mode = 3, rank / world_size configured): every rank scatters the
     super-k-mers of its own reads into the job's lists on its own GPU (no owner filter), list l belongs to rank l % world, and
     the chunks a rank holds of other ranks' lists travel as they lie -- one all-to-all of (list, granules) pairs and one of the
@@ -199,59 +199,87 @@ def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx
 
     bases / quals: uint8 tensors on the spectrum's device, offsets: int64 tensor [n + 1].  stream_origin: position of this rank's
     first base in the whole input (default: the bases of the lower ranks, found by an all-gather) -- with it the first sighting of
-    a k-mer is the first one in the whole input, as in a serial build, whatever the ranks' timing.  stats (a dict, optional)
-    accumulates "bytes_to_peers", "records_sent" (granules), "chunks", "alltoall_ms"."""
+    a k-mer is the first one in the whole input, as in a serial build, whatever the ranks' timing.  pieces > 1 (the same on every
+    rank): the reads go through in that many pieces and the all-to-all of piece i runs (RCCL's own stream) while the library's
+    stream extracts piece i + 1 -- over xGMI the exchange of a C2 batch takes about as long as its extraction.  stats (a dict,
+    optional) accumulates "bytes_to_peers", "records_sent" (granules), "chunks", "alltoall_ms"."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = bases.device
     n = offsets.numel() - 1
-    total = int(offsets[n].item() - offsets[0].item()) if n else 0
+    nccl = dist.get_backend(group) == "nccl"
+    pieces = max(1, int(pieces))
+    cuts = [min(n, ((n * i // pieces) + 63) // 64 * 64) for i in range(pieces)] + [n]
+    cut_off = [int(x) for x in offsets[torch.tensor(cuts, dtype=torch.int64, device=offsets.device)].cpu().tolist()] if n else [0] * (pieces + 1)
+    total = cut_off[-1] - cut_off[0]
     if stream_origin is None:
-        mine = torch.tensor([total], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        mine = torch.tensor([total], dtype=torch.int64, device=dev if nccl else "cpu")
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine, group=group)
         stream_origin = sum(int(t.item()) for t in every[:rank])
     spectrum.sk_exchange_begin()
-    spectrum.set_stream_origin(stream_origin)
-    if n:
-        spectrum.buildKmerSpectrumDevice(bases.data_ptr(), None if quals is None else quals.data_ptr(), offsets.data_ptr(), n, total, first_read_idx)
-    chunks, granules = spectrum.sk_exchange_counts()
-    send_c = [int(chunks[r]) if r != rank else 0 for r in range(world)]
-    send_g = [int(granules[r]) if r != rank else 0 for r in range(world)]
-    goff, coff, ag, ac = [], [], 0, 0
-    for r in range(world):
-        goff.append(ag)
-        coff.append(ac)
-        ag += send_g[r]
-        ac += send_c[r]
-    data = torch.empty((max(ag, 1), 4), dtype=torch.int32, device=dev)
-    meta = torch.empty((max(ac, 1), 2), dtype=torch.int32, device=dev)
-    spectrum.sk_exchange_pack(data.data_ptr(), meta.data_ptr(), goff, coff)
-    _, recv_c = _exchange_counts(torch.tensor(send_c, dtype=torch.int64, device=dev), group)
-    _, recv_g = _exchange_counts(torch.tensor(send_g, dtype=torch.int64, device=dev), group)
-    timed = None
-    if dev.type == "cuda":
-        timed = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        timed[0].record()
-    got_meta = _all_to_all_sliced(meta[:ac], send_c, recv_c, group)
-    got_data = _all_to_all_sliced(data[:ag], send_g, recv_g, group)
-    if timed:
-        timed[1].record()
-        torch.cuda.synchronize(dev)
-    if sum(recv_c):
-        spectrum.sk_exchange_adopt(got_data.data_ptr(), got_meta.data_ptr(), sum(recv_c), sum(recv_g))
-    if stats is not None:
-        stats["chunks"] = stats.get("chunks", 0) + sum(send_c)
-        stats["records_sent"] = stats.get("records_sent", 0) + sum(send_g)
-        stats["bytes_to_peers"] = stats.get("bytes_to_peers", 0) + 16 * sum(send_g) + 8 * sum(send_c)
-        if timed:
-            stats["alltoall_ms"] = stats.get("alltoall_ms", 0.0) + timed[0].elapsed_time(timed[1])
+
+    def start(i):
+        """close piece i's lists, pack what belongs to others, exchange the counts, set the two all-to-alls going"""
+        chunks, granules = spectrum.sk_exchange_counts()
+        send_c = [int(chunks[r]) if r != rank else 0 for r in range(world)]
+        send_g = [int(granules[r]) if r != rank else 0 for r in range(world)]
+        goff, coff, ag, ac = [], [], 0, 0
+        for r in range(world):
+            goff.append(ag)
+            coff.append(ac)
+            ag += send_g[r]
+            ac += send_c[r]
+        data = torch.empty((max(ag, 1), 4), dtype=torch.int32, device=dev)
+        meta = torch.empty((max(ac, 1), 2), dtype=torch.int32, device=dev)
+        spectrum.sk_exchange_pack(data.data_ptr(), meta.data_ptr(), goff, coff)
+        _, recv_c = _exchange_counts(torch.tensor(send_c, dtype=torch.int64, device=dev), group)
+        _, recv_g = _exchange_counts(torch.tensor(send_g, dtype=torch.int64, device=dev), group)
+        timed = None
+        if dev.type == "cuda":
+            timed = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            timed[0].record()
+        works = []
+        got_meta = _all_to_all_sliced(meta[:ac], send_c, recv_c, group, works=works if pieces > 1 else None)
+        got_data = _all_to_all_sliced(data[:ag], send_g, recv_g, group, works=works if pieces > 1 else None)
+        if stats is not None:
+            stats["chunks"] = stats.get("chunks", 0) + sum(send_c)
+            stats["records_sent"] = stats.get("records_sent", 0) + sum(send_g)
+            stats["bytes_to_peers"] = stats.get("bytes_to_peers", 0) + 16 * sum(send_g) + 8 * sum(send_c)
+        return dict(meta=got_meta, data=got_data, recv_c=recv_c, recv_g=recv_g, works=works, timed=timed, keep=(data, meta))
+
+    def finish(x):
+        """wait for the piece's all-to-alls, append what arrived to this rank's lists"""
+        for w in x["works"]:
+            w[0].wait()
+        if x["timed"]:
+            x["timed"][1].record()
+            torch.cuda.synchronize(dev)
+            if stats is not None:
+                stats["alltoall_ms"] = stats.get("alltoall_ms", 0.0) + x["timed"][0].elapsed_time(x["timed"][1])
+        if sum(x["recv_c"]):
+            spectrum.sk_exchange_adopt(x["data"].data_ptr(), x["meta"].data_ptr(), sum(x["recv_c"]), sum(x["recv_g"]))
+
+    pending = None
+    for i in range(pieces):
+        lo, hi = cuts[i], cuts[i + 1]
+        if hi > lo:
+            # the handle adds a call's bases to its stream position; the offsets handed in are absolute, so the origin stays put
+            spectrum.set_stream_origin(stream_origin)
+            spectrum.buildKmerSpectrumDevice(bases.data_ptr(), None if quals is None else quals.data_ptr(), offsets.data_ptr() + 8 * lo, hi - lo,
+                                             cut_off[i + 1] - cut_off[i], first_read_idx + lo)
+        if pending is not None:
+            finish(pending)
+        pending = start(i)
+    finish(pending)
     return spectrum
 
 
-def _all_to_all_sliced(send, send_split, recv_split, group=None, max_rows=None):
+def _all_to_all_sliced(send, send_split, recv_split, group=None, max_rows=None, works=None):
     """_all_to_all_flat in slices, so that no single message exceeds MAX_CHUNK_BYTES (see there); every rank runs the same number of
-    slices.  send: [sum(send_split), words] rows grouped by destination; returns the received rows grouped by source."""
+    slices.  send: [sum(send_split), words] rows grouped by destination; returns the received rows grouped by source.  works (a
+    list, RCCL only): the collectives are started with async_op and (work, tensors to keep alive) pairs are appended to it -- the
+    returned tensor is complete once every work has been waited for (a single slice only; more slices run one after the other)."""
     world = len(send_split)
     words = send.shape[1] if send.dim() > 1 else 1
     if max_rows is None:
@@ -267,6 +295,9 @@ def _all_to_all_sliced(send, send_split, recv_split, group=None, max_rows=None):
             host = torch.empty(got.shape, dtype=got.dtype)
             dist.all_to_all_single(host, piece.cpu().contiguous(), output_split_sizes=rs, input_split_sizes=ss, group=group)
             got.copy_(host)
+        elif works is not None and slices == 1:
+            src = piece.contiguous()
+            works.append((dist.all_to_all_single(got, src, output_split_sizes=rs, input_split_sizes=ss, group=group, async_op=True), (src, got)))
         else:
             dist.all_to_all_single(got, piece.contiguous(), output_split_sizes=rs, input_split_sizes=ss, group=group)
         return got

@@ -115,7 +115,7 @@ def _worker_sk(rank, world, port, tmp, k):
         to = torch.from_numpy(rb.offsets.astype(np.int64)).to(dev)
         sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0, rank=rank, world_size=world, build_mode=3))
         xs = {}
-        build_partitioned_superkmers(sp, tb, tq, to, first_read_idx=lo, stats=xs)
+        build_partitioned_superkmers(sp, tb, tq, to, first_read_idx=lo, stats=xs, pieces=1 if world == 2 else 3)      # three ranks: in three pieces
         sp.finalize(2)
         np.save(os.path.join(tmp, "image.%d.npy" % rank), sp.image(KMR_MAP_WEAK))
         st = sp.stats()
