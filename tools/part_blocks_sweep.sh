@@ -1,5 +1,6 @@
+# the k-mer partition (build_mode 2) with 128 / 160 / 192 / 256 partition blocks: how its two passes scale with the CUs they run on
 for pb in 128 160 192 256; do
-  KMR_PART_BLOCKS=$pb python bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/pb_$pb.json 2> gpurun_out/pb_$pb.err || exit 1
+  python bench.py --steps 3 --warmup 1 --no-cpu --no-h2d --build-mode 2 --tune partition_blocks=$pb > gpurun_out/pb_$pb.json 2> gpurun_out/pb_$pb.err || exit 1
   python - <<PY
 import json
 d=json.load(open("gpurun_out/pb_$pb.json"))
