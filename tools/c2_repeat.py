@@ -14,7 +14,7 @@ p = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0)
 bad = 0
 for rep in range(reps):
     seed = 1 + rep % nseeds
-    bases, quals, offsets = bench.gen_reads(n, 5 * n, seed, 0, dev)
+    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, seed, 0, dev)
     torch.cuda.synchronize()
     if rep % 5 == 4:
         p = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0))   # fresh handle, recycled memory

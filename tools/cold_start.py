@@ -7,7 +7,7 @@ import bench
 import kmernator_amd as ka
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 dev = torch.device("cuda", 0)
-bases, quals, offsets = bench.gen_reads(n, 5 * n, 1, 0, dev)
+bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev)
 torch.cuda.synchronize()
 t0 = time.time()
 sp = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0))

@@ -7,7 +7,7 @@ from helpers import KMR_MAP_WEAK, KMR_VALUE_EXT
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 21
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
-bases, quals, offsets = bench.gen_reads(n, 5 * n, 3, 0, dev)
+bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev)
 torch.cuda.synchronize()
 imgs = {}
 for mode in (2, 1):

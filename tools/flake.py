@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 n3 = 3000000
 rb = synth_reads(n3, read_len=150, genome_len=5 * n3, seed=1)
 n = 10_000_000
-bases, quals, offsets = bench.gen_reads(n, 5 * n, 1, 0, dev)
+bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev)
 torch.cuda.synchronize()
 good = None
 for it in range(iters):

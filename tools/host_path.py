@@ -5,7 +5,7 @@ import torch, numpy as np
 import bench, kmernator_amd as ka
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
-bases, quals, offsets = bench.gen_reads(n, 5 * n, 1, 0, dev)
+bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev)
 hb, hq, ho = bases.cpu().numpy(), quals.cpu().numpy(), offsets.cpu().numpy().astype(np.uint64)
 sp = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0))
 for rep in range(3):

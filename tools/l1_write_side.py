@@ -8,7 +8,7 @@ import bench
 import kmernator_amd as ka
 n = 10_000_000
 dev = torch.device("cuda", 0)
-bases, quals, offsets = bench.gen_reads(n, 5 * n, 1, 0, dev)
+bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev)
 torch.cuda.synchronize()
 for same in (0, 1, 64, 192, 1024, 0):
     if same:
