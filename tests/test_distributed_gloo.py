@@ -237,3 +237,107 @@ def test_sliced_all_to_all_and_the_reduces(world):
         mp.spawn(_sliced_worker, args=(world, port, tmp), nprocs=world, join=True)
         texts = [open(os.path.join(tmp, "ok.%d" % r)).read() for r in range(world)]
         assert all(t == texts[0] for t in texts) and texts[0].startswith("Counts, Weights and Directions")
+
+
+# ---------------------------------------------------------------- the list-chunk exchange driver (build_mode 3, N > 1) on the CPU
+class _FakeListSpectrum:
+    """Stands in for a build_mode 3 handle in build_partitioned_superkmers: `extracting` a piece makes, for every other owner, a
+    known number of chunks with a known fill whose granules carry (sender, owner, piece, chunk, granule); pack lays them out as the
+    library does (owner after owner, data and meta in the same order), adopt records what arrives.  What is tested is the driver:
+    pieces, offsets, the two counts exchanges, the sliced all-to-alls, and that meta and data still belong together at the owner."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.piece, self.pending, self.adopted, self.origin, self.begun = rank, world, -1, None, [], [], False
+
+    def sk_exchange_begin(self):
+        self.begun = True
+
+    def set_stream_origin(self, o):
+        self.origin.append(int(o))
+
+    def buildKmerSpectrumDevice(self, b, q, o, n, total, first):
+        self.piece += 1
+        self.pending = {r: [((self.rank * 7 + r * 3 + self.piece * 5 + c) % 64) + 1 for c in range((self.rank + 2 * r + self.piece) % 4 + (1 if n else 0))]
+                        for r in range(self.world)}
+
+    def sk_exchange_counts(self):
+        if self.pending is None:
+            self.pending = {r: [] for r in range(self.world)}
+        ch = np.array([len(self.pending[r]) for r in range(self.world)], dtype=np.uint64)
+        gr = np.array([sum(self.pending[r]) for r in range(self.world)], dtype=np.uint64)
+        return ch, gr
+
+    def sk_exchange_pack(self, data_ptr, meta_ptr, goff, coff):
+        import ctypes as C
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            g, c = goff[r], coff[r]
+            for ci, fill in enumerate(self.pending[r]):
+                meta = np.array([1000 * r + ci, fill], dtype=np.int32)
+                C.memmove(meta_ptr + 8 * c, meta.ctypes.data, 8)
+                gran = np.array([[self.rank, r, self.piece * 100 + ci, gi] for gi in range(fill)], dtype=np.int32)
+                C.memmove(data_ptr + 16 * g, gran.ctypes.data, 16 * fill)
+                g += fill
+                c += 1
+        self.pending = None
+
+    def sk_exchange_adopt(self, data_ptr, meta_ptr, n_chunks, n_granules):
+        import ctypes as C
+        meta = np.zeros((n_chunks, 2), dtype=np.int32)
+        data = np.zeros((n_granules, 4), dtype=np.int32)
+        C.memmove(meta.ctypes.data, meta_ptr, 8 * n_chunks)
+        C.memmove(data.ctypes.data, data_ptr, 16 * n_granules)
+        self.adopted.append((meta, data))
+
+
+def _list_worker(rank, world, port, tmp, pieces):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmernator_amd.distributed import build_partitioned_superkmers
+        n = 500 + 300 * rank
+        offsets = torch.arange(n + 1, dtype=torch.int64) * 100
+        bases = torch.zeros(int(offsets[-1]) + 64, dtype=torch.uint8)
+        sp = _FakeListSpectrum(rank, world)
+        stats = {}
+        build_partitioned_superkmers(sp, bases, bases, offsets, first_read_idx=0, stats=stats, pieces=pieces)
+        assert sp.begun and sp.piece == pieces - 1
+        # global ordinals: this rank starts behind the bases of the lower ranks, and the origin does not move from piece to piece
+        assert sp.origin == [sum(100 * (500 + 300 * r) for r in range(rank))] * pieces
+        # what arrived: from every other rank and every piece exactly the chunks that rank made for this owner, data behind meta
+        got = {}
+        for meta, data in sp.adopted:
+            at = 0
+            for lid, fill in meta:
+                g = data[at:at + fill]
+                at += fill
+                assert lid // 1000 == rank and len(g) == fill and np.all(g[:, 1] == rank) and np.array_equal(g[:, 3], np.arange(fill))
+                sender, tag = int(g[0, 0]), int(g[0, 2])
+                assert np.all(g[:, 0] == sender) and np.all(g[:, 2] == tag) and tag % 100 == lid % 1000
+                got[(sender, tag)] = int(fill)
+            assert at == len(data)
+        want = {}
+        for s in range(world):
+            if s == rank:
+                continue
+            for p in range(pieces):
+                fake = _FakeListSpectrum(s, world)
+                fake.piece = p - 1
+                fake.buildKmerSpectrumDevice(0, 0, 0, 1, 0, 0)
+                for ci, fill in enumerate(fake.pending[rank]):
+                    want[(s, p * 100 + ci)] = fill
+        assert got == want
+        assert stats["bytes_to_peers"] > 0
+        open(os.path.join(tmp, "ok.%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pieces", [(2, 1), (3, 3), (2, 4)])
+def test_list_chunk_exchange_driver(world, pieces):
+    port = 29900 + (os.getpid() % 500) + 10 * world + pieces
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_list_worker, args=(world, port, tmp, pieces), nprocs=world, join=True)
+        assert all(os.path.exists(os.path.join(tmp, "ok.%d" % r)) for r in range(world))
