@@ -865,15 +865,15 @@ def test_million_noisy_reads_against_the_oracle(k):
     o.close()
 
 
-@pytest.mark.parametrize("k,mode", [(21, 2), (31, 3), (51, 3), (95, 1), (127, 3)])
-def test_streaming_lookups_equal_table_probes(k, mode):
+@pytest.mark.parametrize("k,mode,ext", [(21, 2, False), (31, 3, False), (51, 3, False), (95, 1, False), (127, 3, False), (21, 2, True), (31, 1, True)])
+def test_streaming_lookups_equal_table_probes(k, mode, ext):
     """f1 as a streaming pass (reads -> super-k-mers -> minimizer lists, the weak map's entries grouped by the same lists, answers from
     LDS) against the per-k-mer probes: same trims and scores, for reads with N's, reads shorter than k, reads longer than an LDS tile,
     spectra built in any mode (a handle that never made lists sizes them for the batch) and a second batch against the same map."""
     rb = synth_reads(4000, read_len=180, genome_len=60000, seed=k, quality="noisy", n_rate=0.003)
     odd = synth_reads(12, read_len=12000, genome_len=60000, seed=k + 1, quality="noisy", n_rate=0.001)
     short = synth_reads(50, read_len=k - 1, genome_len=60000, seed=k + 2)
-    cfg = default_config(k, estimated_raw_kmers=4000 * 180)
+    cfg = default_config(k, estimated_raw_kmers=4000 * 180, **(dict(value_kind=KMR_VALUE_EXT) if ext else {}))      # extension values: the count heads the 60-byte value too
     a, b = product(cfg, mode, stream_lookups=1, long_list_chunks=(4 if k == 51 else 1024)), product(cfg, mode, stream_lookups=0)      # k = 51: most lists answered in pieces
     for p in (a, b):
         add(p, rb)
