@@ -2931,8 +2931,9 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
 	if (n_chunks == 0) return KMR_OK;
 	hipSetDevice(h->device);
 	rc = sk_ensure_state(h); if (rc) return rc;
-	const int grid = (int)std::min<uint64_t>((n_chunks + SK_ADOPT_WAVES - 1) / SK_ADOPT_WAVES, (uint64_t)num_cus(h) * 8);
-	rc = pool_reserve(h, h->l1, n_granules / SK_CHUNK_G + ((1ull << h->sk_bits) / h->cfg.world_size) + (uint64_t)grid * SK_ADOPT_WAVES * 130 + 64, true); if (rc) return rc;
+	const int grid = (int)std::min<uint64_t>((n_chunks + SK_ADOPT_WAVES * SK_ADOPT_GROUP - 1) / (SK_ADOPT_WAVES * SK_ADOPT_GROUP), (uint64_t)num_cus(h) * 8);
+	/* (a received chunk is appended as one piece: at worst every one of them opens a chunk of its own) */
+	rc = pool_reserve(h, h->l1, n_chunks + n_granules / SK_CHUNK_G + ((1ull << h->sk_bits) / h->cfg.world_size) + (uint64_t)grid * SK_ADOPT_WAVES * 130 + 64, true); if (rc) return rc;
 	uint32_t *cnt = nullptr; uint64_t *start = nullptr;
 	HIPCHK(h, hipMalloc((void **)&cnt, 4 * (n_chunks + 1))); HIPCHK(h, hipMalloc((void **)&start, 8 * (n_chunks + 1)));
 	hipLaunchKernelGGL(sk_meta_counts_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, h->stream, (const uint2 *)dev_meta, n_chunks, cnt);

@@ -1539,25 +1539,48 @@ void sk_owner_count_kernel(const uint32_t *chunk_list, const uint32_t *chunk_cou
 	__syncthreads();
 	if (threadIdx.x < world) { if (lc[threadIdx.x]) { atomicAdd(&chunks[threadIdx.x], lc[threadIdx.x]); atomicAdd(&granules[threadIdx.x], lg[threadIdx.x]); } }
 }
-/* the chunks of other owners -> send buffers (owner after owner), one wavefront per chunk; the chunk leaves the pool */
+/* the chunks of other owners -> send buffers (owner after owner); the chunks leave the pool.  A block takes SK_PACK_TILE chunks: every
+ * thread looks at its chunks and books them in LDS -- ONE word per owner, chunks << 40 | granules, so that a chunk's place among
+ * the (list, granules) pairs and the place of its granules are booked together and the data lies in the order of the pairs -- one
+ * thread per owner then books the tile's totals in the owner's device cursor (a handful of atomics per tile: per chunk they
+ * were 2.6 x 10^6 atomics on `world` addresses, 31 ms for half a C2 batch), and the wavefronts copy chunk after chunk, a granule per
+ * lane. */
+static const int SK_PACK_TILE = 1024;
 __global__ __launch_bounds__(256)
 void sk_pack_kernel(PoolView pool, uint32_t n_chunks, uint32_t world, uint32_t rank, const unsigned long long *granule_base, const unsigned long long *chunk_base,
                     unsigned long long *granule_cursor, unsigned long long *chunk_cursor, uint4 *out_data, uint2 *out_meta) {
-	const int lane = threadIdx.x & 63;
-	const uint64_t wavesPerGrid = (uint64_t)gridDim.x * (blockDim.x >> 6);
-	for (uint64_t c = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c < n_chunks; c += wavesPerGrid) {
-		const uint32_t l = pool.chunk_list[c], cnt = pool.chunk_count[c];
-		if (l == NO_CHUNK || cnt == 0 || l % world == rank) continue;
-		const uint32_t o = l % world;
-		/* ONE cursor per owner, chunks << 40 | granules: the chunk's place among the (list, granules) pairs and the place of its granules
-		 * are booked together, so the data lies in the order of the pairs (the owner finds a chunk's granules by a prefix sum of them) */
-		unsigned long long both = 0;
-		if (lane == 0) both = atomicAdd(&granule_cursor[o], (1ull << 40) | (unsigned long long)cnt);
-		both = ((unsigned long long)(uint32_t)__shfl((int)(both >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)both, 0, 64);
-		const unsigned long long gp = both & ((1ull << 40) - 1), cp = both >> 40;
-		(void)chunk_cursor;
-		if ((uint32_t)lane < cnt) out_data[granule_base[o] + gp + lane] = ((const uint4 *)pool.base)[c * SK_CHUNK_G + lane];
-		if (lane == 0) { out_meta[chunk_base[o] + cp] = make_uint2(l, cnt); pool.chunk_list[c] = NO_CHUNK; pool.chunk_count[c] = 0; }
+	__shared__ unsigned long long s_book[SK_OWNER_MAX], s_base[SK_OWNER_MAX];
+	__shared__ unsigned long long s_at[SK_PACK_TILE];          /* per chunk of the tile: place in the tile's share of its owner (chunks << 40 | granules), ~0 = stays */
+	__shared__ uint32_t s_list[SK_PACK_TILE];
+	__shared__ uint8_t s_cnt[SK_PACK_TILE], s_own[SK_PACK_TILE];
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	(void)chunk_cursor;
+	for (uint64_t tile = (uint64_t)blockIdx.x * SK_PACK_TILE; tile < n_chunks; tile += (uint64_t)gridDim.x * SK_PACK_TILE) {
+		__syncthreads();
+		if (t < (int)SK_OWNER_MAX) s_book[t] = 0;
+		__syncthreads();
+		for (int i = t; i < SK_PACK_TILE; i += 256) {
+			const uint64_t c = tile + i;
+			unsigned long long at = ~0ull; uint32_t l = NO_CHUNK, cnt = 0, o = 0;
+			if (c < n_chunks) {
+				l = pool.chunk_list[c]; cnt = pool.chunk_count[c];
+				if (l != NO_CHUNK && cnt != 0 && l % world != rank) { o = l % world; if (cnt > SK_CHUNK_G) cnt = SK_CHUNK_G; at = atomicAdd(&s_book[o], (1ull << 40) | (unsigned long long)cnt); }
+			}
+			s_at[i] = at; s_list[i] = l; s_cnt[i] = (uint8_t)cnt; s_own[i] = (uint8_t)o;
+		}
+		__syncthreads();
+		if ((uint32_t)t < world) s_base[t] = s_book[t] ? atomicAdd(&granule_cursor[t], s_book[t]) : 0ull;
+		__syncthreads();
+		for (int i = wv; i < SK_PACK_TILE; i += 4) {
+			const unsigned long long at = s_at[i];
+			if (at == ~0ull) continue;
+			const uint64_t c = tile + i;
+			const uint32_t o = s_own[i], cnt = s_cnt[i];
+			const unsigned long long both = s_base[o] + at;          /* chunk and granule fields add up separately (neither overflows its field) */
+			const unsigned long long gp = both & ((1ull << 40) - 1), cp = both >> 40;
+			if ((uint32_t)lane < cnt) out_data[granule_base[o] + gp + lane] = ((const uint4 *)pool.base)[c * SK_CHUNK_G + lane];
+			if (lane == 0) { out_meta[chunk_base[o] + cp] = make_uint2(s_list[i], cnt); pool.chunk_list[c] = NO_CHUNK; pool.chunk_count[c] = 0; }
+		}
 	}
 }
 /* lists of other owners start afresh (their chunks are gone) */
@@ -1568,9 +1591,11 @@ __global__ void sk_state_drop_kernel(unsigned long long *state, uint64_t n, uint
 __global__ void sk_meta_counts_kernel(const uint2 *meta, uint64_t n, uint32_t *counts) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) counts[i] = meta[i].y;
 }
-/* received chunks -> this rank's own lists: one wavefront per chunk, the header lane of every record books room in the record's
- * list and copies its granules */
-static const int SK_ADOPT_WAVES = 4;
+/* received chunks -> this rank's own lists: one wavefront per chunk.  A chunk's records all belong to one list and lie back to
+ * back, so the chunk's used granules are appended as ONE piece (one booking of the list's word; they land behind what the list's
+ * open chunk holds if they fit, else at the head of a fresh chunk) and copied a granule per lane -- booking record by record put 32
+ * lanes of a wavefront on the same word at once (65 ms for half a C2 batch). */
+static const int SK_ADOPT_WAVES = 4, SK_ADOPT_GROUP = 8;
 __global__ __launch_bounds__(SK_ADOPT_WAVES * 64)
 void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t *in_start, uint64_t n_in, SkParams sp, PoolView pool) {
 	__shared__ SkSlab s_slab[SK_ADOPT_WAVES];
@@ -1579,19 +1604,21 @@ void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t 
 	if (lane == 0) { slab->base[0] = atomicAdd(pool.head, 64u); slab->base[1] = atomicAdd(pool.head, 64u); slab->next = 0; slab->hot_list = SK_NO_LIST; slab->hot_state = 0; }
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 	const uint64_t wavesPerGrid = (uint64_t)gridDim.x * SK_ADOPT_WAVES;
-	for (uint64_t c = (uint64_t)blockIdx.x * SK_ADOPT_WAVES + wave; c < n_in; c += wavesPerGrid) {
-		const uint2 m = in_meta[c];
-		const uint32_t list = m.x, cnt = m.y < SK_CHUNK_G ? m.y : SK_CHUNK_G;
-		const uint4 *src = in_data + in_start[c];
-		uint4 cur = make_uint4(0, 0, 0, 0);
-		if ((uint32_t)lane < cnt) cur = src[lane];
-		const uint32_t glen = (cur.y >> 17) & 0x7fu;
-		unsigned long long starts = 0;
-		if (__all((lane & 1) != 0 || (uint32_t)lane >= cnt || glen == 2u)) starts = 0x5555555555555555ull & (cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull));
-		else for (uint32_t pos = 0; pos < cnt; ) { starts |= 1ull << pos; const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos); pos += step ? step : SK_CHUNK_G; }
-		if (((starts >> lane) & 1ull) && glen && (uint32_t)lane + glen <= cnt) {
-			const uint64_t at = sk_append(sp.state, list, glen, slab, pool);
-			if (at != ~0ull) { uint4 *dst = (uint4 *)pool.base + at; dst[0] = cur; for (uint32_t g = 1; g < glen; g++) dst[g] = src[lane + g]; }
+	/* SK_ADOPT_GROUP chunks per wavefront and round: their bookings are made by as many lanes at once (a booking is a round trip to
+	 * a word somewhere in HBM), then the chunks are copied one after the other */
+	for (uint64_t c0 = ((uint64_t)blockIdx.x * SK_ADOPT_WAVES + wave) * SK_ADOPT_GROUP; c0 < n_in; c0 += wavesPerGrid * SK_ADOPT_GROUP) {
+		uint32_t myList = 0, myCnt = 0; unsigned long long myStart = 0, myAt = ~0ull;
+		if (lane < SK_ADOPT_GROUP && c0 + lane < n_in) {
+			const uint2 m = in_meta[c0 + lane];
+			myList = m.x; myCnt = m.y < SK_CHUNK_G ? m.y : SK_CHUNK_G; myStart = in_start[c0 + lane];
+			if (myCnt) myAt = sk_append(sp.state, myList, myCnt, slab, pool);
+		}
+#pragma unroll
+		for (int j = 0; j < SK_ADOPT_GROUP; j++) {
+			const uint32_t cnt = (uint32_t)__shfl((int)myCnt, j, 64);
+			const unsigned long long at = ((unsigned long long)(uint32_t)__shfl((int)(myAt >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)myAt, j, 64);
+			const unsigned long long st = ((unsigned long long)(uint32_t)__shfl((int)(myStart >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)myStart, j, 64);
+			if (at != ~0ull && (uint32_t)lane < cnt) ((uint4 *)pool.base)[at + lane] = in_data[st + lane];
 		}
 		if (slab->next >= 64u) {
 			__builtin_amdgcn_wave_barrier();
