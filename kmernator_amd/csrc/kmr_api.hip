@@ -1416,6 +1416,8 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	}
 	/* long lists (SkLong in kmr_superkmer.hpp): found from the CSR, cut into work items, counted by a second launch into a merge table */
 	SkLong<W> lgMain; lgMain.item_c0 = lgMain.item_c1 = nullptr; lgMain.n_items = 0; lgMain.long_threshold = 0; lgMain.merge.slots = nullptr; lgMain.merge.ext = nullptr; lgMain.merge.log2cap = 0; lgMain.merge_used = nullptr;
+	lgMain.list_first = 0; lgMain.list_stride = 1;
+	if (h->sk_exchange && h->cfg.world_size > 1) { lgMain.list_first = h->cfg.rank; lgMain.list_stride = h->cfg.world_size; }      /* the other lists went to their owners */
 	SkLong<W> lgItems = lgMain;
 	uint64_t n_items = 0, long_chunks = 0;
 	const uint64_t LONG_CHUNKS = h->tune.long_list_chunks ? h->tune.long_list_chunks : 1024, PIECE = LONG_CHUNKS / 2;
@@ -1452,7 +1454,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = nullptr; out.scursor = cursors + 1; out.scap = h->us_cap;
 		out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
 		rc = zero_work_counter(h); if (rc) return rc;
-		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (nl + SK_LBATCH - 1) / SK_LBATCH);
+		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (nl / lgMain.list_stride + SK_LBATCH) / SK_LBATCH);
 		auto kern = tracking ? sk_count_kernel<W, COUNT_LOG2S, true> : sk_count_kernel<W, COUNT_LOG2S, false>;
 		const size_t smem = tracking ? sk_count_smem_bytes<W, COUNT_LOG2S, true>() : sk_count_smem_bytes<W, COUNT_LOG2S, false>();
 		if (tracking) HIPCHK(h, hipMemsetAsync(tv.d_unique, 0, 8 * (tv.n + 1), h->stream));

@@ -834,6 +834,8 @@ template <int W> struct SkLong {
 	const uint64_t *item_c0, *item_c1;      /* item mode: chunk range of work item i (device); null = the lists of list_start */
 	uint64_t n_items;
 	uint64_t long_threshold;                /* list mode: lists of more chunks than this are skipped (0 = none) */
+	uint32_t list_first, list_stride;       /* list mode: the lists looked at are list_first, list_first + list_stride, ... -- after an owner exchange a rank only holds
+	                                           the lists it owns (rank, rank + world, ...), and a job's list space is world times a rank's share */
 	Table<W> merge;                         /* item mode: where the tables go */
 	unsigned long long *merge_used;         /* slots of it claimed so far: beyond 5/8 of the table the launch gives up (ERR_TABLE_FULL) and the host comes back with a larger one */
 };
@@ -890,19 +892,21 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 		if (t == 0) s_list = atomicAdd(work_counter, grab);
 		lds_barrier();
 		const uint64_t lfirst = s_list;
-		const uint64_t n_work = itemMode ? lg.n_items : n_lists;
+		const uint64_t stride = lg.list_stride ? lg.list_stride : 1u;
+		const uint64_t n_work = itemMode ? lg.n_items : (n_lists > lg.list_first ? (n_lists - lg.list_first + stride - 1) / stride : 0);
 		if (lfirst >= n_work) break;
 		const uint32_t nl = (uint32_t)(n_work - lfirst < (uint64_t)grab ? n_work - lfirst : (uint64_t)grab);
 		if ((uint32_t)t < nl) {
 			uint64_t a, b;
 			if (itemMode) { a = lg.item_c0[lfirst + t]; b = lg.item_c1[lfirst + t]; }
-			else { a = list_start[lfirst + t]; b = list_start[lfirst + t + 1]; if (lg.long_threshold && b - a > lg.long_threshold) b = a; }      /* a long list: the second launch's */
+			else { const uint64_t l = lg.list_first + (lfirst + t) * stride; a = list_start[l]; b = list_start[l + 1]; if (lg.long_threshold && b - a > lg.long_threshold) b = a; }      /* a long list: the second launch's */
 			s_c0[t] = a; s_c1[t] = b;
 		}
 		lds_barrier();
 		/* the batch's chunk descriptors are contiguous in list_chunks: the first SK_DESC_CAP of them wait in LDS, so that a chunk can be
 		 * requested a whole list ahead without a descriptor load in front of it */
-		const uint64_t dbase = itemMode ? s_c0[0] : list_start[lfirst], dend = itemMode ? s_c1[0] : list_start[lfirst + nl];
+		/* (with a stride the lists in between hold no chunks -- they went to their owners -- so the batch's descriptors are still one run) */
+		const uint64_t dbase = itemMode ? s_c0[0] : list_start[lg.list_first + lfirst * stride], dend = itemMode ? s_c1[0] : list_start[lg.list_first + (lfirst + nl - 1) * stride + 1];
 		const uint64_t dcached = dend - dbase < (uint64_t)SK_DESC_CAP ? dend - dbase : (uint64_t)SK_DESC_CAP;      /* descriptors [dbase, dbase + dcached) are in LDS (item mode: the first item's) */
 		if ((uint64_t)t < dcached) { const uint64_t d = list_chunks[dbase + t]; s_dchunk[t] = (uint32_t)d; s_dcount[t] = (uint8_t)(d >> 32); }
 		lds_barrier();
