@@ -98,6 +98,7 @@ struct kmr_handle {
 	/* streaming lookups (sk_index_* / sk_lookup_kernel): the weak map's entries grouped by minimizer list, of map generation ix_gen */
 	uint64_t *ix_start = nullptr, *ix_keys = nullptr; uint32_t *ix_counts = nullptr; uint64_t ix_cap = 0, ix_lists = 0, ix_gen = ~0ull;
 	DevStats *scratch_stats = nullptr;
+	uint8_t *adopt_buf = nullptr; size_t adopt_cap = 0;      /* kmr_sk_exchange_adopt_dev's scan */
 	/* size tracker (kmr_config.size_tracker): one record per read fed so far, and the elements made of them at kmr_finalize */
 	SkTrackRec *trk = nullptr; uint64_t trk_cap = 0, trk_n = 0; std::vector<uint64_t> trk_elems;
 	bool sk_fast_div = false;          /* see kmr_create: the chain's divide as multiply-and-correct */
@@ -1659,6 +1660,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->lut) hipFree(h->lut);
 	if (h->xo_dev) hipFree(h->xo_dev);
 	if (h->trk) hipFree(h->trk);
+	if (h->adopt_buf) hipFree(h->adopt_buf);
 	if (h->ix_start) hipFree(h->ix_start); if (h->ix_keys) hipFree(h->ix_keys); if (h->ix_counts) hipFree(h->ix_counts); if (h->scratch_stats) hipFree(h->scratch_stats);
 	exchange_free(h);
 	if (h->stream) hipStreamDestroy(h->stream);
@@ -2936,8 +2938,13 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
 	const int grid = (int)std::min<uint64_t>((n_chunks + SK_ADOPT_WAVES * SK_ADOPT_GROUP - 1) / (SK_ADOPT_WAVES * SK_ADOPT_GROUP), (uint64_t)num_cus(h) * 8);
 	/* (a received chunk is appended as one piece: at worst every one of them opens a chunk of its own) */
 	rc = pool_reserve(h, h->l1, n_chunks + n_granules / SK_CHUNK_G + ((1ull << h->sk_bits) / h->cfg.world_size) + (uint64_t)grid * SK_ADOPT_WAVES * 130 + 64, true); if (rc) return rc;
-	uint32_t *cnt = nullptr; uint64_t *start = nullptr;
-	HIPCHK(h, hipMalloc((void **)&cnt, 4 * (n_chunks + 1))); HIPCHK(h, hipMalloc((void **)&start, 8 * (n_chunks + 1)));
+	/* per-chunk counts and their scan: a grow-only buffer of the handle (a job adopts once per piece and batch) */
+	const size_t need = 8 * (n_chunks + 1) + 4 * (n_chunks + 1) + 256;
+	if (h->adopt_cap < need) {
+		if (h->adopt_buf) { hipStreamSynchronize(h->stream); hipFree(h->adopt_buf); h->adopt_buf = nullptr; h->adopt_cap = 0; }
+		HIPCHK(h, hipMalloc((void **)&h->adopt_buf, need + need / 4)); h->adopt_cap = need + need / 4;
+	}
+	uint64_t *start = (uint64_t *)h->adopt_buf; uint32_t *cnt = (uint32_t *)(h->adopt_buf + 8 * (n_chunks + 1));
 	hipLaunchKernelGGL(sk_meta_counts_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, h->stream, (const uint2 *)dev_meta, n_chunks, cnt);
 	rc = exclusive_scan(h, cnt, n_chunks, start);
 	if (!rc) {
@@ -2945,7 +2952,6 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
 		if (hipGetLastError() != hipSuccess) rc = fail(h, KMR_ERR_HIP, "sk_adopt_kernel launch");
 	}
 	hipStreamSynchronize(h->stream);
-	hipFree(cnt); hipFree(start);
 	return rc ? rc : sync_state(h);
 }
 
