@@ -1098,6 +1098,46 @@ void sort_buckets_kernel(SortView<W> v, const uint64_t *start, uint64_t nb) {
 				if (v.b8) v.b8[lo + rank] = b8;
 				if (v.pkt) v.pkt[lo + rank] = pkt;
 			}
+		} else if (n <= 256) {
+			/* up to four entries per lane (buckets fuller than the 32 per bucket they were sized for: an underestimated k-mer count, or
+			 * -- seen with 80 entries per bucket -- every error k-mer kept): the same rank sort, every key of the bucket read by all
+			 * lanes at once from the (cached) array.  One lane heap-sorting such buckets took 200 ms for 2 x 10^6 of them. */
+			Key<W> key[4];
+			uint32_t vals[4][VW > 0 ? VW : 1];
+			uint8_t b8[4] = {0, 0, 0, 0}; uint32_t pkt[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const uint64_t idx = (uint64_t)lane + 64u * e;
+				const bool have = idx < n;
+#pragma unroll
+				for (int j = 0; j < W; j++) key[e].w[j] = have ? v.keys[(lo + idx) * W + j] : ~0ull;
+				if (have) {
+#pragma unroll
+					for (int j = 0; j < VW; j++) vals[e][j] = v.vals[(lo + idx) * VW + j];
+					if (v.b8) b8[e] = v.b8[lo + idx];
+					if (v.pkt) pkt[e] = v.pkt[lo + idx];
+				}
+			}
+			for (uint32_t i = 0; i < (uint32_t)n; i++) {
+				Key<W> other;
+#pragma unroll
+				for (int j = 0; j < W; j++) other.w[j] = v.keys[(lo + i) * W + j];
+#pragma unroll
+				for (int e = 0; e < 4; e++) rank[e] += (key_lt<W>(other, key[e]) || (key_eq<W>(other, key[e]) && i < (uint32_t)lane + 64u * e)) ? 1u : 0u;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      /* every lane has read every key before any is overwritten */
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				if ((uint64_t)lane + 64u * e < n) {
+#pragma unroll
+					for (int j = 0; j < W; j++) v.keys[(lo + rank[e]) * W + j] = key[e].w[j];
+#pragma unroll
+					for (int j = 0; j < VW; j++) v.vals[(lo + rank[e]) * VW + j] = vals[e][j];
+					if (v.b8) v.b8[lo + rank[e]] = b8[e];
+					if (v.pkt) v.pkt[lo + rank[e]] = pkt[e];
+				}
+			}
 		} else if (lane == 0) {
 			auto sift = [&](uint64_t root, uint64_t end) {
 				for (;;) {
