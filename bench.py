@@ -45,8 +45,10 @@ def parse_args():
     ap.add_argument("--force-exchange", action="store_true", help="run the owner-exchange path even on one GPU (sanity/timing of the N>1 code)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="development: all ranks share GPU 0 and talk over gloo (RCCL refuses two "
                     "ranks on one device); exercises the N>1 code, its timings mean nothing")
-    ap.add_argument("--exchange-pieces", type=int, default=4, help="N > 1: the batch goes through the list exchange in this many pieces, the all-to-all of one "
-                    "running while the next is extracted")
+    ap.add_argument("--exchange-pieces", type=int, default=1, help="N > 1: the batch goes through the list exchange in this many pieces, the all-to-all of one "
+                    "running while the next is extracted.  Default 1: with 10 M reads per rank a rank holds half a chunk for each of the job's "
+                    "lists at 8 ranks, so every further piece sends (and the owner adopts) that many more partly filled chunks "
+                    "(tools/two_rank_step.py: 43.8 ms of compute per step in one piece, 48.4 in two)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="kmr_tune knob of the handle (measurement sweeps), e.g. partition_blocks=192")
     ap.add_argument("--no-check", action="store_true", help="development: skip the conservation assert (ablation runs of a debug build)")
     ap.add_argument("--build-mode", type=int, default=0, help="kmr_config.build_mode: 0 auto, 1 device table, 2 two-level k-mer partition, 3 super-k-mer lists")

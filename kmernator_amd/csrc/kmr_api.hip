@@ -1344,7 +1344,8 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		/* room for this launch: a granule per k-mer is more than any input takes (flat qualities: a quarter of that), one open
 		 * chunk per list and two slabs of 64 chunks per wavefront */
 		const uint64_t bases = m * avg + avg;
-		rc = pool_reserve(h, h->l1, bases / SK_CHUNK_G + (h->l1.base ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * 2 * SK_WAVES * 130 + 64, true); if (rc) return rc;
+		/* (inside an exchange the lists of other owners start afresh after every pack: an open chunk per list for every call) */
+		rc = pool_reserve(h, h->l1, bases / SK_CHUNK_G + ((h->l1.base && !h->sk_exchange) ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * 2 * SK_WAVES * 130 + 64, true); if (rc) return rc;
 		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b); time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
 		SkParams sp = sk_params(h);
 		if (h->cfg.size_tracker) sp.track = h->trk + h->trk_n + r;

@@ -1,7 +1,7 @@
 """development tool: one step of a `world`-rank weak-scaling job (10 M reads per rank) as rank 0 lives it, on ONE GPU: rank 0's handle
 and a stand-in handle for every other rank in turn extract their own reads, pack, and hand each other their segments through device
 memory (no RCCL: the wire is not measured); rank 0 adopts what the others hold for it and finalizes.  Prints what rank 0 spends in
-each phase.  usage: tools/two_rank_step.py [reads per rank] [world]"""
+each phase.  usage: tools/two_rank_step.py [reads per rank] [world] [pieces]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +10,7 @@ import kmernator_amd as ka
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+pieces = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda", 0)
 L = bench.READ_LEN
 mk = lambda r: ka.KmerSpectrum(ka.default_config(bench.K, estimated_raw_kmers=n * 120 * world, device=0, rank=r, world_size=world, build_mode=3))
@@ -17,31 +18,39 @@ me, other = mk(0), mk(1)
 reads = [bench.gen_reads(torch, n, 5 * n * world, 1, r, dev, "flat") for r in range(world)]
 
 def extract_and_pack(h, r, rk):
+    """the rank's batch in `pieces` pieces: extract, counts, pack after each; returns the packed pieces and the time spent"""
     b, q, o = reads[r % len(reads)]
-    h.reset(); h.sk_exchange_begin(); h.set_stream_origin(r * n * L)
-    torch.cuda.synchronize(); t0 = time.time()
-    h.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr(), n, n * L, r * n); h.sync(); t1 = time.time()
-    chunks, granules = h.sk_exchange_counts(); t2 = time.time()
-    sc = [int(c) if i != rk else 0 for i, c in enumerate(chunks)]; sg = [int(g) if i != rk else 0 for i, g in enumerate(granules)]
-    goff = [int(x) for x in np.concatenate([[0], np.cumsum(sg)[:-1]])]; coff = [int(x) for x in np.concatenate([[0], np.cumsum(sc)[:-1]])]
-    data = torch.empty((max(sum(sg), 1), 4), dtype=torch.int32, device=dev); meta = torch.empty((max(sum(sc), 1), 2), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize(); t3 = time.time()
-    h.sk_exchange_pack(data.data_ptr(), meta.data_ptr(), goff, coff); t4 = time.time()
-    return dict(extract=t1 - t0, counts=t2 - t1, pack=t4 - t3, data=data, meta=meta, sc=sc, sg=sg, goff=goff, coff=coff)
+    h.reset(); h.sk_exchange_begin()
+    out = dict(extract=0.0, counts=0.0, pack=0.0, parts=[])
+    for i in range(pieces):
+        lo, hi = n * i // pieces, n * (i + 1) // pieces
+        h.set_stream_origin(r * n * L)
+        torch.cuda.synchronize(); t0 = time.time()
+        h.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr() + 8 * lo, hi - lo, (hi - lo) * L, r * n + lo); h.sync(); t1 = time.time()
+        chunks, granules = h.sk_exchange_counts(); t2 = time.time()
+        sc = [int(c) if j != rk else 0 for j, c in enumerate(chunks)]; sg = [int(g) if j != rk else 0 for j, g in enumerate(granules)]
+        goff = [int(x) for x in np.concatenate([[0], np.cumsum(sg)[:-1]])]; coff = [int(x) for x in np.concatenate([[0], np.cumsum(sc)[:-1]])]
+        data = torch.empty((max(sum(sg), 1), 4), dtype=torch.int32, device=dev); meta = torch.empty((max(sum(sc), 1), 2), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(); t3 = time.time()
+        h.sk_exchange_pack(data.data_ptr(), meta.data_ptr(), goff, coff); t4 = time.time()
+        out["extract"] += t1 - t0; out["counts"] += t2 - t1; out["pack"] += t4 - t3
+        out["parts"].append(dict(data=data, meta=meta, sc=sc, sg=sg, goff=goff, coff=coff))
+    return out
 
 for rep in range(2):
     mine = extract_and_pack(me, 0, 0)
-    adopt = 0.0; got = 0.0
+    adopt = 0.0; got = 0.0; npieces = 0
     for r in range(1, world):
         x = extract_and_pack(other, r, 1)          # the stand-in is configured as rank 1: what it holds for owner 0 is what rank r would hold
-        torch.cuda.synchronize(); t0 = time.time()
-        me.sk_exchange_adopt(x["data"][x["goff"][0]:].data_ptr(), x["meta"][x["coff"][0]:].data_ptr(), x["sc"][0], x["sg"][0]); me.sync()
-        adopt += time.time() - t0; got += 16 * x["sg"][0] / 1e9
+        for part in x["parts"]:
+            torch.cuda.synchronize(); t0 = time.time()
+            me.sk_exchange_adopt(part["data"][part["goff"][0]:].data_ptr(), part["meta"][part["coff"][0]:].data_ptr(), part["sc"][0], part["sg"][0]); me.sync()
+            adopt += time.time() - t0; got += 16 * part["sg"][0] / 1e9; npieces += part["sc"][0]
         del x
     torch.cuda.synchronize(); t0 = time.time()
     me.kernel_time_reset(); me.finalize(2); torch.cuda.synchronize(); t1 = time.time()
     st = me.stats()
-    sent = 16 * sum(mine["sg"]) / 1e9
-    print("rep %d, rank 0 of %d: extract %.1f ms, counts %.1f, pack %.1f (%.2f GB out), adopt %.1f (%.2f GB in), finalize %.1f (count %.1f, buckets %.1f) -> %.1f ms without the wire; %d distinct" % (
-        rep, world, mine["extract"] * 1e3, mine["counts"] * 1e3, mine["pack"] * 1e3, sent, adopt * 1e3, got, (t1 - t0) * 1e3, me.kernel_time(5)[0], me.kernel_time(6)[0],
+    sent = 16 * sum(sum(p["sg"]) for p in mine["parts"]) / 1e9
+    print("rep %d, rank 0 of %d, %d pieces: extract %.1f ms, counts %.1f, pack %.1f (%.2f GB out), adopt %.1f (%.2f GB in, %d chunks), finalize %.1f (count %.1f, buckets %.1f) -> %.1f ms without the wire; %d distinct" % (
+        rep, world, pieces, mine["extract"] * 1e3, mine["counts"] * 1e3, mine["pack"] * 1e3, sent, adopt * 1e3, got, npieces, (t1 - t0) * 1e3, me.kernel_time(5)[0], me.kernel_time(6)[0],
         (mine["extract"] + mine["counts"] + mine["pack"] + adopt + t1 - t0) * 1e3, st["unique_kmers"]), flush=True)
