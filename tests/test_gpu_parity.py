@@ -921,3 +921,30 @@ def test_long_lists_counted_in_pieces(k, chunks):
     cfg = default_config(k, estimated_raw_kmers=20000 * 40)
     o, p = run_both(cfg, rb, min_depth=1, mode=3, long_list_chunks=chunks)      # singleton map kept
     assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+
+
+@pytest.mark.parametrize("mode", [3, 2])
+def test_build_score_reset_build_again(mode):
+    """the streaming lookups borrow the handle's list pool and list state after kmr_finalize: a kmr_reset and a second build on the same
+    handle must not see anything of them (and a second scoring call reuses the list index of the map)"""
+    k = 31
+    rb1 = synth_reads(6000, read_len=150, genome_len=50000, seed=91, quality="noisy", n_rate=0.002)
+    rb2 = synth_reads(5000, read_len=120, genome_len=40000, seed=92, quality="noisy", n_rate=0.002)
+    cfg = default_config(k, estimated_raw_kmers=6000 * 120)
+    p = product(cfg, mode)
+    for rb in (rb1, rb2, rb1):
+        o = OracleSpectrum(cfg)
+        o.add_reads(rb)
+        o.finalize(2)
+        p.reset()
+        add(p, rb)
+        p.finalize(2)
+        assert o.stats() == p.stats()
+        assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False) == o.stats()["weak_entries"]
+        a = p.scoreAndTrimReads(rb.bases, rb.offsets, 2, "MEDIAN")
+        b = p.scoreAndTrimReads(rb2.bases, rb2.offsets, 2, "AVG")
+        counts, off = p.getCountsForReads(rb.bases, rb.offsets)
+        for i in range(0, rb.n, 37):
+            eo, el, es, et = score_and_trim(counts[int(off[i]):int(off[i + 1])], rb.seq(i), k, 2, "MEDIAN")
+            assert (int(a[0][i]), int(a[1][i]), bool(a[3][i])) == (eo, el, et) and abs(float(a[2][i]) - es) <= 1e-5 * max(1.0, abs(es))
+        assert len(b[0]) == rb2.n
