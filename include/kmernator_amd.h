@@ -510,7 +510,8 @@ void *kmr_stream(kmr_handle *h);
  * (0 = one per CU), "entry_share" (initial entry-buffer share of the count pass, < 0 = from the probe), "lookup_table",
  * "narrow_tallies", "keep_level1_state" (1 / 0), "superkmer_minimizer" (minimizer length of build_mode 3, 0 = default),
  * "stream_lookups" (1: kmr_score_* gets its k-mer counts from a streaming pass over minimizer lists where k allows it; 0: per-k-mer
- * probes of the lookup table), "long_list_chunks" (super-k-mer lists of more 1 KB chunks are counted / looked up in pieces, 1024).
+ * probes of the lookup table), "long_list_chunks" (super-k-mer lists of more 1 KB chunks are counted / looked up in pieces, 1024), "coarse_lists" (owner exchange:
+ * 1 = scatter into and exchange coarse lists that the owner splits before the count pass, 0 = the job's fine lists; default 0).
  * Call before the first kmr_add_reads* of a build.  KMR_ERR_INVALID_ARG for an unknown knob. */
 int kmr_tune(kmr_handle *h, const char *knob, double value);
 

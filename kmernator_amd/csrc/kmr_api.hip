@@ -66,6 +66,7 @@ struct Tuning {
 	double entry_share = -1.0;        /* >= 0: initial size of the count pass's entry buffers as a share of the records */
 	bool no_lut = false, no_narrow = false, no_l1_state = false, no_stream_lookups = false;
 	uint64_t long_list_chunks = 0;     /* lists of more chunks are counted in pieces (0: 1024) */
+	bool no_coarse_lists = true;       /* exchange: scatter into the job's fine lists (default) or, kmr_tune("coarse_lists", 1), into coarse ones that the owner splits before the count pass (sk_refine_kernel: not yet fast enough to pay) */
 };
 
 struct kmr_handle {
@@ -126,6 +127,9 @@ struct kmr_handle {
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr, *us_pkt = nullptr; uint64_t uw_cap = 0, us_cap = 0;
 	/* build_mode 3 (kmr_superkmer.hpp): list words, minimizer geometry, table of k-fold quality products */
 	unsigned long long *sk_state = nullptr; uint32_t sk_bits = 0, sk_m = 0, sk_off = 0, sk_win = 0; double *dPk = nullptr;
+	/* exchange with world_size > 1: sk_bits are the COARSE lists reads are scattered into and that travel; each holds 2^sk_fine_shift
+	 * fine lists, made by sk_refine_kernel before the count pass (fine state: sk_fine_state, 2^(sk_bits + sk_fine_shift) words) */
+	uint32_t sk_fine_shift = 0; unsigned long long *sk_fine_state = nullptr; uint64_t sk_fine_cap = 0;
 	uint32_t sk_min_override = 0;
 	/* kmr_extract_by_owner_host: owner segments of one batch kept on the device between the sizing call and the copy-out */
 	/* kmr_exchange_* (kmr_exchange_rccl.hpp): communicator, gather scratch, grow-only send / receive buffers, what the job was fed so far */
@@ -1311,6 +1315,11 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		 * half as long (C4: count pass 133 -> 93 ms; another halving costs more in per-list work than it saves) */
 		const uint64_t per_list = (h->tune.target_list == 2048 && W > 1) ? 700 : h->tune.target_list / 2 + 200;
 		uint32_t bits = 6; while (bits < 24 && (est >> bits) > per_list) bits++;
+		h->sk_fine_shift = 0;
+		if (h->sk_exchange && h->cfg.world_size > 1 && !h->tune.no_coarse_lists) {
+			uint32_t sh = 0; while ((1u << sh) < h->cfg.world_size) sh++;
+			if (bits >= 6 + sh) { h->sk_fine_shift = sh; bits -= sh; }      /* the lists of the wire: as many and as full as one GPU's */
+		}
 		h->sk_bits = bits;
 		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8ull << bits));
 		hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(1ull << bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << bits);
@@ -1371,10 +1380,33 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
 	rc = arena_reset(h); if (rc) return rc;
-	const uint64_t nl = h->sk_state ? 1ull << h->sk_bits : 1;
+	uint64_t nl = h->sk_state ? 1ull << h->sk_bits : 1;
 	if (h->sk_state) {
 		hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);
 		HIPCHK(h, hipGetLastError());
+	}
+	const bool refined = h->sk_state && h->sk_fine_shift > 0;
+	if (refined) {
+		/* the coarse lists this rank owns (its own share and what it adopted) -> fine lists (sk_refine_kernel) */
+		const uint32_t fine_bits = h->sk_bits + h->sk_fine_shift;
+		const uint64_t nlf = 1ull << fine_bits;
+		unsigned int head = 0;
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+		HIPCHK(h, hipMemcpy(&head, h->l1.head, 4, hipMemcpyDeviceToHost));
+		if (head > h->l1.cap) head = h->l1.cap;
+		if (h->sk_fine_cap < nlf) {
+			if (h->sk_fine_state) hipFree(h->sk_fine_state);
+			h->sk_fine_state = nullptr; h->sk_fine_cap = 0;
+			HIPCHK(h, hipMalloc((void **)&h->sk_fine_state, 8 * nlf)); h->sk_fine_cap = nlf;
+		}
+		hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(nlf)), dim3(256), 0, h->stream, h->sk_fine_state, nlf);
+		const int rgrid = (int)std::min<uint64_t>(((uint64_t)head + SK_REFINE_WAVES - 1) / SK_REFINE_WAVES + 1, (uint64_t)num_cus(h) * 8);
+		/* every old chunk's records again, cut into at most 2^shift pieces per chunk (a piece may open a chunk), an open chunk per owned fine list */
+		rc = pool_reserve(h, h->l1, (uint64_t)head * 2 + nlf / h->cfg.world_size + (uint64_t)rgrid * SK_REFINE_WAVES * 130 + 64, true); if (rc) return rc;
+		if (head) hipLaunchKernelGGL(sk_refine_kernel, dim3(rgrid), dim3(SK_REFINE_WAVES * 64), 0, h->stream, pool_view(h, h->l1), head, fine_bits, h->sk_fine_state);
+		hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nlf)), dim3(256), 0, h->stream, h->sk_fine_state, nlf, h->l1.chunk_count, h->l1.cap);
+		HIPCHK(h, hipGetLastError());
+		nl = nlf;
 	}
 	uint64_t *ls = nullptr, *lc = nullptr; uint32_t nch = 0;
 	rc = build_csr(h, h->l1, nl, 0, &ls, &lc, &nch); if (rc) return rc;
@@ -1419,7 +1451,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	/* long lists (SkLong in kmr_superkmer.hpp): found from the CSR, cut into work items, counted by a second launch into a merge table */
 	SkLong<W> lgMain; lgMain.item_c0 = lgMain.item_c1 = nullptr; lgMain.n_items = 0; lgMain.long_threshold = 0; lgMain.merge.slots = nullptr; lgMain.merge.ext = nullptr; lgMain.merge.log2cap = 0; lgMain.merge_used = nullptr;
 	lgMain.list_first = 0; lgMain.list_stride = 1;
-	if (h->sk_exchange && h->cfg.world_size > 1) { lgMain.list_first = h->cfg.rank; lgMain.list_stride = h->cfg.world_size; }      /* the other lists went to their owners */
+	if (h->sk_exchange && h->cfg.world_size > 1 && !refined) { lgMain.list_first = h->cfg.rank; lgMain.list_stride = h->cfg.world_size; }      /* the other lists went to their owners */
 	SkLong<W> lgItems = lgMain;
 	uint64_t n_items = 0, long_chunks = 0;
 	const uint64_t LONG_CHUNKS = h->tune.long_list_chunks ? h->tune.long_list_chunks : 1024, PIECE = LONG_CHUNKS / 2;
@@ -1662,6 +1694,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->xo_dev) hipFree(h->xo_dev);
 	if (h->trk) hipFree(h->trk);
 	if (h->adopt_buf) hipFree(h->adopt_buf);
+	if (h->sk_fine_state) hipFree(h->sk_fine_state);
 	if (h->ix_start) hipFree(h->ix_start); if (h->ix_keys) hipFree(h->ix_keys); if (h->ix_counts) hipFree(h->ix_counts); if (h->scratch_stats) hipFree(h->scratch_stats);
 	exchange_free(h);
 	if (h->stream) hipStreamDestroy(h->stream);
@@ -1740,6 +1773,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "lookup_table") h->tune.no_lut = value == 0;
 	else if (k == "stream_lookups") h->tune.no_stream_lookups = value == 0;
 	else if (k == "long_list_chunks") h->tune.long_list_chunks = value < 2 ? 2 : (uint64_t)value;
+	else if (k == "coarse_lists") h->tune.no_coarse_lists = value == 0;
 	else if (k == "narrow_tallies") h->tune.no_narrow = value == 0;
 	else if (k == "keep_level1_state") h->tune.no_l1_state = value == 0;
 	else if (k == "superkmer_minimizer") {

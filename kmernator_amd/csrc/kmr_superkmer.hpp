@@ -1640,5 +1640,78 @@ void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t 
 	}
 }
 
+/* ------------------------------------------------------------------ coarse lists on the wire, fine lists for the count pass */
+/* In a job of `world` ranks a rank used to scatter its reads into the JOB's fine lists (2^23 of them at 8 ranks x 10 M reads: half a
+ * chunk per list and rank -- slower extraction, half-filled chunks to pack, send and adopt, and no way to send a batch in pieces
+ * without multiplying them).  Now the lists a rank scatters into, exchanges and adopts are COARSE: 2^shift fine lists each (shift =
+ * ceil(log2 world)), as many and as full as on one GPU; the owner of a coarse list is coarse % world, i.e. all its fine lists have
+ * one owner.  Before the count pass the owner splits what it holds: one wavefront per chunk, the records of a chunk grouped by the
+ * fine list their minimizer selects (the low `shift` bits of the fine id vary within a chunk), ONE booking per group -- all groups'
+ * bookings are made at once by their first lanes -- and every record copied to its place in the group's piece. */
+static const int SK_REFINE_WAVES = 4;
+__global__ __launch_bounds__(SK_REFINE_WAVES * 64)
+void sk_refine_kernel(PoolView pool, uint32_t n_before, uint32_t fine_bits, unsigned long long *fine_state) {
+	__shared__ SkSlab s_slab[SK_REFINE_WAVES];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	SkSlab *slab = &s_slab[wave];
+	if (lane == 0) { slab->base[0] = atomicAdd(pool.head, 64u); slab->base[1] = atomicAdd(pool.head, 64u); slab->next = 0; slab->hot_list = SK_NO_LIST; slab->hot_state = 0; }
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+	const uint64_t wavesPerGrid = (uint64_t)gridDim.x * SK_REFINE_WAVES;
+	const uint4 *poolg = (const uint4 *)pool.base;
+	for (uint64_t c = (uint64_t)blockIdx.x * SK_REFINE_WAVES + wave; c < n_before; c += wavesPerGrid) {
+		const uint32_t l = pool.chunk_list[c];
+		uint32_t cnt = pool.chunk_count[c];
+		if (l == NO_CHUNK || cnt == 0) continue;
+		if (cnt > SK_CHUNK_G) cnt = SK_CHUNK_G;
+		uint4 cur = make_uint4(0, 0, 0, 0);
+		if ((uint32_t)lane < cnt) cur = poolg[c * SK_CHUNK_G + lane];
+		const uint32_t glen = (cur.y >> 17) & 0x7fu;
+		unsigned long long starts = 0;
+		if (__all((lane & 1) != 0 || (uint32_t)lane >= cnt || glen == 2u)) starts = 0x5555555555555555ull & (cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull));
+		else for (uint32_t pos = 0; pos < cnt; ) { starts |= 1ull << pos; const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos); pos += step ? step : SK_CHUNK_G; }
+		const bool isRec = ((starts >> lane) & 1ull) && glen && (uint32_t)lane + glen <= cnt;
+		const uint32_t fine = isRec ? sk_list_of(cur.z, fine_bits) : 0u;      /* cur.z: the record's minimizer hash */
+		/* groups: lanes with the same fine list; a lane learns its offset inside the group's piece, the group's total and its first lane */
+		uint32_t goff = 0, gtot = 0; int gfirst = -1;
+		bool done = !isRec;
+		for (int round = 0; round < 64; round++) {
+			const unsigned long long pending = __ballot(!done);
+			if (!pending) break;
+			const int leader = __ffsll((long long)pending) - 1;
+			const uint32_t lf = (uint32_t)__shfl((int)fine, leader, 64);
+			const bool mine = !done && fine == lf;
+			uint32_t incl = mine ? glen : 0u;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += x; }
+			const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			if (mine) { goff = incl - glen; gtot = tot; gfirst = leader; done = true; }
+		}
+		unsigned long long at = ~0ull;
+		if (isRec && gfirst == lane) at = sk_append(fine_state, fine, gtot, slab, pool);      /* every group's first lane at once */
+		const int src = gfirst < 0 ? 0 : gfirst;
+		const unsigned long long gat = ((unsigned long long)(uint32_t)__shfl((int)(at >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)at, src, 64);
+		if (isRec && gat != ~0ull) {
+			uint4 *dst = (uint4 *)pool.base + gat + goff;
+			dst[0] = cur;
+			for (uint32_t g = 1; g < glen; g++) dst[g] = poolg[c * SK_CHUNK_G + lane + g];
+		}
+		__builtin_amdgcn_wave_barrier();
+		if (lane == 0) { pool.chunk_list[c] = NO_CHUNK; pool.chunk_count[c] = 0; }
+		if (slab->next >= 64u) {
+			__builtin_amdgcn_wave_barrier();
+			if (lane == 0) { const uint32_t used = slab->next; slab->base[0] = slab->base[1]; slab->base[1] = atomicAdd(pool.head, 64u); slab->next = used >= 128u ? 64u : used - 64u; }
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	const uint32_t used = slab->next < 128u ? slab->next : 128u;
+	for (uint32_t idx = used + (uint32_t)lane; idx < 128u; idx += 64) { const uint32_t cc = slab->base[idx >> 6] + (idx & 63u); if (cc < pool.cap) { pool.chunk_list[cc] = NO_CHUNK; pool.chunk_count[cc] = 0; } }
+	if (lane == 0 && slab->hot_list < SK_LIST_LOCKED) {
+		const uint32_t hc = (uint32_t)(slab->hot_state >> 32), hf = (uint32_t)slab->hot_state;
+		if (hc < pool.cap) pool.chunk_count[hc] = hf < SK_CHUNK_G ? hf : SK_CHUNK_G;
+	}
+}
+
 }  // namespace kmr
 #endif

@@ -99,7 +99,7 @@ def test_ranks_sharing_one_gpu(world, pipeline):
                 assert np.array_equal(a, b)
 
 
-def _worker_sk(rank, world, port, tmp, k):
+def _worker_sk(rank, world, port, tmp, k, coarse=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -114,6 +114,7 @@ def _worker_sk(rank, world, port, tmp, k):
         tq = torch.from_numpy(np.concatenate([rb.quals, np.zeros(64, np.uint8)])).to(dev)
         to = torch.from_numpy(rb.offsets.astype(np.int64)).to(dev)
         sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0, rank=rank, world_size=world, build_mode=3))
+        sp.tune(coarse_lists=coarse)
         xs = {}
         build_partitioned_superkmers(sp, tb, tq, to, first_read_idx=lo, stats=xs, pieces=1 if world == 2 else 3)      # three ranks: in three pieces
         sp.finalize(2)
@@ -126,17 +127,18 @@ def _worker_sk(rank, world, port, tmp, k):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k", [(2, 31), (3, 51)])
-def test_superkmer_exchange_ranks_sharing_one_gpu(world, k):
+@pytest.mark.parametrize("world,k,coarse", [(2, 31, 0), (3, 51, 0), (3, 31, 1), (2, 51, 1)])
+def test_superkmer_exchange_ranks_sharing_one_gpu(world, k, coarse):
     """The N > 1 build of build_mode 3 (every rank scatters its reads' super-k-mers into the job's lists, the chunks of other
     owners travel, the owner appends them to its lists) with 2 and 3 ranks on this GPU over gloo: the union of the ranks' weak
     maps is the weak map of one spectrum over the same reads -- same keys, counts, direction biases -- every k-mer lives on
     exactly one rank, the statistics add up, and every rank's reads score as on the whole spectrum (a lookup goes to the owner of
-    the k-mer's list, not to its lookup3 owner)."""
+    the k-mer's list, not to its lookup3 owner).  coarse = 1: the ranks scatter into, exchange and adopt coarse lists (2^ceil(log2 world)
+    fine lists each) and the owner splits them before the count pass (kmr_tune "coarse_lists")."""
     import kmernator_amd as ka
     port = 32100 + (os.getpid() % 1500) + world
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker_sk, args=(world, port, tmp, k), nprocs=world, join=True)
+        mp.spawn(_worker_sk, args=(world, port + 17 * coarse, tmp, k, coarse), nprocs=world, join=True)
         rb = _reads()
         multi = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0))
         for r in range(world):
