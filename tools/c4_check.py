@@ -1,7 +1,8 @@
 """development tool: k = 51 (two-word keys) at scale: the default build (super-k-mer lists) and, for the image comparison, the
 device-table build.  usage: tools/c4_check.py [reads] [k] [read_len] [modes e.g. 3,2,1] [knob=value ...]"""
-import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, numpy as np
 import bench, kmernator_amd as ka
 from helpers import KMR_MAP_WEAK
