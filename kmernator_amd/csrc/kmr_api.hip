@@ -27,6 +27,8 @@
 #include "kmr_ingest.hpp"
 #include "kmr_artifact.hpp"
 #include "kmr_superkmer.hpp"
+#define KMR_INSTANCES_EXTERN
+#include "kmr_instances.hpp"      /* the heavy kernels are compiled in kmr_inst_*.hip */
 
 using namespace kmr;
 
@@ -671,7 +673,6 @@ int stage_reads(kmr_handle *h, const char *bases, const char *quals, const uint6
 
 /* ---------------------------------------------------------------------- */
 /* streaming build path (kmr_partition.hpp)                                  */
-const int COUNT_LOG2S = 10;                  /* 1024-slot LDS table per final list (expected ~350 distinct keys) */
 #define TARGET_LIST_RECORDS (h->tune.target_list)      /* records per final list the partition bits aim for (kmr_tune "target_list_records") */
 const double MAX_LIST_DISTINCT = 600.0;       /* distinct keys per final list the 1024-slot table takes comfortably (limit 819) */
 const uint64_t L2_ITEM_CHUNKS = 16384;       /* level-2 work item = up to 1M records of one level-1 list */
@@ -680,7 +681,7 @@ const uint64_t SUB_BATCH_BASES = 1ull << 30;      /* linear records of one sub-b
 size_t rec_bytes(kmr_handle *h) { return h->superkmer_mode ? 16 : 8 * h->W + (h->ext ? 16 : 8); }      /* Record<W> / RecordX<W>; a 16-byte granule of a super-k-mer record */
 /* partition kernel shape: one 1024-thread block per compute unit, 8 records per thread per batch, a
  * 4-record write-combining line per list in LDS (see partition_direct_kernel) */
-const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
+/* (PD_THREADS, PD_RPT, PD_LINE and COUNT_LOG2S: kmr_instances.hpp) */
 /* partition bits per level that keep the per-list book-keeping and lines inside the 160 KB of LDS */
 int max_part_bits(kmr_handle *h) { return rec_bytes(h) <= 24 ? 10 : 9; }
 PoolView pool_view(kmr_handle *h, HostPool &p) { PoolView v; v.base = p.base; v.chunk_list = p.chunk_list; v.chunk_count = p.chunk_count; v.head = p.head; v.cap = p.cap; v.err = h->derr; return v; }

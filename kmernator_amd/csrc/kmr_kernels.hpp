@@ -126,6 +126,7 @@ struct ReadsView {
 };
 
 static const uint32_t UNIT_KMERS = 9216;     /* k-mers per segment: 9 * 1024, and 9216 + 127 bases fit a tile */
+#ifndef KMR_INSTANCE_TU
 __global__ void unit_count_kernel(const uint64_t *offsets, uint64_t n, uint32_t k, uint32_t span, uint32_t *counts, unsigned int *maxLen) {
 	unsigned int mx = 0;
 	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
@@ -138,6 +139,8 @@ __global__ void unit_count_kernel(const uint64_t *offsets, uint64_t n, uint32_t 
 	/* one word serves ~90 M atomics/s: only a wavefront that would raise the maximum it can see touches it */
 	if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(maxLen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxLen, mx);
 }
+#endif
+#ifndef KMR_INSTANCE_TU
 __global__ void unit_fill_kernel(const uint64_t *offsets, uint64_t n, uint32_t k, uint32_t span, const uint64_t *ufirst,
                                  uint64_t *u_start, uint64_t *u_end, uint64_t *u_read) {
 	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
@@ -150,6 +153,7 @@ __global__ void unit_fill_kernel(const uint64_t *offsets, uint64_t n, uint32_t k
 		}
 	}
 }
+#endif
 
 /* ----------------------------------------------------------------------- */
 /* device hash table: AoS slots so one probe touches one 32-byte sector      */
@@ -737,9 +741,11 @@ __global__ void lut_build_kernel(MapView<W> weak, uint64_t n, uint64_t *slots, u
 		}
 	}
 }
+#ifndef KMR_INSTANCE_TU
 __global__ void lut_clear_kernel(uint64_t *slots, uint64_t n_slots, uint32_t stride) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) slots[i * stride] = EMPTY_KEY;
 }
+#endif
 
 template <int W> struct LookupOp {
 	LutView<W> lut;                /* slots == nullptr: search the sorted buckets */
@@ -794,9 +800,11 @@ __global__ void lookup_words_kernel(MapView<W> weak, LutView<W> lut, const uint6
 	}
 }
 /* processRespond (:848-854): the answer to request i belongs to the k-mer at position pos[i] of the read batch */
+#ifndef KMR_INSTANCE_TU
 __global__ void scatter_counts_kernel(const uint32_t *counts, const uint32_t *pos, uint64_t n, uint32_t *position_counts) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) position_counts[pos[i]] = counts[i];
 }
+#endif
 
 /* ReadSelector::scoreAndTrimReads for one read per lane (src/ReadSelector.h:1182-1207): numKmers is cut at the
  * first N/X markup (_setNumKmers :1037-1047), the read is trimmed to the first longest run of k-mers whose count
@@ -849,6 +857,7 @@ __device__ __forceinline__ void score_one_read(const T *cv, uint32_t numKmers, u
  * range too (count_off is an exclusive scan, or the base offsets themselves), copied into LDS as u16; then every lane walks
  * its own read in LDS.  Groups whose counts do not fit the LDS window (long reads) walk them in global memory. */
 static const int SC_WAVES = 3, SC_CAP = 10240;
+#ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(SC_WAVES * 64)
 void score_reads_kernel(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, uint32_t k, const uint32_t *counts,
                         const uint64_t *count_off, float minScore, int scoring, uint32_t *trimOffset, uint32_t *trimLength,
@@ -897,6 +906,7 @@ void score_reads_kernel(const uint8_t *bases, const uint64_t *offsets, uint64_t 
 		}
 	}
 }
+#endif
 
 /* ----------------------------------------------------------------------- */
 /* records -> table (receiver side of the exchange)                           */
@@ -1154,6 +1164,7 @@ void sort_buckets_kernel(SortView<W> v, const uint64_t *start, uint64_t nb) {
 }
 
 /* on-disk image (src/Kmer.h:3143-3159): header + offsets + per bucket {u32 n; keys; values} */
+#ifndef KMR_INSTANCE_TU
 __global__ void image_header_kernel(uint8_t *img, const uint64_t *start, uint64_t nb, uint32_t kb, uint32_t vbytes) {
 	uint64_t *numbers = (uint64_t *)img;
 	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
@@ -1164,6 +1175,7 @@ __global__ void image_header_kernel(uint8_t *img, const uint64_t *start, uint64_
 		for (int j = 0; j < 4; j++) img[off + j] = (uint8_t)(n >> (8 * j));
 	}
 }
+#endif
 template <int W>
 __global__ void image_entries_kernel(uint8_t *img, const uint64_t *start, uint64_t nb, uint32_t kb, uint32_t vbytes,
                                      const uint64_t *keys, const uint32_t *vals, uint32_t vw, const uint8_t *b8, const uint32_t *pkt, uint64_t n) {
@@ -1183,6 +1195,7 @@ __global__ void image_entries_kernel(uint8_t *img, const uint64_t *start, uint64
 	}
 }
 /* inverse: image -> per-bucket counts, then entries */
+#ifndef KMR_INSTANCE_TU
 __global__ void image_counts_kernel(const uint8_t *img, uint64_t nb, uint32_t *counts) {
 	const uint64_t *numbers = (const uint64_t *)img;
 	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
@@ -1192,6 +1205,7 @@ __global__ void image_counts_kernel(const uint8_t *img, uint64_t nb, uint32_t *c
 		counts[b] = n;
 	}
 }
+#endif
 template <int W>
 __global__ void image_unpack_kernel(const uint8_t *img, const uint64_t *start, uint64_t nb, uint32_t kb, uint32_t vbytes,
                                     uint64_t *keys, uint32_t *vals, uint32_t vw, uint8_t *b8, uint32_t *pkt, uint64_t n) {
@@ -1216,10 +1230,12 @@ __global__ void image_unpack_kernel(const uint8_t *img, const uint64_t *start, u
 /* merge of two bucketed maps with the same bucket count (KmerMapByKmerArrayPair::mergeAdd src/Kmer.h:3209-3261 for
  * disjoint key sets, which is what buildKmerSpectrumInParts merges, src/KmerSpectrum.h:1871-1884): entry e of the source
  * map goes to dst_start[b] + shift[b] + (e - src_start[b]); the buckets are sorted afterwards and checked for duplicates. */
+#ifndef KMR_INSTANCE_TU
 __global__ void merge_counts_kernel(const uint64_t *a_start, const uint64_t *b_start, uint64_t nb, uint32_t *counts) {
 	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x)
 		counts[b] = (uint32_t)((a_start[b + 1] - a_start[b]) + (b_start[b + 1] - b_start[b]));
 }
+#endif
 template <int W>
 __global__ void merge_copy_kernel(const uint64_t *src_start, const uint64_t *other_start, bool after_other, uint64_t nb, uint64_t n,
                                   const uint64_t *skeys, const uint32_t *svals, uint32_t vw, const uint8_t *sb8, const uint32_t *spkt,
@@ -1245,6 +1261,7 @@ __global__ void duplicate_keys_kernel(const uint64_t *start, uint64_t nb, const 
 		}
 }
 
+#ifndef KMR_INSTANCE_TU
 __global__ void histogram_kernel(const uint32_t *vals, uint32_t vw, uint64_t n, uint32_t nbins, unsigned long long *counts, double *weights) {
 	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
 		uint32_t c = vals[e * vw] & 0xffffu;
@@ -1253,12 +1270,14 @@ __global__ void histogram_kernel(const uint32_t *vals, uint32_t vw, uint64_t n, 
 		if (weights) atomicAdd(&weights[c], (double)__uint_as_float(vals[e * vw + 1]));
 	}
 }
+#endif
 
 /* KmerSpectrum::Histogram::set/addRecord (src/KmerSpectrum.h:964-974,1036-1056) over the weak map (vals != NULL) or the
  * singleton map (sweight != NULL).  getIdx (:936-938) goes through a 65536-entry table the host fills with its own libm, so
  * the log() that decides a bucket is the one the reference would have used.  Buckets below HIST_LDS (where nearly all
  * entries fall) are accumulated per block in LDS. */
 static const int HIST_LDS = 512;
+#ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(256)
 void ref_histogram_kernel(const uint32_t *vals, uint32_t vw, const uint8_t *sweight, uint64_t n, const uint32_t *idx_of_count,
                           unsigned long long *visits, unsigned long long *visitedCount, double *visitedWeight) {
@@ -1279,10 +1298,12 @@ void ref_histogram_kernel(const uint32_t *vals, uint32_t vw, const uint8_t *swei
 	__syncthreads();
 	for (int i = threadIdx.x; i < HIST_LDS; i += blockDim.x) if (lv[i]) { atomicAdd(&visits[i], (unsigned long long)lv[i]); atomicAdd(&visitedCount[i], lc[i]); atomicAdd(&visitedWeight[i], lw[i]); }
 }
+#endif
 
 /* ----------------------------------------------------------------------- */
 /* exclusive scan u32 -> u64 (bucket sizes -> bucket starts), three launches */
 static const int SCAN_ITEMS = 2048;   /* per block of 256 threads */
+#ifndef KMR_INSTANCE_TU
 __global__ void scan_block_sums_kernel(const uint32_t *in, uint64_t n, unsigned long long *blockSums) {
 	__shared__ unsigned long long red[256];
 	const uint64_t base = (uint64_t)blockIdx.x * SCAN_ITEMS;
@@ -1293,6 +1314,8 @@ __global__ void scan_block_sums_kernel(const uint32_t *in, uint64_t n, unsigned 
 	for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
 	if (threadIdx.x == 0) blockSums[blockIdx.x] = red[0];
 }
+#endif
+#ifndef KMR_INSTANCE_TU
 __global__ void scan_sums_kernel(unsigned long long *blockSums, uint64_t nblocks, unsigned long long *total) {
 	/* single block; sequential over chunks of 256 */
 	__shared__ unsigned long long buf[256];
@@ -1317,6 +1340,8 @@ __global__ void scan_sums_kernel(unsigned long long *blockSums, uint64_t nblocks
 	}
 	if (threadIdx.x == 0) *total = carry;
 }
+#endif
+#ifndef KMR_INSTANCE_TU
 __global__ void scan_apply_kernel(const uint32_t *in, uint64_t n, const unsigned long long *blockSums, uint64_t *out) {
 	__shared__ unsigned long long buf[256];
 	const uint64_t base = (uint64_t)blockIdx.x * SCAN_ITEMS;
@@ -1337,6 +1362,7 @@ __global__ void scan_apply_kernel(const uint32_t *in, uint64_t n, const unsigned
 	for (int j = 0; j < per; j++) { const uint64_t i = base + (uint64_t)threadIdx.x * per + j; if (i < n) out[i] = run; run += local[j]; }
 	if (base + SCAN_ITEMS >= n && threadIdx.x == 255) out[n] = run;   /* total at out[n] */
 }
+#endif
 
 }  // namespace kmr
 #endif

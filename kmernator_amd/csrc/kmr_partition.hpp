@@ -242,10 +242,13 @@ void owner_scatter_kernel(const typename PoolRec<W, EXT>::type *linear, const ui
 
 /* measurement aid: point every tile at the records of one of the first `distinct` tiles (KMR_DEBUG_SAME_TILE = distinct;
  * equal-length reads only: a tile's region is tile_records long) */
+#ifndef KMR_INSTANCE_TU
 __global__ void same_tile_kernel(uint64_t *koff, uint64_t n_tiles, uint64_t distinct, uint64_t tile_records) {
 	for (uint64_t t = distinct + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * blockDim.x) koff[t * 64] = (t % distinct) * tile_records;
 }
+#endif
 /* k-mer capacity of every work unit (a read, or a segment of a long read) */
+#ifndef KMR_INSTANCE_TU
 __global__ void kmer_capacity_kernel(ReadsView rv, uint32_t k, uint32_t *cap) {
 	const uint64_t n = rv.u_start ? rv.n_units : rv.n_reads;
 	for (uint64_t u = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u < n; u += (uint64_t)gridDim.x * blockDim.x) {
@@ -254,6 +257,7 @@ __global__ void kmer_capacity_kernel(ReadsView rv, uint32_t k, uint32_t *cap) {
 		cap[u] = (rv.discarded && rv.discarded[r]) ? 0u : (L >= k ? (uint32_t)(L - k + 1) : 0u);
 	}
 }
+#endif
 
 /* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every global load and store the
  * wavefront has in flight (s_waitcnt vmcnt(0)), which would expose the HBM latency of the prefetched records and
@@ -298,6 +302,7 @@ template <int W, bool EXT, int G> __host__ __device__ inline size_t partition_st
 	return ((((size_t)3 << bits) * 4 + 15) & ~(size_t)15) + ((size_t)G << bits) * sizeof(typename PoolRec<W, EXT>::type);
 }
 /* empty state: no open chunk, nothing waiting */
+#ifndef KMR_INSTANCE_TU
 __global__ void partition_state_init_kernel(uint8_t *state, size_t stride, int bits, uint32_t n_blocks) {
 	const uint32_t P = 1u << bits;
 	for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
@@ -305,6 +310,7 @@ __global__ void partition_state_init_kernel(uint8_t *state, size_t stride, int b
 		for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) { gs[p] = NO_CHUNK; gs[P + p] = 0; gs[2 * P + p] = 0; }
 	}
 }
+#endif
 
 /* ------------------------------------------------------------------ partition kernel */
 /* Per batch (THREADS * RPT records held in registers, RPT per thread):
@@ -634,6 +640,7 @@ void partition_direct_kernel(PartSource<W> S, PoolView out, unsigned int *work_c
  * (block, list). */
 static const int CSR_LDS_LISTS = 4096;
 static const int CSR_THREADS = 256, CSR_ITEMS = 16;       /* chunks per thread */
+#ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(CSR_THREADS)
 void chunk_hist_kernel(const uint32_t *chunk_list, uint32_t n_chunks, uint32_t *list_nchunks, uint32_t nl) {
 	__shared__ uint32_t lh[CSR_LDS_LISTS];
@@ -649,6 +656,8 @@ void chunk_hist_kernel(const uint32_t *chunk_list, uint32_t n_chunks, uint32_t *
 	}
 	if (priv) { __syncthreads(); for (uint32_t i = threadIdx.x; i < nl; i += CSR_THREADS) if (lh[i]) atomicAdd(&list_nchunks[i], lh[i]); }
 }
+#endif
+#ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(CSR_THREADS)
 void chunk_scatter_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, uint32_t first, const uint64_t *list_start,
                           uint32_t *cursor, uint64_t *list_chunks, uint32_t nl) {
@@ -677,8 +686,10 @@ void chunk_scatter_kernel(const uint32_t *chunk_list, const uint32_t *chunk_coun
 		list_chunks[list_start[l] + pos] = ((uint64_t)chunk_count[c] << 32) | (c + first);      /* chunk_list/chunk_count point at chunk `first` */
 	}
 }
+#endif
 
 /* debugging aid (KMR_DEBUG): records held by a pool */
+#ifndef KMR_INSTANCE_TU
 __global__ void pool_records_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, unsigned long long *total, unsigned long long *nvalid) {
 	unsigned long long s = 0, v = 0;
 	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x)
@@ -686,6 +697,7 @@ __global__ void pool_records_kernel(const uint32_t *chunk_list, const uint32_t *
 	s = wave_sum(s); v = wave_sum(v);
 	if ((threadIdx.x & 63) == 0) { atomicAdd(total, s); atomicAdd(nvalid, v); }
 }
+#endif
 
 /* Share of distinct keys among the records, measured on a sample, so the count pass can size its lists: a k-mer's
  * copies all have the same partition order, so the PROBE_SPLIT blocks of probe p scan ONE level-1 list and keep the
@@ -795,6 +807,7 @@ struct CountOut {
  * is the longest list (in chunks of CH records) the narrow instantiation takes; the few longer ones (a k-mer that repeats
  * 10^5 times) go through the wide one in a second launch (list_filter). */
 static const uint64_t COUNT_NARROW_CHUNKS = 65535 / CH;
+#ifndef KMR_INSTANCE_TU
 __global__ void max_list_chunks_kernel(const uint64_t *list_start, uint64_t n_lists, unsigned int *out) {
 	unsigned int m = 0;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_lists; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -806,6 +819,7 @@ __global__ void max_list_chunks_kernel(const uint64_t *list_start, uint64_t n_li
 	for (int off = 32; off > 0; off >>= 1) { const unsigned int x = (unsigned int)__shfl_xor((int)m, off, 64); m = x > m ? x : m; }
 	if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
+#endif
 template <int W, bool EXT, int LOG2S, bool NARROW = false>
 __host__ __device__ constexpr size_t count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (EXT ? (NARROW ? 28 : 52) : 0)); }
 

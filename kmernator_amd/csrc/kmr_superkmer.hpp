@@ -77,10 +77,13 @@ struct SkParams {
  * ordinal = stream ordinal of the run's first k-mer; the others follow by +1. */
 __host__ __device__ __forceinline__ uint32_t sk_base_granules(uint32_t n, uint32_t k) { return (n + k - 1 + 63) / 64; }
 
+#ifndef KMR_INSTANCE_TU
 __global__ void sk_state_init_kernel(unsigned long long *state, uint64_t n) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) state[i] = ((unsigned long long)NO_CHUNK << 32) | SK_CHUNK_G;
 }
+#endif
 /* the open chunk of every list gets its fill count (chunks closed by an append already have theirs) */
+#ifndef KMR_INSTANCE_TU
 __global__ void sk_close_kernel(const unsigned long long *state, uint64_t n, uint32_t *chunk_count, uint32_t cap) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		const unsigned long long s = state[i];
@@ -88,6 +91,7 @@ __global__ void sk_close_kernel(const unsigned long long *state, uint64_t n, uin
 		if (c != NO_CHUNK && c < cap) chunk_count[c] = f < SK_CHUNK_G ? f : SK_CHUNK_G;
 	}
 }
+#endif
 
 /* Reserve g granules in list `list`: lock-free append to a chain of fixed chunks.  The list's word is open chunk << 32 |
  * fill; an atomic add books [fill, fill + g).  The ONE adder that crosses the end of the chunk closes it (its fill count is
@@ -1335,6 +1339,7 @@ void sk_merge_emit_kernel(Table<W> tbl, CountOut out, FinalizeParams f) {
 	}
 }
 /* lists of more than `threshold` chunks -> work items of `piece` chunks each (their number through *n_items; nothing is written past cap) */
+#ifndef KMR_INSTANCE_TU
 __global__ void sk_long_items_kernel(const uint64_t *list_start, uint64_t n_lists, uint64_t threshold, uint64_t piece, uint64_t *item_c0, uint64_t *item_c1, uint64_t cap, unsigned long long *n_items, uint32_t *item_list = nullptr) {
 	for (uint64_t l = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; l < n_lists; l += (uint64_t)gridDim.x * blockDim.x) {
 		const uint64_t a = list_start[l], b = list_start[l + 1];
@@ -1344,6 +1349,7 @@ __global__ void sk_long_items_kernel(const uint64_t *list_start, uint64_t n_list
 		for (uint64_t i = 0; i < n && at + i < cap; i++) { item_c0[at + i] = a + i * piece; item_c1[at + i] = a + (i + 1) * piece < b ? a + (i + 1) * piece : b; if (item_list) item_list[at + i] = (uint32_t)l; }
 	}
 }
+#endif
 
 /* ------------------------------------------------------------------ lookups as a streaming pass (f1) */
 /* ReadSelector::scoreAndTrimReads asks the weak map for the count of every k-mer of every read (getValue, src/ReadSelector.h:924-931;
@@ -1530,6 +1536,7 @@ void sk_lookup_kernel(PoolView pool, const uint64_t *list_start, const uint64_t 
  * _buildKmerSpectrumMPI (src/DistributedFunctions.h:340-458; MPI_Alltoallv, src/MPIBuffer.h:588-600) with ~4 bytes per k-mer on
  * the wire instead of 24 + kb; the owner function is the build's own (a k-mer's minimizer decides), not getDistributedThreadId. */
 static const uint32_t SK_OWNER_MAX = 64;
+#ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(256)
 void sk_owner_count_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, uint32_t world, unsigned long long *chunks, unsigned long long *granules) {
 	__shared__ unsigned long long lc[SK_OWNER_MAX], lg[SK_OWNER_MAX];
@@ -1543,6 +1550,7 @@ void sk_owner_count_kernel(const uint32_t *chunk_list, const uint32_t *chunk_cou
 	__syncthreads();
 	if (threadIdx.x < world) { if (lc[threadIdx.x]) { atomicAdd(&chunks[threadIdx.x], lc[threadIdx.x]); atomicAdd(&granules[threadIdx.x], lg[threadIdx.x]); } }
 }
+#endif
 /* the chunks of other owners -> send buffers (owner after owner); the chunks leave the pool.  A block takes SK_PACK_TILE chunks: every
  * thread looks at its chunks and books them in LDS -- ONE word per owner, chunks << 40 | granules, so that a chunk's place among
  * the (list, granules) pairs and the place of its granules are booked together and the data lies in the order of the pairs -- one
@@ -1550,6 +1558,7 @@ void sk_owner_count_kernel(const uint32_t *chunk_list, const uint32_t *chunk_cou
  * were 2.6 x 10^6 atomics on `world` addresses, 31 ms for half a C2 batch), and the wavefronts copy chunk after chunk, a granule per
  * lane. */
 static const int SK_PACK_TILE = 1024;
+#ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(256)
 void sk_pack_kernel(PoolView pool, uint32_t n_chunks, uint32_t world, uint32_t rank, const unsigned long long *granule_base, const unsigned long long *chunk_base,
                     unsigned long long *granule_cursor, unsigned long long *chunk_cursor, uint4 *out_data, uint2 *out_meta) {
@@ -1587,19 +1596,25 @@ void sk_pack_kernel(PoolView pool, uint32_t n_chunks, uint32_t world, uint32_t r
 		}
 	}
 }
+#endif
 /* lists of other owners start afresh (their chunks are gone) */
+#ifndef KMR_INSTANCE_TU
 __global__ void sk_state_drop_kernel(unsigned long long *state, uint64_t n, uint32_t world, uint32_t rank) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
 		if (i % world != rank) state[i] = ((unsigned long long)NO_CHUNK << 32) | SK_CHUNK_G;
 }
+#endif
+#ifndef KMR_INSTANCE_TU
 __global__ void sk_meta_counts_kernel(const uint2 *meta, uint64_t n, uint32_t *counts) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) counts[i] = meta[i].y;
 }
+#endif
 /* received chunks -> this rank's own lists: one wavefront per chunk.  A chunk's records all belong to one list and lie back to
  * back, so the chunk's used granules are appended as ONE piece (one booking of the list's word; they land behind what the list's
  * open chunk holds if they fit, else at the head of a fresh chunk) and copied a granule per lane -- booking record by record put 32
  * lanes of a wavefront on the same word at once (65 ms for half a C2 batch). */
 static const int SK_ADOPT_WAVES = 4, SK_ADOPT_GROUP = 8;
+#ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(SK_ADOPT_WAVES * 64)
 void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t *in_start, uint64_t n_in, SkParams sp, PoolView pool) {
 	__shared__ SkSlab s_slab[SK_ADOPT_WAVES];
@@ -1639,6 +1654,7 @@ void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t 
 		if (hc < pool.cap) pool.chunk_count[hc] = hf < SK_CHUNK_G ? hf : SK_CHUNK_G;
 	}
 }
+#endif
 
 /* ------------------------------------------------------------------ coarse lists on the wire, fine lists for the count pass */
 /* In a job of `world` ranks a rank used to scatter its reads into the JOB's fine lists (2^23 of them at 8 ranks x 10 M reads: half a
@@ -1649,6 +1665,7 @@ void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t 
  * fine list their minimizer selects (the low `shift` bits of the fine id vary within a chunk), ONE booking per group -- all groups'
  * bookings are made at once by their first lanes -- and every record copied to its place in the group's piece. */
 static const int SK_REFINE_WAVES = 4;
+#ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(SK_REFINE_WAVES * 64)
 void sk_refine_kernel(PoolView pool, uint32_t n_before, uint32_t fine_bits, unsigned long long *fine_state) {
 	__shared__ SkSlab s_slab[SK_REFINE_WAVES];
@@ -1712,6 +1729,7 @@ void sk_refine_kernel(PoolView pool, uint32_t n_before, uint32_t fine_bits, unsi
 		if (hc < pool.cap) pool.chunk_count[hc] = hf < SK_CHUNK_G ? hf : SK_CHUNK_G;
 	}
 }
+#endif
 
 }  // namespace kmr
 #endif

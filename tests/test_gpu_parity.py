@@ -522,9 +522,11 @@ def test_build_modes_agree_at_scale():
         add(p, rb)
         p.finalize(2)
         res.append((p.stats(), p.image(KMR_MAP_WEAK), p.histogram(1024)[0]))
-    assert res[0][0] == res[1][0]
-    assert np.array_equal(res[0][1], res[1][1])
-    st, _, hist = res[1]
+    for other in res[1:]:                # all three build modes, the default one (3) included
+        assert res[0][0] == other[0]
+        assert np.array_equal(res[0][1], other[1])
+        assert np.array_equal(res[0][2], other[2])
+    st, _, hist = res[2]
     # size-independent bookkeeping: every good occurrence is in exactly one entry
     assert int(hist.sum()) == st["weak_entries"]
     assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
@@ -545,15 +547,19 @@ def test_mostly_distinct_kmers_both_modes_agree(k):
         add(p, rb)
         p.finalize(2)
         res.append((p.stats(), p.image(KMR_MAP_WEAK)))
-    assert res[0][0] == res[1][0]
+    assert len(res) == len(MODES) == 3
+    for other in res[1:]:                # every mode against the device-table path
+        assert res[0][0] == other[0]
+        assert np.array_equal(res[0][1], other[1])
     assert res[0][0]["unique_kmers"] > 0.6 * res[0][0]["raw_good_kmers"]
-    assert np.array_equal(res[0][1], res[1][1])
 
 
 def test_c2_full_size_properties():
     """BASELINE.json configs[1] at full size (10M reads x 150 bp, k=31, 1.2e9 k-mers) through the device-pointer
     entry point bench.py times: counts conserve the k-mers, the image is sorted and bucket-consistent (sampled),
-    lookups of k-mers taken from the reads return their image counts, and a second build is bit-identical."""
+    lookups of k-mers taken from the reads return their image counts, a second build is bit-identical, and the
+    statistics and the weak image equal those of the device-table build (build_mode 1, an independent algorithm)
+    byte for byte."""
     import torch
     import bench
     n = 10_000_000
@@ -599,6 +605,16 @@ def test_c2_full_size_properties():
             assert counts.min() >= 2
             checked += cnt
     assert checked > 1000
+    # the same input through the open-addressed device table: statistics and image digest must agree
+    st0, dg0 = p.stats(), _image_digest(p)
+    p.close()
+    del p, imgs, img
+    p1 = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0, build_mode=1))
+    p1.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
+    p1.finalize(2)
+    assert p1.stats() == st0
+    assert _image_digest(p1) == dg0
+    p1.close()
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -803,15 +819,15 @@ def _image_digest(sp, which=KMR_MAP_WEAK):
 
 
 def test_c4_full_size_k51():
-    """BASELINE.json configs[3] at full size: k = 51 (two-word keys), 50 M synthetic 100 bp reads = 2.5e9 k-mers over 5e9 input
-    bases -- more than 2^32, so the stream ordinal that decides which sighting of a k-mer was its first (directionBias, the
+    """BASELINE.json configs[3] exactly as SURVEY 8(d) defines it: k = 51 (two-word keys), 50 M synthetic 150 bp reads of a 250 Mbp
+    genome, seed 3 = 5e9 k-mers over 7.5e9 input bases -- more than 2^32, so the stream ordinal that decides which sighting of a k-mer was its first (directionBias, the
     quantised first weight) has to be wider than 32 bits.  The default build (super-k-mer lists) must conserve the k-mers, be
     consistent with its own histogram and lookups, and give the weak map of the device-table build (build_mode 1, 40-bit
     ordinals in the slots) BYTE FOR BYTE -- counts, weights and direction biases; build_mode 2's 16-byte records carry 32
     ordinal bits and must refuse the input instead of being quietly wrong."""
     import torch
     import bench
-    n, rl, k = 50_000_000, 100, 51
+    n, rl, k = 50_000_000, 150, 51
     dev = torch.device("cuda", 0)
     bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev, read_len=rl)
     torch.cuda.synchronize()
