@@ -27,6 +27,7 @@
 #include "kmr_ingest.hpp"
 #include "kmr_artifact.hpp"
 #include "kmr_superkmer.hpp"
+#include "kmr_buckets.hpp"
 #define KMR_INSTANCES_EXTERN
 #include "kmr_instances.hpp"      /* the heavy kernels are compiled in kmr_inst_*.hip */
 
@@ -68,6 +69,7 @@ struct Tuning {
 	double entry_share = -1.0;        /* >= 0: initial size of the count pass's entry buffers as a share of the records */
 	bool no_lut = false, no_narrow = false, no_l1_state = false, no_stream_lookups = false;
 	uint64_t long_list_chunks = 0;     /* lists of more chunks are counted in pieces (0: 1024) */
+	uint64_t binned_min = 1ull << 18;  /* weak maps of at least this many entries are bucketed by the radix partition of kmr_buckets.hpp (build_mode 3) */
 	bool no_coarse_lists = true;       /* exchange: scatter into the job's fine lists (default) or, kmr_tune("coarse_lists", 1), into coarse ones that the owner splits before the count pass (sk_refine_kernel: not yet fast enough to pay) */
 };
 
@@ -127,6 +129,8 @@ struct kmr_handle {
 	uint32_t *ucnt = nullptr; uint64_t *ufirst = nullptr, *u_start = nullptr, *u_end = nullptr, *u_read = nullptr;
 	uint64_t ucnt_n = 0, ufirst_n = 0, units_n = 0; unsigned int *umax = nullptr;
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr, *us_pkt = nullptr; uint64_t uw_cap = 0, us_cap = 0;
+	/* build_mode 3: the count pass's weak entries packed (kmr_buckets.hpp: W key words + one value word), and the radix partition's scratch of the same layout */
+	uint64_t *ue = nullptr, *ue2 = nullptr; uint64_t ue_cap = 0, ue2_cap = 0;
 	/* build_mode 3 (kmr_superkmer.hpp): list words, minimizer geometry, table of k-fold quality products */
 	unsigned long long *sk_state = nullptr; uint32_t sk_bits = 0, sk_m = 0, sk_off = 0, sk_win = 0; double *dPk = nullptr;
 	/* exchange with world_size > 1: sk_bits are the COARSE lists reads are scattered into and that travel; each holds 2^sk_fine_shift
@@ -803,6 +807,7 @@ template <int W, bool EXT> int partition_level1(kmr_handle *h, const void *linea
 			if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && (double)mfree < (double)chunks * CH * rec_bytes(h) * 1.02 + (double)(2ull << 30)) {
 				HIPCHK(h, hipStreamSynchronize(h->stream));
 				if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt);
+	if (h->ue) hipFree(h->ue); if (h->ue2) hipFree(h->ue2); h->ue = h->ue2 = nullptr; h->ue_cap = h->ue2_cap = 0;
 				h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->uw_cap = h->us_cap = 0;
 			}
 		}
@@ -980,7 +985,7 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint32_t first, uint64_t 
 	return 0;
 }
 
-int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing);
+int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing, bool weak_uncounted = false);
 
 template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_depth) {
 	int rc = sync_state(h);
@@ -1110,7 +1115,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 	}
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
 	HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
-	CountOut out; out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wcursor = cursors; out.wcap = h->uw_cap;
+	CountOut out; out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wentries = nullptr; out.wcursor = cursors; out.wcap = h->uw_cap;
 	out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = (uint32_t *)h->us_pkt; out.scursor = cursors + 1; out.scap = h->us_cap;
 	out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
 	rc = zero_work_counter(h); if (rc) return rc;
@@ -1201,8 +1206,90 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 	return rc;
 }
 
-/* unsorted kept entries (h->uw_*, h->us_*) + per-bucket counts -> bucketed sorted maps */
-template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing) {
+/* The weak map out of the count pass's packed entries (h->ue) by the radix partition of kmr_buckets.hpp (COUNT_DIR values).
+ * done = false and nothing changed when the geometry does not fit: the caller takes the scatter + per-bucket sort. */
+template <int W> int binned_buckets_t(kmr_handle *h, uint64_t wslots, uint64_t wn, bool &done) {
+	done = false;
+	DevMap &wm = h->weak;
+	const uint64_t nb = wm.nb;
+	uint32_t B = 0; while ((1ull << (B + 1)) <= nb) B++;
+	if (h->ext || wn < h->tune.binned_min || wn == 0 || (1ull << B) != nb || wslots >= (1ull << 40)) return 0;
+	uint32_t g = 0; while (g < std::min<uint32_t>(B, BB_MAX_GROUP_BITS) && (wn >> (B - g)) < 512) g++;
+	const uint32_t R = B - g;
+	if (R < 1 || R > 2 * BB_MAX_BITS || (wn >> R) > 1024) return 0;
+	const uint32_t bits1 = R <= (uint32_t)BB_MAX_BITS ? R : (R + 1) / 2, bits2 = R - bits1;
+	const uint64_t bins1 = 1ull << bits1, groups = 1ull << R;
+	uint32_t *hist1 = nullptr, *hist2 = nullptr, *pad1 = nullptr; uint64_t *start1 = nullptr, *gstart = nullptr; unsigned long long *cursor = nullptr; unsigned int *dmax = nullptr;
+	int rc = arena_get(h, &hist1, bins1); if (rc) return rc;
+	rc = arena_get(h, &start1, bins1 + 1); if (rc) return rc;
+	rc = arena_get(h, &cursor, groups); if (rc) return rc;
+	rc = arena_get(h, &dmax, 1); if (rc) return rc;
+	if (bits2) { rc = arena_get(h, &hist2, groups); if (rc) return rc; rc = arena_get(h, &pad1, bins1); if (rc) return rc; rc = arena_get(h, &gstart, groups + 1); if (rc) return rc; }
+	HIPCHK(h, hipMemsetAsync(hist1, 0, 4 * bins1, h->stream)); HIPCHK(h, hipMemsetAsync(dmax, 0, 4, h->stream));
+	BbInput in1; in1.entries = h->ue; in1.seg_start = nullptr; in1.seg_count = nullptr; in1.n_seg = 1; in1.n_slots = wslots; in1.holes = 1;
+	auto hist_grid = [&](uint64_t n_slots, uint32_t &tpb) { const uint64_t tiles = (n_slots + BB_TILE - 1) / BB_TILE; tpb = (uint32_t)std::max<uint64_t>(1, (tiles + 2047) / 2048); return (unsigned)((tiles + tpb - 1) / tpb); };
+	auto scatter_grid = [&](uint64_t n_slots) { const uint64_t tiles = (n_slots + BB_TILE - 1) / BB_TILE; return (unsigned)std::min<uint64_t>(tiles, (uint64_t)num_cus(h) * 8); };
+	auto scratch = [&](uint64_t entries) -> int {      /* h->ue2: the other side of the partition's ping-pong */
+		if (h->ue2 && h->ue2_cap >= entries) return 0;
+		if (h->ue2) hipFree(h->ue2); h->ue2 = nullptr; h->ue2_cap = 0;
+		HIPCHK(h, hipMalloc((void **)&h->ue2, 8ull * (W + 1) * entries)); h->ue2_cap = entries;
+		return 0;
+	};
+	auto group_launch = [&](const uint64_t *entries, const uint64_t *gs, const uint32_t *gc) -> int {
+		int rc2 = reserve_bytes(h, (void **)&wm.keys, wm.c_keys, 8ull * W * wn); if (rc2) return rc2;
+		rc2 = reserve_bytes(h, (void **)&wm.vals, wm.c_vals, 12ull * wn); if (rc2) return rc2;
+		auto gk = bb_group_kernel<W>;
+		HIPCHK(h, hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bb_group_smem_bytes<W>()));
+		hipLaunchKernelGGL(gk, dim3((unsigned)std::min<uint64_t>(groups, (uint64_t)num_cus(h) * 8)), dim3(BB_THREADS), bb_group_smem_bytes<W>(), h->stream, entries, wm.keys, wm.vals, gs, gc, groups, g, h->hkb, nb, wm.start, wn, h->derr);
+		HIPCHK(h, hipGetLastError());
+		return 0;
+	};
+	const uint32_t shift1 = B - bits1;
+	uint32_t tpb = 1; unsigned grid = hist_grid(wslots, tpb);
+	hipLaunchKernelGGL(bb_hist_kernel<W>, dim3(grid), dim3(BB_THREADS), 0, h->stream, in1, shift1, bits1, h->hkb, nb, tpb, hist1);
+	unsigned int mx = 0;
+	if (!bits2) {
+		/* one level: its bins are the groups, their scan is where the groups lie in the map */
+		hipLaunchKernelGGL(bb_pad_kernel, dim3(grid_for(bins1)), dim3(256), 0, h->stream, (const uint32_t *)hist1, bins1, (uint32_t *)nullptr, dmax);
+		HIPCHK(h, hipMemcpyAsync(&mx, dmax, 4, hipMemcpyDeviceToHost, h->stream));
+		rc = exclusive_scan(h, hist1, bins1, start1); if (rc) return rc;      /* (synchronises) */
+		if (mx > BB_GROUP_CAP) return 0;
+		rc = scratch(wn); if (rc) return rc;
+		hipLaunchKernelGGL(bb_cursor_init_kernel, dim3(grid_for(bins1)), dim3(256), 0, h->stream, (const uint64_t *)start1, bins1, cursor);
+		hipLaunchKernelGGL(bb_scatter_kernel<W>, dim3(scatter_grid(wslots)), dim3(BB_THREADS), 0, h->stream, in1, shift1, bits1, h->hkb, nb, cursor, h->ue2);
+		rc = group_launch(h->ue2, start1, hist1); if (rc) return rc;
+		done = true;
+		return 0;
+	}
+	/* two levels: the first one's bins start at tile boundaries (the second level reads them tile by tile) */
+	hipLaunchKernelGGL(bb_pad_kernel, dim3(grid_for(bins1)), dim3(256), 0, h->stream, (const uint32_t *)hist1, bins1, pad1, dmax);
+	rc = exclusive_scan(h, pad1, bins1, start1); if (rc) return rc;
+	uint64_t padded_total = 0;
+	HIPCHK(h, hipMemcpy(&padded_total, start1 + bins1, 8, hipMemcpyDeviceToHost));
+	rc = scratch(std::max(padded_total, wn)); if (rc) return rc;
+	hipLaunchKernelGGL(bb_cursor_init_kernel, dim3(grid_for(bins1)), dim3(256), 0, h->stream, (const uint64_t *)start1, bins1, cursor);
+	hipLaunchKernelGGL(bb_scatter_kernel<W>, dim3(scatter_grid(wslots)), dim3(BB_THREADS), 0, h->stream, in1, shift1, bits1, h->hkb, nb, cursor, h->ue2);
+	BbInput in2; in2.entries = h->ue2; in2.seg_start = start1; in2.seg_count = hist1; in2.n_seg = (uint32_t)bins1; in2.n_slots = padded_total; in2.holes = 0;
+	const uint32_t shift2 = g;
+	HIPCHK(h, hipMemsetAsync(hist2, 0, 4 * groups, h->stream)); HIPCHK(h, hipMemsetAsync(dmax, 0, 4, h->stream));
+	grid = hist_grid(padded_total, tpb);
+	hipLaunchKernelGGL(bb_hist_kernel<W>, dim3(grid), dim3(BB_THREADS), 0, h->stream, in2, shift2, bits2, h->hkb, nb, tpb, hist2);
+	hipLaunchKernelGGL(bb_pad_kernel, dim3(grid_for(groups)), dim3(256), 0, h->stream, (const uint32_t *)hist2, groups, (uint32_t *)nullptr, dmax);
+	HIPCHK(h, hipMemcpyAsync(&mx, dmax, 4, hipMemcpyDeviceToHost, h->stream));
+	rc = exclusive_scan(h, hist2, groups, gstart); if (rc) return rc;
+	/* the packed entries the count pass wrote are about to be overwritten (the second level writes where the first one read): a
+	 * group too large for the LDS arrays sends the build down the other path BEFORE that */
+	if (mx > BB_GROUP_CAP || h->ue_cap < wn) return 0;
+	hipLaunchKernelGGL(bb_cursor_init_kernel, dim3(grid_for(groups)), dim3(256), 0, h->stream, (const uint64_t *)gstart, groups, cursor);
+	hipLaunchKernelGGL(bb_scatter_kernel<W>, dim3(scatter_grid(padded_total)), dim3(BB_THREADS), 0, h->stream, in2, shift2, bits2, h->hkb, nb, cursor, h->ue);
+	rc = group_launch(h->ue, gstart, hist2); if (rc) return rc;
+	done = true;
+	return 0;
+}
+
+/* weak_uncounted: the count pass kept no per-bucket counts of the weak entries (wc is scratch): the radix partition of
+ * kmr_buckets.hpp needs none, and if it declines they are counted here */
+template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing, bool weak_uncounted) {
 	const uint32_t vw = h->ext ? 15 : 3;
 	DevMap &wm = h->weak, &sm = h->sing;
 	clear_map(wm); clear_map(sm);          /* the buffers of the previous build are reused when they are large enough */
@@ -1210,15 +1297,32 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 	sm.nb = h->nb_sing; sm.n = keepSing ? sn : 0; sm.present = keepSing;
 	int rc = reserve_bytes(h, (void **)&wm.start, wm.c_start, 8 * (wm.nb + 1)); if (rc) return rc;
 	rc = reserve_bytes(h, (void **)&sm.start, sm.c_start, 8 * (sm.nb + 1)); if (rc) return rc;
-	rc = exclusive_scan(h, wc, wm.nb, wm.start); if (rc) return rc;
+	bool weakDone = false;
+	if (weak_uncounted) {
+		rc = binned_buckets_t<W>(h, wslots, wn, weakDone); if (rc) return rc;
+		if (!weakDone) {      /* the other path wants keys and values apart and a count per bucket */
+			if (!h->uw_keys || h->uw_cap < wslots) {
+				if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
+				const uint64_t cap = std::max<uint64_t>(wslots, 16);
+				HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * cap)); HIPCHK(h, hipMalloc(&h->uw_vals, 12ull * cap)); h->uw_cap = cap;
+			}
+			HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream));
+			if (wslots) hipLaunchKernelGGL(bb_unpack_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->ue, wslots, h->hkb, wm.nb, (uint64_t *)h->uw_keys, (uint32_t *)h->uw_vals, wc);
+			HIPCHK(h, hipGetLastError());
+		}
+	}
+	if (!weakDone) { rc = exclusive_scan(h, wc, wm.nb, wm.start); if (rc) return rc; }
 	rc = exclusive_scan(h, sc, sm.nb, sm.start); if (rc) return rc;
-	rc = reserve_bytes(h, (void **)&wm.keys, wm.c_keys, 8ull * W * wm.n); if (rc) return rc;
-	rc = reserve_bytes(h, (void **)&wm.vals, wm.c_vals, 4ull * vw * wm.n); if (rc) return rc;
+	if (!weakDone) {
+		rc = reserve_bytes(h, (void **)&wm.keys, wm.c_keys, 8ull * W * wm.n); if (rc) return rc;
+		rc = reserve_bytes(h, (void **)&wm.vals, wm.c_vals, 4ull * vw * wm.n); if (rc) return rc;
+	}
 	rc = reserve_bytes(h, (void **)&sm.keys, sm.c_keys, 8ull * W * sm.n); if (rc) return rc;
 	rc = reserve_bytes(h, (void **)&sm.sweight, sm.c_sw, sm.n); if (rc) return rc;
 	if (h->ext) { rc = reserve_bytes(h, (void **)&sm.spkt, sm.c_pkt, 4 * sm.n); if (rc) return rc; }
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * sm.nb, h->stream));
-	if (wm.n && vw > 4) hipLaunchKernelGGL((entry_scatter_kernel<W, true>), dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
+	if (weakDone) { /* keys, values and bucket starts are in place */ }
+	else if (wm.n && vw > 4) hipLaunchKernelGGL((entry_scatter_kernel<W, true>), dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->uw_keys, (const uint32_t *)h->uw_vals,
 	                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, wslots, vw, h->hkb, wm.nb, wm.start, wc, wm.keys, wm.vals, (uint8_t *)nullptr, (uint32_t *)nullptr);
 	else if (wm.n) {
 		/* lists cut by minimizer (build_mode 3) scatter their entries over unrelated buckets: 64-bit cursors that start at the buckets'
@@ -1233,7 +1337,8 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 	                            (const uint8_t *)h->us_b8, (const uint32_t *)h->us_pkt, sslots, 0u, h->hkb, sm.nb, sm.start, sc, sm.keys, (uint32_t *)nullptr, sm.sweight, h->ext ? sm.spkt : (uint32_t *)nullptr);
 	HIPCHK(h, hipGetLastError());
 	SortView<W> sv; sv.keys = wm.keys; sv.vals = wm.vals; sv.b8 = nullptr; sv.pkt = nullptr; sv.vw = vw;
-	if (h->ext) hipLaunchKernelGGL((sort_buckets_kernel<W, 15>), dim3(grid_for(wm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, wm.start, wm.nb);
+	if (weakDone) { /* sorted by bb_group_kernel */ }
+	else if (h->ext) hipLaunchKernelGGL((sort_buckets_kernel<W, 15>), dim3(grid_for(wm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, wm.start, wm.nb);
 	else hipLaunchKernelGGL((sort_buckets_kernel<W, 3>), dim3(grid_for(wm.nb, 4, 1 << 20)), dim3(256), 0, h->stream, sv, wm.start, wm.nb);
 	if (sm.n) {
 		SortView<W> ss; ss.keys = sm.keys; ss.vals = nullptr; ss.b8 = sm.sweight; ss.pkt = h->ext ? sm.spkt : nullptr; ss.vw = 0;
@@ -1243,9 +1348,9 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	return 0;
 }
-int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing) {
-	switch (h->W) { case 1: return finish_maps_t<1>(h, wc, sc, wslots, sslots, wn, sn, keepSing); case 2: return finish_maps_t<2>(h, wc, sc, wslots, sslots, wn, sn, keepSing);
-	case 3: return finish_maps_t<3>(h, wc, sc, wslots, sslots, wn, sn, keepSing); default: return finish_maps_t<4>(h, wc, sc, wslots, sslots, wn, sn, keepSing); }
+int finish_maps_from_entries(kmr_handle *h, uint32_t *wc, uint32_t *sc, uint64_t wslots, uint64_t sslots, uint64_t wn, uint64_t sn, bool keepSing, bool weak_uncounted) {
+	switch (h->W) { case 1: return finish_maps_t<1>(h, wc, sc, wslots, sslots, wn, sn, keepSing, weak_uncounted); case 2: return finish_maps_t<2>(h, wc, sc, wslots, sslots, wn, sn, keepSing, weak_uncounted);
+	case 3: return finish_maps_t<3>(h, wc, sc, wslots, sslots, wn, sn, keepSing, weak_uncounted); default: return finish_maps_t<4>(h, wc, sc, wslots, sslots, wn, sn, keepSing, weak_uncounted); }
 }
 int finalize_partition(kmr_handle *h, uint32_t min_depth) {
 #define FPT(Wv) (h->ext ? finalize_partition_t<Wv, true>(h, min_depth) : finalize_partition_t<Wv, false>(h, min_depth))
@@ -1414,14 +1519,17 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	const uint32_t vw = 3;
 	const uint64_t slack = (uint64_t)num_cus(h) * 4 * 8192 + 16;
 	const uint64_t wbound = f.has_singletons ? G / 2 : G, sbound = keepSing ? G : 0;
-	const uint64_t wmax = wbound + wbound / 8 + slack, smax = keepSing ? sbound + sbound / 8 + slack : 16;
+	/* (after an owner exchange the lists this rank counts hold other ranks' k-mers too -- G only knows this rank's own reads: no upper
+	 * bound then, the pass is repeated with doubled buffers until the entries fit) */
+	const bool adopted = h->sk_exchange && h->cfg.world_size > 1;
+	const uint64_t wmax = adopted ? (1ull << 40) : wbound + wbound / 8 + slack, smax = keepSing ? (adopted ? (1ull << 40) : sbound + sbound / 8 + slack) : 16;
 	/* entry buffers: sequencing data keeps a few per cent of its k-mers as weak entries; the pass is run again with larger
 	 * buffers when that was not enough */
 	uint64_t wcap = std::min<uint64_t>(wmax, G / (f.has_singletons ? 8 : 3) + slack), scap = keepSing ? std::min<uint64_t>(smax, G / 3 + slack) : 16;
 	if (h->tune.entry_share >= 0) { wcap = std::min<uint64_t>(wmax, (uint64_t)((double)G * h->tune.entry_share) + 16384); if (keepSing) scap = std::min<uint64_t>(smax, (uint64_t)((double)G * h->tune.entry_share) + 16384);
-		if (h->uw_keys) { hipFree(h->uw_keys); hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0; }
+		if (h->ue) { hipFree(h->ue); h->ue = nullptr; h->ue_cap = 0; }
 		if (h->us_keys) { hipFree(h->us_keys); hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0; } }
-	if (h->uw_keys && h->uw_cap >= wcap) wcap = h->uw_cap;
+	if (h->ue && h->ue_cap >= wcap) wcap = h->ue_cap;
 	if (h->us_keys && h->us_cap >= scap) scap = h->us_cap;
 	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr; unsigned long long *cursors = nullptr;
 	rc = arena_get(h, &wc, h->nb_weak); if (rc) return rc; rc = arena_get(h, &sc, h->nb_sing); if (rc) return rc;
@@ -1475,9 +1583,9 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	uint32_t merge_log2 = 16;
 	hipEvent_t tca, tcb; time_begin(h, KMR_TIME_COUNT, &tca, &tcb);
 	for (int attempt = 0; ; attempt++) {
-		if (!h->uw_keys || h->uw_cap < wcap) {
-			if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
-			HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, hipMalloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
+		if (!h->ue || h->ue_cap < wcap) {
+			if (h->ue) hipFree(h->ue); h->ue = nullptr; h->ue_cap = 0;
+			HIPCHK(h, hipMalloc((void **)&h->ue, 8ull * (W + 1) * wcap)); h->ue_cap = wcap;
 		}
 		if (!h->us_keys || h->us_cap < scap) {
 			if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0;
@@ -1485,9 +1593,9 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		}
 		HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
 		HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
-		CountOut out; out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wcursor = cursors; out.wcap = h->uw_cap;
+		CountOut out; out.wkeys = nullptr; out.wvals = nullptr; out.wentries = h->ue; out.wcursor = cursors; out.wcap = h->ue_cap;
 		out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = nullptr; out.scursor = cursors + 1; out.scap = h->us_cap;
-		out.weakCount = wc; out.singCount = sc; out.fc = fc; out.err = h->derr;
+		out.weakCount = nullptr; out.singCount = sc; out.fc = fc; out.err = h->derr;      /* weak entries are bucketed without a per-bucket histogram (kmr_buckets.hpp) */
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (nl / lgMain.list_stride + SK_LBATCH) / SK_LBATCH);
 		auto kern = tracking ? sk_count_kernel<W, COUNT_LOG2S, true> : sk_count_kernel<W, COUNT_LOG2S, false>;
@@ -1545,7 +1653,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		}
 	}
 	hipEvent_t tma, tmb; time_begin(h, KMR_TIME_BUCKETS, &tma, &tmb);
-	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing);
+	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing, true);
 	time_end(h, KMR_TIME_BUCKETS, tma, tmb);
 	if (rc) return rc;
 	time_end(h, 1, ea, eb);
@@ -1774,6 +1882,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "lookup_table") h->tune.no_lut = value == 0;
 	else if (k == "stream_lookups") h->tune.no_stream_lookups = value == 0;
 	else if (k == "long_list_chunks") h->tune.long_list_chunks = value < 2 ? 2 : (uint64_t)value;
+	else if (k == "binned_buckets_min") h->tune.binned_min = value >= 0 ? (uint64_t)value : ~0ull;        /* < 0: never */
 	else if (k == "coarse_lists") h->tune.no_coarse_lists = value == 0;
 	else if (k == "narrow_tallies") h->tune.no_narrow = value == 0;
 	else if (k == "keep_level1_state") h->tune.no_l1_state = value == 0;

@@ -796,6 +796,7 @@ static const int COUNT_THREADS = 256;
 struct CountOut {
 	/* unsorted kept entries */
 	uint64_t *wkeys; uint32_t *wvals; unsigned long long *wcursor; uint64_t wcap;
+	uint64_t *wentries;      /* build_mode 3: the weak entries packed, W key words + one value word each (kmr_buckets.hpp), instead of wkeys / wvals */
 	uint64_t *skeys; uint8_t *sweight; uint32_t *spkt; unsigned long long *scursor; uint64_t scap;
 	uint32_t *weakCount, *singCount;        /* per bucket */
 	FinalizeCounters *fc;

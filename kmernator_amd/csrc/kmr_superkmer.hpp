@@ -31,6 +31,7 @@
 #define KMR_SUPERKMER_HPP_
 
 #include "kmr_partition.hpp"
+#include "kmr_buckets.hpp"
 
 namespace kmr {
 
@@ -845,14 +846,27 @@ template <int W> struct SkLong {
 };
 
 template <int W, int LOG2S, bool TRACK = false>
-__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + 2 + (TRACK ? 8 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
+__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (TRACK ? 8 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
+
+/* Life of a list in the block (round 3: two block barriers per list instead of eight):
+ *   insert   the four wavefronts take the list's chunks on their own (chunk c0 + wave, + 4, ...), the table is shared through
+ *            LDS atomics                                                                                        -- barrier A
+ *   emit     every wavefront looks after a quarter of the table's slots: what a slot holds is classified (append() /
+ *            purgeMinDepth semantics), kept entries go to the WAVEFRONT's own output slab (positions by ballot, a slab of
+ *            SK_OSLAB entries is taken with one device atomic when the last one is full), and the slot is cleared on the
+ *            spot -- the table is empty again when the next list starts, there is no clearing pass            -- barrier B
+ * A list whose distinct keys overflow the table (rare: the lists are sized for ~40 % load) is redone in sub-passes that split
+ * it by further hash bits, with barriers around every step (the cold path below).  The flags the insert phase raises
+ * (claimed slots, overflow) exist twice and alternate from list to list, so nobody has to wait for their reset. */
+static const unsigned long long SK_OSLAB = 2048;      /* entries a wavefront reserves at a time in the count pass's output */
 
 template <int W, int LOG2S, bool TRACK = false>
-__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10 && !TRACK) ? 4 : 1)
+__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 2 : 1))
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
                      CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv, SkLong<W> lg) {
 	constexpr int S = 1 << LOG2S;
 	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
+	constexpr int WSLOTS = S / SK_STAGE_CHUNKS;        /* slots a wavefront looks after in the emit phase */
 	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
 	uint64_t *tkeys = (uint64_t *)csm;                                 /* [S][W] */
 	unsigned long long *tcnt = (unsigned long long *)(tkeys + (size_t)S * W);
@@ -860,15 +874,12 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	unsigned long long *tfirst = (unsigned long long *)(twsum + S);
 	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
 	uint4 *stage = (uint4 *)(tstate + (W > 1 ? S : 0));                /* 16-byte aligned: every table array is a multiple of 16 bytes */
-	uint16_t *s_kept = (uint16_t *)(stage + SK_STAGE_G);               /* [S] table slots of the entries to write out */
-	uint8_t *recOf = (uint8_t *)(s_kept + S);                          /* [4][64] per wavefront: header lane of the record a lane's first k-mer lies in */
+	uint8_t *recOf = (uint8_t *)(stage + SK_STAGE_G);                  /* [4][64] per wavefront: header lane of the record a lane's first k-mer lies in */
 	/* size tracker: the second-smallest first-sighting word of every slot, and this block's share of the two difference arrays */
-	unsigned long long *tsecond = (unsigned long long *)(csm + (size_t)S * (8 * W + 24 + (W > 1 ? 4 : 0) + 2) + (size_t)SK_STAGE_G * 16 + 256 + 64);
+	unsigned long long *tsecond = (unsigned long long *)(csm + (size_t)S * (8 * W + 24 + (W > 1 ? 4 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64);
 	unsigned int *trkU = (unsigned int *)(tsecond + (TRACK ? S : 0)), *trkS = trkU + (SK_TRACK_MAX + 1);
-	__shared__ uint32_t s_list, s_claimed, s_overflow, s_sp, s_nw, s_ns, s_n2;
-	__shared__ unsigned long long s_wbase, s_sbase;
-	__shared__ unsigned long long s_wpos, s_wend, s_spos, s_send;
-	__shared__ unsigned long long s_holeW0, s_holeW1, s_holeS0, s_holeS1;
+	__shared__ uint32_t s_list, s_sp;
+	__shared__ uint32_t s_claimed[2], s_overflow[2];
 	__shared__ uint32_t s_stackBits[40], s_stackVal[40];
 	__shared__ unsigned long long s_c0[SK_LBATCH + 1], s_c1[SK_LBATCH + 1];      /* chunk range of every list (work item) of the batch */
 	__shared__ uint32_t s_dchunk[SK_DESC_CAP];
@@ -877,18 +888,19 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	if (TRACK) for (int i = t; i < 2 * (int)(SK_TRACK_MAX + 1); i += COUNT_THREADS) trkU[i] = 0;
 	const uint32_t vw = 3;
 	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;
-	constexpr unsigned long long OSLAB = 8192;
-	if (t == 0) { s_wpos = s_wend = 0; s_spos = s_send = 0; }
+	/* this wavefront's output slabs: [wpos, wend) of the weak entries, [spos, send) of the singletons */
+	unsigned long long wpos = 0, wend = 0, spos = 0, send = 0;
+	bool outFull = false;
+	if (t == 0) { s_claimed[0] = s_claimed[1] = 0; s_overflow[0] = s_overflow[1] = 0; s_sp = 0; }
+	for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
 	lds_barrier();
 	/* classify() of kmr_kernels.hpp folded into launch-wide scalars: a count of one goes to class singC when singletons are separate,
-	 * any other count below weakMin is dropped.  When no singleton is written out and the kept entries are exactly the keys seen at
-	 * least keepFrom >= 2 times (FilterReads' defaults: 2), the insert loop files them itself and the table is never scanned. */
+	 * any other count below weakMin is dropped */
 	const uint32_t singC = f.has_singletons ? (f.min_depth > 1 ? 0u : 2u) : 3u;
 	const uint32_t weakMin = ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1) ? f.min_depth : 0u;
-	const uint32_t keepFrom = singC == 0u ? (weakMin > 2u ? weakMin : 2u) : weakMin;
-	const bool fastEmit = !TRACK && singC != 2u && keepFrom >= 2u;      /* (the size tracker looks at every slot) */
 	const uint4 *poolg = (const uint4 *)pool.base;
 	uint4 pre = make_uint4(0, 0, 0, 0); uint32_t preCount = 0; uint64_t preList = ~0ull;      /* this wavefront's first chunk of the list named */
+	uint32_t gen = 0;                                  /* lists this block has counted: the flag pair in use is gen & 1 */
 
 	const bool itemMode = lg.item_c0 != nullptr;
 	const uint32_t grab = itemMode ? 1u : SK_LBATCH;      /* work items are large: one at a time */
@@ -926,20 +938,13 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 			const uint64_t c0 = s_c0[lj], c1 = s_c1[lj];
 			if (c0 == c1) continue;
 			if (itemMode && (__hip_atomic_load(out.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ERR_TABLE_FULL)) continue;      /* uniform enough: the launch is void anyway */
-			lds_barrier();
-			if (t == 0) { s_sp = 1; s_stackBits[0] = 0; s_stackVal[0] = 0; }
-			lds_barrier();
-			bool firstPass = true;        /* sub-passes of a split list load their chunks themselves */
-			while (s_sp > 0) {
-				const uint32_t bits = s_stackBits[s_sp - 1], val = s_stackVal[s_sp - 1];
-				lds_barrier();
-				if (t == 0) { s_sp--; s_claimed = 0; s_overflow = 0; s_nw = 0; s_ns = 0; s_n2 = 0; }
-				for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
-				lds_barrier();
+			uint32_t fl = gen & 1u;                    /* this list's flags */
+			gen++;
+			/* ---- insert: wavefront w takes chunks c0 + w, c0 + w + 4, ... of the list, each one on its own: it stages the chunk in its
+			 * quarter of the staging area, finds the record starts, maps k-mer slots to records and inserts (only the k-mers whose hash
+			 * bits `bits` equal val: sub-passes of a split list) */
+			auto insert_pass = [&](const uint32_t bits, const uint32_t val, const bool firstPass) {
 				const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
-				/* insert: wavefront w takes chunks c0 + w, c0 + w + 4, ... of the list, each one on its own: it stages the chunk in its
-				 * quarter of the staging area, finds the record starts, maps k-mer slots to records and inserts -- no block-wide
-				 * barrier until all four are through (the table is shared through LDS atomics) */
 				uint4 *wstage = stage + wv * SK_CHUNK_G;
 				uint8_t *wrecOf = recOf + wv * 64;
 				uint4 cur = make_uint4(0, 0, 0, 0); uint32_t curCount = 0;
@@ -950,7 +955,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					preList = ~0ull;
 					if (lj + 1 < nl) { const uint64_t n0 = s_c0[lj + 1], n1 = s_c1[lj + 1]; if (n0 + wv < n1) { fetch(n0 + wv, pre, preCount); preList = lfirst + lj + 1; } }
 				}
-				for (uint64_t ci = c0 + wv; ci < c1 && !s_overflow && s_claimed <= LIMIT; ci += SK_STAGE_CHUNKS) {
+				for (uint64_t ci = c0 + wv; ci < c1 && !s_overflow[fl] && s_claimed[fl] <= LIMIT; ci += SK_STAGE_CHUNKS) {
 					uint4 nxt = make_uint4(0, 0, 0, 0); uint32_t nxtCount = 0;
 					if (ci + SK_STAGE_CHUNKS < c1) fetch(ci + SK_STAGE_CHUNKS, nxt, nxtCount);
 					wstage[lane] = cur;
@@ -1087,7 +1092,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 									}
 									s = (s + 1) & (S - 1);
 								}
-								if (!placed) s_overflow = 1;      /* table full */
+								if (!placed) s_overflow[fl] = 1;      /* table full */
 								else {
 									atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(cfwd ? 1 : 0) << 32));
 									atomicAdd(&twsum[s], (double)wa);
@@ -1103,15 +1108,157 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 							}
 						}
 					}
-					if (SK_DBG(dbgFlags, 1) && dbgSink == 0x12345u) s_overflow = 2;
+					if (SK_DBG(dbgFlags, 1) && dbgSink == 0x12345u) s_overflow[fl] = 2;
 					claimedHere = (uint32_t)wave_sum((unsigned long long)claimedHere);
-					if (lane == 0 && claimedHere) atomicAdd(&s_claimed, claimedHere);
+					if (lane == 0 && claimedHere) atomicAdd(&s_claimed[fl], claimedHere);
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 					cur = nxt; curCount = nxtCount;
 				}
-				firstPass = false;
+			};
+			/* ---- emit: this wavefront's quarter of the table -> entries of its output slabs (or the merge table / the size tracker's
+			 * difference arrays), every slot cleared behind it */
+			auto emit_pass = [&]() {
+#pragma unroll 1
+				for (int i = 0; i < WSLOTS / 64; i++) {
+					const int s = wv * WSLOTS + i * 64 + lane;
+					const unsigned long long cf = tcnt[s];
+					const uint32_t count = (uint32_t)cf;
+					const bool used = count != 0;      /* every claim is followed by its own count */
+					if (!__any(used)) continue;
+					if (!itemMode) { uniq += used ? 1u : 0u; single += (used && count == 1) ? 1u : 0u; }      /* (item mode: a key may lie in several items' tables; sk_merge_emit_kernel counts) */
+					uint32_t cls = !used ? 0u : ((count == 1 && singC != 3u) ? singC : (count < weakMin ? 0u : 1u));
+					if (SK_DBG(dbgFlags, 2)) cls = 0;
+					Key<W> key;
+#pragma unroll
+					for (int q = 0; q < W; q++) key.w[q] = used ? tkeys[(size_t)s * W + q] : 0ull;
+					const unsigned long long fst = used ? tfirst[s] : NO_FIRST;
+					const double wsum = used ? twsum[s] : 0.0;
+					if (TRACK && used) {
+						/* the key counts as seen from the first boundary behind its first sighting on, and as a singleton until the
+						 * first boundary behind its second one: index = number of boundaries <= the ordinal */
+						auto behind = [&](unsigned long long ord) -> uint32_t {
+							uint32_t lo = 0, hi = tv.n;
+							while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (tv.bounds[mid] <= ord) lo = mid + 1; else hi = mid; }
+							return lo;
+						};
+						const uint32_t iu = behind(fst >> 24);
+						atomicAdd(&trkU[iu], 1u);
+						atomicAdd(&trkS[iu], 1u);
+						const unsigned long long sec = tsecond[s];
+						if (sec != NO_FIRST) atomicAdd(&trkS[behind(sec >> 24)], 0xffffffffu);      /* -1 */
+					}
+					if (itemMode) {      /* a range of a long list: the slot goes into the merge table, entries come from there */
+						cls = 0;
+						/* multi-word keys are claimed through a state word that a loser polls until the winner has written the key: two
+						 * lanes of one wavefront after the same empty slot would wait on each other forever, so there the lanes of a
+						 * wavefront go one after the other (a handful of keys per item; other wavefronts are no problem) */
+						for (int turn = 0; turn < (W == 1 ? 1 : 64); turn++) {
+							if (used && (W == 1 || lane == turn) && !(__hip_atomic_load(out.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ERR_TABLE_FULL)) {
+								bool claimed;
+								const uint64_t ms = table_find_or_insert<W>(lg.merge, key, part_hash<W>(key.w), claimed);
+								if (claimed && atomicAdd(lg.merge_used, 1ull) > (5ull << lg.merge.log2cap) / 8) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
+								if (ms == ~0ull) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
+								else {
+									Slot<W> *sl = &lg.merge.slots[ms];
+									atomicAdd(&sl->cntfwd, cf);
+									atomicAdd(&sl->wsum, wsum);
+									atomicMin(&sl->first, fst);
+								}
+							}
+						}
+					}
+					const unsigned long long mw = __ballot(cls == 1), ms = __ballot(cls == 2);
+					const unsigned long long below = (1ull << lane) - 1;
+					if (mw) {
+						const uint32_t cnt = (uint32_t)__builtin_popcountll(mw);
+						if (wpos + cnt > wend) {           /* the slab is full: its tail becomes a hole, a new one is taken */
+							for (unsigned long long e = wpos + lane; e < wend && e < out.wcap; e += 64) { if (out.wentries) out.wentries[e * (W + 1) + W] = 0; else out.wvals[e * vw] = 0; }
+							unsigned long long g = 0;
+							if (lane == 0) g = atomicAdd(out.wcursor, SK_OSLAB);
+							wpos = ((unsigned long long)(uint32_t)__shfl((int)(g >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)g, 0, 64);
+							wend = wpos + SK_OSLAB;
+							if (wend > out.wcap) { if (lane == 0) atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); outFull = true; wend = wpos; }
+						}
+						if (!outFull) {
+							if (cls == 1) {
+								const uint64_t pos = wpos + (uint32_t)__builtin_popcountll(mw & below);
+								uint32_t fwdc = (uint32_t)(cf >> 32), cnt16 = count;
+								if (f.has_singletons && first_forward(fst)) fwdc -= 1;
+								if (cnt16 > 65535u) { cnt16 = 65535u; if (fwdc > 65534u) fwdc = 65534u; }
+								if (fwdc > 65535u) fwdc = 65535u;
+								const uint32_t wbits = __float_as_uint((float)(f.has_singletons ? wsum + first_weight_shift(fst) : wsum));
+								if (out.wentries) {
+									uint64_t ew[W + 1];
+#pragma unroll
+									for (int q = 0; q < W; q++) ew[q] = key.w[q];
+									ew[W] = bb_pack_value(cnt16, wbits, fwdc);
+									bb_store_entry<W>(out.wentries, pos, ew);
+								} else {
+#pragma unroll
+									for (int q = 0; q < W; q++) out.wkeys[pos * W + q] = key.w[q];
+									uint32_t *v = out.wvals + pos * vw;
+									v[0] = cnt16; v[1] = wbits; v[2] = fwdc;
+								}
+							}
+							wpos += cnt; keptW += lane == 0 ? cnt : 0u;
+						}
+					}
+					if (out.weakCount) {      /* (null in build_mode 3's own finalize: the map is bucketed by kmr_buckets.hpp, which counts for itself) */
+						const uint64_t bucket = cls == 1 ? key_hash<W>(key, f.kb) & (f.nb_weak - 1) : 0;
+						bucket_count_add(out.weakCount, bucket, cls == 1 && !outFull);
+					}
+					if (ms) {
+						const uint32_t cnt = (uint32_t)__builtin_popcountll(ms);
+						if (spos + cnt > send) {
+							for (unsigned long long e = spos + lane; e < send && e < out.scap; e += 64) out.sweight[e] = 0;
+							unsigned long long g = 0;
+							if (lane == 0) g = atomicAdd(out.scursor, SK_OSLAB);
+							spos = ((unsigned long long)(uint32_t)__shfl((int)(g >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)g, 0, 64);
+							send = spos + SK_OSLAB;
+							if (send > out.scap) { if (lane == 0) atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); outFull = true; send = spos; }
+						}
+						uint64_t bucket = 0;
+						if (!outFull && cls == 2) {
+							const uint64_t pos = spos + (uint32_t)__builtin_popcountll(ms & below);
+							bucket = key_hash<W>(key, f.kb) & (f.nb_sing - 1);
+#pragma unroll
+							for (int q = 0; q < W; q++) out.skeys[pos * W + q] = key.w[q];
+							const float wf = (float)wsum;
+							out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
+						}
+						bucket_count_add(out.singCount, bucket, cls == 2 && !outFull);
+						if (!outFull) { spos += cnt; keptS += lane == 0 ? cnt : 0u; }
+					}
+					if (used) { tkeys[(size_t)s * W] = EMPTY_KEY; tcnt[s] = 0; twsum[s] = 0.0; tfirst[s] = NO_FIRST; if (W > 1) tstate[s] = 0; if (TRACK) tsecond[s] = NO_FIRST; }
+				}
+			};
+			auto clear_table = [&]() {
+				for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
+			};
+
+			insert_pass(0, 0, true);
+			lds_barrier();                                                   /* A: every insert of the list is in the table */
+			const bool ovf = s_overflow[fl] != 0 || s_claimed[fl] > LIMIT;
+			if (t == 0) { s_claimed[fl ^ 1u] = 0; s_overflow[fl ^ 1u] = 0; }      /* the other pair: last read before the barrier B of the list before, next raised after this list's */
+			if (!ovf) {
+				emit_pass();
+				lds_barrier();                                               /* B: the table is empty again */
+				continue;
+			}
+			/* ---- cold path: the list's distinct keys do not fit the table: sub-passes by further hash bits, a small stack of (bits, value) */
+			clear_table();
+			if (t == 0) { s_sp = 2; s_stackBits[0] = 1; s_stackVal[0] = 0; s_stackBits[1] = 1; s_stackVal[1] = 1; }
+			lds_barrier();
+			while (s_sp > 0) {
+				const uint32_t bits = s_stackBits[s_sp - 1], val = s_stackVal[s_sp - 1];
 				lds_barrier();
-				if (s_overflow || s_claimed > LIMIT) {       /* split this sub-pass in two by one more hash bit */
+				if (t == 0) { s_sp--; s_claimed[fl] = 0; s_overflow[fl] = 0; }
+				lds_barrier();
+				insert_pass(bits, val, false);
+				lds_barrier();
+				if (s_overflow[fl] || s_claimed[fl] > LIMIT) {       /* split this sub-pass in two by one more hash bit */
+					lds_barrier();
+					clear_table();
 					if (t == 0) {
 						if (bits >= 20) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
 						else {
@@ -1122,166 +1269,28 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					lds_barrier();
 					continue;
 				}
-				/* emit: as count_kernel (weak entries from the front of s_kept, singletons from its back) */
-				if (SK_DBG(dbgFlags, 2)) { lds_barrier(); continue; }
-				if (itemMode) {      /* a range of a long list: the table goes into the merge table, entries come from there */
-					for (int i0 = t & ~63; i0 < S; i0 += COUNT_THREADS) {
-						const int i = i0 + lane;
-						const bool used = W == 1 ? tkeys[i] != EMPTY_KEY : tstate[i] == 2;
-						/* multi-word keys are claimed through a state word that a loser polls until the winner has written the key: two
-						 * lanes of one wavefront after the same empty slot would wait on each other forever, so there the lanes of a
-						 * wavefront go one after the other (a handful of keys per item; other wavefronts are no problem) */
-						for (int turn = 0; turn < (W == 1 ? 1 : 64); turn++) {
-							if (used && (W == 1 || lane == turn) && !(__hip_atomic_load(out.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ERR_TABLE_FULL)) {
-								Key<W> key;
-#pragma unroll
-								for (int q = 0; q < W; q++) key.w[q] = tkeys[(size_t)i * W + q];
-								bool claimed;
-								const uint64_t ms = table_find_or_insert<W>(lg.merge, key, part_hash<W>(key.w), claimed);
-								if (claimed && atomicAdd(lg.merge_used, 1ull) > (5ull << lg.merge.log2cap) / 8) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
-								if (ms == ~0ull) atomicOr(out.err, (uint32_t)ERR_TABLE_FULL);
-								else {
-									Slot<W> *sl = &lg.merge.slots[ms];
-									atomicAdd(&sl->cntfwd, tcnt[i]);
-									atomicAdd(&sl->wsum, twsum[i]);
-									atomicMin(&sl->first, tfirst[i]);
-								}
-							}
-						}
-					}
-					lds_barrier();
-					continue;
-				}
-				if (fastEmit) {       /* only the counts are looked at: a slot is kept from keepFrom sightings on, nothing goes to the singleton map */
-					if (t == 0) uniq += s_claimed;
-#pragma unroll
-					for (int i = 0; i < S / COUNT_THREADS; i++) {
-						const int s = i * COUNT_THREADS + t;
-						const uint32_t count = (uint32_t)tcnt[s];
-						const unsigned long long mk = __ballot(count >= keepFrom), m1 = __ballot(count == 1u);
-						if (lane == 0) single += (unsigned long long)__builtin_popcountll(m1);
-						if (mk == 0) continue;
-						uint32_t bw = 0;
-						if (lane == 0) bw = atomicAdd(&s_nw, (uint32_t)__builtin_popcountll(mk));
-						bw = (uint32_t)__shfl((int)bw, 0, 64);
-						if (count >= keepFrom) s_kept[bw + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1))] = (uint16_t)s;
-					}
-				} else {
-				uint32_t cls[S / COUNT_THREADS];
-#pragma unroll
-				for (int i = 0; i < S / COUNT_THREADS; i++) {
-					const int s = i * COUNT_THREADS + t;
-					const bool used = W == 1 ? tkeys[s] != EMPTY_KEY : tstate[s] == 2;
-					const uint32_t count = (uint32_t)tcnt[s];
-					uniq += used ? 1u : 0u;
-					single += (used && count == 1) ? 1u : 0u;
-					cls[i] = !used ? 0u : ((count == 1 && singC != 3u) ? singC : (count < weakMin ? 0u : 1u));
-					if (TRACK && used) {
-						/* the key counts as seen from the first boundary behind its first sighting on, and as a singleton until the
-						 * first boundary behind its second one: index = number of boundaries <= the ordinal */
-						auto behind = [&](unsigned long long ord) -> uint32_t {
-							uint32_t lo = 0, hi = tv.n;
-							while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (tv.bounds[mid] <= ord) lo = mid + 1; else hi = mid; }
-							return lo;
-						};
-						const uint32_t iu = behind(tfirst[s] >> 24);
-						atomicAdd(&trkU[iu], 1u);
-						atomicAdd(&trkS[iu], 1u);
-						const unsigned long long sec = tsecond[s];
-						if (sec != NO_FIRST) atomicAdd(&trkS[behind(sec >> 24)], 0xffffffffu);      /* -1 */
-					}
-				}
-				const unsigned long long below = (1ull << lane) - 1;
-#pragma unroll
-				for (int i = 0; i < S / COUNT_THREADS; i++) {
-					const int s = i * COUNT_THREADS + t;
-					const uint32_t c = cls[i];
-					const unsigned long long mw = __ballot(c == 1), ms = __ballot(c == 2);
-					if ((mw | ms) == 0) continue;
-					uint32_t bw = 0, bs = 0;
-					if (lane == 0) { if (mw) bw = atomicAdd(&s_nw, (uint32_t)__builtin_popcountll(mw)); if (ms) bs = atomicAdd(&s_ns, (uint32_t)__builtin_popcountll(ms)); }
-					bw = (uint32_t)__shfl((int)bw, 0, 64); bs = (uint32_t)__shfl((int)bs, 0, 64);
-					if (c == 1) s_kept[bw + (uint32_t)__builtin_popcountll(mw & below)] = (uint16_t)s;
-					else if (c == 2) s_kept[S - 1 - (bs + (uint32_t)__builtin_popcountll(ms & below))] = (uint16_t)s;
-				}
-				}
-				lds_barrier();
-				if (t == 0) {
-					s_holeW0 = s_holeW1 = 0; s_holeS0 = s_holeS1 = 0;
-					if (s_nw && s_wpos + s_nw > s_wend) {
-						s_holeW0 = s_wpos; s_holeW1 = s_wend < out.wcap ? s_wend : out.wcap;
-						const unsigned long long g = s_nw > OSLAB ? s_nw : OSLAB; s_wpos = atomicAdd(out.wcursor, g); s_wend = s_wpos + g;
-					}
-					if (s_ns && s_spos + s_ns > s_send) {
-						s_holeS0 = s_spos; s_holeS1 = s_send < out.scap ? s_send : out.scap;
-						const unsigned long long g = s_ns > OSLAB ? s_ns : OSLAB; s_spos = atomicAdd(out.scursor, g); s_send = s_spos + g;
-					}
-					s_wbase = s_wpos; s_wpos += s_nw; keptW += s_nw;
-					s_sbase = s_spos; s_spos += s_ns; keptS += s_ns;
-					if (s_wend > out.wcap || s_send > out.scap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); s_nw = 0xffffffffu; }
-				}
-				lds_barrier();
-				for (unsigned long long e = s_holeW0 + t; e < s_holeW1; e += COUNT_THREADS) out.wvals[e * vw] = 0;
-				for (unsigned long long e = s_holeS0 + t; e < s_holeS1; e += COUNT_THREADS) out.sweight[e] = 0;
-				if (s_nw != 0xffffffffu) {
-					for (uint32_t e0 = (uint32_t)t & ~63u; e0 < s_nw; e0 += COUNT_THREADS) {
-						const uint32_t e = e0 + (uint32_t)lane;
-						const bool live = e < s_nw;
-						uint64_t bucket = 0;
-						if (live) {
-							const uint32_t s = s_kept[e];
-							Key<W> key;
-#pragma unroll
-							for (int q = 0; q < W; q++) key.w[q] = tkeys[(size_t)s * W + q];
-							bucket = key_hash<W>(key, f.kb) & (f.nb_weak - 1);
-							const unsigned long long cf = tcnt[s];
-							const uint64_t pos = s_wbase + e;
-#pragma unroll
-							for (int q = 0; q < W; q++) out.wkeys[pos * W + q] = key.w[q];
-							uint32_t fwdc = (uint32_t)(cf >> 32), cnt = (uint32_t)cf;
-							const unsigned long long fst = tfirst[s];
-							if (f.has_singletons && first_forward(fst)) fwdc -= 1;
-							if (cnt > 65535u) { cnt = 65535u; if (fwdc > 65534u) fwdc = 65534u; }
-							if (fwdc > 65535u) fwdc = 65535u;
-							uint32_t *v = out.wvals + pos * vw;
-							v[0] = cnt; v[1] = __float_as_uint((float)(f.has_singletons ? twsum[s] + first_weight_shift(fst) : twsum[s])); v[2] = fwdc;
-						}
-						bucket_count_add(out.weakCount, bucket, live);
-					}
-					for (uint32_t e0 = (uint32_t)t & ~63u; e0 < s_ns; e0 += COUNT_THREADS) {
-						const uint32_t e = e0 + (uint32_t)lane;
-						const bool live = e < s_ns;
-						uint64_t bucket = 0;
-						if (live) {
-							const uint32_t s = s_kept[S - 1 - e];
-							Key<W> key;
-#pragma unroll
-							for (int q = 0; q < W; q++) key.w[q] = tkeys[(size_t)s * W + q];
-							bucket = key_hash<W>(key, f.kb) & (f.nb_sing - 1);
-							const uint64_t pos = s_sbase + e;
-#pragma unroll
-							for (int q = 0; q < W; q++) out.skeys[pos * W + q] = key.w[q];
-							const float wf = (float)twsum[s];
-							out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
-						}
-						bucket_count_add(out.singCount, bucket, live);
-					}
-				}
+				emit_pass();
 				lds_barrier();
 			}
+			/* both flag pairs are clean for the lists to come */
+			if (t == 0) { s_claimed[0] = s_claimed[1] = 0; s_overflow[0] = s_overflow[1] = 0; }
+			lds_barrier();
 		}
 	}
-	lds_barrier();
-	for (unsigned long long e = s_wpos + t; e < s_wend && e < out.wcap; e += COUNT_THREADS) out.wvals[e * vw] = 0;
-	for (unsigned long long e = s_spos + t; e < s_send && e < out.scap; e += COUNT_THREADS) out.sweight[e] = 0;
+	/* the unused tails of this wavefront's slabs are holes */
+	for (unsigned long long e = wpos + lane; e < wend && e < out.wcap; e += 64) { if (out.wentries) out.wentries[e * (W + 1) + W] = 0; else out.wvals[e * vw] = 0; }
+	for (unsigned long long e = spos + lane; e < send && e < out.scap; e += 64) out.sweight[e] = 0;
 	uniq = wave_sum(uniq); single = wave_sum(single);
-	if (lane == 0) { if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single); }
-	if (t == 0) { if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS); }
+	if (lane == 0) {
+		if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single);
+		if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS);
+	}
 	if (TRACK) {
 		lds_barrier();
 		for (uint32_t i = (uint32_t)t; i <= tv.n && i <= SK_TRACK_MAX; i += COUNT_THREADS) { if (trkU[i]) atomicAdd(&tv.d_unique[i], trkU[i]); if (trkS[i]) atomicAdd(&tv.d_single[i], trkS[i]); }
 	}
 }
+
 
 /* the merge table of the long lists -> entries, with count_kernel's rules (classify folded into scalars as in sk_count_kernel) */
 template <int W>
@@ -1306,14 +1315,23 @@ void sk_merge_emit_kernel(Table<W> tbl, CountOut out, FinalizeParams f) {
 				const unsigned long long pos = atomicAdd(out.wcursor, 1ull);
 				if (pos >= out.wcap) { atomicOr(out.err, (uint32_t)ERR_ENTRIES_FULL); cls = 0; }
 				else {
-					bucket = key_hash<W>(key, f.kb) & (f.nb_weak - 1);
-#pragma unroll
-					for (int q = 0; q < W; q++) out.wkeys[pos * W + q] = key.w[q];
+					if (out.weakCount) bucket = key_hash<W>(key, f.kb) & (f.nb_weak - 1);
 					if (f.has_singletons && first_forward(sl.first)) fwdc -= 1;
 					if (cnt > 65535u) { cnt = 65535u; if (fwdc > 65534u) fwdc = 65534u; }
 					if (fwdc > 65535u) fwdc = 65535u;
-					uint32_t *v = out.wvals + pos * vw;
-					v[0] = cnt; v[1] = __float_as_uint((float)(f.has_singletons ? sl.wsum + first_weight_shift(sl.first) : sl.wsum)); v[2] = fwdc;
+					const uint32_t wbits = __float_as_uint((float)(f.has_singletons ? sl.wsum + first_weight_shift(sl.first) : sl.wsum));
+					if (out.wentries) {
+						uint64_t ew[W + 1];
+#pragma unroll
+						for (int q = 0; q < W; q++) ew[q] = key.w[q];
+						ew[W] = bb_pack_value(cnt, wbits, fwdc);
+						bb_store_entry<W>(out.wentries, pos, ew);
+					} else {
+#pragma unroll
+						for (int q = 0; q < W; q++) out.wkeys[pos * W + q] = key.w[q];
+						uint32_t *v = out.wvals + pos * vw;
+						v[0] = cnt; v[1] = wbits; v[2] = fwdc;
+					}
 					keptW++;
 				}
 			} else if (cls == 2) {
@@ -1329,7 +1347,7 @@ void sk_merge_emit_kernel(Table<W> tbl, CountOut out, FinalizeParams f) {
 				}
 			}
 		}
-		bucket_count_add(out.weakCount, bucket, cls == 1);
+		if (out.weakCount) bucket_count_add(out.weakCount, bucket, cls == 1);
 		bucket_count_add(out.singCount, bucket, cls == 2);
 	}
 	uniq = wave_sum(uniq); single = wave_sum(single); keptW = wave_sum(keptW); keptS = wave_sum(keptS);

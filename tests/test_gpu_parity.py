@@ -509,6 +509,27 @@ def test_many_distinct_keys_force_subpass_split():
     assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
 
 
+@pytest.mark.parametrize("k,nbw,reads", [(31, 1 << 10, 4000), (31, 1 << 16, 30000), (31, 1 << 20, 30000), (51, 1 << 19, 20000), (127, 1 << 12, 6000)])
+def test_buckets_by_radix_partition(k, nbw, reads):
+    """The weak map of the default build is bucketed by an MSD radix partition over the bucket index (kmr_buckets.hpp) instead of a
+    scatter of single entries + per-bucket sort.  Forced on small inputs (kmr_tune binned_buckets_min = 0) in geometries that take one
+    level (few buckets), two levels (2^19 / 2^20 buckets: 11 - 12 bits to resolve) and multi-word keys: bucket offsets, key order and
+    values must be the serial oracle's; with the partition switched off (-1) the image must be the same bytes."""
+    rb = synth_reads(reads, read_len=150, genome_len=reads * 12, seed=321 + k, err=0.01)
+    cfg = default_config(k, estimated_raw_kmers=reads * (150 - k + 1), num_buckets_weak=nbw, num_buckets_singleton=nbw)
+    o, p = run_both(cfg, rb, min_depth=2, mode=3, binned_buckets_min=0)
+    n = compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    assert n > reads
+    q = product(cfg, 3, binned_buckets_min=-1)
+    add(q, rb)
+    q.finalize(2)
+    assert np.array_equal(p.image(KMR_MAP_WEAK), q.image(KMR_MAP_WEAK))
+    # and with singletons kept (min_depth 1: the singleton map takes the per-bucket path beside it)
+    o1, p1 = run_both(cfg, rb, min_depth=1, mode=3, binned_buckets_min=0)
+    compare_weak_images(o1.image(KMR_MAP_WEAK), p1.image(KMR_MAP_WEAK), p1.kb, False)
+    assert np.array_equal(o1.image(KMR_MAP_SINGLETON), p1.image(KMR_MAP_SINGLETON))
+
+
 def test_build_modes_agree_at_scale():
     """3M reads (360M k-mers, two sub-batches, ~2.6e5 final lists): the device-table path and the streaming
     partition path are independent algorithms; their statistics and weak images must be byte-identical
