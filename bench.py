@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (C2 = 10M)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: C2 = 10M; with --gpus 8 C3 = 12.5M per GPU)")
     ap.add_argument("--quality", choices=["flat", "noisy"], default="flat", help="SURVEY 8(d): flat Q40 (the headline), or noisy "
                     "(Q in {40,30,20,10,2} with p = {.80,.10,.05,.04,.01}, errors at Q10: the divide chain and the discard path are live)")
     ap.add_argument("--cpu-reads", type=int, default=1_000_000, help="reads of the CPU baseline's sample")
@@ -201,10 +201,14 @@ def main():
     import kmernator_amd as ka
     from kmernator_amd.distributed import build_partitioned, build_partitioned_superkmers
 
-    n_reads = args.reads
+    # BASELINE.json configs: 1 GPU = C2 (10 M reads, seed 1, 50 Mbp); 8 GPUs = C3 exactly (100 M reads = 12.5 M per GPU, seed 2, 500 Mbp);
+    # other rank counts keep C2's per-GPU batch (weak scaling: 10 M reads per GPU of one shared genome at 30x)
+    c3 = world == 8 and args.reads in (0, 12_500_000)
+    n_reads = args.reads or (12_500_000 if c3 else 10_000_000)
+    seed = 2 if c3 else 1
     kmers_per_read = READ_LEN - K + 1
-    genome_len = 5 * n_reads * world               # 30x coverage
-    bases, quals, offsets = gen_reads(torch, n_reads, genome_len, 1, rank, dev, args.quality)
+    genome_len = 500_000_000 if c3 else 5 * n_reads * world               # 30x coverage
+    bases, quals, offsets = gen_reads(torch, n_reads, genome_len, seed, rank, dev, args.quality)
     total_bases = n_reads * READ_LEN
     torch.cuda.synchronize()
 
@@ -330,8 +334,8 @@ def main():
             "distinct_kmers_per_sec": uniq_total / (dt / args.steps),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: k=31, %d synthetic 150 bp reads per GPU, genome %d bp (30x), 1%% substitutions, %s, "
-                                   "min-depth 2, %s" % (n_reads, genome_len, "flat Q40" if args.quality == "flat" else "noisy qualities (SURVEY 8d)",
+            "config": {"workload": "%s: k=31, %d synthetic 150 bp reads per GPU, seed %d, genome %d bp (30x), 1%% substitutions, %s, "
+                                   "min-depth 2, %s" % ("C3 (BASELINE.json configs[2]: 100 M reads over 8 GPUs)" if c3 else ("C2" if world == 1 else "C2's batch per GPU, weak scaling"), n_reads, seed, genome_len, "flat Q40" if args.quality == "flat" else "noisy qualities (SURVEY 8d)",
                                                         "single hash partition" if world == 1 else "owner-partitioned RCCL all-to-all over %d GPUs" % world),
                        "k": K, "read_len": READ_LEN, "reads_per_gpu": n_reads, "total_kmers": total_kmers, "good_kmers_rank0": st["raw_good_kmers"],
                        "distinct_kmers": uniq_total, "build_mode": mode, "quality": args.quality,

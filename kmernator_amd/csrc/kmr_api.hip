@@ -1602,8 +1602,8 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		const size_t smem = tracking ? sk_count_smem_bytes<W, COUNT_LOG2S, true>() : sk_count_smem_bytes<W, COUNT_LOG2S, false>();
 		if (tracking) HIPCHK(h, hipMemsetAsync(tv.d_unique, 0, 8 * (tv.n + 1), h->stream));
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-		if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, COUNT_THREADS, smem); fprintf(stderr, "sk_count<W=%d>: %d blocks per CU (LDS %zu), %llu lists, %u chunks\n", W, nb, smem, (unsigned long long)nl, nch); }
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lgMain);
+		if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, SKC_THREADS, smem); fprintf(stderr, "sk_count<W=%d>: %d blocks per CU (LDS %zu), %llu lists, %u chunks\n", W, nb, smem, (unsigned long long)nl, nch); }
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(SKC_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lgMain);
 		HIPCHK(h, hipGetLastError());
 		Slot<W> *mslots = nullptr;
 		if (n_items) {
@@ -1615,7 +1615,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 			HIPCHK(h, hipMemsetAsync(lgItems.merge_used, 0, 8, h->stream));
 			rc = zero_work_counter(h); if (rc) { hipFree(mslots); return rc; }
 			const int grid2 = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, n_items);
-			hipLaunchKernelGGL(kern, dim3(grid2), dim3(COUNT_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lgItems);
+			hipLaunchKernelGGL(kern, dim3(grid2), dim3(SKC_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lgItems);
 			hipLaunchKernelGGL(sk_merge_emit_kernel<W>, dim3(grid_for(1ull << merge_log2)), dim3(256), 0, h->stream, lgItems.merge, out, f);
 			if (hipGetLastError() != hipSuccess) { hipFree(mslots); return fail(h, KMR_ERR_HIP, "long-list launches"); }
 		}

@@ -181,21 +181,23 @@ void bb_scatter_kernel(BbInput in, uint32_t shift, uint32_t bits, uint32_t kb, u
 	}
 }
 
-template <int W> __host__ __device__ constexpr size_t bb_group_smem_bytes() { return (size_t)BB_GROUP_CAP * (8 * W + 12 + 2 + 2 + 2); }
+static const int BB_GROUP_PER_THREAD = (BB_GROUP_CAP + BB_THREADS - 1) / BB_THREADS;
+template <int W> __host__ __device__ constexpr size_t bb_group_smem_bytes() { return (size_t)BB_GROUP_CAP * (8 * W + 8 + 2 + 2); }
 
 /* One block per group of 2^gbits neighbouring buckets: its entries lie at [gstart[G], gstart[G] + gcount[G]) of `entries` and go
- * to the same range of the map's key and value arrays, in (bucket, key) order. */
+ * to the same range of the map's key and value arrays, in (bucket, key) order.  A thread keeps its (up to six) entries in
+ * registers while the buckets are counted and scanned, then files them into LDS bucket by bucket, so that the rank loop of an
+ * entry walks the consecutive keys of its bucket (independent LDS reads, no index in between). */
 template <int W>
 __global__ __launch_bounds__(BB_THREADS)
 void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, const uint64_t *gstart, const uint32_t *gcount, uint64_t n_groups, uint32_t gbits, uint32_t kb, uint64_t nb,
                      uint64_t *start, uint64_t n_total, uint32_t *err) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t gsm[];
-	uint64_t *skeys = (uint64_t *)gsm;                                   /* [CAP][W] */
-	uint32_t *svals = (uint32_t *)(skeys + (size_t)BB_GROUP_CAP * W);      /* [CAP][3] */
-	uint16_t *sbucket = (uint16_t *)(svals + (size_t)BB_GROUP_CAP * 3);    /* bucket of an entry inside the group */
-	uint16_t *order = sbucket + BB_GROUP_CAP;                            /* entries grouped by bucket */
-	uint16_t *final_ = order + BB_GROUP_CAP;                             /* entries in (bucket, key) order */
-	__shared__ uint32_t bcnt[1 << BB_MAX_GROUP_BITS], bstart[(1 << BB_MAX_GROUP_BITS) + 1], bscan[BB_THREADS];
+	uint64_t *skeys = (uint64_t *)gsm;                                   /* [CAP][W] keys, grouped by bucket */
+	uint64_t *svalw = skeys + (size_t)BB_GROUP_CAP * W;                  /* [CAP] value words, same order   */
+	uint16_t *sbucket = (uint16_t *)(svalw + BB_GROUP_CAP);              /* bucket (inside the group) of the entry at a position */
+	uint16_t *final_ = sbucket + BB_GROUP_CAP;                           /* position (in bucket order) of the entry that ends up at a place */
+	__shared__ uint32_t bcnt[1 << BB_MAX_GROUP_BITS], bstart[(1 << BB_MAX_GROUP_BITS) + 1], bscan[BB_THREADS / 64];
 	const int t = threadIdx.x;
 	const uint32_t nbk = 1u << gbits;
 	for (uint64_t G = blockIdx.x; G < n_groups; G += gridDim.x) {
@@ -205,16 +207,22 @@ void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, co
 		if ((uint32_t)t < nbk) bcnt[t] = 0;
 		if (n > BB_GROUP_CAP) { if (t == 0) atomicOr(err, (uint32_t)ERR_ENTRIES_FULL); continue; }      /* (the host looked at the largest group before the launch) */
 		__syncthreads();
-		for (uint32_t i = t; i < n; i += BB_THREADS) {
-			uint64_t ew[W + 1];
-			bb_load_entry<W>(entries, base + i, ew);
+		uint64_t ew[BB_GROUP_PER_THREAD][W + 1]; uint32_t lb[BB_GROUP_PER_THREAD];
+#pragma unroll
+		for (int u = 0; u < BB_GROUP_PER_THREAD; u++) {
+			const uint32_t i = (uint32_t)u * BB_THREADS + t;
+			lb[u] = 0xffffffffu;
+			if (i < n) bb_load_entry<W>(entries, base + i, ew[u]);
+		}
+#pragma unroll
+		for (int u = 0; u < BB_GROUP_PER_THREAD; u++) {
+			const uint32_t i = (uint32_t)u * BB_THREADS + t;
+			if (i >= n) continue;
 			Key<W> key;
 #pragma unroll
-			for (int q = 0; q < W; q++) { key.w[q] = ew[q]; skeys[(size_t)i * W + q] = ew[q]; }
-			svals[i * 3] = (uint32_t)ew[W] & 0xffffu; svals[i * 3 + 1] = (uint32_t)(ew[W] >> 32); svals[i * 3 + 2] = ((uint32_t)ew[W] >> 16) & 0xffffu;
-			const uint32_t lb = (uint32_t)(key_hash<W>(key, kb) & (nb - 1)) & (nbk - 1);
-			sbucket[i] = (uint16_t)lb;
-			atomicAdd(&bcnt[lb], 1u);
+			for (int q = 0; q < W; q++) key.w[q] = ew[u][q];
+			lb[u] = (uint32_t)(key_hash<W>(key, kb) & (nb - 1)) & (nbk - 1);
+			atomicAdd(&bcnt[lb[u]], 1u);
 		}
 		__syncthreads();
 		/* exclusive scan of the bucket counts (<= 256 of them, one per thread): inside every wavefront, then the wavefronts' totals */
@@ -231,30 +239,39 @@ void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, co
 			if (t == 0) { bstart[nbk] = n; if (G == n_groups - 1) start[nb] = n_total; }
 		}
 		__syncthreads();
-		for (uint32_t i = t; i < n; i += BB_THREADS) { const uint32_t lb = sbucket[i]; order[bstart[lb] + atomicAdd(&bcnt[lb], 1u)] = (uint16_t)i; }
+#pragma unroll
+		for (int u = 0; u < BB_GROUP_PER_THREAD; u++) {
+			if (lb[u] == 0xffffffffu) continue;
+			const uint32_t pos = bstart[lb[u]] + atomicAdd(&bcnt[lb[u]], 1u);
+#pragma unroll
+			for (int q = 0; q < W; q++) skeys[(size_t)pos * W + q] = ew[u][q];
+			svalw[pos] = ew[u][W];
+			sbucket[pos] = (uint16_t)lb[u];
+		}
 		__syncthreads();
 		for (uint32_t p = t; p < n; p += BB_THREADS) {
-			const uint32_t i = order[p], lb = sbucket[i];
-			const uint32_t s = bstart[lb], e = bstart[lb + 1];
+			const uint32_t b = sbucket[p];
+			const uint32_t s = bstart[b], e = bstart[b + 1];
 			Key<W> mine;
 #pragma unroll
-			for (int q = 0; q < W; q++) mine.w[q] = skeys[(size_t)i * W + q];
+			for (int q = 0; q < W; q++) mine.w[q] = skeys[(size_t)p * W + q];
 			uint32_t rank = 0;
+#pragma unroll 4
 			for (uint32_t qx = s; qx < e; qx++) {
-				const uint32_t j = order[qx];
 				Key<W> other;
 #pragma unroll
-				for (int q = 0; q < W; q++) other.w[q] = skeys[(size_t)j * W + q];
+				for (int q = 0; q < W; q++) other.w[q] = skeys[(size_t)qx * W + q];
 				rank += (key_lt<W>(other, mine) || (key_eq<W>(other, mine) && qx < p)) ? 1u : 0u;
 			}
-			final_[s + rank] = (uint16_t)i;
+			final_[s + rank] = (uint16_t)p;
 		}
 		__syncthreads();
 		for (uint32_t p = t; p < n; p += BB_THREADS) {
 			const uint32_t i = final_[p];
 #pragma unroll
 			for (int q = 0; q < W; q++) keys[(base + p) * W + q] = skeys[(size_t)i * W + q];
-			vals[(base + p) * 3] = svals[i * 3]; vals[(base + p) * 3 + 1] = svals[i * 3 + 1]; vals[(base + p) * 3 + 2] = svals[i * 3 + 2];
+			const uint64_t vw_ = svalw[i];
+			vals[(base + p) * 3] = (uint32_t)vw_ & 0xffffu; vals[(base + p) * 3 + 1] = (uint32_t)(vw_ >> 32); vals[(base + p) * 3 + 2] = ((uint32_t)vw_ >> 16) & 0xffffu;
 		}
 	}
 }

@@ -845,6 +845,11 @@ template <int W> struct SkLong {
 	unsigned long long *merge_used;         /* slots of it claimed so far: beyond 5/8 of the table the launch gives up (ERR_TABLE_FULL) and the host comes back with a larger one */
 };
 
+/* lanes of ONE wavefront hand data to each other through LDS: the LDS executes a wavefront's instructions in issue order, so all that
+ * is needed is that the compiler keeps the order (a workgroup-scope fence here also drains the vector-memory counter, i.e. waits for
+ * every prefetch in flight) */
+__device__ __forceinline__ void sk_wave_lds_order() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+
 template <int W, int LOG2S, bool TRACK = false>
 __host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (TRACK ? 8 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
 
@@ -858,15 +863,19 @@ __host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 <
  * A list whose distinct keys overflow the table (rare: the lists are sized for ~40 % load) is redone in sub-passes that split
  * it by further hash bits, with barriers around every step (the cold path below).  The flags the insert phase raises
  * (claimed slots, overflow) exist twice and alternate from list to list, so nobody has to wait for their reset. */
+#ifndef KMR_SKC_WAVES
+#define KMR_SKC_WAVES 4
+#endif
+static const int SKC_WAVES = KMR_SKC_WAVES, SKC_THREADS = SKC_WAVES * 64;      /* wavefronts of a count block (they share one table) */
 static const unsigned long long SK_OSLAB = 2048;      /* entries a wavefront reserves at a time in the count pass's output */
 
 template <int W, int LOG2S, bool TRACK = false>
-__global__ __launch_bounds__(COUNT_THREADS, (W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 2 : 1))
+__global__ __launch_bounds__(SKC_THREADS, (W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 2 : 1))
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
                      CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv, SkLong<W> lg) {
 	constexpr int S = 1 << LOG2S;
 	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
-	constexpr int WSLOTS = S / SK_STAGE_CHUNKS;        /* slots a wavefront looks after in the emit phase */
+	constexpr int WSLOTS = S / SKC_WAVES;        /* slots a wavefront looks after in the emit phase */
 	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
 	uint64_t *tkeys = (uint64_t *)csm;                                 /* [S][W] */
 	unsigned long long *tcnt = (unsigned long long *)(tkeys + (size_t)S * W);
@@ -885,14 +894,14 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	__shared__ uint32_t s_dchunk[SK_DESC_CAP];
 	__shared__ uint8_t s_dcount[SK_DESC_CAP];
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-	if (TRACK) for (int i = t; i < 2 * (int)(SK_TRACK_MAX + 1); i += COUNT_THREADS) trkU[i] = 0;
+	if (TRACK) for (int i = t; i < 2 * (int)(SK_TRACK_MAX + 1); i += SKC_THREADS) trkU[i] = 0;
 	const uint32_t vw = 3;
 	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;
 	/* this wavefront's output slabs: [wpos, wend) of the weak entries, [spos, send) of the singletons */
 	unsigned long long wpos = 0, wend = 0, spos = 0, send = 0;
 	bool outFull = false;
 	if (t == 0) { s_claimed[0] = s_claimed[1] = 0; s_overflow[0] = s_overflow[1] = 0; s_sp = 0; }
-	for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
+	for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
 	lds_barrier();
 	/* classify() of kmr_kernels.hpp folded into launch-wide scalars: a count of one goes to class singC when singletons are separate,
 	 * any other count below weakMin is dropped */
@@ -924,13 +933,16 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 		/* (with a stride the lists in between hold no chunks -- they went to their owners -- so the batch's descriptors are still one run) */
 		const uint64_t dbase = itemMode ? s_c0[0] : list_start[lg.list_first + lfirst * stride], dend = itemMode ? s_c1[0] : list_start[lg.list_first + (lfirst + nl - 1) * stride + 1];
 		const uint64_t dcached = dend - dbase < (uint64_t)SK_DESC_CAP ? dend - dbase : (uint64_t)SK_DESC_CAP;      /* descriptors [dbase, dbase + dcached) are in LDS (item mode: the first item's) */
-		if ((uint64_t)t < dcached) { const uint64_t d = list_chunks[dbase + t]; s_dchunk[t] = (uint32_t)d; s_dcount[t] = (uint8_t)(d >> 32); }
+		for (uint64_t i = (uint64_t)t; i < dcached; i += SKC_THREADS) { const uint64_t d = list_chunks[dbase + i]; s_dchunk[i] = (uint32_t)d; s_dcount[i] = (uint8_t)(d >> 32); }
 		lds_barrier();
 		/* this wavefront's chunk ci: granule `lane` of it (zeros past its fill count) and the fill count */
-		auto fetch = [&](uint64_t ci, uint4 &v, uint32_t &count) {
-			uint32_t chunk;
+		auto describe = [&](uint64_t ci, uint32_t &chunk, uint32_t &count) {
 			if (ci - dbase < dcached) { chunk = s_dchunk[ci - dbase]; count = s_dcount[ci - dbase]; }
 			else { const uint64_t d = list_chunks[ci]; chunk = (uint32_t)d; count = (uint32_t)(d >> 32); }
+		};
+		auto fetch = [&](uint64_t ci, uint4 &v, uint32_t &count) {
+			uint32_t chunk;
+			describe(ci, chunk, count);
 			v = make_uint4(0, 0, 0, 0);
 			if ((uint32_t)lane < count) v = poolg[(size_t)chunk * SK_CHUNK_G + lane];
 		};
@@ -950,14 +962,9 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				uint4 cur = make_uint4(0, 0, 0, 0); uint32_t curCount = 0;
 				if (firstPass && preList == lfirst + lj) { cur = pre; curCount = preCount; }        /* requested while the list before was counted */
 				else if (c0 + wv < c1) fetch(c0 + wv, cur, curCount);
-				/* this wavefront's first chunk of the next list travels while this list is counted */
-				if (firstPass) {
-					preList = ~0ull;
-					if (lj + 1 < nl) { const uint64_t n0 = s_c0[lj + 1], n1 = s_c1[lj + 1]; if (n0 + wv < n1) { fetch(n0 + wv, pre, preCount); preList = lfirst + lj + 1; } }
-				}
-				for (uint64_t ci = c0 + wv; ci < c1 && !s_overflow[fl] && s_claimed[fl] <= LIMIT; ci += SK_STAGE_CHUNKS) {
-					uint4 nxt = make_uint4(0, 0, 0, 0); uint32_t nxtCount = 0;
-					if (ci + SK_STAGE_CHUNKS < c1) fetch(ci + SK_STAGE_CHUNKS, nxt, nxtCount);
+				bool wantPre = firstPass;      /* this wavefront's first chunk of the next list is requested below, once the current chunk is out of its registers */
+				if (firstPass) preList = ~0ull;
+				for (uint64_t ci = c0 + wv; ci < c1 && !s_overflow[fl] && s_claimed[fl] <= LIMIT; ci += SKC_WAVES) {
 					wstage[lane] = cur;
 					/* record starts: follow the granule counts from granule 0 */
 					const uint32_t glen = (cur.y >> 17) & 0x7fu;
@@ -990,13 +997,29 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						const uint32_t l0 = (uint32_t)((float)(myOff + Lk - 1) / Lf), l1 = (uint32_t)((float)(myOff + myN - 1) / Lf);      /* exact: small integers */
 						for (uint32_t l = l0; l <= l1 && l < 64u; l++) wrecOf[l] = (uint8_t)lane;
 					}
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					sk_wave_lds_order();
 					const uint32_t e0 = (uint32_t)lane * Lk;
 					uint32_t left = e0 < T ? (T - e0 < Lk ? T - e0 : Lk) : 0u;      /* k-mers this lane still has to do */
 					uint32_t rs = left ? wrecOf[lane] : 0u;
 					uint32_t j = e0 - (uint32_t)__shfl((int)myOff, (int)rs, 64);
 					uint32_t hx = (uint32_t)__shfl((int)cur.x, (int)rs, 64), hy = (uint32_t)__shfl((int)cur.y, (int)rs, 64), hw = (uint32_t)__shfl((int)cur.w, (int)rs, 64);
 					if (SK_DBG(dbgFlags, 4)) left = 0;
+					/* The chunk is in LDS and its headers have been read: only NOW are the next chunks requested (this list's c + 4 and, once
+					 * per list, this wavefront's first chunk of the next list).  Requested at the top of the iteration -- before the current
+					 * chunk's registers were consumed -- the compiler had to drain the vector-memory counter to zero to be sure of the older
+					 * load, i.e. it waited for the request it had just made: every chunk paid a full HBM latency and nothing was prefetched. */
+					uint4 nxt = make_uint4(0, 0, 0, 0); uint32_t nxtCount = 0, nxtChunk = 0, preChunk = 0;
+					/* (descriptors first -- the rare one that is not cached in LDS is a load of its own that has to be waited for -- then the
+					 * two chunk requests back to back with nothing to wait for in between) */
+					const bool wantNxt = ci + SKC_WAVES < c1;
+					bool havePre = false;
+					if (wantNxt) describe(ci + SKC_WAVES, nxtChunk, nxtCount);
+					if (wantPre) {
+						wantPre = false;
+						if (lj + 1 < nl) { const uint64_t n0 = s_c0[lj + 1], n1 = s_c1[lj + 1]; if (n0 + wv < n1) { describe(n0 + wv, preChunk, preCount); havePre = true; preList = lfirst + lj + 1; } }
+					}
+					if (wantNxt && (uint32_t)lane < nxtCount) nxt = poolg[(size_t)nxtChunk * SK_CHUNK_G + lane];
+					if (havePre) { pre = make_uint4(0, 0, 0, 0); if ((uint32_t)lane < preCount) pre = poolg[(size_t)preChunk * SK_CHUNK_G + lane]; }
 					/* the record the lane is in: its k-mer count, bases, weights, first ordinal */
 					uint32_t n = 0; const uint32_t *bw = nullptr, *ww = nullptr; bool uniformW = true; uint64_t ord0 = 0;
 					auto enter_record = [&]() {      /* header in hx, hy, hw */
@@ -1111,9 +1134,10 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					if (SK_DBG(dbgFlags, 1) && dbgSink == 0x12345u) s_overflow[fl] = 2;
 					claimedHere = (uint32_t)wave_sum((unsigned long long)claimedHere);
 					if (lane == 0 && claimedHere) atomicAdd(&s_claimed[fl], claimedHere);
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					sk_wave_lds_order();
 					cur = nxt; curCount = nxtCount;
 				}
+				if (wantPre && lj + 1 < nl) { const uint64_t n0 = s_c0[lj + 1], n1 = s_c1[lj + 1]; if (n0 + wv < n1) { fetch(n0 + wv, pre, preCount); preList = lfirst + lj + 1; } }      /* (no chunk of this list was this wavefront's) */
 			};
 			/* ---- emit: this wavefront's quarter of the table -> entries of its output slabs (or the merge table / the size tracker's
 			 * difference arrays), every slot cleared behind it */
@@ -1233,7 +1257,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				}
 			};
 			auto clear_table = [&]() {
-				for (int i = t; i < S; i += COUNT_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
+				for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
 			};
 
 			insert_pass(0, 0, true);
@@ -1287,7 +1311,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	}
 	if (TRACK) {
 		lds_barrier();
-		for (uint32_t i = (uint32_t)t; i <= tv.n && i <= SK_TRACK_MAX; i += COUNT_THREADS) { if (trkU[i]) atomicAdd(&tv.d_unique[i], trkU[i]); if (trkS[i]) atomicAdd(&tv.d_single[i], trkS[i]); }
+		for (uint32_t i = (uint32_t)t; i <= tv.n && i <= SK_TRACK_MAX; i += SKC_THREADS) { if (trkU[i]) atomicAdd(&tv.d_unique[i], trkU[i]); if (trkS[i]) atomicAdd(&tv.d_single[i], trkS[i]); }
 	}
 }
 
