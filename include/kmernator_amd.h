@@ -373,6 +373,11 @@ int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void 
 int kmr_exchange_add_read_batch(kmr_handle *h, const struct kmr_reads *batch, uint64_t first_global_read_idx);      /* the same for a device-resident read batch ("FASTQ ingest" below); NULL = no reads this round */
 int kmr_exchange_stats(kmr_handle *h, uint64_t *bytes_to_peers, double *alltoall_ms);
 
+/* For a kmr_transport that stages the device segments through host memory (an MPI without device pointers; the -P shim's
+ * TRANSPORT_MPI): copies between host memory and the device buffers alltoallv_dev is handed, ordered behind the handle's stream. */
+int kmr_copy_to_host(kmr_handle *h, void *host_dst, const void *dev_src, uint64_t bytes);
+int kmr_copy_to_device(kmr_handle *h, void *dev_dst, const void *host_src, uint64_t bytes);
+
 /* Host-buffer forms of the two halves for a host whose exchange is MPI_Alltoallv over host memory (the reference's own,
  * src/MPIBuffer.h:588-600; include/kmernator_amd_shim.hpp, GpuDistributedKmerSpectrum).  kmr_extract_by_owner_host: the records
  * of a device-resident batch, owner after owner without gaps; seg_counts[world_size] always receives the counts, and with

@@ -74,8 +74,11 @@ public:
 	 * reference constructs `KS spectrum(0)` first and assigns the real one later */
 	GpuKmerSpectrum(unsigned long estimatedRawKmers = 0, bool separateSingletons = true, int valueKind = KMR_VALUE_COUNT_DIR, int device = -1)
 	    : KS(estimatedRawKmers, separateSingletons), _estimatedRawKmers(estimatedRawKmers), _separateSingletons(separateSingletons),
-	      _valueKind(valueKind), _device(device), _rank(0), _worldSize(1) {}
+	      _valueKind(valueKind), _device(device), _rank(0), _worldSize(1), _sizeTracking(false), _wantSizeHistory(false) {}
 	virtual ~GpuKmerSpectrum() {}
+	/* --size-history-file (apps/FilterReads.cpp:141-147): call before the first build of this object.  Off by default: with it on the
+	 * count pass keeps two first sightings per key and cannot cut hot minimizer lists (homopolymers, satellites) into pieces */
+	void setSizeTracking(bool on) { _wantSizeHistory = on; }
 	/* copy construction and assignment: KS copies its maps (src/KmerSpectrum.h:423-440), the device handle is shared */
 
 	/* replaces KmerSpectrum::buildKmerSpectrum(const ReadSet &[, bool]) (src/KmerSpectrum.h:2081-2086) */
@@ -147,7 +150,7 @@ protected:
 	template <typename World>
 	GpuKmerSpectrum(WorldTag, World &world, unsigned long estimatedRawKmers, bool separateSingletons, int valueKind, int device)
 	    : KS(world, estimatedRawKmers, separateSingletons), _estimatedRawKmers(estimatedRawKmers), _separateSingletons(separateSingletons),
-	      _valueKind(valueKind), _device(device), _rank(0), _worldSize(1) {}
+	      _valueKind(valueKind), _device(device), _rank(0), _worldSize(1), _sizeTracking(false), _wantSizeHistory(false) {}
 
 	struct FlatReads {
 		std::string bases, quals;
@@ -158,8 +161,9 @@ protected:
 	};
 	/* the arrays kmr_add_reads takes: sequence characters with markups applied (N / X), quality characters scaled to
 	 * Read::FASTQ_START_CHAR (REF_QUAL strings for reads without quals), byte offsets per read */
-	static void flatten(const ReadSet &store, FlatReads &fr, bool skipDiscarded) {
-		for (ReadSet::ReadSetSizeType i = 0; i < store.getSize(); i++) {
+	static void flatten(const ReadSet &store, FlatReads &fr, bool skipDiscarded) { flatten(store, fr, skipDiscarded, 0, store.getSize()); }
+	static void flatten(const ReadSet &store, FlatReads &fr, bool skipDiscarded, ReadSet::ReadSetSizeType lo, ReadSet::ReadSetSizeType hi) {
+		for (ReadSet::ReadSetSizeType i = lo; i < hi; i++) {
 			const Read &read = store.getRead(i);
 			const bool dis = read.isDiscarded();
 			if (skipDiscarded) fr.discarded.push_back(dis ? 1 : 0);
@@ -185,8 +189,10 @@ protected:
 		c.kmer_subsample = (uint32_t)KS::getKmerSubsample();                    /* src/KmerSpectrum.h:461 */
 		c.device = _device;
 		c.rank = (uint32_t)_rank; c.world_size = (uint32_t)_worldSize;
-		/* the size history (--size-history-file, apps/FilterReads.cpp:141-147) is kept where the library keeps it: kmr_size_tracker */
-		c.size_tracker = (_valueKind == KMR_VALUE_COUNT_DIR && _worldSize == 1 && c.k >= 16) ? 1 : 0;
+		/* the size history (--size-history-file, apps/FilterReads.cpp:141-147) is kept where the library keeps it: kmr_size_tracker
+		 * -- only when the application asks for the history (setSizeTracking): with it on the count pass keeps two first sightings per
+		 * key and cannot cut hot minimizer lists into pieces */
+		c.size_tracker = (_wantSizeHistory && _valueKind == KMR_VALUE_COUNT_DIR && _worldSize == 1 && c.k >= 16) ? 1 : 0;
 		_sizeTracking = c.size_tracker != 0;
 		return c;
 	}
@@ -247,7 +253,7 @@ protected:
 	unsigned long _estimatedRawKmers;
 	bool _separateSingletons;
 	int _valueKind, _device, _rank, _worldSize;
-	bool _sizeTracking;
+	bool _sizeTracking, _wantSizeHistory;
 };
 
 #ifdef KMERNATOR_AMD_SHIM_MPI
@@ -255,56 +261,125 @@ protected:
 /*
  * The -P tools: DKS = DistributedKmerSpectrum<...> or MeraculousDistributedKmerSpectrum (src/DistributedFunctions.h:100-131,
  * src/Meraculous.h:82-105), one MPI rank per GPU.  buildKmerSpectrum(store) replaces _buildKmerSpectrumMPI
- * (src/DistributedFunctions.h:340-458): the rank's reads -> owner segments on the device (kmr_extract_by_owner_dev) ->
- * MPI_Alltoall of the counts, MPI_Alltoallv of the records (as src/MPIBuffer.h:588-600, but KMR_RECORD_BYTES per k-mer instead of
- * 24 + kb) -> kmr_insert_records_dev at the owner, then the post-steps of buildKmerSpectrum (:560-569).  The owner of a k-mer is
- * getDistributedThreadId (src/Kmer.h:2284-2295), unchanged.  Hosts without MPI use kmr_exchange_* (RCCL over xGMI) instead.
+ * (src/DistributedFunctions.h:340-458) with the library's own owner exchange (kmr_exchange_*): the rank's ReadSet goes to the
+ * device in bounded batches, every batch is one collective step -- extract, all-to-all, insert at the owner -- and the steps of
+ * all ranks are counted out beforehand (MPI_Allreduce MAX) so that every rank makes the same calls.  Two transports:
+ *   TRANSPORT_RCCL (default)  the exchange runs over RCCL / xGMI between the GPUs: rank 0 makes the id (kmr_exchange_unique_id),
+ *                             MPI_Bcast carries it, kmr_exchange_init joins the communicator.  Nothing but the id and the
+ *                             batch count ever goes through MPI -- what replaces MPI_Alltoallv of src/MPIBuffer.h:588-600.
+ *   TRANSPORT_MPI             the same driver over MPI (kmr_exchange_init_transport): MPI_Allgather for the counts; the segments
+ *                             are staged through host memory and travel as point-to-point messages whose sizes and offsets are
+ *                             64-bit (the library never asks for more than 1 GiB per message, and no `int` displacement of an
+ *                             MPI_Alltoallv is involved).  For hosts without RCCL between their GPUs.
+ * The owner of a k-mer is the build's own (getDistributedThreadId for k-mer records, the minimizer list for the default build):
+ * the union of the ranks' maps is the serial spectrum either way.
  */
 template <typename DKS>
 class GpuDistributedKmerSpectrum : public GpuKmerSpectrum<DKS> {
 public:
 	typedef GpuKmerSpectrum<DKS> Base;
+	enum Transport { TRANSPORT_RCCL = 0, TRANSPORT_MPI = 1 };
 	/* DistributedKmerSpectrum(mpi::communicator &, estimatedRawKmers, separateSingletons), src/DistributedFunctions.h:124-131
 	 * (mpi = boost::mpi there; the communicator converts to MPI_Comm) */
-	GpuDistributedKmerSpectrum(mpi::communicator &world, unsigned long estimatedRawKmers = 0, bool separateSingletons = true, int valueKind = KMR_VALUE_COUNT_DIR, int device = -1)
-	    : Base(typename Base::WorldTag(), world, estimatedRawKmers, separateSingletons, valueKind, device), _comm((MPI_Comm)world) {
+	GpuDistributedKmerSpectrum(mpi::communicator &world, unsigned long estimatedRawKmers = 0, bool separateSingletons = true, int valueKind = KMR_VALUE_COUNT_DIR, int device = -1,
+	                           Transport transport = TRANSPORT_RCCL, uint64_t batchBases = (uint64_t)1 << 28)
+	    : Base(typename Base::WorldTag(), world, estimatedRawKmers, separateSingletons, valueKind, device), _comm((MPI_Comm)world), _transport(transport), _batchBases(batchBases), _exchangeReady(false) {
 		MPI_Comm_rank(_comm, &this->_rank); MPI_Comm_size(_comm, &this->_worldSize);
 		this->_estimatedRawKmers = estimatedRawKmers * (unsigned long)this->_worldSize;      /* kmr_config takes the whole job's figure */
 	}
 	virtual void buildKmerSpectrum(const ReadSet &store) { buildKmerSpectrum(store, false); }
 	virtual void buildKmerSpectrum(const ReadSet &store, bool isSolid) {
 		if (isSolid) throw std::runtime_error("GpuDistributedKmerSpectrum: the solid map is not built on this path");
-		typename Base::FlatReads fr;
-		Base::flatten(store, fr, true);
 		this->ensureHandle();
 		kmr_handle *h = this->handle();
-		const int R = this->_worldSize;
 		this->check(kmr_reset(h), "kmr_reset");
-		kmr_reads *batch = NULL;
-		this->check(kmr_reads_from_host(h, fr.bases.data(), fr.anyQuals ? fr.quals.data() : NULL, &fr.offsets[0], store.getSize(), &batch), "kmr_reads_from_host");
-		uint64_t nReads = 0, totalBases = 0;
-		kmr_reads_info(batch, &nReads, &totalBases, NULL, NULL);
-		const uint32_t recBytes = KMR_RECORD_BYTES(KmerSizer::getSequenceLength(), (uint32_t)this->_valueKind);
-		std::vector<char> sendBuf, recvBuf;
-		std::vector<uint64_t> segCounts(R, 0);
-		int rc = kmr_extract_by_owner_host(h, batch, store.getGlobalOffset(this->_rank), &segCounts[0], NULL, 0);      /* sizes first */
-		uint64_t total = 0; for (int r = 0; r < R; r++) total += segCounts[r];
-		sendBuf.resize((size_t)total * recBytes + 1);
-		if (rc == KMR_OK) rc = kmr_extract_by_owner_host(h, batch, store.getGlobalOffset(this->_rank), &segCounts[0], &sendBuf[0], sendBuf.size());
-		kmr_reads_free(batch);
-		this->check(rc, "kmr_extract_by_owner_host");
-		std::vector<int> sc(R), sd(R), rcnt(R), rd(R);
-		std::vector<uint64_t> recvCounts(R, 0);
-		MPI_Alltoall(&segCounts[0], 1, MPI_UINT64_T, &recvCounts[0], 1, MPI_UINT64_T, _comm);
-		uint64_t so = 0, ro = 0;
-		for (int r = 0; r < R; r++) { sc[r] = (int)(segCounts[r] * recBytes); sd[r] = (int)so; so += sc[r]; rcnt[r] = (int)(recvCounts[r] * recBytes); rd[r] = (int)ro; ro += rcnt[r]; }
-		recvBuf.resize((size_t)ro + 1);
-		MPI_Alltoallv(&sendBuf[0], &sc[0], &sd[0], MPI_BYTE, &recvBuf[0], &rcnt[0], &rd[0], MPI_BYTE, _comm);
-		this->check(kmr_insert_records(h, &recvBuf[0], ro / recBytes), "kmr_insert_records");
+		joinExchange(h);
+		/* batches of about _batchBases bases: [lo, hi) read ranges of this rank; every rank makes as many steps as the busiest one */
+		std::vector<ReadSet::ReadSetSizeType> cuts(1, 0);
+		uint64_t acc = 0;
+		for (ReadSet::ReadSetSizeType i = 0; i < store.getSize(); i++) {
+			acc += store.getRead(i).getLength();
+			if (acc >= _batchBases) { cuts.push_back(i + 1); acc = 0; }
+		}
+		if (cuts.back() != store.getSize()) cuts.push_back(store.getSize());
+		unsigned long long mySteps = cuts.size() - 1, steps = 0;
+		MPI_Allreduce(&mySteps, &steps, 1, MPI_UNSIGNED_LONG_LONG, MPI_MAX, _comm);
+		const uint64_t first = store.getGlobalOffset(this->_rank);
+		int failed = KMR_OK; std::string why;
+		for (unsigned long long sidx = 0; sidx < steps; sidx++) {
+			kmr_reads *batch = NULL;
+			int rc = KMR_OK;
+			if (sidx < mySteps && failed == KMR_OK) {
+				typename Base::FlatReads fr;
+				Base::flatten(store, fr, true, cuts[sidx], cuts[sidx + 1]);
+				rc = kmr_reads_from_host(h, fr.bases.data(), fr.anyQuals ? fr.quals.data() : NULL, &fr.offsets[0], cuts[sidx + 1] - cuts[sidx], &batch);
+				if (rc != KMR_OK) { failed = rc; why = kmr_last_error(h); batch = NULL; }
+			}
+			/* (a rank whose copy to the device failed still takes part in the step, with nothing: the library's steps are collective.  A
+			 * failure INSIDE a step comes back on every rank -- the status word of kmr_exchange_add_reads_dev -- so all ranks stop together) */
+			rc = kmr_exchange_add_read_batch(h, batch, first + (sidx < mySteps ? cuts[sidx] : 0));
+			if (batch) kmr_reads_free(batch);
+			if (rc != KMR_OK) { if (failed == KMR_OK) { failed = rc; why = kmr_last_error(h); } break; }
+		}
+		int anyFailed = failed != KMR_OK ? 1 : 0, jobFailed = 0;
+		MPI_Allreduce(&anyFailed, &jobFailed, 1, MPI_INT, MPI_MAX, _comm);
+		if (jobFailed) throw std::runtime_error("GpuDistributedKmerSpectrum::buildKmerSpectrum: " + (failed != KMR_OK ? why : std::string("another rank failed")));
 		this->pull(KmerSpectrumOptions::getOptions().getMinDepth());
 	}
 private:
+	/* once per device handle: the communicator of the exchange */
+	void joinExchange(kmr_handle *h) {
+		if (_exchangeReady) return;
+		if (_transport == TRANSPORT_RCCL) {
+			char id[KMR_EXCHANGE_ID_BYTES];
+			int rc = KMR_OK;
+			if (this->_rank == 0) rc = kmr_exchange_unique_id(id);
+			MPI_Bcast(&rc, 1, MPI_INT, 0, _comm);
+			if (rc != KMR_OK) throw std::runtime_error("kmr_exchange_unique_id failed on rank 0 (no RCCL?): construct with TRANSPORT_MPI");
+			MPI_Bcast(id, KMR_EXCHANGE_ID_BYTES, MPI_BYTE, 0, _comm);
+			this->check(kmr_exchange_init(h, id), "kmr_exchange_init");
+		} else {
+			kmr_transport t;
+			t.user = this; t.allgather_u64 = &mpiAllgather; t.alltoallv_dev = &mpiAlltoallv;
+			this->check(kmr_exchange_init_transport(h, &t), "kmr_exchange_init_transport");
+		}
+		_exchangeReady = true;
+	}
+	static int mpiAllgather(void *user, const uint64_t *mine, uint64_t n, uint64_t *all) {
+		GpuDistributedKmerSpectrum *self = (GpuDistributedKmerSpectrum *)user;
+		return MPI_Allgather(const_cast<uint64_t *>(mine), (int)n, MPI_UINT64_T, all, (int)n, MPI_UINT64_T, self->_comm) == MPI_SUCCESS ? KMR_OK : KMR_ERR_HIP;
+	}
+	/* device segments through host memory: 64-bit sizes and offsets throughout, one message per peer and call (<= 1 GiB each by the
+	 * library's contract, checked), receives posted before the sends */
+	static int mpiAlltoallv(void *user, const void *send, const uint64_t *sendOff, const uint64_t *sendBytes, void *recv, const uint64_t *recvOff, const uint64_t *recvBytes, void *) {
+		GpuDistributedKmerSpectrum *self = (GpuDistributedKmerSpectrum *)user;
+		kmr_handle *h = self->handle();
+		const int R = self->_worldSize;
+		std::vector<std::vector<char> > out(R), in(R);
+		std::vector<MPI_Request> reqs;
+		for (int r = 0; r < R; r++) {
+			if (sendBytes[r] > ((uint64_t)1 << 30) || recvBytes[r] > ((uint64_t)1 << 30)) return KMR_ERR_CAPACITY;
+			if (recvBytes[r]) { in[r].resize((size_t)recvBytes[r]); MPI_Request q; MPI_Irecv(&in[r][0], (int)recvBytes[r], MPI_BYTE, r, 7101, self->_comm, &q); reqs.push_back(q); }
+		}
+		for (int r = 0; r < R; r++) {
+			if (!sendBytes[r]) continue;
+			out[r].resize((size_t)sendBytes[r]);
+			const int rc = kmr_copy_to_host(h, &out[r][0], (const char *)send + sendOff[r], sendBytes[r]);
+			if (rc != KMR_OK) return rc;
+			MPI_Request q; MPI_Isend(&out[r][0], (int)sendBytes[r], MPI_BYTE, r, 7101, self->_comm, &q); reqs.push_back(q);
+		}
+		if (!reqs.empty() && MPI_Waitall((int)reqs.size(), &reqs[0], MPI_STATUSES_IGNORE) != MPI_SUCCESS) return KMR_ERR_HIP;
+		for (int r = 0; r < R; r++) {
+			if (!recvBytes[r]) continue;
+			const int rc = kmr_copy_to_device(h, (char *)recv + recvOff[r], &in[r][0], recvBytes[r]);
+			if (rc != KMR_OK) return rc;
+		}
+		return KMR_OK;
+	}
 	MPI_Comm _comm;
+	Transport _transport;
+	uint64_t _batchBases;
+	bool _exchangeReady;
 };
 #endif /* KMERNATOR_AMD_SHIM_MPI */
 

@@ -70,6 +70,7 @@ struct Tuning {
 	bool no_lut = false, no_narrow = false, no_l1_state = false, no_stream_lookups = false;
 	uint64_t long_list_chunks = 0;     /* lists of more chunks are counted in pieces (0: 1024) */
 	uint64_t binned_min = 1ull << 18;  /* weak maps of at least this many entries are bucketed by the radix partition of kmr_buckets.hpp (build_mode 3) */
+	bool exchange_fail_once = false;   /* tests: the next kmr_exchange_add_reads_dev of this rank fails locally (the other ranks must come back with an error, not hang) */
 	bool no_coarse_lists = true;       /* exchange: scatter into the job's fine lists (default) or, kmr_tune("coarse_lists", 1), into coarse ones that the owner splits before the count pass (sk_refine_kernel: not yet fast enough to pay) */
 };
 
@@ -1882,6 +1883,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "lookup_table") h->tune.no_lut = value == 0;
 	else if (k == "stream_lookups") h->tune.no_stream_lookups = value == 0;
 	else if (k == "long_list_chunks") h->tune.long_list_chunks = value < 2 ? 2 : (uint64_t)value;
+	else if (k == "exchange_fail_once") h->tune.exchange_fail_once = value != 0;
 	else if (k == "binned_buckets_min") h->tune.binned_min = value >= 0 ? (uint64_t)value : ~0ull;        /* < 0: never */
 	else if (k == "coarse_lists") h->tune.no_coarse_lists = value == 0;
 	else if (k == "narrow_tallies") h->tune.no_narrow = value == 0;

@@ -75,7 +75,7 @@ int kmr_exchange_init(kmr_handle *h, const void *id) {
 	ncclComm_t comm = nullptr;
 	RCCLCHK(h, g_rccl.CommInitRank(&comm, (int)h->cfg.world_size, u, (int)h->cfg.rank));
 	h->xc_comm = comm;
-	HIPCHK(h, hipMalloc((void **)&h->xc_small, 8ull * (2 * SK_OWNER_MAX) * (SK_OWNER_MAX + 1)));
+	HIPCHK(h, hipMalloc((void **)&h->xc_small, 8ull * (2 * SK_OWNER_MAX + 2) * (SK_OWNER_MAX + 1)));
 	h->xc_tr.user = h; h->xc_tr.allgather_u64 = rccl_allgather_u64; h->xc_tr.alltoallv_dev = rccl_alltoallv_dev;
 	return exchange_ready(h);
 }
@@ -105,7 +105,7 @@ static int xc_reserve(kmr_handle *h, void **p, uint64_t &cap, uint64_t bytes) {
 static int rccl_allgather_u64(void *user, const uint64_t *mine, uint64_t n, uint64_t *all) {
 	kmr_handle *h = (kmr_handle *)user;
 	const uint32_t world = h->cfg.world_size;
-	if (n > 2 * SK_OWNER_MAX) return fail(h, KMR_ERR_INVALID_ARG, "allgather row too long");
+	if (n > 2 * SK_OWNER_MAX + 2) return fail(h, KMR_ERR_INVALID_ARG, "allgather row too long");
 	unsigned long long *d = h->xc_small;      /* [n] mine, then [world][n] */
 	HIPCHK(h, hipMemcpyAsync(d, mine, 8 * n, hipMemcpyHostToDevice, h->stream));
 	RCCLCHK(h, g_rccl.AllGather(d, d + n, n, ncclUint64, (ncclComm_t)h->xc_comm, h->stream));
@@ -158,49 +158,79 @@ static int xc_alltoallv(kmr_handle *h, const uint8_t *sbuf, const std::vector<ui
 	return 0;
 }
 
+/* A collective step must not be left by one rank alone: what a rank does between two collectives (extraction, packing, growing its
+ * buffers) can fail on that rank only, and the others would wait in the next collective for ever.  Every gathered row therefore
+ * ends in a STATUS word -- the rank's error code so far -- and after each gather all ranks look at all status words: if any is
+ * set, every rank leaves with an error before anything is sent (the failing rank with its own code and message, the others with
+ * KMR_ERR_STATE naming the rank). */
+static int xc_agree(kmr_handle *h, int local_rc, const std::vector<uint64_t> &all, size_t row) {
+	const uint32_t world = h->cfg.world_size;
+	for (uint32_t r = 0; r < world; r++) {
+		const int code = (int)(int64_t)all[(size_t)r * row + row - 1];
+		if (code == 0) continue;
+		if (local_rc) return local_rc;      /* this rank's own error (its message is set) */
+		return fail(h, KMR_ERR_STATE, "exchange: rank " + std::to_string(r) + " failed in this batch (code " + std::to_string(code) + "); no rank sent anything");
+	}
+	return local_rc;
+}
+
 int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_quals, const void *dev_offsets, uint64_t n_reads, uint64_t total_bases,
                                uint64_t first_global_read_idx, const void *dev_discarded) {
-	if (!h || (n_reads && (!dev_bases || !dev_offsets))) return KMR_ERR_INVALID_ARG;
+	if (!h) return KMR_ERR_INVALID_ARG;
 	if (!h->xc_tr.allgather_u64) return fail(h, KMR_ERR_STATE, "kmr_exchange_add_reads_dev before kmr_exchange_init / kmr_exchange_init_transport");
 	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_exchange_add_reads_dev after kmr_finalize (kmr_reset first)");
 	hipSetDevice(h->device);
 	const uint32_t world = h->cfg.world_size, rank = h->cfg.rank;
-	int rc = 0;
-	std::vector<uint64_t> mine(2 * world, 0), all;
+	const size_t row = 2 * (size_t)world + 1;      /* numbers of the step, then the status word */
+	int rc = 0, lrc = 0;                            /* lrc: what went wrong on THIS rank since the last agreement */
+	if (n_reads && (!dev_bases || !dev_offsets)) { lrc = fail(h, KMR_ERR_INVALID_ARG, "null device buffer"); n_reads = 0; total_bases = 0; }
+	if (h->tune.exchange_fail_once) { h->tune.exchange_fail_once = false; lrc = fail(h, KMR_ERR_OOM, "injected failure (kmr_tune exchange_fail_once: the tests' way to fail one rank of a collective step)"); n_reads = 0; total_bases = 0; }
+	std::vector<uint64_t> mine(row, 0), all;
 	hipEvent_t ea = nullptr, eb = nullptr;
+	auto status = [&](int code) { mine[row - 1] = (uint64_t)(int64_t)code; };
 	if (h->superkmer_mode) {
 		/* global ordinals: this rank's batch begins behind the batches of the lower ranks, and behind everything the job was fed before */
 		mine[0] = total_bases;
-		rc = xc_allgather_rows(h, mine, all); if (rc) return rc;
+		rc = xc_allgather_rows(h, mine, all); if (rc) return rc;      /* (a rank that failed already still takes part: it reports at the next gather) */
 		uint64_t before = 0, job = 0;
-		for (uint32_t r = 0; r < world; r++) { if (r < rank) before += all[(size_t)r * 2 * world]; job += all[(size_t)r * 2 * world]; }
-		rc = kmr_set_stream_origin(h, h->xc_job_bases + before); if (rc) return rc;
-		h->xc_job_bases += job;
-		if (n_reads) { rc = kmr_add_reads_dev(h, dev_bases, dev_quals, dev_offsets, n_reads, total_bases, first_global_read_idx, dev_discarded); if (rc) return rc; }
-		std::vector<uint64_t> chunks(world, 0), granules(world, 0);
-		rc = kmr_sk_exchange_counts(h, chunks.data(), granules.data()); if (rc) return rc;
-		std::vector<uint64_t> goff(world, 0), coff(world, 0);
+		for (uint32_t r = 0; r < world; r++) { if (r < rank) before += all[(size_t)r * row]; job += all[(size_t)r * row]; }
+		std::vector<uint64_t> chunks(world, 0), granules(world, 0), goff(world, 0), coff(world, 0);
 		uint64_t ag = 0, ac = 0;
-		for (uint32_t r = 0; r < world; r++) {
-			if (r == rank) chunks[r] = granules[r] = 0;
-			goff[r] = ag; coff[r] = ac; ag += granules[r]; ac += chunks[r];
-			mine[r] = chunks[r]; mine[world + r] = granules[r];
+		if (!lrc) lrc = kmr_set_stream_origin(h, h->xc_job_bases + before);
+		h->xc_job_bases += job;
+		if (!lrc && n_reads) lrc = kmr_add_reads_dev(h, dev_bases, dev_quals, dev_offsets, n_reads, total_bases, first_global_read_idx, dev_discarded);
+		if (!lrc) lrc = kmr_sk_exchange_counts(h, chunks.data(), granules.data());
+		if (!lrc) {
+			for (uint32_t r = 0; r < world; r++) {
+				if (r == rank) chunks[r] = granules[r] = 0;
+				/* sk_pack_kernel books chunks << 40 | granules in one word per owner */
+				if (chunks[r] >= (1ull << 24) || granules[r] >= (1ull << 40)) lrc = fail(h, KMR_ERR_CAPACITY, "exchange: more than 2^24 chunks for one owner in one batch; feed smaller batches");
+				goff[r] = ag; coff[r] = ac; ag += granules[r]; ac += chunks[r];
+			}
 		}
-		rc = xc_reserve(h, &h->xc_send, h->xc_send_cap, 16 * std::max<uint64_t>(ag, 1)); if (rc) return rc;
-		rc = xc_reserve(h, &h->xc_send2, h->xc_send2_cap, 8 * std::max<uint64_t>(ac, 1)); if (rc) return rc;
-		rc = kmr_sk_exchange_pack_dev(h, h->xc_send, h->xc_send2, goff.data(), coff.data()); if (rc) return rc;
+		if (!lrc) lrc = xc_reserve(h, &h->xc_send, h->xc_send_cap, 16 * std::max<uint64_t>(ag, 1));
+		if (!lrc) lrc = xc_reserve(h, &h->xc_send2, h->xc_send2_cap, 8 * std::max<uint64_t>(ac, 1));
+		if (!lrc) lrc = kmr_sk_exchange_pack_dev(h, h->xc_send, h->xc_send2, goff.data(), coff.data());
+		std::fill(mine.begin(), mine.end(), 0);
+		if (!lrc) for (uint32_t r = 0; r < world; r++) { mine[r] = chunks[r]; mine[world + r] = granules[r]; }
+		status(lrc);
 		rc = xc_allgather_rows(h, mine, all); if (rc) return rc;
+		rc = xc_agree(h, lrc, all, row); if (rc) return rc;
 		std::vector<uint64_t> rc_c(world, 0), rc_g(world, 0), rgo(world, 0), rco(world, 0), sgb(world), scb(world), sgo(world), sco(world);
 		uint64_t rg = 0, rcn = 0, biggest = 0;
 		for (uint32_t r = 0; r < world; r++) {
-			rc_c[r] = 8 * all[(size_t)r * 2 * world + rank]; rc_g[r] = 16 * all[(size_t)r * 2 * world + world + rank];
+			rc_c[r] = 8 * all[(size_t)r * row + rank]; rc_g[r] = 16 * all[(size_t)r * row + world + rank];
 			rco[r] = rcn; rgo[r] = rg; rcn += rc_c[r]; rg += rc_g[r];
 			scb[r] = 8 * chunks[r]; sgb[r] = 16 * granules[r]; sco[r] = 8 * coff[r]; sgo[r] = 16 * goff[r];
-			for (uint32_t q = 0; q < world; q++) biggest = std::max<uint64_t>(biggest, 16 * all[(size_t)r * 2 * world + world + q]);
+			for (uint32_t q = 0; q < world; q++) biggest = std::max<uint64_t>(biggest, 16 * all[(size_t)r * row + world + q]);
 		}
 		const uint64_t slices = std::max<uint64_t>(1, (biggest + XC_MAX_MESSAGE - 1) / XC_MAX_MESSAGE);
-		rc = xc_reserve(h, &h->xc_recv, h->xc_recv_cap, std::max<uint64_t>(rg, 16)); if (rc) return rc;
-		rc = xc_reserve(h, &h->xc_recv2, h->xc_recv2_cap, std::max<uint64_t>(rcn, 8)); if (rc) return rc;
+		/* the receive buffers are the last thing that can fail on one rank alone: one more (status-only) agreement before anything moves */
+		lrc = xc_reserve(h, &h->xc_recv, h->xc_recv_cap, std::max<uint64_t>(rg, 16));
+		if (!lrc) lrc = xc_reserve(h, &h->xc_recv2, h->xc_recv2_cap, std::max<uint64_t>(rcn, 8));
+		std::fill(mine.begin(), mine.end(), 0); status(lrc);
+		rc = xc_allgather_rows(h, mine, all); if (rc) return rc;
+		rc = xc_agree(h, lrc, all, row); if (rc) return rc;
 		time_begin(h, KMR_TIME_EXCHANGE, &ea, &eb);
 		rc = xc_alltoallv(h, (const uint8_t *)h->xc_send2, sco, scb, (uint8_t *)h->xc_recv2, rco, rc_c, 1, 8);
 		if (!rc) rc = xc_alltoallv(h, (const uint8_t *)h->xc_send, sgo, sgb, (uint8_t *)h->xc_recv, rgo, rc_g, slices, 16);
@@ -217,35 +247,40 @@ int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void 
 	uint64_t segcap = std::min<uint64_t>(upper, upper / world + upper / (4 * world) + 4096);
 	const uint64_t sb = h->stream_base, rd = h->reads;
 	unsigned long long bad0 = 0; hipMemcpy(&bad0, &h->dstats->sender_bad, 8, hipMemcpyDeviceToHost);      /* a repeated attempt must not count the dropped k-mers twice */
-	if (!h->xc_dcounts) HIPCHK(h, hipMalloc((void **)&h->xc_dcounts, 8 * SK_OWNER_MAX));
-	unsigned long long *dcounts = h->xc_dcounts;
 	std::vector<uint64_t> counts(world, 0);
-	for (;;) {      /* a skewed batch (one owner takes more than its share) is extracted again into larger segments */
-		rc = xc_reserve(h, &h->xc_send, h->xc_send_cap, (uint64_t)world * segcap * rb); if (rc) return rc;
+	if (!lrc && !h->xc_dcounts && hipMalloc((void **)&h->xc_dcounts, 8 * SK_OWNER_MAX) != hipSuccess) { h->xc_dcounts = nullptr; lrc = fail(h, KMR_ERR_OOM, "exchange counters"); }
+	unsigned long long *dcounts = h->xc_dcounts;
+	while (!lrc) {      /* a skewed batch (one owner takes more than its share) is extracted again into larger segments */
+		lrc = xc_reserve(h, &h->xc_send, h->xc_send_cap, (uint64_t)world * segcap * rb); if (lrc) break;
 		h->stream_base = sb; h->reads = rd;
-		if (n_reads) rc = kmr_extract_by_owner_dev(h, dev_bases, dev_quals, dev_offsets, n_reads, total_bases, first_global_read_idx, dev_discarded, h->xc_send, segcap, dcounts);
-		else HIPCHK(h, hipMemsetAsync(dcounts, 0, 8 * world, h->stream));
-		if (!rc) rc = sync_state(h);
-		if (rc == KMR_ERR_CAPACITY && segcap < upper) {
+		if (n_reads) lrc = kmr_extract_by_owner_dev(h, dev_bases, dev_quals, dev_offsets, n_reads, total_bases, first_global_read_idx, dev_discarded, h->xc_send, segcap, dcounts);
+		else if (hipMemsetAsync(dcounts, 0, 8 * world, h->stream) != hipSuccess) lrc = fail(h, KMR_ERR_HIP, "hipMemsetAsync(exchange counters)");
+		if (!lrc) lrc = sync_state(h);
+		if (lrc == KMR_ERR_CAPACITY && segcap < upper) {
 			uint32_t e = 0; hipMemcpy(&e, h->derr, 4, hipMemcpyDeviceToHost); e &= ~(uint32_t)ERR_SEGMENT_OVERFLOW; hipMemcpy(h->derr, &e, 4, hipMemcpyHostToDevice); hipMemcpy(&h->dstats->sender_bad, &bad0, 8, hipMemcpyHostToDevice);
 			segcap = std::min<uint64_t>(upper, segcap * 2);
+			lrc = 0;
 			continue;
 		}
-		if (rc) return rc;
 		break;
 	}
-	HIPCHK(h, hipMemcpy(counts.data(), dcounts, 8 * world, hipMemcpyDeviceToHost));
-	for (uint32_t r = 0; r < world; r++) mine[r] = counts[r];
+	if (!lrc && hipMemcpy(counts.data(), dcounts, 8 * world, hipMemcpyDeviceToHost) != hipSuccess) lrc = fail(h, KMR_ERR_HIP, "hipMemcpy(exchange counters)");
+	if (!lrc) for (uint32_t r = 0; r < world; r++) mine[r] = counts[r];
+	status(lrc);
 	rc = xc_allgather_rows(h, mine, all); if (rc) return rc;
+	rc = xc_agree(h, lrc, all, row); if (rc) return rc;
 	std::vector<uint64_t> sbytes(world), soff(world), rbytes(world, 0), roff(world, 0);
 	uint64_t got = 0, biggest = 0, sent = 0;
 	for (uint32_t r = 0; r < world; r++) {
 		sbytes[r] = r == rank ? 0 : counts[r] * rb; soff[r] = (uint64_t)r * segcap * rb; sent += sbytes[r];
-		rbytes[r] = r == rank ? 0 : all[(size_t)r * 2 * world + rank] * rb; roff[r] = got; got += rbytes[r];
-		for (uint32_t q = 0; q < world; q++) if (q != r) biggest = std::max<uint64_t>(biggest, all[(size_t)r * 2 * world + q] * rb);
+		rbytes[r] = r == rank ? 0 : all[(size_t)r * row + rank] * rb; roff[r] = got; got += rbytes[r];
+		for (uint32_t q = 0; q < world; q++) if (q != r) biggest = std::max<uint64_t>(biggest, all[(size_t)r * row + q] * rb);
 	}
 	const uint64_t slices = std::max<uint64_t>(1, (biggest + XC_MAX_MESSAGE - 1) / XC_MAX_MESSAGE);
-	rc = xc_reserve(h, &h->xc_recv, h->xc_recv_cap, std::max<uint64_t>(got, 16)); if (rc) return rc;
+	lrc = xc_reserve(h, &h->xc_recv, h->xc_recv_cap, std::max<uint64_t>(got, 16));
+	std::fill(mine.begin(), mine.end(), 0); status(lrc);
+	rc = xc_allgather_rows(h, mine, all); if (rc) return rc;
+	rc = xc_agree(h, lrc, all, row); if (rc) return rc;
 	time_begin(h, KMR_TIME_EXCHANGE, &ea, &eb);
 	rc = xc_alltoallv(h, (const uint8_t *)h->xc_send, soff, sbytes, (uint8_t *)h->xc_recv, roff, rbytes, slices, rb);
 	time_end(h, KMR_TIME_EXCHANGE, ea, eb);
@@ -255,6 +290,20 @@ int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void 
 	if (counts[rank]) { rc = kmr_insert_records_dev(h, (const uint8_t *)h->xc_send + (uint64_t)rank * segcap * rb, counts[rank]); if (rc) return rc; }
 	if (got) { rc = kmr_insert_records_dev(h, h->xc_recv, got / rb); if (rc) return rc; }
 	return sync_state(h);
+}
+int kmr_copy_to_host(kmr_handle *h, void *host_dst, const void *dev_src, uint64_t bytes) {
+	if (!h || (bytes && (!host_dst || !dev_src))) return KMR_ERR_INVALID_ARG;
+	hipSetDevice(h->device);
+	HIPCHK(h, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	return KMR_OK;
+}
+int kmr_copy_to_device(kmr_handle *h, void *dev_dst, const void *host_src, uint64_t bytes) {
+	if (!h || (bytes && (!dev_dst || !host_src))) return KMR_ERR_INVALID_ARG;
+	hipSetDevice(h->device);
+	HIPCHK(h, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	return KMR_OK;
 }
 int kmr_exchange_add_read_batch(kmr_handle *h, const kmr_reads *r, uint64_t first_global_read_idx) {
 	if (!h) return KMR_ERR_INVALID_ARG;

@@ -1020,29 +1020,52 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					}
 					if (wantNxt && (uint32_t)lane < nxtCount) nxt = poolg[(size_t)nxtChunk * SK_CHUNK_G + lane];
 					if (havePre) { pre = make_uint4(0, 0, 0, 0); if ((uint32_t)lane < preCount) pre = poolg[(size_t)preChunk * SK_CHUNK_G + lane]; }
-					/* the record the lane is in: its k-mer count, bases, weights, first ordinal */
-					uint32_t n = 0; const uint32_t *bw = nullptr, *ww = nullptr; bool uniformW = true; uint64_t ord0 = 0;
+					/* the record the lane is in: its k-mer count, weights, first ordinal */
+					uint32_t n = 0; const uint32_t *ww = nullptr; bool uniformW = true; uint64_t ord0 = 0;
 					auto enter_record = [&]() {      /* header in hx, hy, hw */
 						n = (hy >> 8) & 0xffu;
-						bw = (const uint32_t *)(wstage + rs + 1);
-						ww = bw + 4 * sk_base_granules(n, k);
+						ww = (const uint32_t *)(wstage + rs + 1) + 4 * sk_base_granules(n, k);
 						uniformW = ((hy >> 16) & 1u) != 0;
 						ord0 = (uint64_t)hx | ((uint64_t)(hy & 0xffu) << 32);
 					};
-					/* current k-mer: canonical key, strand, table slot and what its home slot holds.  Every k-mer is cut out of its record's
-					 * bases and reverse-complemented on its own (~30 instructions): rolling one base in would be cheaper per k-mer, but
-					 * lanes change records at different times and the wavefront would pay for both paths at nearly every step. */
-					Key<W> key; bool fwd = true; uint64_t h = 0; uint32_t slot = 0; uint64_t seen = 0, seenFirst = 0; bool mine = false;
+					/* The bases of the k-mers a lane expands lie in REGISTERS: a window of 2 W + 2 dwords of its record's packed bases, the
+					 * current k-mer `sb` bits into it (0 <= sb <= 62); the next k-mer of the same record is the window two bits further on
+					 * (no LDS read, and nothing to wait for, per k-mer).  A lane that will run out of its record has the NEXT record's header
+					 * and first window in registers already: they were requested when the lane entered the current one. */
+					constexpr int NWD = 2 * W + 2;
+					uint32_t win[NWD], nwin[NWD], sb = 0;
+					uint4 nh = make_uint4(0, 0, 0, 0); uint32_t nrs = 0;
+#pragma unroll
+					for (int i = 0; i < NWD; i++) { win[i] = 0; nwin[i] = 0; }
+					auto seed_window = [&]() {       /* the window of k-mer j of the record at granule rs (a record entered in its middle, or a window run out) */
+						const uint32_t *bw = (const uint32_t *)(wstage + rs + 1) + (j >> 4);
+#pragma unroll
+						for (int i = 0; i < NWD; i++) win[i] = bw[i];
+						sb = 2u * (j & 15u);
+					};
+					auto request_next_record = [&]() {      /* header and first window of the record behind the current one (indices kept inside the staging area) */
+						nrs = rs + ((hy >> 17) & 0x7fu);
+						const uint32_t g0 = nrs < SK_CHUNK_G - 1 ? nrs : SK_CHUNK_G - 1;
+						nh = wstage[g0];
+#pragma unroll
+						for (int q = 0; q < (NWD + 3) / 4; q++) {
+							const uint32_t g = g0 + 1 + q < SK_CHUNK_G ? g0 + 1 + q : SK_CHUNK_G - 1;
+							const uint4 v = wstage[g];
+							if (4 * q < NWD) nwin[4 * q] = v.x; if (4 * q + 1 < NWD) nwin[4 * q + 1] = v.y; if (4 * q + 2 < NWD) nwin[4 * q + 2] = v.z; if (4 * q + 3 < NWD) nwin[4 * q + 3] = v.w;
+						}
+					};
+					/* next k-mer: canonical key, strand, table slot, weight */
+					Key<W> key; bool fwd = true; uint64_t h = 0; uint32_t slot = 0; bool mine = false; uint32_t wnext = 0;
 #pragma unroll
 					for (int wi = 0; wi < W; wi++) key.w[wi] = 0;
 					auto prepare = [&]() {
 						Key<W> kf;
-						const uint32_t d0 = j >> 4, sft = 2u * (j & 15u);
+						const bool up = sb >= 32u; const uint32_t r = sb & 31u;
 #pragma unroll
 						for (int wi = 0; wi < W; wi++) {
-							const uint32_t a = bw[d0 + 2 * wi], b = bw[d0 + 2 * wi + 1], c = bw[d0 + 2 * wi + 2];
-							const uint64_t hi = ((uint64_t)a << 32) | b;
-							kf.w[wi] = sft ? (hi << sft) | ((uint64_t)c >> (32 - sft)) : hi;
+							const uint32_t d0 = up ? win[2 * wi + 1] : win[2 * wi], d1 = up ? win[2 * wi + 2] : win[2 * wi + 1], d2 = up ? win[2 * wi + 3] : win[2 * wi + 2];
+							const uint32_t hi = (uint32_t)(((((uint64_t)d0) << 32 | d1) << r) >> 32), lo = (uint32_t)(((((uint64_t)d1) << 32 | d2) << r) >> 32);
+							kf.w[wi] = ((uint64_t)hi << 32) | lo;
 						}
 						const uint32_t kbits = 2u * k;
 #pragma unroll
@@ -1057,55 +1080,57 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						h = slot_hash<W>(key.w);
 						slot = (uint32_t)(h >> (64 - LOG2S));
 						mine = ((uint32_t)(h >> 20) & subMask) == val;
-						if constexpr (W == 1) { seen = tkeys[slot]; seenFirst = tfirst[slot]; }
 					};
-					if (left) { enter_record(); prepare(); }
+					if (left) { enter_record(); seed_window(); wnext = uniformW ? hw : ww[j]; request_next_record(); prepare(); }
 					uint32_t dbgSink = 0;
 					for (uint32_t it = 0; it < Lk; it++) {
 						if (left) {
-							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot; const uint64_t cseen = seen; uint64_t cfirst = seenFirst;
-							const float wa = uniformW ? __uint_as_float(hw) : __uint_as_float(ww[j]);
+							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot;
+							const float wa = __uint_as_float(wnext);
 							const uint64_t cord = ord0 + j;
-							/* the next k-mer of this lane (the next record's first one when this record is through), and its home slot requested */
-							j++; left--;
+							/* the claim of the current k-mer's home slot is on its way while the next k-mer is made (one-word keys: a compare-and-swap
+							 * against "empty" returns what the slot holds whether it wins or not, so the slot is not read first) */
+							unsigned long long old = EMPTY_KEY;
+							const bool tableOn = !SK_DBG(dbgFlags, 1) && cmine;
+							if constexpr (W == 1) { if (tableOn) old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)ckey.w[0]); }
+							/* the next k-mer of this lane: two bits further in the window, or the first one of the next record */
+							j++; left--; sb += 2;
 							if (left) {
-								if (j >= n) { rs += (hy >> 17) & 0x7fu; const uint4 hd = wstage[rs]; hx = hd.x; hy = hd.y; hw = hd.w; j = 0; enter_record(); }
+								if (j >= n) {
+									rs = nrs; hx = nh.x; hy = nh.y; hw = nh.w; j = 0; sb = 0;
+#pragma unroll
+									for (int i = 0; i < NWD; i++) win[i] = nwin[i];
+									enter_record();
+									request_next_record();
+								} else if (sb > 62u) seed_window();
+								wnext = uniformW ? hw : ww[j];
 								prepare();
 							}
-							if (SK_DBG(dbgFlags, 1)) { dbgSink ^= (uint32_t)ckey.w[0] ^ s ^ (uint32_t)cseen; }
+							if (SK_DBG(dbgFlags, 1)) { dbgSink ^= (uint32_t)ckey.w[0] ^ s; }
 							else if (cmine) {
 								bool placed = false;
 								if constexpr (W == 1) {
-									uint64_t curk = cseen;
-									if (curk == EMPTY_KEY) {
-										const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)ckey.w[0]);
-										if (old == EMPTY_KEY) { claimedHere++; placed = true; }
-										curk = old;
-									}
-									if (!placed && curk == ckey.w[0]) placed = true;
-									if (!placed) { s = (s + 1) & (S - 1); cfirst = 0; }      /* another slot: its first-sighting word has not been read */
+									if (old == EMPTY_KEY) { claimedHere++; placed = true; }
+									else if (old == ckey.w[0]) placed = true;
+									else s = (s + 1) & (S - 1);
 								}
 								for (int probe = 0; probe < S && !placed; probe++) {
 									if constexpr (W == 1) {
-										uint64_t curk = tkeys[s];
-										if (curk == EMPTY_KEY) {
-											const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)ckey.w[0]);
-											if (old == EMPTY_KEY) { claimedHere++; placed = true; break; }
-											curk = old;
-										}
-										if (curk == ckey.w[0]) { placed = true; break; }
+										const unsigned long long o2 = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)ckey.w[0]);
+										if (o2 == EMPTY_KEY) { claimedHere++; placed = true; break; }
+										if (o2 == ckey.w[0]) { placed = true; break; }
 									} else {
 										uint32_t st = __hip_atomic_load(&tstate[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 										if (st == 0) {
-											const uint32_t old = atomicCAS(&tstate[s], 0u, 1u);
-											if (old == 0) {
+											const uint32_t old2 = atomicCAS(&tstate[s], 0u, 1u);
+											if (old2 == 0) {
 #pragma unroll
 												for (int qq = 0; qq < W; qq++) tkeys[(size_t)s * W + qq] = ckey.w[qq];
 												__hip_atomic_store(&tstate[s], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 												claimedHere++;
 												placed = true; break;
 											}
-											st = old;
+											st = old2;
 										}
 										if (st == 1) { probe--; continue; }      /* writer publishes unconditionally: re-poll the same slot */
 										bool eq = true;
@@ -1119,14 +1144,12 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 								else {
 									atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(cfwd ? 1 : 0) << 32));
 									atomicAdd(&twsum[s], (double)wa);
-									/* the first-sighting word only ever goes down: an occurrence that does not undercut the value read together
-									 * with the key (cfirst; 0 = not read) cannot be the first one and skips the 64-bit LDS atomic */
 									const unsigned long long fp = first_pack(cord, cfwd, wa);
 									if (TRACK) {      /* the two smallest: whichever of (old first, this one) is larger is a candidate for second */
 										const unsigned long long was = atomicMin(&tfirst[s], fp);
 										const unsigned long long cand = was > fp ? was : fp;
 										if (cand != NO_FIRST) atomicMin(&tsecond[s], cand);
-									} else if (W > 1 || cfirst == 0 || fp < cfirst) atomicMin(&tfirst[s], fp);
+									} else atomicMin(&tfirst[s], fp);
 								}
 							}
 						}

@@ -55,6 +55,7 @@ public:
 	Read(const std::string &name, const std::string &fasta, const std::string &quals) : _name(name), _fasta(fasta), _quals(quals), _discarded(false) {}
 	inline bool isDiscarded() const { return _discarded; }                        /* :243 */
 	inline void discard() const { _discarded = true; }                            /* :254: "permitted even on a constant" */
+	uint32_t getLength() const { return (uint32_t)_fasta.size(); }                /* :258 (SequenceLengthType) */
 	std::string getFasta(uint32_t trimOffset = 0, uint32_t trimLength = 0xffffffffu) const { return trimOffset < _fasta.size() ? _fasta.substr(trimOffset, trimLength) : std::string(); }   /* :273 */
 	std::string getQuals(uint32_t trimOffset = 0, uint32_t trimLength = 0xffffffffu) const { return trimOffset < _quals.size() ? _quals.substr(trimOffset, trimLength) : std::string(); }   /* :498 */
 	Read getTrimRead(uint32_t trimOffset, uint32_t trimLength, std::string label = "", std::string nameSuffix = "", bool unmasked = false) {   /* :485 */

@@ -28,6 +28,7 @@ int main(int argc, char **argv) {
 		GKS spectrum(0);                                            /* apps/FilterReads.cpp:126 */
 		long rawKmers = KS::estimateRawKmers(reads);                /* :133 */
 		spectrum = GKS(rawKmers);                                   /* :136 */
+		spectrum.setSizeTracking(true);                             /* --size-history-file given (:141-147): the history is kept by the device build */
 		{ GKS copy(spectrum); GKS other(7); other = copy; }         /* copies share the (not yet made) handle and die quietly */
 		spectrum.buildKmerSpectrumInParts(reads, 0, "");           /* :139 -> virtual buildKmerSpectrum(store, false) */
 		spectrum.optimize();                                        /* :140 */

@@ -191,3 +191,84 @@ def test_ranks_sharing_one_gpu_through_a_host_transport(world, mode, k, skew):
                 assert want.pop(bytes(kk)) == cut(v)
             seen += len(keys)
         assert seen == ms["weak_entries"] and not want
+
+
+def _failing_worker(rank, world, port, tmp, mode, k):
+    """as _worker, but rank 1's second batch fails on that rank alone (kmr_tune exchange_fail_once): every rank has to come back
+    from the collective step with an error -- the failing one with its own, the others naming it -- instead of waiting for ever"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kmernator_amd as ka
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        dev = torch.device("cuda", 0)
+        moved = []
+
+        def allgather(mine):
+            rows = [None] * world
+            dist.all_gather_object(rows, list(mine))
+            return rows
+
+        def alltoallv(send, soff, sbytes, recv, roff, rbytes, stream):
+            assert hip.hipStreamSynchronize(stream) == 0
+            moved.append(sum(sbytes))
+            outs = []
+            for r in range(world):
+                buf = np.empty(sbytes[r], dtype=np.uint8)
+                if sbytes[r]:
+                    assert hip.hipMemcpy(buf.ctypes.data, send + soff[r], sbytes[r], 2) == 0
+                outs.append(torch.from_numpy(buf))
+            ins = [torch.empty(rbytes[r], dtype=torch.uint8) for r in range(world)]
+            reqs = [dist.isend(outs[r], r) for r in range(world) if r != rank and sbytes[r]]
+            for r in range(world):
+                if r != rank and rbytes[r]:
+                    dist.recv(ins[r], r)
+            for q in reqs:
+                q.wait()
+            for r in range(world):
+                if rbytes[r]:
+                    assert hip.hipMemcpy(recv + roff[r], ins[r].numpy().ctypes.data, rbytes[r], 1) == 0
+
+        lo, hi = _slice(rank, world)
+        rb = _reads(False).slice(lo, hi)
+        sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0, rank=rank, world_size=world, build_mode=mode))
+        sp.exchange_init_transport(allgather, alltoallv)
+        outcome = []
+        for i, (a, b) in enumerate(_batches(rank, world)):
+            part = rb.slice(a, b)
+            tb, tq, to = _dev(part, dev)
+            if i == 1 and rank == 1:
+                sp.tune(exchange_fail_once=1)
+            before = len(moved)
+            try:
+                sp.exchange_add_reads(tb.data_ptr(), tq.data_ptr(), to.data_ptr(), b - a, int(part.offsets[-1]), lo + a)
+                outcome.append("ok")
+            except ka.KmerSpectrumError as e:
+                outcome.append(str(e))
+                assert len(moved) == before          # nothing was sent in the failed step
+        open(os.path.join(tmp, "outcome.%d.txt" % rank), "w").write("\n".join(outcome))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_one_failing_rank_fails_the_step_on_every_rank(mode):
+    """kmr_exchange_add_reads_dev agrees on success before every exchange: a rank-local failure between two collectives (an
+    allocation, the extraction, the packing) reaches all ranks through the status word of the gathered rows."""
+    world, k = 3, 31
+    port = 35100 + (os.getpid() % 1500) + mode
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_failing_worker, args=(world, port, tmp, mode, k), nprocs=world, join=True)
+        for r in range(world):
+            first, second = open(os.path.join(tmp, "outcome.%d.txt" % r)).read().split("\n")
+            assert first == "ok"
+            if r == 1:
+                assert "injected failure" in second
+            else:
+                assert "rank 1 failed" in second
