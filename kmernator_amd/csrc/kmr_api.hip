@@ -70,6 +70,7 @@ struct Tuning {
 	bool no_lut = false, no_narrow = false, no_l1_state = false, no_stream_lookups = false;
 	uint64_t long_list_chunks = 0;     /* lists of more chunks are counted in pieces (0: 1024) */
 	uint64_t binned_min = 1ull << 18;  /* weak maps of at least this many entries are bucketed by the radix partition of kmr_buckets.hpp (build_mode 3) */
+	bool no_lean_extract = false;      /* never take sk_extract_lean_kernel (A/B runs, tests of the general kernel on uniform qualities) */
 	bool exchange_fail_once = false;   /* tests: the next kmr_exchange_add_reads_dev of this rank fails locally (the other ranks must come back with an error, not hang) */
 	bool no_coarse_lists = true;       /* exchange: scatter into the job's fine lists (default) or, kmr_tune("coarse_lists", 1), into coarse ones that the owner splits before the count pass (sk_refine_kernel: not yet fast enough to pay) */
 };
@@ -134,6 +135,8 @@ struct kmr_handle {
 	uint64_t *ue = nullptr, *ue2 = nullptr; uint64_t ue_cap = 0, ue2_cap = 0;
 	/* build_mode 3 (kmr_superkmer.hpp): list words, minimizer geometry, table of k-fold quality products */
 	unsigned long long *sk_state = nullptr; uint32_t sk_bits = 0, sk_m = 0, sk_off = 0, sk_win = 0; double *dPk = nullptr;
+	double hP[256], hPk[256];              /* host copies of the probability table and of its k-fold products */
+	unsigned int *qrange = nullptr; bool qual_mixed = false;      /* sk_qual_range_kernel's answer; a build that has seen two different quality characters stops asking */
 	/* exchange with world_size > 1: sk_bits are the COARSE lists reads are scattered into and that travel; each holds 2^sk_fine_shift
 	 * fine lists, made by sk_refine_kernel before the count pass (fine state: sk_fine_state, 2^(sk_bits + sk_fine_shift) words) */
 	uint32_t sk_fine_shift = 0; unsigned long long *sk_fine_state = nullptr; uint64_t sk_fine_cap = 0;
@@ -1389,6 +1392,7 @@ bool sk_geometry(uint32_t k, uint32_t m_wish, uint32_t &win, uint32_t &m, uint32
 	}
 	return false;
 }
+const uint64_t SK_EXTRACT_WAVES_PER_CU = std::max(2 * SK_WAVES, SKL_MIN_BLOCKS * SKL_WAVES);      /* wavefronts an extraction launch keeps per CU (each holds two slabs of 64 chunks) */
 template <int W, int WIN, bool FILT> int launch_sk_extract(kmr_handle *h, const ReadsView &rv, const SkParams &sp, const DevParams *override_params = nullptr) {
 	auto kern = sk_extract_kernel<W, WIN, FILT>;
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_EXTRACT_SMEM));
@@ -1399,6 +1403,42 @@ template <int W, int WIN, bool FILT> int launch_sk_extract(kmr_handle *h, const 
 	if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, SK_WAVES * 64, SK_EXTRACT_SMEM); fprintf(stderr, "sk_extract<W=%d,WIN=%d>: %d blocks of %d waves per CU (LDS %zu), grid %llu, m=%u off=%u bits=%u\n", W, WIN, nb, SK_WAVES, SK_EXTRACT_SMEM, (unsigned long long)blocks, sp.m, sp.off, sp.list_bits); }
 	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SK_WAVES * 64), SK_EXTRACT_SMEM, h->stream, rv, override_params ? *override_params : dev_params(h), sp, pool_view(h, h->l1));
 	HIPCHK(h, hipGetLastError());
+	return 0;
+}
+uint32_t sk_dbg_flags(const char *name);
+bool sp_debug_extract(kmr_handle *h) { (void)h; return sk_dbg_flags("KMR_SK_EXTRACT_DBG") != 0; }      /* the ablation switches live in the general kernel */
+template <int W, int WIN> int launch_sk_extract_lean(kmr_handle *h, const ReadsView &rv, const SkParams &sp, float wK, const DevParams *override_params = nullptr) {
+	auto kern = sk_extract_lean_kernel<W, WIN>;
+	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SKL_EXTRACT_SMEM));
+	const uint64_t tiles = ((rv.u_start ? rv.n_units : rv.n_reads) + 63) / 64;
+	uint64_t blocks = (tiles + SKL_WAVES - 1) / SKL_WAVES;
+	if (blocks == 0) return 0;
+	blocks = std::min<uint64_t>(blocks, (uint64_t)num_cus(h) * SKL_MIN_BLOCKS);      /* resident grid: a wavefront walks tiles tile0, tile0 + stride, ... */
+	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SKL_WAVES * 64), SKL_EXTRACT_SMEM, h->stream, rv, override_params ? *override_params : dev_params(h), sp, pool_view(h, h->l1), wK);
+	HIPCHK(h, hipGetLastError());
+	return 0;
+}
+/* Do all k-mers without an N of these reads weigh the same (no qualities, or one quality character throughout)?  Then wK is that
+ * weight as the general kernel would form it -- (float) of the k-fold product of the character's probability, 1 for REF_QUAL --
+ * and sk_extract_lean_kernel may take the launch. */
+int sk_uniform_weight(kmr_handle *h, const ReadsView &rv, bool &lean, float &wK) {
+	lean = false; wK = 1.0f;
+	if (h->tune.no_lean_extract) return 0;
+	if (!rv.quals) { lean = true; return 0; }
+	if (h->qual_mixed || rv.n_reads == 0) return 0;
+	if (!h->qrange) HIPCHK(h, hipMalloc((void **)&h->qrange, 8));
+	const unsigned int init[2] = {255u, 0u};
+	HIPCHK(h, hipMemcpyAsync(h->qrange, init, 8, hipMemcpyHostToDevice, h->stream));
+	hipLaunchKernelGGL(sk_qual_range_kernel, dim3(num_cus(h) * 8), dim3(256), 0, h->stream, rv.quals, rv.offsets, rv.n_reads, h->qrange);
+	HIPCHK(h, hipGetLastError());
+	unsigned int got[2] = {0, 0};
+	HIPCHK(h, hipMemcpyAsync(got, h->qrange, 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	if (got[0] != got[1]) { h->qual_mixed = got[0] < got[1]; return 0; }      /* (255 > 0: no quality byte at all) */
+	const unsigned int q0 = got[0];
+	if (q0 == 127) { lean = true; wK = 1.0f; return 0; }                       /* Read::REF_QUAL */
+	if (!(h->hP[q0] > 0.0)) return 0;                                          /* below the floor: the general kernel's zero handling */
+	lean = true; wK = (float)h->hPk[q0];
 	return 0;
 }
 uint32_t sk_dbg_flags(const char *name) {
@@ -1450,6 +1490,8 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 	/* world_size > 1: without the exchange a rank keeps the k-mers the reference's owner function gives it (getDistributedThreadId,
 	 * as the other build modes do); inside an exchange (kmr_sk_exchange_begin) every k-mer is kept, the lists decide the owner */
 	const bool filt = dp.subsample > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0 || (dp.world > 1 && !h->sk_exchange);
+	bool lean = false; float wK = 1.0f;
+	if (!filt && !sp_debug_extract(h)) { int rcq = sk_uniform_weight(h, rvAll, lean, wK); if (rcq) return rcq; }
 	for (uint64_t r = 0; r < n; r += chunk) {
 		const uint64_t m = std::min(chunk, n - r);
 		ReadsView rv = rvAll;
@@ -1461,11 +1503,11 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		 * chunk per list and two slabs of 64 chunks per wavefront */
 		const uint64_t bases = m * avg + avg;
 		/* (inside an exchange the lists of other owners start afresh after every pack: an open chunk per list for every call) */
-		rc = pool_reserve(h, h->l1, bases / SK_CHUNK_G + ((h->l1.base && !h->sk_exchange) ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * 2 * SK_WAVES * 130 + 64, true); if (rc) return rc;
+		rc = pool_reserve(h, h->l1, bases / SK_CHUNK_G + ((h->l1.base && !h->sk_exchange) ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * SK_EXTRACT_WAVES_PER_CU * 130 + 64, true); if (rc) return rc;
 		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b); time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
 		SkParams sp = sk_params(h);
 		if (h->cfg.size_tracker) sp.track = h->trk + h->trk_n + r;
-#define SKX(WINv) (filt ? launch_sk_extract<W, WINv, true>(h, rv, sp) : launch_sk_extract<W, WINv, false>(h, rv, sp))
+#define SKX(WINv) (filt ? launch_sk_extract<W, WINv, true>(h, rv, sp) : (lean ? launch_sk_extract_lean<W, WINv>(h, rv, sp, wK) : launch_sk_extract<W, WINv, false>(h, rv, sp)))
 		rc = h->sk_win == 16 ? SKX(16) : (h->sk_win == 8 ? SKX(8) : SKX(4));
 #undef SKX
 		time_end(h, KMR_TIME_EXTRACT, a2, b2); time_end(h, KMR_TIME_BUILD, a, b);
@@ -1763,6 +1805,7 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 			h->superkmer_mode = cfg->build_mode == 3 || sk_auto;
 			double Pk[256];
 			for (int cidx = 0; cidx < 256; cidx++) { double wv = 1.0; for (uint32_t jj = 0; jj < h->k; jj++) wv *= P[cidx]; Pk[cidx] = wv; }      /* the loop of buildWeightedKmers, src/KmerReadUtils.h:205-208 */
+			memcpy(h->hPk, Pk, sizeof(Pk)); memcpy(h->hP, P, sizeof(h->hP));
 			if (hipMalloc((void **)&h->dPk, 2 * sizeof(Pk)) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
 			hipMemcpy(h->dPk, Pk, sizeof(Pk), hipMemcpyHostToDevice);
 			/* reciprocals for the chain's divide, usable only if multiply-and-correct reproduces the correctly rounded quotient of every
@@ -1795,6 +1838,7 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->stream) hipStreamSynchronize(h->stream);
 	for (int which = 0; which < KMR_TIME_GROUPS; which++) for (auto &pr : h->pending_events[which]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 	if (h->slots) hipFree(h->slots); if (h->extslots) hipFree(h->extslots);
+	if (h->qrange) hipFree(h->qrange);
 	if (h->dP) hipFree(h->dP); if (h->dPk) hipFree(h->dPk); if (h->dstats) hipFree(h->dstats); if (h->derr) hipFree(h->derr);
 	free_map(h->weak); free_map(h->sing);
 	free_partition_state(h);
@@ -1831,6 +1875,7 @@ int kmr_reset(kmr_handle *h) {
 		if (h->l1.head) HIPCHK(h, hipMemsetAsync(h->l1.head, 0, 4, h->stream));
 		h->l1.used_ub = 0;
 		h->inserted_records = 0;
+		h->qual_mixed = false;
 		if (h->sk_state) hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(1ull << h->sk_bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << h->sk_bits);
 		if (h->l1_state) {      /* what an unfinished build kept back is dropped with its pool */
 			hipLaunchKernelGGL(partition_state_init_kernel, dim3(partition_blocks(h)), dim3(256), 0, h->stream, h->l1_state,
@@ -1883,6 +1928,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "lookup_table") h->tune.no_lut = value == 0;
 	else if (k == "stream_lookups") h->tune.no_stream_lookups = value == 0;
 	else if (k == "long_list_chunks") h->tune.long_list_chunks = value < 2 ? 2 : (uint64_t)value;
+	else if (k == "lean_extract") h->tune.no_lean_extract = value == 0;
 	else if (k == "exchange_fail_once") h->tune.exchange_fail_once = value != 0;
 	else if (k == "binned_buckets_min") h->tune.binned_min = value >= 0 ? (uint64_t)value : ~0ull;        /* < 0: never */
 	else if (k == "coarse_lists") h->tune.no_coarse_lists = value == 0;
@@ -2033,12 +2079,13 @@ template <int W> int lookup_stream_t(kmr_handle *h, const ReadsView &rvAll, uint
 	h->l1.used_ub = 0;
 	ReadsView rv = rvAll;
 	rc = prepare_units(h, rv); if (rc) return rc;
-	rc = pool_reserve(h, h->l1, total_bases / SK_CHUNK_G + nl + (uint64_t)num_cus(h) * 2 * SK_WAVES * 130 + 64, true); if (rc) return rc;
+	rc = pool_reserve(h, h->l1, total_bases / SK_CHUNK_G + nl + (uint64_t)num_cus(h) * SK_EXTRACT_WAVES_PER_CU * 130 + 64, true); if (rc) return rc;
 	/* every k-mer without an N is asked for: no qualities (weight 1, or 0 with an N), no filters, nothing added to the handle's counters */
 	DevParams dp = dev_params(h);
 	dp.min_weight = 0.5f; dp.subsample = 1; dp.world = 1; dp.num_parts = 1; dp.sub_wnb = 0; dp.sub_snb = 0; dp.stats = h->scratch_stats;
 	SkParams sp = sk_params(h); sp.keep_all_owners = 1; sp.track = nullptr;
-	rc = h->sk_win == 16 ? launch_sk_extract<W, 16, false>(h, rv, sp, &dp) : (h->sk_win == 8 ? launch_sk_extract<W, 8, false>(h, rv, sp, &dp) : launch_sk_extract<W, 4, false>(h, rv, sp, &dp));
+	if (!rv.quals && !h->tune.no_lean_extract) rc = h->sk_win == 16 ? launch_sk_extract_lean<W, 16>(h, rv, sp, 1.0f, &dp) : (h->sk_win == 8 ? launch_sk_extract_lean<W, 8>(h, rv, sp, 1.0f, &dp) : launch_sk_extract_lean<W, 4>(h, rv, sp, 1.0f, &dp));
+	else rc = h->sk_win == 16 ? launch_sk_extract<W, 16, false>(h, rv, sp, &dp) : (h->sk_win == 8 ? launch_sk_extract<W, 8, false>(h, rv, sp, &dp) : launch_sk_extract<W, 4, false>(h, rv, sp, &dp));
 	if (rc) return rc;
 	hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);
 	HIPCHK(h, hipGetLastError());

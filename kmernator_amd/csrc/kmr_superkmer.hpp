@@ -94,6 +94,11 @@ __global__ void sk_close_kernel(const unsigned long long *state, uint64_t n, uin
 }
 #endif
 
+/* lanes of ONE wavefront hand data to each other through LDS: the LDS executes a wavefront's instructions in issue order, so all that
+ * is needed is that the compiler keeps the order (a workgroup-scope fence here also drains the vector-memory counter, i.e. waits for
+ * every prefetch in flight) */
+__device__ __forceinline__ void sk_wave_lds_order() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+
 /* Reserve g granules in list `list`: lock-free append to a chain of fixed chunks.  The list's word is open chunk << 32 |
  * fill; an atomic add books [fill, fill + g).  The ONE adder that crosses the end of the chunk closes it (its fill count is
  * the value it saw), takes a new chunk from its wavefront's slab and publishes it with its own g already booked; adders that
@@ -794,6 +799,318 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 	if (FILT) { nSub = wave_sum(nSub); if (lane == 0 && nSub) atomicAdd(&p.stats->subtracted, nSub); }
 }
 
+/* ------------------------------------------------------------------ extraction when every k-mer without an N weighs the same */
+/* A launch whose reads carry no qualities (FASTA input, a reference: every base has probability 1, src/Sequence.h REF_QUAL) or
+ * one and the same quality character everywhere (found by sk_qual_range_kernel) needs no weight chain: a k-mer's weight is 0 when
+ * its window holds an N and the table's k-fold product of that one probability otherwise (buildWeightedKmers,
+ * src/KmerReadUtils.h:176-248: equal qualities leave the chain where it is, every fresh start gives the same product).  Without the
+ * quality bytes, their flags and the weights ring a wavefront's tile is 7.8 KB of LDS instead of 24, and without the fp64 chain the
+ * walk fits 128 registers: 16 wavefronts per CU instead of 6 -- the general kernel is bound by instruction issue at 1.5
+ * wavefronts per SIMD.  The records, the list appends and their settlement one window later are the general kernel's. */
+static const int SKL_WAVES = 4, SKL_MIN_BLOCKS = 2;      /* 8 wavefronts per CU at 193 registers: 12 (168 registers, or fewer records booked per round) and 16 (128, spilling) were slower -- the pass runs at the chip's rate of scattered device atomics (1.8 x 10^10 per second, one per record) */      /* 168 registers: at 128 (four blocks) the walk spilled 59 dwords */
+static const int SKL_WAVE_LDS = (SK_GROUPS * 4 + SK_GROUPS * 2 + 8 + SK_WINDOW * 64 * 4 + 15) & ~15;
+static const size_t SKL_EXTRACT_SMEM = (size_t)SKL_WAVES * SKL_WAVE_LDS;
+
+/* smallest and largest quality character of the reads offsets[0] .. offsets[n_reads] (min in range[0], max in range[1]) */
+#ifndef KMR_INSTANCE_TU
+__global__ __launch_bounds__(256)
+void sk_qual_range_kernel(const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads, unsigned int *range) {
+	unsigned int lo = 255, hi = 0;
+	const uint64_t b0 = offsets[0], b1 = offsets[n_reads];
+	const uintptr_t p0 = (uintptr_t)(quals + b0), p1 = (uintptr_t)(quals + b1);
+	const uintptr_t a0 = (p0 + 15) & ~(uintptr_t)15, a1 = p1 & ~(uintptr_t)15;      /* the 16-byte aligned middle */
+	const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
+	if (a0 < a1) {
+		const uint4 *q4 = (const uint4 *)a0;
+		const uint64_t n16 = (a1 - a0) / 16;
+		for (uint64_t i = tid; i < n16; i += nthreads) {
+			const uint4 v = q4[i];
+			const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+#pragma unroll
+				for (int b = 0; b < 4; b++) { const unsigned int c = (w4[j] >> (8 * b)) & 0xffu; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+			}
+		}
+		if (tid < 16) { const uintptr_t q = p0 + tid; if (q < a0) { const unsigned int c = *(const uint8_t *)q; lo = c < lo ? c : lo; hi = c > hi ? c : hi; } }
+		if (tid >= 16 && tid < 32) { const uintptr_t q = a1 + (tid - 16); if (q < p1) { const unsigned int c = *(const uint8_t *)q; lo = c < lo ? c : lo; hi = c > hi ? c : hi; } }
+	} else {
+		for (uintptr_t q = p0 + tid; q < p1; q += nthreads) { const unsigned int c = *(const uint8_t *)q; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+	}
+	for (int o = 32; o > 0; o >>= 1) { const unsigned int a = (unsigned int)__shfl_xor((int)lo, o, 64), b = (unsigned int)__shfl_xor((int)hi, o, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+	if ((threadIdx.x & 63) == 0) { atomicMin(&range[0], lo); atomicMax(&range[1], hi); }
+}
+#endif
+
+template <int W, int WIN>
+__global__ __launch_bounds__(SKL_WAVES * 64, SKL_MIN_BLOCKS)
+void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool, float wK) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	__shared__ SkSlab s_slab[SKL_WAVES];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	uint8_t *wb = smem + (size_t)wave * SKL_WAVE_LDS;
+	uint32_t *pk = (uint32_t *)wb;                                      /* [SK_GROUPS] packed bases */
+	uint16_t *nm = (uint16_t *)(pk + SK_GROUPS);                        /* [SK_GROUPS] N flags      */
+	uint32_t *mhr = (uint32_t *)(wb + SK_GROUPS * 6 + 8);               /* [SK_WINDOW][64] minimizer hash */
+	SkSlab *slab = &s_slab[wave];
+	if (lane == 0) { slab->base[0] = atomicAdd(pool.head, 64u); slab->base[1] = atomicAdd(pool.head, 64u); slab->next = 0; slab->hot_list = SK_NO_LIST; slab->hot_state = 0; }
+	__syncthreads();                       /* the only block-wide barrier; waves are independent below */
+
+	const uint32_t k = p.k, m = sp.m;
+	const uint32_t mmask = m >= 16 ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+	const uint32_t mtop = 2 * (m - 1);
+	const uint32_t wbits = __float_as_uint(wK);
+	const bool good = wK > p.min_weight;           /* the same for every k-mer without an N */
+	unsigned long long nRaw = 0, nGood = 0;
+	const uint64_t n_items = rv.u_start ? rv.n_units : rv.n_reads;
+	const uint64_t n_tiles = (n_items + 63) / 64;
+	for (uint64_t tile = (uint64_t)blockIdx.x * SKL_WAVES + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * SKL_WAVES) {
+	const uint64_t r0 = tile * 64;
+	const uint32_t nr = (uint32_t)((n_items - r0) < 64 ? (n_items - r0) : 64);
+	const bool have = (uint32_t)lane < nr;
+	uint64_t myStart = 0, myEnd = 0, myRead = 0;
+	bool myDiscard = true;
+	if (have) {
+		if (rv.u_start) { myStart = rv.u_start[r0 + lane]; myEnd = rv.u_end[r0 + lane]; myRead = rv.u_read[r0 + lane]; }
+		else { myRead = r0 + lane; myStart = rv.offsets[myRead]; myEnd = rv.offsets[myRead + 1]; }
+		myDiscard = rv.discarded ? (rv.discarded[myRead] != 0) : false;
+	}
+	uint32_t tRaw = 0, tGood = 0;
+	uint32_t done = 0;
+	while (done < nr) {
+		const uint64_t B0 = __shfl(myStart, (int)done, 64);
+		const bool fits = have && (uint32_t)lane >= done && (myEnd - B0 <= (uint64_t)TILE_SPAN);
+		unsigned long long fm = __ballot(fits) >> done;
+		uint32_t n = ~fm ? (uint32_t)__builtin_ctzll(~fm) : 64u;
+		if (n > nr - done) n = nr - done;
+		if (n == 0) {                                        /* read longer than a tile */
+			if (lane == 0) atomicOr(p.err, (uint32_t)ERR_READ_TOO_LONG);
+			done += 1;
+			continue;
+		}
+		const uint64_t B1 = __shfl(myEnd, (int)(done + n - 1), 64);
+		const uintptr_t gb = (uintptr_t)rv.bases + B0;
+		const uintptr_t ab = gb & ~(uintptr_t)15;
+		const uint32_t nb16 = (uint32_t)(((uintptr_t)rv.bases + B1 - ab + 15) >> 4);
+		/* stage the tile: 16 bytes per lane and round, coalesced; bases leave as 2 bits each plus an N flag.  All rounds' loads are
+		 * issued before the first one is packed. */
+		{
+			const uint4 *gbp = (const uint4 *)(rv.bases + (ptrdiff_t)(ab - (uintptr_t)rv.bases));
+			constexpr int STG = (TILE_BUF / 16 + 63) / 64;
+			uint4 vb[STG];
+#pragma unroll
+			for (int c = 0; c < STG; c++) { const uint32_t idx = (uint32_t)lane + 64u * c; vb[c] = make_uint4(0, 0, 0, 0); if (idx < nb16) vb[c] = gbp[idx]; }
+#pragma unroll
+			for (int c = 0; c < STG; c++) {
+				const uint32_t idx = (uint32_t)lane + 64u * c;
+				const uint32_t w4[4] = {vb[c].x, vb[c].y, vb[c].z, vb[c].w};
+				uint32_t packed = 0, nflags = 0;
+#pragma unroll
+				for (int b = 0; b < 16; b++) {
+					const uint32_t code = base_code((uint8_t)(w4[b >> 2] >> (8 * (b & 3))));
+					packed |= (code & 3u) << (30 - 2 * b);          /* markup packs as A */
+					nflags |= (code >> 2) << b;
+				}
+				if (idx < nb16 + 4u && idx < (uint32_t)SK_GROUPS) { pk[idx] = idx < nb16 ? packed : 0u; nm[idx] = idx < nb16 ? (uint16_t)nflags : (uint16_t)0; }      /* (four groups of padding behind the data) */
+			}
+		}
+		sk_wave_lds_order();
+
+		const bool active = have && (uint32_t)lane >= done && (uint32_t)lane < done + n && !myDiscard;
+		const uint32_t L = active ? (uint32_t)(myEnd - myStart) : 0;
+		const uint32_t rbOff = active ? (uint32_t)(gb - ab) + (uint32_t)(myStart - B0) : 0u;
+		uint32_t Lmax = L;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { uint32_t x = __shfl_xor(Lmax, o, 64); Lmax = x > Lmax ? x : Lmax; }
+		const uint64_t ord0 = rv.stream_base + myStart;      /* + k-mer index = stream ordinal of the occurrence */
+		uint32_t zc = 0;
+		constexpr int ZN = W == 1 ? 1 : (W == 2 ? 2 : 3);      /* history of N flags, one bit per position: k + 1 bits */
+		uint64_t zbits[3] = {0, 0, 0};
+		uint32_t mf = 0, mr = 0;
+		uint32_t hs[WIN];
+#pragma unroll
+		for (int i = 0; i < WIN; i++) hs[i] = 0xffffffffu;
+		uint32_t pref = 0xffffffffu;
+		bool runOpen = false, runInWin = false;
+		uint32_t runStart = 0, runN = 0, runMh = 0;
+		/* records booked but not yet written: start | n << 16 | 1 << 24 | 1 << 30 (an address, not a booking) | 1 << 31, minimizer hash, what the booking add returned */
+		uint32_t q_info[SK_RR], q_mh[SK_RR]; unsigned long long q_booked[SK_RR];
+#pragma unroll
+		for (int r = 0; r < SK_RR; r++) { q_info[r] = 0; q_mh[r] = 0; q_booked[r] = 0; }
+		auto flush_pending = [&]() {
+			uint64_t at[SK_RR]; bool waits[SK_RR];
+#pragma unroll
+			for (int r = 0; r < SK_RR; r++) {
+				waits[r] = false; at[r] = ~0ull;
+				if (q_info[r] >> 31) {
+					const uint32_t nn = (q_info[r] >> 16) & 0xffu;
+					if ((q_info[r] >> 30) & 1u) at[r] = q_booked[r];
+					else at[r] = sk_append_settle(sp.state, sk_list_of(q_mh[r], sp.list_bits), 1 + sk_base_granules(nn, k), q_booked[r], slab, pool, waits[r]);
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < SK_RR; r++) if (waits[r]) {
+				const uint32_t nn = (q_info[r] >> 16) & 0xffu;
+				at[r] = sk_append(sp.state, sk_list_of(q_mh[r], sp.list_bits), 1 + sk_base_granules(nn, k), slab, pool);
+			}
+#pragma unroll
+			for (int r = 0; r < SK_RR; r++) {
+				if ((q_info[r] >> 31) && at[r] != ~0ull) {
+					const uint32_t start = q_info[r] & 0xffffu, nn = (q_info[r] >> 16) & 0xffu;
+					const uint32_t nbg = sk_base_granules(nn, k);
+					uint4 *dst = (uint4 *)pool.base + at[r];
+					const uint64_t ord = ord0 + start;
+					dst[0] = make_uint4((uint32_t)ord, (uint32_t)(ord >> 32) | (nn << 8) | (1u << 16) | ((1 + nbg) << 17), q_mh[r], wbits);
+					const uint32_t xb = rbOff + start;
+					for (uint32_t b = 0; b < nbg; b++)
+						dst[1 + b] = make_uint4(sk_bases16(pk, xb + 64 * b), sk_bases16(pk, xb + 64 * b + 16), sk_bases16(pk, xb + 64 * b + 32), sk_bases16(pk, xb + 64 * b + 48));
+				}
+				q_info[r] = 0;
+			}
+		};
+		for (uint32_t jb = 0; jb < Lmax || __any(runOpen); jb += SK_WINDOW) {
+			const uint32_t nmw = sk_flags16(nm, rbOff + jb);
+			const int32_t xm = (int32_t)(rbOff + jb) - (int32_t)sp.off;
+			const uint32_t mpkw = xm >= 0 ? sk_bases16(pk, (uint32_t)xm) : (xm > -16 ? sk_bases16(pk, 0u) >> (2 * (uint32_t)(-xm)) : 0u);
+			const bool cinOpen = runOpen; const uint32_t cinStart = runStart, cinN = runN, cinMh = runMh;
+			uint32_t Sm = 0, Vm = 0;
+			runInWin = false;
+			/* the window's positions: which of them end a k-mer (km), which of those hold no N in their k bases (Vm) */
+			const bool live = jb < L;
+			const uint32_t nin = live ? (L - jb < (uint32_t)SK_WINDOW ? L - jb : (uint32_t)SK_WINDOW) : 0u;
+			const uint32_t inmask = (1u << nin) - 1u;
+			const uint32_t tk = jb + 1 >= k ? 0u : k - 1 - jb;            /* first position of the window that ends a k-mer (may be >= 16: none) */
+			const uint32_t km = tk < 16u ? (inmask & ~((1u << tk) - 1u)) : 0u;
+			const uint32_t zm = nmw & inmask;
+			uint32_t zcpos = 0;                                              /* positions at which the k bases behind hold an N */
+			if (__any(zm != 0 || zc != 0)) {
+				if (k >= (uint32_t)SK_WINDOW) {
+					uint32_t field;                                          /* history bits k-16 .. k-1 (bit b = position jb - 1 - b) */
+					{
+						const uint32_t lo = k - 16u, wi = lo >> 6, sh = lo & 63u;
+						uint64_t a = zbits[wi < (uint32_t)ZN ? wi : ZN - 1];
+						if (wi >= (uint32_t)ZN) a = 0;
+						uint64_t b = (wi + 1 < (uint32_t)ZN) ? zbits[wi + 1 < (uint32_t)ZN ? wi + 1 : ZN - 1] : 0ull;
+						field = (uint32_t)((sh ? (a >> sh) | (b << (64u - sh)) : a) & 0xffffu);
+					}
+					const uint32_t lm = __builtin_bitreverse32(field) >> 16;     /* bit t: the flag that leaves at position jb + t */
+					uint32_t zcw = zc;
+#pragma unroll
+					for (int t = 0; t < SK_WINDOW; t++) { zcw += (zm >> t) & 1u; zcw -= (lm >> t) & 1u; zcpos |= (zcw != 0 ? 1u : 0u) << t; }
+					zc = zcw;
+					if (ZN > 2) zbits[2] = (zbits[2] << 16) | (zbits[1] >> 48);
+					if (ZN > 1) zbits[1] = (zbits[1] << 16) | (zbits[0] >> 48);
+					zbits[0] = (zbits[0] << 16) | (uint64_t)(__builtin_bitreverse32(zm) >> 16);
+				} else {
+#pragma nounroll
+					for (uint32_t t = 0; t < (uint32_t)SK_WINDOW; t++) {
+						const bool z = ((zm >> t) & 1u) != 0;
+						if (ZN > 2) zbits[2] = (zbits[2] << 1) | (zbits[1] >> 63);
+						if (ZN > 1) zbits[1] = (zbits[1] << 1) | (zbits[0] >> 63);
+						zbits[0] = (zbits[0] << 1) | (z ? 1ull : 0ull);
+						zc += z ? 1u : 0u;
+						zc -= (uint32_t)((zbits[ZN == 1 ? 0 : (k >> 6)] >> (k & 63)) & 1ull);
+						zcpos |= (zc != 0 ? 1u : 0u) << t;
+					}
+				}
+			} else if (live) {      /* no N anywhere near: the histories move on by sixteen clean positions */
+				if (ZN > 2) zbits[2] = (zbits[2] << 16) | (zbits[1] >> 48);
+				if (ZN > 1) zbits[1] = (zbits[1] << 16) | (zbits[0] >> 48);
+				zbits[0] <<= 16;
+			}
+			Vm = good ? (km & ~zcpos) : 0u;
+			tRaw += (uint32_t)__builtin_popcount(km); tGood += (uint32_t)__builtin_popcount(Vm);
+#pragma unroll
+			for (int t = 0; t < SK_WINDOW; t++) {
+				/* minimizer of the k-mer that ends at position jb + t: m-mer ending sp.off positions back, canonical, hashed; minimum of the
+				 * last WIN of them by block decomposition (prefix minimum of the current block, suffix minima of the one before) */
+				const uint32_t mc = (mpkw >> (30 - 2 * t)) & 3u;
+				mf = ((mf << 2) | mc) & mmask;
+				mr = (mr >> 2) | ((3u - mc) << mtop);
+				const uint32_t x = sk_mmer_hash(mf < mr ? mf : mr);
+				const int r = t % WIN;
+				pref = r == 0 ? x : (x < pref ? x : pref);
+				hs[r] = x;
+				uint32_t M = pref;
+				if (r < WIN - 1) { const uint32_t sfx = hs[r + 1 < WIN ? r + 1 : 0]; M = sfx < M ? sfx : M; }
+				else {
+#pragma unroll
+					for (int u = WIN - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
+				}
+				const bool valid = ((Vm >> t) & 1u) != 0;
+				const bool cont = runOpen && M == runMh && runN < SK_MAX_N;
+				const bool nw = valid && !cont;
+				Sm |= nw ? (1u << t) : 0u;
+				runStart = nw ? jb + (uint32_t)t + 1 - k : runStart;
+				runN = nw ? 1u : runN + ((valid && cont) ? 1u : 0u);
+				runMh = nw ? M : runMh;
+				runInWin = runInWin || nw;
+				runOpen = valid || (runOpen && (uint32_t)t < tk);
+				mhr[t * 64 + lane] = M;
+			}
+			if (!live) runOpen = false;
+			/* gather: every run that ended in this window becomes a record of its list (as in sk_extract_kernel; every record is uniform) */
+			const uint32_t brk = (~Vm | Sm) & 0xffffu;
+			bool pendC = false; uint32_t lead = 16;
+			if (cinOpen) { lead = (uint32_t)__builtin_ctz(brk | 0x10000u); pendC = lead < 16; }
+			uint32_t Srem = Sm;
+			if (runOpen && runInWin && Sm) Srem &= ~(1u << (31 - __builtin_clz(Sm)));      /* the run still open is the last one begun */
+			flush_pending();
+			bool firstRound = true;
+			const uint32_t hotNow = slab->hot_list;
+			while (__any(pendC || Srem)) {
+#pragma unroll
+				for (int r = 0; r < SK_RR; r++) {
+					q_info[r] = 0;
+					if (pendC) { pendC = false; q_info[r] = (1u << 31) | (1u << 24) | ((cinN + lead) << 16) | cinStart; q_mh[r] = cinMh; }
+					else if (Srem) {
+						const uint32_t pos = (uint32_t)__builtin_ctz(Srem); Srem &= Srem - 1;
+						const uint32_t end = pos + 1 + (uint32_t)__builtin_ctz((brk >> (pos + 1)) | (1u << (15 - pos)));
+						q_info[r] = (1u << 31) | (1u << 24) | ((end - pos) << 16) | (jb + pos + 1 - k);
+						q_mh[r] = mhr[pos * 64 + lane];
+					}
+					if (q_info[r] >> 31) {
+						const uint32_t nn = (q_info[r] >> 16) & 0xffu;
+						const uint32_t need = 1 + sk_base_granules(nn, k), myList = sk_list_of(q_mh[r], sp.list_bits);
+						if (myList == hotNow) { q_booked[r] = sk_append_hot(slab, myList, need, pool); q_info[r] |= 1u << 30; }
+						else q_booked[r] = atomicAdd(sp.state + myList, (unsigned long long)need);
+					}
+				}
+				if (!firstRound || __any(pendC || Srem)) flush_pending();      /* more rounds to come: settle now */
+				firstRound = false;
+			}
+			if (slab->next >= 64u) {
+				__builtin_amdgcn_wave_barrier();
+				if (lane == 0) { const uint32_t used = slab->next; slab->base[0] = slab->base[1]; slab->base[1] = atomicAdd(pool.head, 64u); slab->next = used >= 128u ? 64u : used - 64u; }
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+		flush_pending();                   /* the last window's records: their bases are read from this tile */
+		done += n;
+		sk_wave_lds_order();               /* all lanes are done reading the tile before it is overwritten */
+	}
+	nRaw += tRaw; nGood += tGood;
+	if (sp.track && have && !myDiscard) {
+		SkTrackRec *tr = sp.track + myRead;
+		if (rv.u_start) { atomicAdd(&tr->raw, tRaw); atomicAdd(&tr->good, tGood); atomicMax(&tr->end_ordinal, (unsigned long long)(rv.stream_base + myEnd)); }
+		else { tr->raw = tRaw; tr->good = tGood; tr->end_ordinal = rv.stream_base + myEnd; }
+	}
+	}
+	/* chunks of the slabs nobody took belong to no list */
+	__builtin_amdgcn_wave_barrier();
+	{
+		const uint32_t used = slab->next < 128u ? slab->next : 128u;
+		for (uint32_t idx = used + (uint32_t)lane; idx < 128u; idx += 64) { const uint32_t c = slab->base[idx >> 6] + (idx & 63u); if (c < pool.cap) { pool.chunk_list[c] = NO_CHUNK; pool.chunk_count[c] = 0; } }
+		if (lane == 0 && slab->hot_list < SK_LIST_LOCKED) {      /* the open chunk of the wavefront's hot chain */
+			const uint32_t hc = (uint32_t)(slab->hot_state >> 32), hf = (uint32_t)slab->hot_state;
+			if (hc < pool.cap) pool.chunk_count[hc] = hf < SK_CHUNK_G ? hf : SK_CHUNK_G;
+		}
+	}
+	nRaw = wave_sum(nRaw); nGood = wave_sum(nGood);
+	if (lane == 0) { atomicAdd(&p.stats->raw, nRaw); atomicAdd(&p.stats->good, nGood); }
+}
+
 /* reverse complement of a left-justified k-mer of W words, left-justified again */
 template <int W> __device__ __forceinline__ Key<W> key_revcomp(const Key<W> &f, uint32_t k) {
 	Key<W> r;
@@ -844,11 +1161,6 @@ template <int W> struct SkLong {
 	Table<W> merge;                         /* item mode: where the tables go */
 	unsigned long long *merge_used;         /* slots of it claimed so far: beyond 5/8 of the table the launch gives up (ERR_TABLE_FULL) and the host comes back with a larger one */
 };
-
-/* lanes of ONE wavefront hand data to each other through LDS: the LDS executes a wavefront's instructions in issue order, so all that
- * is needed is that the compiler keeps the order (a workgroup-scope fence here also drains the vector-memory counter, i.e. waits for
- * every prefetch in flight) */
-__device__ __forceinline__ void sk_wave_lds_order() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 
 template <int W, int LOG2S, bool TRACK = false>
 __host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (TRACK ? 8 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }

@@ -530,6 +530,65 @@ def test_buckets_by_radix_partition(k, nbw, reads):
     assert np.array_equal(o1.image(KMR_MAP_SINGLETON), p1.image(KMR_MAP_SINGLETON))
 
 
+def _uniform_quality_reads(seed, k, quals):
+    """reads whose k-mers all weigh the same unless they hold an N: one quality character everywhere ('flat'), REF_QUAL ('ref'), or
+    no qualities at all ('none'); N's at 0.3 % of the positions, a few reads longer than an LDS tile, a few shorter than k"""
+    rng = np.random.default_rng(seed)
+    parts = [synth_reads(6000, read_len=150, genome_len=90000, seed=seed), synth_reads(6, read_len=11000, genome_len=90000, seed=seed + 1),
+             synth_reads(40, read_len=k - 1, genome_len=90000, seed=seed + 2), synth_reads(500, read_len=97, genome_len=90000, seed=seed + 3)]
+    out = []
+    for rb in parts:
+        b = rb.bases.copy()
+        b[rng.random(b.size) < 0.003] = ord("N")
+        q = None if quals == "none" else np.full(b.size, 127 if quals == "ref" else ord("I"), dtype=np.uint8)
+        out.append(ReadBatch.from_arrays(b, q, rb.offsets))
+    return out
+
+
+@pytest.mark.parametrize("quals", ["flat", "ref", "none"])
+@pytest.mark.parametrize("k", [13, 21, 31, 32, 51, 127])
+def test_uniform_weight_extraction(k, quals):
+    """sk_extract_lean_kernel takes launches whose k-mers all weigh the same (no qualities, or one quality character): the spectrum
+    must be the serial oracle's, and byte for byte what the general kernel makes of the same reads (kmr_tune lean_extract = 0) -- with
+    N's in the reads, reads cut into units, reads shorter than k, several calls."""
+    batches = _uniform_quality_reads(900 + k, k, quals)
+    cfg = default_config(k, estimated_raw_kmers=1_100_000)
+    o = OracleSpectrum(cfg)
+    p, g = product(cfg, 3), product(cfg, 3, lean_extract=0)
+    first = 0
+    for rb in batches:
+        o.add_reads(rb, first_idx=first)
+        add(p, rb, first=first)
+        add(g, rb, first=first)
+        first += rb.n
+    for x in (o, p, g):
+        x.finalize(1)
+    assert o.stats() == p.stats() == g.stats()
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+    assert np.array_equal(p.image(KMR_MAP_WEAK), g.image(KMR_MAP_WEAK))
+    assert np.array_equal(p.image(KMR_MAP_SINGLETON), g.image(KMR_MAP_SINGLETON))
+
+
+def test_quality_mix_is_noticed_between_calls():
+    """a build whose first call is uniform and whose second is not (and the other way round): every call picks its own kernel"""
+    a = _uniform_quality_reads(77, 31, "flat")[0]
+    b = synth_reads(5000, read_len=150, genome_len=90000, seed=78, quality="noisy", n_rate=0.002)
+    for order in ((a, b), (b, a)):
+        cfg = default_config(31, estimated_raw_kmers=1_400_000)
+        o = OracleSpectrum(cfg)
+        p = product(cfg, 3)
+        first = 0
+        for rb in order:
+            o.add_reads(rb, first_idx=first)
+            add(p, rb, first=first)
+            first += rb.n
+        o.finalize(2)
+        p.finalize(2)
+        assert o.stats() == p.stats()
+        compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+
+
 def test_build_modes_agree_at_scale():
     """3M reads (360M k-mers, two sub-batches, ~2.6e5 final lists): the device-table path and the streaming
     partition path are independent algorithms; their statistics and weak images must be byte-identical
