@@ -1316,7 +1316,8 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 		}
 	}
 	if (!weakDone) { rc = exclusive_scan(h, wc, wm.nb, wm.start); if (rc) return rc; }
-	rc = exclusive_scan(h, sc, sm.nb, sm.start); if (rc) return rc;
+	if (keepSing) { rc = exclusive_scan(h, sc, sm.nb, sm.start); if (rc) return rc; }
+	else HIPCHK(h, hipMemsetAsync(sm.start, 0, 8 * (sm.nb + 1), h->stream));      /* no singleton map is kept: every bucket starts (and ends) at 0 */
 	if (!weakDone) {
 		rc = reserve_bytes(h, (void **)&wm.keys, wm.c_keys, 8ull * W * wm.n); if (rc) return rc;
 		rc = reserve_bytes(h, (void **)&wm.vals, wm.c_vals, 4ull * vw * wm.n); if (rc) return rc;

@@ -1367,7 +1367,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						}
 					};
 					/* next k-mer: canonical key, strand, table slot, weight */
-					Key<W> key; bool fwd = true; uint64_t h = 0; uint32_t slot = 0; bool mine = false; uint32_t wnext = 0;
+					Key<W> key; bool fwd = true; uint64_t h = 0; uint32_t slot = 0, step = 1; bool mine = false; uint32_t wnext = 0;
 #pragma unroll
 					for (int wi = 0; wi < W; wi++) key.w[wi] = 0;
 					auto prepare = [&]() {
@@ -1391,13 +1391,17 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						key = fwd ? kf : kr;
 						h = slot_hash<W>(key.w);
 						slot = (uint32_t)(h >> (64 - LOG2S));
+						/* a key that does not find its home slot free (or its own) goes on in steps of an odd number taken from other bits of its
+						 * hash: with steps of one the occupied slots grow into runs, and the wavefront waits for the longest probe sequence
+						 * among its 64 lanes every time (one claim attempt and one LDS round trip per step) */
+						step = ((uint32_t)(h >> (64 - 2 * LOG2S)) & (uint32_t)(S - 1)) | 1u;
 						mine = ((uint32_t)(h >> 20) & subMask) == val;
 					};
 					if (left) { enter_record(); seed_window(); wnext = uniformW ? hw : ww[j]; request_next_record(); prepare(); }
 					uint32_t dbgSink = 0;
 					for (uint32_t it = 0; it < Lk; it++) {
 						if (left) {
-							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot;
+							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot; const uint32_t cstep = step;
 							const float wa = __uint_as_float(wnext);
 							const uint64_t cord = ord0 + j;
 							/* the claim of the current k-mer's home slot is on its way while the next k-mer is made (one-word keys: a compare-and-swap
@@ -1424,7 +1428,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 								if constexpr (W == 1) {
 									if (old == EMPTY_KEY) { claimedHere++; placed = true; }
 									else if (old == ckey.w[0]) placed = true;
-									else s = (s + 1) & (S - 1);
+									else s = (s + cstep) & (S - 1);
 								}
 								for (int probe = 0; probe < S && !placed; probe++) {
 									if constexpr (W == 1) {
@@ -1450,7 +1454,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 										for (int qq = 0; qq < W; qq++) eq = eq && (tkeys[(size_t)s * W + qq] == ckey.w[qq]);
 										if (eq) { placed = true; break; }
 									}
-									s = (s + 1) & (S - 1);
+									s = (s + cstep) & (S - 1);
 								}
 								if (!placed) s_overflow[fl] = 1;      /* table full */
 								else {
