@@ -1521,6 +1521,83 @@ int add_reads_superkmer(kmr_handle *h, const ReadsView &rv, uint64_t total_bases
 	switch (h->W) { case 1: return add_reads_superkmer_t<1>(h, rv, total_bases); case 2: return add_reads_superkmer_t<2>(h, rv, total_bases);
 	case 3: return add_reads_superkmer_t<3>(h, rv, total_bases); default: return add_reads_superkmer_t<4>(h, rv, total_bases); }
 }
+/* k-mers seen more than 65 535 times (sat_*_kernel in kmr_superkmer.hpp): weightedCount and directionBias of their entries in the
+ * finished weak map from their first 65 535 sightings in input order, as the serial reference keeps them. */
+template <int W> int saturated_fix_t(kmr_handle *h, const uint64_t *ls, const uint64_t *lc, uint64_t nl, unsigned long long n_clamped, unsigned long long n_sightings, uint32_t has_singletons) {
+	DevMap &wm = h->weak;
+	if (!n_clamped || !wm.n) return 0;
+	uint32_t list_bits = 0; while ((1ull << list_bits) < nl) list_bits++;
+	unsigned long long *dfound = nullptr; uint64_t *d_entry = nullptr; uint32_t *d_list = nullptr;
+	std::vector<void *> owned;
+	auto release = [&]() { for (void *p : owned) hipFree(p); owned.clear(); };
+#define SATCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { release(); h->err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+	auto dalloc = [&](void **p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256)); if (e == hipSuccess) owned.push_back(*p); return e; };
+	SATCHK(dalloc((void **)&dfound, 8));
+	uint64_t cap = std::min<uint64_t>(wm.n, 4 * n_clamped + 1024);
+	unsigned long long found = 0;
+	for (;;) {
+		SATCHK(dalloc((void **)&d_entry, 8 * cap)); SATCHK(dalloc((void **)&d_list, 4 * cap));
+		SATCHK(hipMemsetAsync(dfound, 0, 8, h->stream));
+		hipLaunchKernelGGL(sat_find_kernel<W>, dim3(grid_for(wm.n)), dim3(256), 0, h->stream, (const uint64_t *)wm.keys, (const uint32_t *)wm.vals, wm.n, h->sk_m, h->sk_off, h->sk_win, list_bits, dfound, cap, d_entry, d_list);
+		SATCHK(hipGetLastError());
+		SATCHK(hipMemcpyAsync(&found, dfound, 8, hipMemcpyDeviceToHost, h->stream)); SATCHK(hipStreamSynchronize(h->stream));
+		if (found <= cap) break;
+		cap = found;      /* more entries at exactly 65 535 than expected: again with room for all */
+	}
+	if (found >= (1ull << 23)) { release(); return 0; }      /* (more than 8 x 10^6 saturated keys: left as the count pass made them) */
+	std::vector<uint64_t> entry(found); std::vector<uint32_t> lst(found);
+	SATCHK(hipMemcpy(entry.data(), d_entry, 8 * found, hipMemcpyDeviceToHost)); SATCHK(hipMemcpy(lst.data(), d_list, 4 * found, hipMemcpyDeviceToHost));
+	std::vector<uint32_t> order(found);
+	for (uint32_t i = 0; i < found; i++) order[i] = i;
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lst[a] != lst[b] ? lst[a] < lst[b] : entry[a] < entry[b]; });
+	std::vector<uint64_t> sentry(found); std::vector<uint32_t> dl; std::vector<uint64_t> le0, le1;
+	for (uint32_t i = 0; i < found; i++) {
+		sentry[i] = entry[order[i]];
+		const uint32_t l = lst[order[i]];
+		if (dl.empty() || dl.back() != l) { dl.push_back(l); le0.push_back(i); le1.push_back(i + 1); } else le1.back() = i + 1;
+	}
+	SATCHK(hipMemcpy(d_entry, sentry.data(), 8 * found, hipMemcpyHostToDevice));
+	SATCHK(hipMemcpy(d_list, dl.data(), 4 * dl.size(), hipMemcpyHostToDevice));
+	uint64_t *d_c0 = nullptr, *d_c1 = nullptr;
+	SATCHK(dalloc((void **)&d_c0, 8 * dl.size())); SATCHK(dalloc((void **)&d_c1, 8 * dl.size()));
+	hipLaunchKernelGGL(sat_gather_kernel, dim3(grid_for(dl.size())), dim3(256), 0, h->stream, ls, (const uint32_t *)d_list, (uint64_t)dl.size(), d_c0, d_c1);
+	SATCHK(hipGetLastError());
+	std::vector<uint64_t> c0(dl.size()), c1(dl.size());
+	SATCHK(hipMemcpy(c0.data(), d_c0, 8 * dl.size(), hipMemcpyDeviceToHost)); SATCHK(hipMemcpy(c1.data(), d_c1, 8 * dl.size(), hipMemcpyDeviceToHost));
+	/* work items: pieces of 256 chunks of those lists */
+	std::vector<uint64_t> ic0, ic1, ie0, ie1;
+	for (size_t i = 0; i < dl.size(); i++)
+		for (uint64_t a = c0[i]; a < c1[i]; a += 256) { ic0.push_back(a); ic1.push_back(std::min(c1[i], a + 256)); ie0.push_back(le0[i]); ie1.push_back(le1[i]); }
+	if (ic0.empty()) { release(); return 0; }
+	uint64_t *d_items = nullptr;
+	const size_t ni = ic0.size();
+	SATCHK(dalloc((void **)&d_items, 32 * ni));
+	SATCHK(hipMemcpy(d_items, ic0.data(), 8 * ni, hipMemcpyHostToDevice)); SATCHK(hipMemcpy(d_items + ni, ic1.data(), 8 * ni, hipMemcpyHostToDevice));
+	SATCHK(hipMemcpy(d_items + 2 * ni, ie0.data(), 8 * ni, hipMemcpyHostToDevice)); SATCHK(hipMemcpy(d_items + 3 * ni, ie1.data(), 8 * ni, hipMemcpyHostToDevice));
+	/* every sighting of those keys: the clamped ones' true counts are known, the others have exactly 65 535 */
+	const uint64_t pcap = n_sightings + (found - std::min<unsigned long long>(found, n_clamped)) * 65535ull + 64;
+	unsigned long long *pk_in = nullptr, *pk_out = nullptr; uint32_t *pv_in = nullptr, *pv_out = nullptr;
+	SATCHK(dalloc((void **)&pk_in, 8 * pcap)); SATCHK(dalloc((void **)&pk_out, 8 * pcap)); SATCHK(dalloc((void **)&pv_in, 4 * pcap)); SATCHK(dalloc((void **)&pv_out, 4 * pcap));
+	SATCHK(hipMemsetAsync(dfound, 0, 8, h->stream));
+	int rc = zero_work_counter(h); if (rc) { release(); return rc; }
+	hipLaunchKernelGGL(sat_collect_kernel<W>, dim3((unsigned)std::min<uint64_t>(ni, (uint64_t)num_cus(h) * 4)), dim3(256), 0, h->stream, pool_view(h, h->l1), lc, h->k, (const uint64_t *)wm.keys, (const uint64_t *)d_entry,
+	                   (const uint64_t *)d_items, (const uint64_t *)(d_items + ni), (const uint64_t *)(d_items + 2 * ni), (const uint64_t *)(d_items + 3 * ni), (uint64_t)ni, dfound, pcap, pk_in, pv_in, h->work_counter);
+	SATCHK(hipGetLastError());
+	unsigned long long n_pairs = 0;
+	SATCHK(hipMemcpyAsync(&n_pairs, dfound, 8, hipMemcpyDeviceToHost, h->stream)); SATCHK(hipStreamSynchronize(h->stream));
+	if (n_pairs > pcap) { release(); return fail(h, KMR_ERR_CAPACITY, "sightings of saturated k-mers (internal sizing error)"); }
+	size_t tmp_bytes = 0; void *tmp = nullptr;
+	if (kmr::sort_pairs_u64_u32(nullptr, &tmp_bytes, pk_in, pk_out, pv_in, pv_out, n_pairs, h->stream) != 0) { release(); return fail(h, KMR_ERR_HIP, "radix sort (size query)"); }
+	SATCHK(dalloc(&tmp, tmp_bytes));
+	if (kmr::sort_pairs_u64_u32(tmp, &tmp_bytes, pk_in, pk_out, pv_in, pv_out, n_pairs, h->stream) != 0) { release(); return fail(h, KMR_ERR_HIP, "radix sort"); }
+	hipLaunchKernelGGL(sat_reduce_kernel, dim3((unsigned)std::min<uint64_t>(found, 4096)), dim3(256), 0, h->stream, (const unsigned long long *)pk_out, (const uint32_t *)pv_out, (uint64_t)n_pairs, (const uint64_t *)d_entry, (uint64_t)found, has_singletons, wm.vals);
+	SATCHK(hipGetLastError());
+	SATCHK(hipStreamSynchronize(h->stream));
+	release();
+#undef SATCHK
+	return 0;
+}
+
 template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	int rc = sync_state(h);
 	if (rc) return rc;
@@ -1700,6 +1777,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing, true);
 	time_end(h, KMR_TIME_BUCKETS, tma, tmb);
 	if (rc) return rc;
+	if (c.saturated) { rc = saturated_fix_t<W>(h, ls, lc, nl, c.saturated, c.sat_sightings, f.has_singletons); if (rc) return rc; }
 	time_end(h, 1, ea, eb);
 	h->has_singletons = keepSing;
 	h->stats.weak_entries = h->weak.n; h->stats.singleton_entries = keepSing ? h->sing.n : 0;

@@ -25,6 +25,9 @@
 
 namespace kmr {
 
+/* kmr_sort.hip: (u64, u32) pairs sorted by key on the device (rocPRIM); tmp == nullptr returns the scratch size in *tmp_bytes */
+int sort_pairs_u64_u32(void *tmp, size_t *tmp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned int *vals_in, unsigned int *vals_out, size_t n, hipStream_t stream);
+
 static const int BB_TILE = 4096;            /* entries per tile: a tile never spans two segments                       */
 static const int BB_THREADS = 256;
 static const int BB_PER_THREAD = BB_TILE / BB_THREADS;

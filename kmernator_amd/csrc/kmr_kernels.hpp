@@ -968,7 +968,7 @@ struct FinalizeParams {
 	uint32_t has_singletons;      /* cfg.separate_singletons */
 	uint64_t nb_weak, nb_sing;
 };
-struct FinalizeCounters { unsigned long long unique, singletons, weak_kept, sing_kept; };
+struct FinalizeCounters { unsigned long long unique, singletons, weak_kept, sing_kept, saturated, sat_sightings; };      /* saturated: keys seen more than 65 535 times (build_mode 3 counts them and their sightings) */
 
 /* where does an entry with 'count' occurrences end up? 1 = weak, 2 = singleton, 0 = dropped.
  * append() keeps count==1 keys in the singleton map when hasSingletons (src/KmerSpectrum.h:1646-1655);

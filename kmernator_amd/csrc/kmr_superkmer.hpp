@@ -1208,7 +1208,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	if (TRACK) for (int i = t; i < 2 * (int)(SK_TRACK_MAX + 1); i += SKC_THREADS) trkU[i] = 0;
 	const uint32_t vw = 3;
-	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0;
+	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0, satK = 0, satS = 0;
 	/* this wavefront's output slabs: [wpos, wend) of the weak entries, [spos, send) of the singletons */
 	unsigned long long wpos = 0, wend = 0, spos = 0, send = 0;
 	bool outFull = false;
@@ -1547,7 +1547,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 								const uint64_t pos = wpos + (uint32_t)__builtin_popcountll(mw & below);
 								uint32_t fwdc = (uint32_t)(cf >> 32), cnt16 = count;
 								if (f.has_singletons && first_forward(fst)) fwdc -= 1;
-								if (cnt16 > 65535u) { cnt16 = 65535u; if (fwdc > 65534u) fwdc = 65534u; }
+								if (cnt16 > 65535u) { satK++; satS += count; cnt16 = 65535u; if (fwdc > 65534u) fwdc = 65534u; }      /* (weight and direction of such a key are redone from its first 65 535 sightings, sat_*_kernel) */
 								if (fwdc > 65535u) fwdc = 65535u;
 								const uint32_t wbits = __float_as_uint((float)(f.has_singletons ? wsum + first_weight_shift(fst) : wsum));
 								if (out.wentries) {
@@ -1643,10 +1643,11 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	/* the unused tails of this wavefront's slabs are holes */
 	for (unsigned long long e = wpos + lane; e < wend && e < out.wcap; e += 64) { if (out.wentries) out.wentries[e * (W + 1) + W] = 0; else out.wvals[e * vw] = 0; }
 	for (unsigned long long e = spos + lane; e < send && e < out.scap; e += 64) out.sweight[e] = 0;
-	uniq = wave_sum(uniq); single = wave_sum(single);
+	uniq = wave_sum(uniq); single = wave_sum(single); satK = wave_sum(satK); satS = wave_sum(satS);
 	if (lane == 0) {
 		if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single);
 		if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS);
+		if (satK) { atomicAdd(&out.fc->saturated, satK); atomicAdd(&out.fc->sat_sightings, satS); }
 	}
 	if (TRACK) {
 		lds_barrier();
@@ -1680,7 +1681,7 @@ void sk_merge_emit_kernel(Table<W> tbl, CountOut out, FinalizeParams f) {
 				else {
 					if (out.weakCount) bucket = key_hash<W>(key, f.kb) & (f.nb_weak - 1);
 					if (f.has_singletons && first_forward(sl.first)) fwdc -= 1;
-					if (cnt > 65535u) { cnt = 65535u; if (fwdc > 65534u) fwdc = 65534u; }
+					if (cnt > 65535u) { atomicAdd(&out.fc->saturated, 1ull); atomicAdd(&out.fc->sat_sightings, (unsigned long long)cnt); cnt = 65535u; if (fwdc > 65534u) fwdc = 65534u; }
 					if (fwdc > 65535u) fwdc = 65535u;
 					const uint32_t wbits = __float_as_uint((float)(f.has_singletons ? sl.wsum + first_weight_shift(sl.first) : sl.wsum));
 					if (out.wentries) {
@@ -1908,6 +1909,205 @@ void sk_lookup_kernel(PoolView pool, const uint64_t *list_start, const uint64_t 
 		}
 	}
 }
+
+/* ------------------------------------------------------------------ k-mers seen more than 65 535 times */
+/* TrackingData::track stops at MAX_COUNT (src/KmerTrackingData.h:427-448): the 65 535 sightings a saturated k-mer's weightedCount and
+ * directionBias (:517-529) are made of are its FIRST 65 535 in input order.  The count pass adds up all sightings (it has no order);
+ * for the handful of keys it clamps, this pass goes back to their lists, writes down every sighting as (key index, stream ordinal,
+ * strand; weight), sorts them (kmr_sort.hip) and sums the first 65 535 of every key -- with the first one of all treated as the
+ * promotion from the singleton map treats it (direction lost, weight as the singleton byte kept it, :641-658). */
+/* entries of the finished weak map whose count is 65 535: their index in the map and the list their minimizer selects */
+template <int W>
+__global__ __launch_bounds__(256)
+void sat_find_kernel(const uint64_t *keys, const uint32_t *vals, uint64_t n, uint32_t m, uint32_t off, uint32_t win, uint32_t list_bits,
+                     unsigned long long *found, uint64_t cap, uint64_t *sat_entry, uint32_t *sat_list) {
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+		if ((vals[e * 3] & 0xffffu) != 65535u) continue;
+		const unsigned long long at = atomicAdd(found, 1ull);
+		if (at < cap) { sat_entry[at] = e; sat_list[at] = sk_list_of(sk_key_minimizer<W>(keys + e * W, m, off, win), list_bits); }
+	}
+}
+#ifndef KMR_INSTANCE_TU
+__global__ void sat_gather_kernel(const uint64_t *list_start, const uint32_t *lists, uint64_t n, uint64_t *c0, uint64_t *c1) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { c0[i] = list_start[lists[i]]; c1[i] = list_start[lists[i] + 1]; }
+}
+#endif
+/* work item i: chunks [item_c0[i], item_c1[i]) of a list, saturated keys [item_e0[i], item_e1[i]) (indices into sat_entry, which is
+ * ordered by list).  Every sighting of one of those keys becomes a pair: key = index << 41 | ordinal << 1 | forward, value = weight. */
+static const uint32_t SAT_FILL = 192;
+template <int W>
+__global__ __launch_bounds__(256)
+void sat_collect_kernel(PoolView pool, const uint64_t *list_chunks, uint32_t k, const uint64_t *map_keys, const uint64_t *sat_entry,
+                        const uint64_t *item_c0, const uint64_t *item_c1, const uint64_t *item_e0, const uint64_t *item_e1, uint64_t n_items,
+                        unsigned long long *cursor, uint64_t cap, unsigned long long *out_keys, uint32_t *out_vals, unsigned int *work_counter) {
+	constexpr int S = 256;
+	__shared__ uint64_t tkeys[S * W];
+	__shared__ uint32_t tval[S], tstate[S];
+	__shared__ __attribute__((aligned(16))) uint4 stage[4 * SK_CHUNK_G];
+	__shared__ uint8_t recOf[4 * 64];
+	__shared__ uint32_t s_item;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const uint4 *poolg = (const uint4 *)pool.base;
+	for (;;) {
+		__syncthreads();
+		if (t == 0) s_item = atomicAdd(work_counter, 1u);
+		__syncthreads();
+		const uint64_t it = s_item;
+		if (it >= n_items) break;
+		const uint64_t c0 = item_c0[it], c1 = item_c1[it], e0 = item_e0[it], e1 = item_e1[it];
+		for (uint64_t eb = e0; eb < e1; eb += SAT_FILL) {
+			__syncthreads();
+			for (int i = t; i < S; i += 256) tstate[i] = 0;
+			__syncthreads();
+			const uint64_t ee = eb + SAT_FILL < e1 ? eb + SAT_FILL : e1;
+			for (uint64_t e = eb + (uint64_t)t; e < ee; e += 256) {
+				uint64_t kw[W];
+#pragma unroll
+				for (int q = 0; q < W; q++) kw[q] = map_keys[sat_entry[e] * W + q];
+				uint32_t sl = (uint32_t)(slot_hash<W>(kw) >> 56);
+				while (atomicCAS(&tstate[sl], 0u, 1u) != 0u) sl = (sl + 1) & (S - 1);
+#pragma unroll
+				for (int q = 0; q < W; q++) tkeys[(size_t)sl * W + q] = kw[q];
+				tval[sl] = (uint32_t)e;
+			}
+			__syncthreads();
+			uint4 *wstage = stage + wv * SK_CHUNK_G;
+			uint8_t *wrecOf = recOf + wv * 64;
+			for (uint64_t ci = c0 + wv; ci < c1; ci += 4) {
+				const uint64_t d = list_chunks[ci];
+				const uint32_t chunk = (uint32_t)d, curCount = (uint32_t)(d >> 32);
+				uint4 cur = make_uint4(0, 0, 0, 0);
+				if ((uint32_t)lane < curCount) cur = poolg[(size_t)chunk * SK_CHUNK_G + lane];
+				sk_wave_lds_order();      /* the lanes are done with the chunk before */
+				wstage[lane] = cur;
+				const uint32_t glen = (cur.y >> 17) & 0x7fu;
+				unsigned long long starts = 0;
+				if (__all((lane & 1) != 0 || (uint32_t)lane >= curCount || glen == 2u)) starts = 0x5555555555555555ull & (curCount >= 64u ? ~0ull : ((1ull << curCount) - 1ull));
+				else for (uint32_t pos = 0; pos < curCount; ) {
+					starts |= 1ull << pos;
+					const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos);
+					pos += step ? step : SK_CHUNK_G;
+				}
+				/* the chunk's k-mers dealt evenly over the lanes, as in sk_lookup_kernel */
+				const bool isStart = (starts >> lane) & 1ull;
+				const uint32_t myN = isStart ? (cur.y >> 8) & 0xffu : 0u;
+				uint32_t incl = myN;
+#pragma unroll
+				for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += x; }
+				const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+				const uint32_t myOff = incl - myN;
+				const uint32_t Lk = (T + 63u) >> 6;
+				if (myN) {
+					const float Lf = (float)Lk;
+					const uint32_t l0 = (uint32_t)((float)(myOff + Lk - 1) / Lf), l1 = (uint32_t)((float)(myOff + myN - 1) / Lf);
+					for (uint32_t l = l0; l <= l1 && l < 64u; l++) wrecOf[l] = (uint8_t)lane;
+				}
+				sk_wave_lds_order();
+				const uint32_t k0 = (uint32_t)lane * Lk;
+				uint32_t left = k0 < T ? (T - k0 < Lk ? T - k0 : Lk) : 0u;
+				uint32_t rs = left ? wrecOf[lane] : 0u;
+				uint32_t j = k0 - (uint32_t)__shfl((int)myOff, (int)rs, 64);
+				uint32_t hx = (uint32_t)__shfl((int)cur.x, (int)rs, 64), hy = (uint32_t)__shfl((int)cur.y, (int)rs, 64), hw = (uint32_t)__shfl((int)cur.w, (int)rs, 64);
+				uint32_t n = 0; const uint32_t *bw = nullptr, *ww = nullptr; uint64_t ord0 = 0; bool uniformW = true;
+				for (uint32_t itr = 0; itr < Lk; itr++) {
+					uint32_t found = 0xffffffffu, wbits = 0; bool fwd = true; uint64_t ord = 0;
+					if (left) {
+						if (itr == 0 || j >= n) {
+							if (itr != 0) { rs += (hy >> 17) & 0x7fu; const uint4 hd = wstage[rs]; hx = hd.x; hy = hd.y; hw = hd.w; j = 0; }
+							n = (hy >> 8) & 0xffu;
+							bw = (const uint32_t *)(wstage + rs + 1);
+							ww = bw + 4 * sk_base_granules(n, k);
+							uniformW = ((hy >> 16) & 1u) != 0;
+							ord0 = (uint64_t)hx | ((uint64_t)(hy & 0xffu) << 32);
+						}
+						Key<W> kf;
+						const uint32_t d0 = j >> 4, sft = 2u * (j & 15u);
+#pragma unroll
+						for (int wi = 0; wi < W; wi++) {
+							const uint32_t a = bw[d0 + 2 * wi], b = bw[d0 + 2 * wi + 1], c = bw[d0 + 2 * wi + 2];
+							const uint64_t hi = ((uint64_t)a << 32) | b;
+							kf.w[wi] = sft ? (hi << sft) | ((uint64_t)c >> (32 - sft)) : hi;
+						}
+						const uint32_t kbits = 2u * k;
+#pragma unroll
+						for (int wi = 0; wi < W; wi++) {
+							const uint32_t lo = 64u * wi;
+							if (kbits <= lo) kf.w[wi] = 0;
+							else if (kbits < lo + 64u) kf.w[wi] &= ~0ull << (lo + 64u - kbits);
+						}
+						const Key<W> kr = key_revcomp<W>(kf, k);
+						fwd = key_le<W>(kf, kr);
+						const Key<W> key = fwd ? kf : kr;
+						uint32_t sl = (uint32_t)(slot_hash<W>(key.w) >> 56);
+						for (int probe = 0; probe < S; probe++) {
+							if (tstate[sl] == 0) break;
+							bool eq = true;
+#pragma unroll
+							for (int q = 0; q < W; q++) eq = eq && tkeys[(size_t)sl * W + q] == key.w[q];
+							if (eq) { found = tval[sl]; break; }
+							sl = (sl + 1) & (S - 1);
+						}
+						wbits = uniformW ? hw : ww[j];
+						ord = ord0 + j;
+						j++; left--;
+					}
+					/* the lanes that hit a saturated key take consecutive places: one device atomic per wavefront and step */
+					const unsigned long long hit = __ballot(found != 0xffffffffu);
+					if (hit) {
+						unsigned long long base = 0;
+						if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__builtin_popcountll(hit));
+						base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+						if (found != 0xffffffffu) {
+							const unsigned long long at = base + (unsigned long long)__builtin_popcountll(hit & ((1ull << lane) - 1));
+							if (at < cap) { out_keys[at] = ((unsigned long long)found << 41) | ((unsigned long long)ord << 1) | (fwd ? 1ull : 0ull); out_vals[at] = wbits; }
+						}
+					}
+				}
+			}
+		}
+	}
+}
+/* one block per saturated key (index b into sat_entry): its sightings are the sorted pairs with key >> 41 == b; the first 65 535 of
+ * them make weightedCount and directionBias of map entry sat_entry[b] (a key with no more than 65 535 sightings keeps what it has).
+ * The weights are added as the reference adds them -- one after the other in input order into a float (weightedCount += weight,
+ * src/KmerTrackingData.h:440: at 6 x 10^4 a float moves in steps of 2^-8, so 65 534 additions of ~1 drift by tens against the exact sum)
+ * -- by one thread out of LDS tiles the block loads together; the direction count is a plain sum. */
+#ifndef KMR_INSTANCE_TU
+__global__ __launch_bounds__(256)
+void sat_reduce_kernel(const unsigned long long *keys, const uint32_t *weights, uint64_t n_pairs, const uint64_t *sat_entry, uint64_t n_sat, uint32_t has_singletons, uint32_t *map_vals) {
+	constexpr int TILE = 4096;
+	__shared__ float s_w[TILE]; __shared__ unsigned int s_f[256];
+	const int t = threadIdx.x;
+	for (uint64_t b = blockIdx.x; b < n_sat; b += gridDim.x) {
+		auto lower = [&](unsigned long long v) { uint64_t lo = 0, hi = n_pairs; while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (keys[mid] < v) lo = mid + 1; else hi = mid; } return lo; };
+		const uint64_t s = lower((unsigned long long)b << 41), e = lower((unsigned long long)(b + 1) << 41);
+		__syncthreads();
+		if (e - s <= 65535) continue;
+		/* sighting 1: without a singleton map it is tracked like the others; with one it comes back from there without its direction and
+		 * with the weight the singleton byte kept (src/KmerTrackingData.h:641-658) */
+		const float w1 = __uint_as_float(weights[s]);
+		float acc = has_singletons ? (float)((double)(first_weight_bits(w1) >> 15) / 254.0) : (float)(0.0 + (double)w1);
+		unsigned int f = 0;
+		for (uint64_t i = s + 1 + t; i < s + 65535; i += 256) f += (unsigned int)(keys[i] & 1ull);      /* sightings 2 .. 65 535 */
+		s_f[t] = f;
+		for (uint64_t base = s + 1; base < s + 65535; base += TILE) {
+			const uint64_t nt = s + 65535 - base < (uint64_t)TILE ? s + 65535 - base : (uint64_t)TILE;
+			__syncthreads();
+			for (uint64_t i = t; i < nt; i += 256) s_w[i] = __uint_as_float(weights[base + i]);
+			__syncthreads();
+			if (t == 0) for (uint64_t i = 0; i < nt; i++) acc = (float)((double)acc + (double)s_w[i]);
+		}
+		__syncthreads();
+		for (int o = 128; o > 0; o >>= 1) { if (t < o) s_f[t] += s_f[t + o]; __syncthreads(); }
+		if (t == 0) {
+			unsigned int fwd = s_f[0];
+			if (!has_singletons) fwd += (unsigned int)(keys[s] & 1ull);
+			uint32_t *v = map_vals + sat_entry[b] * 3;
+			v[1] = __float_as_uint(acc); v[2] = fwd;
+		}
+	}
+}
+#endif
 
 /* ------------------------------------------------------------------ owner exchange of super-k-mer lists */
 /* One process per GPU: every rank scatters the super-k-mers of ITS reads into all 2^list_bits lists; list l belongs to rank

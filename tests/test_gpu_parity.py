@@ -1000,7 +1000,17 @@ def test_low_complexity_reads(mode):
     rb = type(rb).from_arrays(bases.reshape(-1), quals.reshape(-1), rb.offsets)
     cfg = default_config(31, estimated_raw_kmers=24000 * 120)
     o, p = run_both(cfg, rb, mode=mode)
-    assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False, saturated_dir_free=True) == o.stats()["weak_entries"]
+    # the default build redoes its saturated keys from their first 65 535 sightings in input order (sat_*_kernel): directionBias exact,
+    # weightedCount within the usual tolerance.  The two other modes have no order to go by: those entries are exempt there.
+    assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False, saturated_dir_free=(mode != 3)) == o.stats()["weak_entries"]
+    if mode == 3:
+        _, _, buckets = parse_image(p.image(KMR_MAP_WEAK), p.kb, 12)
+        sat = sum(int(((np.ascontiguousarray(v).view(np.uint32).reshape(len(v), 3)[:, 0] & 0xffff) == 65535).sum()) for _, v in buckets if len(v))
+        assert sat >= 3          # poly-A / poly-T and the two phases of the AC repeat
+        # without a singleton map (no first sighting to set aside) and with the lists counted in pieces (merge table path)
+        for kw, tune in ((dict(separate_singletons=0), dict()), (dict(), dict(long_list_chunks=8))):
+            o2, p2 = run_both(default_config(31, estimated_raw_kmers=24000 * 120, **kw), rb, mode=3, **tune)
+            assert compare_weak_images(o2.image(KMR_MAP_WEAK), p2.image(KMR_MAP_WEAK), p2.kb, False) == o2.stats()["weak_entries"]
 
 
 @pytest.mark.parametrize("k,chunks", [(31, 2), (51, 3), (27, 16)])
