@@ -108,6 +108,9 @@ struct kmr_handle {
 	uint8_t *adopt_buf = nullptr; size_t adopt_cap = 0;      /* kmr_sk_exchange_adopt_dev's scan */
 	/* size tracker (kmr_config.size_tracker): one record per read fed so far, and the elements made of them at kmr_finalize */
 	SkTrackRec *trk = nullptr; uint64_t trk_cap = 0, trk_n = 0; std::vector<uint64_t> trk_elems;
+	/* the thresholds passed so far (SizeTracker::nextToTrack and the elements' first two counters), found call by call while the
+	 * reads are still at hand: the stream ordinal behind the k-mer at which rawKmers reached the threshold, rawKmers, rawGoodKmers */
+	long trk_next = 128; uint64_t trk_raw = 0, trk_good = 0; std::vector<unsigned long long> trk_bounds; std::vector<uint64_t> trk_snap_raw, trk_snap_good;
 	bool sk_fast_div = false;          /* see kmr_create: the chain's divide as multiply-and-correct */
 	bool sender_launch = false;        /* extract_by_owner_t, build (not request) mode: dev_params tells the kernel to count what it does not send */
 	bool sk_exchange = false;          /* kmr_sk_exchange_begin: the lists are the whole job's, every owner's k-mers are kept until the exchange */
@@ -1476,16 +1479,13 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
 	const uint64_t sub_bases = h->tune.sub_batch_bases ? h->tune.sub_batch_bases : (1ull << 31);
 	const uint64_t chunk = std::max<uint64_t>(64, (sub_bases / avg) & ~63ull);
-	if (h->cfg.size_tracker && n) {
-		if (h->trk_n + n > h->trk_cap) {
-			const uint64_t cap = std::max<uint64_t>(h->trk_n + n, h->trk_cap * 2);
-			SkTrackRec *bigger = nullptr;
-			HIPCHK(h, hipMalloc((void **)&bigger, cap * sizeof(SkTrackRec)));
-			if (h->trk_n) HIPCHK(h, hipMemcpyAsync(bigger, h->trk, h->trk_n * sizeof(SkTrackRec), hipMemcpyDeviceToDevice, h->stream));
-			if (h->trk) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->trk); }
-			h->trk = bigger; h->trk_cap = cap;
+	if (h->cfg.size_tracker && n) {      /* per-read records of this call (raw and good k-mers, end ordinal) */
+		h->trk_n = 0;
+		if (n > h->trk_cap) {
+			if (h->trk) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->trk); h->trk = nullptr; h->trk_cap = 0; }
+			HIPCHK(h, hipMalloc((void **)&h->trk, n * sizeof(SkTrackRec))); h->trk_cap = n;
 		}
-		HIPCHK(h, hipMemsetAsync(h->trk + h->trk_n, 0, n * sizeof(SkTrackRec), h->stream));
+		HIPCHK(h, hipMemsetAsync(h->trk, 0, n * sizeof(SkTrackRec), h->stream));
 	}
 	const DevParams dp = dev_params(h);
 	/* world_size > 1: without the exchange a rank keeps the k-mers the reference's owner function gives it (getDistributedThreadId,
@@ -1507,14 +1507,50 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		rc = pool_reserve(h, h->l1, bases / SK_CHUNK_G + ((h->l1.base && !h->sk_exchange) ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * SK_EXTRACT_WAVES_PER_CU * 130 + 64, true); if (rc) return rc;
 		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b); time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
 		SkParams sp = sk_params(h);
-		if (h->cfg.size_tracker) sp.track = h->trk + h->trk_n + r;
+		if (h->cfg.size_tracker) sp.track = h->trk + r;
 #define SKX(WINv) (filt ? launch_sk_extract<W, WINv, true>(h, rv, sp) : (lean ? launch_sk_extract_lean<W, WINv>(h, rv, sp, wK) : launch_sk_extract<W, WINv, false>(h, rv, sp)))
 		rc = h->sk_win == 16 ? SKX(16) : (h->sk_win == 8 ? SKX(8) : SKX(4));
 #undef SKX
 		time_end(h, KMR_TIME_EXTRACT, a2, b2); time_end(h, KMR_TIME_BUILD, a, b);
 		if (rc) return rc;
 	}
-	if (h->cfg.size_tracker) h->trk_n += n;
+	if (h->cfg.size_tracker && n) {
+		/* SizeTracker::track (src/KmerSpectrum.h:879-894) is called before every k-mer: the thresholds this call's reads pass, each at
+		 * the t-th raw k-mer of some read; the walk of those reads (sk_track_boundary_kernel) gives the ordinal and the good k-mers */
+		std::vector<SkTrackRec> recs(n);
+		HIPCHK(h, hipMemcpyAsync(recs.data(), h->trk, n * sizeof(SkTrackRec), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+		std::vector<SkBoundary> bd; std::vector<uint64_t> good_before;
+		const bool walkable = (dp.sub_wnb | dp.sub_snb) == 0;      /* (a subtracting reference decides per k-mer what is raw: read ends there) */
+		for (uint64_t r = 0; r < n; r++) {
+			while ((uint64_t)h->trk_next <= h->trk_raw + recs[r].raw) {
+				SkBoundary b; b.read = r; b.t = (uint32_t)((uint64_t)h->trk_next - h->trk_raw); b.good = 0; b.ordinal = 0;
+				if (!walkable) { b.t = recs[r].raw; b.good = recs[r].good; b.ordinal = recs[r].end_ordinal; }
+				bd.push_back(b); good_before.push_back(h->trk_good);
+				h->trk_snap_raw.push_back(walkable ? (uint64_t)h->trk_next : h->trk_raw + recs[r].raw);
+				h->trk_next = (long)((double)h->trk_next * 1.05);
+				if (!walkable) break;      /* one element per read end */
+			}
+			if (!walkable) while ((uint64_t)h->trk_next <= h->trk_raw + recs[r].raw) h->trk_next = (long)((double)h->trk_next * 1.05);
+			h->trk_raw += recs[r].raw; h->trk_good += recs[r].good;
+		}
+		if (h->trk_bounds.size() + bd.size() > SK_TRACK_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "size tracker: more than 512 elements");
+		if (!bd.empty() && walkable) {
+			SkBoundary *dbd = nullptr;
+			HIPCHK(h, hipMalloc((void **)&dbd, bd.size() * sizeof(SkBoundary)));
+			hipError_t e = hipMemcpyAsync(dbd, bd.data(), bd.size() * sizeof(SkBoundary), hipMemcpyHostToDevice, h->stream);
+			if (e == hipSuccess) {
+				ReadsView rv = rvAll; rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
+				hipLaunchKernelGGL(sk_track_boundary_kernel<W>, dim3((unsigned)((bd.size() + 63) / 64)), dim3(64), 0, h->stream, rv, dp, dbd, (uint32_t)bd.size());
+				e = hipGetLastError();
+			}
+			if (e == hipSuccess) e = hipMemcpyAsync(bd.data(), dbd, bd.size() * sizeof(SkBoundary), hipMemcpyDeviceToHost, h->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+			hipFree(dbd);
+			if (e != hipSuccess) return fail(h, KMR_ERR_HIP, std::string("size tracker boundaries: ") + hipGetErrorString(e));
+		}
+		for (size_t i = 0; i < bd.size(); i++) { h->trk_bounds.push_back(bd[i].ordinal); h->trk_snap_good.push_back(good_before[i] + bd[i].good); }
+	}
 	return 0;
 }
 int add_reads_superkmer(kmr_handle *h, const ReadsView &rv, uint64_t total_bases) {
@@ -1662,15 +1698,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	SkTrackView tv; tv.bounds = nullptr; tv.n = 0; tv.d_unique = tv.d_single = nullptr;
 	const bool tracking = h->cfg.size_tracker != 0;
 	if (tracking) {
-		std::vector<SkTrackRec> recs(h->trk_n);
-		if (h->trk_n) HIPCHK(h, hipMemcpy(recs.data(), h->trk, h->trk_n * sizeof(SkTrackRec), hipMemcpyDeviceToHost));
-		long nextToTrack = 128; uint64_t raw = 0, good = 0; unsigned long long endmax = 0;
-		for (const SkTrackRec &r : recs) {
-			raw += r.raw; good += r.good; endmax = std::max(endmax, r.end_ordinal);
-			if ((long)raw < nextToTrack) continue;
-			bounds.push_back(endmax); snap_raw.push_back(raw); snap_good.push_back(good);
-			nextToTrack = (long)((double)nextToTrack * 1.05);
-		}
+		bounds = h->trk_bounds; snap_raw = h->trk_snap_raw; snap_good = h->trk_snap_good;
 		if (bounds.size() > SK_TRACK_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "size tracker: more than 512 elements");
 		unsigned long long *db = nullptr; unsigned int *dd = nullptr;
 		rc = arena_get(h, &db, bounds.size() + 1); if (rc) return rc;
@@ -1971,6 +1999,7 @@ int kmr_reset(kmr_handle *h) {
 	memset(&h->stats, 0, sizeof(h->stats));
 	h->occupied = h->pending_kmers = 0; h->stream_base = 0; h->reads = 0; h->subtracted = 0; h->xc_job_bases = 0; h->xc_bytes_to_peers = 0;
 	h->trk_n = 0; h->trk_elems.clear();
+	h->trk_next = 128; h->trk_raw = h->trk_good = 0; h->trk_bounds.clear(); h->trk_snap_raw.clear(); h->trk_snap_good.clear();
 	h->finalized = false; h->map_gen++; h->has_singletons = h->cfg.separate_singletons != 0;
 	return KMR_OK;
 }

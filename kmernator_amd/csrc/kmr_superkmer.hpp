@@ -71,6 +71,54 @@ struct SkParams {
 	const double *Pk;      /* 256 entries: P[c] multiplied k times in sequence, the weight of a window of k equal qualities */
 };
 
+/* Size history at k-mer granularity (SizeTracker::track before every append, src/KmerSpectrum.h:879-894,1574-1581): the element
+ * taken when rawKmers reaches a threshold holds the counters after exactly that many raw k-mers, i.e. somewhere inside a read.  For
+ * every (read, t) pair -- the threshold falls on the t-th raw k-mer of that read -- one thread walks the read as buildWeightedKmers
+ * does (src/KmerReadUtils.h:176-248: the same products, quotients and restarts, in the same order) and reports the stream ordinal
+ * behind that k-mer and how many of the read's first t raw k-mers were good. */
+struct SkBoundary { uint64_t read; uint32_t t, good; unsigned long long ordinal; };
+template <int W>
+__global__ __launch_bounds__(64)
+void sk_track_boundary_kernel(ReadsView rv, DevParams p, SkBoundary *bd, uint32_t n_bd) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_bd) return;
+	const uint64_t r = bd[i].read, b0 = rv.offsets[r], L = rv.offsets[r + 1] - b0;
+	const uint32_t k = p.k, target = bd[i].t;
+	const uint8_t *bs = rv.bases + b0, *qs = rv.quals ? rv.quals + b0 : nullptr;
+	const bool isRef = !qs || (L > 0 && qs[0] == 127);
+	const bool filt = p.subsample > 1 || p.num_parts > 1 || p.world > 1;
+	Roller<W> roll; roll.init(k);
+	double w = 0.0;
+	uint32_t raw = 0, good = 0, nN = 0;
+	unsigned long long ord = rv.stream_base + b0 + L;
+	for (uint64_t j = 0; j < L; j++) {
+		const uint32_t code = base_code(bs[j]);
+		nN += code >> 2;
+		if (j >= k) nN -= base_code(bs[j - k]) >> 2;
+		if (filt) roll.push(code & 3u);
+		if (j + 1 < k) continue;
+		const uint64_t x = j + 1 - k;                                    /* k-mer index */
+		if (isRef) w = 1.0;
+		else if (x % 1024 == 0 || w == 0.0) { w = 1.0; for (uint32_t jj = 0; jj < k; jj++) w *= p.P[qs[x + jj]]; }
+		else w *= p.P[qs[x + k - 1]] / p.P[qs[x - 1]];
+		if (nN) w = 0.0;
+		bool mine = true;
+		if (filt) {
+			const Key<W> kf = roll.getFwd(), kr = roll.getRc();
+			const Key<W> canon = key_le<W>(kf, kr) ? kf : kr;
+			const uint64_t hash = key_hash<W>(canon, p.kb);
+			if (p.subsample > 1 && hash % p.subsample != 0) mine = false;
+			if (p.world > 1 && distributed_thread_id(hash, p.world) != p.rank) mine = false;
+			if (p.num_parts > 1 && distributed_thread_id(hash, p.num_parts) != p.part_idx) mine = false;
+		}
+		if (!mine) continue;
+		raw++;
+		if ((float)w > p.min_weight) good++;
+		if (raw == target) { ord = rv.stream_base + b0 + x + 1; break; }
+	}
+	bd[i].good = good; bd[i].ordinal = ord;
+}
+
 /* Record, in 16-byte granules:
  *   granule 0   { ordinal low 32 | ordinal bits 32..39, n << 8, uniform << 16, granules << 17 | minimizer hash | weight (f32 bits) }
  *   granules    the run's n + k - 1 bases, 64 per granule, first base in the top two bits of the first dword

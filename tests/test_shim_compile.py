@@ -73,7 +73,7 @@ def test_shim_demo_runs_the_filterreads_stanza(k, fq, start):
     assert got == exp
     st = o.stats()
     assert "raw %d good %d unique %d singleton %d weak %d" % (st["raw_kmers"], st["raw_good_kmers"], st["unique_kmers"], st["singleton_kmers"], st["weak_entries"]) in p.stderr
-    # the size history the reference object now holds (FilterReads.cpp:141-147 writes it out): the oracle's read-boundary history
+    # the size history the reference object now holds (FilterReads.cpp:141-147 writes it out): the oracle's per-k-mer history, the reference's own
     hist = [tuple(int(v) for v in line.split("\t")[1:]) for line in p.stderr.splitlines() if line.startswith("history\t")]
-    want = [tuple(int(v) for v in e) for e in o.size_tracker(per_read=True, force_last=True)]
+    want = [tuple(int(v) for v in e) for e in o.size_tracker(per_read=False, force_last=True)]
     assert hist == want and len(hist) > 100

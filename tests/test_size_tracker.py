@@ -1,10 +1,11 @@
 """f3: KmerSpectrum::SizeTracker (src/KmerSpectrum.h:812-900, trackSpectrum :1574-1581, the --size-history-file of FilterReads).
 
-The reference samples its four counters before every k-mer it appends; the product applies the same rule after every read.
-The oracle keeps both histories.  No fixture of the reference holds a size history (its test scripts do not write one), so what pins
-the restatement is the source text; what is tested: the rule's arithmetic (thresholds 128, 134, 140 ... as `long *= 1.05`
-truncates), that the per-read history is the per-k-mer one sampled at most one read later, and -- on the GPU -- that the product's
-history equals the oracle's per-read history element for element."""
+The reference samples its four counters before every k-mer it appends, and so does the product (round 3: the thresholds are located
+at the exact k-mer inside a read; round 2 applied the rule at read ends).  The oracle keeps both histories.  No fixture of the
+reference holds a size history (its test scripts do not write one), so what pins the restatement is the source text; what is
+tested: the rule's arithmetic (thresholds 128, 134, 140 ... as `long *= 1.05` truncates), that the per-read history is the
+per-k-mer one sampled at most one read later, and -- on the GPU -- that the product's history equals the oracle's PER-K-MER
+history, the reference's own, element for element (with sub-sampling, without a singleton map, over several calls, long reads)."""
 import numpy as np
 import pytest
 
@@ -77,7 +78,7 @@ def _reduce_worker(rank, world, port, tmp):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,sub,sing", [(31, 1, 1), (51, 1, 1), (25, 3, 1), (31, 1, 0)])
-def test_product_history_equals_the_oracles_per_read_history(k, sub, sing):
+def test_product_history_equals_the_oracles_per_kmer_history(k, sub, sing):
     import kmernator_amd as ka
     rb = synth_reads(30000, read_len=150, genome_len=200000, seed=k, quality="noisy", n_rate=0.002)
     kw = dict(estimated_raw_kmers=30000 * (150 - k + 1), kmer_subsample=sub, separate_singletons=sing)
@@ -91,7 +92,7 @@ def test_product_history_equals_the_oracles_per_read_history(k, sub, sing):
     o.finalize(2)
     p.finalize(2)
     for force in (False, True):
-        want = o.size_tracker(per_read=True, force_last=force)
+        want = o.size_tracker(per_read=False, force_last=force)
         got = p.getSizeTracker(force_last=force).elements
         assert got.shape == want.shape and len(want) > 150
         assert np.array_equal(got, want), np.argwhere(got != want)[:5]
@@ -115,7 +116,7 @@ def test_long_reads_and_the_phix_fixture():
         p.buildKmerSpectrum(rb.bases, rb.quals, rb.offsets)
         o.finalize(2)
         p.finalize(2)
-        assert np.array_equal(p.getSizeTracker().elements, o.size_tracker())
+        assert np.array_equal(p.getSizeTracker().elements, o.size_tracker(per_read=False))
 
 
 @pytest.mark.gpu
