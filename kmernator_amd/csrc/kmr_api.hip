@@ -1247,7 +1247,7 @@ template <int W> int binned_buckets_t(kmr_handle *h, uint64_t wslots, uint64_t w
 		rc2 = reserve_bytes(h, (void **)&wm.vals, wm.c_vals, 12ull * wn); if (rc2) return rc2;
 		auto gk = bb_group_kernel<W>;
 		HIPCHK(h, hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bb_group_smem_bytes<W>()));
-		hipLaunchKernelGGL(gk, dim3((unsigned)std::min<uint64_t>(groups, (uint64_t)num_cus(h) * 8)), dim3(BB_THREADS), bb_group_smem_bytes<W>(), h->stream, entries, wm.keys, wm.vals, gs, gc, groups, g, h->hkb, nb, wm.start, wn, h->derr);
+		hipLaunchKernelGGL(gk, dim3((unsigned)std::min<uint64_t>(groups, (uint64_t)num_cus(h) * 8)), dim3(BB_GROUP_THREADS), bb_group_smem_bytes<W>(), h->stream, entries, wm.keys, wm.vals, gs, gc, groups, g, h->hkb, nb, wm.start, wn, h->derr);
 		HIPCHK(h, hipGetLastError());
 		return 0;
 	};

@@ -28,8 +28,9 @@ namespace kmr {
 /* kmr_sort.hip: (u64, u32) pairs sorted by key on the device (rocPRIM); tmp == nullptr returns the scratch size in *tmp_bytes */
 int sort_pairs_u64_u32(void *tmp, size_t *tmp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned int *vals_in, unsigned int *vals_out, size_t n, hipStream_t stream);
 
-static const int BB_TILE = 4096;            /* entries per tile: a tile never spans two segments                       */
-static const int BB_THREADS = 256;
+static const int BB_TILE = 8192;            /* entries per tile: a tile never spans two segments (8192 over 256 bins: runs of 32 entries = 512 bytes) */
+static const int BB_THREADS = 512;
+static const int BB_GROUP_THREADS = 256;    /* threads of a bb_group_kernel block */
 static const int BB_PER_THREAD = BB_TILE / BB_THREADS;
 static const int BB_MAX_BITS = 10;          /* bins per level <= 1024                                                   */
 static const int BB_MAX_GROUP_BITS = 8;     /* buckets per group <= 256                                                 */
@@ -184,7 +185,7 @@ void bb_scatter_kernel(BbInput in, uint32_t shift, uint32_t bits, uint32_t kb, u
 	}
 }
 
-static const int BB_GROUP_PER_THREAD = (BB_GROUP_CAP + BB_THREADS - 1) / BB_THREADS;
+static const int BB_GROUP_PER_THREAD = (BB_GROUP_CAP + BB_GROUP_THREADS - 1) / BB_GROUP_THREADS;
 template <int W> __host__ __device__ constexpr size_t bb_group_smem_bytes() { return (size_t)BB_GROUP_CAP * (8 * W + 8 + 2 + 2); }
 
 /* One block per group of 2^gbits neighbouring buckets: its entries lie at [gstart[G], gstart[G] + gcount[G]) of `entries` and go
@@ -192,7 +193,7 @@ template <int W> __host__ __device__ constexpr size_t bb_group_smem_bytes() { re
  * registers while the buckets are counted and scanned, then files them into LDS bucket by bucket, so that the rank loop of an
  * entry walks the consecutive keys of its bucket (independent LDS reads, no index in between). */
 template <int W>
-__global__ __launch_bounds__(BB_THREADS)
+__global__ __launch_bounds__(BB_GROUP_THREADS)
 void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, const uint64_t *gstart, const uint32_t *gcount, uint64_t n_groups, uint32_t gbits, uint32_t kb, uint64_t nb,
                      uint64_t *start, uint64_t n_total, uint32_t *err) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t gsm[];
@@ -200,7 +201,7 @@ void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, co
 	uint64_t *svalw = skeys + (size_t)BB_GROUP_CAP * W;                  /* [CAP] value words, same order   */
 	uint16_t *sbucket = (uint16_t *)(svalw + BB_GROUP_CAP);              /* bucket (inside the group) of the entry at a position */
 	uint16_t *final_ = sbucket + BB_GROUP_CAP;                           /* position (in bucket order) of the entry that ends up at a place */
-	__shared__ uint32_t bcnt[1 << BB_MAX_GROUP_BITS], bstart[(1 << BB_MAX_GROUP_BITS) + 1], bscan[BB_THREADS / 64];
+	__shared__ uint32_t bcnt[1 << BB_MAX_GROUP_BITS], bstart[(1 << BB_MAX_GROUP_BITS) + 1], bscan[BB_GROUP_THREADS / 64];
 	const int t = threadIdx.x;
 	const uint32_t nbk = 1u << gbits;
 	for (uint64_t G = blockIdx.x; G < n_groups; G += gridDim.x) {
@@ -213,13 +214,13 @@ void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, co
 		uint64_t ew[BB_GROUP_PER_THREAD][W + 1]; uint32_t lb[BB_GROUP_PER_THREAD];
 #pragma unroll
 		for (int u = 0; u < BB_GROUP_PER_THREAD; u++) {
-			const uint32_t i = (uint32_t)u * BB_THREADS + t;
+			const uint32_t i = (uint32_t)u * BB_GROUP_THREADS + t;
 			lb[u] = 0xffffffffu;
 			if (i < n) bb_load_entry<W>(entries, base + i, ew[u]);
 		}
 #pragma unroll
 		for (int u = 0; u < BB_GROUP_PER_THREAD; u++) {
-			const uint32_t i = (uint32_t)u * BB_THREADS + t;
+			const uint32_t i = (uint32_t)u * BB_GROUP_THREADS + t;
 			if (i >= n) continue;
 			Key<W> key;
 #pragma unroll
@@ -252,7 +253,7 @@ void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, co
 			sbucket[pos] = (uint16_t)lb[u];
 		}
 		__syncthreads();
-		for (uint32_t p = t; p < n; p += BB_THREADS) {
+		for (uint32_t p = t; p < n; p += BB_GROUP_THREADS) {
 			const uint32_t b = sbucket[p];
 			const uint32_t s = bstart[b], e = bstart[b + 1];
 			Key<W> mine;
@@ -269,7 +270,7 @@ void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, co
 			final_[s + rank] = (uint16_t)p;
 		}
 		__syncthreads();
-		for (uint32_t p = t; p < n; p += BB_THREADS) {
+		for (uint32_t p = t; p < n; p += BB_GROUP_THREADS) {
 			const uint32_t i = final_[p];
 #pragma unroll
 			for (int q = 0; q < W; q++) keys[(base + p) * W + q] = skeys[(size_t)i * W + q];
