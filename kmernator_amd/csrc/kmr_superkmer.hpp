@@ -1230,7 +1230,7 @@ static const int SKC_WAVES = KMR_SKC_WAVES, SKC_THREADS = SKC_WAVES * 64;      /
 static const unsigned long long SK_OSLAB = 2048;      /* entries a wavefront reserves at a time in the count pass's output */
 
 template <int W, int LOG2S, bool TRACK = false>
-__global__ __launch_bounds__(SKC_THREADS, (W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 2 : 1))
+__global__ __launch_bounds__(SKC_THREADS, (W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 3 : 1))
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
                      CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv, SkLong<W> lg) {
 	constexpr int S = 1 << LOG2S;
@@ -1414,11 +1414,15 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 							if (4 * q < NWD) nwin[4 * q] = v.x; if (4 * q + 1 < NWD) nwin[4 * q + 1] = v.y; if (4 * q + 2 < NWD) nwin[4 * q + 2] = v.z; if (4 * q + 3 < NWD) nwin[4 * q + 3] = v.w;
 						}
 					};
-					/* next k-mer: canonical key, strand, table slot, weight */
-					Key<W> key; bool fwd = true; uint64_t h = 0; uint32_t slot = 0, step = 1; bool mine = false; uint32_t wnext = 0;
+					/* a k-mer on its way to the table: canonical key, strand, home slot and probe step, weight, stream ordinal.  Two of them
+					 * exist per lane -- the one being inserted and the one being made -- and the loop below alternates their roles instead of
+					 * copying one into the other every step (the copies were a quarter of the loop's vector instructions) */
+					struct KState { Key<W> key; bool fwd, mine; uint32_t slot, step, w; uint64_t ord; };
+					KState kA, kB;
 #pragma unroll
-					for (int wi = 0; wi < W; wi++) key.w[wi] = 0;
-					auto prepare = [&]() {
+					for (int wi = 0; wi < W; wi++) { kA.key.w[wi] = 0; kB.key.w[wi] = 0; }
+					kA.fwd = kB.fwd = true; kA.mine = kB.mine = false; kA.slot = kB.slot = 0; kA.step = kB.step = 1; kA.w = kB.w = 0; kA.ord = kB.ord = 0;
+					auto prepare = [&](KState &st) {      /* the k-mer at (record rs, index j): window bit offset sb */
 						Key<W> kf;
 						const bool up = sb >= 32u; const uint32_t r = sb & 31u;
 #pragma unroll
@@ -1435,29 +1439,31 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 							else if (kbits < lo + 64u) kf.w[wi] &= ~0ull << (lo + 64u - kbits);
 						}
 						const Key<W> kr = key_revcomp<W>(kf, k);
-						fwd = key_le<W>(kf, kr);
-						key = fwd ? kf : kr;
-						h = slot_hash<W>(key.w);
-						slot = (uint32_t)(h >> (64 - LOG2S));
+						st.fwd = key_le<W>(kf, kr);
+						st.key = st.fwd ? kf : kr;
+						const uint64_t h = slot_hash<W>(st.key.w);
+						st.slot = (uint32_t)(h >> (64 - LOG2S));
 						/* a key that does not find its home slot free (or its own) goes on in steps of an odd number taken from other bits of its
 						 * hash: with steps of one the occupied slots grow into runs, and the wavefront waits for the longest probe sequence
 						 * among its 64 lanes every time (one claim attempt and one LDS round trip per step) */
-						step = ((uint32_t)(h >> (64 - 2 * LOG2S)) & (uint32_t)(S - 1)) | 1u;
-						mine = ((uint32_t)(h >> 20) & subMask) == val;
+						st.step = ((uint32_t)(h >> (64 - 2 * LOG2S)) & (uint32_t)(S - 1)) | 1u;
+						st.mine = ((uint32_t)(h >> 20) & subMask) == val;
+						st.w = uniformW ? hw : ww[j];
+						st.ord = ord0 + j;
 					};
-					if (left) { enter_record(); seed_window(); wnext = uniformW ? hw : ww[j]; request_next_record(); prepare(); }
+					if (left) { enter_record(); seed_window(); request_next_record(); prepare(kA); }
 					uint32_t dbgSink = 0;
-					for (uint32_t it = 0; it < Lk; it++) {
+					/* one step: the current k-mer's claim is sent off, the lane's next k-mer is made (two bits further in the window, or the first
+					 * one of the next record), then the claim is looked at and the three sums go to the slot */
+					auto step_one = [&](KState &cur, KState &nxt) {
 						if (left) {
-							const Key<W> ckey = key; const bool cfwd = fwd, cmine = mine; uint32_t s = slot; const uint32_t cstep = step;
-							const float wa = __uint_as_float(wnext);
-							const uint64_t cord = ord0 + j;
-							/* the claim of the current k-mer's home slot is on its way while the next k-mer is made (one-word keys: a compare-and-swap
-							 * against "empty" returns what the slot holds whether it wins or not, so the slot is not read first) */
+							uint32_t s = cur.slot;
+							const float wa = __uint_as_float(cur.w);
+							/* (one-word keys: a compare-and-swap against "empty" returns what the slot holds whether it wins or not, so the slot is
+							 * not read first) */
 							unsigned long long old = EMPTY_KEY;
-							const bool tableOn = !SK_DBG(dbgFlags, 1) && cmine;
-							if constexpr (W == 1) { if (tableOn) old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)ckey.w[0]); }
-							/* the next k-mer of this lane: two bits further in the window, or the first one of the next record */
+							const bool tableOn = !SK_DBG(dbgFlags, 1) && cur.mine;
+							if constexpr (W == 1) { if (tableOn) old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)cur.key.w[0]); }
 							j++; left--; sb += 2;
 							if (left) {
 								if (j >= n) {
@@ -1467,29 +1473,28 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 									enter_record();
 									request_next_record();
 								} else if (sb > 62u) seed_window();
-								wnext = uniformW ? hw : ww[j];
-								prepare();
+								prepare(nxt);
 							}
-							if (SK_DBG(dbgFlags, 1)) { dbgSink ^= (uint32_t)ckey.w[0] ^ s; }
-							else if (cmine) {
+							if (SK_DBG(dbgFlags, 1)) { dbgSink ^= (uint32_t)cur.key.w[0] ^ s; }
+							else if (cur.mine) {
 								bool placed = false;
 								if constexpr (W == 1) {
 									if (old == EMPTY_KEY) { claimedHere++; placed = true; }
-									else if (old == ckey.w[0]) placed = true;
-									else s = (s + cstep) & (S - 1);
+									else if (old == cur.key.w[0]) placed = true;
+									else s = (s + cur.step) & (S - 1);
 								}
 								for (int probe = 0; probe < S && !placed; probe++) {
 									if constexpr (W == 1) {
-										const unsigned long long o2 = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)ckey.w[0]);
+										const unsigned long long o2 = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)cur.key.w[0]);
 										if (o2 == EMPTY_KEY) { claimedHere++; placed = true; break; }
-										if (o2 == ckey.w[0]) { placed = true; break; }
+										if (o2 == cur.key.w[0]) { placed = true; break; }
 									} else {
 										uint32_t st = __hip_atomic_load(&tstate[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 										if (st == 0) {
 											const uint32_t old2 = atomicCAS(&tstate[s], 0u, 1u);
 											if (old2 == 0) {
 #pragma unroll
-												for (int qq = 0; qq < W; qq++) tkeys[(size_t)s * W + qq] = ckey.w[qq];
+												for (int qq = 0; qq < W; qq++) tkeys[(size_t)s * W + qq] = cur.key.w[qq];
 												__hip_atomic_store(&tstate[s], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 												claimedHere++;
 												placed = true; break;
@@ -1499,16 +1504,16 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 										if (st == 1) { probe--; continue; }      /* writer publishes unconditionally: re-poll the same slot */
 										bool eq = true;
 #pragma unroll
-										for (int qq = 0; qq < W; qq++) eq = eq && (tkeys[(size_t)s * W + qq] == ckey.w[qq]);
+										for (int qq = 0; qq < W; qq++) eq = eq && (tkeys[(size_t)s * W + qq] == cur.key.w[qq]);
 										if (eq) { placed = true; break; }
 									}
-									s = (s + cstep) & (S - 1);
+									s = (s + cur.step) & (S - 1);
 								}
 								if (!placed) s_overflow[fl] = 1;      /* table full */
 								else {
-									atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(cfwd ? 1 : 0) << 32));
+									atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(cur.fwd ? 1 : 0) << 32));
 									atomicAdd(&twsum[s], (double)wa);
-									const unsigned long long fp = first_pack(cord, cfwd, wa);
+									const unsigned long long fp = first_pack(cur.ord, cur.fwd, wa);
 									if (TRACK) {      /* the two smallest: whichever of (old first, this one) is larger is a candidate for second */
 										const unsigned long long was = atomicMin(&tfirst[s], fp);
 										const unsigned long long cand = was > fp ? was : fp;
@@ -1517,7 +1522,8 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 								}
 							}
 						}
-					}
+					};
+					for (uint32_t it = 0; it < Lk; it += 2) { step_one(kA, kB); step_one(kB, kA); }
 					if (SK_DBG(dbgFlags, 1) && dbgSink == 0x12345u) s_overflow[fl] = 2;
 					claimedHere = (uint32_t)wave_sum((unsigned long long)claimedHere);
 					if (lane == 0 && claimedHere) atomicAdd(&s_claimed[fl], claimedHere);
