@@ -351,25 +351,31 @@ def main():
             weak = st["weak_entries"]
             if mode == "super-k-mer lists":
                 sk_bytes = (3.8 if args.quality == "flat" else 9.4) * raw_local      # a 32-byte record per ~8.5 k-mers (+ 4 bytes per k-mer when the weights differ)
-                per = [("sk_extract_kernel (extract + weight chain + minimizer + list scatter)", 2, raw_local * 2.0 * READ_LEN / kmers_per_read + sk_bytes),
-                       ("sk_count_kernel (expand + count in LDS)", 5, sk_bytes + weak * 20.0),
-                       ("bucket scan + entry_scatter_kernel + sort_buckets_kernel", 6, weak * 60.0)]
+                lean = args.quality == "flat"      # one quality character: the launch goes to sk_extract_lean_kernel (bases only are read)
+                per = [("sk_extract_lean_kernel (bases only: minimizer + runs + list scatter)" if lean else "sk_extract_kernel (extract + weight chain + minimizer + list scatter)", 2,
+                        raw_local * (1.0 if lean else 2.0) * READ_LEN / kmers_per_read + sk_bytes,
+                        "scattered device atomics: one returning 64-bit add per record, ~1.8e10/s chip-wide" if lean else "vector-instruction issue at 1.5 wavefronts per SIMD (LDS: 24 KB per wavefront)"),
+                       ("sk_count_kernel (expand + count in LDS)", 5, sk_bytes + weak * 16.0,
+                        "vector-instruction issue (VALU busy ~65 % of a SIMD's cycles at 4 wavefronts per SIMD; LDS caps the occupancy)"),
+                       ("bb_hist + bb_scatter (x levels) + bb_group_kernel (radix partition by bucket, per-group sort)", 6, weak * (16.0 * 5 + 20.0),
+                        "HBM / L2 transactions")]
             else:
                 rec = 8 * ((kb + 7) // 8) + 8
-                per = [("extract_kernel<LinearOp>", 2, raw_local * (2.0 * READ_LEN / kmers_per_read + rec)),
-                       ("partition_direct_kernel<level 1>", 3, raw_local * 2.0 * rec),
-                       ("partition_direct_kernel<level 2>", 4, raw_local * 2.0 * rec),
-                       ("count_kernel", 5, raw_local * rec + weak * 20.0),
-                       ("bucket scan + entry_scatter_kernel + sort_buckets_kernel", 6, weak * 60.0)]
+                per = [("extract_kernel<LinearOp>", 2, raw_local * (2.0 * READ_LEN / kmers_per_read + rec), "HBM write stream"),
+                       ("partition_direct_kernel<level 1>", 3, raw_local * 2.0 * rec, "scattered 16-byte stores"),
+                       ("partition_direct_kernel<level 2>", 4, raw_local * 2.0 * rec, "scattered 16-byte stores"),
+                       ("count_kernel", 5, raw_local * rec + weak * 20.0, "LDS latency"),
+                       ("bucket scan + entry_scatter_kernel + sort_buckets_kernel", 6, weak * 60.0, "HBM")]
             kernels = []
-            for name, grp, nbytes in per:
+            for name, grp, nbytes, limiter in per:
                 ms, launches = ktimes[grp]
                 if launches == 0:
                     continue
                 ms_step = ms / max(1, args.steps)
                 kernels.append({"name": name, "ms_per_step": ms_step, "launches_per_step": launches // max(1, args.steps),
                                 "ms_per_launch": ms / launches, "bytes_per_step": nbytes,
-                                "achieved_GBps": nbytes / (ms_step / 1e3) / 1e9, "frac": nbytes / (ms_step / 1e3) / HBM_PEAK})
+                                "achieved_GBps": nbytes / (ms_step / 1e3) / 1e9, "frac": nbytes / (ms_step / 1e3) / HBM_PEAK, "limiter": limiter})
+            out["roofline"]["limiter_source"] = "profiles/r03_sq_counters.json (SQ / LDS / L2 counters per kernel, tools/sq_counters.sh)"
             out["roofline"]["kernels"] = kernels
             if kernels:
                 dom = max(kernels, key=lambda k: k["ms_per_step"])
@@ -379,14 +385,15 @@ def main():
         if exchange:
             out["exchange"] = {k: (v / max(1, args.steps) if isinstance(v, (int, float)) else v) for k, v in xstats.items()}
         # HBM bytes from the PMC counters: bench.py cannot run rocprofv3 on itself, so the committed summary of the same command
-        # (tools/pmc.sh -> profiles/r02_pmc_traffic.json) is quoted when it describes this workload and build mode
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            if tj.get("build_mode") == mode and n_reads == 10_000_000 and world == 1 and args.quality == tj.get("quality", "flat"):
-                out["roofline"]["traffic"] = tj["hot_path_total_GB_per_step"] * 1e9
-                out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic.json (bytes per step, FETCH_SIZE x2 corrected)"
-        except Exception:
-            pass
+        # (tools/pmc.sh -> profiles/r03_pmc_traffic.json) is quoted when it describes this workload and build mode
+        for tf in ("r03_pmc_traffic.json", "r03_pmc_traffic_noisy.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+                if tj.get("build_mode") == mode and n_reads == 10_000_000 and world == 1 and args.quality == tj.get("quality", "flat"):
+                    out["roofline"]["traffic"] = tj["hot_path_total_GB_per_step"] * 1e9
+                    out["roofline"]["traffic_source"] = "profiles/%s (bytes per step, FETCH_SIZE x2 corrected; measured at commit %s)" % (tf, tj.get("commit", "?"))
+            except Exception:
+                pass
         if h2d:
             out.update({"value_incl_h2d": h2d["value_incl_h2d"], "h2d_ms": h2d["h2d_ms"]})
             out["h2d"] = h2d

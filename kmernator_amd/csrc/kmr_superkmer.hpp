@@ -1227,6 +1227,11 @@ __host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 <
 #define KMR_SKC_WAVES 4
 #endif
 static const int SKC_WAVES = KMR_SKC_WAVES, SKC_THREADS = SKC_WAVES * 64;      /* wavefronts of a count block (they share one table) */
+/* Multi-word keys whose last word ends in pad bits (k not a multiple of 32) are claimed like one-word keys: a compare-and-swap on the
+ * FIRST word; the winner then writes the other words, the last one last, and whoever finds its own first word in a slot reads the last
+ * word -- SK_KEY_PENDING (all ones: no padded word looks like that) until the winner has written it -- and compares.  One LDS round
+ * trip per probe instead of two (state word, then the key). */
+static const unsigned long long SK_KEY_PENDING = ~0ull;
 static const unsigned long long SK_OSLAB = 2048;      /* entries a wavefront reserves at a time in the count pass's output */
 
 template <int W, int LOG2S, bool TRACK = false>
@@ -1261,7 +1266,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	unsigned long long wpos = 0, wend = 0, spos = 0, send = 0;
 	bool outFull = false;
 	if (t == 0) { s_claimed[0] = s_claimed[1] = 0; s_overflow[0] = s_overflow[1] = 0; s_sp = 0; }
-	for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
+	for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)i * W + W - 1] = SK_KEY_PENDING; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
 	lds_barrier();
 	/* classify() of kmr_kernels.hpp folded into launch-wide scalars: a count of one goes to class singC when singletons are separate,
 	 * any other count below weakMin is dropped */
@@ -1317,6 +1322,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 			 * bits `bits` equal val: sub-passes of a split list) */
 			auto insert_pass = [&](const uint32_t bits, const uint32_t val, const bool firstPass) {
 				const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
+				const bool padded = W > 1 && (k & 31u) != 0;      /* the last key word ends in pad bits: the claim protocol of SK_KEY_PENDING */
 				uint4 *wstage = stage + wv * SK_CHUNK_G;
 				uint8_t *wrecOf = recOf + wv * 64;
 				uint4 cur = make_uint4(0, 0, 0, 0); uint32_t curCount = 0;
@@ -1463,7 +1469,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 							 * not read first) */
 							unsigned long long old = EMPTY_KEY;
 							const bool tableOn = !SK_DBG(dbgFlags, 1) && cur.mine;
-							if constexpr (W == 1) { if (tableOn) old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)cur.key.w[0]); }
+							if (W == 1 || padded) { if (tableOn) old = atomicCAS((unsigned long long *)&tkeys[(size_t)s * W], (unsigned long long)EMPTY_KEY, (unsigned long long)cur.key.w[0]); }
 							j++; left--; sb += 2;
 							if (left) {
 								if (j >= n) {
@@ -1483,7 +1489,41 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 									else if (old == cur.key.w[0]) placed = true;
 									else s = (s + cur.step) & (S - 1);
 								}
-								for (int probe = 0; probe < S && !placed; probe++) {
+								if (W > 1 && padded) {
+									/* Every round: claim attempt, then ALL of this wavefront's winners publish their remaining words, then the lanes that met
+									 * their own first word look at the last one.  Nobody leaves the loop alone (the exit is wave-uniform) and nobody waits
+									 * inside a round: a lane may only ever poll for a winner in ANOTHER wavefront -- lanes of one wavefront that waited on each
+									 * other inside a divergent loop would depend on where the compiler places the winner's store. */
+									bool poll = false;
+									for (int probe = 0; probe < 8 * S; probe++) {
+										const bool active = !placed;
+										if (probe > 0 && active && !poll) old = atomicCAS((unsigned long long *)&tkeys[(size_t)s * W], (unsigned long long)EMPTY_KEY, (unsigned long long)cur.key.w[0]);
+										const bool won = active && !poll && old == EMPTY_KEY;
+										if (won) {
+#pragma unroll
+											for (int qq = 1; qq < W - 1; qq++) tkeys[(size_t)s * W + qq] = cur.key.w[qq];
+											__hip_atomic_store(&tkeys[(size_t)s * W + W - 1], cur.key.w[W - 1], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      /* the last word is the one waited for */
+											claimedHere++; placed = true;
+										}
+										sk_wave_lds_order();
+										if (active && !won) {
+											bool moveOn = true;
+											if (old == cur.key.w[0]) {
+												const unsigned long long last = __hip_atomic_load(&tkeys[(size_t)s * W + W - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+												if (last == SK_KEY_PENDING) { poll = true; moveOn = false; }      /* a winner in another wavefront is between its two writes */
+												else {
+													bool eq = last == cur.key.w[W - 1];
+#pragma unroll
+													for (int qq = 1; qq < W - 1; qq++) eq = eq && (tkeys[(size_t)s * W + qq] == cur.key.w[qq]);
+													if (eq) { placed = true; moveOn = false; }
+												}
+											}
+											if (moveOn) { poll = false; s = (s + cur.step) & (S - 1); }
+										}
+										if (!__any(!placed)) break;
+									}
+								}
+								for (int probe = 0; probe < S && !placed && !(W > 1 && padded); probe++) {
 									if constexpr (W == 1) {
 										const unsigned long long o2 = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)cur.key.w[0]);
 										if (o2 == EMPTY_KEY) { claimedHere++; placed = true; break; }
@@ -1646,11 +1686,11 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						bucket_count_add(out.singCount, bucket, cls == 2 && !outFull);
 						if (!outFull) { spos += cnt; keptS += lane == 0 ? cnt : 0u; }
 					}
-					if (used) { tkeys[(size_t)s * W] = EMPTY_KEY; tcnt[s] = 0; twsum[s] = 0.0; tfirst[s] = NO_FIRST; if (W > 1) tstate[s] = 0; if (TRACK) tsecond[s] = NO_FIRST; }
+					if (used) { tkeys[(size_t)s * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)s * W + W - 1] = SK_KEY_PENDING; tcnt[s] = 0; twsum[s] = 0.0; tfirst[s] = NO_FIRST; if (W > 1) tstate[s] = 0; if (TRACK) tsecond[s] = NO_FIRST; }
 				}
 			};
 			auto clear_table = [&]() {
-				for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
+				for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)i * W + W - 1] = SK_KEY_PENDING; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
 			};
 
 			insert_pass(0, 0, true);
