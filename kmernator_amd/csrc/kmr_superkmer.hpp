@@ -1262,6 +1262,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	if (TRACK) for (int i = t; i < 2 * (int)(SK_TRACK_MAX + 1); i += SKC_THREADS) trkU[i] = 0;
 	const uint32_t vw = 3;
 	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0, satK = 0, satS = 0;
+	unsigned long long uniqW = 0, singleW = 0;      /* wave-uniform: used slots and slots with a count of one, from ballots */
 	/* this wavefront's output slabs: [wpos, wend) of the weak entries, [spos, send) of the singletons */
 	unsigned long long wpos = 0, wend = 0, spos = 0, send = 0;
 	bool outFull = false;
@@ -1575,14 +1576,36 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 			/* ---- emit: this wavefront's quarter of the table -> entries of its output slabs (or the merge table / the size tracker's
 			 * difference arrays), every slot cleared behind it */
 			auto emit_pass = [&]() {
-#pragma unroll 1
+				/* Of a list's used slots only a few need more than a look at their count (C2: ~350 used, ~55 kept): the slots that do --
+				 * kept entries; every used slot for a piece of a long list or under the size tracker -- are collected first (their indices
+				 * go to this wavefront's quarter of the staging area, idle now), and the heavy part runs over them densely. */
+				uint16_t *wsel = (uint16_t *)(stage + wv * SK_CHUNK_G);
+				static_assert(WSLOTS * 2 <= (int)SK_CHUNK_G * 16, "the selected slots' indices live in one staging quarter");
+				uint32_t nsel = 0;
+				unsigned long long usedMask[WSLOTS / 64];
+				const unsigned long long below = (1ull << lane) - 1;
+#pragma unroll
 				for (int i = 0; i < WSLOTS / 64; i++) {
 					const int s = wv * WSLOTS + i * 64 + lane;
-					const unsigned long long cf = tcnt[s];
-					const uint32_t count = (uint32_t)cf;
+					const uint32_t count = (uint32_t)tcnt[s];
 					const bool used = count != 0;      /* every claim is followed by its own count */
-					if (!__any(used)) continue;
-					if (!itemMode) { uniq += used ? 1u : 0u; single += (used && count == 1) ? 1u : 0u; }      /* (item mode: a key may lie in several items' tables; sk_merge_emit_kernel counts) */
+					const unsigned long long um = __ballot(used);
+					usedMask[i] = um;
+					if (!itemMode) { uniqW += (uint32_t)__builtin_popcountll(um); singleW += (uint32_t)__builtin_popcountll(__ballot(count == 1)); }      /* (item mode: a key may lie in several items' tables; sk_merge_emit_kernel counts) */
+					uint32_t cls = !used ? 0u : ((count == 1 && singC != 3u) ? singC : (count < weakMin ? 0u : 1u));
+					if (SK_DBG(dbgFlags, 2)) cls = 0;
+					const bool need = (itemMode || TRACK) ? used : cls != 0;
+					const unsigned long long nm = __ballot(need);
+					if (need) wsel[nsel + (uint32_t)__builtin_popcountll(nm & below)] = (uint16_t)s;
+					nsel += (uint32_t)__builtin_popcountll(nm);
+				}
+				sk_wave_lds_order();
+#pragma unroll 1
+				for (uint32_t sb0 = 0; sb0 < nsel; sb0 += 64) {
+					const bool used = sb0 + (uint32_t)lane < nsel;
+					const int s = used ? (int)wsel[sb0 + lane] : wv * WSLOTS;
+					const unsigned long long cf = used ? tcnt[s] : 0ull;
+					const uint32_t count = (uint32_t)cf;
 					uint32_t cls = !used ? 0u : ((count == 1 && singC != 3u) ? singC : (count < weakMin ? 0u : 1u));
 					if (SK_DBG(dbgFlags, 2)) cls = 0;
 					Key<W> key;
@@ -1625,7 +1648,6 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						}
 					}
 					const unsigned long long mw = __ballot(cls == 1), ms = __ballot(cls == 2);
-					const unsigned long long below = (1ull << lane) - 1;
 					if (mw) {
 						const uint32_t cnt = (uint32_t)__builtin_popcountll(mw);
 						if (wpos + cnt > wend) {           /* the slab is full: its tail becomes a hole, a new one is taken */
@@ -1686,7 +1708,12 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						bucket_count_add(out.singCount, bucket, cls == 2 && !outFull);
 						if (!outFull) { spos += cnt; keptS += lane == 0 ? cnt : 0u; }
 					}
-					if (used) { tkeys[(size_t)s * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)s * W + W - 1] = SK_KEY_PENDING; tcnt[s] = 0; twsum[s] = 0.0; tfirst[s] = NO_FIRST; if (W > 1) tstate[s] = 0; if (TRACK) tsecond[s] = NO_FIRST; }
+				}
+				sk_wave_lds_order();
+#pragma unroll
+				for (int i = 0; i < WSLOTS / 64; i++) {
+					const int s = wv * WSLOTS + i * 64 + lane;
+					if ((usedMask[i] >> lane) & 1ull) { tkeys[(size_t)s * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)s * W + W - 1] = SK_KEY_PENDING; tcnt[s] = 0; twsum[s] = 0.0; tfirst[s] = NO_FIRST; if (W > 1) tstate[s] = 0; if (TRACK) tsecond[s] = NO_FIRST; }
 				}
 			};
 			auto clear_table = [&]() {
@@ -1737,7 +1764,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	/* the unused tails of this wavefront's slabs are holes */
 	for (unsigned long long e = wpos + lane; e < wend && e < out.wcap; e += 64) { if (out.wentries) out.wentries[e * (W + 1) + W] = 0; else out.wvals[e * vw] = 0; }
 	for (unsigned long long e = spos + lane; e < send && e < out.scap; e += 64) out.sweight[e] = 0;
-	uniq = wave_sum(uniq); single = wave_sum(single); satK = wave_sum(satK); satS = wave_sum(satS);
+	uniq = wave_sum(uniq) + uniqW; single = wave_sum(single) + singleW; satK = wave_sum(satK); satS = wave_sum(satS);
 	if (lane == 0) {
 		if (uniq) atomicAdd(&out.fc->unique, uniq); if (single) atomicAdd(&out.fc->singletons, single);
 		if (keptW) atomicAdd(&out.fc->weak_kept, keptW); if (keptS) atomicAdd(&out.fc->sing_kept, keptS);
