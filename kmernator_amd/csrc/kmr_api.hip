@@ -1397,8 +1397,8 @@ bool sk_geometry(uint32_t k, uint32_t m_wish, uint32_t &win, uint32_t &m, uint32
 	return false;
 }
 const uint64_t SK_EXTRACT_WAVES_PER_CU = std::max(2 * SK_WAVES, SKL_MIN_BLOCKS * SKL_WAVES);      /* wavefronts an extraction launch keeps per CU (each holds two slabs of 64 chunks) */
-template <int W, int WIN, bool FILT> int launch_sk_extract(kmr_handle *h, const ReadsView &rv, const SkParams &sp, const DevParams *override_params = nullptr) {
-	auto kern = sk_extract_kernel<W, WIN, FILT>;
+template <int W, int WIN, bool FILT, bool EXT = false> int launch_sk_extract(kmr_handle *h, const ReadsView &rv, const SkParams &sp, const DevParams *override_params = nullptr) {
+	auto kern = sk_extract_kernel<W, WIN, FILT, EXT>;
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_EXTRACT_SMEM));
 	const uint64_t tiles = ((rv.u_start ? rv.n_units : rv.n_reads) + 63) / 64;
 	uint64_t blocks = (tiles + SK_WAVES - 1) / SK_WAVES;
@@ -1464,7 +1464,8 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		 * sub-passes.  At k <= 32 a list of ~1200 k-mers holds ~350 distinct ones in sequencing data; longer k-mers are hit by read
 		 * errors more often (k = 51, 1 % errors: 40 % of the k-mers hold one and are nearly all distinct), so their lists are cut
 		 * half as long (C4: count pass 133 -> 93 ms; another halving costs more in per-list work than it saves) */
-		const uint64_t per_list = (h->tune.target_list == 2048 && W > 1) ? 700 : h->tune.target_list / 2 + 200;
+		/* (extension values: a 512-slot table, COUNT_LOG2S_EXT) */
+		const uint64_t per_list = h->ext ? (W > 1 ? 400 : 600) : ((h->tune.target_list == 2048 && W > 1) ? 700 : h->tune.target_list / 2 + 200);
 		uint32_t bits = 6; while (bits < 24 && (est >> bits) > per_list) bits++;
 		h->sk_fine_shift = 0;
 		if (h->sk_exchange && h->cfg.world_size > 1 && !h->tune.no_coarse_lists) {
@@ -1492,7 +1493,7 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 	 * as the other build modes do); inside an exchange (kmr_sk_exchange_begin) every k-mer is kept, the lists decide the owner */
 	const bool filt = dp.subsample > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0 || (dp.world > 1 && !h->sk_exchange);
 	bool lean = false; float wK = 1.0f;
-	if (!filt && !sp_debug_extract(h)) { int rcq = sk_uniform_weight(h, rvAll, lean, wK); if (rcq) return rcq; }
+	if (!filt && !h->ext && !sp_debug_extract(h)) { int rcq = sk_uniform_weight(h, rvAll, lean, wK); if (rcq) return rcq; }      /* (extension values want every neighbour's quality: the general kernel) */
 	for (uint64_t r = 0; r < n; r += chunk) {
 		const uint64_t m = std::min(chunk, n - r);
 		ReadsView rv = rvAll;
@@ -1504,11 +1505,12 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		 * chunk per list and two slabs of 64 chunks per wavefront */
 		const uint64_t bases = m * avg + avg;
 		/* (inside an exchange the lists of other owners start afresh after every pack: an open chunk per list for every call) */
-		rc = pool_reserve(h, h->l1, bases / SK_CHUNK_G + ((h->l1.base && !h->sk_exchange) ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * SK_EXTRACT_WAVES_PER_CU * 130 + 64, true); if (rc) return rc;
+		rc = pool_reserve(h, h->l1, (h->ext ? 2 : 1) * bases / SK_CHUNK_G + ((h->l1.base && !h->sk_exchange) ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * SK_EXTRACT_WAVES_PER_CU * 130 + 64, true); if (rc) return rc;
 		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b); time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
 		SkParams sp = sk_params(h);
 		if (h->cfg.size_tracker) sp.track = h->trk + r;
-#define SKX(WINv) (filt ? launch_sk_extract<W, WINv, true>(h, rv, sp) : (lean ? launch_sk_extract_lean<W, WINv>(h, rv, sp, wK) : launch_sk_extract<W, WINv, false>(h, rv, sp)))
+#define SKX(WINv) (h->ext ? (filt ? launch_sk_extract<W, WINv, true, true>(h, rv, sp) : launch_sk_extract<W, WINv, false, true>(h, rv, sp)) : \
+                   (filt ? launch_sk_extract<W, WINv, true>(h, rv, sp) : (lean ? launch_sk_extract_lean<W, WINv>(h, rv, sp, wK) : launch_sk_extract<W, WINv, false>(h, rv, sp))))
 		rc = h->sk_win == 16 ? SKX(16) : (h->sk_win == 8 ? SKX(8) : SKX(4));
 #undef SKX
 		time_end(h, KMR_TIME_EXTRACT, a2, b2); time_end(h, KMR_TIME_BUILD, a, b);
@@ -1574,7 +1576,7 @@ template <int W> int saturated_fix_t(kmr_handle *h, const uint64_t *ls, const ui
 	for (;;) {
 		SATCHK(dalloc((void **)&d_entry, 8 * cap)); SATCHK(dalloc((void **)&d_list, 4 * cap));
 		SATCHK(hipMemsetAsync(dfound, 0, 8, h->stream));
-		hipLaunchKernelGGL(sat_find_kernel<W>, dim3(grid_for(wm.n)), dim3(256), 0, h->stream, (const uint64_t *)wm.keys, (const uint32_t *)wm.vals, wm.n, h->sk_m, h->sk_off, h->sk_win, list_bits, dfound, cap, d_entry, d_list);
+		hipLaunchKernelGGL(sat_find_kernel<W>, dim3(grid_for(wm.n)), dim3(256), 0, h->stream, (const uint64_t *)wm.keys, (const uint32_t *)wm.vals, wm.n, h->sk_m, h->sk_off, h->sk_win, list_bits, dfound, cap, d_entry, d_list, h->ext ? 15u : 3u);
 		SATCHK(hipGetLastError());
 		SATCHK(hipMemcpyAsync(&found, dfound, 8, hipMemcpyDeviceToHost, h->stream)); SATCHK(hipStreamSynchronize(h->stream));
 		if (found <= cap) break;
@@ -1626,7 +1628,7 @@ template <int W> int saturated_fix_t(kmr_handle *h, const uint64_t *ls, const ui
 	if (kmr::sort_pairs_u64_u32(nullptr, &tmp_bytes, pk_in, pk_out, pv_in, pv_out, n_pairs, h->stream) != 0) { release(); return fail(h, KMR_ERR_HIP, "radix sort (size query)"); }
 	SATCHK(dalloc(&tmp, tmp_bytes));
 	if (kmr::sort_pairs_u64_u32(tmp, &tmp_bytes, pk_in, pk_out, pv_in, pv_out, n_pairs, h->stream) != 0) { release(); return fail(h, KMR_ERR_HIP, "radix sort"); }
-	hipLaunchKernelGGL(sat_reduce_kernel, dim3((unsigned)std::min<uint64_t>(found, 4096)), dim3(256), 0, h->stream, (const unsigned long long *)pk_out, (const uint32_t *)pv_out, (uint64_t)n_pairs, (const uint64_t *)d_entry, (uint64_t)found, has_singletons, wm.vals);
+	hipLaunchKernelGGL(sat_reduce_kernel, dim3((unsigned)std::min<uint64_t>(found, 4096)), dim3(256), 0, h->stream, (const unsigned long long *)pk_out, (const uint32_t *)pv_out, (uint64_t)n_pairs, (const uint64_t *)d_entry, (uint64_t)found, has_singletons, wm.vals, h->ext ? 15u : 3u);
 	SATCHK(hipGetLastError());
 	SATCHK(hipStreamSynchronize(h->stream));
 	release();
@@ -1673,7 +1675,8 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	}
 	uint64_t *ls = nullptr, *lc = nullptr; uint32_t nch = 0;
 	rc = build_csr(h, h->l1, nl, 0, &ls, &lc, &nch); if (rc) return rc;
-	const uint32_t vw = 3;
+	const uint32_t vw = h->ext ? 15 : 3;
+	const bool ext = h->ext;      /* extension values: entries of 15 value words, keys and values apart, bucketed by the scatter + per-bucket sort */
 	const uint64_t slack = (uint64_t)num_cus(h) * 4 * 8192 + 16;
 	const uint64_t wbound = f.has_singletons ? G / 2 : G, sbound = keepSing ? G : 0;
 	/* (after an owner exchange the lists this rank counts hold other ranks' k-mers too -- G only knows this rank's own reads: no upper
@@ -1686,7 +1689,8 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	if (h->tune.entry_share >= 0) { wcap = std::min<uint64_t>(wmax, (uint64_t)((double)G * h->tune.entry_share) + 16384); if (keepSing) scap = std::min<uint64_t>(smax, (uint64_t)((double)G * h->tune.entry_share) + 16384);
 		if (h->ue) { hipFree(h->ue); h->ue = nullptr; h->ue_cap = 0; }
 		if (h->us_keys) { hipFree(h->us_keys); hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0; } }
-	if (h->ue && h->ue_cap >= wcap) wcap = h->ue_cap;
+	if (!ext && h->ue && h->ue_cap >= wcap) wcap = h->ue_cap;
+	if (ext && h->uw_keys && h->uw_cap >= wcap) wcap = h->uw_cap;
 	if (h->us_keys && h->us_cap >= scap) scap = h->us_cap;
 	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr; unsigned long long *cursors = nullptr;
 	rc = arena_get(h, &wc, h->nb_weak); if (rc) return rc; rc = arena_get(h, &sc, h->nb_sing); if (rc) return rc;
@@ -1712,7 +1716,8 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	if (h->sk_exchange && h->cfg.world_size > 1 && !refined) { lgMain.list_first = h->cfg.rank; lgMain.list_stride = h->cfg.world_size; }      /* the other lists went to their owners */
 	SkLong<W> lgItems = lgMain;
 	uint64_t n_items = 0, long_chunks = 0;
-	const uint64_t LONG_CHUNKS = h->tune.long_list_chunks ? h->tune.long_list_chunks : 1024, PIECE = LONG_CHUNKS / 2;
+	/* (extension values: the 16-bit tallies of a block's table are exact below 65 536 k-mers, SK_EXT_LONG_CHUNKS) */
+	const uint64_t LONG_CHUNKS = ext ? std::min<uint64_t>(h->tune.long_list_chunks ? h->tune.long_list_chunks : SK_EXT_LONG_CHUNKS, SK_EXT_LONG_CHUNKS) : (h->tune.long_list_chunks ? h->tune.long_list_chunks : 1024), PIECE = std::max<uint64_t>(1, LONG_CHUNKS / 2);
 	if (!tracking && nch > LONG_CHUNKS) {
 		const uint64_t cap = (uint64_t)nch / PIECE + 2 * 1024 + 16;
 		uint64_t *ic0 = nullptr, *ic1 = nullptr; unsigned long long *dn = nullptr;
@@ -1732,47 +1737,54 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	uint32_t merge_log2 = 16;
 	hipEvent_t tca, tcb; time_begin(h, KMR_TIME_COUNT, &tca, &tcb);
 	for (int attempt = 0; ; attempt++) {
-		if (!h->ue || h->ue_cap < wcap) {
+		if (!ext && (!h->ue || h->ue_cap < wcap)) {
 			if (h->ue) hipFree(h->ue); h->ue = nullptr; h->ue_cap = 0;
 			HIPCHK(h, hipMalloc((void **)&h->ue, 8ull * (W + 1) * wcap)); h->ue_cap = wcap;
 		}
-		if (!h->us_keys || h->us_cap < scap) {
+		if (ext && (!h->uw_keys || h->uw_cap < wcap)) {
+			if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
+			HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, hipMalloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
+		}
+		if (!h->us_keys || h->us_cap < scap || (ext && !h->us_pkt)) {
 			if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0;
-			HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); h->us_cap = scap;
+			HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); if (ext) HIPCHK(h, hipMalloc(&h->us_pkt, 4 * scap)); h->us_cap = scap;
 		}
 		HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
 		HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
 		CountOut out; out.wkeys = nullptr; out.wvals = nullptr; out.wentries = h->ue; out.wcursor = cursors; out.wcap = h->ue_cap;
 		out.skeys = (uint64_t *)h->us_keys; out.sweight = (uint8_t *)h->us_b8; out.spkt = nullptr; out.scursor = cursors + 1; out.scap = h->us_cap;
 		out.weakCount = nullptr; out.singCount = sc; out.fc = fc; out.err = h->derr;      /* weak entries are bucketed without a per-bucket histogram (kmr_buckets.hpp) */
+		if (ext) { out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wentries = nullptr; out.wcap = h->uw_cap; out.spkt = (uint32_t *)h->us_pkt; out.weakCount = wc; }
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (nl / lgMain.list_stride + SK_LBATCH) / SK_LBATCH);
-		auto kern = tracking ? sk_count_kernel<W, COUNT_LOG2S, true> : sk_count_kernel<W, COUNT_LOG2S, false>;
-		const size_t smem = tracking ? sk_count_smem_bytes<W, COUNT_LOG2S, true>() : sk_count_smem_bytes<W, COUNT_LOG2S, false>();
+		auto kern = ext ? sk_count_kernel<W, COUNT_LOG2S_EXT, false, true> : (tracking ? sk_count_kernel<W, COUNT_LOG2S, true> : sk_count_kernel<W, COUNT_LOG2S, false>);
+		const size_t smem = ext ? sk_count_smem_bytes<W, COUNT_LOG2S_EXT, false, true>() : (tracking ? sk_count_smem_bytes<W, COUNT_LOG2S, true>() : sk_count_smem_bytes<W, COUNT_LOG2S, false>());
 		if (tracking) HIPCHK(h, hipMemsetAsync(tv.d_unique, 0, 8 * (tv.n + 1), h->stream));
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 		if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, SKC_THREADS, smem); fprintf(stderr, "sk_count<W=%d>: %d blocks per CU (LDS %zu), %llu lists, %u chunks\n", W, nb, smem, (unsigned long long)nl, nch); }
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(SKC_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lgMain);
 		HIPCHK(h, hipGetLastError());
-		Slot<W> *mslots = nullptr;
+		Slot<W> *mslots = nullptr; ExtSlot *mext = nullptr;
 		if (n_items) {
 			/* the merge table holds the distinct keys of the long lists: few when a list is long because a k-mer repeats, at most the
 			 * k-mers of those lists; it starts small and the attempt is repeated with a larger one if it fills */
 			if (hipMalloc((void **)&mslots, sizeof(Slot<W>) << merge_log2) != hipSuccess) return fail(h, KMR_ERR_OOM, "merge table of the long lists");
-			hipLaunchKernelGGL(table_clear_kernel<W>, dim3(grid_for(1ull << merge_log2)), dim3(256), 0, h->stream, mslots, (ExtSlot *)nullptr, 1ull << merge_log2);
-			lgItems.merge.slots = mslots; lgItems.merge.ext = nullptr; lgItems.merge.log2cap = merge_log2;
+			if (ext && hipMalloc((void **)&mext, sizeof(ExtSlot) << merge_log2) != hipSuccess) { hipFree(mslots); return fail(h, KMR_ERR_OOM, "merge table of the long lists"); }
+			hipLaunchKernelGGL(table_clear_kernel<W>, dim3(grid_for(1ull << merge_log2)), dim3(256), 0, h->stream, mslots, mext, 1ull << merge_log2);
+			lgItems.merge.slots = mslots; lgItems.merge.ext = mext; lgItems.merge.log2cap = merge_log2;
 			HIPCHK(h, hipMemsetAsync(lgItems.merge_used, 0, 8, h->stream));
-			rc = zero_work_counter(h); if (rc) { hipFree(mslots); return rc; }
+			rc = zero_work_counter(h); if (rc) { hipFree(mslots); if (mext) hipFree(mext); return rc; }
 			const int grid2 = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, n_items);
 			hipLaunchKernelGGL(kern, dim3(grid2), dim3(SKC_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, nl, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lgItems);
 			hipLaunchKernelGGL(sk_merge_emit_kernel<W>, dim3(grid_for(1ull << merge_log2)), dim3(256), 0, h->stream, lgItems.merge, out, f);
-			if (hipGetLastError() != hipSuccess) { hipFree(mslots); return fail(h, KMR_ERR_HIP, "long-list launches"); }
+			if (hipGetLastError() != hipSuccess) { hipFree(mslots); if (mext) hipFree(mext); return fail(h, KMR_ERR_HIP, "long-list launches"); }
 		}
 		uint32_t cerr = 0;
 		HIPCHK(h, hipMemcpyAsync(&c, fc, sizeof(c), hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(cur, cursors, 16, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(h, hipMemcpyAsync(&cerr, h->derr, 4, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		if (mslots) hipFree(mslots);
+		if (mext) hipFree(mext);
 		if (n_items && (cerr & ERR_TABLE_FULL) && merge_log2 < 30) {      /* the merge table filled: again with a larger one */
 			cerr &= ~(uint32_t)(ERR_TABLE_FULL | ERR_ENTRIES_FULL);
 			HIPCHK(h, hipMemcpy(h->derr, &cerr, 4, hipMemcpyHostToDevice));
@@ -1802,7 +1814,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		}
 	}
 	hipEvent_t tma, tmb; time_begin(h, KMR_TIME_BUCKETS, &tma, &tmb);
-	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing, true);
+	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing, !ext);
 	time_end(h, KMR_TIME_BUCKETS, tma, tmb);
 	if (rc) return rc;
 	if (c.saturated) { rc = saturated_fix_t<W>(h, ls, lc, nl, c.saturated, c.sat_sightings, f.has_singletons); if (rc) return rc; }
@@ -1900,14 +1912,13 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 		h->partition_mode = cfg->build_mode != 1;
 		/* auto: super-k-mer lists where they apply (count / direction values, one partition, k >= 13), else the two-level k-mer partition */
 		uint32_t wish_w = 0, wish_m = 0, wish_o = 0;
-		const bool sk_auto = cfg->build_mode == 0 && !h->ext && cfg->world_size <= 1 && sk_geometry(h->k, 0, wish_w, wish_m, wish_o);
+		const bool sk_auto = cfg->build_mode == 0 && cfg->world_size <= 1 && sk_geometry(h->k, 0, wish_w, wish_m, wish_o);
 		h->auto_mode = cfg->build_mode == 0;
 		/* (an auto handle of a multi-rank job starts on the k-mer partition -- plain kmr_add_reads* there means the getDistributedThreadId
 		 * filter -- but is made ready for the lists: kmr_exchange_init moves it over) */
 		/* (and any handle whose k has a minimizer geometry can answer lookups as a streaming pass over the same lists) */
 		const bool sk_ready = sk_geometry(h->k, 0, wish_w, wish_m, wish_o);
 		if (cfg->build_mode == 3 || sk_auto || sk_ready) {
-			if (h->ext && cfg->build_mode == 3) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) builds KMR_VALUE_COUNT_DIR values only"); break; }
 			if (!sk_geometry(h->k, 0, h->sk_win, h->sk_m, h->sk_off)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "build_mode 3 (super-k-mer lists) needs k >= 13"); break; }
 			h->superkmer_mode = cfg->build_mode == 3 || sk_auto;
 			double Pk[256];
@@ -1927,7 +1938,7 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 			h->sk_fast_div = fast;
 			hipMemcpy(h->dPk + 256, Rp, sizeof(Rp), hipMemcpyHostToDevice);
 		}
-		if (cfg->size_tracker && (!h->superkmer_mode || cfg->world_size > 1)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "size_tracker: kept by the super-k-mer build (build_mode 0 / 3, direction-counting values, k >= 13) of a single partition"); break; }
+		if (cfg->size_tracker && (!h->superkmer_mode || h->ext || cfg->world_size > 1)) { rc = fail(nullptr, KMR_ERR_UNSUPPORTED, "size_tracker: kept by the super-k-mer build (build_mode 0 / 3, direction-counting values, k >= 13) of a single partition"); break; }
 		if (!h->partition_mode) {
 			rc = alloc_table(h, h->log2cap, &h->slots, &h->extslots);
 			if (rc) { g_create_error = h->err; break; }

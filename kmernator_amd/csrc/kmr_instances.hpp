@@ -14,7 +14,8 @@
 
 namespace kmr {
 
-static const int COUNT_LOG2S = 10;                            /* 1024-slot LDS table per final list (expected ~350 distinct keys) */
+static const int COUNT_LOG2S = 10;
+static const int COUNT_LOG2S_EXT = 9;                        /* build_mode 3 with extension values: 60 bytes per slot; 512 slots let three blocks share a CU (lists half as long) */                            /* 1024-slot LDS table per final list (expected ~350 distinct keys) */
 /* partition kernel shape: one 1024-thread block per compute unit, 8 records per thread per batch, a 4-record write-combining
  * line per list in LDS (see partition_direct_kernel) */
 static const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
@@ -26,14 +27,15 @@ static const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
 #endif
 
 /* build_mode 3: extraction into super-k-mer lists */
-#define KMR_SKX(W, WIN, FILT) KMR_T __global__ void sk_extract_kernel<W, WIN, FILT>(ReadsView, DevParams, SkParams, PoolView);
+#define KMR_SKX(W, WIN, FILT) KMR_T __global__ void sk_extract_kernel<W, WIN, FILT, false>(ReadsView, DevParams, SkParams, PoolView); KMR_T __global__ void sk_extract_kernel<W, WIN, FILT, true>(ReadsView, DevParams, SkParams, PoolView);
 #define KMR_SKXL(W, WIN) KMR_T __global__ void sk_extract_lean_kernel<W, WIN>(ReadsView, DevParams, SkParams, PoolView, float);
 #define KMR_SKX_W(W) KMR_SKX(W, 16, false) KMR_SKX(W, 16, true) KMR_SKX(W, 8, false) KMR_SKX(W, 8, true) KMR_SKX(W, 4, false) KMR_SKX(W, 4, true) KMR_SKXL(W, 16) KMR_SKXL(W, 8) KMR_SKXL(W, 4)
 
 /* build_mode 3: count pass and streaming lookups */
-#define KMR_SKC(W, TRACK) KMR_T __global__ void sk_count_kernel<W, COUNT_LOG2S, TRACK>(PoolView, const uint64_t *, const uint64_t *, uint64_t, uint32_t, CountOut, FinalizeParams, unsigned int *, uint32_t, SkTrackView, SkLong<W>);
+#define KMR_SKC(W, TRACK) KMR_SKCX(W, TRACK, false)
+#define KMR_SKCX(W, TRACK, EXT) KMR_T __global__ void sk_count_kernel<W, EXT ? COUNT_LOG2S_EXT : COUNT_LOG2S, TRACK, EXT>(PoolView, const uint64_t *, const uint64_t *, uint64_t, uint32_t, CountOut, FinalizeParams, unsigned int *, uint32_t, SkTrackView, SkLong<W>);
 #define KMR_SKL(W) KMR_T __global__ void sk_lookup_kernel<W>(PoolView, const uint64_t *, const uint64_t *, uint64_t, uint32_t, const uint64_t *, const uint64_t *, const uint32_t *, uint32_t *, uint64_t, unsigned int *, const uint64_t *, const uint64_t *, const uint32_t *, uint64_t, uint64_t);
-#define KMR_SKC_W(W) KMR_SKC(W, false) KMR_SKC(W, true) KMR_SKL(W)
+#define KMR_SKC_W(W) KMR_SKC(W, false) KMR_SKC(W, true) KMR_SKCX(W, false, true) KMR_SKL(W)
 
 /* build modes 1 and 2, lookups, owner requests: the k-mer extraction with its Ops */
 #define KMR_EX(W, EXT, OP, SUB) KMR_T __global__ void extract_kernel<W, EXT, OP, SUB>(ReadsView, DevParams, OP);

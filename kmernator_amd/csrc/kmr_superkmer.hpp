@@ -125,6 +125,15 @@ void sk_track_boundary_kernel(ReadsView rv, DevParams p, SkBoundary *bd, uint32_
  *   granules    n f32 weights, 4 per granule -- only when the run's weights are not all equal (uniform == 0)
  * ordinal = stream ordinal of the run's first k-mer; the others follow by +1. */
 __host__ __device__ __forceinline__ uint32_t sk_base_granules(uint32_t n, uint32_t k) { return (n + k - 1 + 63) / 64; }
+/* Records of a build with extension values (KMR_VALUE_EXT: ExtensionTrackingData, src/KmerTrackingData.h:1027-1126) end in
+ *   granules    ceil(n / 8): two bytes per k-mer, the quality of its LEFT neighbour and of its RIGHT neighbour,
+ *               as (quality char - fastq base) & 0xff, Read::REF_QUAL for a read without qualities and the minimum
+ *               extension quality where the read ends (Extension('X', extMinQuality), src/KmerReadUtils.h:224-236)
+ * and say in their header (bits 24..26, 27..29 of the second word; bit 30 marks such a record) which base lies left of the first
+ * k-mer and right of the last one: 0..3, or 5 = 'X' where the read ends.  The neighbours in between are the record's own bases. */
+static const uint32_t SK_EXT_X = 5u;
+__host__ __device__ __forceinline__ uint32_t sk_ext_granules(uint32_t n) { return (n + 7) / 8; }
+__host__ __device__ __forceinline__ uint32_t sk_rec_granules(uint32_t n, uint32_t k, bool uniform, bool ext) { return 1 + sk_base_granules(n, k) + (uniform ? 0u : (n + 3) / 4) + (ext ? sk_ext_granules(n) : 0u); }
 
 #ifndef KMR_INSTANCE_TU
 __global__ void sk_state_init_kernel(unsigned long long *state, uint64_t n) {
@@ -272,7 +281,16 @@ static const int SK_GROUPS = TILE_BUF / 16 + 8;               /* 16-base groups 
 static const int SK_WAVE_LDS = (SK_Q_BYTES + SK_GROUPS * 4 + SK_GROUPS * 2 + SK_GROUPS * 4 + 2 * SK_WINDOW * 64 * 4 + 64 + 15) & ~15;
 static const size_t SK_EXTRACT_SMEM = (size_t)SK_WAVES * SK_WAVE_LDS;
 
-template <int W, int WIN, bool FILT>
+/* eight bytes from byte offset off of an LDS array (whose base is 4-byte aligned), by aligned loads */
+__device__ __forceinline__ uint2 sk_lds_bytes8(const uint8_t *base, uint32_t off) {
+	const uint32_t *a = (const uint32_t *)(base + (off & ~3u));
+	const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], sh = off & 3u;
+	return make_uint2(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh));
+}
+/* (x - c) & 0xff in every byte of x; c4 = (256 - c) & 0xff in every byte */
+__device__ __forceinline__ uint32_t sk_bytes_add(uint32_t x, uint32_t c4) { return ((x & 0x7f7f7f7fu) + (c4 & 0x7f7f7f7fu)) ^ ((x ^ c4) & 0x80808080u); }
+
+template <int W, int WIN, bool FILT, bool EXT = false>
 __global__ __launch_bounds__(SK_WAVES * 64, 2)
 void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -432,13 +450,13 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				if ((q_info[r] >> 31) && !SK_DBG(sp.dbg, 1)) {
 					const uint32_t n = (q_info[r] >> 16) & 0xffu; const bool uni = (q_info[r] >> 24) & 1u;
 					if ((q_info[r] >> 30) & 1u) at[r] = q_booked[r];
-					else at[r] = sk_append_settle(sp.state, sk_list_of(q_mh[r], sp.list_bits), 1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4), q_booked[r], slab, pool, waits[r]);
+					else at[r] = sk_append_settle(sp.state, sk_list_of(q_mh[r], sp.list_bits), sk_rec_granules(n, k, uni, EXT), q_booked[r], slab, pool, waits[r]);
 				}
 			}
 #pragma unroll
 			for (int r = 0; r < SK_RR; r++) if (waits[r]) {
 				const uint32_t n = (q_info[r] >> 16) & 0xffu; const bool uni = (q_info[r] >> 24) & 1u;
-				at[r] = sk_append(sp.state, sk_list_of(q_mh[r], sp.list_bits), 1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4), slab, pool);
+				at[r] = sk_append(sp.state, sk_list_of(q_mh[r], sp.list_bits), sk_rec_granules(n, k, uni, EXT), slab, pool);
 			}
 #pragma unroll
 			for (int r = 0; r < SK_RR; r++) {
@@ -447,7 +465,37 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 					const uint32_t nbg = sk_base_granules(n, k), nwg = uni ? 0u : (n + 3) / 4;
 					uint4 *dst = (uint4 *)pool.base + at[r];
 					const uint64_t ord = ord0 + start;
-					dst[0] = make_uint4((uint32_t)ord, (uint32_t)(ord >> 32) | (n << 8) | ((uni ? 1u : 0u) << 16) | ((1 + nbg + nwg) << 17), q_mh[r], q_w0[r]);
+					uint32_t hdrExt = 0;
+					if constexpr (EXT) {
+						/* neighbours outside the run: the base before its first k-mer and the one behind its last (in the tile; for the first / last
+						 * k-mer of a unit of a long read in the read itself; 'X' with the minimum extension quality where the read ends), and the
+						 * qualities of every k-mer's two neighbours */
+						const uint32_t c4 = ((256u - (p.fastq_start & 0xffu)) & 0xffu) * 0x01010101u;
+						const uint32_t qref = (127u - p.fastq_start) & 0xffu;
+						const uint32_t e = start + n + k - 1;                 /* position behind the last k-mer */
+						uint32_t oL = SK_EXT_X, oR = SK_EXT_X, qL = p.ext_min_q & 0xffu, qR = p.ext_min_q & 0xffu;
+						if (start > 0) { oL = (sk_bases16(pk, rbOff + start - 1) >> 30) & 3u; qL = isRef ? qref : ((uint32_t)rq[start - 1] - p.fastq_start) & 0xffu; }
+						else if (rv.u_start && myStart > rv.offsets[myRead]) { uint32_t c = base_code(rv.bases[myStart - 1]); oL = c == 4 ? 0u : c; qL = isRef ? qref : ((uint32_t)rv.quals[myStart - 1] - p.fastq_start) & 0xffu; }
+						if (e < L) { oR = (sk_bases16(pk, rbOff + e) >> 30) & 3u; qR = isRef ? qref : ((uint32_t)rq[e] - p.fastq_start) & 0xffu; }
+						else if (rv.u_start && myEnd < rv.offsets[myRead + 1]) { uint32_t c = base_code(rv.bases[myEnd]); oR = c == 4 ? 0u : c; qR = isRef ? qref : ((uint32_t)rv.quals[myEnd] - p.fastq_start) & 0xffu; }
+						hdrExt = (oL << 24) | (oR << 27) | (1u << 30);
+						const uint32_t neg = sk_ext_granules(n);
+						for (uint32_t g = 0; g < neg; g++) {
+							uint2 lq = make_uint2(qref * 0x01010101u, qref * 0x01010101u), rqv = lq;
+							if (!isRef) {
+								const uint32_t offL = rqOff + start + 8 * g;      /* lq[8 g + i] is the quality at start + 8 g + i - 1 */
+								if (offL == 0) { const uint2 v = sk_lds_bytes8(tq, 0u); lq = make_uint2(v.x << 8, (v.y << 8) | (v.x >> 24)); }
+								else lq = sk_lds_bytes8(tq, offL - 1);
+								rqv = sk_lds_bytes8(tq, rqOff + start + k + 8 * g);
+								lq.x = sk_bytes_add(lq.x, c4); lq.y = sk_bytes_add(lq.y, c4); rqv.x = sk_bytes_add(rqv.x, c4); rqv.y = sk_bytes_add(rqv.y, c4);
+							}
+							if (g == 0) lq.x = (lq.x & ~0xffu) | qL;              /* (the same value again when the neighbour lies in the tile) */
+							if (g == (n - 1) >> 3) { const uint32_t b = (n - 1) & 7u; if (b < 4) rqv.x = (rqv.x & ~(0xffu << (8 * b))) | (qR << (8 * b)); else rqv.y = (rqv.y & ~(0xffu << (8 * (b - 4)))) | (qR << (8 * (b - 4))); }
+							dst[1 + nbg + nwg + g] = make_uint4(__builtin_amdgcn_perm(rqv.x, lq.x, 0x05010400u), __builtin_amdgcn_perm(rqv.x, lq.x, 0x07030602u),
+							                                    __builtin_amdgcn_perm(rqv.y, lq.y, 0x05010400u), __builtin_amdgcn_perm(rqv.y, lq.y, 0x07030602u));
+						}
+					}
+					dst[0] = make_uint4((uint32_t)ord, (uint32_t)(ord >> 32) | (n << 8) | ((uni ? 1u : 0u) << 16) | (sk_rec_granules(n, k, uni, EXT) << 17) | hdrExt, q_mh[r], q_w0[r]);
 					const uint32_t xb = rbOff + start;
 					for (uint32_t b = 0; b < nbg; b++)
 						dst[1 + b] = make_uint4(sk_bases16(pk, xb + 64 * b), sk_bases16(pk, xb + 64 * b + 16), sk_bases16(pk, xb + 64 * b + 32), sk_bases16(pk, xb + 64 * b + 48));
@@ -802,7 +850,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 					}
 					if ((q_info[r] >> 31) && !SK_DBG(sp.dbg, 1)) {
 						const uint32_t n = (q_info[r] >> 16) & 0xffu; const bool uni = (q_info[r] >> 24) & 1u;
-						const uint32_t need = 1 + sk_base_granules(n, k) + (uni ? 0u : (n + 3) / 4), myList = sk_list_of(q_mh[r], sp.list_bits);
+						const uint32_t need = sk_rec_granules(n, k, uni, EXT), myList = sk_list_of(q_mh[r], sp.list_bits);
 						if (myList == hotNow) { q_booked[r] = sk_append_hot(slab, myList, need, pool); q_info[r] |= 1u << 30; }      /* an address, not what a booking add returned */
 						else q_booked[r] = atomicAdd(sp.state + myList, (unsigned long long)need);
 					}
@@ -1210,8 +1258,14 @@ template <int W> struct SkLong {
 	unsigned long long *merge_used;         /* slots of it claimed so far: beyond 5/8 of the table the launch gives up (ERR_TABLE_FULL) and the host comes back with a larger one */
 };
 
-template <int W, int LOG2S, bool TRACK = false>
-__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (TRACK ? 8 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
+/* EXT (extension values): six more words per slot -- the twelve tallies as 16-bit halves, exact while a block's share of a list stays
+ * below 65 536 k-mers (the host cuts longer lists into pieces, SK_EXT_LONG_CHUNKS) -- and the packet of one occurrence, read only
+ * when the key ends as a singleton: 60 bytes per slot, two blocks per CU */
+template <int W, int LOG2S, bool TRACK = false, bool EXT = false>
+__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (TRACK ? 8 : 0) + (EXT ? 28 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
+/* a chunk of extension records holds at most ~6.4 k-mers per granule (n = 128: 21 granules): 128 chunks stay below 65 536 k-mers */
+static const uint64_t SK_EXT_LONG_CHUNKS = 128;
+__device__ __forceinline__ uint32_t sk_ext_char(uint32_t code) { return (uint32_t)((0x584e54474341ull >> (8 * code)) & 0xffu); }      /* "ACGTNX" */
 
 /* Life of a list in the block (round 3: two block barriers per list instead of eight):
  *   insert   the four wavefronts take the list's chunks on their own (chunk c0 + wave, + 4, ...), the table is shared through
@@ -1234,8 +1288,8 @@ static const int SKC_WAVES = KMR_SKC_WAVES, SKC_THREADS = SKC_WAVES * 64;      /
 static const unsigned long long SK_KEY_PENDING = ~0ull;
 static const unsigned long long SK_OSLAB = 2048;      /* entries a wavefront reserves at a time in the count pass's output */
 
-template <int W, int LOG2S, bool TRACK = false>
-__global__ __launch_bounds__(SKC_THREADS, (W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 3 : 1))
+template <int W, int LOG2S, bool TRACK = false, bool EXT = false>
+__global__ __launch_bounds__(SKC_THREADS, EXT ? (W == 1 ? (LOG2S <= 9 ? 3 : 2) : 1) : ((W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 3 : 1)))
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
                      CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv, SkLong<W> lg) {
 	constexpr int S = 1 << LOG2S;
@@ -1247,10 +1301,12 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	double *twsum = (double *)(tcnt + S);
 	unsigned long long *tfirst = (unsigned long long *)(twsum + S);
 	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
-	uint4 *stage = (uint4 *)(tstate + (W > 1 ? S : 0));                /* 16-byte aligned: every table array is a multiple of 16 bytes */
+	uint32_t *ttally = tstate + (W > 1 ? S : 0);                       /* EXT only: [S][6] tallies (left A C | G T | N X, right A C | G T | N X as 16-bit halves), [S] packets */
+	uint32_t *tpkt = ttally + (EXT ? 6 * S : 0);
+	uint4 *stage = (uint4 *)(tpkt + (EXT ? S : 0));                    /* 16-byte aligned: every table array is a multiple of 16 bytes */
 	uint8_t *recOf = (uint8_t *)(stage + SK_STAGE_G);                  /* [4][64] per wavefront: header lane of the record a lane's first k-mer lies in */
 	/* size tracker: the second-smallest first-sighting word of every slot, and this block's share of the two difference arrays */
-	unsigned long long *tsecond = (unsigned long long *)(csm + (size_t)S * (8 * W + 24 + (W > 1 ? 4 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64);
+	unsigned long long *tsecond = (unsigned long long *)(csm + (size_t)S * (8 * W + 24 + (W > 1 ? 4 : 0) + (EXT ? 28 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64);
 	unsigned int *trkU = (unsigned int *)(tsecond + (TRACK ? S : 0)), *trkS = trkU + (SK_TRACK_MAX + 1);
 	__shared__ uint32_t s_list, s_sp;
 	__shared__ uint32_t s_claimed[2], s_overflow[2];
@@ -1260,7 +1316,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	__shared__ uint8_t s_dcount[SK_DESC_CAP];
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	if (TRACK) for (int i = t; i < 2 * (int)(SK_TRACK_MAX + 1); i += SKC_THREADS) trkU[i] = 0;
-	const uint32_t vw = 3;
+	const uint32_t vw = EXT ? 15 : 3;
 	unsigned long long uniq = 0, single = 0, keptW = 0, keptS = 0, satK = 0, satS = 0;
 	unsigned long long uniqW = 0, singleW = 0;      /* wave-uniform: used slots and slots with a count of one, from ballots */
 	/* this wavefront's output slabs: [wpos, wend) of the weak entries, [spos, send) of the singletons */
@@ -1268,6 +1324,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	bool outFull = false;
 	if (t == 0) { s_claimed[0] = s_claimed[1] = 0; s_overflow[0] = s_overflow[1] = 0; s_sp = 0; }
 	for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)i * W + W - 1] = SK_KEY_PENDING; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
+	if (EXT) for (int i = t; i < 6 * S; i += SKC_THREADS) ttally[i] = 0;
 	lds_barrier();
 	/* classify() of kmr_kernels.hpp folded into launch-wide scalars: a count of one goes to class singC when singletons are separate,
 	 * any other count below weakMin is dropped */
@@ -1389,11 +1446,14 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					if (havePre) { pre = make_uint4(0, 0, 0, 0); if ((uint32_t)lane < preCount) pre = poolg[(size_t)preChunk * SK_CHUNK_G + lane]; }
 					/* the record the lane is in: its k-mer count, weights, first ordinal */
 					uint32_t n = 0; const uint32_t *ww = nullptr; bool uniformW = true; uint64_t ord0 = 0;
+					const uint8_t *xq = nullptr;      /* EXT: the record's neighbour qualities */
+					uint32_t leftCarry = 0;           /* EXT: the base left of the next k-mer to be made, when it is a base of the same record */
 					auto enter_record = [&]() {      /* header in hx, hy, hw */
 						n = (hy >> 8) & 0xffu;
 						ww = (const uint32_t *)(wstage + rs + 1) + 4 * sk_base_granules(n, k);
 						uniformW = ((hy >> 16) & 1u) != 0;
 						ord0 = (uint64_t)hx | ((uint64_t)(hy & 0xffu) << 32);
+						if (EXT) xq = (const uint8_t *)(ww + (uniformW ? 0u : 4u * ((n + 3) / 4)));
 					};
 					/* The bases of the k-mers a lane expands lie in REGISTERS: a window of 2 W + 2 dwords of its record's packed bases, the
 					 * current k-mer `sb` bits into it (0 <= sb <= 62); the next k-mer of the same record is the window two bits further on
@@ -1424,11 +1484,11 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					/* a k-mer on its way to the table: canonical key, strand, home slot and probe step, weight, stream ordinal.  Two of them
 					 * exist per lane -- the one being inserted and the one being made -- and the loop below alternates their roles instead of
 					 * copying one into the other every step (the copies were a quarter of the loop's vector instructions) */
-					struct KState { Key<W> key; bool fwd, mine; uint32_t slot, step, w; uint64_t ord; };
+					struct KState { Key<W> key; bool fwd, mine; uint32_t slot, step, w; uint64_t ord; uint32_t x; };      /* x (EXT): left code | right code << 8 | left quality << 16 | right quality << 24, as the canonical strand sees them */
 					KState kA, kB;
 #pragma unroll
 					for (int wi = 0; wi < W; wi++) { kA.key.w[wi] = 0; kB.key.w[wi] = 0; }
-					kA.fwd = kB.fwd = true; kA.mine = kB.mine = false; kA.slot = kB.slot = 0; kA.step = kB.step = 1; kA.w = kB.w = 0; kA.ord = kB.ord = 0;
+					kA.fwd = kB.fwd = true; kA.mine = kB.mine = false; kA.slot = kB.slot = 0; kA.step = kB.step = 1; kA.w = kB.w = 0; kA.ord = kB.ord = 0; kA.x = kB.x = 0;
 					auto prepare = [&](KState &st) {      /* the k-mer at (record rs, index j): window bit offset sb */
 						Key<W> kf;
 						const bool up = sb >= 32u; const uint32_t r = sb & 31u;
@@ -1439,6 +1499,16 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 							kf.w[wi] = ((uint64_t)hi << 32) | lo;
 						}
 						const uint32_t kbits = 2u * k;
+						uint32_t rcIn = 0; uint64_t kfFirst = 0;
+						if constexpr (EXT) {
+							/* the base behind the k-mer: base k of the 32 W bases just cut out of the window (k = 32 W: the next dword of the record) */
+							kfFirst = kf.w[0];
+							if ((k >> 5) < (uint32_t)W) { uint64_t wsel = kf.w[0];
+#pragma unroll
+								for (int wi = 1; wi < W; wi++) if ((k >> 5) == (uint32_t)wi) wsel = kf.w[wi];
+								rcIn = (uint32_t)(wsel >> (62u - 2u * (k & 31u))) & 3u; }
+							else { const uint32_t b = j + k; rcIn = (((const uint32_t *)(wstage + rs + 1))[b >> 4] >> (30 - 2 * (b & 15u))) & 3u; }
+						}
 #pragma unroll
 						for (int wi = 0; wi < W; wi++) {
 							const uint32_t lo = 64u * wi;
@@ -1457,8 +1527,28 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						st.mine = ((uint32_t)(h >> 20) & subMask) == val;
 						st.w = uniformW ? hw : ww[j];
 						st.ord = ord0 + j;
+						if constexpr (EXT) {
+							/* the two neighbours of k-mer j of the record (Extension left / right of buildWeightedKmers, src/KmerReadUtils.h:224-236):
+							 * what the header says lies outside the run for its first / last k-mer; in between the left one is the first base of the
+							 * k-mer made before this one (leftCarry) and the right one the base behind the k-mer in the window it was cut from; seen
+							 * from the other strand they swap and are complemented */
+							uint32_t lc = j > 0 ? leftCarry : (hy >> 24) & 7u, rc = (hy >> 27) & 7u;
+							if (j + 1 < n) rc = rcIn;
+							leftCarry = (uint32_t)(kfFirst >> 62);
+							const uint32_t q2 = ((const uint16_t *)xq)[j];
+							uint32_t lq = q2 & 0xffu, rq = q2 >> 8;
+							if (!st.fwd) {
+								const uint32_t tl = rc < 4u ? 3u - rc : rc, tr = lc < 4u ? 3u - lc : lc, tq = rq;
+								lc = tl; rc = tr; rq = lq; lq = tq;
+							}
+							st.x = lc | (rc << 8) | (lq << 16) | (rq << 24);
+						}
 					};
-					if (left) { enter_record(); seed_window(); request_next_record(); prepare(kA); }
+					if (left) {
+						enter_record(); seed_window(); request_next_record();
+						if (EXT && j > 0) { const uint32_t b = j - 1; leftCarry = (((const uint32_t *)(wstage + rs + 1))[b >> 4] >> (30 - 2 * (b & 15u))) & 3u; }      /* (a lane that starts inside a record) */
+						prepare(kA);
+					}
 					uint32_t dbgSink = 0;
 					/* one step: the current k-mer's claim is sent off, the lane's next k-mer is made (two bits further in the window, or the first
 					 * one of the next record), then the claim is looked at and the three sums go to the slot */
@@ -1485,6 +1575,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 							if (SK_DBG(dbgFlags, 1)) { dbgSink ^= (uint32_t)cur.key.w[0] ^ s; }
 							else if (cur.mine) {
 								bool placed = false;
+								const uint32_t claimedBefore = claimedHere;
 								if constexpr (W == 1) {
 									if (old == EMPTY_KEY) { claimedHere++; placed = true; }
 									else if (old == cur.key.w[0]) placed = true;
@@ -1560,6 +1651,12 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 										const unsigned long long cand = was > fp ? was : fp;
 										if (cand != NO_FIRST) atomicMin(&tsecond[s], cand);
 									} else atomicMin(&tfirst[s], fp);
+									if constexpr (EXT) {      /* ExtensionTracking::trackExtension (src/KmerTrackingData.h:195-201) */
+										const uint32_t lc = cur.x & 0xffu, rc = (cur.x >> 8) & 0xffu, lq = (cur.x >> 16) & 0xffu, rq = cur.x >> 24;
+										if (lq >= f.ext_min_q || lc > 3u) atomicAdd(&ttally[(size_t)s * 6 + (lc >> 1)], 1u << (16 * (lc & 1u)));
+										if (rq >= f.ext_min_q || rc > 3u) atomicAdd(&ttally[(size_t)s * 6 + 3 + (rc >> 1)], 1u << (16 * (rc & 1u)));
+										if (claimedHere != claimedBefore) tpkt[s] = sk_ext_char(lc) | (sk_ext_char(rc) << 8) | (cur.x & 0xffff0000u);      /* the packet of the sighting that claimed the slot: read only when it stays the only one */
+									}
 								}
 							}
 						}
@@ -1643,6 +1740,12 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 									atomicAdd(&sl->cntfwd, cf);
 									atomicAdd(&sl->wsum, wsum);
 									atomicMin(&sl->first, fst);
+									if constexpr (EXT) {
+										ExtSlot *es = &lg.merge.ext[ms];
+#pragma unroll
+										for (int j = 0; j < 12; j++) { const uint32_t v = (ttally[(size_t)s * 6 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu; if (v) atomicAdd(&es->tally[j], v); }
+										es->pkt = tpkt[s];
+									}
 								}
 							}
 						}
@@ -1677,6 +1780,10 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 									for (int q = 0; q < W; q++) out.wkeys[pos * W + q] = key.w[q];
 									uint32_t *v = out.wvals + pos * vw;
 									v[0] = cnt16; v[1] = wbits; v[2] = fwdc;
+									if constexpr (EXT) {
+#pragma unroll
+										for (int j = 0; j < 12; j++) v[3 + j] = (ttally[(size_t)s * 6 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
+									}
 								}
 							}
 							wpos += cnt; keptW += lane == 0 ? cnt : 0u;
@@ -1704,6 +1811,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 							for (int q = 0; q < W; q++) out.skeys[pos * W + q] = key.w[q];
 							const float wf = (float)wsum;
 							out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
+							if constexpr (EXT) out.spkt[pos] = tpkt[s];
 						}
 						bucket_count_add(out.singCount, bucket, cls == 2 && !outFull);
 						if (!outFull) { spos += cnt; keptS += lane == 0 ? cnt : 0u; }
@@ -1713,11 +1821,18 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 #pragma unroll
 				for (int i = 0; i < WSLOTS / 64; i++) {
 					const int s = wv * WSLOTS + i * 64 + lane;
-					if ((usedMask[i] >> lane) & 1ull) { tkeys[(size_t)s * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)s * W + W - 1] = SK_KEY_PENDING; tcnt[s] = 0; twsum[s] = 0.0; tfirst[s] = NO_FIRST; if (W > 1) tstate[s] = 0; if (TRACK) tsecond[s] = NO_FIRST; }
+					if ((usedMask[i] >> lane) & 1ull) {
+						tkeys[(size_t)s * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)s * W + W - 1] = SK_KEY_PENDING; tcnt[s] = 0; twsum[s] = 0.0; tfirst[s] = NO_FIRST; if (W > 1) tstate[s] = 0; if (TRACK) tsecond[s] = NO_FIRST;
+						if constexpr (EXT) {
+#pragma unroll
+							for (int q = 0; q < 6; q++) ttally[(size_t)s * 6 + q] = 0;
+						}
+					}
 				}
 			};
 			auto clear_table = [&]() {
 				for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)i * W + W - 1] = SK_KEY_PENDING; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
+				if (EXT) for (int i = t; i < 6 * S; i += SKC_THREADS) ttally[i] = 0;
 			};
 
 			insert_pass(0, 0, true);
@@ -1781,7 +1896,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 template <int W>
 __global__ __launch_bounds__(256)
 void sk_merge_emit_kernel(Table<W> tbl, CountOut out, FinalizeParams f) {
-	const uint32_t vw = 3;
+	const uint32_t vw = tbl.ext ? 15 : 3;      /* a table with extension tallies beside its slots: entries of 15 value words */
 	const uint32_t singC = f.has_singletons ? (f.min_depth > 1 ? 0u : 2u) : 3u;
 	const uint32_t weakMin = ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1) ? f.min_depth : 0u;
 	const uint64_t cap = 1ull << tbl.log2cap;
@@ -1816,6 +1931,7 @@ void sk_merge_emit_kernel(Table<W> tbl, CountOut out, FinalizeParams f) {
 						for (int q = 0; q < W; q++) out.wkeys[pos * W + q] = key.w[q];
 						uint32_t *v = out.wvals + pos * vw;
 						v[0] = cnt; v[1] = wbits; v[2] = fwdc;
+						if (tbl.ext) for (int j = 0; j < 12; j++) v[3 + j] = tbl.ext[i].tally[j];
 					}
 					keptW++;
 				}
@@ -1828,6 +1944,7 @@ void sk_merge_emit_kernel(Table<W> tbl, CountOut out, FinalizeParams f) {
 					for (int q = 0; q < W; q++) out.skeys[pos * W + q] = key.w[q];
 					const float wf = (float)sl.wsum;
 					out.sweight[pos] = (uint8_t)((unsigned char)(((double)wf * 254.0)) + 1);
+					if (tbl.ext && out.spkt) out.spkt[pos] = tbl.ext[i].pkt;
 					keptS++;
 				}
 			}
@@ -2041,9 +2158,9 @@ void sk_lookup_kernel(PoolView pool, const uint64_t *list_start, const uint64_t 
 template <int W>
 __global__ __launch_bounds__(256)
 void sat_find_kernel(const uint64_t *keys, const uint32_t *vals, uint64_t n, uint32_t m, uint32_t off, uint32_t win, uint32_t list_bits,
-                     unsigned long long *found, uint64_t cap, uint64_t *sat_entry, uint32_t *sat_list) {
+                     unsigned long long *found, uint64_t cap, uint64_t *sat_entry, uint32_t *sat_list, uint32_t vw = 3) {
 	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
-		if ((vals[e * 3] & 0xffffu) != 65535u) continue;
+		if ((vals[e * vw] & 0xffffu) != 65535u) continue;
 		const unsigned long long at = atomicAdd(found, 1ull);
 		if (at < cap) { sat_entry[at] = e; sat_list[at] = sk_list_of(sk_key_minimizer<W>(keys + e * W, m, off, win), list_bits); }
 	}
@@ -2195,7 +2312,7 @@ void sat_collect_kernel(PoolView pool, const uint64_t *list_chunks, uint32_t k, 
  * -- by one thread out of LDS tiles the block loads together; the direction count is a plain sum. */
 #ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(256)
-void sat_reduce_kernel(const unsigned long long *keys, const uint32_t *weights, uint64_t n_pairs, const uint64_t *sat_entry, uint64_t n_sat, uint32_t has_singletons, uint32_t *map_vals) {
+void sat_reduce_kernel(const unsigned long long *keys, const uint32_t *weights, uint64_t n_pairs, const uint64_t *sat_entry, uint64_t n_sat, uint32_t has_singletons, uint32_t *map_vals, uint32_t vw = 3) {
 	constexpr int TILE = 4096;
 	__shared__ float s_w[TILE]; __shared__ unsigned int s_f[256];
 	const int t = threadIdx.x;
@@ -2223,7 +2340,7 @@ void sat_reduce_kernel(const unsigned long long *keys, const uint32_t *weights, 
 		if (t == 0) {
 			unsigned int fwd = s_f[0];
 			if (!has_singletons) fwd += (unsigned int)(keys[s] & 1ull);
-			uint32_t *v = map_vals + sat_entry[b] * 3;
+			uint32_t *v = map_vals + sat_entry[b] * vw;
 			v[1] = __float_as_uint(acc); v[2] = fwd;
 		}
 	}

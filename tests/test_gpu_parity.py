@@ -24,8 +24,8 @@ def product(cfg, mode=0, **tune):
     for name, _ in cfg._fields_:
         setattr(c, name, getattr(cfg, name))
     c.build_mode = mode
-    if mode == 3 and (cfg.value_kind == KMR_VALUE_EXT or cfg.k < 13):
-        pytest.skip("build_mode 3 builds count / direction values at k >= 13")
+    if mode == 3 and cfg.k < 13:
+        pytest.skip("build_mode 3 (super-k-mer lists) needs k >= 13")
     return ka.KmerSpectrum(c).tune(**tune)
 
 
@@ -868,10 +868,13 @@ def test_score_partitioned_driver_single_rank():
         dist.destroy_process_group()
 
 
-def test_ext_hot_kmer_takes_the_wide_tally_table():
+@pytest.mark.parametrize("mode", [2, 3])
+def test_ext_hot_kmer_takes_the_wide_tally_table(mode):
     """extension values: the count pass keeps 16-bit tallies for lists of up to 65 535 records and sends longer ones through
     the 32-bit table in a second launch -- a k-mer that occurs 130 000 times (homopolymer reads) must come out with its
-    exact tallies (the reference's are u32, only `count` saturates at 65 535), next to ordinary lists"""
+    exact tallies (the reference's are u32, only `count` saturates at 65 535), next to ordinary lists.  build_mode 3: the long list is
+    cut into pieces of at most SK_EXT_LONG_CHUNKS chunks whose tables (16-bit tallies) are added into a device table with 32-bit
+    ones; its saturated keys keep the reference's weightedCount / directionBias (first 65 535 sightings)"""
     k = 21
     rng = np.random.default_rng(17)
     base = synth_reads(4000, read_len=100, seed=8, quality="noisy", n_rate=0.001)
@@ -885,8 +888,8 @@ def test_ext_hot_kmer_takes_the_wide_tally_table():
         quals.insert(at, q)
     rb = ReadBatch(seqs, quals)
     cfg = default_config(k, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2, num_buckets_weak=256, num_buckets_singleton=1024)
-    o, p = run_both(cfg, rb, min_depth=2, mode=2)
-    n = compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, True, saturated_dir_free=True)
+    o, p = run_both(cfg, rb, min_depth=2, mode=mode)
+    n = compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, True, saturated_dir_free=(mode != 3))
     assert n > 1000
     hot = np.zeros((1, p.kb), dtype=np.uint8)          # A^21 packed
     assert p.getCount(hot)[0] == 65535 == o.lookup(hot)[0]
@@ -1026,6 +1029,11 @@ def test_long_lists_counted_in_pieces(k, chunks):
         assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False) == o.stats()["weak_entries"]
     cfg = default_config(k, estimated_raw_kmers=20000 * 40)
     o, p = run_both(cfg, rb, min_depth=1, mode=3, long_list_chunks=chunks)      # singleton map kept
+    assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+    # extension values: the pieces' 16-bit tallies and packets go through the merge table's 32-bit ones
+    cfg = default_config(k, estimated_raw_kmers=20000 * 40, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2)
+    o, p = run_both(cfg, rb, min_depth=1, mode=3, long_list_chunks=chunks)
+    assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, True) == o.stats()["weak_entries"]
     assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
 
 

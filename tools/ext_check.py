@@ -7,10 +7,11 @@ from helpers import KMR_MAP_WEAK, KMR_VALUE_EXT
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 21
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
-bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev)
+quality = sys.argv[3] if len(sys.argv) > 3 else "flat"
+bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev, quality=quality)
 torch.cuda.synchronize()
 imgs = {}
-for mode in (2, 1):
+for mode in (3, 2, 1):
     sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2))
     for rep in range(2):
         sp.reset(); torch.cuda.synchronize(); t0 = time.time()
@@ -18,4 +19,4 @@ for mode in (2, 1):
         sp.finalize(2); dt = time.time() - t0
     st = sp.stats(); print("mode", mode, "k", k, "%.1f ms" % (dt * 1e3), "%.2f G kmers/s" % (st["raw_kmers"] / dt / 1e9), st, flush=True)
     imgs[mode] = sp.image(KMR_MAP_WEAK); del sp
-print("images identical:", np.array_equal(imgs[1], imgs[2]))
+print("images identical: 2 vs 1", np.array_equal(imgs[1], imgs[2]), " 3 vs 1", np.array_equal(imgs[1], imgs[3]))
