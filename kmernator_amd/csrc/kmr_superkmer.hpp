@@ -1265,6 +1265,7 @@ template <int W, int LOG2S, bool TRACK = false, bool EXT = false>
 __host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (TRACK ? 8 : 0) + (EXT ? 28 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
 /* a chunk of extension records holds at most ~6.4 k-mers per granule (n = 128: 21 granules): 128 chunks stay below 65 536 k-mers */
 static const uint64_t SK_EXT_LONG_CHUNKS = 128;
+static const int SK_EXT_BLOCKS = 3;      /* blocks per CU of the count pass with extension values (166 registers; four -- 128 registers, 34 dwords spilled -- ran 11 % slower) */
 __device__ __forceinline__ uint32_t sk_ext_char(uint32_t code) { return (uint32_t)((0x584e54474341ull >> (8 * code)) & 0xffu); }      /* "ACGTNX" */
 
 /* Life of a list in the block (round 3: two block barriers per list instead of eight):
@@ -1289,7 +1290,7 @@ static const unsigned long long SK_KEY_PENDING = ~0ull;
 static const unsigned long long SK_OSLAB = 2048;      /* entries a wavefront reserves at a time in the count pass's output */
 
 template <int W, int LOG2S, bool TRACK = false, bool EXT = false>
-__global__ __launch_bounds__(SKC_THREADS, EXT ? (W == 1 ? (LOG2S <= 9 ? 3 : 2) : 1) : ((W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 3 : 1)))
+__global__ __launch_bounds__(SKC_THREADS, EXT ? (W == 1 ? (LOG2S <= 9 ? SK_EXT_BLOCKS : 2) : 1) : ((W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 3 : 1)))
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
                      CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv, SkLong<W> lg) {
 	constexpr int S = 1 << LOG2S;
