@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--cpu-reads", type=int, default=1_000_000, help="reads of the CPU baseline's sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--h2d-pieces", type=int, default=4, help="pieces the packed PCIe-inclusive leg sends a batch in")
     ap.add_argument("--force-exchange", action="store_true", help="run the owner-exchange path even on one GPU (sanity/timing of the N>1 code)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="development: all ranks share GPU 0 and talk over gloo (RCCL refuses two "
                     "ranks on one device); exercises the N>1 code, its timings mean nothing")
@@ -267,56 +268,88 @@ def main():
     # ones they receive, so the flat-quality case -- nothing discarded -- is the one that can be checked there)
     assert args.no_check or raw_total == total_kmers or (exchange and mode_num != 3 and args.quality != "flat"), (raw_total, total_kmers)
 
-    # PCIe-inclusive leg (t_build from "first byte of in-memory reads available"): the reads start in pinned host memory
-    # and go to the device in eight pieces on a copy stream while the library's stream builds the pieces that have arrived
+    # PCIe-inclusive legs (t_build from "first byte of in-memory reads available"): the reads start in pinned host memory and
+    # go to the device in eight pieces on a copy stream while the library's stream builds the pieces that have arrived.  Twice: as
+    # text (kmr_add_reads_dev: a byte per base and per quality), and as the reference's Read keeps them (kmr_add_reads_twobit_dev:
+    # bases 2-bit packed, every read on bytes of its own; one quality character for all bases where the input has just one)
     h2d = None
     if not args.no_h2d and not exchange and rank == 0:
-        hb = torch.empty(total_bases, dtype=torch.uint8).pin_memory()
-        hq = torch.empty(total_bases, dtype=torch.uint8).pin_memory()
-        hb.copy_(bases[:total_bases])
-        hq.copy_(quals[:total_bases])
-        db = torch.empty_like(bases)
-        dq = torch.empty_like(quals)
-        db[total_bases:] = 0
-        dq[total_bases:] = 0
-        pieces = 8
-        per = (n_reads + pieces - 1) // pieces
         lib_stream = torch.cuda.ExternalStream(sp.stream(), device=dev)
         copy_stream = torch.cuda.Stream(device=dev)
+        uniform_q = args.quality == "flat"
+        PB = (READ_LEN + 3) // 4                                      # packed bytes per read
 
-        def h2d_step(copy_only=False):
-            sp.reset()
-            torch.cuda.synchronize()
-            evs = []
-            with torch.cuda.stream(copy_stream):
-                for c in range(pieces):
-                    lo, hi = c * per * READ_LEN, min(n_reads, (c + 1) * per) * READ_LEN
-                    db[lo:hi].copy_(hb[lo:hi], non_blocking=True)
-                    dq[lo:hi].copy_(hq[lo:hi], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(copy_stream)
-                    evs.append(ev)
-            if not copy_only:
-                for c in range(pieces):
-                    r0, r1 = c * per, min(n_reads, (c + 1) * per)
-                    lib_stream.wait_event(evs[c])
-                    sp.buildKmerSpectrumDevice(db.data_ptr(), dq.data_ptr(), offsets.data_ptr() + 8 * r0, r1 - r0, (r1 - r0) * READ_LEN, r0)
-                sp.finalize(2)
-            torch.cuda.synchronize()
+        def leg(packed, pieces):
+            per = (n_reads + pieces - 1) // pieces
+            hq = dq = None
+            if packed:
+                hb = torch.empty(n_reads * PB, dtype=torch.uint8).pin_memory()
+                for lo in range(0, n_reads, 1 << 20):                    # TwoBitSequence::compressSequence of every read (A C G T -> 0 1 2 3, first base in bits 7-6)
+                    m = min(1 << 20, n_reads - lo)
+                    c = bases[lo * READ_LEN:(lo + m) * READ_LEN].view(m, READ_LEN)
+                    c = ((c >> 1) & 3) ^ ((c >> 2) & 1)
+                    c = torch.nn.functional.pad(c, (0, PB * 4 - READ_LEN)).view(m, PB, 4)
+                    hb[lo * PB:(lo + m) * PB].copy_((c[:, :, 0] << 6 | c[:, :, 1] << 4 | c[:, :, 2] << 2 | c[:, :, 3]).reshape(-1))
+                db = torch.empty(n_reads * PB + 64, dtype=torch.uint8, device=dev)
+                tb_off = torch.arange(n_reads + 1, device=dev, dtype=torch.int64) * PB
+                unit = PB
+            else:
+                hb = torch.empty(total_bases, dtype=torch.uint8).pin_memory()
+                hb.copy_(bases[:total_bases])
+                db = torch.empty_like(bases)
+                db[total_bases:] = 0
+                unit = READ_LEN
+            if not (packed and uniform_q):
+                hq = torch.empty(total_bases, dtype=torch.uint8).pin_memory()
+                hq.copy_(quals[:total_bases])
+                dq = torch.empty_like(quals)
+                dq[total_bases:] = 0
+            nbytes = hb.numel() + (hq.numel() if hq is not None else 0)
 
-        h2d_step()
-        t1 = time.perf_counter()
-        for _ in range(max(1, args.steps)):
-            h2d_step()
-        t_incl = (time.perf_counter() - t1) / max(1, args.steps)
-        assert args.no_check or sp.stats()["raw_kmers"] == n_reads * kmers_per_read
-        t1 = time.perf_counter()
-        h2d_step(copy_only=True)
-        t_copy = time.perf_counter() - t1
-        h2d = {"value_incl_h2d": n_reads * kmers_per_read / t_incl, "ms_per_step_incl_h2d": t_incl * 1e3, "h2d_ms": t_copy * 1e3,
-               "h2d_GBps": 2.0 * total_bases / t_copy / 1e9,
-               "how": "bases + quals (%.1f GB) from pinned host memory in %d pieces on a copy stream, each piece built as it arrives" % (2.0 * total_bases / 1e9, pieces)}
-        del hb, hq, db, dq
+            def step(copy_only=False):
+                sp.reset()
+                torch.cuda.synchronize()
+                evs = []
+                with torch.cuda.stream(copy_stream):
+                    for c in range(pieces):
+                        r0, r1 = c * per, min(n_reads, (c + 1) * per)
+                        db[r0 * unit:r1 * unit].copy_(hb[r0 * unit:r1 * unit], non_blocking=True)
+                        if hq is not None:
+                            dq[r0 * READ_LEN:r1 * READ_LEN].copy_(hq[r0 * READ_LEN:r1 * READ_LEN], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
+                        evs.append(ev)
+                if not copy_only:
+                    for c in range(pieces):
+                        r0, r1 = c * per, min(n_reads, (c + 1) * per)
+                        lib_stream.wait_event(evs[c])
+                        if packed:
+                            sp.buildKmerSpectrumTwoBitDevice(db.data_ptr(), tb_off.data_ptr() + 8 * r0, offsets.data_ptr() + 8 * r0, r1 - r0, (r1 - r0) * READ_LEN,
+                                                             quals_ptr=None if dq is None else dq.data_ptr() + r0 * READ_LEN, uniform_quality=(33 + 40) if dq is None else 0, first_read_idx=r0)
+                        else:
+                            sp.buildKmerSpectrumDevice(db.data_ptr(), dq.data_ptr(), offsets.data_ptr() + 8 * r0, r1 - r0, (r1 - r0) * READ_LEN, r0)
+                    sp.finalize(2)
+                torch.cuda.synchronize()
+
+            step()
+            t1 = time.perf_counter()
+            for _ in range(max(1, args.steps)):
+                step()
+            t_incl = (time.perf_counter() - t1) / max(1, args.steps)
+            st = sp.stats()
+            assert args.no_check or (st["raw_kmers"] == n_reads * kmers_per_read and st["unique_kmers"] == uniq_local), (st, uniq_local)
+            t1 = time.perf_counter()
+            step(copy_only=True)
+            t_copy = time.perf_counter() - t1
+            return {"pieces": pieces, "value_incl_h2d": n_reads * kmers_per_read / t_incl, "ms_per_step_incl_h2d": t_incl * 1e3, "h2d_ms": t_copy * 1e3, "h2d_GB": nbytes / 1e9,
+                    "h2d_GBps": nbytes / t_copy / 1e9}
+
+        text = leg(False, 8)
+        text["how"] = "bases + quals as text (%.1f GB) from pinned host memory in %d pieces on a copy stream, each piece built as it arrives (kmr_add_reads_dev)" % (text["h2d_GB"], text["pieces"])
+        h2d = leg(True, args.h2d_pieces)
+        h2d["how"] = ("bases 2-bit packed as the reference's Read keeps them%s (%.2f GB) from pinned host memory in %d pieces on a copy stream, each piece unpacked and built "
+                      "on the device as it arrives (kmr_add_reads_twobit_dev)" % (", one quality character for all bases" if uniform_q else " + quals as text", h2d["h2d_GB"], h2d["pieces"]))
+        h2d["as_text"] = text
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

@@ -449,6 +449,27 @@ int kmr_reads_copy(const kmr_reads *r, char *bases, char *quals, uint64_t *offse
 int kmr_reads_twobit(kmr_handle *h, const kmr_reads *r, uint8_t *twobit, uint64_t twobit_capacity, uint64_t *twobit_offsets,
                      uint32_t *markup_pos, char *markup_char, uint64_t markup_capacity, uint64_t *markup_offsets,
                      uint64_t *twobit_bytes, uint64_t *n_markups);
+/* Feed a batch in the form the reference's Read keeps it (src/Sequence.h:166-171,287-289: bases as a TwoBitSequence -- 2 bits per base, every
+ * read on bytes of its own, first base in bits 7-6 -- plus markups for everything that is not ACGT, qualities as characters or
+ * none): what a ReadSet hands over without a string per read, and a quarter of the bytes of kmr_add_reads on the way to the
+ * device.  Replaces Read::getFasta / getQuals in front of KmerReadUtils::buildWeightedKmers (src/KmerReadUtils.h:176-190) and
+ * TwoBitSequence::uncompressSequence + applyMarkup (src/TwoBitSequence.cpp:286-340), which run on the device.
+ *   twobit / twobit_offsets   packed bases, read i = bytes [twobit_offsets[i], twobit_offsets[i+1]) (>= ceil(L_i / 4) of them; the layout
+ *                             kmr_reads_twobit writes); the device form takes NULL offsets when every read starts on the byte
+ *                             behind the one before it
+ *   offsets                   n_reads + 1 base offsets (read i has offsets[i+1] - offsets[i] bases), as for kmr_add_reads
+ *   markup_offsets / _pos / _char   optional: read i's markups are entries [markup_offsets[i], markup_offsets[i+1]), position and character
+ *   quals                     qualities indexed by offsets (host form; the device form: dev_quals[0] is the quality of the call's first
+ *                             base), or NULL and uniform_quality = the ONE quality character every base of the batch has (0: reads
+ *                             without qualities, weight 1.0 as kmr_add_reads with quals == NULL)
+ * Results are those of kmr_add_reads on the same reads.  The device form is asynchronous on the handle's stream like kmr_add_reads_dev. */
+int kmr_add_reads_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *twobit_offsets, const uint64_t *offsets,
+                         const uint64_t *markup_offsets, const uint32_t *markup_pos, const char *markup_char,
+                         const char *quals, int uniform_quality, uint64_t n_reads, uint64_t first_global_read_idx, const uint8_t *discarded);
+int kmr_add_reads_twobit_dev(kmr_handle *h, const void *dev_twobit, const void *dev_twobit_offsets, const void *dev_offsets,
+                             const void *dev_markup_offsets, const void *dev_markup_pos, const void *dev_markup_char,
+                             const void *dev_quals, int uniform_quality, uint64_t n_reads, uint64_t total_bases,
+                             uint64_t first_global_read_idx, const void *dev_discarded);
 /* kmr_add_reads_dev on the batch, then kmr_sync */
 int kmr_add_read_batch(kmr_handle *h, const kmr_reads *r, uint64_t first_global_read_idx);
 void kmr_reads_free(kmr_reads *r);

@@ -55,7 +55,7 @@ class KmrArtifactConfig(C.Structure):
 # every symbol include/kmernator_amd.h declares
 EXPORTS = [
     "kmr_abi_version", "kmr_config_init", "kmr_create", "kmr_destroy", "kmr_last_error", "kmr_num_buckets",
-    "kmr_add_reads", "kmr_add_reads_dev", "kmr_sync", "kmr_finalize", "kmr_get_stats", "kmr_lookup",
+    "kmr_add_reads", "kmr_add_reads_dev", "kmr_add_reads_twobit", "kmr_add_reads_twobit_dev", "kmr_sync", "kmr_finalize", "kmr_get_stats", "kmr_lookup",
     "kmr_lookup_reads", "kmr_image_size", "kmr_write_image", "kmr_load_image", "kmr_count_histogram",
     "kmr_dump_mercount", "kmr_dump_mergraph", "kmr_hash", "kmr_hash_of_kind", "kmr_bucket_idx", "kmr_local_thread_id",
     "kmr_distributed_thread_id", "kmr_compress_sequence", "kmr_least_complement", "kmr_extract_by_owner_dev",
@@ -89,6 +89,8 @@ def load():
     lib.kmr_num_buckets.argtypes = [vp, C.c_int, u64p]
     lib.kmr_add_reads.argtypes = [vp, vp, vp, u64p, C.c_uint64, C.c_uint64, u8p]
     lib.kmr_add_reads_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    lib.kmr_add_reads_twobit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_uint64, C.c_uint64, vp]
+    lib.kmr_add_reads_twobit_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     lib.kmr_sync.argtypes = [vp]
     lib.kmr_finalize.argtypes = [vp, C.c_uint32]
     lib.kmr_get_stats.argtypes = [vp, C.POINTER(KmrStats)]

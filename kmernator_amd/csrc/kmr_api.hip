@@ -133,6 +133,10 @@ struct kmr_handle {
 	/* work units of batches that contain reads longer than one tile */
 	uint32_t *ucnt = nullptr; uint64_t *ufirst = nullptr, *u_start = nullptr, *u_end = nullptr, *u_read = nullptr;
 	uint64_t ucnt_n = 0, ufirst_n = 0, units_n = 0; unsigned int *umax = nullptr;
+	/* kmr_add_reads_twobit*: the unpacked batch (ASCII bases, one quality character throughout, offsets counted from the call's first read) */
+	uint8_t *tb_bases = nullptr, *tb_quals = nullptr; uint64_t *tb_rel = nullptr, *tb_off = nullptr; uint32_t *tb_len = nullptr;
+	uint64_t tb_bases_cap = 0, tb_quals_cap = 0, tb_quals_filled = 0, tb_n = 0; int tb_quals_char = -1;
+	int uniform_q_hint = -1;           /* >= 0 while kmr_add_reads_twobit_dev feeds a batch whose qualities are this one character */
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr, *us_pkt = nullptr; uint64_t uw_cap = 0, us_cap = 0;
 	/* build_mode 3: the count pass's weak entries packed (kmr_buckets.hpp: W key words + one value word), and the radix partition's scratch of the same layout */
 	uint64_t *ue = nullptr, *ue2 = nullptr; uint64_t ue_cap = 0, ue2_cap = 0;
@@ -1430,6 +1434,13 @@ int sk_uniform_weight(kmr_handle *h, const ReadsView &rv, bool &lean, float &wK)
 	if (h->tune.no_lean_extract) return 0;
 	if (!rv.quals) { lean = true; return 0; }
 	if (h->qual_mixed || rv.n_reads == 0) return 0;
+	if (h->uniform_q_hint >= 0) {      /* the caller said so (kmr_add_reads_twobit*): no pass over the quality bytes, no round trip */
+		const unsigned int q0 = (unsigned int)h->uniform_q_hint;
+		if (q0 == 127) { lean = true; wK = 1.0f; return 0; }
+		if (!(h->hP[q0] > 0.0)) return 0;
+		lean = true; wK = (float)h->hPk[q0];
+		return 0;
+	}
 	if (!h->qrange) HIPCHK(h, hipMalloc((void **)&h->qrange, 8));
 	const unsigned int init[2] = {255u, 0u};
 	HIPCHK(h, hipMemcpyAsync(h->qrange, init, 8, hipMemcpyHostToDevice, h->stream));
@@ -1841,6 +1852,8 @@ void free_partition_state(kmr_handle *h) {
 	if (h->work_counter) hipFree(h->work_counter); if (h->linear) hipFree(h->linear); if (h->tile_count) hipFree(h->tile_count);
 	if (h->kcap) hipFree(h->kcap); if (h->koff) hipFree(h->koff);
 	if (h->ucnt) hipFree(h->ucnt); if (h->ufirst) hipFree(h->ufirst); if (h->u_start) { hipFree(h->u_start); hipFree(h->u_end); hipFree(h->u_read); } if (h->umax) hipFree(h->umax);
+	if (h->tb_bases) hipFree(h->tb_bases); if (h->tb_quals) hipFree(h->tb_quals); if (h->tb_rel) hipFree(h->tb_rel); if (h->tb_off) hipFree(h->tb_off); if (h->tb_len) hipFree(h->tb_len);
+	h->tb_bases = h->tb_quals = nullptr; h->tb_rel = h->tb_off = nullptr; h->tb_len = nullptr; h->tb_bases_cap = h->tb_quals_cap = h->tb_quals_filled = h->tb_n = 0; h->tb_quals_char = -1;
 	h->ucnt = nullptr; h->ufirst = nullptr; h->u_start = h->u_end = h->u_read = nullptr; h->umax = nullptr; h->ucnt_n = h->ufirst_n = h->units_n = 0;
 	if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt);
 	h->us_pkt = nullptr; h->work_counter = nullptr; h->linear = nullptr; h->tile_count = nullptr; h->kcap = nullptr; h->koff = nullptr;
@@ -2095,6 +2108,95 @@ int kmr_add_reads(kmr_handle *h, const char *bases, const char *quals, const uin
 	if (!rc) rc = sync_state(h);
 	else hipStreamSynchronize(h->stream);
 	s.release();
+	return rc;
+}
+
+int kmr_add_reads_twobit_dev(kmr_handle *h, const void *dev_twobit, const void *dev_twobit_offsets, const void *dev_offsets,
+                             const void *dev_markup_offsets, const void *dev_markup_pos, const void *dev_markup_char,
+                             const void *dev_quals, int uniform_quality, uint64_t n_reads, uint64_t total_bases,
+                             uint64_t first_global_read_idx, const void *dev_discarded) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_add_reads after kmr_finalize");
+	if (n_reads == 0) return KMR_OK;
+	if (!dev_twobit || !dev_offsets) return fail(h, KMR_ERR_INVALID_ARG, "null device buffer");
+	if (dev_markup_offsets && (!dev_markup_pos || !dev_markup_char)) return fail(h, KMR_ERR_INVALID_ARG, "markup offsets without markups");
+	if (uniform_quality < 0 || uniform_quality > 255 || (dev_quals && uniform_quality)) return fail(h, KMR_ERR_INVALID_ARG, "uniform_quality: 0, or the one quality character of a batch without a quality array");
+	hipSetDevice(h->device);
+	/* grow-only scratch of the handle; everything below is ordered on the handle's stream, so the next call's unpack waits for
+	 * this call's extraction */
+	if (h->tb_bases_cap < total_bases + 64) {
+		if (h->tb_bases) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->tb_bases); h->tb_bases = nullptr; h->tb_bases_cap = 0; }
+		HIPCHK(h, hipMalloc((void **)&h->tb_bases, total_bases + 64)); h->tb_bases_cap = total_bases + 64;
+		HIPCHK(h, hipMemsetAsync(h->tb_bases, 0, total_bases + 64, h->stream));
+	}
+	if (h->tb_n < n_reads + 1) {
+		if (h->tb_rel) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->tb_rel); hipFree(h->tb_off); hipFree(h->tb_len); h->tb_rel = h->tb_off = nullptr; h->tb_len = nullptr; h->tb_n = 0; }
+		HIPCHK(h, hipMalloc((void **)&h->tb_rel, 8 * (n_reads + 1))); HIPCHK(h, hipMalloc((void **)&h->tb_off, 8 * (n_reads + 1))); HIPCHK(h, hipMalloc((void **)&h->tb_len, 4 * (n_reads + 1)));
+		h->tb_n = n_reads + 1;
+	}
+	const uint64_t *tboff = (const uint64_t *)dev_twobit_offsets;
+	if (!tboff) {      /* every read on the byte behind the one before it: ceil(L / 4) bytes each */
+		hipLaunchKernelGGL(twobit_bytes_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, (const uint64_t *)dev_offsets, n_reads, h->tb_len);
+		HIPCHK(h, hipGetLastError());
+		int rc = exclusive_scan(h, h->tb_len, n_reads, h->tb_off); if (rc) return rc;
+		tboff = h->tb_off;
+	}
+	hipLaunchKernelGGL(twobit_unpack_kernel, dim3((unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)num_cus(h) * 32)), dim3(256), 0, h->stream,
+	                   (const uint8_t *)dev_twobit, tboff, (const uint64_t *)dev_offsets, n_reads, h->tb_bases, h->tb_rel);
+	HIPCHK(h, hipGetLastError());
+	if (dev_markup_offsets) {
+		hipLaunchKernelGGL(twobit_markup_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, (const uint64_t *)dev_markup_offsets, (const uint32_t *)dev_markup_pos,
+		                   (const uint8_t *)dev_markup_char, (const uint64_t *)h->tb_rel, n_reads, h->tb_bases);
+		HIPCHK(h, hipGetLastError());
+	}
+	const void *q = dev_quals;
+	if (!dev_quals && uniform_quality) {
+		if (h->tb_quals_cap < total_bases + 64) {
+			if (h->tb_quals) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->tb_quals); h->tb_quals = nullptr; h->tb_quals_cap = 0; }
+			HIPCHK(h, hipMalloc((void **)&h->tb_quals, total_bases + 64)); h->tb_quals_cap = total_bases + 64; h->tb_quals_filled = 0; h->tb_quals_char = -1;
+		}
+		if (h->tb_quals_char != uniform_quality || h->tb_quals_filled < total_bases) {      /* (a buffer the last call filled with the same character stands) */
+			HIPCHK(h, hipMemsetAsync(h->tb_quals, uniform_quality, h->tb_quals_cap, h->stream));
+			h->tb_quals_char = uniform_quality; h->tb_quals_filled = h->tb_quals_cap;
+		}
+		q = h->tb_quals;
+	}
+	/* (dev_quals[0] is the quality of the call's first base: the unpacked batch and its offsets start there too) */
+	h->uniform_q_hint = (!dev_quals && uniform_quality) ? uniform_quality : -1;
+	const int rc = kmr_add_reads_dev(h, h->tb_bases, q, h->tb_rel, n_reads, total_bases, first_global_read_idx, dev_discarded);
+	h->uniform_q_hint = -1;
+	return rc;
+}
+
+int kmr_add_reads_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *twobit_offsets, const uint64_t *offsets,
+                         const uint64_t *markup_offsets, const uint32_t *markup_pos, const char *markup_char,
+                         const char *quals, int uniform_quality, uint64_t n_reads, uint64_t first_global_read_idx, const uint8_t *discarded) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_add_reads after kmr_finalize");
+	if (n_reads == 0) return KMR_OK;
+	if (!twobit || !twobit_offsets || !offsets) return fail(h, KMR_ERR_INVALID_ARG, "null buffer");
+	hipSetDevice(h->device);
+	const uint64_t total = offsets[n_reads] - offsets[0], tbytes = twobit_offsets[n_reads] - twobit_offsets[0], nm = markup_offsets ? markup_offsets[n_reads] - markup_offsets[0] : 0;
+	std::vector<void *> owned;
+	auto release = [&]() { for (void *p : owned) hipFree(p); owned.clear(); };
+	auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
+		hipError_t e = hipMalloc(dst, std::max<size_t>(bytes + 64, 256)); if (e != hipSuccess) return e;
+		owned.push_back(*dst);
+		return bytes ? hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+	};
+#define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->stream); release(); h->err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+	void *dtb = nullptr, *dto = nullptr, *doff = nullptr, *dmo = nullptr, *dmp = nullptr, *dmc = nullptr, *dq = nullptr, *dd = nullptr;
+	std::vector<uint64_t> rel(n_reads + 1), trel(n_reads + 1), mrel(markup_offsets ? n_reads + 1 : 0);
+	for (uint64_t i = 0; i <= n_reads; i++) { rel[i] = offsets[i] - offsets[0]; trel[i] = twobit_offsets[i] - twobit_offsets[0]; if (markup_offsets) mrel[i] = markup_offsets[i] - markup_offsets[0]; }
+	TBCHK(up(twobit + twobit_offsets[0], tbytes, &dtb)); TBCHK(up(trel.data(), 8 * (n_reads + 1), &dto)); TBCHK(up(rel.data(), 8 * (n_reads + 1), &doff));
+	if (markup_offsets && nm) { TBCHK(up(mrel.data(), 8 * (n_reads + 1), &dmo)); TBCHK(up(markup_pos + markup_offsets[0], 4 * nm, &dmp)); TBCHK(up(markup_char + markup_offsets[0], nm, &dmc)); }
+	if (quals) TBCHK(up(quals + offsets[0], total, &dq));
+	if (discarded) TBCHK(up(discarded, n_reads, &dd));
+#undef TBCHK
+	int rc = kmr_add_reads_twobit_dev(h, dtb, dto, doff, dmo, dmp, dmc, dq, quals ? 0 : uniform_quality, n_reads, total, first_global_read_idx, dd);
+	if (!rc) rc = sync_state(h);
+	else hipStreamSynchronize(h->stream);
+	release();
 	return rc;
 }
 

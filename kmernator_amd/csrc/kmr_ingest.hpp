@@ -268,6 +268,72 @@ __global__ void twobit_pack_kernel(const uint8_t *bases, const uint64_t *offsets
 	}
 }
 
+/* ---- the way back: reads as the reference's Read keeps them (2-bit packed, every read on a byte of its own, + markups) -> the ASCII
+ * batch the extraction kernels take.  Replaces TwoBitSequence::uncompressSequence + applyMarkup (src/TwoBitSequence.cpp:286-340)
+ * over a whole batch. */
+__global__ void twobit_bytes_kernel(const uint64_t *offsets, uint64_t n, uint32_t *packed_len) {
+	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) packed_len[r] = (uint32_t)((offsets[r + 1] - offsets[r] + 3) / 4);
+}
+/* a wavefront takes reads one after the other, a lane per ALIGNED output dword (four bases from two packed bytes); the bytes before the first and behind
+ * the last aligned dword of a read share their dword with its neighbours and are stored one by one.  rel[] = the reads' base
+ * offsets counted from the first read of the call (what the unpacked batch is indexed by). */
+__device__ __forceinline__ uint32_t twobit_char(uint32_t code) { return (0x54474341u >> (8 * code)) & 0xffu; }      /* "ACGT" */
+__global__ __launch_bounds__(256)
+void twobit_unpack_kernel(const uint8_t *__restrict__ twobit, const uint64_t *__restrict__ tb_off, const uint64_t *__restrict__ offsets, uint64_t n, uint8_t *__restrict__ out, uint64_t *__restrict__ rel) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+	const uint64_t o0 = offsets[0];
+	if (wave == 0 && lane == 0) rel[n] = offsets[n] - o0;
+	/* 64 reads per wavefront and round: their offsets arrive with one coalesced load each and are handed round by readlane, and the
+	 * packed bytes of four reads are asked for before the first of them is written out */
+	auto bcast = [&](uint64_t v, uint32_t q) -> uint64_t { return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), (int)q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)q); };
+	for (uint64_t r0 = wave * 64; r0 < n; r0 += nwaves * 64) {
+		const uint64_t rr = r0 + lane < n ? r0 + lane : n - 1;
+		const uint64_t myA = offsets[rr] - o0, myL = offsets[rr + 1] - offsets[rr], myT = tb_off[rr];
+		if (r0 + lane < n) rel[r0 + lane] = myA;
+		const uint32_t cnt = (uint32_t)(n - r0 < 64 ? n - r0 : 64);
+		for (uint32_t q0 = 0; q0 < cnt; q0 += 4) {
+			uint64_t a[4], L[4], h[4], nd[4]; const uint8_t *src[4]; uint32_t v[4], hb[4], tb[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const uint32_t q = q0 + u < cnt ? q0 + u : cnt - 1;
+				a[u] = bcast(myA, q); L[u] = q0 + u < cnt ? bcast(myL, q) : 0; src[u] = twobit + bcast(myT, q);
+				const uint64_t head = (4 - (a[u] & 3)) & 3;
+				h[u] = head < L[u] ? head : L[u]; nd[u] = (L[u] - h[u]) / 4;
+				v[u] = 0; hb[u] = 0; tb[u] = 0;
+				/* the first 64 aligned dwords of the read (a read of up to 259 bases: all of it), its head and tail bytes */
+				if (lane < nd[u]) { const uint64_t j = h[u] + 4 * lane; v[u] = (uint32_t)src[u][j >> 2] << 8; if (j & 3) v[u] |= src[u][(j >> 2) + 1]; }
+				if (lane < h[u]) hb[u] = src[u][0];
+				const uint64_t t0 = h[u] + 4 * nd[u];
+				if (t0 + lane < L[u]) tb[u] = src[u][(t0 + lane) >> 2];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				if (lane < nd[u]) {
+					const uint64_t j = h[u] + 4 * lane; const uint32_t s2 = 2 * (uint32_t)(j & 3);
+					const uint32_t four = (v[u] >> (8 - s2)) & 0xffu;           /* first base in bits 7-6 */
+					*(uint32_t *)(out + a[u] + j) = twobit_char(four >> 6) | (twobit_char((four >> 4) & 3u) << 8) | (twobit_char((four >> 2) & 3u) << 16) | (twobit_char(four & 3u) << 24);
+				}
+				if (lane < h[u]) out[a[u] + lane] = (uint8_t)twobit_char((hb[u] >> (6 - 2 * lane)) & 3u);
+				const uint64_t t0 = h[u] + 4 * nd[u];
+				if (t0 + lane < L[u]) out[a[u] + t0 + lane] = (uint8_t)twobit_char((tb[u] >> (6 - 2 * (uint32_t)((t0 + lane) & 3))) & 3u);
+				for (uint64_t d = 64 + lane; d < nd[u]; d += 64) {      /* longer reads: the rest, dword by dword */
+					const uint64_t j = h[u] + 4 * d; const uint32_t s2 = 2 * (uint32_t)(j & 3);
+					uint32_t w = (uint32_t)src[u][j >> 2] << 8; if (s2) w |= src[u][(j >> 2) + 1];
+					const uint32_t four = (w >> (8 - s2)) & 0xffu;
+					*(uint32_t *)(out + a[u] + j) = twobit_char(four >> 6) | (twobit_char((four >> 4) & 3u) << 8) | (twobit_char((four >> 2) & 3u) << 16) | (twobit_char(four & 3u) << 24);
+				}
+			}
+		}
+	}
+}
+__global__ void twobit_markup_kernel(const uint64_t *mk_off, const uint32_t *mk_pos, const uint8_t *mk_char, const uint64_t *rel, uint64_t n, uint8_t *out) {
+	for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t L = rel[r + 1] - rel[r];
+		for (uint64_t m = mk_off[r]; m < mk_off[r + 1]; m++) if (mk_pos[m] < L) out[rel[r] + mk_pos[m]] = mk_char[m];
+	}
+}
+
 __global__ void ingest_shift_quals(uint8_t *quals, uint64_t n, int delta) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) quals[i] = (uint8_t)(quals[i] + delta);
 }

@@ -92,6 +92,28 @@ class KmerSpectrum:
         """Same, device pointers (torch tensor .data_ptr()); asynchronous, see sync()."""
         self._call("add_reads_dev", self.h, bases_ptr, quals_ptr, offsets_ptr, n_reads, total_bases, first_read_idx, discarded_ptr)
 
+    def buildKmerSpectrumTwoBit(self, twobit, twobit_offsets, offsets, quals=None, uniform_quality=0, markups=None, first_read_idx=0, discarded=None):
+        """KmerSpectrum::buildKmerSpectrum(const ReadSet&) on reads kept as the reference's Read keeps them: 2-bit packed bases (every read on
+        bytes of its own) + markups (positions, chars, offsets[n+1]) + qualities (an array, or one character for all, or none)
+        -- kmr_add_reads_twobit, host arrays"""
+        tw = _u8(twobit)
+        to = np.ascontiguousarray(twobit_offsets, dtype=np.uint64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        q = None if quals is None else _u8(quals)
+        d = None if discarded is None else _u8(discarded)
+        mp = mc = mo = None
+        if markups is not None:
+            mp = np.ascontiguousarray(markups[0], dtype=np.uint32); mc = _u8(markups[1]); mo = np.ascontiguousarray(markups[2], dtype=np.uint64)
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        self._call("add_reads_twobit", self.h, vp(tw), vp(to), vp(offsets), vp(mo), vp(mp), vp(mc), vp(q), int(uniform_quality), n, first_read_idx, vp(d))
+
+    def buildKmerSpectrumTwoBitDevice(self, twobit_ptr, twobit_offsets_ptr, offsets_ptr, n_reads, total_bases, quals_ptr=None, uniform_quality=0,
+                                      markup_offsets_ptr=None, markup_pos_ptr=None, markup_char_ptr=None, first_read_idx=0, discarded_ptr=None):
+        """Same, device pointers (kmr_add_reads_twobit_dev); asynchronous, see sync().  quals_ptr points at the quality of the call's first base."""
+        self._call("add_reads_twobit_dev", self.h, twobit_ptr, twobit_offsets_ptr, offsets_ptr, markup_offsets_ptr, markup_pos_ptr, markup_char_ptr,
+                   quals_ptr, int(uniform_quality), n_reads, total_bases, first_read_idx, discarded_ptr)
+
     def buildKmerSpectrumFromReadSet(self, read_set, first_read_idx=0):
         """KmerSpectrum::buildKmerSpectrum(const ReadSet&) on a device-resident ReadSet (kmr_add_read_batch)."""
         self._call("add_read_batch", self.h, read_set.r, first_read_idx)

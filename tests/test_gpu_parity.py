@@ -1037,6 +1037,58 @@ def test_long_lists_counted_in_pieces(k, chunks):
     assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
 
 
+def _pack_twobit(rb):
+    """the reads of a ReadBatch as TwoBitSequence::compressSequence leaves them (src/TwoBitSequence.cpp:242-269): per read ceil(L / 4) bytes,
+    first base in bits 7-6, anything but ACGT packed as A and written down as a markup ('.' as 'N')"""
+    code = np.full(256, 4, dtype=np.uint8)
+    for c, v in zip(b"ACGTacgt", (0, 1, 2, 3, 0, 1, 2, 3)):
+        code[c] = v
+    tw, to, mp, mc, mo = [], [0], [], [], [0]
+    for i in range(rb.n):
+        a, b = int(rb.offsets[i]), int(rb.offsets[i + 1])
+        cs = code[rb.bases[a:b]]
+        for j in np.nonzero(cs == 4)[0]:
+            mp.append(int(j)); mc.append(ord("N") if rb.bases[a + j] == ord(".") else int(rb.bases[a + j]))
+        cs = np.where(cs == 4, 0, cs).astype(np.uint8)
+        pad = (-len(cs)) % 4
+        cs = np.concatenate([cs, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+        tw.append((cs[:, 0] << 6 | cs[:, 1] << 4 | cs[:, 2] << 2 | cs[:, 3]).astype(np.uint8))
+        to.append(to[-1] + len(tw[-1])); mo.append(len(mp))
+    return (np.concatenate(tw) if tw else np.zeros(0, np.uint8), np.array(to, np.uint64), (np.array(mp, np.uint32), np.array(mc, np.uint8), np.array(mo, np.uint64)))
+
+
+@pytest.mark.parametrize("mode", [3, 2])
+@pytest.mark.parametrize("quals", ["array", "uniform", "none"])
+def test_twobit_feed_equals_ascii_feed(mode, quals):
+    """kmr_add_reads_twobit: reads handed over as the reference's Read keeps them (2-bit packed + markups, src/Sequence.h:166-171) must build
+    the spectrum kmr_add_reads builds from their text -- ragged lengths (0, 1, k - 1, k, 4 m + 1 ...), N's and lower case, qualities as an
+    array / one character for every base / none, fed in two calls; and that spectrum is the oracle's"""
+    k = 31
+    rng = np.random.default_rng(5)
+    rb0 = synth_reads(3000, read_len=150, genome_len=30000, seed=44, quality="noisy" if quals == "array" else "flat", n_rate=0.003)
+    seqs, qs = [], []
+    for i in range(rb0.n):
+        L = int(rng.choice([150, 149, 147, 121, 33, 31, 30, 5, 1, 0], p=[0.5, 0.1, 0.1, 0.1, 0.05, 0.05, 0.04, 0.03, 0.02, 0.01]))
+        s = bytes(rb0.seq(i)[:L]); q = bytes(rb0.qual(i)[:L])
+        if i % 17 == 0: s = s.lower()
+        seqs.append(s); qs.append(q)
+    rb = ReadBatch(seqs, qs if quals == "array" else ([b"I" * len(s) for s in seqs] if quals == "uniform" else None))
+    cfg = default_config(k, estimated_raw_kmers=3000 * 120)
+    o = OracleSpectrum(cfg); o.add_reads(rb); o.finalize(1)
+    pa = product(cfg, mode); add(pa, rb); pa.finalize(1)
+    pt = product(cfg, mode)
+    half = rb.n // 2
+    for part, first in ((rb.slice(0, half), 0), (rb.slice(half, rb.n), half)):
+        tw, to, mk = _pack_twobit(part)
+        pt.buildKmerSpectrumTwoBit(tw, to, part.offsets, quals=part.quals if quals == "array" else None, uniform_quality=ord("I") if quals == "uniform" else 0,
+                                   markups=mk, first_read_idx=first)
+    pt.finalize(1)
+    assert pa.stats() == pt.stats() == o.stats()
+    for which in (KMR_MAP_WEAK, KMR_MAP_SINGLETON):
+        assert np.array_equal(pa.image(which), pt.image(which))
+    assert compare_weak_images(o.image(KMR_MAP_WEAK), pt.image(KMR_MAP_WEAK), pt.kb, False) == o.stats()["weak_entries"]
+
+
 @pytest.mark.parametrize("mode", [3, 2])
 def test_build_score_reset_build_again(mode):
     """the streaming lookups borrow the handle's list pool and list state after kmr_finalize: a kmr_reset and a second build on the same
