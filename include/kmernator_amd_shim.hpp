@@ -24,7 +24,7 @@
  *   apps/FilterReads-P.cpp:110      KS spectrum(world, rawKmers) -> GpuDistributedKmerSpectrum<KS> spectrum(world, rawKmers)
  *   apps/CMakeLists.txt        target_link_libraries(<tool> kmernator_amd), -I<this repo>/include, -DKMERNATOR_AMD_SHIM_MPI for the -P tools
  *
- * buildKmerSpectrum() flattens the ReadSet into the arrays kmr_add_reads takes, runs the build on the MI355X and fills weak
+ * buildKmerSpectrum() hands the ReadSet over as it keeps its reads (2-bit packed bases + markups, kmr_add_reads_twobit), runs the build on the MI355X and fills weak
  * (and singleton) -- the reference's OWN map objects -- from the images the library writes in the store() layout
  * (src/Kmer.h:3143-3159) through the copying constructor KmerMapByKmerArrayPair(const void *) (src/Kmer.h:3124-3135), exactly
  * as KmerSpectrum::restoreMmap does (src/KmerSpectrum.h:489-518).  Everything downstream (optimize, trackSpectrum, histogram,
@@ -85,12 +85,15 @@ public:
 	virtual void buildKmerSpectrum(const ReadSet &store) { buildKmerSpectrum(store, false); }
 	virtual void buildKmerSpectrum(const ReadSet &store, bool isSolid) {
 		if (isSolid) { KS::buildKmerSpectrum(store, isSolid); return; }       /* solid map: not on this path */
-		FlatReads fr;
-		flatten(store, fr, true);
+		/* the reads go over as the ReadSet keeps them -- 2-bit packed bases and markups (src/Sequence.h:166-171), no string per read -- and
+		 * are unpacked on the device (kmr_add_reads_twobit); qualities as characters, or Read::REF_QUAL for all when no read has any */
+		PackedReads pr;
+		flattenTwoBit(store, pr, 0, store.getSize());
 		ensureHandle();
 		check(kmr_reset(_handle.get()), "kmr_reset");
-		check(kmr_add_reads(_handle.get(), fr.bases.data(), fr.anyQuals ? fr.quals.data() : NULL, &fr.offsets[0], store.getSize(), 0,
-		                    fr.discarded.empty() ? NULL : &fr.discarded[0]), "kmr_add_reads");
+		check(kmr_add_reads_twobit(_handle.get(), pr.twobit.empty() ? (const uint8_t *)"" : &pr.twobit[0], &pr.twobitOffsets[0], &pr.offsets[0],
+		                           pr.markupPos.empty() ? NULL : &pr.markupOffsets[0], pr.markupPos.empty() ? NULL : &pr.markupPos[0], pr.markupPos.empty() ? NULL : &pr.markupChar[0],
+		                           pr.anyQuals ? pr.quals.data() : NULL, 0, store.getSize(), 0, &pr.discarded[0]), "kmr_add_reads_twobit");
 		pull(KmerSpectrumOptions::getOptions().getMinDepth());
 	}
 
@@ -169,6 +172,36 @@ protected:
 			if (skipDiscarded) fr.discarded.push_back(dis ? 1 : 0);
 			if (!(skipDiscarded && dis)) { fr.bases += read.getFasta(); fr.quals += read.getQuals(); fr.anyQuals = true; }
 			fr.offsets.push_back(fr.bases.size());
+		}
+	}
+	struct PackedReads {
+		std::vector<uint8_t> twobit, discarded; std::string quals; std::vector<char> markupChar; std::vector<uint32_t> markupPos;
+		std::vector<uint64_t> twobitOffsets, offsets, markupOffsets;
+		bool anyQuals;
+		PackedReads() : twobitOffsets(1, 0), offsets(1, 0), markupOffsets(1, 0), anyQuals(false) {}
+	};
+	/* the arrays kmr_add_reads_twobit takes, straight from the reads' own storage: Sequence::getTwoBitSequence / getMarkups
+	 * (src/Sequence.h:280-289); a discarded read is handed over empty */
+	static void flattenTwoBit(const ReadSet &store, PackedReads &pr, ReadSet::ReadSetSizeType lo, ReadSet::ReadSetSizeType hi) {
+		bool someQuals = false, someWithout = false;
+		for (ReadSet::ReadSetSizeType i = lo; i < hi; i++) { const Read &read = store.getRead(i); if (read.isDiscarded()) continue; if (read.hasQuals()) someQuals = true; else someWithout = true; }
+		pr.anyQuals = someQuals;      /* (a mix: the reads without get their REF_QUAL string, as getQuals() gives it) */
+		(void)someWithout;
+		for (ReadSet::ReadSetSizeType i = lo; i < hi; i++) {
+			const Read &read = store.getRead(i);
+			const bool dis = read.isDiscarded();
+			pr.discarded.push_back(dis ? 1 : 0);
+			if (!dis) {
+				const uint32_t nb = read.getTwoBitEncodingSequenceLength();
+				const uint8_t *tb = (const uint8_t *)read.getTwoBitSequence();
+				pr.twobit.insert(pr.twobit.end(), tb, tb + nb);
+				const Read::BaseLocationVectorType mk = read.getMarkups();
+				for (size_t m = 0; m < mk.size(); m++) { pr.markupChar.push_back(mk[m].first); pr.markupPos.push_back((uint32_t)mk[m].second); }
+				if (pr.anyQuals) { const std::string q = read.getQuals(); pr.quals += q.size() == read.getLength() ? q : std::string(read.getLength(), (char)127); }
+			}
+			pr.twobitOffsets.push_back(pr.twobit.size());
+			pr.offsets.push_back(pr.offsets.back() + (dis ? 0 : read.getLength()));
+			pr.markupOffsets.push_back(pr.markupPos.size());
 		}
 	}
 	static std::string trimLabel(uint32_t off, uint32_t len) { std::ostringstream ss; ss << "AFTrim:" << off << "+" << len; return ss.str(); }

@@ -16,6 +16,7 @@
 
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace Kmernator { typedef uint32_t ReadSetSizeType; }
@@ -56,6 +57,14 @@ public:
 	inline bool isDiscarded() const { return _discarded; }                        /* :243 */
 	inline void discard() const { _discarded = true; }                            /* :254: "permitted even on a constant" */
 	uint32_t getLength() const { return (uint32_t)_fasta.size(); }                /* :258 (SequenceLengthType) */
+	inline bool hasQuals() const { return !_quals.empty(); }                      /* :241 */
+	/* the form the reference keeps a sequence in (:166-171): TwoBitSequence::compressSequence of the text (src/TwoBitSequence.cpp:242-269) */
+	typedef unsigned char TwoBitEncoding;                                         /* src/TwoBitSequence.h:66 */
+	typedef std::pair<char, uint32_t> BaseLocationType;                           /* src/TwoBitSequence.h:80-81 */
+	typedef std::vector<BaseLocationType> BaseLocationVectorType;
+	uint32_t getTwoBitEncodingSequenceLength() const { return (uint32_t)((_fasta.size() + 3) / 4); }   /* :287 */
+	const TwoBitEncoding *getTwoBitSequence() const { pack(); return _twobit.empty() ? NULL : &_twobit[0]; }   /* :289 */
+	BaseLocationVectorType getMarkups() const { pack(); return _markups; }       /* :280 */
 	std::string getFasta(uint32_t trimOffset = 0, uint32_t trimLength = 0xffffffffu) const { return trimOffset < _fasta.size() ? _fasta.substr(trimOffset, trimLength) : std::string(); }   /* :273 */
 	std::string getQuals(uint32_t trimOffset = 0, uint32_t trimLength = 0xffffffffu) const { return trimOffset < _quals.size() ? _quals.substr(trimOffset, trimLength) : std::string(); }   /* :498 */
 	Read getTrimRead(uint32_t trimOffset, uint32_t trimLength, std::string label = "", std::string nameSuffix = "", bool unmasked = false) {   /* :485 */
@@ -64,7 +73,18 @@ public:
 	}
 	const std::string &getName() const { return _name; }
 private:
+	void pack() const {
+		if (_twobit.size() == (_fasta.size() + 3) / 4 && (!_twobit.empty() || _fasta.empty())) return;
+		_twobit.assign((_fasta.size() + 3) / 4, 0); _markups.clear();
+		for (size_t i = 0; i < _fasta.size(); i++) {
+			unsigned code = 0;
+			switch (_fasta[i]) { case 'A': case 'a': code = 0; break; case 'C': case 'c': code = 1; break; case 'G': case 'g': code = 2; break; case 'T': case 't': code = 3; break;
+			default: _markups.push_back(BaseLocationType(_fasta[i] == '.' ? 'N' : _fasta[i], (uint32_t)i)); }
+			_twobit[i >> 2] = (TwoBitEncoding)(_twobit[i >> 2] | (code << (6 - 2 * (i & 3))));
+		}
+	}
 	std::string _name, _fasta, _quals;
+	mutable std::vector<TwoBitEncoding> _twobit; mutable BaseLocationVectorType _markups;
 	mutable bool _discarded;
 };
 
