@@ -21,7 +21,7 @@ for mode in modes:
         sp.reset(); sp.kernel_time_reset(); torch.cuda.synchronize(); t0 = time.time()
         sp.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * L, 0)
         sp.sync(); t1 = time.time(); sp.finalize(2); dt = time.time() - t0
-        print("  rep", rep, "build %.1f ms finalize %.1f ms" % ((t1 - t0) * 1e3, (time.time() - t1) * 1e3), "kernel groups", [round(sp.kernel_time(g)[0], 1) for g in range(7)], flush=True)
+        print("  rep", rep, "build %.1f ms finalize %.1f ms" % ((t1 - t0) * 1e3, (time.time() - t1) * 1e3), "kernel groups", [round(sp.kernel_time(g)[0], 1) for g in range(7)], "launches", [sp.kernel_time(g)[1] for g in range(7)], flush=True)
     st = sp.stats(); print("mode", mode, "k", k, "%d x %d bp: %.1f ms" % (n, L, dt * 1e3), "%.2f G kmers/s" % (st["raw_kmers"] / dt / 1e9), st, flush=True)
     if len(modes) > 1:
         imgs[mode] = sp.image(KMR_MAP_WEAK)
