@@ -95,9 +95,8 @@ typedef struct kmr_config {
 	uint32_t num_parts;              /* --build-partitions: keep k-mers whose                  */
 	uint32_t part_idx;               /*   getDMPThread(kmer,num_parts)==part_idx; 0/1 = all    */
 	uint32_t build_mode;             /* 0 = auto (3 where it applies, else 2), 1 = open-addressed device table, 2 = two-level
-	                                    k-mer partition + LDS counting (both value kinds in 1 and 2), 3 = super-k-mer lists:
-	                                    one scatter pass by minimizer, expansion + counting in LDS (count / direction
-	                                    values, k >= 13, single partition) */
+	                                    k-mer partition + LDS counting, 3 = super-k-mer lists: one scatter pass by minimizer,
+	                                    expansion + counting in LDS (k >= 13; both value kinds in all three modes) */
 	uint64_t max_table_entries;      /* 0 = size from estimated_raw_kmers; else distinct-key
 	                                    capacity of the device table                           */
 	uint32_t hash_kind;              /* kmr_hash_kind: which hash places a k-mer in its bucket / owner / part / subsample.

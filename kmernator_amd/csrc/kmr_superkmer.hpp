@@ -156,6 +156,18 @@ __global__ void sk_close_kernel(const unsigned long long *state, uint64_t n, uin
  * every prefetch in flight) */
 __device__ __forceinline__ void sk_wave_lds_order() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 
+/* inclusive prefix sum over the 64 lanes by data-parallel-primitive moves (row shifts inside the rows of 16, then the row totals
+ * broadcast into the rows behind): six vector additions, no LDS permutes */
+__device__ __forceinline__ uint32_t sk_wave_scan_u32(uint32_t x) {
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);      /* row_shr:1 */
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);      /* row_shr:2 */
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);      /* row_shr:4 */
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);      /* row_shr:8 */
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     /* row_bcast:15 into rows 1 and 3 */
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     /* row_bcast:31 into rows 2 and 3 */
+	return x;
+}
+
 /* Reserve g granules in list `list`: lock-free append to a chain of fixed chunks.  The list's word is open chunk << 32 |
  * fill; an atomic add books [fill, fill + g).  The ONE adder that crosses the end of the chunk closes it (its fill count is
  * the value it saw), takes a new chunk from its wavefront's slab and publishes it with its own g already booked; adders that
@@ -1411,15 +1423,15 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					 * current one is being added. */
 					const bool isStart = (starts >> lane) & 1ull;
 					const uint32_t myN = isStart ? (cur.y >> 8) & 0xffu : 0u;
-					uint32_t incl = myN;
-#pragma unroll
-					for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += x; }
+					const uint32_t incl = sk_wave_scan_u32(myN);      /* (six LDS permutes with their address arithmetic cost the pass 0.85 ms) */
 					const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 					const uint32_t myOff = incl - myN;
 					const uint32_t Lk = (T + 63u) >> 6;
 					if (myN) {
-						const float Lf = (float)Lk;
-						const uint32_t l0 = (uint32_t)((float)(myOff + Lk - 1) / Lf), l1 = (uint32_t)((float)(myOff + myN - 1) / Lf);      /* exact: small integers */
+						/* floor(x / Lk) as (x + 0.5) * (1 / Lk): x < 2^14 and Lk <= 128 leave the product at least 0.5 / Lk away from an integer,
+						 * a thousand times the rounding error of the reciprocal and the product (two f32 divisions are 24 instructions) */
+						const float inv = __builtin_amdgcn_rcpf((float)Lk);
+						const uint32_t l0 = (uint32_t)(((float)(myOff + Lk - 1) + 0.5f) * inv), l1 = (uint32_t)(((float)(myOff + myN - 1) + 0.5f) * inv);
 						for (uint32_t l = l0; l <= l1 && l < 64u; l++) wrecOf[l] = (uint8_t)lane;
 					}
 					sk_wave_lds_order();
@@ -1664,7 +1676,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					};
 					for (uint32_t it = 0; it < Lk; it += 2) { step_one(kA, kB); step_one(kB, kA); }
 					if (SK_DBG(dbgFlags, 1) && dbgSink == 0x12345u) s_overflow[fl] = 2;
-					claimedHere = (uint32_t)wave_sum((unsigned long long)claimedHere);
+					claimedHere = (uint32_t)__builtin_amdgcn_readlane((int)sk_wave_scan_u32(claimedHere), 63);
 					if (lane == 0 && claimedHere) atomicAdd(&s_claimed[fl], claimedHere);
 					sk_wave_lds_order();
 					cur = nxt; curCount = nxtCount;
