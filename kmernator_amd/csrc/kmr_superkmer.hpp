@@ -2097,15 +2097,13 @@ void sk_lookup_kernel(PoolView pool, const uint64_t *list_start, const uint64_t 
 					/* the chunk's k-mers dealt evenly over the lanes, as in sk_count_kernel */
 					const bool isStart = (starts >> lane) & 1ull;
 					const uint32_t myN = isStart ? (cur.y >> 8) & 0xffu : 0u;
-					uint32_t incl = myN;
-#pragma unroll
-					for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += x; }
+					const uint32_t incl = sk_wave_scan_u32(myN);
 					const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 					const uint32_t myOff = incl - myN;
 					const uint32_t Lk = (T + 63u) >> 6;
 					if (myN) {
-						const float Lf = (float)Lk;
-						const uint32_t l0 = (uint32_t)((float)(myOff + Lk - 1) / Lf), l1 = (uint32_t)((float)(myOff + myN - 1) / Lf);
+						const float inv = __builtin_amdgcn_rcpf((float)Lk);      /* as in sk_count_kernel */
+						const uint32_t l0 = (uint32_t)(((float)(myOff + Lk - 1) + 0.5f) * inv), l1 = (uint32_t)(((float)(myOff + myN - 1) + 0.5f) * inv);
 						for (uint32_t l = l0; l <= l1 && l < 64u; l++) wrecOf[l] = (uint8_t)lane;
 					}
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2242,15 +2240,13 @@ void sat_collect_kernel(PoolView pool, const uint64_t *list_chunks, uint32_t k, 
 				/* the chunk's k-mers dealt evenly over the lanes, as in sk_lookup_kernel */
 				const bool isStart = (starts >> lane) & 1ull;
 				const uint32_t myN = isStart ? (cur.y >> 8) & 0xffu : 0u;
-				uint32_t incl = myN;
-#pragma unroll
-				for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += x; }
+				const uint32_t incl = sk_wave_scan_u32(myN);
 				const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 				const uint32_t myOff = incl - myN;
 				const uint32_t Lk = (T + 63u) >> 6;
 				if (myN) {
-					const float Lf = (float)Lk;
-					const uint32_t l0 = (uint32_t)((float)(myOff + Lk - 1) / Lf), l1 = (uint32_t)((float)(myOff + myN - 1) / Lf);
+					const float inv = __builtin_amdgcn_rcpf((float)Lk);      /* as in sk_count_kernel */
+					const uint32_t l0 = (uint32_t)(((float)(myOff + Lk - 1) + 0.5f) * inv), l1 = (uint32_t)(((float)(myOff + myN - 1) + 0.5f) * inv);
 					for (uint32_t l = l0; l <= l1 && l < 64u; l++) wrecOf[l] = (uint8_t)lane;
 				}
 				sk_wave_lds_order();
