@@ -1089,6 +1089,34 @@ def test_twobit_feed_equals_ascii_feed(mode, quals):
     assert compare_weak_images(o.image(KMR_MAP_WEAK), pt.image(KMR_MAP_WEAK), pt.kb, False) == o.stats()["weak_entries"]
 
 
+def test_twobit_device_feed_without_byte_offsets():
+    """kmr_add_reads_twobit_dev with device arrays: twobit offsets left out (every read starts on the byte behind the one before it: the
+    library scans ceil(L / 4) itself), markups and a discarded read, two calls whose offsets do not start at zero -- the spectrum of
+    kmr_add_reads on the same reads"""
+    torch = pytest.importorskip("torch")
+    k = 31
+    rb = synth_reads(2500, read_len=101, genome_len=20000, seed=12, quality="noisy", n_rate=0.004)
+    disc = np.zeros(rb.n, np.uint8); disc[7] = 1
+    rb.discarded = disc
+    cfg = default_config(k, estimated_raw_kmers=2500 * 71)
+    pa = product(cfg, 3); add(pa, rb); pa.finalize(1)
+    tw, to, (mp, mc, mo) = _pack_twobit(rb)
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a).view(dt) if dt else np.ascontiguousarray(a)).to(dev)
+    d_tw, d_off, d_mo, d_mp, d_mc, d_q, d_d = t(tw), t(rb.offsets, np.int64), t(mo, np.int64), t(mp, np.int32), t(mc), t(rb.quals), t(disc)
+    pt = product(cfg, 3)
+    half = 1200
+    for r0, r1 in ((0, half), (half, rb.n)):
+        b0, b1 = int(rb.offsets[r0]), int(rb.offsets[r1])
+        pt.buildKmerSpectrumTwoBitDevice(d_tw.data_ptr() + int(to[r0]), None, d_off.data_ptr() + 8 * r0, r1 - r0, b1 - b0, quals_ptr=d_q.data_ptr() + b0,
+                                         markup_offsets_ptr=d_mo.data_ptr() + 8 * r0, markup_pos_ptr=d_mp.data_ptr(), markup_char_ptr=d_mc.data_ptr(),
+                                         first_read_idx=r0, discarded_ptr=d_d.data_ptr() + r0)
+    pt.sync(); pt.finalize(1)
+    assert pa.stats() == pt.stats()
+    for which in (KMR_MAP_WEAK, KMR_MAP_SINGLETON):
+        assert np.array_equal(pa.image(which), pt.image(which))
+
+
 @pytest.mark.parametrize("mode", [3, 2])
 def test_build_score_reset_build_again(mode):
     """the streaming lookups borrow the handle's list pool and list state after kmr_finalize: a kmr_reset and a second build on the same
