@@ -1470,29 +1470,16 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					};
 					/* The bases of the k-mers a lane expands lie in REGISTERS: a window of 2 W + 2 dwords of its record's packed bases, the
 					 * current k-mer `sb` bits into it (0 <= sb <= 62); the next k-mer of the same record is the window two bits further on
-					 * (no LDS read, and nothing to wait for, per k-mer).  A lane that will run out of its record has the NEXT record's header
-					 * and first window in registers already: they were requested when the lane entered the current one. */
+					 * (no LDS read, and nothing to wait for, per k-mer). */
 					constexpr int NWD = 2 * W + 2;
-					uint32_t win[NWD], nwin[NWD], sb = 0;
-					uint4 nh = make_uint4(0, 0, 0, 0); uint32_t nrs = 0;
+					uint32_t win[NWD], sb = 0;
 #pragma unroll
-					for (int i = 0; i < NWD; i++) { win[i] = 0; nwin[i] = 0; }
+					for (int i = 0; i < NWD; i++) win[i] = 0;
 					auto seed_window = [&]() {       /* the window of k-mer j of the record at granule rs (a record entered in its middle, or a window run out) */
 						const uint32_t *bw = (const uint32_t *)(wstage + rs + 1) + (j >> 4);
 #pragma unroll
 						for (int i = 0; i < NWD; i++) win[i] = bw[i];
 						sb = 2u * (j & 15u);
-					};
-					auto request_next_record = [&]() {      /* header and first window of the record behind the current one (indices kept inside the staging area) */
-						nrs = rs + ((hy >> 17) & 0x7fu);
-						const uint32_t g0 = nrs < SK_CHUNK_G - 1 ? nrs : SK_CHUNK_G - 1;
-						nh = wstage[g0];
-#pragma unroll
-						for (int q = 0; q < (NWD + 3) / 4; q++) {
-							const uint32_t g = g0 + 1 + q < SK_CHUNK_G ? g0 + 1 + q : SK_CHUNK_G - 1;
-							const uint4 v = wstage[g];
-							if (4 * q < NWD) nwin[4 * q] = v.x; if (4 * q + 1 < NWD) nwin[4 * q + 1] = v.y; if (4 * q + 2 < NWD) nwin[4 * q + 2] = v.z; if (4 * q + 3 < NWD) nwin[4 * q + 3] = v.w;
-						}
 					};
 					/* a k-mer on its way to the table: canonical key, strand, home slot and probe step, weight, stream ordinal.  Two of them
 					 * exist per lane -- the one being inserted and the one being made -- and the loop below alternates their roles instead of
@@ -1558,7 +1545,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						}
 					};
 					if (left) {
-						enter_record(); seed_window(); request_next_record();
+						enter_record(); seed_window();
 						if (EXT && j > 0) { const uint32_t b = j - 1; leftCarry = (((const uint32_t *)(wstage + rs + 1))[b >> 4] >> (30 - 2 * (b & 15u))) & 3u; }      /* (a lane that starts inside a record) */
 						prepare(kA);
 					}
@@ -1577,11 +1564,14 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 							j++; left--; sb += 2;
 							if (left) {
 								if (j >= n) {
-									rs = nrs; hx = nh.x; hy = nh.y; hw = nh.w; j = 0; sb = 0;
-#pragma unroll
-									for (int i = 0; i < NWD; i++) win[i] = nwin[i];
+									/* the next record is fetched when the lane gets there (two LDS reads, waited for on the spot).  Its header and first window
+									 * used to be asked for a record ahead and held in registers: eight of the 128 -- without them nothing spills and the pass
+									 * is 0.45 ms faster, the exposed LDS latency notwithstanding */
+									rs = rs + ((hy >> 17) & 0x7fu);
+									{ const uint32_t g0 = rs < SK_CHUNK_G - 1 ? rs : SK_CHUNK_G - 1; const uint4 hh = wstage[g0]; hx = hh.x; hy = hh.y; hw = hh.w; }
+									j = 0;
+									seed_window();
 									enter_record();
-									request_next_record();
 								} else if (sb > 62u) seed_window();
 								prepare(nxt);
 							}
