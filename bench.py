@@ -389,7 +389,7 @@ def main():
                         raw_local * (1.0 if lean else 2.0) * READ_LEN / kmers_per_read + sk_bytes,
                         "scattered device atomics: one returning 64-bit add per record, ~1.8e10/s chip-wide" if lean else "vector-instruction issue at 1.5 wavefronts per SIMD (LDS: 24 KB per wavefront)"),
                        ("sk_count_kernel (expand + count in LDS)", 5, sk_bytes + weak * 16.0,
-                        "vector-instruction issue (VALU busy ~73 % of a SIMD's cycles at 4 wavefronts per SIMD; LDS and the 128-register limit cap the occupancy)"),
+                        "vector-instruction issue (VALU busy ~70 % of a SIMD's cycles at 4 wavefronts per SIMD; LDS caps the occupancy)"),
                        ("bb_hist + bb_scatter (x levels) + bb_group_kernel (radix partition by bucket, per-group sort)", 6, weak * (16.0 * 5 + 20.0),
                         "HBM / L2 transactions")]
             else:
