@@ -99,7 +99,7 @@ def test_ranks_sharing_one_gpu(world, pipeline):
                 assert np.array_equal(a, b)
 
 
-def _worker_sk(rank, world, port, tmp, k, coarse=0):
+def _worker_sk(rank, world, port, tmp, k, coarse=0, ext=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -113,7 +113,8 @@ def _worker_sk(rank, world, port, tmp, k, coarse=0):
         tb = torch.from_numpy(np.concatenate([rb.bases, np.zeros(64, np.uint8)])).to(dev)
         tq = torch.from_numpy(np.concatenate([rb.quals, np.zeros(64, np.uint8)])).to(dev)
         to = torch.from_numpy(rb.offsets.astype(np.int64)).to(dev)
-        sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0, rank=rank, world_size=world, build_mode=3))
+        xkw = dict(value_kind=1, min_weight=0.0, min_quality_score=2) if ext else {}
+        sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0, rank=rank, world_size=world, build_mode=3, **xkw))
         sp.tune(coarse_lists=coarse)
         xs = {}
         build_partitioned_superkmers(sp, tb, tq, to, first_read_idx=lo, stats=xs, pieces=1 if world == 2 else 3)      # three ranks: in three pieces
@@ -127,20 +128,23 @@ def _worker_sk(rank, world, port, tmp, k, coarse=0):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,coarse", [(2, 31, 0), (3, 51, 0), (3, 31, 1), (2, 51, 1)])
-def test_superkmer_exchange_ranks_sharing_one_gpu(world, k, coarse):
+@pytest.mark.parametrize("world,k,coarse,ext", [(2, 31, 0, 0), (3, 51, 0, 0), (3, 31, 1, 0), (2, 51, 1, 0), (2, 21, 0, 1), (3, 31, 0, 1)])
+def test_superkmer_exchange_ranks_sharing_one_gpu(world, k, coarse, ext):
     """The N > 1 build of build_mode 3 (every rank scatters its reads' super-k-mers into the job's lists, the chunks of other
     owners travel, the owner appends them to its lists) with 2 and 3 ranks on this GPU over gloo: the union of the ranks' weak
     maps is the weak map of one spectrum over the same reads -- same keys, counts, direction biases -- every k-mer lives on
     exactly one rank, the statistics add up, and every rank's reads score as on the whole spectrum (a lookup goes to the owner of
     the k-mer's list, not to its lookup3 owner).  coarse = 1: the ranks scatter into, exchange and adopt coarse lists (2^ceil(log2 world)
-    fine lists each) and the owner splits them before the count pass (kmr_tune "coarse_lists")."""
+    fine lists each) and the owner splits them before the count pass (kmr_tune "coarse_lists").  ext = 1: extension values -- the records
+    that travel carry their neighbour bases and qualities, the twelve tallies of every k-mer must be the whole spectrum's too."""
     import kmernator_amd as ka
     port = 32100 + (os.getpid() % 1500) + world
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker_sk, args=(world, port + 17 * coarse, tmp, k, coarse), nprocs=world, join=True)
+        mp.spawn(_worker_sk, args=(world, port + 17 * coarse + 31 * ext, tmp, k, coarse, ext), nprocs=world, join=True)
         rb = _reads()
-        multi = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0))
+        xkw = dict(value_kind=1, min_weight=0.0, min_quality_score=2) if ext else {}
+        vbytes = 60 if ext else 12
+        multi = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=N_READS * (READ_LEN - k + 1), device=0, **xkw))
         for r in range(world):
             lo, hi = _slice(r, world)
             part = rb.slice(lo, hi)
@@ -150,17 +154,17 @@ def test_superkmer_exchange_ranks_sharing_one_gpu(world, k, coarse):
         stats = sum(np.load(os.path.join(tmp, "stats.%d.npy" % r)) for r in range(world))
         assert (int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])) == (ms["raw_kmers"], ms["raw_good_kmers"], ms["weak_entries"], ms["unique_kmers"]), (stats, ms)
         assert int(stats[4]) > 0
-        _, _, whole = parse_image(multi.image(KMR_MAP_WEAK), multi.kb, 12)
+        _, _, whole = parse_image(multi.image(KMR_MAP_WEAK), multi.kb, vbytes)
         wk = np.concatenate([kk for kk, _ in whole if len(kk)])
         wv = np.concatenate([v for _, v in whole if len(v)])
-        want = {bytes(kk): bytes(v[:2]) + bytes(v[8:10]) for kk, v in zip(wk, wv)}       # count and directionBias bytes (the first sighting through an exchange is still the first in the stream: ordinals travel)
+        want = {bytes(kk): bytes(v[:2]) + bytes(v[8:]) for kk, v in zip(wk, wv)}       # count, directionBias (the first sighting through an exchange is still the first in the stream: ordinals travel) and the extension tallies
         seen = 0
         for r in range(world):
-            _, _, buckets = parse_image(np.load(os.path.join(tmp, "image.%d.npy" % r)), multi.kb, 12)
+            _, _, buckets = parse_image(np.load(os.path.join(tmp, "image.%d.npy" % r)), multi.kb, vbytes)
             keys = np.concatenate([kk for kk, _ in buckets if len(kk)])
             vals = np.concatenate([v for _, v in buckets if len(v)])
             for kk, v in zip(keys, vals):
-                assert want.pop(bytes(kk)) == bytes(v[:2]) + bytes(v[8:10])
+                assert want.pop(bytes(kk)) == bytes(v[:2]) + bytes(v[8:])
             seen += len(keys)
         assert seen == ms["weak_entries"] and not want
         for r in range(world):
