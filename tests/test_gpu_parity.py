@@ -231,6 +231,18 @@ def test_reference_reads_without_quals_and_discarded(mode):
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
 
 
+@pytest.mark.parametrize("k", [21, 51])
+def test_ext_values_with_filters_on_the_lists(k):
+    """extension values through the FILTERING extraction of build_mode 3 (a hash partition of the k-mers, a sub-sample): the part's weak
+    map with all its tallies and the singletons' packets are the oracle's"""
+    rb = synth_reads(3000, read_len=110, seed=21, quality="noisy", n_rate=0.003)
+    for kw in (dict(num_parts=3, part_idx=1), dict(kmer_subsample=3)):
+        cfg = default_config(k, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2, num_buckets_weak=256, num_buckets_singleton=512, **kw)
+        o, p = run_both(cfg, rb, min_depth=1, mode=3)
+        assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, True) == o.stats()["weak_entries"]
+        assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_owner_and_part_filters(mode):
     """getDistributedThreadId owner filter (src/Kmer.h:2284-2295) and --build-partitions (:1680)"""
