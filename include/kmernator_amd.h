@@ -433,6 +433,11 @@ int kmr_reads_info(const kmr_reads *r, uint64_t *n_reads, uint64_t *total_bases,
  * handle's fastq_start_char); names are empty */
 int kmr_reads_from_host(kmr_handle *h, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n_reads,
                         kmr_reads **out);
+/* ... and from reads the host keeps as the reference's Read does (arrays as for kmr_add_reads_twobit below: 2-bit packed bases, markups,
+ * qualities as characters / one character for all / none = Read::REF_QUAL): a quarter of the base bytes on the bus */
+int kmr_reads_from_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *twobit_offsets, const uint64_t *offsets,
+                          const uint64_t *markup_offsets, const uint32_t *markup_pos, const char *markup_char,
+                          const char *quals, int uniform_quality, uint64_t n_reads, kmr_reads **out);
 /* device arrays in the layout kmr_add_reads_dev takes: bases[total], quals[total], u64 offsets[n+1] */
 int kmr_reads_device_ptrs(const kmr_reads *r, void **dev_bases, void **dev_quals, void **dev_offsets);
 /* copies to host; any pointer may be NULL.  name_off/name_len: span of each read's name line

@@ -343,9 +343,12 @@ public:
 			kmr_reads *batch = NULL;
 			int rc = KMR_OK;
 			if (sidx < mySteps && failed == KMR_OK) {
-				typename Base::FlatReads fr;
-				Base::flatten(store, fr, true, cuts[sidx], cuts[sidx + 1]);
-				rc = kmr_reads_from_host(h, fr.bases.data(), fr.anyQuals ? fr.quals.data() : NULL, &fr.offsets[0], cuts[sidx + 1] - cuts[sidx], &batch);
+				/* (the batch goes over as the ReadSet keeps it: packed bases + markups, kmr_reads_from_twobit; a discarded read is empty) */
+				typename Base::PackedReads pr;
+				Base::flattenTwoBit(store, pr, cuts[sidx], cuts[sidx + 1]);
+				rc = kmr_reads_from_twobit(h, pr.twobit.empty() ? (const uint8_t *)"" : &pr.twobit[0], &pr.twobitOffsets[0], &pr.offsets[0],
+				                           pr.markupPos.empty() ? NULL : &pr.markupOffsets[0], pr.markupPos.empty() ? NULL : &pr.markupPos[0], pr.markupPos.empty() ? NULL : &pr.markupChar[0],
+				                           pr.anyQuals ? pr.quals.data() : NULL, 0, cuts[sidx + 1] - cuts[sidx], &batch);
 				if (rc != KMR_OK) { failed = rc; why = kmr_last_error(h); batch = NULL; }
 			}
 			/* (a rank whose copy to the device failed still takes part in the step, with nothing: the library's steps are collective.  A

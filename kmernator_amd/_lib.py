@@ -64,7 +64,7 @@ EXPORTS = [
     "kmr_add_read_batch", "kmr_reads_free", "kmr_histogram", "kmr_histogram_bins", "kmr_merge_image", "kmr_subtract_reference", "kmr_subtracted", "kmr_score_read_batch",
     "kmr_artifact_config_init", "kmr_artifact_filter_create", "kmr_artifact_filter_info", "kmr_artifact_filter_entries",
     "kmr_artifact_filter_free", "kmr_artifact_filter_apply",
-    "kmr_tune", "kmr_set_stream_origin", "kmr_size_tracker", "kmr_exchange_unique_id", "kmr_exchange_init", "kmr_exchange_init_transport", "kmr_exchange_add_reads_dev", "kmr_exchange_add_read_batch", "kmr_exchange_stats", "kmr_copy_to_host", "kmr_copy_to_device", "kmr_sk_exchange_begin", "kmr_sk_exchange_counts", "kmr_sk_exchange_pack_dev", "kmr_sk_exchange_adopt_dev", "kmr_extract_by_owner_host", "kmr_insert_records", "kmr_reads_from_host", "kmr_reads_twobit", "kmr_lookup_requests_dev", "kmr_lookup_keys_dev", "kmr_scatter_counts_dev", "kmr_score_counts_dev",
+    "kmr_tune", "kmr_set_stream_origin", "kmr_size_tracker", "kmr_exchange_unique_id", "kmr_exchange_init", "kmr_exchange_init_transport", "kmr_exchange_add_reads_dev", "kmr_exchange_add_read_batch", "kmr_exchange_stats", "kmr_copy_to_host", "kmr_copy_to_device", "kmr_sk_exchange_begin", "kmr_sk_exchange_counts", "kmr_sk_exchange_pack_dev", "kmr_sk_exchange_adopt_dev", "kmr_extract_by_owner_host", "kmr_insert_records", "kmr_reads_from_host", "kmr_reads_from_twobit", "kmr_reads_twobit", "kmr_lookup_requests_dev", "kmr_lookup_keys_dev", "kmr_scatter_counts_dev", "kmr_score_counts_dev",
 ]
 
 _lib = None
@@ -89,6 +89,7 @@ def load():
     lib.kmr_num_buckets.argtypes = [vp, C.c_int, u64p]
     lib.kmr_add_reads.argtypes = [vp, vp, vp, u64p, C.c_uint64, C.c_uint64, u8p]
     lib.kmr_add_reads_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    lib.kmr_reads_from_twobit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_uint64, C.POINTER(vp)]
     lib.kmr_add_reads_twobit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_uint64, C.c_uint64, vp]
     lib.kmr_add_reads_twobit_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     lib.kmr_sync.argtypes = [vp]

@@ -3053,6 +3053,46 @@ int kmr_reads_twobit(kmr_handle *h, const kmr_reads *r, uint8_t *twobit, uint64_
 	return KMR_OK;
 }
 
+int kmr_reads_from_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *twobit_offsets, const uint64_t *offsets,
+                          const uint64_t *markup_offsets, const uint32_t *markup_pos, const char *markup_char,
+                          const char *quals, int uniform_quality, uint64_t n_reads, kmr_reads **out) {
+	if (!h || !out || !offsets || !twobit_offsets || (n_reads && !twobit)) return KMR_ERR_INVALID_ARG;
+	if (uniform_quality < 0 || uniform_quality > 255 || (quals && uniform_quality)) return fail(h, KMR_ERR_INVALID_ARG, "uniform_quality: 0, or the one quality character of a batch without a quality array");
+	*out = nullptr;
+	hipSetDevice(h->device);
+	const uint64_t first = offsets[0], total = offsets[n_reads] - first, tbytes = twobit_offsets[n_reads] - twobit_offsets[0];
+	const uint64_t nm = markup_offsets ? markup_offsets[n_reads] - markup_offsets[0] : 0;
+	std::unique_ptr<kmr_reads, void (*)(kmr_reads *)> r(new kmr_reads, kmr_reads_free);
+	r->device = h->device; r->n = n_reads; r->total = total; r->input_base = h->cfg.fastq_start_char;
+	HIPCHK(h, hipMalloc((void **)&r->bases, total + 64)); HIPCHK(h, hipMalloc((void **)&r->quals, total + 64));
+	HIPCHK(h, hipMalloc((void **)&r->offsets, 8 * (n_reads + 1)));
+	HIPCHK(h, hipMalloc((void **)&r->name_off, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, hipMalloc((void **)&r->name_len, 4 * std::max<uint64_t>(n_reads, 1)));
+	HIPCHK(h, hipMemset(r->bases + total, 0, 64)); HIPCHK(h, hipMemset(r->quals + total, 0, 64));
+	HIPCHK(h, hipMemset(r->name_off, 0, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, hipMemset(r->name_len, 0, 4 * std::max<uint64_t>(n_reads, 1)));
+	/* qualities: the array, the one character, or Read::REF_QUAL (a batch always has a quality array; REF_QUAL reads weigh 1) */
+	if (quals) { if (total) HIPCHK(h, hipMemcpy(r->quals, quals + first, total, hipMemcpyHostToDevice)); }
+	else HIPCHK(h, hipMemset(r->quals, uniform_quality ? uniform_quality : 127, total));
+	if (!n_reads) { HIPCHK(h, hipMemset(r->offsets, 0, 8)); *out = r.release(); return KMR_OK; }
+	ArtBuf tmp; uint8_t *dtb, *dmc = nullptr; uint64_t *dto, *doff, *dmo = nullptr; uint32_t *dmp = nullptr;
+	HIPCHK(h, tmp.get(&dtb, tbytes + 64)); HIPCHK(h, tmp.get(&dto, n_reads + 1)); HIPCHK(h, tmp.get(&doff, n_reads + 1));
+	std::vector<uint64_t> rel(n_reads + 1), trel(n_reads + 1), mrel(markup_offsets ? n_reads + 1 : 0);
+	for (uint64_t i = 0; i <= n_reads; i++) { rel[i] = offsets[i] - first; trel[i] = twobit_offsets[i] - twobit_offsets[0]; if (markup_offsets) mrel[i] = markup_offsets[i] - markup_offsets[0]; }
+	if (tbytes) HIPCHK(h, hipMemcpy(dtb, twobit + twobit_offsets[0], tbytes, hipMemcpyHostToDevice));
+	HIPCHK(h, hipMemcpy(dto, trel.data(), 8 * (n_reads + 1), hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(doff, rel.data(), 8 * (n_reads + 1), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(twobit_unpack_kernel, dim3((unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)num_cus(h) * 32)), dim3(256), 0, h->stream, (const uint8_t *)dtb, (const uint64_t *)dto, (const uint64_t *)doff, n_reads, r->bases, r->offsets);
+	HIPCHK(h, hipGetLastError());
+	if (nm) {
+		HIPCHK(h, tmp.get(&dmo, n_reads + 1)); HIPCHK(h, tmp.get(&dmp, nm)); HIPCHK(h, tmp.get(&dmc, nm));
+		HIPCHK(h, hipMemcpy(dmo, mrel.data(), 8 * (n_reads + 1), hipMemcpyHostToDevice));
+		HIPCHK(h, hipMemcpy(dmp, markup_pos + markup_offsets[0], 4 * nm, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(dmc, markup_char + markup_offsets[0], nm, hipMemcpyHostToDevice));
+		hipLaunchKernelGGL(twobit_markup_kernel, dim3(grid_for(n_reads)), dim3(256), 0, h->stream, (const uint64_t *)dmo, (const uint32_t *)dmp, (const uint8_t *)dmc, (const uint64_t *)r->offsets, n_reads, r->bases);
+		HIPCHK(h, hipGetLastError());
+	}
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	*out = r.release();
+	return KMR_OK;
+}
+
 /* ---- stateless helpers ------------------------------------------------- */
 uint64_t kmr_hash(const uint8_t *key, uint32_t len) {
 	if (!key || len == 0 || len > 32) return 0;

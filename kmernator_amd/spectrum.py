@@ -503,6 +503,22 @@ class ReadSet:
                        offsets.ctypes.data_as(C.POINTER(C.c_uint64)), offsets.size - 1, C.byref(r))
         return cls._adopt(spectrum, b"", r)
 
+    @classmethod
+    def from_twobit(cls, spectrum, twobit, twobit_offsets, offsets, quals=None, uniform_quality=0, markups=None):
+        """reads the host keeps as the reference's Read does (2-bit packed bases, every read on bytes of its own; markups = (positions, chars,
+        offsets[n+1]); qualities an array, one character for all, or none): kmr_reads_from_twobit"""
+        tw = np.ascontiguousarray(twobit, dtype=np.uint8)
+        to = np.ascontiguousarray(twobit_offsets, dtype=np.uint64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        q = None if quals is None else np.ascontiguousarray(quals, dtype=np.uint8)
+        mp = mc = mo = None
+        if markups is not None:
+            mp = np.ascontiguousarray(markups[0], dtype=np.uint32); mc = np.ascontiguousarray(markups[1], dtype=np.uint8); mo = np.ascontiguousarray(markups[2], dtype=np.uint64)
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        r = C.c_void_p()
+        spectrum._call("reads_from_twobit", spectrum.h, vp(tw), vp(to), vp(offsets), vp(mo), vp(mp), vp(mc), vp(q), int(uniform_quality), offsets.size - 1, C.byref(r))
+        return cls._adopt(spectrum, b"", r)
+
     def twobit(self):
         """(packed bases, offsets[n+1], markup positions, markup chars, markup offsets[n+1]): every read as
         TwoBitSequence::compressSequence packs it (src/TwoBitSequence.cpp:242-269), on the device"""

@@ -1101,6 +1101,24 @@ def test_twobit_feed_equals_ascii_feed(mode, quals):
     assert compare_weak_images(o.image(KMR_MAP_WEAK), pt.image(KMR_MAP_WEAK), pt.kb, False) == o.stats()["weak_entries"]
 
 
+def test_read_batch_from_packed_reads():
+    """kmr_reads_from_twobit: the device batch made from packed reads holds the reads' text again (upper case, markups back in place) and
+    the qualities given -- an array, one character, or Read::REF_QUAL -- and builds the spectrum of the text"""
+    rb = synth_reads(1500, read_len=97, genome_len=12000, seed=3, quality="noisy", n_rate=0.01)
+    tw, to, mk = _pack_twobit(rb)
+    cfg = default_config(31, estimated_raw_kmers=1500 * 67)
+    sp = product(cfg, 3)
+    for quals, uq, want_q in ((rb.quals, 0, rb.quals), (None, ord("5"), np.full(rb.bases.size, ord("5"), np.uint8)), (None, 0, np.full(rb.bases.size, 127, np.uint8))):
+        rs = ka.ReadSet.from_twobit(sp, tw, to, rb.offsets, quals=quals, uniform_quality=uq, markups=mk)
+        b, q, o, _ = rs.arrays()
+        assert np.array_equal(b, rb.bases) and np.array_equal(q, want_q) and np.array_equal(o, rb.offsets)
+        rs.close()
+    rs = ka.ReadSet.from_twobit(sp, tw, to, rb.offsets, quals=rb.quals, markups=mk)
+    sp.buildKmerSpectrumFromReadSet(rs); sp.finalize(1)
+    pa = product(cfg, 3); add(pa, rb); pa.finalize(1)
+    assert pa.stats() == sp.stats() and np.array_equal(pa.image(KMR_MAP_WEAK), sp.image(KMR_MAP_WEAK))
+
+
 def test_twobit_device_feed_without_byte_offsets():
     """kmr_add_reads_twobit_dev with device arrays: twobit offsets left out (every read starts on the byte behind the one before it: the
     library scans ceil(L / 4) itself), markups and a discarded read, two calls whose offsets do not start at zero -- the spectrum of
