@@ -70,6 +70,7 @@ struct Tuning {
 	bool no_lut = false, no_narrow = false, no_l1_state = false, no_stream_lookups = false;
 	uint64_t long_list_chunks = 0;     /* lists of more chunks are counted in pieces (0: 1024) */
 	uint64_t binned_min = 1ull << 18;  /* weak maps of at least this many entries are bucketed by the radix partition of kmr_buckets.hpp (build_mode 3) */
+	uint64_t twobit_piece_bases = 0;   /* kmr_add_reads_twobit: bases per piece of the host-to-device pipeline (0 = 2^26) */
 	bool no_lean_extract = false;      /* never take sk_extract_lean_kernel (A/B runs, tests of the general kernel on uniform qualities) */
 	bool exchange_fail_once = false;   /* tests: the next kmr_exchange_add_reads_dev of this rank fails locally (the other ranks must come back with an error, not hang) */
 	bool no_coarse_lists = true;       /* exchange: scatter into the job's fine lists (default) or, kmr_tune("coarse_lists", 1), into coarse ones that the owner splits before the count pass (sk_refine_kernel: not yet fast enough to pay) */
@@ -136,6 +137,8 @@ struct kmr_handle {
 	/* kmr_add_reads_twobit*: the unpacked batch (ASCII bases, one quality character throughout, offsets counted from the call's first read) */
 	uint8_t *tb_bases = nullptr, *tb_quals = nullptr; uint64_t *tb_rel = nullptr, *tb_off = nullptr; uint32_t *tb_len = nullptr;
 	uint64_t tb_bases_cap = 0, tb_quals_cap = 0, tb_quals_filled = 0, tb_n = 0; int tb_quals_char = -1;
+	hipStream_t tb_copy_stream = nullptr; hipEvent_t tb_ready[2] = {nullptr, nullptr}, tb_consumed[2] = {nullptr, nullptr}; bool tb_set_used[2] = {false, false};
+	uint8_t *tb_stage[2][8] = {{nullptr}}; size_t tb_stage_cap[2][8] = {{0}};      /* kmr_add_reads_twobit: two sets of staging buffers for the pieces on the bus */
 	int uniform_q_hint = -1;           /* >= 0 while kmr_add_reads_twobit_dev feeds a batch whose qualities are this one character */
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr, *us_pkt = nullptr; uint64_t uw_cap = 0, us_cap = 0;
 	/* build_mode 3: the count pass's weak entries packed (kmr_buckets.hpp: W key words + one value word), and the radix partition's scratch of the same layout */
@@ -1852,6 +1855,8 @@ void free_partition_state(kmr_handle *h) {
 	if (h->work_counter) hipFree(h->work_counter); if (h->linear) hipFree(h->linear); if (h->tile_count) hipFree(h->tile_count);
 	if (h->kcap) hipFree(h->kcap); if (h->koff) hipFree(h->koff);
 	if (h->ucnt) hipFree(h->ucnt); if (h->ufirst) hipFree(h->ufirst); if (h->u_start) { hipFree(h->u_start); hipFree(h->u_end); hipFree(h->u_read); } if (h->umax) hipFree(h->umax);
+	for (int a = 0; a < 2; a++) for (int b = 0; b < 8; b++) { if (h->tb_stage[a][b]) hipFree(h->tb_stage[a][b]); h->tb_stage[a][b] = nullptr; h->tb_stage_cap[a][b] = 0; }
+	if (h->tb_copy_stream) { hipStreamDestroy(h->tb_copy_stream); h->tb_copy_stream = nullptr; for (int a = 0; a < 2; a++) { hipEventDestroy(h->tb_ready[a]); hipEventDestroy(h->tb_consumed[a]); h->tb_set_used[a] = false; } }
 	if (h->tb_bases) hipFree(h->tb_bases); if (h->tb_quals) hipFree(h->tb_quals); if (h->tb_rel) hipFree(h->tb_rel); if (h->tb_off) hipFree(h->tb_off); if (h->tb_len) hipFree(h->tb_len);
 	h->tb_bases = h->tb_quals = nullptr; h->tb_rel = h->tb_off = nullptr; h->tb_len = nullptr; h->tb_bases_cap = h->tb_quals_cap = h->tb_quals_filled = h->tb_n = 0; h->tb_quals_char = -1;
 	h->ucnt = nullptr; h->ufirst = nullptr; h->u_start = h->u_end = h->u_read = nullptr; h->umax = nullptr; h->ucnt_n = h->ufirst_n = h->units_n = 0;
@@ -2061,6 +2066,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "stream_lookups") h->tune.no_stream_lookups = value == 0;
 	else if (k == "long_list_chunks") h->tune.long_list_chunks = value < 2 ? 2 : (uint64_t)value;
 	else if (k == "lean_extract") h->tune.no_lean_extract = value == 0;
+	else if (k == "twobit_piece_bases") h->tune.twobit_piece_bases = (uint64_t)value;
 	else if (k == "exchange_fail_once") h->tune.exchange_fail_once = value != 0;
 	else if (k == "binned_buckets_min") h->tune.binned_min = value >= 0 ? (uint64_t)value : ~0ull;        /* < 0: never */
 	else if (k == "coarse_lists") h->tune.no_coarse_lists = value == 0;
@@ -2176,27 +2182,51 @@ int kmr_add_reads_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *t
 	if (n_reads == 0) return KMR_OK;
 	if (!twobit || !twobit_offsets || !offsets) return fail(h, KMR_ERR_INVALID_ARG, "null buffer");
 	hipSetDevice(h->device);
-	const uint64_t total = offsets[n_reads] - offsets[0], tbytes = twobit_offsets[n_reads] - twobit_offsets[0], nm = markup_offsets ? markup_offsets[n_reads] - markup_offsets[0] : 0;
-	std::vector<void *> owned;
-	auto release = [&]() { for (void *p : owned) hipFree(p); owned.clear(); };
-	auto up = [&](const void *src, size_t bytes, void **dst) -> hipError_t {
-		hipError_t e = hipMalloc(dst, std::max<size_t>(bytes + 64, 256)); if (e != hipSuccess) return e;
-		owned.push_back(*dst);
-		return bytes ? hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+	/* The batch goes over in pieces of about 2^28 bases through two sets of staging buffers and a copy stream of the handle's own:
+	 * while the device unpacks and extracts piece i, piece i + 1 is on the bus (the host's pageable memory: the calling thread feeds
+	 * the copies, the device does not wait for it). */
+	struct Stage { uint8_t *b[8]; size_t cap[8]; };      /* 0 packed bases, 1 their offsets, 2 base offsets, 3 markup offsets, 4 positions, 5 characters, 6 qualities, 7 discarded */
+	if (!h->tb_copy_stream) { HIPCHK(h, hipStreamCreateWithFlags(&h->tb_copy_stream, hipStreamNonBlocking)); for (int i = 0; i < 2; i++) { HIPCHK(h, hipEventCreateWithFlags(&h->tb_ready[i], hipEventDisableTiming)); HIPCHK(h, hipEventCreateWithFlags(&h->tb_consumed[i], hipEventDisableTiming)); } }
+	auto stage = [&](int set, int which, const void *src, size_t bytes, void **dst) -> hipError_t {
+		uint8_t *&buf = h->tb_stage[set][which]; size_t &cap = h->tb_stage_cap[set][which];
+		if (cap < bytes + 64) {
+			if (buf) { hipError_t e0 = hipStreamSynchronize(h->stream); if (e0 != hipSuccess) return e0; hipFree(buf); buf = nullptr; cap = 0; }
+			hipError_t e = hipMalloc((void **)&buf, bytes + bytes / 8 + 4096); if (e != hipSuccess) return e;
+			cap = bytes + bytes / 8 + 4096 - 64;
+		}
+		*dst = buf;
+		return bytes ? hipMemcpyAsync(buf, src, bytes, hipMemcpyHostToDevice, h->tb_copy_stream) : hipSuccess;
 	};
-#define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->stream); release(); h->err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
-	void *dtb = nullptr, *dto = nullptr, *doff = nullptr, *dmo = nullptr, *dmp = nullptr, *dmc = nullptr, *dq = nullptr, *dd = nullptr;
-	std::vector<uint64_t> rel(n_reads + 1), trel(n_reads + 1), mrel(markup_offsets ? n_reads + 1 : 0);
-	for (uint64_t i = 0; i <= n_reads; i++) { rel[i] = offsets[i] - offsets[0]; trel[i] = twobit_offsets[i] - twobit_offsets[0]; if (markup_offsets) mrel[i] = markup_offsets[i] - markup_offsets[0]; }
-	TBCHK(up(twobit + twobit_offsets[0], tbytes, &dtb)); TBCHK(up(trel.data(), 8 * (n_reads + 1), &dto)); TBCHK(up(rel.data(), 8 * (n_reads + 1), &doff));
-	if (markup_offsets && nm) { TBCHK(up(mrel.data(), 8 * (n_reads + 1), &dmo)); TBCHK(up(markup_pos + markup_offsets[0], 4 * nm, &dmp)); TBCHK(up(markup_char + markup_offsets[0], nm, &dmc)); }
-	if (quals) TBCHK(up(quals + offsets[0], total, &dq));
-	if (discarded) TBCHK(up(discarded, n_reads, &dd));
+#define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->tb_copy_stream); hipStreamSynchronize(h->stream); h->err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+	const uint64_t piece_bases = h->tune.twobit_piece_bases ? h->tune.twobit_piece_bases : (1ull << 28);
+	int rc = KMR_OK; int set = 0;
+	for (uint64_t r0 = 0; r0 < n_reads && rc == KMR_OK; set ^= 1) {
+		uint64_t r1 = r0 + 1;
+		while (r1 < n_reads && offsets[r1 + 1] - offsets[r0] <= piece_bases) r1++;
+		const uint64_t m = r1 - r0, total = offsets[r1] - offsets[r0], tbytes = twobit_offsets[r1] - twobit_offsets[r0];
+		const uint64_t nm = markup_offsets ? markup_offsets[r1] - markup_offsets[r0] : 0;
+		void *dtb = nullptr, *dto = nullptr, *doff = nullptr, *dmo = nullptr, *dmp = nullptr, *dmc = nullptr, *dq = nullptr, *dd = nullptr;
+		/* (the offset arrays go over as they are: the unpack kernel counts base offsets from the piece's first one itself, and the packed
+		 * bytes / markups are addressed through pointers moved back by the piece's first offset -- no pass over the reads on the host) */
+		if (h->tb_set_used[set]) TBCHK(hipStreamWaitEvent(h->tb_copy_stream, h->tb_consumed[set], 0));      /* the piece that used this set last has been unpacked and extracted */
+		TBCHK(stage(set, 0, twobit + twobit_offsets[r0], tbytes, &dtb)); TBCHK(stage(set, 1, twobit_offsets + r0, 8 * (m + 1), &dto)); TBCHK(stage(set, 2, offsets + r0, 8 * (m + 1), &doff));
+		dtb = (uint8_t *)dtb - twobit_offsets[r0];
+		if (nm) {
+			TBCHK(stage(set, 3, markup_offsets + r0, 8 * (m + 1), &dmo)); TBCHK(stage(set, 4, markup_pos + markup_offsets[r0], 4 * nm, &dmp)); TBCHK(stage(set, 5, markup_char + markup_offsets[r0], nm, &dmc));
+			dmp = (uint32_t *)dmp - markup_offsets[r0]; dmc = (uint8_t *)dmc - markup_offsets[r0];
+		}
+		if (quals) TBCHK(stage(set, 6, quals + offsets[r0], total, &dq));
+		if (discarded) TBCHK(stage(set, 7, discarded + r0, m, &dd));
+		TBCHK(hipEventRecord(h->tb_ready[set], h->tb_copy_stream));
+		TBCHK(hipStreamWaitEvent(h->stream, h->tb_ready[set], 0));
+		rc = kmr_add_reads_twobit_dev(h, dtb, dto, doff, dmo, dmp, dmc, dq, quals ? 0 : uniform_quality, m, total, first_global_read_idx + r0, dd);
+		TBCHK(hipEventRecord(h->tb_consumed[set], h->stream)); h->tb_set_used[set] = true;
+		r0 = r1;
+	}
 #undef TBCHK
-	int rc = kmr_add_reads_twobit_dev(h, dtb, dto, doff, dmo, dmp, dmc, dq, quals ? 0 : uniform_quality, n_reads, total, first_global_read_idx, dd);
+	hipStreamSynchronize(h->tb_copy_stream);
 	if (!rc) rc = sync_state(h);
 	else hipStreamSynchronize(h->stream);
-	release();
 	return rc;
 }
 
