@@ -2101,6 +2101,24 @@ int kmr_add_reads_dev(kmr_handle *h, const void *dev_bases, const void *dev_qual
 	return rc;
 }
 
+/* one piece of a host batch onto the device: staging set `set` of the handle (grow-only), the copy on the handle's copy stream */
+static hipError_t tb_stage_copy(kmr_handle *h, int set, int which, const void *src, size_t bytes, void **dst) {
+	uint8_t *&buf = h->tb_stage[set][which]; size_t &cap = h->tb_stage_cap[set][which];
+	if (cap < bytes + 64) {
+		if (buf) { hipError_t e0 = hipStreamSynchronize(h->stream); if (e0 != hipSuccess) return e0; hipFree(buf); buf = nullptr; cap = 0; }
+		hipError_t e = hipMalloc((void **)&buf, bytes + bytes / 8 + 4096); if (e != hipSuccess) return e;
+		cap = bytes + bytes / 8 + 4096 - 64;
+	}
+	*dst = buf;
+	return bytes ? hipMemcpyAsync(buf, src, bytes, hipMemcpyHostToDevice, h->tb_copy_stream) : hipSuccess;
+}
+static int tb_pipeline_ready(kmr_handle *h) {
+	if (h->tb_copy_stream) return 0;
+	HIPCHK(h, hipStreamCreateWithFlags(&h->tb_copy_stream, hipStreamNonBlocking));
+	for (int i = 0; i < 2; i++) { HIPCHK(h, hipEventCreateWithFlags(&h->tb_ready[i], hipEventDisableTiming)); HIPCHK(h, hipEventCreateWithFlags(&h->tb_consumed[i], hipEventDisableTiming)); }
+	return 0;
+}
+
 int kmr_add_reads(kmr_handle *h, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n_reads,
                   uint64_t first_global_read_idx, const uint8_t *discarded) {
 	if (!h) return KMR_ERR_INVALID_ARG;
@@ -2108,12 +2126,33 @@ int kmr_add_reads(kmr_handle *h, const char *bases, const char *quals, const uin
 	if (n_reads == 0) return KMR_OK;
 	if (!bases || !offsets) return fail(h, KMR_ERR_INVALID_ARG, "null buffer");
 	hipSetDevice(h->device);
-	StagedReads s; uint64_t total = 0;
-	int rc = stage_reads(h, bases, quals, offsets, n_reads, discarded, s, total);
-	if (!rc) rc = kmr_add_reads_dev(h, s.b, s.q, s.o, n_reads, total, first_global_read_idx, s.d);
+	/* pieces of about 2^28 bases through two sets of staging buffers and the handle's copy stream: piece i + 1 is on the bus while the
+	 * device extracts piece i; the offsets go over as they are (the device arrays are addressed through pointers moved back by the
+	 * piece's first offset) */
+	{ int rcp = tb_pipeline_ready(h); if (rcp) return rcp; }
+#define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->tb_copy_stream); hipStreamSynchronize(h->stream); h->err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+	const uint64_t piece_bases = h->tune.twobit_piece_bases ? h->tune.twobit_piece_bases : (1ull << 28);
+	int rc = KMR_OK; int set = 0;
+	for (uint64_t r0 = 0; r0 < n_reads && rc == KMR_OK; set ^= 1) {
+		uint64_t r1 = r0 + 1;
+		while (r1 < n_reads && offsets[r1 + 1] - offsets[r0] <= piece_bases) r1++;
+		const uint64_t m = r1 - r0, total = offsets[r1] - offsets[r0];
+		void *db = nullptr, *dq = nullptr, *doff = nullptr, *dd = nullptr;
+		if (h->tb_set_used[set]) TBCHK(hipStreamWaitEvent(h->tb_copy_stream, h->tb_consumed[set], 0));
+		TBCHK(tb_stage_copy(h, set, 0, bases + offsets[r0], total, &db)); TBCHK(tb_stage_copy(h, set, 2, offsets + r0, 8 * (m + 1), &doff));
+		if (quals) TBCHK(tb_stage_copy(h, set, 6, quals + offsets[r0], total, &dq));
+		if (discarded) TBCHK(tb_stage_copy(h, set, 7, discarded + r0, m, &dd));
+		TBCHK(hipMemsetAsync((uint8_t *)db + total, 0, 64, h->tb_copy_stream)); if (dq) TBCHK(hipMemsetAsync((uint8_t *)dq + total, 0, 64, h->tb_copy_stream));
+		TBCHK(hipEventRecord(h->tb_ready[set], h->tb_copy_stream));
+		TBCHK(hipStreamWaitEvent(h->stream, h->tb_ready[set], 0));
+		rc = kmr_add_reads_dev(h, (uint8_t *)db - offsets[r0], dq ? (uint8_t *)dq - offsets[r0] : nullptr, doff, m, total, first_global_read_idx + r0, dd);
+		TBCHK(hipEventRecord(h->tb_consumed[set], h->stream)); h->tb_set_used[set] = true;
+		r0 = r1;
+	}
+#undef TBCHK
+	hipStreamSynchronize(h->tb_copy_stream);
 	if (!rc) rc = sync_state(h);
 	else hipStreamSynchronize(h->stream);
-	s.release();
 	return rc;
 }
 
@@ -2185,18 +2224,8 @@ int kmr_add_reads_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *t
 	/* The batch goes over in pieces of about 2^28 bases through two sets of staging buffers and a copy stream of the handle's own:
 	 * while the device unpacks and extracts piece i, piece i + 1 is on the bus (the host's pageable memory: the calling thread feeds
 	 * the copies, the device does not wait for it). */
-	struct Stage { uint8_t *b[8]; size_t cap[8]; };      /* 0 packed bases, 1 their offsets, 2 base offsets, 3 markup offsets, 4 positions, 5 characters, 6 qualities, 7 discarded */
-	if (!h->tb_copy_stream) { HIPCHK(h, hipStreamCreateWithFlags(&h->tb_copy_stream, hipStreamNonBlocking)); for (int i = 0; i < 2; i++) { HIPCHK(h, hipEventCreateWithFlags(&h->tb_ready[i], hipEventDisableTiming)); HIPCHK(h, hipEventCreateWithFlags(&h->tb_consumed[i], hipEventDisableTiming)); } }
-	auto stage = [&](int set, int which, const void *src, size_t bytes, void **dst) -> hipError_t {
-		uint8_t *&buf = h->tb_stage[set][which]; size_t &cap = h->tb_stage_cap[set][which];
-		if (cap < bytes + 64) {
-			if (buf) { hipError_t e0 = hipStreamSynchronize(h->stream); if (e0 != hipSuccess) return e0; hipFree(buf); buf = nullptr; cap = 0; }
-			hipError_t e = hipMalloc((void **)&buf, bytes + bytes / 8 + 4096); if (e != hipSuccess) return e;
-			cap = bytes + bytes / 8 + 4096 - 64;
-		}
-		*dst = buf;
-		return bytes ? hipMemcpyAsync(buf, src, bytes, hipMemcpyHostToDevice, h->tb_copy_stream) : hipSuccess;
-	};
+	{ int rcp = tb_pipeline_ready(h); if (rcp) return rcp; }
+	auto stage = [&](int set, int which, const void *src, size_t bytes, void **dst) -> hipError_t { return tb_stage_copy(h, set, which, src, bytes, dst); };
 #define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->tb_copy_stream); hipStreamSynchronize(h->stream); h->err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
 	const uint64_t piece_bases = h->tune.twobit_piece_bases ? h->tune.twobit_piece_bases : (1ull << 28);
 	int rc = KMR_OK; int set = 0;
