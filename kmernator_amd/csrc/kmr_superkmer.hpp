@@ -2431,7 +2431,7 @@ __global__ void sk_meta_counts_kernel(const uint2 *meta, uint64_t n, uint32_t *c
  * back, so the chunk's used granules are appended as ONE piece (one booking of the list's word; they land behind what the list's
  * open chunk holds if they fit, else at the head of a fresh chunk) and copied a granule per lane -- booking record by record put 32
  * lanes of a wavefront on the same word at once (65 ms for half a C2 batch). */
-static const int SK_ADOPT_WAVES = 4, SK_ADOPT_GROUP = 8;
+static const int SK_ADOPT_WAVES = 4, SK_ADOPT_GROUP = 32;
 #ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(SK_ADOPT_WAVES * 64)
 void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t *in_start, uint64_t n_in, SkParams sp, PoolView pool) {
@@ -2450,12 +2450,21 @@ void sk_adopt_kernel(const uint4 *in_data, const uint2 *in_meta, const uint64_t 
 			myList = m.x; myCnt = m.y < SK_CHUNK_G ? m.y : SK_CHUNK_G; myStart = in_start[c0 + lane];
 			if (myCnt) myAt = sk_append(sp.state, myList, myCnt, slab, pool);
 		}
+		/* the group's granules are asked for together (the sources' positions are known before the bookings come back), then stored where the
+		 * bookings say; the per-chunk scalars come by readlane (j is a constant after unrolling), not by LDS permutes */
+		uint4 v[SK_ADOPT_GROUP];
 #pragma unroll
 		for (int j = 0; j < SK_ADOPT_GROUP; j++) {
-			const uint32_t cnt = (uint32_t)__shfl((int)myCnt, j, 64);
-			const unsigned long long at = ((unsigned long long)(uint32_t)__shfl((int)(myAt >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)myAt, j, 64);
-			const unsigned long long st = ((unsigned long long)(uint32_t)__shfl((int)(myStart >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)myStart, j, 64);
-			if (at != ~0ull && (uint32_t)lane < cnt) ((uint4 *)pool.base)[at + lane] = in_data[st + lane];
+			const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)myCnt, j);
+			const unsigned long long st = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(myStart >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)myStart, j);
+			v[j] = make_uint4(0, 0, 0, 0);
+			if ((uint32_t)lane < cnt) v[j] = in_data[st + lane];
+		}
+#pragma unroll
+		for (int j = 0; j < SK_ADOPT_GROUP; j++) {
+			const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)myCnt, j);
+			const unsigned long long at = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(myAt >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)myAt, j);
+			if (at != ~0ull && (uint32_t)lane < cnt) ((uint4 *)pool.base)[at + lane] = v[j];
 		}
 		if (slab->next >= 64u) {
 			__builtin_amdgcn_wave_barrier();
