@@ -19,7 +19,8 @@
  * (src/KmerReadUtils.h:176-248), KmerSpectrum::append + track() (src/KmerSpectrum.h:1578-1668,
  * src/KmerTrackingData.h:427,517,641) and purgeMinDepth (:1805-1815).  The minimizer, the list function and the record
  * format are private: no result depends on them (tests hold the maps byte-identical to the other build modes and to the
- * oracle).  Values: TrackingDataWithDirection / TrackingDataSingleton (KMR_VALUE_COUNT_DIR) only.
+ * oracle).  Values: TrackingDataWithDirection / TrackingDataSingleton (KMR_VALUE_COUNT_DIR) and, with two quality bytes per k-mer and
+ * the two outer neighbours in a record, ExtensionTrackingData / ...Singleton (KMR_VALUE_EXT: sk_extract_kernel<..., EXT>, sk_count_kernel<..., EXT>).
  *
  * Minimizer of a k-mer: the smallest hash among the canonical m-mers at WIN consecutive offsets placed symmetrically inside
  * the k-mer ([off, off + WIN) with 2 * off + WIN = k - m + 1), so a k-mer and its reverse complement see the same set of
