@@ -231,6 +231,20 @@ def test_reference_reads_without_quals_and_discarded(mode):
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
 
 
+@pytest.mark.parametrize("k", [13, 16, 17, 32, 33, 47, 64, 65, 96, 127])
+def test_ext_values_on_the_lists_many_k(k):
+    """extension values on the super-k-mer lists across key widths and the window geometries of small k: a k-mer's right neighbour comes
+    out of the register window it was cut from -- except at k = 32 W, where it is the record's next dword -- its left one from the k-mer
+    made before it; reads of 260 bases, N's, with and without a singleton map: tallies and singleton packets are the oracle's"""
+    rb = synth_reads(1200, read_len=260, genome_len=9000, seed=300 + k, quality="noisy", n_rate=0.004)
+    for sep in (1, 0):
+        cfg = default_config(k, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2, num_buckets_weak=128, num_buckets_singleton=256, separate_singletons=sep)
+        o, p = run_both(cfg, rb, min_depth=1, mode=3)
+        assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, True) == o.stats()["weak_entries"]
+        if sep:
+            assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+
+
 @pytest.mark.parametrize("k", [21, 51])
 def test_ext_values_with_filters_on_the_lists(k):
     """extension values through the FILTERING extraction of build_mode 3 (a hash partition of the k-mers, a sub-sample): the part's weak
