@@ -1411,6 +1411,8 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					/* the usual chunk holds two-granule records only (a header and up to 64 bases): if every even granule says "2" where a
 					 * header keeps its granule count, every even granule is a header (granule 0 is one, and each one vouches for the next) */
 					if (__all((lane & 1) != 0 || (uint32_t)lane >= curCount || glen == 2u)) starts = 0x5555555555555555ull & (curCount >= 64u ? ~0ull : ((1ull << curCount) - 1ull));
+					/* (the usual chunk of a build with extension values: header, bases, qualities -- three granules a record) */
+					else if (EXT && __all(((uint32_t)lane * 43u >> 7) * 3u != (uint32_t)lane || (uint32_t)lane >= curCount || glen == 3u)) starts = 0x9249249249249249ull & (curCount >= 64u ? ~0ull : ((1ull << curCount) - 1ull));
 					else for (uint32_t pos = 0; pos < curCount; ) {
 						starts |= 1ull << pos;
 						const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos);
