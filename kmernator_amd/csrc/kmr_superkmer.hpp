@@ -1413,10 +1413,24 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					if (__all((lane & 1) != 0 || (uint32_t)lane >= curCount || glen == 2u)) starts = 0x5555555555555555ull & (curCount >= 64u ? ~0ull : ((1ull << curCount) - 1ull));
 					/* (the usual chunk of a build with extension values: header, bases, qualities -- three granules a record) */
 					else if (EXT && __all(((uint32_t)lane * 43u >> 7) * 3u != (uint32_t)lane || (uint32_t)lane >= curCount || glen == 3u)) starts = 0x9249249249249249ull & (curCount >= 64u ? ~0ull : ((1ull << curCount) - 1ull));
-					else for (uint32_t pos = 0; pos < curCount; ) {
+					else {
+						/* Records of mixed sizes (a weight per k-mer, extension values of long runs).  Every granule that READS like a header -- a k-mer
+						 * count and a granule count that agree -- is a candidate; the candidates are exactly the headers iff following the granule
+						 * counts maps them one-to-one onto themselves without the first (each but granule 0 is pointed at by one, the pointers only
+						 * go forward): eight ballots by distance instead of a scalar walk with a v_readlane per record.  A data granule that
+						 * passes for a header breaks the equality, and the walk decides. */
+						const uint32_t hn = (cur.y >> 8) & 0xffu;
+						const bool cand = (uint32_t)lane < curCount && hn >= 1u && hn <= SK_MAX_N && glen == sk_rec_granules(hn, k, ((cur.y >> 16) & 1u) != 0, EXT) && ((cur.y >> 30) & 1u) == (EXT ? 1u : 0u);
+						const unsigned long long C = __ballot(cand), inRange = curCount >= 64u ? ~0ull : ((1ull << curCount) - 1ull);
+						unsigned long long N = 0;
+#pragma unroll
+						for (uint32_t d = 2; d <= 9; d++) N |= __ballot(cand && glen == d) << d;
+						if ((C & 1ull) && !__any(cand && glen > 9u) && (N & inRange) == (C & ~1ull)) starts = C;
+						else for (uint32_t pos = 0; pos < curCount; ) {
 						starts |= 1ull << pos;
 						const uint32_t step = (uint32_t)__builtin_amdgcn_readlane((int)glen, (int)pos);
 						pos += step ? step : SK_CHUNK_G;        /* a zero would never end: a corrupt chunk is dropped */
+					}
 					}
 					/* The chunk's k-mers are dealt out evenly: with T of them, lane l takes slots [l Lk, (l + 1) Lk), Lk = ceil(T / 64),
 					 * in the order the records lie in the chunk.  The record a lane starts in is told to it by that record's header
