@@ -43,7 +43,7 @@ static const uint32_t SK_CHUNK_G = 64;        /* 16-byte granules per chunk: 1 K
 static const uint32_t SK_MAX_N = KMR_SK_MAX_N;         /* k-mers per record                                                    */
 static const int SK_WAVES = 3;                /* wavefronts per block of sk_extract_kernel (two blocks per CU by LDS) */
 static const int SK_WINDOW = 16;              /* positions between two gathers = the unroll of the position loop      */
-static const int SK_RR = 4;                   /* records a lane books per gather round                                */
+static const int SK_RR = 3, SKL_RR = 4;      /* general / lean extraction (general: 2 / 3 / 4 / 6 per round = 19.2 / 19.0 / 19.25 / 19.8 ms per noisy C2 batch; lean: 1 / 2 / 3 / 4 / 6 = 8.1 / 7.7 / 7.8 / 7.7 / 9.6): records a lane books per gather round */
 
 #ifdef KMR_DEBUG_HOOKS
 #define SK_DBG(flags, bit) (((flags) & (bit)) != 0)
@@ -1043,13 +1043,13 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 		bool runOpen = false, runInWin = false;
 		uint32_t runStart = 0, runN = 0, runMh = 0;
 		/* records booked but not yet written: start | n << 16 | 1 << 24 | 1 << 30 (an address, not a booking) | 1 << 31, minimizer hash, what the booking add returned */
-		uint32_t q_info[SK_RR], q_mh[SK_RR]; unsigned long long q_booked[SK_RR];
+		uint32_t q_info[SKL_RR], q_mh[SKL_RR]; unsigned long long q_booked[SKL_RR];
 #pragma unroll
-		for (int r = 0; r < SK_RR; r++) { q_info[r] = 0; q_mh[r] = 0; q_booked[r] = 0; }
+		for (int r = 0; r < SKL_RR; r++) { q_info[r] = 0; q_mh[r] = 0; q_booked[r] = 0; }
 		auto flush_pending = [&]() {
-			uint64_t at[SK_RR]; bool waits[SK_RR];
+			uint64_t at[SKL_RR]; bool waits[SKL_RR];
 #pragma unroll
-			for (int r = 0; r < SK_RR; r++) {
+			for (int r = 0; r < SKL_RR; r++) {
 				waits[r] = false; at[r] = ~0ull;
 				if (q_info[r] >> 31) {
 					const uint32_t nn = (q_info[r] >> 16) & 0xffu;
@@ -1058,12 +1058,12 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 				}
 			}
 #pragma unroll
-			for (int r = 0; r < SK_RR; r++) if (waits[r]) {
+			for (int r = 0; r < SKL_RR; r++) if (waits[r]) {
 				const uint32_t nn = (q_info[r] >> 16) & 0xffu;
 				at[r] = sk_append(sp.state, sk_list_of(q_mh[r], sp.list_bits), 1 + sk_base_granules(nn, k), slab, pool);
 			}
 #pragma unroll
-			for (int r = 0; r < SK_RR; r++) {
+			for (int r = 0; r < SKL_RR; r++) {
 				if ((q_info[r] >> 31) && at[r] != ~0ull) {
 					const uint32_t start = q_info[r] & 0xffffu, nn = (q_info[r] >> 16) & 0xffu;
 					const uint32_t nbg = sk_base_granules(nn, k);
@@ -1169,7 +1169,7 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 			const uint32_t hotNow = slab->hot_list;
 			while (__any(pendC || Srem)) {
 #pragma unroll
-				for (int r = 0; r < SK_RR; r++) {
+				for (int r = 0; r < SKL_RR; r++) {
 					q_info[r] = 0;
 					if (pendC) { pendC = false; q_info[r] = (1u << 31) | (1u << 24) | ((cinN + lead) << 16) | cinStart; q_mh[r] = cinMh; }
 					else if (Srem) {
