@@ -303,6 +303,21 @@ __device__ __forceinline__ uint2 sk_lds_bytes8(const uint8_t *base, uint32_t off
 /* (x - c) & 0xff in every byte of x; c4 = (256 - c) & 0xff in every byte */
 __device__ __forceinline__ uint32_t sk_bytes_add(uint32_t x, uint32_t c4) { return ((x & 0x7f7f7f7fu) + (c4 & 0x7f7f7f7fu)) ^ ((x ^ c4) & 0x80808080u); }
 
+/* the product a weight chain starts afresh with: P[q] of the k qualities from *q on, multiplied in sequence (buildWeightedKmers,
+ * src/KmerReadUtils.h:205-208) */
+static const int SK_PB = 8;      /* (4 / 8 / 16 at a time: 18.45 / 18.45 / 18.7 ms per noisy C2 batch; factor by factor 19.2) */
+__device__ __forceinline__ double sk_fresh_product(const double *sP, const uint8_t *q, uint32_t k) {
+	double w = 1.0;
+	for (uint32_t j0 = 0; j0 < k; j0 += SK_PB) {
+		double pv[SK_PB];
+#pragma unroll
+		for (int u = 0; u < SK_PB; u++) pv[u] = sP[q[j0 + u < k ? j0 + u : k - 1]];
+#pragma unroll
+		for (int u = 0; u < SK_PB; u++) if (j0 + u < k) w *= pv[u];
+	}
+	return w;
+}
+
 template <int W, int WIN, bool FILT, bool EXT = false>
 __global__ __launch_bounds__(SK_WAVES * 64, 2)
 void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
@@ -718,7 +733,11 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				if (tR < 16) {
 					const uint32_t jR = jb + tR, iR = jR + 1 - k;
 					if (qrunR + 1 >= k) wR = sp.Pk[rq[jR]];                 /* k equal qualities: the table holds the same sequence of products */
-					else { wR = 1.0; for (uint32_t jj = 0; jj < k; jj++) wR *= sP[rq[iR + jj]]; }
+					else {
+						/* the k probabilities first (SK_PB at a time: the byte reads, then the table reads, each batch ONE LDS round trip), then the
+						 * multiplications in the reference's order -- factor by factor it was two dependent LDS round trips each */
+						wR = sk_fresh_product(sP, rq + iR, k);
+					}
 				}
 			}
 #pragma unroll 4      /* (rolled: 19.9 ms per noisy C2 batch; by 2: 19.6; by 4: 19.4; by 8: 19.7; whole: 19.9 -- the code of 16 bodies) */
@@ -731,7 +750,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				const bool live = hasK && !zero && !isRef;
 				const bool fresh = live && ((i & 1023u) == 0 || w == 0.0);
 				if (__any(fresh && t != tR)) {
-					if (fresh && t != tR) { w = 1.0; for (uint32_t jj = 0; jj < k; jj++) w *= sP[rq[i + jj]]; }      /* (the table entry is this very product) */
+										if (fresh && t != tR) { w = 1.0; for (uint32_t jj = 0; jj < k; jj++) w *= sP[rq[i + jj]]; }      /* (rare, and inside the unrolled sweep: the plain loop) */      /* (the table entry is this very product) */
 				}
 				w = (fresh && t == tR) ? wR : w;
 				const uint32_t q = rq[hasK ? j : 0u], qo = rq[(hasK && i > 0) ? i - 1 : 0u];
@@ -784,7 +803,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 					else if (isRef) w = 1.0;
 					else if ((i & 1023u) == 0 || w == 0.0) {
 						if (qrun + 1 >= k) w = sp.Pk[rq[j]];                 /* k equal qualities: the table holds the same sequence of products */
-						else { w = 1.0; for (uint32_t jj = 0; jj < k; jj++) w *= sP[rq[i + jj]]; }
+						else w = sk_fresh_product(sP, rq + i, k);
 					} else if (qrun < k) {
 						/* x / x == 1.0 exactly, so equal qualities leave w unchanged; a run of k+1 equal chars proves that without a load */
 						const uint32_t q = rq[j], qo = rq[i - 1];
