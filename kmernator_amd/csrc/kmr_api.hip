@@ -71,6 +71,7 @@ struct Tuning {
 	uint64_t long_list_chunks = 0;     /* lists of more chunks are counted in pieces (0: 1024) */
 	uint64_t binned_min = 1ull << 18;  /* weak maps of at least this many entries are bucketed by the radix partition of kmr_buckets.hpp (build_mode 3) */
 	uint64_t twobit_piece_bases = 0;   /* kmr_add_reads_twobit: bases per piece of the host-to-device pipeline (0 = 2^26) */
+	bool no_packed_direct = false;     /* kmr_add_reads_twobit* always unpack to text first (A/B runs, tests of the unpack path) */
 	bool no_lean_extract = false;      /* never take sk_extract_lean_kernel (A/B runs, tests of the general kernel on uniform qualities) */
 	bool exchange_fail_once = false;   /* tests: the next kmr_exchange_add_reads_dev of this rank fails locally (the other ranks must come back with an error, not hang) */
 	bool no_coarse_lists = true;       /* exchange: scatter into the job's fine lists (default) or, kmr_tune("coarse_lists", 1), into coarse ones that the owner splits before the count pass (sk_refine_kernel: not yet fast enough to pay) */
@@ -139,6 +140,7 @@ struct kmr_handle {
 	uint64_t tb_bases_cap = 0, tb_quals_cap = 0, tb_quals_filled = 0, tb_n = 0; int tb_quals_char = -1;
 	hipStream_t tb_copy_stream = nullptr; hipEvent_t tb_ready[2] = {nullptr, nullptr}, tb_consumed[2] = {nullptr, nullptr}; bool tb_set_used[2] = {false, false};
 	uint8_t *tb_stage[2][8] = {{nullptr}}; size_t tb_stage_cap[2][8] = {{0}};      /* kmr_add_reads_twobit: two sets of staging buffers for the pieces on the bus */
+	const SkPacked *packed_direct = nullptr;      /* set while kmr_add_reads_twobit_dev feeds a batch that sk_extract_lean_kernel<.., PACKED> takes as it is */
 	int uniform_q_hint = -1;           /* >= 0 while kmr_add_reads_twobit_dev feeds a batch whose qualities are this one character */
 	void *uw_keys = nullptr, *uw_vals = nullptr, *us_keys = nullptr, *us_b8 = nullptr, *us_pkt = nullptr; uint64_t uw_cap = 0, us_cap = 0;
 	/* build_mode 3: the count pass's weak entries packed (kmr_buckets.hpp: W key words + one value word), and the radix partition's scratch of the same layout */
@@ -332,19 +334,19 @@ const size_t EXTRACT_SMEM = (size_t)WAVES_PER_BLOCK * 2 * TILE_BUF;
 int exclusive_scan(kmr_handle *h, const uint32_t *in, uint64_t n, uint64_t *out);
 
 /* If the batch holds reads longer than one LDS tile, cut them into work units (see ReadsView) and point rv at them. */
-int prepare_units(kmr_handle *h, ReadsView &rv) {
+int prepare_units(kmr_handle *h, ReadsView &rv, uint32_t span = (uint32_t)TILE_SPAN) {
 	rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
 	const uint64_t n = rv.n_reads;
 	if (n == 0) return 0;
 	if (!h->umax) HIPCHK(h, hipMalloc((void **)&h->umax, 4));
 	HIPCHK(h, hipMemsetAsync(h->umax, 0, 4, h->stream));
 	if (!h->ucnt || h->ucnt_n < n + 1) { if (h->ucnt) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->ucnt); } h->ucnt = nullptr; HIPCHK(h, hipMalloc((void **)&h->ucnt, 4 * (n + 1))); h->ucnt_n = n + 1; }
-	hipLaunchKernelGGL(unit_count_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, rv.offsets, n, h->k, (uint32_t)TILE_SPAN, h->ucnt, h->umax);
+	hipLaunchKernelGGL(unit_count_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, rv.offsets, n, h->k, span, h->ucnt, h->umax);
 	HIPCHK(h, hipGetLastError());
 	unsigned int mx = 0;
 	HIPCHK(h, hipMemcpyAsync(&mx, h->umax, 4, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
-	if (mx <= (unsigned)TILE_SPAN) return 0;                   /* the usual case: every read is one unit */
+	if (mx <= span) return 0;                   /* the usual case: every read is one unit */
 	if (!h->ufirst || h->ufirst_n < n + 1) { if (h->ufirst) hipFree(h->ufirst); h->ufirst = nullptr; HIPCHK(h, hipMalloc((void **)&h->ufirst, 8 * (n + 1))); h->ufirst_n = n + 1; }
 	int rc = exclusive_scan(h, h->ucnt, n, h->ufirst); if (rc) return rc;
 	uint64_t U = 0;
@@ -355,7 +357,7 @@ int prepare_units(kmr_handle *h, ReadsView &rv) {
 		HIPCHK(h, hipMalloc((void **)&h->u_start, 8 * U)); HIPCHK(h, hipMalloc((void **)&h->u_end, 8 * U)); HIPCHK(h, hipMalloc((void **)&h->u_read, 8 * U));
 		h->units_n = U;
 	}
-	hipLaunchKernelGGL(unit_fill_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, rv.offsets, n, h->k, (uint32_t)TILE_SPAN, h->ufirst, h->u_start, h->u_end, h->u_read);
+	hipLaunchKernelGGL(unit_fill_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, rv.offsets, n, h->k, span, h->ufirst, h->u_start, h->u_end, h->u_read);
 	HIPCHK(h, hipGetLastError());
 	rv.u_start = h->u_start; rv.u_end = h->u_end; rv.u_read = h->u_read; rv.n_units = U;
 	return 0;
@@ -1418,14 +1420,16 @@ template <int W, int WIN, bool FILT, bool EXT = false> int launch_sk_extract(kmr
 }
 uint32_t sk_dbg_flags(const char *name);
 bool sp_debug_extract(kmr_handle *h) { (void)h; return sk_dbg_flags("KMR_SK_EXTRACT_DBG") != 0; }      /* the ablation switches live in the general kernel */
-template <int W, int WIN> int launch_sk_extract_lean(kmr_handle *h, const ReadsView &rv, const SkParams &sp, float wK, const DevParams *override_params = nullptr) {
-	auto kern = sk_extract_lean_kernel<W, WIN>;
+template <int W, int WIN, bool PACKED = false> int launch_sk_extract_lean(kmr_handle *h, const ReadsView &rv, const SkParams &sp, float wK, const DevParams *override_params = nullptr, const SkPacked *packed = nullptr) {
+	auto kern = sk_extract_lean_kernel<W, WIN, PACKED>;
+	SkPacked pkd; pkd.bytes = nullptr; pkd.off = nullptr; pkd.mk_off = nullptr; pkd.mk_pos = nullptr; pkd.mk_char = nullptr;
+	if (PACKED) pkd = *packed;
 	HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SKL_EXTRACT_SMEM));
 	const uint64_t tiles = ((rv.u_start ? rv.n_units : rv.n_reads) + 63) / 64;
 	uint64_t blocks = (tiles + SKL_WAVES - 1) / SKL_WAVES;
 	if (blocks == 0) return 0;
 	blocks = std::min<uint64_t>(blocks, (uint64_t)num_cus(h) * SKL_MIN_BLOCKS);      /* resident grid: a wavefront walks tiles tile0, tile0 + stride, ... */
-	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SKL_WAVES * 64), SKL_EXTRACT_SMEM, h->stream, rv, override_params ? *override_params : dev_params(h), sp, pool_view(h, h->l1), wK);
+	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SKL_WAVES * 64), SKL_EXTRACT_SMEM, h->stream, rv, override_params ? *override_params : dev_params(h), sp, pool_view(h, h->l1), wK, pkd);
 	HIPCHK(h, hipGetLastError());
 	return 0;
 }
@@ -1435,7 +1439,7 @@ template <int W, int WIN> int launch_sk_extract_lean(kmr_handle *h, const ReadsV
 int sk_uniform_weight(kmr_handle *h, const ReadsView &rv, bool &lean, float &wK) {
 	lean = false; wK = 1.0f;
 	if (h->tune.no_lean_extract) return 0;
-	if (!rv.quals) { lean = true; return 0; }
+	if (!rv.quals && h->uniform_q_hint < 0) { lean = true; return 0; }
 	if (h->qual_mixed || rv.n_reads == 0) return 0;
 	if (h->uniform_q_hint >= 0) {      /* the caller said so (kmr_add_reads_twobit*): no pass over the quality bytes, no round trip */
 		const unsigned int q0 = (unsigned int)h->uniform_q_hint;
@@ -1508,13 +1512,14 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 	const bool filt = dp.subsample > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0 || (dp.world > 1 && !h->sk_exchange);
 	bool lean = false; float wK = 1.0f;
 	if (!filt && !h->ext && !sp_debug_extract(h)) { int rcq = sk_uniform_weight(h, rvAll, lean, wK); if (rcq) return rcq; }      /* (extension values want every neighbour's quality: the general kernel) */
+	if (h->packed_direct && (!lean || h->cfg.size_tracker)) return fail(h, KMR_ERR_STATE, "internal: a packed batch handed to an extraction that wants text");      /* (sk_packed_direct_ok said otherwise) */
 	for (uint64_t r = 0; r < n; r += chunk) {
 		const uint64_t m = std::min(chunk, n - r);
 		ReadsView rv = rvAll;
 		rv.offsets = rvAll.offsets + r; rv.n_reads = m;
 		rv.discarded = rvAll.discarded ? rvAll.discarded + r : nullptr;
 		rv.first_read_idx = rvAll.first_read_idx + r;
-		int rc = prepare_units(h, rv); if (rc) return rc;
+		int rc = prepare_units(h, rv, h->packed_direct ? SK_PACKED_SPAN : (uint32_t)TILE_SPAN); if (rc) return rc;
 		/* room for this launch: a granule per k-mer is more than any input takes (flat qualities: a quarter of that), one open
 		 * chunk per list and two slabs of 64 chunks per wavefront */
 		const uint64_t bases = m * avg + avg;
@@ -1525,6 +1530,10 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		if (h->cfg.size_tracker) sp.track = h->trk + r;
 #define SKX(WINv) (h->ext ? (filt ? launch_sk_extract<W, WINv, true, true>(h, rv, sp) : launch_sk_extract<W, WINv, false, true>(h, rv, sp)) : \
                    (filt ? launch_sk_extract<W, WINv, true>(h, rv, sp) : (lean ? launch_sk_extract_lean<W, WINv>(h, rv, sp, wK) : launch_sk_extract<W, WINv, false>(h, rv, sp))))
+		if (h->packed_direct) {
+			SkPacked pkd = *h->packed_direct; pkd.off += r; if (pkd.mk_off) pkd.mk_off += r;
+			rc = h->sk_win == 16 ? launch_sk_extract_lean<W, 16, true>(h, rv, sp, wK, nullptr, &pkd) : (h->sk_win == 8 ? launch_sk_extract_lean<W, 8, true>(h, rv, sp, wK, nullptr, &pkd) : launch_sk_extract_lean<W, 4, true>(h, rv, sp, wK, nullptr, &pkd));
+		} else
 		rc = h->sk_win == 16 ? SKX(16) : (h->sk_win == 8 ? SKX(8) : SKX(4));
 #undef SKX
 		time_end(h, KMR_TIME_EXTRACT, a2, b2); time_end(h, KMR_TIME_BUILD, a, b);
@@ -2066,6 +2075,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "stream_lookups") h->tune.no_stream_lookups = value == 0;
 	else if (k == "long_list_chunks") h->tune.long_list_chunks = value < 2 ? 2 : (uint64_t)value;
 	else if (k == "lean_extract") h->tune.no_lean_extract = value == 0;
+	else if (k == "packed_direct") h->tune.no_packed_direct = value == 0;
 	else if (k == "twobit_piece_bases") h->tune.twobit_piece_bases = (uint64_t)value;
 	else if (k == "exchange_fail_once") h->tune.exchange_fail_once = value != 0;
 	else if (k == "binned_buckets_min") h->tune.binned_min = value >= 0 ? (uint64_t)value : ~0ull;        /* < 0: never */
@@ -2156,6 +2166,14 @@ int kmr_add_reads(kmr_handle *h, const char *bases, const char *quals, const uin
 	return rc;
 }
 
+/* May sk_extract_lean_kernel<.., PACKED> take a packed batch as it is?  Whenever add_reads_superkmer_t would hand the unpacked
+ * batch to the lean extraction: lists, direction-counting values, nothing that filters k-mers, and one weight for every k-mer. */
+static bool sk_packed_direct_ok(kmr_handle *h, bool has_quals, int uniform_quality) {
+	if (!h->superkmer_mode || h->ext || h->cfg.size_tracker || h->tune.no_lean_extract || h->tune.no_packed_direct || sp_debug_extract(h) || has_quals || h->qual_mixed) return false;
+	const DevParams dp = dev_params(h);
+	if (dp.subsample > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0 || (dp.world > 1 && !h->sk_exchange)) return false;
+	return uniform_quality == 0 || uniform_quality == 127 || h->hP[uniform_quality] > 0.0;
+}
 int kmr_add_reads_twobit_dev(kmr_handle *h, const void *dev_twobit, const void *dev_twobit_offsets, const void *dev_offsets,
                              const void *dev_markup_offsets, const void *dev_markup_pos, const void *dev_markup_char,
                              const void *dev_quals, int uniform_quality, uint64_t n_reads, uint64_t total_bases,
@@ -2169,7 +2187,8 @@ int kmr_add_reads_twobit_dev(kmr_handle *h, const void *dev_twobit, const void *
 	hipSetDevice(h->device);
 	/* grow-only scratch of the handle; everything below is ordered on the handle's stream, so the next call's unpack waits for
 	 * this call's extraction */
-	if (h->tb_bases_cap < total_bases + 64) {
+	const bool direct = sk_packed_direct_ok(h, dev_quals != nullptr, uniform_quality);
+	if (!direct && h->tb_bases_cap < total_bases + 64) {
 		if (h->tb_bases) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->tb_bases); h->tb_bases = nullptr; h->tb_bases_cap = 0; }
 		HIPCHK(h, hipMalloc((void **)&h->tb_bases, total_bases + 64)); h->tb_bases_cap = total_bases + 64;
 		HIPCHK(h, hipMemsetAsync(h->tb_bases, 0, total_bases + 64, h->stream));
@@ -2185,6 +2204,20 @@ int kmr_add_reads_twobit_dev(kmr_handle *h, const void *dev_twobit, const void *
 		HIPCHK(h, hipGetLastError());
 		int rc = exclusive_scan(h, h->tb_len, n_reads, h->tb_off); if (rc) return rc;
 		tboff = h->tb_off;
+	}
+	if (direct) {
+		/* the lean extraction stages the packed bytes as they are: no unpacked copy of the batch, no quality bytes */
+		hipLaunchKernelGGL(offsets_rel_kernel, dim3(grid_for(n_reads + 1)), dim3(256), 0, h->stream, (const uint64_t *)dev_offsets, n_reads, h->tb_rel);
+		HIPCHK(h, hipGetLastError());
+		if (h->stream_base + total_bases > MAX_STREAM_ORDINAL) return fail(h, KMR_ERR_CAPACITY, "more than 2^40 input bases on one handle");
+		ReadsView rv; rv.bases = nullptr; rv.quals = nullptr; rv.offsets = h->tb_rel; rv.discarded = (const uint8_t *)dev_discarded; rv.n_reads = n_reads;
+		rv.stream_base = h->stream_base; rv.first_read_idx = first_global_read_idx; rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
+		SkPacked pkd; pkd.bytes = (const uint8_t *)dev_twobit; pkd.off = tboff; pkd.mk_off = (const uint64_t *)dev_markup_offsets; pkd.mk_pos = (const uint32_t *)dev_markup_pos; pkd.mk_char = (const uint8_t *)dev_markup_char;
+		h->packed_direct = &pkd; h->uniform_q_hint = uniform_quality ? uniform_quality : -1;
+		const int rc = add_reads_superkmer(h, rv, total_bases);
+		h->packed_direct = nullptr; h->uniform_q_hint = -1;
+		h->stream_base += total_bases; h->reads += n_reads; h->stats.reads = h->reads;
+		return rc;
 	}
 	hipLaunchKernelGGL(twobit_unpack_kernel, dim3((unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)num_cus(h) * 32)), dim3(256), 0, h->stream,
 	                   (const uint8_t *)dev_twobit, tboff, (const uint64_t *)dev_offsets, n_reads, h->tb_bases, h->tb_rel);

@@ -334,6 +334,12 @@ __global__ void twobit_markup_kernel(const uint64_t *mk_off, const uint32_t *mk_
 	}
 }
 
+/* rel[i] = offsets[i] - offsets[0], i = 0 .. n: a call's reads addressed from its first base */
+__global__ void offsets_rel_kernel(const uint64_t *offsets, uint64_t n, uint64_t *rel) {
+	const uint64_t o0 = offsets[0];
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) rel[i] = offsets[i] - o0;
+}
+
 __global__ void ingest_shift_quals(uint8_t *quals, uint64_t n, int delta) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) quals[i] = (uint8_t)(quals[i] + delta);
 }

@@ -28,7 +28,7 @@ static const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
 
 /* build_mode 3: extraction into super-k-mer lists */
 #define KMR_SKX(W, WIN, FILT) KMR_T __global__ void sk_extract_kernel<W, WIN, FILT, false>(ReadsView, DevParams, SkParams, PoolView); KMR_T __global__ void sk_extract_kernel<W, WIN, FILT, true>(ReadsView, DevParams, SkParams, PoolView);
-#define KMR_SKXL(W, WIN) KMR_T __global__ void sk_extract_lean_kernel<W, WIN>(ReadsView, DevParams, SkParams, PoolView, float);
+#define KMR_SKXL(W, WIN) KMR_T __global__ void sk_extract_lean_kernel<W, WIN, false>(ReadsView, DevParams, SkParams, PoolView, float, SkPacked); KMR_T __global__ void sk_extract_lean_kernel<W, WIN, true>(ReadsView, DevParams, SkParams, PoolView, float, SkPacked);
 #define KMR_SKX_W(W) KMR_SKX(W, 16, false) KMR_SKX(W, 16, true) KMR_SKX(W, 8, false) KMR_SKX(W, 8, true) KMR_SKX(W, 4, false) KMR_SKX(W, 4, true) KMR_SKXL(W, 16) KMR_SKXL(W, 8) KMR_SKXL(W, 4)
 
 /* build_mode 3: count pass and streaming lookups */

@@ -970,9 +970,24 @@ void sk_qual_range_kernel(const uint8_t *quals, const uint64_t *offsets, uint64_
 }
 #endif
 
-template <int W, int WIN>
+/* PACKED: the bases arrive as the reference's Read keeps them (TwoBitSequence, src/TwoBitSequence.cpp:242-269: four bases per byte, the
+ * first one in bits 7-6, every read on bytes of its own) plus markups -- kmr_add_reads_twobit* with one quality character for the
+ * batch.  Four packed bytes read as a big-endian dword ARE a group of the tile's LDS form, so the tile is staged with a byte swap
+ * per dword instead of sixteen base_code()s per group, a quarter of the bytes come in, and no unpacked copy of the batch is
+ * written and read back; a read's place in the tile is a base offset as before (4 * its byte offset, + the bases a unit of a
+ * long read starts behind the read's first one).  Markups set the N flag of their position (a markup that names a base rewrites it). */
+struct SkPacked {
+	const uint8_t *bytes;          /* packed bases */
+	const uint64_t *off;           /* per read: byte offset of its first base */
+	const uint64_t *mk_off;        /* per read: its markups are entries [mk_off[i], mk_off[i + 1]); may be null */
+	const uint32_t *mk_pos;        /* position inside the read */
+	const uint8_t *mk_char;
+};
+static const uint32_t SK_PACKED_SPAN = TILE_SPAN - 64;      /* bases of a tile: the staging starts on a 16-byte boundary, up to 60 bases in front of the first read */
+
+template <int W, int WIN, bool PACKED = false>
 __global__ __launch_bounds__(SKL_WAVES * 64, SKL_MIN_BLOCKS)
-void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool, float wK) {
+void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool, float wK, SkPacked pkd) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	__shared__ SkSlab s_slab[SKL_WAVES];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1003,11 +1018,14 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 		else { myRead = r0 + lane; myStart = rv.offsets[myRead]; myEnd = rv.offsets[myRead + 1]; }
 		myDiscard = rv.discarded ? (rv.discarded[myRead] != 0) : false;
 	}
+	/* PACKED: where this lane's bases are, counted in bases from pkd.bytes */
+	uint64_t myPb = 0, myPe = 0;
+	if (PACKED && have) { myPb = 4 * pkd.off[myRead] + (myStart - rv.offsets[myRead]); myPe = myPb + (myEnd - myStart); }
 	uint32_t tRaw = 0, tGood = 0;
 	uint32_t done = 0;
 	while (done < nr) {
-		const uint64_t B0 = __shfl(myStart, (int)done, 64);
-		const bool fits = have && (uint32_t)lane >= done && (myEnd - B0 <= (uint64_t)TILE_SPAN);
+		const uint64_t B0 = PACKED ? __shfl(myPb, (int)done, 64) : __shfl(myStart, (int)done, 64);
+		const bool fits = have && (uint32_t)lane >= done && (PACKED ? (myPb >= B0 && myPe - B0 <= (uint64_t)SK_PACKED_SPAN) : (myEnd - B0 <= (uint64_t)TILE_SPAN));
 		unsigned long long fm = __ballot(fits) >> done;
 		uint32_t n = ~fm ? (uint32_t)__builtin_ctzll(~fm) : 64u;
 		if (n > nr - done) n = nr - done;
@@ -1016,13 +1034,34 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 			done += 1;
 			continue;
 		}
-		const uint64_t B1 = __shfl(myEnd, (int)(done + n - 1), 64);
-		const uintptr_t gb = (uintptr_t)rv.bases + B0;
+		uint64_t B1 = __shfl(PACKED ? myPe : myEnd, (int)(done + n - 1), 64);
+		if (PACKED) {      /* (nothing says that the reads' bytes lie in the order of the reads: the tile ends where the last of its reads does) */
+			uint64_t e = ((uint32_t)lane >= done && (uint32_t)lane < done + n) ? myPe : 0;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) { const uint64_t x = __shfl_xor(e, o, 64); e = x > e ? x : e; }
+			B1 = e;
+		}
+		const uintptr_t gb = PACKED ? (uintptr_t)pkd.bytes + (uintptr_t)(B0 >> 2) : (uintptr_t)rv.bases + B0;
 		const uintptr_t ab = gb & ~(uintptr_t)15;
-		const uint32_t nb16 = (uint32_t)(((uintptr_t)rv.bases + B1 - ab + 15) >> 4);
+		const uint32_t nb16 = PACKED ? (uint32_t)(((uintptr_t)pkd.bytes + (uintptr_t)((B1 + 3) >> 2) - ab + 15) >> 4) : (uint32_t)(((uintptr_t)rv.bases + B1 - ab + 15) >> 4);
 		/* stage the tile: 16 bytes per lane and round, coalesced; bases leave as 2 bits each plus an N flag.  All rounds' loads are
 		 * issued before the first one is packed. */
-		{
+		if (PACKED) {
+			const uint4 *gbp = (const uint4 *)ab;
+			constexpr int STGP = (SK_GROUPS / 4 + 63) / 64;
+			static_assert(SK_GROUPS % 4 == 0, "the packed staging writes four groups at a time");
+			uint4 vb[STGP];
+#pragma unroll
+			for (int c = 0; c < STGP; c++) { const uint32_t idx = (uint32_t)lane + 64u * c; vb[c] = make_uint4(0, 0, 0, 0); if (idx < nb16 && idx < (uint32_t)(SK_GROUPS / 4)) vb[c] = gbp[idx]; }
+#pragma unroll
+			for (int c = 0; c < STGP; c++) {
+				const uint32_t idx = (uint32_t)lane + 64u * c;
+				if (idx < (uint32_t)(SK_GROUPS / 4)) {      /* (zeros behind the data) */
+					((uint4 *)pk)[idx] = make_uint4(__builtin_bswap32(vb[c].x), __builtin_bswap32(vb[c].y), __builtin_bswap32(vb[c].z), __builtin_bswap32(vb[c].w));
+					((uint2 *)nm)[idx] = make_uint2(0, 0);
+				}
+			}
+		} else {
 			const uint4 *gbp = (const uint4 *)(rv.bases + (ptrdiff_t)(ab - (uintptr_t)rv.bases));
 			constexpr int STG = (TILE_BUF / 16 + 63) / 64;
 			uint4 vb[STG];
@@ -1046,7 +1085,20 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 
 		const bool active = have && (uint32_t)lane >= done && (uint32_t)lane < done + n && !myDiscard;
 		const uint32_t L = active ? (uint32_t)(myEnd - myStart) : 0;
-		const uint32_t rbOff = active ? (uint32_t)(gb - ab) + (uint32_t)(myStart - B0) : 0u;
+		const uint32_t rbOff = active ? (PACKED ? (uint32_t)(myPb - 4 * (uint64_t)(ab - (uintptr_t)pkd.bytes)) : (uint32_t)(gb - ab) + (uint32_t)(myStart - B0)) : 0u;
+		if (PACKED && pkd.mk_off) {      /* applyMarkup (src/TwoBitSequence.cpp:314-340) on the tile */
+			if (active) {
+				const uint64_t inRead = myStart - rv.offsets[myRead];      /* a unit of a long read starts that far inside it */
+				for (uint64_t e = pkd.mk_off[myRead]; e < pkd.mk_off[myRead + 1]; e++) {
+					const uint64_t mp = pkd.mk_pos[e];
+					if (mp < inRead || mp - inRead >= L) continue;
+					const uint32_t x = rbOff + (uint32_t)(mp - inRead), code = base_code(pkd.mk_char[e]);
+					if (code >> 2) atomicOr((uint32_t *)nm + (x >> 5), 1u << (x & 31u));
+					else { const uint32_t sh = 30u - 2u * (x & 15u); atomicAnd(pk + (x >> 4), ~(3u << sh)); atomicOr(pk + (x >> 4), code << sh); }
+				}
+			}
+			sk_wave_lds_order();
+		}
 		uint32_t Lmax = L;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) { uint32_t x = __shfl_xor(Lmax, o, 64); Lmax = x > Lmax ? x : Lmax; }

@@ -1161,6 +1161,80 @@ def test_twobit_device_feed_without_byte_offsets():
         assert np.array_equal(pa.image(which), pt.image(which))
 
 
+@pytest.mark.parametrize("k", [21, 31, 51])
+@pytest.mark.parametrize("uq", [ord("I"), 0])
+def test_twobit_packed_bytes_staged_directly(k, uq):
+    """kmr_add_reads_twobit_dev with one quality character (or none) on the lists: sk_extract_lean_kernel<.., PACKED> stages the packed bytes
+    as they are -- no unpacked copy.  Held to the unpack-first path (tune packed_direct = 0) and to kmr_add_reads on the text: ragged reads,
+    N markups, a markup that names a base, a discarded read, reads of 9 800 (between the two tile spans) and 25 000 bases (cut into
+    units, with N's inside), the reads' bytes with gaps between them and in the opposite order of the reads, two calls whose offsets
+    do not start at zero.  Window of 8 (k = 21) and 16, one- and two-word keys."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(100 + k)
+    rb0 = synth_reads(2000, read_len=150, genome_len=20000, seed=50 + k, quality="flat", n_rate=0.004)
+    seqs = []
+    for i in range(rb0.n):
+        L = int(rng.choice([150, 149, 147, 121, k + 2, k, k - 1, 5, 1, 0], p=[0.5, 0.1, 0.1, 0.1, 0.05, 0.05, 0.04, 0.03, 0.02, 0.01]))
+        seqs.append(bytes(rb0.seq(i)[:L]))
+    for L in (9800, 25000):
+        g = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+        g[rng.integers(0, L, 12)] = ord("N")
+        seqs.insert(len(seqs) // 3, g.tobytes())
+        seqs.append(g[::-1].tobytes())
+    rb = ReadBatch(seqs, None if uq == 0 else [bytes([uq]) * len(s) for s in seqs])
+    disc = np.zeros(rb.n, np.uint8); disc[11] = 1
+    rb.discarded = disc
+    cfg = default_config(k, estimated_raw_kmers=int(rb.bases.size))
+    pa = product(cfg, 3); add(pa, rb); pa.finalize(1)
+    tw, to, (mp, mc, mo) = _pack_twobit(rb)
+    # a markup that names a base: the packed bits say A, the markup says what the text holds (applyMarkup writes the character back)
+    mp, mc, mo = list(mp), list(mc), [int(x) for x in mo]
+    done = 0
+    for i in range(rb.n):
+        a, L = int(rb.offsets[i]), int(rb.offsets[i + 1] - rb.offsets[i])
+        if L < 40 or done >= 20 or mo[i + 1] != mo[i]:
+            continue
+        j = 17
+        if rb.bases[a + j] in b"CGT":
+            byte, sh = int(to[i]) + j // 4, 6 - 2 * (j % 4)
+            tw[byte] &= ~(3 << sh) & 0xff
+            at = mo[i]
+            mp.insert(at, j); mc.insert(at, int(rb.bases[a + j]))
+            for r in range(i + 1, rb.n + 1):
+                mo[r] += 1
+            done += 1
+    assert done == 20
+    mp, mc, mo = np.array(mp, np.uint32), np.array(mc, np.uint8), np.array(mo, np.uint64)
+    # the reads' bytes in the opposite order of the reads, seven bytes of something else between them
+    to2 = np.zeros(rb.n + 1, np.uint64)
+    tw2 = np.full(int(tw.size) + 7 * rb.n + 64, 0xa7, np.uint8)
+    at = 13
+    for i in range(rb.n - 1, -1, -1):
+        nb = int(to[i + 1] - to[i])
+        tw2[at:at + nb] = tw[int(to[i]):int(to[i + 1])]
+        to2[i] = at
+        at += nb + 7
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a).view(dt) if dt else np.ascontiguousarray(a)).to(dev)
+    d_off, d_mo, d_mp, d_mc, d_d = t(rb.offsets, np.int64), t(mo, np.int64), t(mp, np.int32), t(mc), t(disc)
+    images = []
+    for layout, direct in (("packed", 1), ("packed", 0), ("scattered", 1)):
+        d_tw = t(tw if layout == "packed" else tw2)
+        d_to = None if layout == "packed" else t(to2, np.int64)
+        pt = product(cfg, 3, packed_direct=direct)
+        half = rb.n // 2 + 1
+        for r0, r1 in ((0, half), (half, rb.n)):
+            b0, b1 = int(rb.offsets[r0]), int(rb.offsets[r1])
+            pt.buildKmerSpectrumTwoBitDevice(d_tw.data_ptr() + (int(to[r0]) if d_to is None else 0), None if d_to is None else d_to.data_ptr() + 8 * r0,
+                                             d_off.data_ptr() + 8 * r0, r1 - r0, b1 - b0, uniform_quality=uq,
+                                             markup_offsets_ptr=d_mo.data_ptr() + 8 * r0, markup_pos_ptr=d_mp.data_ptr(), markup_char_ptr=d_mc.data_ptr(),
+                                             first_read_idx=r0, discarded_ptr=d_d.data_ptr() + r0)
+        pt.sync(); pt.finalize(1)
+        assert pa.stats() == pt.stats(), (layout, direct)
+        for which in (KMR_MAP_WEAK, KMR_MAP_SINGLETON):
+            assert np.array_equal(pa.image(which), pt.image(which)), (layout, direct, which)
+
+
 @pytest.mark.parametrize("mode", [3, 2])
 def test_build_score_reset_build_again(mode):
     """the streaming lookups borrow the handle's list pool and list state after kmr_finalize: a kmr_reset and a second build on the same
