@@ -951,13 +951,19 @@ void sk_qual_range_kernel(const uint8_t *quals, const uint64_t *offsets, uint64_
 	if (a0 < a1) {
 		const uint4 *q4 = (const uint4 *)a0;
 		const uint64_t n16 = (a1 - a0) / 16;
-		for (uint64_t i = tid; i < n16; i += nthreads) {
-			const uint4 v = q4[i];
-			const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+		/* four loads in flight per thread (one at a time the pass ran at 3.4 TB/s on a C2 batch, 1.5 TB/s on a quarter of it) */
+		for (uint64_t i0 = tid; i0 < n16; i0 += 4 * nthreads) {
+			uint4 v[4];
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
+			for (int u = 0; u < 4; u++) { const uint64_t i = i0 + (uint64_t)u * nthreads; v[u] = q4[i < n16 ? i : i0]; }
 #pragma unroll
-				for (int b = 0; b < 4; b++) { const unsigned int c = (w4[j] >> (8 * b)) & 0xffu; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+			for (int u = 0; u < 4; u++) {
+				const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+#pragma unroll
+					for (int b = 0; b < 4; b++) { const unsigned int c = (w4[j] >> (8 * b)) & 0xffu; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+				}
 			}
 		}
 		if (tid < 16) { const uintptr_t q = p0 + tid; if (q < a0) { const unsigned int c = *(const uint8_t *)q; lo = c < lo ? c : lo; hi = c > hi ? c : hi; } }
