@@ -466,7 +466,10 @@ int kmr_reads_twobit(kmr_handle *h, const kmr_reads *r, uint8_t *twobit, uint64_
  *   quals                     qualities indexed by offsets (host form; the device form: dev_quals[0] is the quality of the call's first
  *                             base), or NULL and uniform_quality = the ONE quality character every base of the batch has (0: reads
  *                             without qualities, weight 1.0 as kmr_add_reads with quals == NULL)
- * Results are those of kmr_add_reads on the same reads.  The device form is asynchronous on the handle's stream like kmr_add_reads_dev. */
+ * Results are those of kmr_add_reads on the same reads.  The device form is asynchronous on the handle's stream like kmr_add_reads_dev.
+ * A batch without a quality array (one character, or none) that is built on the super-k-mer lists with direction-counting values is
+ * extracted from the packed bytes as they are; every other batch is unpacked to text in a scratch of the handle first.  kmr_tune
+ * "packed_direct" = 0 forces the unpack (tests, A/B runs). */
 int kmr_add_reads_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *twobit_offsets, const uint64_t *offsets,
                          const uint64_t *markup_offsets, const uint32_t *markup_pos, const char *markup_char,
                          const char *quals, int uniform_quality, uint64_t n_reads, uint64_t first_global_read_idx, const uint8_t *discarded);
