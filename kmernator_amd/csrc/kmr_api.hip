@@ -1483,7 +1483,11 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		 * errors more often (k = 51, 1 % errors: 40 % of the k-mers hold one and are nearly all distinct), so their lists are cut
 		 * half as long (C4: count pass 133 -> 93 ms; another halving costs more in per-list work than it saves) */
 		/* (extension values: a 512-slot table, COUNT_LOG2S_EXT) */
-		const uint64_t per_list = h->ext ? (W > 1 ? 400 : 600) : ((h->tune.target_list == 2048 && W > 1) ? 700 : h->tune.target_list / 2 + 200);
+		/* (one-word keys: the count pass costs 8.8 ms per 10^9 k-mers of C2-like reads with lists of 1300-1600 k-mers, 9.25 at 1144 and at
+		 * 1830, 10.2 at 2000 -- overflowing tables --, 11.2 at 715 and ~13 at 570 -- twice the per-list work: between two powers of two
+		 * the longer lists win up to ~1900 k-mers; 1536 leaves the table room for inputs with more distinct k-mers than C2's 30 %.  Until
+		 * round 3 the bound was 1224: a 12.5 M-read batch went to 2^21 lists of 715 and took 32.2 ms instead of 27.8) */
+		const uint64_t per_list = h->ext ? (W > 1 ? 400 : 600) : ((h->tune.target_list == 2048 && W > 1) ? 700 : h->tune.target_list * 3 / 4);
 		uint32_t bits = 6; while (bits < 24 && (est >> bits) > per_list) bits++;
 		h->sk_fine_shift = 0;
 		if (h->sk_exchange && h->cfg.world_size > 1 && !h->tune.no_coarse_lists) {

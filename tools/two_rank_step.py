@@ -1,7 +1,7 @@
 """development tool: one step of a `world`-rank weak-scaling job (10 M reads per rank) as rank 0 lives it, on ONE GPU: rank 0's handle
 and a stand-in handle for every other rank in turn extract their own reads, pack, and hand each other their segments through device
 memory (no RCCL: the wire is not measured); rank 0 adopts what the others hold for it and finalizes.  Prints what rank 0 spends in
-each phase.  usage: tools/two_rank_step.py [reads per rank] [world] [pieces]"""
+each phase.  usage: tools/two_rank_step.py [reads per rank] [world] [pieces] [knob=value ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +13,8 @@ world = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 pieces = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda", 0)
 L = bench.READ_LEN
-mk = lambda r: ka.KmerSpectrum(ka.default_config(bench.K, estimated_raw_kmers=n * 120 * world, device=0, rank=r, world_size=world, build_mode=3))
+tune = {kv.split('=')[0]: float(kv.split('=')[1]) for kv in sys.argv[4:]}      # knob=value ...
+mk = lambda r: ka.KmerSpectrum(ka.default_config(bench.K, estimated_raw_kmers=n * 120 * world, device=0, rank=r, world_size=world, build_mode=3)).tune(**tune)
 me, other = mk(0), mk(1)
 reads = [bench.gen_reads(torch, n, 5 * n * world, 1, r, dev, "flat") for r in range(world)]
 
