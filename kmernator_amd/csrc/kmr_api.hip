@@ -71,6 +71,7 @@ struct Tuning {
 	uint64_t long_list_chunks = 0;     /* lists of more chunks are counted in pieces (0: 1024) */
 	uint64_t binned_min = 1ull << 18;  /* weak maps of at least this many entries are bucketed by the radix partition of kmr_buckets.hpp (build_mode 3) */
 	uint64_t twobit_piece_bases = 0;   /* kmr_add_reads_twobit: bases per piece of the host-to-device pipeline (0 = 2^26) */
+	bool pow2_lists = false;           /* the list count of build_mode 3 always a power of two (A/B runs, tests of both list functions) */
 	bool no_packed_direct = false;     /* kmr_add_reads_twobit* always unpack to text first (A/B runs, tests of the unpack path) */
 	bool no_lean_extract = false;      /* never take sk_extract_lean_kernel (A/B runs, tests of the general kernel on uniform qualities) */
 	bool exchange_fail_once = false;   /* tests: the next kmr_exchange_add_reads_dev of this rank fails locally (the other ranks must come back with an error, not hang) */
@@ -1495,8 +1496,15 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 			if (bits >= 6 + sh) { h->sk_fine_shift = sh; bits -= sh; }      /* the lists of the wire: as many and as full as one GPU's */
 		}
 		h->sk_bits = bits;
-		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8ull << bits));
-		hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(1ull << bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << bits);
+		/* one GPU, one-word keys, direction-counting values: the list count the count pass likes best instead of a power of two -- lists
+		 * of ~1450 k-mers (8.8 ms per 10^9 k-mers; C2's 2^20 lists of 1144: 9.25).  The code of such a count is the count (sk_list_of). */
+		if (W == 1 && !h->ext && h->cfg.world_size <= 1 && !h->sk_exchange && h->tune.target_list == 2048 && !h->tune.pow2_lists) {
+			const uint64_t nlists = (est / 1450 + 63) & ~63ull;
+			if (nlists > 64 && nlists < (1ull << bits) && nlists < (1ull << 31)) h->sk_bits = (uint32_t)nlists;
+		}
+		const uint64_t nl0 = sk_list_count(h->sk_bits);
+		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8 * nl0));
+		hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(nl0)), dim3(256), 0, h->stream, h->sk_state, nl0);
 		HIPCHK(h, hipGetLastError());
 	}
 	const uint64_t avg = n ? std::max<uint64_t>(1, total_bases / n) : 1;
@@ -1528,7 +1536,7 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		 * chunk per list and two slabs of 64 chunks per wavefront */
 		const uint64_t bases = m * avg + avg;
 		/* (inside an exchange the lists of other owners start afresh after every pack: an open chunk per list for every call) */
-		rc = pool_reserve(h, h->l1, (h->ext ? 2 : 1) * bases / SK_CHUNK_G + ((h->l1.base && !h->sk_exchange) ? 0 : (1ull << h->sk_bits)) + (uint64_t)num_cus(h) * SK_EXTRACT_WAVES_PER_CU * 130 + 64, true); if (rc) return rc;
+		rc = pool_reserve(h, h->l1, (h->ext ? 2 : 1) * bases / SK_CHUNK_G + ((h->l1.base && !h->sk_exchange) ? 0 : sk_list_count(h->sk_bits)) + (uint64_t)num_cus(h) * SK_EXTRACT_WAVES_PER_CU * 130 + 64, true); if (rc) return rc;
 		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b); time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
 		SkParams sp = sk_params(h);
 		if (h->cfg.size_tracker) sp.track = h->trk + r;
@@ -1592,6 +1600,7 @@ template <int W> int saturated_fix_t(kmr_handle *h, const uint64_t *ls, const ui
 	DevMap &wm = h->weak;
 	if (!n_clamped || !wm.n) return 0;
 	uint32_t list_bits = 0; while ((1ull << list_bits) < nl) list_bits++;
+	if ((1ull << list_bits) != nl) list_bits = (uint32_t)nl;      /* a list count that is not a power of two is its own code (sk_list_of) */
 	unsigned long long *dfound = nullptr; uint64_t *d_entry = nullptr; uint32_t *d_list = nullptr;
 	std::vector<void *> owned;
 	auto release = [&]() { for (void *p : owned) hipFree(p); owned.clear(); };
@@ -1672,7 +1681,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
 	rc = arena_reset(h); if (rc) return rc;
-	uint64_t nl = h->sk_state ? 1ull << h->sk_bits : 1;
+	uint64_t nl = h->sk_state ? sk_list_count(h->sk_bits) : 1;
 	if (h->sk_state) {
 		hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);
 		HIPCHK(h, hipGetLastError());
@@ -2025,7 +2034,7 @@ int kmr_reset(kmr_handle *h) {
 		h->l1.used_ub = 0;
 		h->inserted_records = 0;
 		h->qual_mixed = false;
-		if (h->sk_state) hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(1ull << h->sk_bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << h->sk_bits);
+		if (h->sk_state) hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(sk_list_count(h->sk_bits))), dim3(256), 0, h->stream, h->sk_state, sk_list_count(h->sk_bits));
 		if (h->l1_state) {      /* what an unfinished build kept back is dropped with its pool */
 			hipLaunchKernelGGL(partition_state_init_kernel, dim3(partition_blocks(h)), dim3(256), 0, h->stream, h->l1_state,
 			                   h->l1_state_bytes / (size_t)partition_blocks(h), h->bits1, (uint32_t)partition_blocks(h));
@@ -2080,6 +2089,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "long_list_chunks") h->tune.long_list_chunks = value < 2 ? 2 : (uint64_t)value;
 	else if (k == "lean_extract") h->tune.no_lean_extract = value == 0;
 	else if (k == "packed_direct") h->tune.no_packed_direct = value == 0;
+	else if (k == "pow2_lists") h->tune.pow2_lists = value != 0;
 	else if (k == "twobit_piece_bases") h->tune.twobit_piece_bases = (uint64_t)value;
 	else if (k == "exchange_fail_once") h->tune.exchange_fail_once = value != 0;
 	else if (k == "binned_buckets_min") h->tune.binned_min = value >= 0 ? (uint64_t)value : ~0ull;        /* < 0: never */
@@ -2361,7 +2371,7 @@ bool stream_lookups_possible(kmr_handle *h) {
 }
 template <int W> int sk_index_t(kmr_handle *h) {
 	if (h->ix_gen == h->map_gen && h->ix_start) return 0;
-	const uint64_t nl = 1ull << h->sk_bits, n = h->weak.n;
+	const uint64_t nl = sk_list_count(h->sk_bits), n = h->weak.n;
 	const uint32_t vw = h->ext ? 15 : 3;
 	if (h->ix_lists != nl) { if (h->ix_start) hipFree(h->ix_start); h->ix_start = nullptr; HIPCHK(h, hipMalloc((void **)&h->ix_start, 8 * (nl + 1))); h->ix_lists = nl; }
 	if (h->ix_cap < n) {
@@ -2390,7 +2400,7 @@ template <int W> int lookup_stream_t(kmr_handle *h, const ReadsView &rvAll, uint
 	}
 	if (!h->scratch_stats) HIPCHK(h, hipMalloc((void **)&h->scratch_stats, sizeof(DevStats)));
 	rc = sk_index_t<W>(h); if (rc) return rc;
-	const uint64_t nl = 1ull << h->sk_bits;
+	const uint64_t nl = sk_list_count(h->sk_bits);
 	hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl);
 	if (h->l1.head) HIPCHK(h, hipMemsetAsync(h->l1.head, 0, 4, h->stream));
 	h->l1.used_ub = 0;
@@ -3439,7 +3449,7 @@ int kmr_sk_exchange_counts(kmr_handle *h, uint64_t *chunks, uint64_t *granules) 
 	rc = sk_ensure_state(h); if (rc) return rc;
 	rc = sync_state(h); if (rc) return rc;
 	const uint32_t world = h->cfg.world_size;
-	const uint64_t nl = 1ull << h->sk_bits;
+	const uint64_t nl = sk_list_count(h->sk_bits);
 	unsigned int head = 0;
 	HIPCHK(h, hipMemcpy(&head, h->l1.head, 4, hipMemcpyDeviceToHost));
 	if (head > h->l1.cap) head = h->l1.cap;
@@ -3472,7 +3482,7 @@ int kmr_sk_exchange_pack_dev(kmr_handle *h, void *dev_data, void *dev_meta, cons
 	if (e == hipSuccess && head) {
 		hipLaunchKernelGGL(sk_pack_kernel, dim3(grid_for((uint64_t)head * 64, 256, num_cus(h) * 8)), dim3(256), 0, h->stream, pool_view(h, h->l1), head, world, h->cfg.rank,
 		                   d, d + SK_OWNER_MAX, d + 2 * SK_OWNER_MAX, d + 3 * SK_OWNER_MAX, (uint4 *)dev_data, (uint2 *)dev_meta);
-		hipLaunchKernelGGL(sk_state_drop_kernel, dim3(grid_for(1ull << h->sk_bits)), dim3(256), 0, h->stream, h->sk_state, 1ull << h->sk_bits, world, h->cfg.rank);
+		hipLaunchKernelGGL(sk_state_drop_kernel, dim3(grid_for(sk_list_count(h->sk_bits))), dim3(256), 0, h->stream, h->sk_state, sk_list_count(h->sk_bits), world, h->cfg.rank);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);      /* hv and d go out of scope */
@@ -3488,7 +3498,7 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
 	rc = sk_ensure_state(h); if (rc) return rc;
 	const int grid = (int)std::min<uint64_t>((n_chunks + SK_ADOPT_WAVES * SK_ADOPT_GROUP - 1) / (SK_ADOPT_WAVES * SK_ADOPT_GROUP), (uint64_t)num_cus(h) * 8);
 	/* (a received chunk is appended as one piece: at worst every one of them opens a chunk of its own) */
-	rc = pool_reserve(h, h->l1, n_chunks + n_granules / SK_CHUNK_G + ((1ull << h->sk_bits) / h->cfg.world_size) + (uint64_t)grid * SK_ADOPT_WAVES * 130 + 64, true); if (rc) return rc;
+	rc = pool_reserve(h, h->l1, n_chunks + n_granules / SK_CHUNK_G + (sk_list_count(h->sk_bits) / h->cfg.world_size) + (uint64_t)grid * SK_ADOPT_WAVES * 130 + 64, true); if (rc) return rc;
 	/* per-chunk counts and their scan: a grow-only buffer of the handle (a job adopts once per piece and batch) */
 	const size_t need = 8 * (n_chunks + 1) + 4 * (n_chunks + 1) + 256;
 	if (h->adopt_cap < need) {

@@ -88,7 +88,15 @@ __host__ __device__ __forceinline__ uint32_t sk_fmix(uint32_t h) { h ^= h >> 16;
 /* order of the canonical m-mers (the minimizer is the smallest) */
 __host__ __device__ __forceinline__ uint32_t sk_mmer_hash(uint32_t canon) { return sk_fmix(canon ^ 0x9e3779b9u); }
 /* list of a minimizer: minima crowd near zero, so the list is cut from a second scramble of the hash, not from its top bits */
-__host__ __device__ __forceinline__ uint32_t sk_list_of(uint32_t mh, uint32_t list_bits) { return list_bits ? sk_fmix(mh * 0x2545f491u + 0x7f4a7c15u) >> (32 - list_bits) : 0u; }
+/* `list_bits` is a CODE: up to 32 it is the number of bits of a power-of-two list count (the top bits of the scramble); above 32 it is
+ * the list count itself, any number (multiply-shift: floor(scramble * count / 2^32)) -- a single GPU's build sizes its lists for the
+ * count pass (~1450 k-mers each, sk_list_code_for in kmr_api.hip) instead of taking the next power of two.  Exchanges between ranks
+ * (owner = list % ranks, coarse and fine lists) keep powers of two. */
+__host__ __device__ __forceinline__ uint32_t sk_list_of(uint32_t mh, uint32_t list_bits) {
+	const uint32_t x = sk_fmix(mh * 0x2545f491u + 0x7f4a7c15u);
+	return list_bits > 32u ? (uint32_t)(((uint64_t)x * list_bits) >> 32) : (list_bits ? x >> (32 - list_bits) : 0u);
+}
+__host__ __device__ __forceinline__ uint64_t sk_list_count(uint32_t list_bits) { return list_bits > 32u ? (uint64_t)list_bits : 1ull << list_bits; }
 
 /* Owner of a k-mer in a job built on super-k-mer lists (build_mode 3 + exchange): the list of its canonical minimizer, modulo the
  * ranks.  OwnerFn.m == 0: the reference's getDistributedThreadId (lookup3).  sk_key_minimizer recomputes, from the packed k-mer,

@@ -63,7 +63,7 @@ struct SkParams {
 	uint32_t dbg;          /* measurement switches of a -DKMR_DEBUG_HOOKS build (they void the result): extract 1 = no list appends, 2 = no gather; count 1 = no table, 2 = no emit, 4 = no insert loop */
 	uint32_t m;            /* minimizer length in bases, <= 16                                        */
 	uint32_t off;          /* offset inside the k-mer of the first m-mer the minimizer looks at       */
-	uint32_t list_bits;    /* lists = 2^list_bits                                                     */
+	uint32_t list_bits;    /* code of the list count (sk_list_of): <= 32 = that many bits, above = the count itself */
 	uint32_t fast_div;     /* 1: P[a] / P[b] may be formed as fma(fma(-q0, P[b], P[a]), R[b], q0), q0 = P[a] * R[b], R = 1 / P: the host has checked that this gives the correctly rounded quotient for every pair of table entries (kmr_create) */
 	const double *Rp;      /* 256 entries: 1 / P[c] (0 where P[c] == 0) */
 	uint32_t keep_all_owners;      /* world_size > 1: 1 inside an owner exchange (the list decides the owner), 0 = keep what getDistributedThreadId gives this rank */
