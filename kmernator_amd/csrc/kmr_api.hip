@@ -71,6 +71,7 @@ struct Tuning {
 	uint64_t long_list_chunks = 0;     /* lists of more chunks are counted in pieces (0: 1024) */
 	uint64_t binned_min = 1ull << 18;  /* weak maps of at least this many entries are bucketed by the radix partition of kmr_buckets.hpp (build_mode 3) */
 	uint64_t twobit_piece_bases = 0;   /* kmr_add_reads_twobit: bases per piece of the host-to-device pipeline (0 = 2^26) */
+	uint64_t list_aim = 0;             /* k-mers per list the list count of a single GPU's build aims for (0: the defaults of add_reads_superkmer_t) */
 	bool pow2_lists = false;           /* the list count of build_mode 3 always a power of two (A/B runs, tests of both list functions) */
 	bool no_packed_direct = false;     /* kmr_add_reads_twobit* always unpack to text first (A/B runs, tests of the unpack path) */
 	bool no_lean_extract = false;      /* never take sk_extract_lean_kernel (A/B runs, tests of the general kernel on uniform qualities) */
@@ -1498,9 +1499,13 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		h->sk_bits = bits;
 		/* one GPU, one-word keys, direction-counting values: the list count the count pass likes best instead of a power of two -- lists
 		 * of ~1450 k-mers (8.8 ms per 10^9 k-mers; C2's 2^20 lists of 1144: 9.25).  The code of such a count is the count (sk_list_of). */
-		if (W == 1 && !h->ext && h->cfg.world_size <= 1 && !h->sk_exchange && h->tune.target_list == 2048 && !h->tune.pow2_lists) {
-			const uint64_t nlists = (est / 1450 + 63) & ~63ull;
-			if (nlists > 64 && nlists < (1ull << bits) && nlists < (1ull << 31)) h->sk_bits = (uint32_t)nlists;
+		if (h->cfg.world_size <= 1 && !h->sk_exchange && h->tune.target_list == 2048 && !h->tune.pow2_lists) {
+			/* (two-word keys: lists just below their bound instead of anywhere between half of it and the bound -- C4 at 665 / 850 / 1100
+			 * k-mers per list: 195.7 / 201 / 275 ms.  Extension values, 10 M reads at k = 21: 2^22 lists of 310 69.4 ms; 570 / 800 / 1000 /
+			 * 1300 per list: 58.6 / 55.8 / 55.2 / 62.4 ms) */
+			const uint64_t aim = h->tune.list_aim ? h->tune.list_aim : (W == 1 ? (h->ext ? 800 : 1450) : per_list * 19 / 20);
+			const uint64_t nlists = (est / aim + 63) & ~63ull;
+			if (nlists > 64 && (nlists < (1ull << bits) || h->tune.list_aim) && nlists < (1ull << 31)) h->sk_bits = (uint32_t)nlists;
 		}
 		const uint64_t nl0 = sk_list_count(h->sk_bits);
 		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8 * nl0));
@@ -2090,6 +2095,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "lean_extract") h->tune.no_lean_extract = value == 0;
 	else if (k == "packed_direct") h->tune.no_packed_direct = value == 0;
 	else if (k == "pow2_lists") h->tune.pow2_lists = value != 0;
+	else if (k == "list_aim") h->tune.list_aim = value >= 1 ? (uint64_t)value : 0;
 	else if (k == "twobit_piece_bases") h->tune.twobit_piece_bases = (uint64_t)value;
 	else if (k == "exchange_fail_once") h->tune.exchange_fail_once = value != 0;
 	else if (k == "binned_buckets_min") h->tune.binned_min = value >= 0 ? (uint64_t)value : ~0ull;        /* < 0: never */

@@ -1161,6 +1161,27 @@ def test_twobit_device_feed_without_byte_offsets():
         assert np.array_equal(pa.image(which), pt.image(which))
 
 
+@pytest.mark.parametrize("k,ext", [(31, False), (21, False), (51, False), (21, True)])
+def test_list_counts_that_are_not_powers_of_two(k, ext):
+    """build_mode 3 on one GPU sizes its lists for the count pass (sk_list_of's code above 32: the count itself, multiply-shift) instead of
+    taking a power of two: the maps must not know -- held to the power-of-two lists (tune pow2_lists), to two other list lengths
+    (tune list_aim, one of them short enough to be many lists, one long enough to overflow tables) and to the oracle"""
+    rb = synth_reads(40000, read_len=150, genome_len=150000, seed=300 + k, quality="noisy", n_rate=0.002)
+    kw = dict(value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2) if ext else {}
+    cfg = default_config(k, estimated_raw_kmers=40000 * (150 - k + 1), **kw)
+    o = OracleSpectrum(cfg); o.add_reads(rb); o.finalize(2)
+    ref = None
+    for tune in (dict(pow2_lists=1), dict(), dict(list_aim=333), dict(list_aim=5000)):
+        p = product(cfg, 3, **tune); add(p, rb); p.finalize(2)
+        assert p.stats() == o.stats(), tune
+        img = (p.image(KMR_MAP_WEAK), p.image(KMR_MAP_SINGLETON))
+        if ref is None:
+            ref = img
+            assert compare_weak_images(o.image(KMR_MAP_WEAK), img[0], p.kb, ext) == o.stats()["weak_entries"]
+        else:
+            assert np.array_equal(ref[0], img[0]) and np.array_equal(ref[1], img[1]), tune
+
+
 @pytest.mark.parametrize("k", [21, 31, 51])
 @pytest.mark.parametrize("uq", [ord("I"), 0])
 def test_twobit_packed_bytes_staged_directly(k, uq):

@@ -12,8 +12,9 @@ bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev, quality=qual
 torch.cuda.synchronize()
 imgs = {}
 modes = tuple(int(x) for x in os.environ.get("EXT_MODES", "3,2,1").split(","))
+tune = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in sys.argv[4:]}      # knob=value ...
 for mode in modes:
-    sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2))
+    sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode, value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2)).tune(**tune)
     for rep in range(2):
         sp.reset(); sp.kernel_time_reset(); torch.cuda.synchronize(); t0 = time.time()
         sp.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
