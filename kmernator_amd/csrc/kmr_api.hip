@@ -1475,6 +1475,13 @@ uint32_t sk_dbg_flags(const char *name) {
 SkParams sk_params(kmr_handle *h) { SkParams sp; sp.dbg = sk_dbg_flags("KMR_SK_EXTRACT_DBG"); sp.keep_all_owners = h->sk_exchange ? 1u : 0u; sp.track = nullptr; sp.m = h->sk_m; sp.off = h->sk_off; sp.list_bits = h->sk_bits; sp.state = h->sk_state; sp.Pk = h->dPk; sp.Rp = h->dPk + 256; sp.fast_div = h->sk_fast_div ? 1u : 0u; return sp; }
 template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll, uint64_t total_bases) {
 	const uint64_t n = rvAll.n_reads;
+	const DevParams dp = dev_params(h);
+	/* world_size > 1: without the exchange a rank keeps the k-mers the reference's owner function gives it (getDistributedThreadId,
+	 * as the other build modes do); inside an exchange (kmr_sk_exchange_begin) every k-mer is kept, the lists decide the owner */
+	const bool filt = dp.subsample > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0 || (dp.world > 1 && !h->sk_exchange);
+	bool lean = false; float wK = 1.0f;
+	if (!filt && !h->ext && !sp_debug_extract(h)) { int rcq = sk_uniform_weight(h, rvAll, lean, wK); if (rcq) return rcq; }      /* (extension values want every neighbour's quality: the general kernel) */
+	if (h->packed_direct && (!lean || h->cfg.size_tracker)) return fail(h, KMR_ERR_STATE, "internal: a packed batch handed to an extraction that wants text");      /* (sk_packed_direct_ok said otherwise) */
 	if (!h->sk_state) {
 		/* lists: about 1100 k-mers each, as the final lists of the two-level partition */
 		/* the list space is the whole job's (with world_size > 1 a rank owns every world_size-th list): sized from the caller's estimate
@@ -1503,7 +1510,10 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 			/* (two-word keys: lists just below their bound instead of anywhere between half of it and the bound -- C4 at 665 / 850 / 1100
 			 * k-mers per list: 195.7 / 201 / 275 ms.  Extension values, 10 M reads at k = 21: 2^22 lists of 310 69.4 ms; 570 / 800 / 1000 /
 			 * 1300 per list: 58.6 / 55.8 / 55.2 / 62.4 ms) */
-			const uint64_t aim = h->tune.list_aim ? h->tune.list_aim : (W == 1 ? (h->ext ? 800 : 1450) : per_list * 19 / 20);
+			/* (est counts raw k-mers: reads with qualities of their own lose some of them to the weight floor -- the noisy C2 batch at 1300 /
+			 * 1450 / 1600 / 1750 raw k-mers per list: count pass 12.7 / 11.4 / 11.1 / 11.0 ms; flat qualities at 1450 / 1550 / 1650: 10.6 /
+			 * 10.8 / 10.8.  The first call's qualities decide) */
+			const uint64_t aim = h->tune.list_aim ? h->tune.list_aim : (W == 1 ? (h->ext ? 800 : (lean ? 1450 : 1700)) : per_list * 19 / 20);
 			const uint64_t nlists = (est / aim + 63) & ~63ull;
 			if (nlists > 64 && (nlists < (1ull << bits) || h->tune.list_aim) && nlists < (1ull << 31)) h->sk_bits = (uint32_t)nlists;
 		}
@@ -1523,13 +1533,6 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		}
 		HIPCHK(h, hipMemsetAsync(h->trk, 0, n * sizeof(SkTrackRec), h->stream));
 	}
-	const DevParams dp = dev_params(h);
-	/* world_size > 1: without the exchange a rank keeps the k-mers the reference's owner function gives it (getDistributedThreadId,
-	 * as the other build modes do); inside an exchange (kmr_sk_exchange_begin) every k-mer is kept, the lists decide the owner */
-	const bool filt = dp.subsample > 1 || dp.num_parts > 1 || (dp.sub_wnb | dp.sub_snb) != 0 || (dp.world > 1 && !h->sk_exchange);
-	bool lean = false; float wK = 1.0f;
-	if (!filt && !h->ext && !sp_debug_extract(h)) { int rcq = sk_uniform_weight(h, rvAll, lean, wK); if (rcq) return rcq; }      /* (extension values want every neighbour's quality: the general kernel) */
-	if (h->packed_direct && (!lean || h->cfg.size_tracker)) return fail(h, KMR_ERR_STATE, "internal: a packed batch handed to an extraction that wants text");      /* (sk_packed_direct_ok said otherwise) */
 	for (uint64_t r = 0; r < n; r += chunk) {
 		const uint64_t m = std::min(chunk, n - r);
 		ReadsView rv = rvAll;
