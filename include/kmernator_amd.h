@@ -545,6 +545,10 @@ void *kmr_stream(kmr_handle *h);
  * "stream_lookups" (1: kmr_score_* gets its k-mer counts from a streaming pass over minimizer lists where k allows it; 0: per-k-mer
  * probes of the lookup table), "long_list_chunks" (super-k-mer lists of more 1 KB chunks are counted / looked up in pieces, 1024), "coarse_lists" (owner exchange:
  * 1 = scatter into and exchange coarse lists that the owner splits before the count pass, 0 = the job's fine lists; default 0).
+ *   "pow2_lists" (1: the list count of build_mode 3 is always a power of two; default 0: a single GPU's build takes est / list_aim lists),
+ *   "list_aim" (k-mers per list that count aims for; default 1450 when every k-mer weighs the same, 1700 raw k-mers otherwise, 800 with
+ *   extension values, just below the table's bound for keys of more than one word), "packed_direct" (0: kmr_add_reads_twobit* always
+ *   unpack to text first).
  * Call before the first kmr_add_reads* of a build.  KMR_ERR_INVALID_ARG for an unknown knob. */
 int kmr_tune(kmr_handle *h, const char *knob, double value);
 
