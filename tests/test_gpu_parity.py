@@ -927,6 +927,59 @@ def _image_digest(sp, which=KMR_MAP_WEAK):
     return img.size, hashlib.blake2b(memoryview(img), digest_size=16).hexdigest()
 
 
+def test_c2_full_size_noisy_qualities():
+    """BASELINE.json configs[1] at full size with qualities of their own (bench.py --quality noisy: the general extraction with the
+    weight chain, 9-byte records, weights summed in f64): the default build against the device-table build (build_mode 1, an
+    independent algorithm) -- statistics and histogram equal, and the two weak images equal BYTE FOR BYTE (layout, keys, counts,
+    direction biases) except inside weightedCount fields, where the two sides add the same weights in different orders and round
+    once: those stay within SURVEY section 7's 1e-5 * count.  Found from the bytes that differ, so nothing is walked in Python."""
+    import torch
+    import bench
+    n = 10_000_000
+    dev = torch.device("cuda", 0)
+    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev, "noisy")
+    torch.cuda.synchronize()
+    res = []
+    for mode in (0, 1):
+        p = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0, build_mode=mode))
+        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
+        p.finalize(2)
+        st = p.stats()
+        hist = p.histogram(4096)[0]
+        assert st["raw_kmers"] == n * 120 and 0 < st["raw_good_kmers"] < st["raw_kmers"]      # the weight floor discards some
+        assert int(hist.sum()) == st["weak_entries"]
+        assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
+        res.append((st, hist, p.image(KMR_MAP_WEAK)))
+        p.close()
+        del p
+    (st0, h0, a), (st1, h1, b) = res
+    assert st0 == st1 and st0["weak_entries"] > 10_000_000
+    assert np.array_equal(h0, h1)
+    assert a.size == b.size
+    nb = int(np.frombuffer(a[:8].tobytes(), dtype=np.uint64)[0])
+    assert np.array_equal(a[:16 + 8 * nb], b[:16 + 8 * nb])               # header and bucket offsets
+    offs = np.frombuffer(a[16:16 + 8 * nb].tobytes(), dtype=np.uint64).astype(np.int64)
+    assert np.all(np.diff(offs) >= 4)
+    d = np.flatnonzero(a != b).astype(np.int64)
+    if d.size:
+        bucket = np.searchsorted(offs, d, side="right") - 1
+        o = offs[bucket]
+        cnt = np.zeros(d.size, dtype=np.int64)
+        for j in range(4):                                                 # the bucket's entry count (little-endian u32 at its offset)
+            cnt |= a[o + j].astype(np.int64) << (8 * j)
+            assert np.array_equal(a[o + j], b[o + j])
+        rel = d - (o + 4 + 8 * cnt)                                        # position inside the bucket's value array
+        assert np.all(rel >= 0) and np.all(rel < 12 * cnt)
+        assert np.all((rel % 12 >= 4) & (rel % 12 < 8))                    # only bytes of the f32 weightedCount differ
+        e = np.unique(o + 4 + 8 * cnt + 12 * (rel // 12))                  # the entries concerned
+        def field(img, at, width):
+            return np.stack([img[e + at + j] for j in range(width)], axis=1).copy()
+        count = field(a, 0, 2).view(np.uint16).reshape(-1).astype(np.float64)
+        wa, wb = field(a, 4, 4).view(np.float32).reshape(-1), field(b, 4, 4).view(np.float32).reshape(-1)
+        assert np.all(np.abs(wa.astype(np.float64) - wb) <= 1e-5 * count)
+        assert e.size < st0["weak_entries"]
+
+
 def test_c4_full_size_k51():
     """BASELINE.json configs[3] exactly as SURVEY 8(d) defines it: k = 51 (two-word keys), 50 M synthetic 150 bp reads of a 250 Mbp
     genome, seed 3 = 5e9 k-mers over 7.5e9 input bases -- more than 2^32, so the stream ordinal that decides which sighting of a k-mer was its first (directionBias, the
