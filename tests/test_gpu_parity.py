@@ -980,6 +980,32 @@ def test_c2_full_size_noisy_qualities():
         assert e.size < st0["weak_entries"]
 
 
+def test_extension_values_at_scale_modes_agree():
+    """MeraculousCounter's settings (BASELINE.json configs[4]: k = 21, extension values, min quality 2, no weight floor) at 5 M
+    synthetic reads = 6.5e8 k-mers: the default build (extension records on the super-k-mer lists) against the device-table build
+    (build_mode 1) -- statistics equal and the weak images, 60-byte values with all twelve tallies, byte for byte."""
+    import torch
+    import bench
+    n, k = 5_000_000, 21
+    dev = torch.device("cuda", 0)
+    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev)
+    torch.cuda.synchronize()
+    res = []
+    for mode in (0, 1):
+        p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode, value_kind=KMR_VALUE_EXT,
+                                              min_weight=0.0, min_quality_score=2))
+        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
+        p.finalize(2)
+        st = p.stats()
+        assert st["raw_kmers"] == n * (150 - k + 1) == st["raw_good_kmers"]
+        assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
+        res.append((st, _image_digest(p)))
+        p.close()
+        del p
+    assert res[0][0] == res[1][0] and res[0][0]["weak_entries"] > 10_000_000
+    assert res[0][1] == res[1][1]
+
+
 def test_c4_full_size_k51():
     """BASELINE.json configs[3] exactly as SURVEY 8(d) defines it: k = 51 (two-word keys), 50 M synthetic 150 bp reads of a 250 Mbp
     genome, seed 3 = 5e9 k-mers over 7.5e9 input bases -- more than 2^32, so the stream ordinal that decides which sighting of a k-mer was its first (directionBias, the
