@@ -980,6 +980,42 @@ def test_c2_full_size_noisy_qualities():
         assert e.size < st0["weak_entries"]
 
 
+def test_c2_full_size_packed_feed_in_pieces():
+    """The PCIe-inclusive leg of bench.py at full size (configs[1]): the batch handed over 2-bit packed as the reference's Read
+    keeps it (TwoBitSequence::compressSequence, one quality character for all bases), in four calls, staged by the extraction as
+    it lies -- statistics and weak image must equal those of the text feed in one call byte for byte (the same stream ordinals,
+    hence the same first sightings)."""
+    import torch
+    import bench
+    n, rl, pieces = 10_000_000, 150, 4
+    dev = torch.device("cuda", 0)
+    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev)
+    PB = (rl + 3) // 4
+    db = torch.empty(n * PB + 64, dtype=torch.uint8, device=dev)
+    for lo in range(0, n, 1 << 20):
+        m = min(1 << 20, n - lo)
+        c = bases[lo * rl:(lo + m) * rl].view(m, rl)
+        c = ((c >> 1) & 3) ^ ((c >> 2) & 1)                                # A C G T -> 0 1 2 3
+        c = torch.nn.functional.pad(c, (0, PB * 4 - rl)).view(m, PB, 4)
+        db[lo * PB:(lo + m) * PB] = (c[:, :, 0] << 6 | c[:, :, 1] << 4 | c[:, :, 2] << 2 | c[:, :, 3]).reshape(-1)
+    tb_off = torch.arange(n + 1, device=dev, dtype=torch.int64) * PB
+    torch.cuda.synchronize()
+    p = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0))
+    p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * rl, 0)
+    p.finalize(2)
+    st0, dg0 = p.stats(), _image_digest(p)
+    p.reset()
+    per = (n + pieces - 1) // pieces
+    for c in range(pieces):
+        r0, r1 = c * per, min(n, (c + 1) * per)
+        p.buildKmerSpectrumTwoBitDevice(db.data_ptr(), tb_off.data_ptr() + 8 * r0, offsets.data_ptr() + 8 * r0, r1 - r0, (r1 - r0) * rl,
+                                        quals_ptr=None, uniform_quality=33 + 40, first_read_idx=r0)
+    p.finalize(2)
+    assert p.stats() == st0 and st0["raw_kmers"] == n * 120
+    assert _image_digest(p) == dg0
+    p.close()
+
+
 def test_extension_values_at_scale_modes_agree():
     """MeraculousCounter's settings (BASELINE.json configs[4]: k = 21, extension values, min quality 2, no weight floor) at 5 M
     synthetic reads = 6.5e8 k-mers: the default build (extension records on the super-k-mer lists) against the device-table build
