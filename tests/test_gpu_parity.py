@@ -955,29 +955,66 @@ def test_c2_full_size_noisy_qualities():
     (st0, h0, a), (st1, h1, b) = res
     assert st0 == st1 and st0["weak_entries"] > 10_000_000
     assert np.array_equal(h0, h1)
+    assert _images_equal_outside_weights(a, b, 8) < st0["weak_entries"]
+
+
+def _images_equal_outside_weights(a, b, kb):
+    """two weak images (12-byte values, keys of kb bytes) equal byte for byte except inside weightedCount fields, which may differ by
+    1e-5 * count; found from the bytes that differ, nothing is walked in Python.  Returns the entries that differ."""
     assert a.size == b.size
     nb = int(np.frombuffer(a[:8].tobytes(), dtype=np.uint64)[0])
     assert np.array_equal(a[:16 + 8 * nb], b[:16 + 8 * nb])               # header and bucket offsets
     offs = np.frombuffer(a[16:16 + 8 * nb].tobytes(), dtype=np.uint64).astype(np.int64)
     assert np.all(np.diff(offs) >= 4)
     d = np.flatnonzero(a != b).astype(np.int64)
-    if d.size:
-        bucket = np.searchsorted(offs, d, side="right") - 1
-        o = offs[bucket]
-        cnt = np.zeros(d.size, dtype=np.int64)
-        for j in range(4):                                                 # the bucket's entry count (little-endian u32 at its offset)
-            cnt |= a[o + j].astype(np.int64) << (8 * j)
-            assert np.array_equal(a[o + j], b[o + j])
-        rel = d - (o + 4 + 8 * cnt)                                        # position inside the bucket's value array
-        assert np.all(rel >= 0) and np.all(rel < 12 * cnt)
-        assert np.all((rel % 12 >= 4) & (rel % 12 < 8))                    # only bytes of the f32 weightedCount differ
-        e = np.unique(o + 4 + 8 * cnt + 12 * (rel // 12))                  # the entries concerned
-        def field(img, at, width):
-            return np.stack([img[e + at + j] for j in range(width)], axis=1).copy()
-        count = field(a, 0, 2).view(np.uint16).reshape(-1).astype(np.float64)
-        wa, wb = field(a, 4, 4).view(np.float32).reshape(-1), field(b, 4, 4).view(np.float32).reshape(-1)
-        assert np.all(np.abs(wa.astype(np.float64) - wb) <= 1e-5 * count)
-        assert e.size < st0["weak_entries"]
+    if not d.size:
+        return 0
+    bucket = np.searchsorted(offs, d, side="right") - 1
+    o = offs[bucket]
+    cnt = np.zeros(d.size, dtype=np.int64)
+    for j in range(4):                                                     # the bucket's entry count (little-endian u32 at its offset)
+        cnt |= a[o + j].astype(np.int64) << (8 * j)
+        assert np.array_equal(a[o + j], b[o + j])
+    rel = d - (o + 4 + kb * cnt)                                           # position inside the bucket's value array
+    assert np.all(rel >= 0) and np.all(rel < 12 * cnt)
+    assert np.all((rel % 12 >= 4) & (rel % 12 < 8))                        # only bytes of the f32 weightedCount differ
+    e = np.unique(o + 4 + kb * cnt + 12 * (rel // 12))                     # the entries concerned
+
+    def field(img, at, width):
+        return np.stack([img[e + at + j] for j in range(width)], axis=1).copy()
+    count = field(a, 0, 2).view(np.uint16).reshape(-1).astype(np.float64)
+    wa, wb = field(a, 4, 4).view(np.float32).reshape(-1), field(b, 4, 4).view(np.float32).reshape(-1)
+    assert np.all(np.abs(wa.astype(np.float64) - wb) <= 1e-5 * count)
+    return int(e.size)
+
+
+@pytest.mark.parametrize("k,quality", [(51, "noisy"), (64, "flat"), (96, "flat"), (96, "noisy"), (127, "flat"), (127, "noisy")])
+def test_multiword_keys_at_scale_modes_agree(k, quality):
+    """two-, three- and four-word keys at 3 M reads x 150 bp of a 30x genome (up to 3e8 k-mers), flat qualities and qualities of
+    their own: the default build against the device-table build -- statistics equal, weak images byte for byte (flat), or byte for
+    byte outside weightedCount and there within 1e-5 * count (noisy: the same weights added in another order)."""
+    import torch
+    import bench
+    n = 3_000_000
+    dev = torch.device("cuda", 0)
+    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 7, 0, dev, quality)
+    torch.cuda.synchronize()
+    res = []
+    for mode in (0, 1):
+        p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode))
+        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
+        p.finalize(2)
+        st = p.stats()
+        assert st["raw_kmers"] == n * (150 - k + 1) and st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
+        res.append((st, p.image(KMR_MAP_WEAK), p.kb))
+        p.close()
+        del p
+    (st0, a, kb), (st1, b, _) = res
+    assert st0 == st1 and st0["weak_entries"] > 100_000
+    if quality == "flat":
+        assert np.array_equal(a, b)
+    else:
+        assert _images_equal_outside_weights(a, b, kb) < st0["weak_entries"]
 
 
 def test_c2_full_size_packed_feed_in_pieces():
