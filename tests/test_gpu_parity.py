@@ -1017,6 +1017,29 @@ def test_multiword_keys_at_scale_modes_agree(k, quality):
         assert _images_equal_outside_weights(a, b, kb) < st0["weak_entries"]
 
 
+@pytest.mark.parametrize("k,min_depth,sep", [(31, 1, 1), (31, 3, 1), (31, 1, 0), (51, 1, 1)])
+def test_singleton_maps_at_scale_modes_agree(k, min_depth, sep):
+    """3 M reads with the singleton map kept (min-depth 1) or purged below 3, with and without a separate singleton map: the default
+    build against the device-table build -- statistics, weak image and singleton image (1-byte values: the quantised weight)
+    byte for byte.  The small cases of test_singleton_map_and_min_depth_variants go against the oracle; this one is about size."""
+    import torch
+    import bench
+    n = 3_000_000
+    dev = torch.device("cuda", 0)
+    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 5, 0, dev)
+    torch.cuda.synchronize()
+    res = []
+    for mode in (0, 1):
+        p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode, separate_singletons=sep))
+        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
+        p.finalize(min_depth)
+        res.append((p.stats(), _image_digest(p, KMR_MAP_WEAK), _image_digest(p, KMR_MAP_SINGLETON)))
+        p.close()
+        del p
+    assert res[0] == res[1]
+    assert res[0][0]["unique_kmers"] > 1_000_000
+
+
 def test_c2_full_size_packed_feed_in_pieces():
     """The PCIe-inclusive leg of bench.py at full size (configs[1]): the batch handed over 2-bit packed as the reference's Read
     keeps it (TwoBitSequence::compressSequence, one quality character for all bases), in four calls, staged by the extraction as
