@@ -1040,6 +1040,69 @@ def test_singleton_maps_at_scale_modes_agree(k, min_depth, sep):
     assert res[0][0]["unique_kmers"] > 1_000_000
 
 
+@pytest.mark.parametrize("world,k", [(2, 31), (4, 31), (2, 51)])
+def test_list_exchange_at_scale_on_one_gpu(world, k):
+    """The N > 1 build of the default mode at a size where a rank packs and adopts millions of chunks (the two-rank tests on one GPU
+    use 6e4 reads): `world` handles on one GPU, 2 M reads each of one shared genome, every rank extracts into the job's lists with
+    global stream ordinals, packs what the others own (kmr_sk_exchange_counts / _pack_dev), the segments are handed over in device
+    memory as the all-to-all would deliver them, every owner adopts and finalizes.  The ranks' maps must partition the spectrum of
+    one handle fed the same reads in rank order: unique / weak / singleton counts and the count histograms add up to the whole's."""
+    import torch
+    import bench
+    n, L = 2_000_000, 150
+    dev = torch.device("cuda", 0)
+    reads = [bench.gen_reads(torch, n, 5 * n * world, 4, r, dev) for r in range(world)]
+    torch.cuda.synchronize()
+    per = L - k + 1
+    hs, packed = [], []
+    for r in range(world):
+        h = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per * world, device=0, rank=r, world_size=world, build_mode=3))
+        b, q, o = reads[r]
+        h.sk_exchange_begin()
+        h.set_stream_origin(r * n * L)
+        h.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr(), n, n * L, r * n)
+        chunks, granules = h.sk_exchange_counts()
+        sc = [int(c) if j != r else 0 for j, c in enumerate(chunks)]
+        sg = [int(g) if j != r else 0 for j, g in enumerate(granules)]
+        goff = [int(x) for x in np.concatenate([[0], np.cumsum(sg)[:-1]])]
+        coff = [int(x) for x in np.concatenate([[0], np.cumsum(sc)[:-1]])]
+        data = torch.empty((max(sum(sg), 1), 4), dtype=torch.int32, device=dev)
+        meta = torch.empty((max(sum(sc), 1), 2), dtype=torch.int32, device=dev)
+        h.sk_exchange_pack(data.data_ptr(), meta.data_ptr(), goff, coff)
+        assert sum(sc) > 100_000                                              # the size this test is about
+        hs.append(h)
+        packed.append((data, meta, sc, sg, goff, coff))
+    for owner in range(world):
+        for r in range(world):
+            if r == owner:
+                continue
+            data, meta, sc, sg, goff, coff = packed[r]
+            if sc[owner]:
+                hs[owner].sk_exchange_adopt(data[goff[owner]:].data_ptr(), meta[coff[owner]:].data_ptr(), sc[owner], sg[owner])
+        hs[owner].sync()
+    tot = {"unique_kmers": 0, "weak_entries": 0, "singleton_kmers": 0}
+    hist = None
+    for h in hs:
+        h.finalize(2)
+        st = h.stats()
+        for key in tot:
+            tot[key] += st[key]
+        hh = h.histogram(1024)[0].astype(np.int64)
+        hist = hh if hist is None else hist + hh
+        h.close()
+    del packed
+    whole = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per * world, device=0))
+    for r in range(world):
+        b, q, o = reads[r]
+        whole.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr(), n, n * L, r * n)
+    whole.finalize(2)
+    st = whole.stats()
+    assert st["raw_kmers"] == world * n * per
+    assert {key: st[key] for key in tot} == tot
+    assert np.array_equal(whole.histogram(1024)[0].astype(np.int64), hist)
+    whole.close()
+
+
 def test_c2_full_size_packed_feed_in_pieces():
     """The PCIe-inclusive leg of bench.py at full size (configs[1]): the batch handed over 2-bit packed as the reference's Read
     keeps it (TwoBitSequence::compressSequence, one quality character for all bases), in four calls, staged by the extraction as
