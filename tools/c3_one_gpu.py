@@ -15,12 +15,12 @@ L, K = bench.READ_LEN, bench.K
 per = L - K + 1
 sp = ka.KmerSpectrum(ka.default_config(K, estimated_raw_kmers=n * per * world, device=0))
 for rep in range(2):
-    sp.reset(); sp.kernel_time_reset(); t_build = 0.0
+    sp.reset(); sp.kernel_time_reset(); t_build = 0.0; calls = []
     for r in range(world):
         b, q, o = bench.gen_reads(torch, n, 500_000_000 if world == 8 and n == 12_500_000 else 5 * n * world, 2, r, dev)
         torch.cuda.synchronize(); t0 = time.time()
         sp.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr(), n, n * L, r * n); sp.sync()
-        t_build += time.time() - t0
+        t_build += time.time() - t0; calls.append(round((time.time() - t0) * 1e3, 1))
         del b, q, o
     torch.cuda.synchronize(); t0 = time.time()
     sp.finalize(2); torch.cuda.synchronize(); t_fin = time.time() - t0
@@ -31,4 +31,5 @@ for rep in range(2):
     print("rep %d: %d reads, %.3e k-mers: build calls %.1f ms + finalize %.1f ms = %.1f ms -> %.2f G k-mers/s; kernel groups %s; raw %d good %d unique %d weak %d; conservation defect %d, hist sum - weak %d; mem %.1f GB" % (
         rep, n * world, st["raw_kmers"], t_build * 1e3, t_fin * 1e3, tot * 1e3, st["raw_kmers"] / tot / 1e9, [round(sp.kernel_time(g)[0], 1) for g in range(7)],
         st["raw_kmers"], st["raw_good_kmers"], st["unique_kmers"], st["weak_entries"], cons, int(hist.sum()) - st["weak_entries"], torch.cuda.mem_get_info()[0] / 1e9), flush=True)
+    print("   ms per call:", calls, flush=True)
     assert st["raw_kmers"] == n * world * per and cons == 0 and int(hist.sum()) == st["weak_entries"]
