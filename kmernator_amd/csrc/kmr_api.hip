@@ -55,6 +55,7 @@ struct HostPool {                    /* owner of one chunk pool */
 	uint8_t *base = nullptr; uint32_t *chunk_list = nullptr, *chunk_count = nullptr; unsigned int *head = nullptr;
 	uint32_t cap = 0; size_t chunk_bytes = 0;
 	uint64_t used_ub = 0;            /* host-side upper bound of chunks handed out */
+	uint64_t presize = 0;            /* chunks the next allocation takes beyond what is asked for (a job fed in many calls, see sk_add_reads) */
 };
 
 }  // namespace
@@ -740,7 +741,9 @@ int pool_reserve(kmr_handle *h, HostPool &p, uint64_t extra, bool keep) {
 	if (!p.head) { HIPCHK(h, hipMalloc((void **)&p.head, 4)); HIPCHK(h, hipMemset(p.head, 0, 4)); }
 	if (!keep) HIPCHK(h, hipMemsetAsync(p.head, 0, 4, h->stream));
 	if (need <= p.cap) return 0;
-	const uint64_t ncap = keep && used ? need + need / 4 : need;
+	uint64_t ncap = keep && used ? need + need / 4 : need;
+	if (p.presize && need + p.presize < 0xffffffffull) ncap = std::max(ncap, need + p.presize);
+	p.presize = 0;
 	p.chunk_bytes = (size_t)CH * rec_bytes(h);
 	uint8_t *nb; uint32_t *nl, *nc;
 	HIPCHK(h, hipMalloc((void **)&nb, ncap * p.chunk_bytes));
@@ -1543,6 +1546,20 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		/* room for this launch: a granule per k-mer is more than any input takes (flat qualities: a quarter of that), one open
 		 * chunk per list and two slabs of 64 chunks per wavefront */
 		const uint64_t bases = m * avg + avg;
+		/* A job fed in many calls (estimated_raw_kmers says how much is to come) gets its pool in ONE allocation: this call's worst case
+		 * plus what the rest of the job typically takes (flat qualities ~0.25 granules per base, a weight per k-mer ~0.55), at most half
+		 * of the free memory.  Growing call by call frees the old pool every time, and an allocation right after tens of GB were freed
+		 * waits seconds for the driver to clear them (config 3's whole input in eight calls: 5.1 s for the first build);
+		 * denser input than that still grows the pool as before */
+		if (!h->l1.base && r == 0 && h->cfg.world_size <= 1 && !h->sk_exchange && h->cfg.estimated_raw_kmers) {
+			const double job_bases = (double)h->cfg.estimated_raw_kmers * (double)avg / (double)(avg > h->k ? avg - h->k + 1 : 1);
+			const double rest = job_bases - (double)total_bases;
+			size_t fr = 0, tot = 0;
+			if (rest > 0 && hipMemGetInfo(&fr, &tot) == hipSuccess) {
+				const uint64_t want = (uint64_t)(rest * (h->ext ? 2.0 : 1.0) * (lean ? 0.3 : 0.65) / SK_CHUNK_G);
+				h->l1.presize = std::min<uint64_t>(want, (uint64_t)(fr / 2) / ((size_t)CH * rec_bytes(h)));
+			}
+		}
 		/* (inside an exchange the lists of other owners start afresh after every pack: an open chunk per list for every call) */
 		rc = pool_reserve(h, h->l1, (h->ext ? 2 : 1) * bases / SK_CHUNK_G + ((h->l1.base && !h->sk_exchange) ? 0 : sk_list_count(h->sk_bits)) + (uint64_t)num_cus(h) * SK_EXTRACT_WAVES_PER_CU * 130 + 64, true); if (rc) return rc;
 		hipEvent_t a, b, a2, b2; time_begin(h, KMR_TIME_BUILD, &a, &b); time_begin(h, KMR_TIME_EXTRACT, &a2, &b2);
