@@ -26,3 +26,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_torch_cache(request):
+    """The at-scale GPU tests generate their reads with torch; its caching allocator keeps every block it ever took, and the
+    library allocates beside it with hipMalloc -- after a few tests of 10^7 ... 10^8 reads the cache holds tens of GB the next
+    test's device table cannot have (C4's device-table build failed with KMR_ERR_OOM behind the config-3 test).  Hand the cache
+    back after every GPU test."""
+    yield
+    if "gpu" in request.keywords and "torch" in sys.modules:
+        import gc
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()

@@ -1103,40 +1103,6 @@ def test_list_exchange_at_scale_on_one_gpu(world, k):
     whole.close()
 
 
-def test_c3_whole_input_on_one_gpu():
-    """BASELINE.json configs[2]'s WHOLE input -- 100 M synthetic 150 bp reads of a 500 Mbp genome, seed 2, k = 31: 1.2e10 k-mers, what
-    bench.py --gpus 8 spreads over eight GPUs, rank r's reads as bench.py generates them -- built on ONE GPU in eight calls (each
-    rank's batch generated, fed and dropped in turn; 1.5e10 bases of stream ordinals, ~8.3e6 lists, ~130 GB of the 288).  Size-independent
-    properties: every k-mer is counted once, the histogram accounts for every weak entry, the map has the reference's largest bucket
-    count, and sampled k-mers of the reads are found with counts >= 2 where the map holds them."""
-    import torch
-    import bench
-    world, n, L, k = 8, 12_500_000, 150, 31
-    dev = torch.device("cuda", 0)
-    per = L - k + 1
-    p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per * world, device=0))
-    sample = None
-    for r in range(world):
-        b, q, o = bench.gen_reads(torch, n, 500_000_000, 2, r, dev)
-        p.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr(), n, n * L, r * n)
-        p.sync()
-        if r == 3:
-            sample = b[:200 * L].cpu().numpy().copy()
-        del b, q, o
-    p.finalize(2)
-    st = p.stats()
-    assert st["raw_kmers"] == world * n * per == st["raw_good_kmers"]
-    hist = p.histogram(4096)[0]
-    assert int(hist.sum()) == st["weak_entries"]
-    assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
-    assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"] and st["unique_kmers"] > 3_000_000_000
-    # 200 reads of rank 3: at 30x coverage most of their k-mers are in the weak map, and a k-mer that is has been seen at least twice
-    counts, _ = p.getCountsForReads(sample, np.arange(201, dtype=np.uint64) * L)
-    assert counts.size == 200 * per
-    assert np.count_nonzero(counts) > 0.5 * counts.size and np.all((counts == 0) | (counts >= 2))
-    p.close()
-
-
 def test_c2_full_size_packed_feed_in_pieces():
     """The PCIe-inclusive leg of bench.py at full size (configs[1]): the batch handed over 2-bit packed as the reference's Read
     keeps it (TwoBitSequence::compressSequence, one quality character for all bases), in four calls, staged by the extraction as
