@@ -234,6 +234,32 @@ int kmr_load_image(kmr_handle *h, int which_map, const void *src, uint64_t len);
  * KMR_ERR_UNSUPPORTED if the two maps share a k-mer. */
 int kmr_merge_image(kmr_handle *h, int which_map, const void *src, uint64_t len);
 
+/* Order-independent digest of a finalized map: a spectrum of 10^9 entries is compared, and the rank / part maps of a partitioned
+ * build are added up, without moving the maps (the reference compares maps entry by entry on the host, e.g. the store / restore
+ * check of test/KmerTest.cpp:545-594; nothing of the kind exists there for a whole spectrum).  Per entry
+ *   e = mix(..mix(mix(v0 ^ w[0]) ^ w[1])..)  over the key's 8-byte big-endian words (the packed canonical k-mer, zero padded),
+ *   mix(x): x += 0x9E3779B97F4A7C15; x = (x ^ x >> 30) * 0xBF58476D1CE4E5B9; x = (x ^ x >> 27) * 0x94D049BB133111EB; x ^ x >> 31
+ *   weak map:      v0 = count | directionBias << 16; extension values then fold their 12 u32 tallies in pairs (lo | hi << 32)
+ *   singleton map: v0 = 1 << 32 | _weight | packet << 40
+ * hash_sum / hash_xor are the sum (mod 2^64) and the xor of e over all entries, count_sum / dir_sum the plain sums;
+ * weighted_sum adds weightedCount (singleton map: (_weight - 1) / 254) in double -- its last bits depend on the order of addition,
+ * as the reference's own float accumulation does (src/KmerTrackingData.h:427-448). */
+typedef struct kmr_digest {
+	uint64_t entries, count_sum, dir_sum, hash_sum, hash_xor;
+	double weighted_sum;
+} kmr_digest;
+int kmr_map_digest(kmr_handle *h, int which_map, kmr_digest *out);
+
+/* The synthetic reads of SURVEY.md section 8(d) (what bench.py times and the full-size parity tests build), generated on the
+ * current device into caller-owned device buffers: reads first_read .. first_read + n_reads (global indices: a rank's share of a
+ * job is a range) of read_len bases over a uniform random genome of genome_len bases, random strand, 1 % substitutions, no N;
+ * Phred-33 qualities, all 'I' or (noisy_quals) Q 40/30/20/10/2 with probabilities .80/.10/.05/.04/.01 and Q10 on errors.
+ * Integer arithmetic only (xorshift64*, defined in kmernator_amd/csrc/kmr_synth.hpp), so the CPU restatement of the tests gives
+ * the same bytes.  dev_bases / dev_quals: n_reads * read_len bytes (dev_quals may be NULL); dev_offsets: n_reads + 1 entries or
+ * NULL.  Runs on the null stream and returns when the bytes are there.  The reference has no generator; its inputs are files. */
+int kmr_synth_reads_dev(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, uint32_t noisy_quals,
+                        void *dev_bases, void *dev_quals, uint64_t *dev_offsets);
+
 /* Histogram of weak counts (KmerSpectrum::Histogram, src/KmerSpectrum.h:909-1057):
  * counts[c] = number of weak entries with count == c for c < n_bins-1, last bin
  * collects the rest; weights[c] = sum of weightedCount (may be NULL). */

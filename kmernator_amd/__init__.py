@@ -6,7 +6,7 @@ KmerSpectrum interface plus the one-process-per-GPU owner-partitioned driver.
 """
 from ._lib import (KMR_MAP_SINGLETON, KMR_MAP_WEAK, KMR_VALUE_COUNT_DIR, KMR_VALUE_EXT, KmrConfig, default_config, load,
                    record_bytes)
-from .spectrum import FilterKnownOddities, KmerSpectrum, KmerSpectrumError, Histogram, ReadSet
+from .spectrum import FilterKnownOddities, KmerSpectrum, KmerSpectrumError, Histogram, ReadSet, synth_reads_device
 
-__all__ = ["KmerSpectrum", "KmerSpectrumError", "ReadSet", "Histogram", "FilterKnownOddities", "KmrConfig", "default_config", "load", "record_bytes",
+__all__ = ["KmerSpectrum", "KmerSpectrumError", "ReadSet", "Histogram", "FilterKnownOddities", "synth_reads_device", "KmrConfig", "default_config", "load", "record_bytes",
            "KMR_MAP_WEAK", "KMR_MAP_SINGLETON", "KMR_VALUE_COUNT_DIR", "KMR_VALUE_EXT"]

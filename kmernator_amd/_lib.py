@@ -46,6 +46,14 @@ class KmrStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class KmrDigest(C.Structure):
+    """kmr_digest"""
+    _fields_ = [(n, C.c_uint64) for n in ("entries", "count_sum", "dir_sum", "hash_sum", "hash_xor")] + [("weighted_sum", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class KmrArtifactConfig(C.Structure):
     """kmr_artifact_config"""
     _fields_ = [(n, C.c_uint32) for n in ("match_length", "edit_distance", "build_edits", "simple_repeat_begin", "simple_repeat_end",
@@ -65,6 +73,7 @@ EXPORTS = [
     "kmr_artifact_config_init", "kmr_artifact_filter_create", "kmr_artifact_filter_info", "kmr_artifact_filter_entries",
     "kmr_artifact_filter_free", "kmr_artifact_filter_apply",
     "kmr_tune", "kmr_set_stream_origin", "kmr_size_tracker", "kmr_exchange_unique_id", "kmr_exchange_init", "kmr_exchange_init_transport", "kmr_exchange_add_reads_dev", "kmr_exchange_add_read_batch", "kmr_exchange_stats", "kmr_copy_to_host", "kmr_copy_to_device", "kmr_sk_exchange_begin", "kmr_sk_exchange_counts", "kmr_sk_exchange_pack_dev", "kmr_sk_exchange_adopt_dev", "kmr_extract_by_owner_host", "kmr_insert_records", "kmr_reads_from_host", "kmr_reads_from_twobit", "kmr_reads_twobit", "kmr_lookup_requests_dev", "kmr_lookup_keys_dev", "kmr_scatter_counts_dev", "kmr_score_counts_dev",
+    "kmr_map_digest", "kmr_synth_reads_dev",
 ]
 
 _lib = None
@@ -167,6 +176,8 @@ def load():
     lib.kmr_histogram_bins.restype = C.c_uint32
     lib.kmr_histogram_bins.argtypes = [C.c_uint32]
     lib.kmr_histogram.argtypes = [vp, C.c_uint32, C.c_double, u64p, u64p, f64p, C.c_uint32]
+    lib.kmr_map_digest.argtypes = [vp, C.c_int, C.POINTER(KmrDigest)]
+    lib.kmr_synth_reads_dev.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, vp]
     _lib = lib
     return lib
 

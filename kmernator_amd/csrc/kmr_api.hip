@@ -9,6 +9,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -28,6 +29,7 @@
 #include "kmr_artifact.hpp"
 #include "kmr_superkmer.hpp"
 #include "kmr_buckets.hpp"
+#include "kmr_synth.hpp"
 #define KMR_INSTANCES_EXTERN
 #include "kmr_instances.hpp"      /* the heavy kernels are compiled in kmr_inst_*.hip */
 
@@ -181,8 +183,35 @@ struct kmr_reads {
 
 namespace {
 
+/* Every device allocation of the library goes through dev_malloc.  An allocation that fails for lack of memory although the card
+ * as a whole could hold it is tried again for a bounded time (memory another handle or torch has just freed is handed back by the
+ * driver with a delay, and work still running on other streams may hold what it is about to free); what was asked for and what the
+ * device had is kept for the error text (oom_note), so that a KMR_ERR_OOM says how far off it was. */
+thread_local char g_oom_note[160] = "";
+hipError_t dev_malloc(void **p, size_t bytes) {
+	hipError_t e = hipMalloc(p, bytes);
+	if (e != hipErrorOutOfMemory) return e;
+	size_t fr = 0, tot = 0;
+	for (int attempt = 0; attempt < 6; attempt++) {
+		(void)hipGetLastError();
+		hipDeviceSynchronize();
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess || bytes > tot) break;
+		usleep(20000u << attempt);      /* 20 ms ... 640 ms: 1.3 s at most */
+		e = hipMalloc(p, bytes);
+		if (e != hipErrorOutOfMemory) return e;
+	}
+	(void)hipGetLastError();
+	hipMemGetInfo(&fr, &tot);
+	snprintf(g_oom_note, sizeof(g_oom_note), " [requested %.3f GB; device has %.3f GB free of %.3f GB]", bytes / 1e9, fr / 1e9, tot / 1e9);
+	*p = nullptr;
+	return hipErrorOutOfMemory;
+}
+std::string oom_note() { std::string s(g_oom_note); g_oom_note[0] = 0; return s; }
+
+std::string hip_err_text(hipError_t e) { return std::string(hipGetErrorString(e)) + (e == hipErrorOutOfMemory ? oom_note() : std::string()); }
+
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-	(h)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+	(h)->err = std::string(#call) + ": " + hip_err_text(e_); \
 	return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
 
 /* diagnostics on stderr and the measurement-only hooks exist in a -DKMR_DEBUG_HOOKS build alone: the shipped library reads no
@@ -193,7 +222,7 @@ bool dbg() { static const bool d = getenv("KMR_DEBUG") != nullptr; return d; }
 constexpr bool dbg() { return false; }
 #endif
 
-int fail(kmr_handle *h, int code, const std::string &msg) { if (h) h->err = msg; else g_create_error = msg; return code; }
+int fail(kmr_handle *h, int code, const std::string &msg) { const std::string m = code == KMR_ERR_OOM ? msg + oom_note() : msg; if (h) h->err = m; else g_create_error = m; return code; }
 
 uint64_t min_pow2(uint64_t n) {   /* BucketExposedMapLogic::getMinPowerOf2, src/Kmer.h:2199-2212 */
 	uint64_t p = n;
@@ -255,8 +284,8 @@ int clear_table_any(kmr_handle *h, void *slots, ExtSlot *ext, uint32_t log2cap) 
 
 int alloc_table(kmr_handle *h, uint32_t log2cap, void **slots, ExtSlot **ext) {
 	*slots = nullptr; *ext = nullptr;
-	HIPCHK(h, hipMalloc(slots, slot_bytes(h->W) << log2cap));
-	if (h->ext) { hipError_t e = hipMalloc((void **)ext, sizeof(ExtSlot) << log2cap); if (e != hipSuccess) { hipFree(*slots); *slots = nullptr; h->err = "hipMalloc(ext slots)"; return KMR_ERR_OOM; } }
+	HIPCHK(h, dev_malloc(slots, slot_bytes(h->W) << log2cap));
+	if (h->ext) { hipError_t e = dev_malloc((void **)ext, sizeof(ExtSlot) << log2cap); if (e != hipSuccess) { hipFree(*slots); *slots = nullptr; h->err = "dev_malloc(ext slots)"; return KMR_ERR_OOM; } }
 	return clear_table_any(h, *slots, *ext, log2cap);
 }
 
@@ -341,23 +370,23 @@ int prepare_units(kmr_handle *h, ReadsView &rv, uint32_t span = (uint32_t)TILE_S
 	rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
 	const uint64_t n = rv.n_reads;
 	if (n == 0) return 0;
-	if (!h->umax) HIPCHK(h, hipMalloc((void **)&h->umax, 4));
+	if (!h->umax) HIPCHK(h, dev_malloc((void **)&h->umax, 4));
 	HIPCHK(h, hipMemsetAsync(h->umax, 0, 4, h->stream));
-	if (!h->ucnt || h->ucnt_n < n + 1) { if (h->ucnt) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->ucnt); } h->ucnt = nullptr; HIPCHK(h, hipMalloc((void **)&h->ucnt, 4 * (n + 1))); h->ucnt_n = n + 1; }
+	if (!h->ucnt || h->ucnt_n < n + 1) { if (h->ucnt) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->ucnt); } h->ucnt = nullptr; HIPCHK(h, dev_malloc((void **)&h->ucnt, 4 * (n + 1))); h->ucnt_n = n + 1; }
 	hipLaunchKernelGGL(unit_count_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, rv.offsets, n, h->k, span, h->ucnt, h->umax);
 	HIPCHK(h, hipGetLastError());
 	unsigned int mx = 0;
 	HIPCHK(h, hipMemcpyAsync(&mx, h->umax, 4, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	if (mx <= span) return 0;                   /* the usual case: every read is one unit */
-	if (!h->ufirst || h->ufirst_n < n + 1) { if (h->ufirst) hipFree(h->ufirst); h->ufirst = nullptr; HIPCHK(h, hipMalloc((void **)&h->ufirst, 8 * (n + 1))); h->ufirst_n = n + 1; }
+	if (!h->ufirst || h->ufirst_n < n + 1) { if (h->ufirst) hipFree(h->ufirst); h->ufirst = nullptr; HIPCHK(h, dev_malloc((void **)&h->ufirst, 8 * (n + 1))); h->ufirst_n = n + 1; }
 	int rc = exclusive_scan(h, h->ucnt, n, h->ufirst); if (rc) return rc;
 	uint64_t U = 0;
 	HIPCHK(h, hipMemcpy(&U, h->ufirst + n, 8, hipMemcpyDeviceToHost));
 	if (h->units_n < U) {
 		if (h->u_start) { hipFree(h->u_start); hipFree(h->u_end); hipFree(h->u_read); }
 		h->u_start = h->u_end = h->u_read = nullptr; h->units_n = 0;
-		HIPCHK(h, hipMalloc((void **)&h->u_start, 8 * U)); HIPCHK(h, hipMalloc((void **)&h->u_end, 8 * U)); HIPCHK(h, hipMalloc((void **)&h->u_read, 8 * U));
+		HIPCHK(h, dev_malloc((void **)&h->u_start, 8 * U)); HIPCHK(h, dev_malloc((void **)&h->u_end, 8 * U)); HIPCHK(h, dev_malloc((void **)&h->u_read, 8 * U));
 		h->units_n = U;
 	}
 	hipLaunchKernelGGL(unit_fill_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, rv.offsets, n, h->k, span, h->ufirst, h->u_start, h->u_end, h->u_read);
@@ -424,7 +453,7 @@ int exclusive_scan(kmr_handle *h, const uint32_t *in, uint64_t n, uint64_t *out 
 	if (h->scan_sums_n < nblocks + 1) {
 		if (h->scan_sums) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->scan_sums); h->scan_sums = nullptr; h->scan_sums_n = 0; }
 		const uint64_t want = std::max<uint64_t>(nblocks + 1, 4096);
-		HIPCHK(h, hipMalloc((void **)&h->scan_sums, sizeof(unsigned long long) * want)); h->scan_sums_n = want;
+		HIPCHK(h, dev_malloc((void **)&h->scan_sums, sizeof(unsigned long long) * want)); h->scan_sums_n = want;
 	}
 	sums = h->scan_sums;
 	total = sums + nblocks;
@@ -442,7 +471,7 @@ int arena_alloc(kmr_handle *h, void **out, size_t bytes) {
 	const size_t need = (bytes + 255) & ~(size_t)255;
 	if (h->arena && h->arena_used + need <= h->arena_cap) { *out = h->arena + h->arena_used; h->arena_used += need; h->arena_want += need; return 0; }
 	h->arena_want += need;
-	HIPCHK(h, hipMalloc(out, std::max<size_t>(need, 256)));
+	HIPCHK(h, dev_malloc(out, std::max<size_t>(need, 256)));
 	h->arena_overflow.push_back(*out);
 	return 0;
 }
@@ -455,7 +484,7 @@ int arena_reset(kmr_handle *h) {
 		if (h->arena) hipFree(h->arena);
 		h->arena = nullptr; h->arena_cap = 0;
 		const size_t want = h->arena_want + h->arena_want / 8 + (1 << 20);
-		if (hipMalloc((void **)&h->arena, want) == hipSuccess) h->arena_cap = want; else { h->arena = nullptr; (void)hipGetLastError(); }
+		if (dev_malloc((void **)&h->arena, want) == hipSuccess) h->arena_cap = want; else { h->arena = nullptr; (void)hipGetLastError(); }
 	}
 	h->arena_used = 0; h->arena_want = 0;
 	return 0;
@@ -478,7 +507,7 @@ int reserve_bytes(kmr_handle *h, void **ptr, size_t &cap, size_t need) {
 	if (*ptr && cap >= need) return 0;
 	if (*ptr) hipFree(*ptr);
 	*ptr = nullptr; cap = 0;
-	HIPCHK(h, hipMalloc(ptr, need));
+	HIPCHK(h, dev_malloc(ptr, need));
 	cap = need;
 	return 0;
 }
@@ -495,7 +524,7 @@ template <int W, bool EXT> int finalize_t(kmr_handle *h, uint32_t min_depth) {
 	FinalizeParams f; f.kb = h->hkb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr;
-	HIPCHK(h, hipMalloc((void **)&wc, 4 * h->nb_weak)); HIPCHK(h, hipMalloc((void **)&sc, 4 * h->nb_sing)); HIPCHK(h, hipMalloc((void **)&fc, sizeof(FinalizeCounters)));
+	HIPCHK(h, dev_malloc((void **)&wc, 4 * h->nb_weak)); HIPCHK(h, dev_malloc((void **)&sc, 4 * h->nb_sing)); HIPCHK(h, dev_malloc((void **)&fc, sizeof(FinalizeCounters)));
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream)); HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream));
 	Table<W> t = table_of<W>(h);
 	const int g = grid_for(1ull << h->log2cap);
@@ -512,12 +541,12 @@ template <int W, bool EXT> int finalize_t(kmr_handle *h, uint32_t min_depth) {
 	wm.nb = h->nb_weak; wm.n = c.weak_kept; wm.present = true;
 	sm.nb = h->nb_sing; sm.n = c.sing_kept; sm.present = keepSing;
 	const uint32_t vw = EXT ? 15 : 3;
-	HIPCHK(h, hipMalloc((void **)&wm.start, 8 * (wm.nb + 1))); HIPCHK(h, hipMalloc((void **)&sm.start, 8 * (sm.nb + 1)));
+	HIPCHK(h, dev_malloc((void **)&wm.start, 8 * (wm.nb + 1))); HIPCHK(h, dev_malloc((void **)&sm.start, 8 * (sm.nb + 1)));
 	rc = exclusive_scan(h, wc, wm.nb, wm.start); if (rc) return rc;
 	rc = exclusive_scan(h, sc, sm.nb, sm.start); if (rc) return rc;
-	HIPCHK(h, hipMalloc((void **)&wm.keys, std::max<uint64_t>(8, 8ull * W * wm.n))); HIPCHK(h, hipMalloc((void **)&wm.vals, std::max<uint64_t>(8, 4ull * vw * wm.n)));
-	HIPCHK(h, hipMalloc((void **)&sm.keys, std::max<uint64_t>(8, 8ull * W * sm.n))); HIPCHK(h, hipMalloc((void **)&sm.sweight, std::max<uint64_t>(8, sm.n)));
-	if (EXT) HIPCHK(h, hipMalloc((void **)&sm.spkt, std::max<uint64_t>(8, 4ull * sm.n)));
+	HIPCHK(h, dev_malloc((void **)&wm.keys, std::max<uint64_t>(8, 8ull * W * wm.n))); HIPCHK(h, dev_malloc((void **)&wm.vals, std::max<uint64_t>(8, 4ull * vw * wm.n)));
+	HIPCHK(h, dev_malloc((void **)&sm.keys, std::max<uint64_t>(8, 8ull * W * sm.n))); HIPCHK(h, dev_malloc((void **)&sm.sweight, std::max<uint64_t>(8, sm.n)));
+	if (EXT) HIPCHK(h, dev_malloc((void **)&sm.spkt, std::max<uint64_t>(8, 4ull * sm.n)));
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
 	hipLaunchKernelGGL((scatter_kernel<W, EXT>), dim3(g), dim3(256), 0, h->stream, t, f, wm.start, wc, wm.keys, wm.vals, sm.start, sc, sm.keys, sm.sweight, sm.spkt);
 	HIPCHK(h, hipGetLastError());
@@ -544,7 +573,7 @@ template <int W> int build_image_t(kmr_handle *h, DevMap &m, bool weakMap) {
 	const uint32_t vw = h->ext ? 15 : 3;
 	const uint32_t vbytes = weakMap ? (h->ext ? 60 : 12) : (h->ext ? 5 : 1);
 	m.image_bytes = 8 * (2 + m.nb) + 4 * m.nb + m.n * (h->kb + vbytes);
-	HIPCHK(h, hipMalloc((void **)&m.image, m.image_bytes));
+	HIPCHK(h, dev_malloc((void **)&m.image, m.image_bytes));
 	hipLaunchKernelGGL(image_header_kernel, dim3(grid_for(m.nb)), dim3(256), 0, h->stream, m.image, m.start, m.nb, h->kb, vbytes);
 	if (m.n) hipLaunchKernelGGL(image_entries_kernel<W>, dim3(grid_for(m.n)), dim3(256), 0, h->stream, m.image, m.start, m.nb, h->kb, vbytes,
 	                           m.keys, weakMap ? m.vals : nullptr, vw, m.sweight, m.spkt, m.n);
@@ -576,15 +605,15 @@ template <int W> int load_image_t(kmr_handle *h, DevMap &m, bool weakMap, const 
 		if (expect > len) return fail(h, KMR_ERR_INVALID_ARG, "image bucket runs past the end");
 	}
 	if (expect != len) return fail(h, KMR_ERR_INVALID_ARG, "image length mismatch");
-	HIPCHK(h, hipMalloc((void **)&m.image, len)); m.image_bytes = len;
+	HIPCHK(h, dev_malloc((void **)&m.image, len)); m.image_bytes = len;
 	HIPCHK(h, hipMemcpy(m.image, src, len, hipMemcpyHostToDevice));
-	uint32_t *counts; HIPCHK(h, hipMalloc((void **)&counts, 4 * nb));
+	uint32_t *counts; HIPCHK(h, dev_malloc((void **)&counts, 4 * nb));
 	hipLaunchKernelGGL(image_counts_kernel, dim3(grid_for(nb)), dim3(256), 0, h->stream, m.image, nb, counts);
-	HIPCHK(h, hipMalloc((void **)&m.start, 8 * (nb + 1)));
+	HIPCHK(h, dev_malloc((void **)&m.start, 8 * (nb + 1)));
 	int rc = exclusive_scan(h, counts, nb, m.start); hipFree(counts); if (rc) return rc;
-	HIPCHK(h, hipMalloc((void **)&m.keys, std::max<uint64_t>(8, 8ull * W * m.n)));
-	if (weakMap) HIPCHK(h, hipMalloc((void **)&m.vals, std::max<uint64_t>(8, 4ull * vw * m.n)));
-	else { HIPCHK(h, hipMalloc((void **)&m.sweight, std::max<uint64_t>(8, m.n))); if (h->ext) HIPCHK(h, hipMalloc((void **)&m.spkt, std::max<uint64_t>(8, 4 * m.n))); }
+	HIPCHK(h, dev_malloc((void **)&m.keys, std::max<uint64_t>(8, 8ull * W * m.n)));
+	if (weakMap) HIPCHK(h, dev_malloc((void **)&m.vals, std::max<uint64_t>(8, 4ull * vw * m.n)));
+	else { HIPCHK(h, dev_malloc((void **)&m.sweight, std::max<uint64_t>(8, m.n))); if (h->ext) HIPCHK(h, dev_malloc((void **)&m.spkt, std::max<uint64_t>(8, 4 * m.n))); }
 	if (m.n) hipLaunchKernelGGL(image_unpack_kernel<W>, dim3(grid_for(m.n)), dim3(256), 0, h->stream, m.image, m.start, nb, h->kb, vbytes, m.keys, m.vals, vw, m.sweight, m.spkt, m.n);
 	/* restore() accepts unsorted buckets (setLastSorted); lookups here need them sorted */
 	SortView<W> sv; sv.keys = m.keys; sv.vals = m.vals; sv.b8 = m.sweight; sv.pkt = m.spkt; sv.vw = weakMap ? vw : 0;
@@ -611,14 +640,14 @@ template <int W> int merge_image_t(kmr_handle *h, DevMap &m, bool weakMap, const
 	DevMap d; d.nb = m.nb; d.n = m.n + t.n; d.present = true;
 	uint32_t *counts = nullptr, *dup = nullptr;
 	auto bail = [&](int code) { free_map(t); free_map(d); if (counts) hipFree(counts); if (dup) hipFree(dup); return code; };
-#define MCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP); } } while (0)
-	MCHK(hipMalloc((void **)&counts, 4 * m.nb)); MCHK(hipMalloc((void **)&dup, 4)); MCHK(hipMemsetAsync(dup, 0, 4, h->stream));
-	MCHK(hipMalloc((void **)&d.start, 8 * (m.nb + 1)));
+#define MCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hip_err_text(e_); return bail(e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP); } } while (0)
+	MCHK(dev_malloc((void **)&counts, 4 * m.nb)); MCHK(dev_malloc((void **)&dup, 4)); MCHK(hipMemsetAsync(dup, 0, 4, h->stream));
+	MCHK(dev_malloc((void **)&d.start, 8 * (m.nb + 1)));
 	hipLaunchKernelGGL(merge_counts_kernel, dim3(grid_for(m.nb)), dim3(256), 0, h->stream, m.start, t.start, m.nb, counts);
 	rc = exclusive_scan(h, counts, m.nb, d.start); if (rc) return bail(rc);
-	MCHK(hipMalloc((void **)&d.keys, std::max<uint64_t>(8, 8ull * W * d.n)));
-	if (weakMap) MCHK(hipMalloc((void **)&d.vals, std::max<uint64_t>(8, 4ull * vw * d.n)));
-	else { MCHK(hipMalloc((void **)&d.sweight, std::max<uint64_t>(8, d.n))); if (h->ext) MCHK(hipMalloc((void **)&d.spkt, std::max<uint64_t>(8, 4 * d.n))); }
+	MCHK(dev_malloc((void **)&d.keys, std::max<uint64_t>(8, 8ull * W * d.n)));
+	if (weakMap) MCHK(dev_malloc((void **)&d.vals, std::max<uint64_t>(8, 4ull * vw * d.n)));
+	else { MCHK(dev_malloc((void **)&d.sweight, std::max<uint64_t>(8, d.n))); if (h->ext) MCHK(dev_malloc((void **)&d.spkt, std::max<uint64_t>(8, 4 * d.n))); }
 	if (m.n) hipLaunchKernelGGL(merge_copy_kernel<W>, dim3(grid_for(m.n)), dim3(256), 0, h->stream, m.start, t.start, false, m.nb, m.n, m.keys, weakMap ? m.vals : nullptr, vw, m.sweight, m.spkt, d.start, d.keys, d.vals, d.sweight, d.spkt);
 	if (t.n) hipLaunchKernelGGL(merge_copy_kernel<W>, dim3(grid_for(t.n)), dim3(256), 0, h->stream, t.start, m.start, true, m.nb, t.n, t.keys, weakMap ? t.vals : nullptr, vw, t.sweight, t.spkt, d.start, d.keys, d.vals, d.sweight, d.spkt);
 	if (!weakMap) launch_sort<W, 0>(h, d, false); else if (h->ext) launch_sort<W, 15>(h, d, true); else launch_sort<W, 3>(h, d, true);
@@ -636,7 +665,7 @@ template <int W> int merge_image_t(kmr_handle *h, DevMap &m, bool weakMap, const
 
 template <int W> int lookup_t(kmr_handle *h, const uint8_t *packed, uint64_t n, uint32_t *counts) {
 	uint8_t *dk; uint32_t *dc;
-	HIPCHK(h, hipMalloc((void **)&dk, std::max<uint64_t>(8, n * h->kb))); HIPCHK(h, hipMalloc((void **)&dc, std::max<uint64_t>(8, 4 * n)));
+	HIPCHK(h, dev_malloc((void **)&dk, std::max<uint64_t>(8, n * h->kb))); HIPCHK(h, dev_malloc((void **)&dc, std::max<uint64_t>(8, 4 * n)));
 	HIPCHK(h, hipMemcpyAsync(dk, packed, n * h->kb, hipMemcpyHostToDevice, h->stream));
 	const uint32_t vw = h->ext ? 15 : 3;
 	hipLaunchKernelGGL(lookup_keys_kernel<W>, dim3(grid_for(n)), dim3(256), 0, h->stream, view_of<W>(h->weak, vw), view_of<W>(h->sing, vw), dk, n, h->hkb, dc);
@@ -658,7 +687,7 @@ template <int W> LutView<W> lut_of(kmr_handle *h) {
 		if (h->lut_bytes < bytes) {
 			if (h->lut) { hipStreamSynchronize(h->stream); hipFree(h->lut); h->lut = nullptr; h->lut_bytes = 0; }
 			size_t fr = 0, tot = 0;
-			if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + (1ull << 30) || hipMalloc((void **)&h->lut, bytes) != hipSuccess) { h->lut = nullptr; (void)hipGetLastError(); return v; }
+			if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + (1ull << 30) || dev_malloc((void **)&h->lut, bytes) != hipSuccess) { h->lut = nullptr; (void)hipGetLastError(); return v; }
 			h->lut_bytes = bytes;
 		}
 		const uint32_t vw = h->ext ? 15 : 3;
@@ -682,13 +711,13 @@ template <int W> int lookup_reads_t(kmr_handle *h, const ReadsView &rv, uint32_t
 struct StagedReads { uint8_t *b = nullptr, *q = nullptr, *d = nullptr; uint64_t *o = nullptr; void release() { if (b) hipFree(b); if (q) hipFree(q); if (d) hipFree(d); if (o) hipFree(o); b = q = d = nullptr; o = nullptr; } };
 int stage_reads(kmr_handle *h, const char *bases, const char *quals, const uint64_t *offsets, uint64_t n, const uint8_t *disc, StagedReads &s, uint64_t &total) {
 	total = n ? offsets[n] - offsets[0] : 0;
-	HIPCHK(h, hipMalloc((void **)&s.b, total + 64)); HIPCHK(h, hipMalloc((void **)&s.o, 8 * (n + 1)));
+	HIPCHK(h, dev_malloc((void **)&s.b, total + 64)); HIPCHK(h, dev_malloc((void **)&s.o, 8 * (n + 1)));
 	HIPCHK(h, hipMemcpyAsync(s.b, bases + (n ? offsets[0] : 0), total, hipMemcpyHostToDevice, h->stream));
 	std::vector<uint64_t> rel(n + 1);
 	for (uint64_t i = 0; i <= n; i++) rel[i] = n ? offsets[i] - offsets[0] : 0;
 	HIPCHK(h, hipMemcpyAsync(s.o, rel.data(), 8 * (n + 1), hipMemcpyHostToDevice, h->stream));
-	if (quals) { HIPCHK(h, hipMalloc((void **)&s.q, total + 64)); HIPCHK(h, hipMemcpyAsync(s.q, quals + (n ? offsets[0] : 0), total, hipMemcpyHostToDevice, h->stream)); }
-	if (disc) { HIPCHK(h, hipMalloc((void **)&s.d, n + 8)); HIPCHK(h, hipMemcpyAsync(s.d, disc, n, hipMemcpyHostToDevice, h->stream)); }
+	if (quals) { HIPCHK(h, dev_malloc((void **)&s.q, total + 64)); HIPCHK(h, hipMemcpyAsync(s.q, quals + (n ? offsets[0] : 0), total, hipMemcpyHostToDevice, h->stream)); }
+	if (disc) { HIPCHK(h, dev_malloc((void **)&s.d, n + 8)); HIPCHK(h, hipMemcpyAsync(s.d, disc, n, hipMemcpyHostToDevice, h->stream)); }
 	HIPCHK(h, hipStreamSynchronize(h->stream));   /* rel[] goes out of scope */
 	return 0;
 }
@@ -738,7 +767,7 @@ int pool_reserve(kmr_handle *h, HostPool &p, uint64_t extra, bool keep) {
 	p.used_ub = (uint64_t)used + extra;
 	const uint64_t need = (uint64_t)used + extra + 64;
 	if (need >= 0xffffffffull) return fail(h, KMR_ERR_CAPACITY, "record pool would exceed 2^32 chunks");
-	if (!p.head) { HIPCHK(h, hipMalloc((void **)&p.head, 4)); HIPCHK(h, hipMemset(p.head, 0, 4)); }
+	if (!p.head) { HIPCHK(h, dev_malloc((void **)&p.head, 4)); HIPCHK(h, hipMemset(p.head, 0, 4)); }
 	if (!keep) HIPCHK(h, hipMemsetAsync(p.head, 0, 4, h->stream));
 	if (need <= p.cap) return 0;
 	uint64_t ncap = keep && used ? need + need / 4 : need;
@@ -746,8 +775,8 @@ int pool_reserve(kmr_handle *h, HostPool &p, uint64_t extra, bool keep) {
 	p.presize = 0;
 	p.chunk_bytes = (size_t)CH * rec_bytes(h);
 	uint8_t *nb; uint32_t *nl, *nc;
-	HIPCHK(h, hipMalloc((void **)&nb, ncap * p.chunk_bytes));
-	HIPCHK(h, hipMalloc((void **)&nl, 4 * ncap)); HIPCHK(h, hipMalloc((void **)&nc, 4 * ncap));
+	HIPCHK(h, dev_malloc((void **)&nb, ncap * p.chunk_bytes));
+	HIPCHK(h, dev_malloc((void **)&nl, 4 * ncap)); HIPCHK(h, dev_malloc((void **)&nc, 4 * ncap));
 	if (used) {
 		HIPCHK(h, hipMemcpy(nb, p.base, (size_t)used * p.chunk_bytes, hipMemcpyDeviceToDevice));
 		HIPCHK(h, hipMemcpy(nl, p.chunk_list, 4ull * used, hipMemcpyDeviceToDevice));
@@ -765,13 +794,13 @@ template <class T> int ensure_buf(kmr_handle *h, T *&ptr, uint64_t &cap, uint64_
 	if (ptr) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree((void *)ptr); }   /* kernels in flight may still read it */
 	ptr = nullptr; cap = 0;
 	const uint64_t n = std::max<uint64_t>(need, 16);
-	HIPCHK(h, hipMalloc((void **)&ptr, n * elem));
+	HIPCHK(h, dev_malloc((void **)&ptr, n * elem));
 	cap = n;
 	return 0;
 }
 
 int zero_work_counter(kmr_handle *h) {
-	if (!h->work_counter) HIPCHK(h, hipMalloc((void **)&h->work_counter, 4));
+	if (!h->work_counter) HIPCHK(h, dev_malloc((void **)&h->work_counter, 4));
 	HIPCHK(h, hipMemsetAsync(h->work_counter, 0, 4, h->stream));
 	return 0;
 }
@@ -793,7 +822,7 @@ template <int W, bool EXT> int ensure_l1_state(kmr_handle *h) {
 	const size_t stride = partition_state_bytes<W, EXT, PD_LINE>(h->bits1), need = stride * (size_t)partition_blocks(h);
 	if (h->l1_state && h->l1_state_bytes == need) return 0;
 	if (h->l1_state) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->l1_state); h->l1_state = nullptr; }
-	HIPCHK(h, hipMalloc((void **)&h->l1_state, need)); h->l1_state_bytes = need;
+	HIPCHK(h, dev_malloc((void **)&h->l1_state, need)); h->l1_state_bytes = need;
 	hipLaunchKernelGGL(partition_state_init_kernel, dim3(partition_blocks(h)), dim3(256), 0, h->stream, h->l1_state, stride, h->bits1, (uint32_t)partition_blocks(h));
 	HIPCHK(h, hipGetLastError());
 	h->l1_state_dirty = false;
@@ -982,14 +1011,14 @@ int build_csr(kmr_handle *h, HostPool &p, uint64_t nl, uint32_t first, uint64_t 
 	*n_chunks_out = used;
 	if (dbg()) {
 		unsigned long long *d, hv[2] = {0, 0};
-		HIPCHK(h, hipMalloc((void **)&d, 16)); HIPCHK(h, hipMemset(d, 0, 16));
+		HIPCHK(h, dev_malloc((void **)&d, 16)); HIPCHK(h, hipMemset(d, 0, 16));
 		if (used) hipLaunchKernelGGL(pool_records_kernel, dim3(grid_for(used)), dim3(256), 0, h->stream, p.chunk_list, p.chunk_count, used, d, d + 1);
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		HIPCHK(h, hipMemcpy(hv, d, 16, hipMemcpyDeviceToHost)); hipFree(d);
 		fprintf(stderr, "build_csr: lists %llu chunks %u valid %llu records %llu (expected %llu)\n", (unsigned long long)nl, used, hv[1], hv[0], (unsigned long long)h->stats.raw_good_kmers);
 		unsigned long long *v, vv[3] = {0, 0, 0};
 		int bits = 0; while ((1ull << bits) < nl) bits++;
-		HIPCHK(h, hipMalloc((void **)&v, 24)); HIPCHK(h, hipMemset(v, 0, 24));
+		HIPCHK(h, dev_malloc((void **)&v, 24)); HIPCHK(h, hipMemset(v, 0, 24));
 		PoolView pvw = pool_view(h, p);
 #define VLK(Wv, E) hipLaunchKernelGGL((verify_lists_kernel<Wv, E>), dim3(4096), dim3(256), 0, h->stream, pvw, *list_start, *list_chunks, nl, bits, h->hkb, part_rot(h), v, v + 1, v + 2)
 		switch (h->W) {
@@ -1128,11 +1157,11 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 	}
 	if (!h->uw_keys || h->uw_cap < wcap) {
 		if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
-		HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, hipMalloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
+		HIPCHK(h, dev_malloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, dev_malloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
 	}
 	if (!h->us_keys || h->us_cap < scap) {
 		if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0;
-		HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); if (EXT) HIPCHK(h, hipMalloc(&h->us_pkt, 4 * scap)); h->us_cap = scap;
+		HIPCHK(h, dev_malloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, dev_malloc(&h->us_b8, scap)); if (EXT) HIPCHK(h, dev_malloc(&h->us_pkt, 4 * scap)); h->us_cap = scap;
 	}
 	HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
 	HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
@@ -1253,7 +1282,7 @@ template <int W> int binned_buckets_t(kmr_handle *h, uint64_t wslots, uint64_t w
 	auto scratch = [&](uint64_t entries) -> int {      /* h->ue2: the other side of the partition's ping-pong */
 		if (h->ue2 && h->ue2_cap >= entries) return 0;
 		if (h->ue2) hipFree(h->ue2); h->ue2 = nullptr; h->ue2_cap = 0;
-		HIPCHK(h, hipMalloc((void **)&h->ue2, 8ull * (W + 1) * entries)); h->ue2_cap = entries;
+		HIPCHK(h, dev_malloc((void **)&h->ue2, 8ull * (W + 1) * entries)); h->ue2_cap = entries;
 		return 0;
 	};
 	auto group_launch = [&](const uint64_t *entries, const uint64_t *gs, const uint32_t *gc) -> int {
@@ -1325,7 +1354,7 @@ template <int W> int finish_maps_t(kmr_handle *h, uint32_t *wc, uint32_t *sc, ui
 			if (!h->uw_keys || h->uw_cap < wslots) {
 				if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
 				const uint64_t cap = std::max<uint64_t>(wslots, 16);
-				HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * cap)); HIPCHK(h, hipMalloc(&h->uw_vals, 12ull * cap)); h->uw_cap = cap;
+				HIPCHK(h, dev_malloc(&h->uw_keys, 8ull * W * cap)); HIPCHK(h, dev_malloc(&h->uw_vals, 12ull * cap)); h->uw_cap = cap;
 			}
 			HIPCHK(h, hipMemsetAsync(wc, 0, 4 * wm.nb, h->stream));
 			if (wslots) hipLaunchKernelGGL(bb_unpack_kernel<W>, dim3(grid_for(wslots)), dim3(256), 0, h->stream, (const uint64_t *)h->ue, wslots, h->hkb, wm.nb, (uint64_t *)h->uw_keys, (uint32_t *)h->uw_vals, wc);
@@ -1453,7 +1482,7 @@ int sk_uniform_weight(kmr_handle *h, const ReadsView &rv, bool &lean, float &wK)
 		lean = true; wK = (float)h->hPk[q0];
 		return 0;
 	}
-	if (!h->qrange) HIPCHK(h, hipMalloc((void **)&h->qrange, 8));
+	if (!h->qrange) HIPCHK(h, dev_malloc((void **)&h->qrange, 8));
 	const unsigned int init[2] = {255u, 0u};
 	HIPCHK(h, hipMemcpyAsync(h->qrange, init, 8, hipMemcpyHostToDevice, h->stream));
 	hipLaunchKernelGGL(sk_qual_range_kernel, dim3(num_cus(h) * 8), dim3(256), 0, h->stream, rv.quals, rv.offsets, rv.n_reads, h->qrange);
@@ -1521,7 +1550,7 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 			if (nlists > 64 && (nlists < (1ull << bits) || h->tune.list_aim) && nlists < (1ull << 31)) h->sk_bits = (uint32_t)nlists;
 		}
 		const uint64_t nl0 = sk_list_count(h->sk_bits);
-		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8 * nl0));
+		HIPCHK(h, dev_malloc((void **)&h->sk_state, 8 * nl0));
 		hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(nl0)), dim3(256), 0, h->stream, h->sk_state, nl0);
 		HIPCHK(h, hipGetLastError());
 	}
@@ -1532,7 +1561,7 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		h->trk_n = 0;
 		if (n > h->trk_cap) {
 			if (h->trk) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->trk); h->trk = nullptr; h->trk_cap = 0; }
-			HIPCHK(h, hipMalloc((void **)&h->trk, n * sizeof(SkTrackRec))); h->trk_cap = n;
+			HIPCHK(h, dev_malloc((void **)&h->trk, n * sizeof(SkTrackRec))); h->trk_cap = n;
 		}
 		HIPCHK(h, hipMemsetAsync(h->trk, 0, n * sizeof(SkTrackRec), h->stream));
 	}
@@ -1599,7 +1628,7 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		if (h->trk_bounds.size() + bd.size() > SK_TRACK_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "size tracker: more than 512 elements");
 		if (!bd.empty() && walkable) {
 			SkBoundary *dbd = nullptr;
-			HIPCHK(h, hipMalloc((void **)&dbd, bd.size() * sizeof(SkBoundary)));
+			HIPCHK(h, dev_malloc((void **)&dbd, bd.size() * sizeof(SkBoundary)));
 			hipError_t e = hipMemcpyAsync(dbd, bd.data(), bd.size() * sizeof(SkBoundary), hipMemcpyHostToDevice, h->stream);
 			if (e == hipSuccess) {
 				ReadsView rv = rvAll; rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
@@ -1629,8 +1658,8 @@ template <int W> int saturated_fix_t(kmr_handle *h, const uint64_t *ls, const ui
 	unsigned long long *dfound = nullptr; uint64_t *d_entry = nullptr; uint32_t *d_list = nullptr;
 	std::vector<void *> owned;
 	auto release = [&]() { for (void *p : owned) hipFree(p); owned.clear(); };
-#define SATCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { release(); h->err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
-	auto dalloc = [&](void **p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256)); if (e == hipSuccess) owned.push_back(*p); return e; };
+#define SATCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { release(); h->err = std::string(#call) + ": " + hip_err_text(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+	auto dalloc = [&](void **p, size_t bytes) -> hipError_t { hipError_t e = dev_malloc(p, std::max<size_t>(bytes, 256)); if (e == hipSuccess) owned.push_back(*p); return e; };
 	SATCHK(dalloc((void **)&dfound, 8));
 	uint64_t cap = std::min<uint64_t>(wm.n, 4 * n_clamped + 1024);
 	unsigned long long found = 0;
@@ -1723,7 +1752,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		if (h->sk_fine_cap < nlf) {
 			if (h->sk_fine_state) hipFree(h->sk_fine_state);
 			h->sk_fine_state = nullptr; h->sk_fine_cap = 0;
-			HIPCHK(h, hipMalloc((void **)&h->sk_fine_state, 8 * nlf)); h->sk_fine_cap = nlf;
+			HIPCHK(h, dev_malloc((void **)&h->sk_fine_state, 8 * nlf)); h->sk_fine_cap = nlf;
 		}
 		hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(nlf)), dim3(256), 0, h->stream, h->sk_fine_state, nlf);
 		const int rgrid = (int)std::min<uint64_t>(((uint64_t)head + SK_REFINE_WAVES - 1) / SK_REFINE_WAVES + 1, (uint64_t)num_cus(h) * 8);
@@ -1800,15 +1829,15 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	for (int attempt = 0; ; attempt++) {
 		if (!ext && (!h->ue || h->ue_cap < wcap)) {
 			if (h->ue) hipFree(h->ue); h->ue = nullptr; h->ue_cap = 0;
-			HIPCHK(h, hipMalloc((void **)&h->ue, 8ull * (W + 1) * wcap)); h->ue_cap = wcap;
+			HIPCHK(h, dev_malloc((void **)&h->ue, 8ull * (W + 1) * wcap)); h->ue_cap = wcap;
 		}
 		if (ext && (!h->uw_keys || h->uw_cap < wcap)) {
 			if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); h->uw_keys = h->uw_vals = nullptr; h->uw_cap = 0;
-			HIPCHK(h, hipMalloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, hipMalloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
+			HIPCHK(h, dev_malloc(&h->uw_keys, 8ull * W * wcap)); HIPCHK(h, dev_malloc(&h->uw_vals, 4ull * vw * wcap)); h->uw_cap = wcap;
 		}
 		if (!h->us_keys || h->us_cap < scap || (ext && !h->us_pkt)) {
 			if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt); h->us_keys = h->us_b8 = h->us_pkt = nullptr; h->us_cap = 0;
-			HIPCHK(h, hipMalloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, hipMalloc(&h->us_b8, scap)); if (ext) HIPCHK(h, hipMalloc(&h->us_pkt, 4 * scap)); h->us_cap = scap;
+			HIPCHK(h, dev_malloc(&h->us_keys, 8ull * W * scap)); HIPCHK(h, dev_malloc(&h->us_b8, scap)); if (ext) HIPCHK(h, dev_malloc(&h->us_pkt, 4 * scap)); h->us_cap = scap;
 		}
 		HIPCHK(h, hipMemsetAsync(wc, 0, 4 * h->nb_weak, h->stream)); HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
 		HIPCHK(h, hipMemsetAsync(fc, 0, sizeof(FinalizeCounters), h->stream)); HIPCHK(h, hipMemsetAsync(cursors, 0, 16, h->stream));
@@ -1829,8 +1858,8 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		if (n_items) {
 			/* the merge table holds the distinct keys of the long lists: few when a list is long because a k-mer repeats, at most the
 			 * k-mers of those lists; it starts small and the attempt is repeated with a larger one if it fills */
-			if (hipMalloc((void **)&mslots, sizeof(Slot<W>) << merge_log2) != hipSuccess) return fail(h, KMR_ERR_OOM, "merge table of the long lists");
-			if (ext && hipMalloc((void **)&mext, sizeof(ExtSlot) << merge_log2) != hipSuccess) { hipFree(mslots); return fail(h, KMR_ERR_OOM, "merge table of the long lists"); }
+			if (dev_malloc((void **)&mslots, sizeof(Slot<W>) << merge_log2) != hipSuccess) return fail(h, KMR_ERR_OOM, "merge table of the long lists");
+			if (ext && dev_malloc((void **)&mext, sizeof(ExtSlot) << merge_log2) != hipSuccess) { hipFree(mslots); return fail(h, KMR_ERR_OOM, "merge table of the long lists"); }
 			hipLaunchKernelGGL(table_clear_kernel<W>, dim3(grid_for(1ull << merge_log2)), dim3(256), 0, h->stream, mslots, mext, 1ull << merge_log2);
 			lgItems.merge.slots = mslots; lgItems.merge.ext = mext; lgItems.merge.log2cap = merge_log2;
 			HIPCHK(h, hipMemsetAsync(lgItems.merge_used, 0, 8, h->stream));
@@ -1908,6 +1937,7 @@ void free_partition_state(kmr_handle *h) {
 	h->tb_bases = h->tb_quals = nullptr; h->tb_rel = h->tb_off = nullptr; h->tb_len = nullptr; h->tb_bases_cap = h->tb_quals_cap = h->tb_quals_filled = h->tb_n = 0; h->tb_quals_char = -1;
 	h->ucnt = nullptr; h->ufirst = nullptr; h->u_start = h->u_end = h->u_read = nullptr; h->umax = nullptr; h->ucnt_n = h->ufirst_n = h->units_n = 0;
 	if (h->uw_keys) hipFree(h->uw_keys); if (h->uw_vals) hipFree(h->uw_vals); if (h->us_keys) hipFree(h->us_keys); if (h->us_b8) hipFree(h->us_b8); if (h->us_pkt) hipFree(h->us_pkt);
+	if (h->ue) hipFree(h->ue); if (h->ue2) hipFree(h->ue2); h->ue = h->ue2 = nullptr; h->ue_cap = h->ue2_cap = 0;
 	h->us_pkt = nullptr; h->work_counter = nullptr; h->linear = nullptr; h->tile_count = nullptr; h->kcap = nullptr; h->koff = nullptr;
 	h->uw_keys = h->uw_vals = h->us_keys = h->us_b8 = nullptr; h->linear_cap = h->tile_cap = h->kcap_n = h->koff_n = h->uw_cap = h->us_cap = 0;
 }
@@ -1970,7 +2000,7 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 		uint32_t lg = 16; while ((1ull << lg) < want && lg < 40) lg++;
 		h->log2cap = lg;
 		double P[256]; quality_table(P, cfg->min_quality_score, cfg->fastq_start_char);
-		if (hipMalloc((void **)&h->dP, sizeof(P)) != hipSuccess || hipMalloc((void **)&h->dstats, sizeof(DevStats)) != hipSuccess || hipMalloc((void **)&h->derr, 4) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
+		if (dev_malloc((void **)&h->dP, sizeof(P)) != hipSuccess || dev_malloc((void **)&h->dstats, sizeof(DevStats)) != hipSuccess || dev_malloc((void **)&h->derr, 4) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
 		hipMemcpy(h->dP, P, sizeof(P), hipMemcpyHostToDevice); hipMemset(h->dstats, 0, sizeof(DevStats)); hipMemset(h->derr, 0, 4);
 		/* build_mode: 0 auto (streaming partition path unless EXT values), 1 table, 2 partition */
 		if (cfg->build_mode > 3) { rc = fail(nullptr, KMR_ERR_INVALID_ARG, "bad build_mode"); break; }
@@ -1989,7 +2019,7 @@ int kmr_create(const kmr_config *cfg, kmr_handle **out) {
 			double Pk[256];
 			for (int cidx = 0; cidx < 256; cidx++) { double wv = 1.0; for (uint32_t jj = 0; jj < h->k; jj++) wv *= P[cidx]; Pk[cidx] = wv; }      /* the loop of buildWeightedKmers, src/KmerReadUtils.h:205-208 */
 			memcpy(h->hPk, Pk, sizeof(Pk)); memcpy(h->hP, P, sizeof(h->hP));
-			if (hipMalloc((void **)&h->dPk, 2 * sizeof(Pk)) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
+			if (dev_malloc((void **)&h->dPk, 2 * sizeof(Pk)) != hipSuccess) { rc = fail(nullptr, KMR_ERR_OOM, "hipMalloc failed"); break; }
 			hipMemcpy(h->dPk, Pk, sizeof(Pk), hipMemcpyHostToDevice);
 			/* reciprocals for the chain's divide, usable only if multiply-and-correct reproduces the correctly rounded quotient of every
 			 * pair of table entries (all 256 x 256 are tried; the kernel divides otherwise) */
@@ -2156,7 +2186,7 @@ static hipError_t tb_stage_copy(kmr_handle *h, int set, int which, const void *s
 	uint8_t *&buf = h->tb_stage[set][which]; size_t &cap = h->tb_stage_cap[set][which];
 	if (cap < bytes + 64) {
 		if (buf) { hipError_t e0 = hipStreamSynchronize(h->stream); if (e0 != hipSuccess) return e0; hipFree(buf); buf = nullptr; cap = 0; }
-		hipError_t e = hipMalloc((void **)&buf, bytes + bytes / 8 + 4096); if (e != hipSuccess) return e;
+		hipError_t e = dev_malloc((void **)&buf, bytes + bytes / 8 + 4096); if (e != hipSuccess) return e;
 		cap = bytes + bytes / 8 + 4096 - 64;
 	}
 	*dst = buf;
@@ -2180,7 +2210,7 @@ int kmr_add_reads(kmr_handle *h, const char *bases, const char *quals, const uin
 	 * device extracts piece i; the offsets go over as they are (the device arrays are addressed through pointers moved back by the
 	 * piece's first offset) */
 	{ int rcp = tb_pipeline_ready(h); if (rcp) return rcp; }
-#define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->tb_copy_stream); hipStreamSynchronize(h->stream); h->err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+#define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->tb_copy_stream); hipStreamSynchronize(h->stream); h->err = std::string(#call) + ": " + hip_err_text(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
 	const uint64_t piece_bases = h->tune.twobit_piece_bases ? h->tune.twobit_piece_bases : (1ull << 28);
 	int rc = KMR_OK; int set = 0;
 	for (uint64_t r0 = 0; r0 < n_reads && rc == KMR_OK; set ^= 1) {
@@ -2230,12 +2260,12 @@ int kmr_add_reads_twobit_dev(kmr_handle *h, const void *dev_twobit, const void *
 	const bool direct = sk_packed_direct_ok(h, dev_quals != nullptr, uniform_quality);
 	if (!direct && h->tb_bases_cap < total_bases + 64) {
 		if (h->tb_bases) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->tb_bases); h->tb_bases = nullptr; h->tb_bases_cap = 0; }
-		HIPCHK(h, hipMalloc((void **)&h->tb_bases, total_bases + 64)); h->tb_bases_cap = total_bases + 64;
+		HIPCHK(h, dev_malloc((void **)&h->tb_bases, total_bases + 64)); h->tb_bases_cap = total_bases + 64;
 		HIPCHK(h, hipMemsetAsync(h->tb_bases, 0, total_bases + 64, h->stream));
 	}
 	if (h->tb_n < n_reads + 1) {
 		if (h->tb_rel) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->tb_rel); hipFree(h->tb_off); hipFree(h->tb_len); h->tb_rel = h->tb_off = nullptr; h->tb_len = nullptr; h->tb_n = 0; }
-		HIPCHK(h, hipMalloc((void **)&h->tb_rel, 8 * (n_reads + 1))); HIPCHK(h, hipMalloc((void **)&h->tb_off, 8 * (n_reads + 1))); HIPCHK(h, hipMalloc((void **)&h->tb_len, 4 * (n_reads + 1)));
+		HIPCHK(h, dev_malloc((void **)&h->tb_rel, 8 * (n_reads + 1))); HIPCHK(h, dev_malloc((void **)&h->tb_off, 8 * (n_reads + 1))); HIPCHK(h, dev_malloc((void **)&h->tb_len, 4 * (n_reads + 1)));
 		h->tb_n = n_reads + 1;
 	}
 	const uint64_t *tboff = (const uint64_t *)dev_twobit_offsets;
@@ -2271,7 +2301,7 @@ int kmr_add_reads_twobit_dev(kmr_handle *h, const void *dev_twobit, const void *
 	if (!dev_quals && uniform_quality) {
 		if (h->tb_quals_cap < total_bases + 64) {
 			if (h->tb_quals) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->tb_quals); h->tb_quals = nullptr; h->tb_quals_cap = 0; }
-			HIPCHK(h, hipMalloc((void **)&h->tb_quals, total_bases + 64)); h->tb_quals_cap = total_bases + 64; h->tb_quals_filled = 0; h->tb_quals_char = -1;
+			HIPCHK(h, dev_malloc((void **)&h->tb_quals, total_bases + 64)); h->tb_quals_cap = total_bases + 64; h->tb_quals_filled = 0; h->tb_quals_char = -1;
 		}
 		if (h->tb_quals_char != uniform_quality || h->tb_quals_filled < total_bases) {      /* (a buffer the last call filled with the same character stands) */
 			HIPCHK(h, hipMemsetAsync(h->tb_quals, uniform_quality, h->tb_quals_cap, h->stream));
@@ -2299,7 +2329,7 @@ int kmr_add_reads_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *t
 	 * the copies, the device does not wait for it). */
 	{ int rcp = tb_pipeline_ready(h); if (rcp) return rcp; }
 	auto stage = [&](int set, int which, const void *src, size_t bytes, void **dst) -> hipError_t { return tb_stage_copy(h, set, which, src, bytes, dst); };
-#define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->tb_copy_stream); hipStreamSynchronize(h->stream); h->err = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
+#define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->tb_copy_stream); hipStreamSynchronize(h->stream); h->err = std::string(#call) + ": " + hip_err_text(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
 	const uint64_t piece_bases = h->tune.twobit_piece_bases ? h->tune.twobit_piece_bases : (1ull << 28);
 	int rc = KMR_OK; int set = 0;
 	for (uint64_t r0 = 0; r0 < n_reads && rc == KMR_OK; set ^= 1) {
@@ -2375,7 +2405,7 @@ int kmr_lookup_reads(kmr_handle *h, const char *bases, const uint64_t *offsets, 
 	uint64_t outN = 0;
 	for (uint64_t r = 0; r < n_reads; r++) { uint64_t L = offsets[r + 1] - offsets[r]; uint64_t nk = L >= h->k ? L - h->k + 1 : 0; outN = std::max(outN, out_offsets[r] + nk); }
 	uint32_t *dout; uint64_t *doff;
-	HIPCHK(h, hipMalloc((void **)&dout, std::max<uint64_t>(8, 4 * outN))); HIPCHK(h, hipMalloc((void **)&doff, 8 * n_reads));
+	HIPCHK(h, dev_malloc((void **)&dout, std::max<uint64_t>(8, 4 * outN))); HIPCHK(h, dev_malloc((void **)&doff, 8 * n_reads));
 	HIPCHK(h, hipMemsetAsync(dout, 0, 4 * outN, h->stream));
 	HIPCHK(h, hipMemcpyAsync(doff, out_offsets, 8 * n_reads, hipMemcpyHostToDevice, h->stream));
 	ReadsView rv; rv.bases = s.b; rv.quals = nullptr; rv.offsets = s.o; rv.discarded = nullptr; rv.n_reads = n_reads; rv.stream_base = 0; rv.first_read_idx = 0; rv.u_start = rv.u_end = rv.u_read = nullptr; rv.n_units = 0;
@@ -2399,10 +2429,10 @@ template <int W> int sk_index_t(kmr_handle *h) {
 	if (h->ix_gen == h->map_gen && h->ix_start) return 0;
 	const uint64_t nl = sk_list_count(h->sk_bits), n = h->weak.n;
 	const uint32_t vw = h->ext ? 15 : 3;
-	if (h->ix_lists != nl) { if (h->ix_start) hipFree(h->ix_start); h->ix_start = nullptr; HIPCHK(h, hipMalloc((void **)&h->ix_start, 8 * (nl + 1))); h->ix_lists = nl; }
+	if (h->ix_lists != nl) { if (h->ix_start) hipFree(h->ix_start); h->ix_start = nullptr; HIPCHK(h, dev_malloc((void **)&h->ix_start, 8 * (nl + 1))); h->ix_lists = nl; }
 	if (h->ix_cap < n) {
 		if (h->ix_keys) hipFree(h->ix_keys); if (h->ix_counts) hipFree(h->ix_counts); h->ix_keys = nullptr; h->ix_counts = nullptr; h->ix_cap = 0;
-		HIPCHK(h, hipMalloc((void **)&h->ix_keys, 8ull * W * n)); HIPCHK(h, hipMalloc((void **)&h->ix_counts, 4 * n)); h->ix_cap = n;
+		HIPCHK(h, dev_malloc((void **)&h->ix_keys, 8ull * W * n)); HIPCHK(h, dev_malloc((void **)&h->ix_counts, 4 * n)); h->ix_cap = n;
 	}
 	uint32_t *elist = nullptr, *hist = nullptr;
 	int rc = arena_get(h, &elist, n); if (rc) return rc;
@@ -2422,9 +2452,9 @@ template <int W> int lookup_stream_t(kmr_handle *h, const ReadsView &rvAll, uint
 	if (!h->sk_state) {      /* a handle that was not built on the lists (loaded image, other build mode): lists sized for this batch */
 		uint32_t bits = 6; while (bits < 24 && (total_bases >> bits) > h->tune.target_list / 2 + 200) bits++;
 		h->sk_bits = bits;
-		HIPCHK(h, hipMalloc((void **)&h->sk_state, 8ull << bits));
+		HIPCHK(h, dev_malloc((void **)&h->sk_state, 8ull << bits));
 	}
-	if (!h->scratch_stats) HIPCHK(h, hipMalloc((void **)&h->scratch_stats, sizeof(DevStats)));
+	if (!h->scratch_stats) HIPCHK(h, dev_malloc((void **)&h->scratch_stats, sizeof(DevStats)));
 	rc = sk_index_t<W>(h); if (rc) return rc;
 	const uint64_t nl = sk_list_count(h->sk_bits);
 	hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl);
@@ -2493,7 +2523,7 @@ static int score_reads_core(kmr_handle *h, const uint8_t *s_b, const uint64_t *s
 	const size_t fixed = al(4 * (n_reads + 1)) + al(8 * (n_reads + 1)) + 3 * al(4 * n_reads) + al(n_reads);
 	if (h->score_buf_bytes < fixed) {
 		if (h->score_buf) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->score_buf); h->score_buf = nullptr; h->score_buf_bytes = 0; }
-		HIPCHK(h, hipMalloc((void **)&h->score_buf, fixed + fixed / 4)); h->score_buf_bytes = fixed + fixed / 4;
+		HIPCHK(h, dev_malloc((void **)&h->score_buf, fixed + fixed / 4)); h->score_buf_bytes = fixed + fixed / 4;
 	}
 	uint8_t *p = h->score_buf;
 	uint32_t *dkc = (uint32_t *)p; p += al(4 * (n_reads + 1));
@@ -2512,7 +2542,7 @@ static int score_reads_core(kmr_handle *h, const uint8_t *s_b, const uint64_t *s
 	}
 	const size_t need = fixed + al(std::max<uint64_t>(8, 4 * outN));
 	if (h->score_buf_bytes < need) {         /* grow, keeping the scan */
-		uint8_t *nbuf; HIPCHK(h, hipMalloc((void **)&nbuf, need + need / 8));
+		uint8_t *nbuf; HIPCHK(h, dev_malloc((void **)&nbuf, need + need / 8));
 		HIPCHK(h, hipMemcpy(nbuf, h->score_buf, al(4 * (n_reads + 1)) + al(8 * (n_reads + 1)), hipMemcpyDeviceToDevice));
 		HIPCHK(h, hipDeviceSynchronize());
 		hipFree(h->score_buf); h->score_buf = nbuf; h->score_buf_bytes = need + need / 8;
@@ -2628,8 +2658,8 @@ int kmr_count_histogram(kmr_handle *h, uint64_t *counts, double *weights, uint32
 	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_count_histogram before kmr_finalize");
 	hipSetDevice(h->device);
 	unsigned long long *dc; double *dw = nullptr;
-	HIPCHK(h, hipMalloc((void **)&dc, 8 * n_bins)); HIPCHK(h, hipMemsetAsync(dc, 0, 8 * n_bins, h->stream));
-	if (weights) { HIPCHK(h, hipMalloc((void **)&dw, 8 * n_bins)); HIPCHK(h, hipMemsetAsync(dw, 0, 8 * n_bins, h->stream)); }
+	HIPCHK(h, dev_malloc((void **)&dc, 8 * n_bins)); HIPCHK(h, hipMemsetAsync(dc, 0, 8 * n_bins, h->stream));
+	if (weights) { HIPCHK(h, dev_malloc((void **)&dw, 8 * n_bins)); HIPCHK(h, hipMemsetAsync(dw, 0, 8 * n_bins, h->stream)); }
 	if (h->weak.present && h->weak.n)
 		hipLaunchKernelGGL(histogram_kernel, dim3(grid_for(h->weak.n)), dim3(256), 0, h->stream, h->weak.vals, h->ext ? 15u : 3u, h->weak.n, n_bins, dc, dw);
 	HIPCHK(h, hipGetLastError());
@@ -2638,6 +2668,46 @@ int kmr_count_histogram(kmr_handle *h, uint64_t *counts, double *weights, uint32
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	hipFree(dc); if (dw) hipFree(dw);
 	return KMR_OK;
+}
+
+/* Order-independent digest of a finalized map (see kmr_synth.hpp): what a full-size build is compared by, and what the ranks or
+ * parts of a partitioned build add up to. */
+int kmr_map_digest(kmr_handle *h, int which_map, kmr_digest *out) {
+	if (!h || !out) return KMR_ERR_INVALID_ARG;
+	if (!h->finalized) return fail(h, KMR_ERR_STATE, "kmr_map_digest before kmr_finalize");
+	if (which_map != KMR_MAP_WEAK && which_map != KMR_MAP_SINGLETON) return fail(h, KMR_ERR_UNSUPPORTED, "no such map");
+	static_assert(sizeof(kmr_digest) == sizeof(synth::Digest), "kmr_digest layout");
+	hipSetDevice(h->device);
+	memset(out, 0, sizeof(*out));
+	const DevMap &m = which_map == KMR_MAP_WEAK ? h->weak : h->sing;
+	if (which_map == KMR_MAP_SINGLETON && !h->has_singletons) return KMR_OK;
+	if (!m.present || !m.n) return KMR_OK;
+	synth::Digest *d;
+	HIPCHK(h, dev_malloc((void **)&d, sizeof(synth::Digest))); HIPCHK(h, hipMemsetAsync(d, 0, sizeof(synth::Digest), h->stream));
+	if (which_map == KMR_MAP_WEAK)
+		hipLaunchKernelGGL(synth::map_digest_kernel, dim3(grid_for(m.n, 256, 4096)), dim3(256), 0, h->stream, m.keys, (uint32_t)h->W, m.vals, h->ext ? 15u : 3u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, m.n, d);
+	else
+		hipLaunchKernelGGL(synth::map_digest_kernel, dim3(grid_for(m.n, 256, 4096)), dim3(256), 0, h->stream, m.keys, (uint32_t)h->W, (const uint32_t *)nullptr, 0u, m.sweight, h->ext ? m.spkt : (const uint32_t *)nullptr, m.n, d);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipMemcpyAsync(out, d, sizeof(synth::Digest), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	hipFree(d);
+	out->entries = m.n;
+	return KMR_OK;
+}
+
+/* SURVEY.md section 8(d)'s synthetic reads, written into caller-owned device memory on the current device (kmr_synth.hpp holds
+ * the definition of the generator): reads first_read .. first_read + n_reads of the job `seed`, read_len bases each. */
+int kmr_synth_reads_dev(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, uint32_t noisy_quals,
+                        void *dev_bases, void *dev_quals, uint64_t *dev_offsets) {
+	if (!dev_bases || read_len == 0 || genome_len < read_len) return KMR_ERR_INVALID_ARG;
+	if (n_reads == 0 && !dev_offsets) return KMR_OK;
+	const uint64_t blocks = (n_reads + 1 + 255) / 256;
+	if (blocks > 0x7fffffffull) return KMR_ERR_CAPACITY;
+	hipLaunchKernelGGL(synth::synth_reads_kernel, dim3((uint32_t)blocks), dim3(256), 0, 0, seed, first_read, n_reads, read_len, genome_len, noisy_quals,
+	                   (uint8_t *)dev_bases, (uint8_t *)dev_quals, dev_offsets);
+	if (hipGetLastError() != hipSuccess) return KMR_ERR_HIP;
+	return hipStreamSynchronize(0) == hipSuccess ? KMR_OK : KMR_ERR_HIP;
 }
 
 /* KmerSpectrum::subtractReference (src/KmerSpectrum.h:472-474; apps/FilterReads-P.cpp:117): k-mers that exist in the finalized
@@ -2697,7 +2767,7 @@ int kmr_histogram(kmr_handle *h, uint32_t zoom_max, double log_base, uint64_t *v
 	const unsigned int zoomLogSkip = (unsigned int)(log((double)zoom_max + 1.0) / logFactor - 1.0);
 	for (uint32_t c = 1; c < 65536; c++) lut[c] = c <= zoom_max ? c : (unsigned int)(log((double)c) / logFactor - zoomLogSkip + zoom_max);
 	uint32_t *dl; unsigned long long *dv, *dc; double *dw;
-	HIPCHK(h, hipMalloc((void **)&dl, 4 * 65536)); HIPCHK(h, hipMalloc((void **)&dv, 8ull * nb)); HIPCHK(h, hipMalloc((void **)&dc, 8ull * nb)); HIPCHK(h, hipMalloc((void **)&dw, 8ull * nb));
+	HIPCHK(h, dev_malloc((void **)&dl, 4 * 65536)); HIPCHK(h, dev_malloc((void **)&dv, 8ull * nb)); HIPCHK(h, dev_malloc((void **)&dc, 8ull * nb)); HIPCHK(h, dev_malloc((void **)&dw, 8ull * nb));
 	HIPCHK(h, hipMemcpyAsync(dl, lut.data(), 4 * 65536, hipMemcpyHostToDevice, h->stream));
 	HIPCHK(h, hipMemsetAsync(dv, 0, 8ull * nb, h->stream)); HIPCHK(h, hipMemsetAsync(dc, 0, 8ull * nb, h->stream)); HIPCHK(h, hipMemsetAsync(dw, 0, 8ull * nb, h->stream));
 	if (h->weak.present && h->weak.n)
@@ -2760,15 +2830,15 @@ static int ingest_dev(kmr_handle *h, const uint8_t *text, uint64_t len, uint32_t
 	uint32_t *blk = nullptr, *derr = nullptr, *llen = nullptr, *keep = nullptr, *klen = nullptr;
 	uint64_t *bbase = nullptr, *lstart = nullptr, *kidx = nullptr, *boff = nullptr;
 	auto cleanup = [&]() { hipFree(blk); hipFree(derr); hipFree(llen); hipFree(keep); hipFree(klen); hipFree(bbase); hipFree(lstart); hipFree(kidx); hipFree(boff); };
-#define ING(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); kmr_reads_free(R); \
+#define ING(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hip_err_text(e_); cleanup(); kmr_reads_free(R); \
 	return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
 #define INGRC(expr) do { int rc_ = (expr); if (rc_) { cleanup(); kmr_reads_free(R); return rc_; } } while (0)
 	const uint64_t nblk = (len + (uint64_t)ING_THREADS * ING_BYTES - 1) / ((uint64_t)ING_THREADS * ING_BYTES);
 	uint64_t n_lines = 0;
-	ING(hipMalloc((void **)&derr, 8)); ING(hipMemsetAsync(derr, 0, 8, h->stream));
+	ING(dev_malloc((void **)&derr, 8)); ING(hipMemsetAsync(derr, 0, 8, h->stream));
 	if (nblk) {
 		if (nblk > 0x7fffffffull) { cleanup(); kmr_reads_free(R); return fail(h, KMR_ERR_INVALID_ARG, "FASTQ block too large for one call"); }
-		ING(hipMalloc((void **)&blk, 4 * nblk)); ING(hipMalloc((void **)&bbase, 8 * (nblk + 1)));
+		ING(dev_malloc((void **)&blk, 4 * nblk)); ING(dev_malloc((void **)&bbase, 8 * (nblk + 1)));
 		hipLaunchKernelGGL(ingest_count_lines, dim3((unsigned)nblk), dim3(ING_THREADS), 0, h->stream, text, len, blk);
 		ING(hipGetLastError());
 		INGRC(exclusive_scan(h, blk, nblk, bbase));
@@ -2778,11 +2848,11 @@ static int ingest_dev(kmr_handle *h, const uint8_t *text, uint64_t len, uint32_t
 	const uint64_t nrec = n_lines / 4;
 	uint64_t n_kept = 0, total = 0;
 	if (nrec) {
-		ING(hipMalloc((void **)&lstart, 8 * n_lines)); ING(hipMalloc((void **)&llen, 4 * n_lines));
+		ING(dev_malloc((void **)&lstart, 8 * n_lines)); ING(dev_malloc((void **)&llen, 4 * n_lines));
 		hipLaunchKernelGGL(ingest_index_lines, dim3((unsigned)nblk), dim3(ING_THREADS), 0, h->stream, text, len, bbase, lstart);
 		hipLaunchKernelGGL(ingest_line_lengths, dim3(grid_for(n_lines)), dim3(256), 0, h->stream, text, len, lstart, n_lines, llen, derr);
-		ING(hipMalloc((void **)&keep, 4 * nrec)); ING(hipMalloc((void **)&klen, 4 * nrec));
-		ING(hipMalloc((void **)&kidx, 8 * (nrec + 1))); ING(hipMalloc((void **)&boff, 8 * (nrec + 1)));
+		ING(dev_malloc((void **)&keep, 4 * nrec)); ING(dev_malloc((void **)&klen, 4 * nrec));
+		ING(dev_malloc((void **)&kidx, 8 * (nrec + 1))); ING(dev_malloc((void **)&boff, 8 * (nrec + 1)));
 		hipLaunchKernelGGL(ingest_records, dim3(grid_for(nrec)), dim3(256), 0, h->stream, text, lstart, llen, nrec, store_comment, keep, klen, derr);
 		ING(hipGetLastError());
 		INGRC(exclusive_scan(h, keep, nrec, kidx));
@@ -2801,8 +2871,8 @@ static int ingest_dev(kmr_handle *h, const uint8_t *text, uint64_t len, uint32_t
 		ING(hipMemcpy(&n_kept, kidx + nrec, 8, hipMemcpyDeviceToHost)); ING(hipMemcpy(&total, boff + nrec, 8, hipMemcpyDeviceToHost));
 	}
 	R->n = n_kept; R->total = total; R->filtered = nrec - n_kept;
-	ING(hipMalloc((void **)&R->bases, total + 64)); ING(hipMalloc((void **)&R->quals, total + 64)); ING(hipMalloc((void **)&R->offsets, 8 * (n_kept + 1)));
-	ING(hipMalloc((void **)&R->name_off, 8 * std::max<uint64_t>(1, n_kept))); ING(hipMalloc((void **)&R->name_len, 4 * std::max<uint64_t>(1, n_kept)));
+	ING(dev_malloc((void **)&R->bases, total + 64)); ING(dev_malloc((void **)&R->quals, total + 64)); ING(dev_malloc((void **)&R->offsets, 8 * (n_kept + 1)));
+	ING(dev_malloc((void **)&R->name_off, 8 * std::max<uint64_t>(1, n_kept))); ING(dev_malloc((void **)&R->name_len, 4 * std::max<uint64_t>(1, n_kept)));
 	ING(hipMemsetAsync(R->bases + total, 0, 64, h->stream)); ING(hipMemsetAsync(R->quals + total, 0, 64, h->stream));
 	ING(hipMemcpyAsync(R->offsets + n_kept, &total, 8, hipMemcpyHostToDevice, h->stream));
 	if (nrec) {
@@ -2838,7 +2908,7 @@ int kmr_ingest_fastq(kmr_handle *h, const char *text, uint64_t len, uint32_t inp
 	*out = nullptr;
 	hipSetDevice(h->device);
 	uint8_t *d = nullptr;
-	HIPCHK(h, hipMalloc((void **)&d, len + 16));
+	HIPCHK(h, dev_malloc((void **)&d, len + 16));
 	hipError_t e = hipMemcpy(d, text, len, hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(d); h->err = std::string("hipMemcpy(FASTQ text): ") + hipGetErrorString(e); return KMR_ERR_HIP; }
 	const int rc = ingest_dev(h, d, len, input_quality_base, store_comment, out);
@@ -2853,9 +2923,9 @@ int kmr_reads_from_host(kmr_handle *h, const char *bases, const char *quals, con
 	const uint64_t first = offsets[0], total = offsets[n_reads] - first;
 	std::unique_ptr<kmr_reads, void (*)(kmr_reads *)> r(new kmr_reads, kmr_reads_free);
 	r->device = h->device; r->n = n_reads; r->total = total; r->input_base = h->cfg.fastq_start_char;
-	HIPCHK(h, hipMalloc((void **)&r->bases, total + 64)); HIPCHK(h, hipMalloc((void **)&r->quals, total + 64));
-	HIPCHK(h, hipMalloc((void **)&r->offsets, 8 * (n_reads + 1)));
-	HIPCHK(h, hipMalloc((void **)&r->name_off, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, hipMalloc((void **)&r->name_len, 4 * std::max<uint64_t>(n_reads, 1)));
+	HIPCHK(h, dev_malloc((void **)&r->bases, total + 64)); HIPCHK(h, dev_malloc((void **)&r->quals, total + 64));
+	HIPCHK(h, dev_malloc((void **)&r->offsets, 8 * (n_reads + 1)));
+	HIPCHK(h, dev_malloc((void **)&r->name_off, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, dev_malloc((void **)&r->name_len, 4 * std::max<uint64_t>(n_reads, 1)));
 	HIPCHK(h, hipMemset(r->bases + total, 0, 64)); HIPCHK(h, hipMemset(r->quals + total, 0, 64));
 	HIPCHK(h, hipMemset(r->name_off, 0, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, hipMemset(r->name_len, 0, 4 * std::max<uint64_t>(n_reads, 1)));
 	if (total) { HIPCHK(h, hipMemcpy(r->bases, bases + first, total, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(r->quals, quals + first, total, hipMemcpyHostToDevice)); }
@@ -2922,7 +2992,7 @@ uint32_t art_log2cap(uint64_t n) { uint32_t l = 10; while ((1ull << l) < 2 * n +
 struct ArtBuf {          /* device scratch of one call, released on every exit path */
 	std::vector<void *> p;
 	~ArtBuf() { for (void *q : p) if (q) hipFree(q); }
-	template <typename T> hipError_t get(T **out, size_t n) { void *q = nullptr; hipError_t e = hipMalloc(&q, std::max<size_t>(sizeof(T) * n, 256)); if (e == hipSuccess) p.push_back(q); *out = (T *)q; return e; }
+	template <typename T> hipError_t get(T **out, size_t n) { void *q = nullptr; hipError_t e = dev_malloc(&q, std::max<size_t>(sizeof(T) * n, 256)); if (e == hipSuccess) p.push_back(q); *out = (T *)q; return e; }
 };
 
 uint64_t art_pack(const char *s, uint32_t len) {      /* TwoBitSequence::compressSequence: anything but ACGT packs as A */
@@ -2938,8 +3008,8 @@ int art_upload(kmr_handle *h, kmr_artifact_filter *f) {
 	f->n_keys = f->keys.size();
 	f->log2cap = art_log2cap(f->n_keys);
 	const uint64_t cap = 1ull << f->log2cap;
-	HIPCHK(h, hipMalloc((void **)&f->d_keys, 8 * cap)); HIPCHK(h, hipMalloc((void **)&f->d_vals, 4 * cap));
-	if (!f->d_bits) HIPCHK(h, hipMalloc((void **)&f->d_bits, (1u << ART_FILTER_LOG2) / 8));
+	HIPCHK(h, dev_malloc((void **)&f->d_keys, 8 * cap)); HIPCHK(h, dev_malloc((void **)&f->d_vals, 4 * cap));
+	if (!f->d_bits) HIPCHK(h, dev_malloc((void **)&f->d_bits, (1u << ART_FILTER_LOG2) / 8));
 	HIPCHK(h, hipMemsetAsync(f->d_bits, 0, (1u << ART_FILTER_LOG2) / 8, h->stream));
 	ArtBuf tmp; uint64_t *dk; uint32_t *dv;
 	HIPCHK(h, tmp.get(&dk, f->n_keys)); HIPCHK(h, tmp.get(&dv, f->n_keys));
@@ -3131,12 +3201,12 @@ int kmr_artifact_filter_apply(kmr_handle *h, const kmr_artifact_filter *f, const
 	const uint64_t n_out = n + n_rem;
 	std::unique_ptr<kmr_reads, void (*)(kmr_reads *)> r(new kmr_reads, kmr_reads_free);
 	r->device = h->device; r->n = n_out; r->input_base = in->input_base; r->filtered = in->filtered;
-	HIPCHK(h, hipMalloc((void **)&r->offsets, 8 * (n_out + 1)));
+	HIPCHK(h, dev_malloc((void **)&r->offsets, 8 * (n_out + 1)));
 	if (n_out) { int rc = exclusive_scan(h, dlen, n_out, r->offsets); if (rc) return rc; HIPCHK(h, hipMemcpy(&r->total, r->offsets + n_out, 8, hipMemcpyDeviceToHost)); }
 	else HIPCHK(h, hipMemset(r->offsets, 0, 8));
-	HIPCHK(h, hipMalloc((void **)&r->bases, r->total + 64)); HIPCHK(h, hipMalloc((void **)&r->quals, r->total + 64));
+	HIPCHK(h, dev_malloc((void **)&r->bases, r->total + 64)); HIPCHK(h, dev_malloc((void **)&r->quals, r->total + 64));
 	HIPCHK(h, hipMemsetAsync(r->bases + r->total, 0, 64, h->stream)); HIPCHK(h, hipMemsetAsync(r->quals + r->total, 0, 64, h->stream));
-	HIPCHK(h, hipMalloc((void **)&r->name_off, 8 * std::max<uint64_t>(n_out, 1))); HIPCHK(h, hipMalloc((void **)&r->name_len, 4 * std::max<uint64_t>(n_out, 1)));
+	HIPCHK(h, dev_malloc((void **)&r->name_off, 8 * std::max<uint64_t>(n_out, 1))); HIPCHK(h, dev_malloc((void **)&r->name_len, 4 * std::max<uint64_t>(n_out, 1)));
 	if (n_out) {
 		hipLaunchKernelGGL(artifact_gather, dim3((unsigned)std::min<uint64_t>((n_out + 3) / 4, 1u << 16)), dim3(256), 0, h->stream,
 		                   in->bases, in->quals, in->offsets, in->name_off, in->name_len, n, n_out, dact, dmin, dro, dsrc, r->offsets, r->bases, r->quals, r->name_off, r->name_len);
@@ -3196,9 +3266,9 @@ int kmr_reads_from_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *
 	const uint64_t nm = markup_offsets ? markup_offsets[n_reads] - markup_offsets[0] : 0;
 	std::unique_ptr<kmr_reads, void (*)(kmr_reads *)> r(new kmr_reads, kmr_reads_free);
 	r->device = h->device; r->n = n_reads; r->total = total; r->input_base = h->cfg.fastq_start_char;
-	HIPCHK(h, hipMalloc((void **)&r->bases, total + 64)); HIPCHK(h, hipMalloc((void **)&r->quals, total + 64));
-	HIPCHK(h, hipMalloc((void **)&r->offsets, 8 * (n_reads + 1)));
-	HIPCHK(h, hipMalloc((void **)&r->name_off, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, hipMalloc((void **)&r->name_len, 4 * std::max<uint64_t>(n_reads, 1)));
+	HIPCHK(h, dev_malloc((void **)&r->bases, total + 64)); HIPCHK(h, dev_malloc((void **)&r->quals, total + 64));
+	HIPCHK(h, dev_malloc((void **)&r->offsets, 8 * (n_reads + 1)));
+	HIPCHK(h, dev_malloc((void **)&r->name_off, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, dev_malloc((void **)&r->name_len, 4 * std::max<uint64_t>(n_reads, 1)));
 	HIPCHK(h, hipMemset(r->bases + total, 0, 64)); HIPCHK(h, hipMemset(r->quals + total, 0, 64));
 	HIPCHK(h, hipMemset(r->name_off, 0, 8 * std::max<uint64_t>(n_reads, 1))); HIPCHK(h, hipMemset(r->name_len, 0, 4 * std::max<uint64_t>(n_reads, 1)));
 	/* qualities: the array, the one character, or Read::REF_QUAL (a batch always has a quality array; REF_QUAL reads weigh 1) */
@@ -3346,7 +3416,7 @@ int kmr_score_counts_dev(kmr_handle *h, const void *dev_bases, const void *dev_o
 	if (n_reads == 0) return KMR_OK;
 	hipSetDevice(h->device);
 	uint32_t *dto, *dtl; float *dsc; uint8_t *dwt;
-	HIPCHK(h, hipMalloc((void **)&dto, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dtl, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dsc, 4 * n_reads)); HIPCHK(h, hipMalloc((void **)&dwt, n_reads));
+	HIPCHK(h, dev_malloc((void **)&dto, 4 * n_reads)); HIPCHK(h, dev_malloc((void **)&dtl, 4 * n_reads)); HIPCHK(h, dev_malloc((void **)&dsc, 4 * n_reads)); HIPCHK(h, dev_malloc((void **)&dwt, n_reads));
 	/* k-mer i of read r sits at position offsets[r] + i: the offsets are their own count offsets */
 	hipLaunchKernelGGL(score_reads_kernel, dim3((unsigned)std::min<uint64_t>(((n_reads + 63) / 64 + SC_WAVES - 1) / SC_WAVES, 1u << 16)), dim3(SC_WAVES * 64), 0, h->stream, (const uint8_t *)dev_bases, (const uint64_t *)dev_offsets, n_reads, h->k,
 	                   (const uint32_t *)dev_position_counts, (const uint64_t *)dev_offsets, (float)minimum_kmer_score, scoring_type, dto, dtl, dsc, dwt);
@@ -3397,13 +3467,13 @@ int kmr_extract_by_owner_host(kmr_handle *h, const kmr_reads *batch, uint64_t fi
 		if (h->xo_dev) { hipFree(h->xo_dev); h->xo_dev = nullptr; }
 		h->xo_counts.assign(world, 0); h->xo_batch = nullptr;
 		unsigned long long *dcounts = nullptr;
-		HIPCHK(h, hipMalloc((void **)&dcounts, 8 * world));
+		HIPCHK(h, dev_malloc((void **)&dcounts, 8 * world));
 		const uint64_t upper = batch->total + 64;          /* k-mers <= bases */
 		uint64_t segcap = std::min<uint64_t>(upper, upper / world + upper / (4 * world) + 4096);
 		const uint64_t sb = h->stream_base, rd = h->reads;
 		unsigned long long bad0 = 0; hipMemcpy(&bad0, &h->dstats->sender_bad, 8, hipMemcpyDeviceToHost);      /* a repeated attempt must not count the dropped k-mers twice */
 		for (;;) {
-			if (hipMalloc(&h->xo_dev, (size_t)world * segcap * rb) != hipSuccess) { hipFree(dcounts); h->xo_dev = nullptr; return fail(h, KMR_ERR_OOM, "owner segments"); }
+			if (dev_malloc(&h->xo_dev, (size_t)world * segcap * rb) != hipSuccess) { hipFree(dcounts); h->xo_dev = nullptr; return fail(h, KMR_ERR_OOM, "owner segments"); }
 			h->stream_base = sb; h->reads = rd;             /* a repeated attempt stamps the same ordinals */
 			int rc = kmr_extract_by_owner_dev(h, batch->bases, batch->quals, batch->offsets, batch->n, batch->total, first_global_read_idx, nullptr, h->xo_dev, segcap, dcounts);
 			if (!rc) rc = sync_state(h);
@@ -3439,7 +3509,7 @@ int kmr_insert_records(kmr_handle *h, const void *host_records, uint64_t n) {
 	hipSetDevice(h->device);
 	const size_t bytes = (size_t)n * KMR_RECORD_BYTES(h->k, h->cfg.value_kind);
 	void *d = nullptr;
-	HIPCHK(h, hipMalloc(&d, bytes));
+	HIPCHK(h, dev_malloc(&d, bytes));
 	hipError_t e = hipMemcpy(d, host_records, bytes, hipMemcpyHostToDevice);
 	int rc = e == hipSuccess ? kmr_insert_records_dev(h, d, n) : KMR_ERR_HIP;
 	if (!rc) rc = sync_state(h); else hipStreamSynchronize(h->stream);
@@ -3480,7 +3550,7 @@ int kmr_sk_exchange_counts(kmr_handle *h, uint64_t *chunks, uint64_t *granules) 
 	HIPCHK(h, hipMemcpy(&head, h->l1.head, 4, hipMemcpyDeviceToHost));
 	if (head > h->l1.cap) head = h->l1.cap;
 	unsigned long long *d = nullptr;
-	HIPCHK(h, hipMalloc((void **)&d, 16 * SK_OWNER_MAX)); HIPCHK(h, hipMemsetAsync(d, 0, 16 * SK_OWNER_MAX, h->stream));
+	HIPCHK(h, dev_malloc((void **)&d, 16 * SK_OWNER_MAX)); HIPCHK(h, hipMemsetAsync(d, 0, 16 * SK_OWNER_MAX, h->stream));
 	hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);
 	if (head) hipLaunchKernelGGL(sk_owner_count_kernel, dim3(grid_for(head)), dim3(256), 0, h->stream, h->l1.chunk_list, h->l1.chunk_count, head, world, d, d + SK_OWNER_MAX);
 	hipError_t e = hipGetLastError();
@@ -3501,7 +3571,7 @@ int kmr_sk_exchange_pack_dev(kmr_handle *h, void *dev_data, void *dev_meta, cons
 	HIPCHK(h, hipMemcpy(&head, h->l1.head, 4, hipMemcpyDeviceToHost));
 	if (head > h->l1.cap) head = h->l1.cap;
 	unsigned long long *d = nullptr;
-	HIPCHK(h, hipMalloc((void **)&d, 32 * SK_OWNER_MAX));
+	HIPCHK(h, dev_malloc((void **)&d, 32 * SK_OWNER_MAX));
 	std::vector<unsigned long long> hv(4 * SK_OWNER_MAX, 0);
 	for (uint32_t r = 0; r < world; r++) { hv[r] = granule_offset[r]; hv[SK_OWNER_MAX + r] = chunk_offset[r]; }
 	hipError_t e = hipMemcpyAsync(d, hv.data(), 32 * SK_OWNER_MAX, hipMemcpyHostToDevice, h->stream);
@@ -3529,7 +3599,7 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
 	const size_t need = 8 * (n_chunks + 1) + 4 * (n_chunks + 1) + 256;
 	if (h->adopt_cap < need) {
 		if (h->adopt_buf) { hipStreamSynchronize(h->stream); hipFree(h->adopt_buf); h->adopt_buf = nullptr; h->adopt_cap = 0; }
-		HIPCHK(h, hipMalloc((void **)&h->adopt_buf, need + need / 4)); h->adopt_cap = need + need / 4;
+		HIPCHK(h, dev_malloc((void **)&h->adopt_buf, need + need / 4)); h->adopt_cap = need + need / 4;
 	}
 	uint64_t *start = (uint64_t *)h->adopt_buf; uint32_t *cnt = (uint32_t *)(h->adopt_buf + 8 * (n_chunks + 1));
 	hipLaunchKernelGGL(sk_meta_counts_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, h->stream, (const uint2 *)dev_meta, n_chunks, cnt);

@@ -75,7 +75,7 @@ int kmr_exchange_init(kmr_handle *h, const void *id) {
 	ncclComm_t comm = nullptr;
 	RCCLCHK(h, g_rccl.CommInitRank(&comm, (int)h->cfg.world_size, u, (int)h->cfg.rank));
 	h->xc_comm = comm;
-	HIPCHK(h, hipMalloc((void **)&h->xc_small, 8ull * (2 * SK_OWNER_MAX + 2) * (SK_OWNER_MAX + 1)));
+	HIPCHK(h, dev_malloc((void **)&h->xc_small, 8ull * (2 * SK_OWNER_MAX + 2) * (SK_OWNER_MAX + 1)));
 	h->xc_tr.user = h; h->xc_tr.allgather_u64 = rccl_allgather_u64; h->xc_tr.alltoallv_dev = rccl_alltoallv_dev;
 	return exchange_ready(h);
 }
@@ -97,7 +97,7 @@ static int xc_reserve(kmr_handle *h, void **p, uint64_t &cap, uint64_t bytes) {
 	if (bytes <= cap && *p) return 0;
 	if (*p) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(*p); *p = nullptr; cap = 0; }
 	bytes = std::max<uint64_t>(bytes + bytes / 8, 4096);
-	if (hipMalloc(p, bytes) != hipSuccess) { *p = nullptr; return fail(h, KMR_ERR_OOM, "exchange buffers"); }
+	if (dev_malloc(p, bytes) != hipSuccess) { *p = nullptr; return fail(h, KMR_ERR_OOM, "exchange buffers"); }
 	cap = bytes;
 	return 0;
 }
@@ -248,7 +248,7 @@ int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void 
 	const uint64_t sb = h->stream_base, rd = h->reads;
 	unsigned long long bad0 = 0; hipMemcpy(&bad0, &h->dstats->sender_bad, 8, hipMemcpyDeviceToHost);      /* a repeated attempt must not count the dropped k-mers twice */
 	std::vector<uint64_t> counts(world, 0);
-	if (!lrc && !h->xc_dcounts && hipMalloc((void **)&h->xc_dcounts, 8 * SK_OWNER_MAX) != hipSuccess) { h->xc_dcounts = nullptr; lrc = fail(h, KMR_ERR_OOM, "exchange counters"); }
+	if (!lrc && !h->xc_dcounts && dev_malloc((void **)&h->xc_dcounts, 8 * SK_OWNER_MAX) != hipSuccess) { h->xc_dcounts = nullptr; lrc = fail(h, KMR_ERR_OOM, "exchange counters"); }
 	unsigned long long *dcounts = h->xc_dcounts;
 	while (!lrc) {      /* a skewed batch (one owner takes more than its share) is extracted again into larger segments */
 		lrc = xc_reserve(h, &h->xc_send, h->xc_send_cap, (uint64_t)world * segcap * rb); if (lrc) break;

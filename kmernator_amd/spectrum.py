@@ -349,6 +349,12 @@ class KmerSpectrum:
                    weights.ctypes.data_as(C.POINTER(C.c_double)), nbins)
         return counts, weights
 
+    def digest(self, which=KMR_MAP_WEAK):
+        """kmr_map_digest: order-independent digest of a finalized map (sums of rank / part digests = the whole spectrum's)"""
+        d = _lib.KmrDigest()
+        self._call("map_digest", self.h, which, C.byref(d))
+        return d.as_dict()
+
     def getHistogram(self, zoom_max=256, log_base=2.0):
         """KmerSpectrum::getHistogram (src/KmerSpectrum.h:1066-1071): Histogram(256).set(*this) -> Histogram"""
         nb = self.lib.kmr_histogram_bins(zoom_max)
@@ -626,3 +632,18 @@ class FilterKnownOddities:
             self.close()
         except Exception:
             pass
+
+
+def synth_reads_device(torch, seed, first_read, n_reads, read_len, genome_len, noisy, device):
+    """kmr_synth_reads_dev into torch tensors on `device`: (bases u8, quals u8, offsets i64).  The buffers carry 64 spare bytes behind
+    the last read, as the device entry points of the build ask for."""
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        bases = torch.zeros(n_reads * read_len + 64, dtype=torch.uint8, device=device)
+        quals = torch.zeros(n_reads * read_len + 64, dtype=torch.uint8, device=device)
+        offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=device)
+        torch.cuda.synchronize()
+        rc = lib.kmr_synth_reads_dev(seed, first_read, n_reads, read_len, genome_len, 1 if noisy else 0, bases.data_ptr(), quals.data_ptr(), offsets.data_ptr())
+        if rc:
+            raise KmerSpectrumError("kmr_synth_reads_dev: %s" % _lib.STATUS.get(rc, rc))
+    return bases, quals, offsets

@@ -664,6 +664,7 @@ struct SpectrumBase {
 	virtual void refHistogram(uint32_t zoomMax, double logBase, uint64_t *visits, uint64_t *visitedCount, double *visitedWeight) = 0;
 	virtual void appendOne(const uint8_t *key, float w, const ExtPacket &e) = 0;
 	virtual uint64_t exportEntries(uint8_t *keys, uint32_t *count, uint32_t *dir, float *weighted, uint32_t *ext, uint64_t cap) = 0;
+	virtual void digest(int which, kmr_digest *out) = 0;
 };
 
 template <class WV, class SV> struct Spectrum : SpectrumBase {
@@ -908,6 +909,44 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 	}
 	static void copyExt(uint32_t *, const TDDir &) {}
 	static void copyExt(uint32_t *dst, const TDExt &v) { memcpy(dst, v.ext, 48); }
+	/* the order-independent map digest include/kmernator_amd.h defines (kmr_map_digest), over this spectrum's own maps */
+	static uint64_t dmix(uint64_t x) {
+		x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
+	}
+	uint64_t foldKey(uint64_t x, const uint8_t *key) const {
+		for (uint32_t o = 0; o < kb; o += 8) {
+			uint64_t w = 0;
+			for (uint32_t j = 0; j < 8; j++) w = (w << 8) | (o + j < kb ? key[o + j] : 0);
+			x = dmix(x ^ w);
+		}
+		return x;
+	}
+	static uint64_t foldExt(uint64_t x, const TDDir &) { return x; }
+	static uint64_t foldExt(uint64_t x, const TDExt &v) {
+		const uint32_t *t = &v.ext[0][0];
+		for (int j = 0; j < 12; j += 2) x = dmix(x ^ (t[j] | ((uint64_t)t[j + 1] << 32)));
+		return x;
+	}
+	static uint64_t singPacket(const SingDir &) { return 0; }
+	static uint64_t singPacket(const SingExt &v) { uint32_t p; memcpy(&p, &v.pkt, 4); return (uint64_t)p << 40; }
+	void digest(int which, kmr_digest *out) {
+		memset(out, 0, sizeof(*out));
+		if (which == KMR_MAP_WEAK) {
+			for (size_t bi = 0; bi < weak.buckets.size(); bi++) for (uint32_t j = 0; j < weak.buckets[bi].size(); j++) {
+				const WV &v = weak.buckets[bi].vals[j];
+				uint64_t x = foldExt(foldKey((uint64_t)v.count | ((uint64_t)v.directionBias << 16), weak.buckets[bi].key(j, kb)), v);
+				out->entries++; out->count_sum += v.count; out->dir_sum += v.directionBias; out->hash_sum += x; out->hash_xor ^= x;
+				out->weighted_sum += (double)v.weightedCount;
+			}
+		} else if (hasSingletons) {
+			for (size_t bi = 0; bi < singleton.buckets.size(); bi++) for (uint32_t j = 0; j < singleton.buckets[bi].size(); j++) {
+				const SV &v = singleton.buckets[bi].vals[j];
+				uint64_t x = foldKey(0x100000000ull | v._weight | singPacket(v), singleton.buckets[bi].key(j, kb));
+				out->entries++; out->count_sum += v._weight ? 1 : 0; out->hash_sum += x; out->hash_xor ^= x;
+				out->weighted_sum += v._weight ? (v._weight - 1) / 254.0 : 0.0;
+			}
+		}
+	}
 	/* flat dump of the weak map in bucket order, for field-by-field parity tests */
 	uint64_t exportEntries(uint8_t *keys, uint32_t *count, uint32_t *dir, float *weighted, uint32_t *ext, uint64_t cap) {
 		uint64_t n = 0;
@@ -1100,6 +1139,46 @@ uint64_t orc_bucket_idx(uint64_t hash, uint64_t nb) { return hash & (nb - 1); }
 uint32_t orc_local_thread_id(uint64_t hash, uint64_t nb, uint32_t t) { return (uint32_t)getLocalThreadId(hash, nb, (int)t); }
 uint32_t orc_distributed_thread_id(uint64_t hash, uint32_t n) { return (uint32_t)getDistributedThreadId(hash, (int)n); }
 uint64_t orc_min_power_of_2(uint64_t n) { return getMinPowerOf2(n); }
+int orc_map_digest(orc_handle *h, int which, kmr_digest *out) { h->s->digest(which, out); return 0; }
+
+/* SURVEY.md section 8(d)'s synthetic reads: the CPU statement of the generator include/kmernator_amd.h describes at
+ * kmr_synth_reads_dev (integer only; xorshift64* streams seeded per genome block and per global read index) */
+static inline uint64_t syn_next(uint64_t &s) { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s * 0x2545F4914F6CDD1Dull; }
+static inline uint64_t syn_state(uint64_t seed, uint64_t stream, uint64_t idx) {
+	uint64_t z = (seed ^ (stream * 0xD1B54A32D192ED03ull)) + idx * 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+	return z ? z : 0x9E3779B97F4A7C15ull;
+}
+void orc_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t L, uint64_t G, uint32_t noisy, char *bases, char *quals, uint64_t *offsets, int threads) {
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+	for (int64_t t = 0; t < (int64_t)n_reads; t++) {
+		uint64_t s = syn_state(seed, 2, first_read + (uint64_t)t);
+		const uint64_t start = (uint64_t)(((unsigned __int128)syn_next(s) * (unsigned __int128)(G - L + 1)) >> 64);
+		const bool strand = (syn_next(s) >> 63) != 0;
+		char *bp = bases + (uint64_t)t * L, *qp = quals ? quals + (uint64_t)t * L : NULL;
+		for (uint32_t i = 0; i < L; i++) {
+			const uint64_t x = syn_next(s);
+			const uint64_t j = strand ? start + L - 1 - i : start + i;
+			uint64_t gs = syn_state(seed, 1, j >> 5);
+			uint32_t code = (uint32_t)(syn_next(gs) >> (2 * (j & 31))) & 3u;
+			if (strand) code = 3u - code;
+			const bool err = (uint32_t)(x >> 32) < 42949673u;
+			if (err) code = (code + 1u + (uint32_t)(((x & 0xffffu) * 3u) >> 16)) & 3u;
+			bp[i] = "ACGT"[code];
+			if (qp) {
+				uint32_t q = 40;
+				if (noisy) {
+					const uint32_t u = (uint32_t)((((x >> 16) & 0xffffu) * 100u) >> 16);
+					q = u < 80 ? 40 : u < 90 ? 30 : u < 95 ? 20 : u < 99 ? 10 : 2;
+					if (err) q = 10;
+				}
+				qp[i] = (char)(33 + q);
+			}
+		}
+	}
+	if (offsets) for (uint64_t t = 0; t <= n_reads; t++) offsets[t] = t * L;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
 	return omp_get_max_threads();

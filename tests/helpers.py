@@ -51,6 +51,14 @@ class KmrStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class KmrDigest(C.Structure):
+    """Mirror of kmr_digest in include/kmernator_amd.h."""
+    _fields_ = [(n, C.c_uint64) for n in ("entries", "count_sum", "dir_sum", "hash_sum", "hash_xor")] + [("weighted_sum", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class KmrArtifactConfig(C.Structure):
     """Mirror of kmr_artifact_config in include/kmernator_amd.h."""
     _fields_ = [(n, C.c_uint32) for n in ("match_length", "edit_distance", "build_edits", "simple_repeat_begin", "simple_repeat_end",
@@ -155,6 +163,9 @@ def oracle_lib():
         lib.orc_parse_fastq.restype = C.c_int64
         lib.orc_parse_fastq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, u32p,
                                         C.c_uint64, C.c_uint64, u32p]
+        lib.orc_map_digest.argtypes = [C.c_void_p, C.c_int, C.POINTER(KmrDigest)]
+        lib.orc_synth_reads.restype = None
+        lib.orc_synth_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, u64p, C.c_int]
         _oracle = lib
     return _oracle
 
@@ -374,6 +385,11 @@ class OracleSpectrum(_SpectrumCommon):
     def dump(self, path, min_depth, graph):
         self._call("dump", self.h, path.encode(), min_depth, 1 if graph else 0)
 
+    def digest(self, which=KMR_MAP_WEAK):
+        d = KmrDigest()
+        self._call("map_digest", self.h, which, C.byref(d))
+        return d.as_dict()
+
     def entries(self):
         n = self.stats()["weak_entries"]
         keys = np.zeros(n * self.kb, dtype=np.uint8)
@@ -444,6 +460,17 @@ def synth_reads(n_reads, read_len=150, genome_len=None, seed=1, err=0.01, qualit
         quals = np.where(ns, 33 + 2, quals).astype(np.uint8)
     offsets = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len))
     return ReadBatch.from_arrays(np.ascontiguousarray(bases.reshape(-1)), np.ascontiguousarray(quals.reshape(-1)), offsets)
+
+
+def synth_reads_8d(seed, first_read, n_reads, read_len=150, genome_len=None, noisy=False, threads=8):
+    """SURVEY.md 8(d)'s generator, CPU statement (orc_synth_reads): the same bytes as kmr_synth_reads_dev for the same arguments"""
+    lib = oracle_lib()
+    bases = np.zeros(n_reads * read_len, dtype=np.uint8)
+    quals = np.zeros(n_reads * read_len, dtype=np.uint8)
+    offsets = np.zeros(n_reads + 1, dtype=np.uint64)
+    lib.orc_synth_reads(seed, first_read, n_reads, read_len, genome_len, 1 if noisy else 0, bases.ctypes.data_as(C.c_void_p),
+                        quals.ctypes.data_as(C.c_void_p), _ptr(offsets, C.c_uint64), threads)
+    return ReadBatch.from_arrays(bases, quals, offsets)
 
 
 def parse_image(buf, kb, vsize):
