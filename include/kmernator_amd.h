@@ -228,10 +228,13 @@ int kmr_write_image(kmr_handle *h, int which_map, void *dst, uint64_t capacity);
  * (src/KmerSpectrum.h:489-518, src/Kmer.h:3124-3135).  The handle must be fresh
  * (no reads added); it becomes finalized. */
 int kmr_load_image(kmr_handle *h, int which_map, const void *src, uint64_t len);
-/* Union of a stored map with the handle's finalized map of the same kind and bucket count: the restore-and-merge
- * loop of KmerSpectrum::buildKmerSpectrumInParts (src/KmerSpectrum.h:1871-1884; KmerMapByKmerArrayPair::mergeAdd,
- * src/Kmer.h:3209-3261, for disjoint key sets).  Parts are built with kmr_config.num_parts / part_idx.
- * KMR_ERR_UNSUPPORTED if the two maps share a k-mer. */
+/* KmerMapByKmerArrayPair::mergeAdd (src/Kmer.h:3209-3261) of a stored map into the handle's finalized map of the same kind and
+ * bucket count: the restore-and-merge loop of KmerSpectrum::buildKmerSpectrumInParts (src/KmerSpectrum.h:1871-1884; parts built
+ * with kmr_config.num_parts / part_idx hold disjoint k-mers) and the weak-map step of KmerSpectrum::mergeVector (:2572-2584): a
+ * k-mer both weak maps hold gets a.add(b) -- += on the u16 count and directionBias (as in the reference they wrap, nothing
+ * saturates), on the float weightedCount and on the u32 extension tallies (src/KmerTrackingData.h:489-493,538-542,1059-1064).
+ * Singleton maps that share a k-mer are refused with KMR_ERR_UNSUPPORTED: that k-mer would have to be promoted into the weak map,
+ * KmerMap::mergePromote, which the reference itself throws on (src/Kmer.h:2675-2677). */
 int kmr_merge_image(kmr_handle *h, int which_map, const void *src, uint64_t len);
 
 /* Order-independent digest of a finalized map: a spectrum of 10^9 entries is compared, and the rank / part maps of a partitioned

@@ -655,8 +655,27 @@ template <int W> int merge_image_t(kmr_handle *h, DevMap &m, bool weakMap, const
 	MCHK(hipGetLastError());
 	uint32_t hdup = 0;
 	MCHK(hipMemcpyAsync(&hdup, dup, 4, hipMemcpyDeviceToHost, h->stream)); MCHK(hipStreamSynchronize(h->stream));
+	if (hdup && !weakMap) {
 #undef MCHK
-	if (hdup) { bail(0); return fail(h, KMR_ERR_UNSUPPORTED, "the two maps share k-mers: only disjoint parts (buildKmerSpectrumInParts) are merged"); }
+		/* (a k-mer in both singleton maps would have to be promoted into the weak map: KmerMap::mergePromote, which the reference
+		 * itself refuses -- "This method is broken", src/Kmer.h:2675-2677) */
+		bail(0); return fail(h, KMR_ERR_UNSUPPORTED, "the two singleton maps share k-mers: merging them means promoting those into the weak map (mergePromote, which the reference refuses too)");
+	}
+	if (hdup) {      /* mergeAdd proper: the k-mers both maps hold add their values */
+#define MCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hip_err_text(e_); free_map(d2); return bail(e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP); } } while (0)
+		DevMap d2; d2.nb = d.nb; d2.present = true;
+		hipLaunchKernelGGL(merge_distinct_kernel<W>, dim3(grid_for(d.nb)), dim3(256), 0, h->stream, d.start, d.nb, d.keys, counts);
+		MCHK(dev_malloc((void **)&d2.start, 8 * (d.nb + 1)));
+		rc = exclusive_scan(h, counts, d.nb, d2.start); if (rc) { free_map(d2); return bail(rc); }
+		MCHK(hipMemcpyAsync(&d2.n, d2.start + d.nb, 8, hipMemcpyDeviceToHost, h->stream)); MCHK(hipStreamSynchronize(h->stream));
+		MCHK(dev_malloc((void **)&d2.keys, std::max<uint64_t>(8, 8ull * W * d2.n)));
+		MCHK(dev_malloc((void **)&d2.vals, std::max<uint64_t>(8, 4ull * vw * d2.n)));
+		hipLaunchKernelGGL(merge_add_kernel<W>, dim3(grid_for(d.nb)), dim3(256), 0, h->stream, d.start, d.nb, d.keys, d.vals, vw, d2.start, d2.keys, d2.vals);
+		MCHK(hipGetLastError()); MCHK(hipStreamSynchronize(h->stream));
+#undef MCHK
+		free_map(d);
+		d = d2;
+	}
 	hipFree(counts); hipFree(dup); free_map(t);
 	free_map(m);
 	m = d;
@@ -1648,8 +1667,9 @@ int add_reads_superkmer(kmr_handle *h, const ReadsView &rv, uint64_t total_bases
 	switch (h->W) { case 1: return add_reads_superkmer_t<1>(h, rv, total_bases); case 2: return add_reads_superkmer_t<2>(h, rv, total_bases);
 	case 3: return add_reads_superkmer_t<3>(h, rv, total_bases); default: return add_reads_superkmer_t<4>(h, rv, total_bases); }
 }
-/* k-mers seen more than 65 535 times (sat_*_kernel in kmr_superkmer.hpp): weightedCount and directionBias of their entries in the
- * finished weak map from their first 65 535 sightings in input order, as the serial reference keeps them. */
+/* k-mers seen SK_ORDERED_FROM times or more (sat_*_kernel in kmr_superkmer.hpp): weightedCount and directionBias of their entries in the
+ * finished weak map from their first 65 535 sightings in input order, added into a float one after the other as the serial reference
+ * does.  n_clamped: how many such keys the count pass kept, n_sightings: their sightings. */
 template <int W> int saturated_fix_t(kmr_handle *h, const uint64_t *ls, const uint64_t *lc, uint64_t nl, unsigned long long n_clamped, unsigned long long n_sightings, uint32_t has_singletons) {
 	DevMap &wm = h->weak;
 	if (!n_clamped || !wm.n) return 0;
@@ -1702,7 +1722,7 @@ template <int W> int saturated_fix_t(kmr_handle *h, const uint64_t *ls, const ui
 	SATCHK(dalloc((void **)&d_items, 32 * ni));
 	SATCHK(hipMemcpy(d_items, ic0.data(), 8 * ni, hipMemcpyHostToDevice)); SATCHK(hipMemcpy(d_items + ni, ic1.data(), 8 * ni, hipMemcpyHostToDevice));
 	SATCHK(hipMemcpy(d_items + 2 * ni, ie0.data(), 8 * ni, hipMemcpyHostToDevice)); SATCHK(hipMemcpy(d_items + 3 * ni, ie1.data(), 8 * ni, hipMemcpyHostToDevice));
-	/* every sighting of those keys: the clamped ones' true counts are known, the others have exactly 65 535 */
+	/* every sighting of those keys (the count pass has added up their true counts; entries of a map merged in later add theirs) */
 	const uint64_t pcap = n_sightings + (found - std::min<unsigned long long>(found, n_clamped)) * 65535ull + 64;
 	unsigned long long *pk_in = nullptr, *pk_out = nullptr; uint32_t *pv_in = nullptr, *pv_out = nullptr;
 	SATCHK(dalloc((void **)&pk_in, 8 * pcap)); SATCHK(dalloc((void **)&pk_out, 8 * pcap)); SATCHK(dalloc((void **)&pv_in, 4 * pcap)); SATCHK(dalloc((void **)&pv_out, 4 * pcap));

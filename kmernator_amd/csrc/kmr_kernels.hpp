@@ -1251,6 +1251,45 @@ __global__ void merge_copy_kernel(const uint64_t *src_start, const uint64_t *oth
 		if (spkt) dpkt[pos] = spkt[e];
 	}
 }
+/* KmerMapByKmerArrayPair::mergeAdd's cmp == 0 branch (src/Kmer.h:3238-3241) over the sorted union of two weak maps: a key both maps
+ * held stands twice in its bucket, next to itself.  First pass: distinct keys per bucket; second pass (after a scan): every run of
+ * equal keys becomes one entry whose value is a.add(b) -- TrackingData::add / TrackingDataWithDirection::add / ExtensionTrackingData::add
+ * (src/KmerTrackingData.h:489-493,538-542,1059-1064): += on the u16 count and directionBias (they wrap, nothing saturates), on the
+ * float weightedCount, on the u32 extension tallies. */
+template <int W>
+__global__ void merge_distinct_kernel(const uint64_t *start, uint64_t nb, const uint64_t *keys, uint32_t *counts) {
+	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t c = 0;
+		for (uint64_t e = start[b]; e < start[b + 1]; e++) {
+			bool eq = e > start[b];
+			for (int j = 0; j < W && eq; j++) eq = keys[e * W + j] == keys[(e - 1) * W + j];
+			c += eq ? 0u : 1u;
+		}
+		counts[b] = c;
+	}
+}
+template <int W>
+__global__ void merge_add_kernel(const uint64_t *start, uint64_t nb, const uint64_t *keys, const uint32_t *vals, uint32_t vw,
+                                 const uint64_t *dst_start, uint64_t *dkeys, uint32_t *dvals) {
+	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t o = dst_start[b];
+		for (uint64_t e = start[b]; e < start[b + 1]; e++) {
+			bool eq = e > start[b];
+			for (int j = 0; j < W && eq; j++) eq = keys[e * W + j] == keys[(e - 1) * W + j];
+			if (!eq) {
+				for (int j = 0; j < W; j++) dkeys[o * W + j] = keys[e * W + j];
+				for (uint32_t j = 0; j < vw; j++) dvals[o * vw + j] = vals[e * vw + j];
+				o++;
+			} else {
+				uint32_t *d = dvals + (o - 1) * vw;
+				d[0] = (d[0] + vals[e * vw]) & 0xffffu;
+				d[1] = __float_as_uint(__uint_as_float(d[1]) + __uint_as_float(vals[e * vw + 1]));
+				d[2] = (d[2] + vals[e * vw + 2]) & 0xffffu;
+				for (uint32_t j = 3; j < vw; j++) d[j] += vals[e * vw + j];
+			}
+		}
+	}
+}
 template <int W>
 __global__ void duplicate_keys_kernel(const uint64_t *start, uint64_t nb, const uint64_t *keys, uint32_t *found) {
 	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x)

@@ -1377,6 +1377,11 @@ static const int SKC_WAVES = KMR_SKC_WAVES, SKC_THREADS = SKC_WAVES * 64;      /
  * word -- SK_KEY_PENDING (all ones: no padded word looks like that) until the winner has written it -- and compares.  One LDS round
  * trip per probe instead of two (state word, then the key). */
 static const unsigned long long SK_KEY_PENDING = ~0ull;
+/* A k-mer seen this often gets its weightedCount (and directionBias) from its sightings IN INPUT ORDER, added one after the other into a
+ * float as TrackingData::track does (weightedCount += weight, src/KmerTrackingData.h:427-448) -- sat_*_kernel below.  Below it the count
+ * pass's exact f64 sum rounded once is within 1e-5 * count of that whatever the order: each of the reference's n float additions is off by
+ * at most 2^-24 of its partial sum (<= n, weights are <= 1), n^2 * 2^-25 in all, <= 1e-5 * n for n <= 335. */
+static const uint32_t SK_ORDERED_FROM = 256;
 static const unsigned long long SK_OSLAB = 2048;      /* entries a wavefront reserves at a time in the count pass's output */
 
 template <int W, int LOG2S, bool TRACK = false, bool EXT = false>
@@ -1863,7 +1868,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 								const uint64_t pos = wpos + (uint32_t)__builtin_popcountll(mw & below);
 								uint32_t fwdc = (uint32_t)(cf >> 32), cnt16 = count;
 								if (f.has_singletons && first_forward(fst)) fwdc -= 1;
-								if (cnt16 > 65535u) { satK++; satS += count; cnt16 = 65535u; if (fwdc > 65534u) fwdc = 65534u; }      /* (weight and direction of such a key are redone from its first 65 535 sightings, sat_*_kernel) */
+								if (cnt16 >= SK_ORDERED_FROM) { satK++; satS += count; if (cnt16 > 65535u) { cnt16 = 65535u; if (fwdc > 65534u) fwdc = 65534u; } }      /* (weight and direction of such a key are redone from its first 65 535 sightings in input order, sat_*_kernel) */
 								if (fwdc > 65535u) fwdc = 65535u;
 								const uint32_t wbits = __float_as_uint((float)(f.has_singletons ? wsum + first_weight_shift(fst) : wsum));
 								if (out.wentries) {
@@ -2014,7 +2019,7 @@ void sk_merge_emit_kernel(Table<W> tbl, CountOut out, FinalizeParams f) {
 				else {
 					if (out.weakCount) bucket = key_hash<W>(key, f.kb) & (f.nb_weak - 1);
 					if (f.has_singletons && first_forward(sl.first)) fwdc -= 1;
-					if (cnt > 65535u) { atomicAdd(&out.fc->saturated, 1ull); atomicAdd(&out.fc->sat_sightings, (unsigned long long)cnt); cnt = 65535u; if (fwdc > 65534u) fwdc = 65534u; }
+					if (cnt >= SK_ORDERED_FROM) { atomicAdd(&out.fc->saturated, 1ull); atomicAdd(&out.fc->sat_sightings, (unsigned long long)cnt); if (cnt > 65535u) { cnt = 65535u; if (fwdc > 65534u) fwdc = 65534u; } }
 					if (fwdc > 65535u) fwdc = 65535u;
 					const uint32_t wbits = __float_as_uint((float)(f.has_singletons ? sl.wsum + first_weight_shift(sl.first) : sl.wsum));
 					if (out.wentries) {
@@ -2255,7 +2260,7 @@ __global__ __launch_bounds__(256)
 void sat_find_kernel(const uint64_t *keys, const uint32_t *vals, uint64_t n, uint32_t m, uint32_t off, uint32_t win, uint32_t list_bits,
                      unsigned long long *found, uint64_t cap, uint64_t *sat_entry, uint32_t *sat_list, uint32_t vw = 3) {
 	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
-		if ((vals[e * vw] & 0xffffu) != 65535u) continue;
+		if ((vals[e * vw] & 0xffffu) < SK_ORDERED_FROM) continue;
 		const unsigned long long at = atomicAdd(found, 1ull);
 		if (at < cap) { sat_entry[at] = e; sat_list[at] = sk_list_of(sk_key_minimizer<W>(keys + e * W, m, off, win), list_bits); }
 	}
@@ -2398,8 +2403,8 @@ void sat_collect_kernel(PoolView pool, const uint64_t *list_chunks, uint32_t k, 
 		}
 	}
 }
-/* one block per saturated key (index b into sat_entry): its sightings are the sorted pairs with key >> 41 == b; the first 65 535 of
- * them make weightedCount and directionBias of map entry sat_entry[b] (a key with no more than 65 535 sightings keeps what it has).
+/* one block per such key (index b into sat_entry): its sightings are the sorted pairs with key >> 41 == b; the first 65 535 of
+ * them make weightedCount and directionBias of map entry sat_entry[b].
  * The weights are added as the reference adds them -- one after the other in input order into a float (weightedCount += weight,
  * src/KmerTrackingData.h:440: at 6 x 10^4 a float moves in steps of 2^-8, so 65 534 additions of ~1 drift by tens against the exact sum)
  * -- by one thread out of LDS tiles the block loads together; the direction count is a plain sum. */
@@ -2413,16 +2418,17 @@ void sat_reduce_kernel(const unsigned long long *keys, const uint32_t *weights, 
 		auto lower = [&](unsigned long long v) { uint64_t lo = 0, hi = n_pairs; while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (keys[mid] < v) lo = mid + 1; else hi = mid; } return lo; };
 		const uint64_t s = lower((unsigned long long)b << 41), e = lower((unsigned long long)(b + 1) << 41);
 		__syncthreads();
-		if (e - s <= 65535) continue;
+		if (e <= s) continue;
+		const uint64_t lim = e - s < 65535 ? e - s : 65535;      /* the reference stops tracking at the 65 535th sighting */
 		/* sighting 1: without a singleton map it is tracked like the others; with one it comes back from there without its direction and
 		 * with the weight the singleton byte kept (src/KmerTrackingData.h:641-658) */
 		const float w1 = __uint_as_float(weights[s]);
 		float acc = has_singletons ? (float)((double)(first_weight_bits(w1) >> 15) / 254.0) : (float)(0.0 + (double)w1);
 		unsigned int f = 0;
-		for (uint64_t i = s + 1 + t; i < s + 65535; i += 256) f += (unsigned int)(keys[i] & 1ull);      /* sightings 2 .. 65 535 */
+		for (uint64_t i = s + 1 + t; i < s + lim; i += 256) f += (unsigned int)(keys[i] & 1ull);      /* sightings 2 .. 65 535 */
 		s_f[t] = f;
-		for (uint64_t base = s + 1; base < s + 65535; base += TILE) {
-			const uint64_t nt = s + 65535 - base < (uint64_t)TILE ? s + 65535 - base : (uint64_t)TILE;
+		for (uint64_t base = s + 1; base < s + lim; base += TILE) {
+			const uint64_t nt = s + lim - base < (uint64_t)TILE ? s + lim - base : (uint64_t)TILE;
 			__syncthreads();
 			for (uint64_t i = t; i < nt; i += 256) s_w[i] = __uint_as_float(weights[base + i]);
 			__syncthreads();

@@ -665,6 +665,7 @@ struct SpectrumBase {
 	virtual void appendOne(const uint8_t *key, float w, const ExtPacket &e) = 0;
 	virtual uint64_t exportEntries(uint8_t *keys, uint32_t *count, uint32_t *dir, float *weighted, uint32_t *ext, uint64_t cap) = 0;
 	virtual void digest(int which, kmr_digest *out) = 0;
+	virtual bool mergeAddWeak(SpectrumBase *src) = 0;
 };
 
 template <class WV, class SV> struct Spectrum : SpectrumBase {
@@ -909,6 +910,34 @@ template <class WV, class SV> struct Spectrum : SpectrumBase {
 	}
 	static void copyExt(uint32_t *, const TDDir &) {}
 	static void copyExt(uint32_t *dst, const TDExt &v) { memcpy(dst, v.ext, 48); }
+	/* KmerMapByKmerArrayPair::mergeAdd (src/Kmer.h:3209-3261) of the weak maps, as KmerSpectrum::mergeVector applies it
+	 * (src/KmerSpectrum.h:2572-2584): both maps sorted, a sorted merge bucket by bucket, a key both hold gets a.valueAt().add(b.valueAt())
+	 * -- TrackingData::add / TrackingDataWithDirection::add / ExtensionTrackingData::add (src/KmerTrackingData.h:489-493,538-542,1059-1064):
+	 * plain += on the u16 count and directionBias (no saturation: they wrap), on the float weightedCount and on the u32 tallies. */
+	static void addValue(TDDir &a, const TDDir &b) { a.count = (uint16_t)(a.count + b.count); a.weightedCount += (double)b.weightedCount; a.directionBias = (uint16_t)(a.directionBias + b.directionBias); }
+	static void addValue(TDExt &a, const TDExt &b) { addValue((TDDir &)a, (const TDDir &)b); for (int d = 0; d < 2; d++) for (int i = 0; i < 6; i++) a.ext[d][i] += b.ext[d][i]; }
+	bool mergeAddWeak(SpectrumBase *srcBase) {
+		Spectrum *src = dynamic_cast<Spectrum *>(srcBase);
+		if (!src || src->weak.numBuckets() != weak.numBuckets()) return false;
+		weak.resortAll(); src->weak.resortAll();
+		for (size_t bi = 0; bi < weak.buckets.size(); bi++) {
+			Bucket<WV> &a = weak.buckets[bi], &b = src->weak.buckets[bi];
+			if (b.size() == 0) continue;
+			if (a.size() == 0) { std::swap(a, b); continue; }      /* mergeTriviallyInterleavedBuckets :2731-2741 */
+			Bucket<WV> merged;
+			uint32_t ia = 0, ib = 0;
+			while (ia < a.size() || ib < b.size()) {
+				int cmp = ia >= a.size() ? 1 : (ib >= b.size() ? -1 : memcmp(a.key(ia, kb), b.key(ib, kb), kb));
+				if (cmp == 0) { WV v = a.vals[ia]; addValue(v, b.vals[ib]); merged.append(a.key(ia, kb), kb, v); ia++; ib++; }
+				else if (cmp < 0) { merged.append(a.key(ia, kb), kb, a.vals[ia]); ia++; }
+				else { merged.append(b.key(ib, kb), kb, b.vals[ib]); ib++; }
+			}
+			merged.endSorted = merged.size();
+			std::swap(a, merged);
+			b.clear();
+		}
+		return true;
+	}
 	/* the order-independent map digest include/kmernator_amd.h defines (kmr_map_digest), over this spectrum's own maps */
 	static uint64_t dmix(uint64_t x) {
 		x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
@@ -1139,6 +1168,7 @@ uint64_t orc_bucket_idx(uint64_t hash, uint64_t nb) { return hash & (nb - 1); }
 uint32_t orc_local_thread_id(uint64_t hash, uint64_t nb, uint32_t t) { return (uint32_t)getLocalThreadId(hash, nb, (int)t); }
 uint32_t orc_distributed_thread_id(uint64_t hash, uint32_t n) { return (uint32_t)getDistributedThreadId(hash, (int)n); }
 uint64_t orc_min_power_of_2(uint64_t n) { return getMinPowerOf2(n); }
+int orc_merge_add(orc_handle *h, orc_handle *src) { return h->s->mergeAddWeak(src->s) ? 0 : KMR_ERR_INVALID_ARG; }
 int orc_map_digest(orc_handle *h, int which, kmr_digest *out) { h->s->digest(which, out); return 0; }
 
 /* SURVEY.md section 8(d)'s synthetic reads: the CPU statement of the generator include/kmernator_amd.h describes at

@@ -164,6 +164,7 @@ def oracle_lib():
         lib.orc_parse_fastq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, u32p,
                                         C.c_uint64, C.c_uint64, u32p]
         lib.orc_map_digest.argtypes = [C.c_void_p, C.c_int, C.POINTER(KmrDigest)]
+        lib.orc_merge_add.argtypes = [C.c_void_p, C.c_void_p]
         lib.orc_synth_reads.restype = None
         lib.orc_synth_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, u64p, C.c_int]
         _oracle = lib
@@ -385,6 +386,10 @@ class OracleSpectrum(_SpectrumCommon):
     def dump(self, path, min_depth, graph):
         self._call("dump", self.h, path.encode(), min_depth, 1 if graph else 0)
 
+    def merge_add(self, other):
+        """KmerMapByKmerArrayPair::mergeAdd of the weak maps (other's weak map is emptied)"""
+        self._call("merge_add", self.h, other.h)
+
     def digest(self, which=KMR_MAP_WEAK):
         d = KmrDigest()
         self._call("map_digest", self.h, which, C.byref(d))
@@ -487,6 +492,80 @@ def parse_image(buf, kb, vsize):
         vals = buf[o + 4 + n * kb:o + 4 + n * (kb + vsize)].reshape(n, vsize)
         buckets.append((keys, vals))
     return nb, mask, buckets
+
+
+def _dmix(x):
+    """mix() of include/kmernator_amd.h's digest, on uint64 arrays"""
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def digest_of_image(buf, kb, ext=False, singleton=False):
+    """kmr_digest as include/kmernator_amd.h defines it, computed from the bytes of a stored map (numpy restatement: what
+    kmr_map_digest and orc_map_digest are both held to)"""
+    vsize = (5 if ext else 1) if singleton else (60 if ext else 12)
+    _, _, buckets = parse_image(buf, kb, vsize)
+    keys = np.concatenate([b[0] for b in buckets]) if buckets else np.zeros((0, kb), np.uint8)
+    vals = np.concatenate([b[1] for b in buckets]) if buckets else np.zeros((0, vsize), np.uint8)
+    n = keys.shape[0]
+    W = (kb + 7) // 8
+    padded = np.zeros((n, 8 * W), dtype=np.uint8)
+    padded[:, :kb] = keys
+    words = padded.reshape(n, W, 8)[:, :, ::-1].copy().view(np.uint64).reshape(n, W)      # big-endian words
+    out = {"entries": n}
+    if singleton:
+        w8 = vals[:, 0].astype(np.uint64)
+        x = np.uint64(1 << 32) | w8
+        if ext:
+            x = x | (np.ascontiguousarray(vals[:, 1:5]).view(np.uint32).reshape(n).astype(np.uint64) << np.uint64(40))
+        out["count_sum"] = int((w8 != 0).sum())
+        out["dir_sum"] = 0
+        out["weighted_sum"] = float(np.where(w8 != 0, (w8.astype(np.float64) - 1.0) / 254.0, 0.0).sum())
+    else:
+        count = np.ascontiguousarray(vals[:, 0:2]).view(np.uint16).reshape(n).astype(np.uint64)
+        dirb = np.ascontiguousarray(vals[:, 8:10]).view(np.uint16).reshape(n).astype(np.uint64)
+        x = count | (dirb << np.uint64(16))
+        out["count_sum"] = int(count.sum())
+        out["dir_sum"] = int(dirb.sum())
+        out["weighted_sum"] = float(np.ascontiguousarray(vals[:, 4:8]).view(np.float32).reshape(n).astype(np.float64).sum())
+    for j in range(W):
+        x = _dmix(x ^ words[:, j])
+    if ext and not singleton:
+        t = np.ascontiguousarray(vals[:, 12:60]).view(np.uint32).reshape(n, 12).astype(np.uint64)
+        for j in range(0, 12, 2):
+            x = _dmix(x ^ (t[:, j] | (t[:, j + 1] << np.uint64(32))))
+    with np.errstate(over="ignore"):
+        out["hash_sum"] = int(x.sum(dtype=np.uint64)) if n else 0
+    out["hash_xor"] = int(np.bitwise_xor.reduce(x)) if n else 0
+    return out
+
+
+def digests_agree(a, b, rel=1e-6):
+    """two kmr_digests: integers equal, weighted_sum within rel (a float accumulation whose order is not part of the contract)"""
+    for key in ("entries", "count_sum", "dir_sum", "hash_sum", "hash_xor"):
+        if int(a[key]) != int(b[key]):
+            return False
+    return abs(a["weighted_sum"] - b["weighted_sum"]) <= rel * max(1.0, abs(a["weighted_sum"]))
+
+
+def add_digests(a, b):
+    """part / rank digests combine into the whole map's (a may be None)"""
+    if a is None:
+        return dict(b)
+    out = {key: a[key] + b[key] for key in ("entries", "count_sum", "dir_sum", "weighted_sum")}
+    out["hash_sum"] = (a["hash_sum"] + b["hash_sum"]) & 0xFFFFFFFFFFFFFFFF
+    out["hash_xor"] = a["hash_xor"] ^ b["hash_xor"]
+    return out
+
+
+def full_size_golden(name):
+    """tests/golden/full_size_digests.json[name] (written by tests/golden/make_full_size_digests.py from the oracle)"""
+    import json
+    with open(os.path.join(GOLDEN, "full_size_digests.json")) as f:
+        return json.load(f)[name]
 
 
 def oracle_extract_by_owner(cfg, rb, seg_capacity):

@@ -76,3 +76,47 @@ def score_and_trim(counts, seq, k, min_score, scoring):
     else:
         sc = 0.0
     return toff, tlen + k - 1, sc, trimmed
+
+
+def passes_length(length, read_length, minimum_length):
+    """ReadSelectorUtil::passesLength (src/ReadSelector.h:209-228): a minimum <= 1 is a fraction of the read, above 1 a length"""
+    if length <= 1.0:
+        return False
+    if minimum_length <= 1.0:
+        return read_length * minimum_length <= length
+    return minimum_length <= length
+
+
+def filterreads_output(names, seqs, quals, labels, discarded, trim_off, trim_len, scores, min_depth, min_read_length, both_pass, qual_shift=0, out_base=33):
+    """What FilterReads writes for a paired read set (apps/FilterReads.h:159-260 with max-kmer-depth and partition-by-depth off):
+    pickAllPassingPairs (src/ReadSelector.h:585-596) over the pairs (2i, 2i+1) -- a pair passes when both (min-passing-in-pair 2)
+    or either of its reads isPassingRead (:550-568: score >= min depth and passesLength of the trimmed length against the read as
+    the artifact filter left it); BOTH reads of a passing pair are picked (pickIfNew only asks for availability) and written in
+    pair order with their own trims (writePicks :1242-1262).  A read whose trim is <= 1 base, or that the artifact filter discarded,
+    prints as one 'N' with quality (output base) + 1 (Sequence::getFasta src/Sequence.cpp:305-311, Read::getQuals :729-733); a discarded read
+    was never scored (scoreAndTrimReads :1195-1197) and has no label.  Per-read inputs are the reads AFTER the artifact filter."""
+    n = len(names)
+    assert n % 2 == 0
+    passing = []
+    for i in range(n):
+        if discarded[i]:
+            passing.append(False)
+        else:
+            passing.append(scores[i] >= min_depth and passes_length(float(trim_len[i]), len(seqs[i]), min_read_length))
+    out = []
+    for p in range(n // 2):
+        a, b = 2 * p, 2 * p + 1
+        ok = (passing[a] and passing[b]) if both_pass else (passing[a] or passing[b])
+        if not ok:
+            continue
+        for i in (a, b):
+            tl = 0 if discarded[i] else int(trim_len[i])
+            if discarded[i] or tl <= 1:
+                s, q = b"N", bytes([out_base + 1])
+            else:
+                to = int(trim_off[i])
+                s = seqs[i][to:to + tl]
+                q = bytes((c + qual_shift) & 0xff for c in quals[i][to:to + tl])
+            head = names[i] + ((b" " + labels[i]) if labels[i] else b"")
+            out.append(b"@" + head + b"\n" + s + b"\n+\n" + q + b"\n")
+    return b"".join(out)

@@ -183,6 +183,50 @@ def test_golden_filterreads_end_to_end_on_the_device():
         assert seq == gold.seq(i), (i, gold.names[i])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("gold_name,mrl,both,out_base", [
+    ("1000-Filtered-0.85.fastq", 0.85, False, 64), ("1000-Filtered-0.85.std.fastq", 0.85, False, 33),
+    ("1000-Filtered-readlength.fastq", 1.0, False, 64), ("1000-Filtered-readlength-both.fastq", 1.0, True, 64), ("1000-Filtered.fastq", 25.0, False, 64)])
+@pytest.mark.parametrize("fq", ["1000.fastq", "1000.std.fastq"])
+def test_filterreads_selection_goldens_on_the_device(fq, gold_name, mrl, both, out_base):
+    """test/runFilterTests.sh:43-63, every golden the script checks, WHOLE FILE byte for byte: FASTQ text -> device reads (quality
+    base detected) -> artifact filter with the run's --min-read-length -> spectrum of the filtered reads -> scoreAndTrimReads, all on
+    the device through the C-ABI; what remains is FilterReads' host-side selection and printing (isPassingRead / isPassingPair /
+    writePicks, src/ReadSelector.h:547-596,1242-1262) over kmr_score_read_batch's output (tests/refsemantics.py)."""
+    import kmernator_amd as ka
+    from refsemantics import filterreads_output
+    gold = fasta(gold_name)
+    sp = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=46000, device=0))
+    rs = ka.ReadSet(sp, fasta(fq))
+    in_base = rs.input_quality_base
+    assert in_base == (33 if "std" in fq else 64)
+    f = ka.FilterKnownOddities(sp, fasta("artifact_sequences.fa"), edit_distance=1, min_read_length=mrl)
+    res, frs = f.applyFilter(rs)
+    assert frs.n == 1000
+    sp.buildKmerSpectrumFromReadSet(frs)
+    sp.finalize(2)
+    to, tl, sc, wt = sp.scoreAndTrimReadSet(frs, 2, "MEDIAN")
+    b, q, off, names = frs.arrays()
+    labels, seqs, quals, disc = [], [], [], []
+    for i in range(1000):
+        d = res["action"][i] == 2
+        disc.append(d)
+        seqs.append(bytes(b[int(off[i]):int(off[i + 1])]))
+        quals.append(bytes(q[int(off[i]):int(off[i + 1])]))
+        label = b""
+        if not d:
+            if res["action"][i] == 1:
+                label += b"AFTrim:%d+%d " % (res["min_pass"][i], res["max_pass"][i] - res["min_pass"][i])
+            if wt[i]:
+                label += b"Trim:%d+%d " % (to[i], tl[i])
+            label += b"MedianScore:%d" % int(sc[i] + 0.5)
+        labels.append(label)
+    # the device read set keeps qualities at Phred-33 (Read::FASTQ_START_CHAR, the reference's internal form)
+    text = filterreads_output([nm.split(b" ")[0] for nm in names], seqs, quals, labels, disc, to, tl, sc, 2, mrl, both, qual_shift=out_base - 33, out_base=out_base)
+    assert text.replace(b"\t", b" ") == gold.replace(b"\t", b" ")
+    assert sum(disc) == {0.85: 5, 1.0: 51, 25.0: 0}[mrl]
+
+
 def _spiked_reads(n, seed, tables, read_len=(30, 160)):
     """synthetic reads with what the filter reacts to: adapter / repeat / PhiX pieces (exact and with one or two substitutions)
     at random places, runs of low quality, N's, reads shorter than the match length"""

@@ -33,7 +33,7 @@ def add(sp, rb, first=0):
     sp.buildKmerSpectrum(rb.bases, rb.quals, rb.offsets, first, rb.discarded)
 
 
-def compare_weak_images(img_o, img_p, kb, ext, dir_tol=0, saturated_dir_free=False, first_tol=0.0):
+def compare_weak_images(img_o, img_p, kb, ext, dir_tol=0, saturated_dir_free=False, first_tol=0.0, exact_from=None):
     """first_tol: 1/254 where the two sides may disagree about which sighting was the first (arrival order through an
     exchange, as in the reference's own MPI build), 0 against the serial oracle"""
     vsize = 60 if ext else 12
@@ -61,6 +61,9 @@ def compare_weak_images(img_o, img_p, kb, ext, dir_tol=0, saturated_dir_free=Fal
         # map kept it ((unsigned char)(w * 254) / 254); the product takes that quantisation from its first-sighting word and
         # rounds an f64 sum once: SURVEY section 7's contract, |d| <= 1e-5 * count
         assert np.all((np.abs(wo.astype(np.float64) - wp) <= first_tol + 1e-5 * cnt) | free)
+        if exact_from is not None:      # k-mers seen that often are accumulated in the reference's order and precision: bit for bit
+            hot = cnt >= exact_from
+            assert np.array_equal(vo32[hot, 1], vp32[hot, 1])
         if ext:
             assert np.array_equal(vo32[:, 3:], vp32[:, 3:])
         n += len(ko)
@@ -363,12 +366,76 @@ def test_build_in_parts_and_merge(k, parts, mode):
     assert np.array_equal(acc.image(KMR_MAP_SINGLETON), whole.image(KMR_MAP_SINGLETON))
     assert acc.stats()["weak_entries"] == whole.stats()["weak_entries"]
     with pytest.raises(ka.KmerSpectrumError, match="share"):
-        acc.merge_image(KMR_MAP_WEAK, whole.image(KMR_MAP_WEAK))
+        acc.merge_image(KMR_MAP_SINGLETON, whole.image(KMR_MAP_SINGLETON))
     wrong = product(default_config(k, num_buckets_weak=256, num_buckets_singleton=1024), mode)
     add(wrong, rb.slice(0, 10))
     wrong.finalize(1)
     with pytest.raises(ka.KmerSpectrumError, match="differing"):
         acc.merge_image(KMR_MAP_WEAK, wrong.image(KMR_MAP_WEAK))
+
+
+@pytest.mark.parametrize("k,ext", [(31, False), (51, False), (21, True), (95, True)])
+def test_merge_add_of_spectra_that_share_kmers(k, ext):
+    """KmerMapByKmerArrayPair::mergeAdd (src/Kmer.h:3209-3261) as KmerSpectrum::mergeVector uses it (src/KmerSpectrum.h:2572-2584):
+    two spectra of different reads of ONE genome (most k-mers in both) -- the merged weak map equals the oracle's mergeAdd of its
+    own two spectra byte for byte: a shared key's count, direction bias and extension tallies are the sums, its weightedCount the
+    float sum; keys of one side only are taken over; a third spectrum is merged on top."""
+    kw = dict(value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2) if ext else {}
+    cfg = default_config(k, num_buckets_weak=2048, num_buckets_singleton=4096, **kw)
+    rbs = [synth_reads(3000, read_len=150, genome_len=30000, seed=70 + i, quality="noisy", n_rate=0.001) for i in range(3)]
+    for rb in rbs[1:]:                       # one genome for all three read sets
+        rb.bases[:] = synth_reads(3000, read_len=150, genome_len=30000, seed=70, quality="noisy").bases
+    rng = np.random.default_rng(3)
+    for i, rb in enumerate(rbs):             # different reads all the same: a rotation of the read order plus fresh errors
+        rb.bases[:] = np.roll(rb.bases.reshape(3000, 150), 500 * i, axis=0).reshape(-1)
+        hit = rng.random(rb.bases.size) < 0.004 * i
+        rb.bases[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+    os_, ps = [], []
+    for rb in rbs:
+        o = OracleSpectrum(cfg)
+        o.add_reads(rb)
+        o.finalize(2)
+        p = product(cfg, 0)
+        add(p, rb)
+        p.finalize(2)
+        os_.append(o)
+        ps.append(p)
+    n0 = ps[0].stats()["weak_entries"]
+    for j in (1, 2):
+        img = ps[j].image(KMR_MAP_WEAK)
+        ps[0].merge_image(KMR_MAP_WEAK, img)
+        os_[0].merge_add(os_[j])
+        io, ip = os_[0].image(KMR_MAP_WEAK), ps[0].image(KMR_MAP_WEAK)
+        n = compare_weak_images(io, ip, ps[0].kb, ext)
+        assert n == ps[0].stats()["weak_entries"]
+    assert n0 < n < n0 + ps[1].stats()["weak_entries"]          # shared keys were added, not appended
+    # lookups see the summed counts
+    keys, cnt, _, _, _ = os_[0].entries()
+    assert np.array_equal(ps[0].getCount(keys[:5000]), cnt[:5000])
+
+
+def test_merge_add_wraps_like_the_reference():
+    """TrackingData::add is `count += other.getCount()` on an unsigned short (src/KmerTrackingData.h:489-493): two maps that hold a
+    k-mer 40 000 times each merge to 80 000 - 65 536 = 14 464, and so does the direction bias -- restated as it is, not repaired"""
+    k = 25
+    cfg = default_config(k, num_buckets_weak=64, num_buckets_singleton=64)
+    seq = b"ACGTTGCAAGGCTTAACCGATCGGATTACAGGCATTCGA"          # 39 bases: 15 k-mers per read
+    n = 40000
+    rb = ReadBatch([seq] * n, [b"I" * len(seq)] * n)
+    o1, o2, p1, p2 = OracleSpectrum(cfg), OracleSpectrum(cfg), product(cfg, 0), product(cfg, 0)
+    for s in (o1, o2):
+        s.add_reads(rb)
+        s.finalize(2)
+    for s in (p1, p2):
+        add(s, rb)
+        s.finalize(2)
+    p1.merge_image(KMR_MAP_WEAK, p2.image(KMR_MAP_WEAK))
+    o1.merge_add(o2)
+    keys, cnt, dirb, w, _ = o1.entries()
+    assert set(cnt.tolist()) == {2 * n - 65536}
+    io, ip = o1.image(KMR_MAP_WEAK), p1.image(KMR_MAP_WEAK)
+    assert compare_weak_images(io, ip, p1.kb, False) == 15
+    assert np.array_equal(p1.getCount(keys), cnt)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -615,114 +682,6 @@ def test_quality_mix_is_noticed_between_calls():
         compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
 
 
-def test_build_modes_agree_at_scale():
-    """3M reads (360M k-mers, two sub-batches, ~2.6e5 final lists): the device-table path and the streaming
-    partition path are independent algorithms; their statistics and weak images must be byte-identical
-    (this caught a list hand-off race that only showed above ~1e8 k-mers)."""
-    n = 3000000
-    rb = synth_reads(n, read_len=150, genome_len=5 * n, seed=1)
-    res = []
-    for mode in MODES:
-        c = ka.default_config(31, estimated_raw_kmers=n * 120, build_mode=mode)
-        p = ka.KmerSpectrum(c)
-        add(p, rb)
-        p.finalize(2)
-        res.append((p.stats(), p.image(KMR_MAP_WEAK), p.histogram(1024)[0]))
-    for other in res[1:]:                # all three build modes, the default one (3) included
-        assert res[0][0] == other[0]
-        assert np.array_equal(res[0][1], other[1])
-        assert np.array_equal(res[0][2], other[2])
-    st, _, hist = res[2]
-    # size-independent bookkeeping: every good occurrence is in exactly one entry
-    assert int(hist.sum()) == st["weak_entries"]
-    assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
-    assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
-
-
-@pytest.mark.parametrize("k", [31, 127])
-def test_mostly_distinct_kmers_both_modes_agree(k):
-    """Low coverage (most k-mers seen once): the streaming path sizes its final lists from the measured share of
-    distinct keys (distinct_probe_kernel) instead of overflowing the count pass's LDS table into sub-passes; the
-    result must not depend on that choice -- byte-identical weak image and statistics against the table path."""
-    n = 400000
-    rb = synth_reads(n, read_len=150, genome_len=60 * n, seed=11)      # ~2.5x coverage
-    res = []
-    for mode in MODES:
-        c = ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), build_mode=mode)
-        p = ka.KmerSpectrum(c)
-        add(p, rb)
-        p.finalize(2)
-        res.append((p.stats(), p.image(KMR_MAP_WEAK)))
-    assert len(res) == len(MODES) == 3
-    for other in res[1:]:                # every mode against the device-table path
-        assert res[0][0] == other[0]
-        assert np.array_equal(res[0][1], other[1])
-    assert res[0][0]["unique_kmers"] > 0.6 * res[0][0]["raw_good_kmers"]
-
-
-def test_c2_full_size_properties():
-    """BASELINE.json configs[1] at full size (10M reads x 150 bp, k=31, 1.2e9 k-mers) through the device-pointer
-    entry point bench.py times: counts conserve the k-mers, the image is sorted and bucket-consistent (sampled),
-    lookups of k-mers taken from the reads return their image counts, a second build is bit-identical, and the
-    statistics and the weak image equal those of the device-table build (build_mode 1, an independent algorithm)
-    byte for byte."""
-    import torch
-    import bench
-    n = 10_000_000
-    dev = torch.device("cuda", 0)
-    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev)
-    torch.cuda.synchronize()
-    c = ka.default_config(31, estimated_raw_kmers=n * 120, device=0)
-    p = ka.KmerSpectrum(c)
-    imgs = []
-    for rep in range(2):
-        p.reset()
-        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
-        p.finalize(2)
-        st = p.stats()
-        assert st["raw_kmers"] == n * 120 == st["raw_good_kmers"]
-        hist = p.histogram(4096)[0]
-        assert int(hist.sum()) == st["weak_entries"]
-        assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
-        assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
-        imgs.append(p.image(KMR_MAP_WEAK))
-    assert np.array_equal(imgs[0], imgs[1])          # deterministic, including the f32 weight sums
-    img = imgs[0]
-    nb = int(np.frombuffer(img[:8].tobytes(), dtype=np.uint64)[0])
-    assert nb == 1 << 21                              # reference sizing for 1.2e9 raw k-mers (SURVEY 8a8)
-    offs = np.frombuffer(img[16:16 + 8 * nb].tobytes(), dtype=np.uint64)
-    lib = ka.load()
-    rng = np.random.default_rng(5)
-    checked = 0
-    for b in rng.integers(0, nb, 300):
-        o = int(offs[b])
-        cnt = int(np.frombuffer(img[o:o + 4].tobytes(), dtype=np.uint32)[0])
-        keys = img[o + 4:o + 4 + 8 * cnt].reshape(cnt, 8)
-        vals = img[o + 4 + 8 * cnt:o + 4 + 20 * cnt].reshape(cnt, 12)
-        prev = None
-        for kk in keys:
-            kb_ = kk.tobytes()
-            assert lib.kmr_hash(kb_, 8) & (nb - 1) == b
-            assert prev is None or prev < kb_
-            prev = kb_
-        if cnt:
-            counts = np.ascontiguousarray(vals[:, :2]).view(np.uint16).reshape(-1)
-            assert np.array_equal(p.getCount(keys), counts.astype(np.uint32))
-            assert counts.min() >= 2
-            checked += cnt
-    assert checked > 1000
-    # the same input through the open-addressed device table: statistics and image digest must agree
-    st0, dg0 = p.stats(), _image_digest(p)
-    p.close()
-    del p, imgs, img
-    p1 = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0, build_mode=1))
-    p1.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
-    p1.finalize(2)
-    assert p1.stats() == st0
-    assert _image_digest(p1) == dg0
-    p1.close()
-
-
 @pytest.mark.parametrize("mode", MODES)
 def test_long_reads_within_tile(mode):
     """reads near the per-wavefront LDS tile limit (9 952 bases): one tile then holds few reads but
@@ -921,299 +880,6 @@ def test_ext_hot_kmer_takes_the_wide_tally_table(mode):
     assert p.getCount(hot)[0] == 65535 == o.lookup(hot)[0]
 
 
-def _image_digest(sp, which=KMR_MAP_WEAK):
-    import hashlib
-    img = sp.image(which)
-    return img.size, hashlib.blake2b(memoryview(img), digest_size=16).hexdigest()
-
-
-def test_c2_full_size_noisy_qualities():
-    """BASELINE.json configs[1] at full size with qualities of their own (bench.py --quality noisy: the general extraction with the
-    weight chain, 9-byte records, weights summed in f64): the default build against the device-table build (build_mode 1, an
-    independent algorithm) -- statistics and histogram equal, and the two weak images equal BYTE FOR BYTE (layout, keys, counts,
-    direction biases) except inside weightedCount fields, where the two sides add the same weights in different orders and round
-    once: those stay within SURVEY section 7's 1e-5 * count.  Found from the bytes that differ, so nothing is walked in Python."""
-    import torch
-    import bench
-    n = 10_000_000
-    dev = torch.device("cuda", 0)
-    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev, "noisy")
-    torch.cuda.synchronize()
-    res = []
-    for mode in (0, 1):
-        p = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0, build_mode=mode))
-        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
-        p.finalize(2)
-        st = p.stats()
-        hist = p.histogram(4096)[0]
-        assert st["raw_kmers"] == n * 120 and 0 < st["raw_good_kmers"] < st["raw_kmers"]      # the weight floor discards some
-        assert int(hist.sum()) == st["weak_entries"]
-        assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
-        res.append((st, hist, p.image(KMR_MAP_WEAK)))
-        p.close()
-        del p
-    (st0, h0, a), (st1, h1, b) = res
-    assert st0 == st1 and st0["weak_entries"] > 10_000_000
-    assert np.array_equal(h0, h1)
-    assert _images_equal_outside_weights(a, b, 8) < st0["weak_entries"]
-
-
-def _images_equal_outside_weights(a, b, kb):
-    """two weak images (12-byte values, keys of kb bytes) equal byte for byte except inside weightedCount fields, which may differ by
-    1e-5 * count; found from the bytes that differ, nothing is walked in Python.  Returns the entries that differ."""
-    assert a.size == b.size
-    nb = int(np.frombuffer(a[:8].tobytes(), dtype=np.uint64)[0])
-    assert np.array_equal(a[:16 + 8 * nb], b[:16 + 8 * nb])               # header and bucket offsets
-    offs = np.frombuffer(a[16:16 + 8 * nb].tobytes(), dtype=np.uint64).astype(np.int64)
-    assert np.all(np.diff(offs) >= 4)
-    d = np.flatnonzero(a != b).astype(np.int64)
-    if not d.size:
-        return 0
-    bucket = np.searchsorted(offs, d, side="right") - 1
-    o = offs[bucket]
-    cnt = np.zeros(d.size, dtype=np.int64)
-    for j in range(4):                                                     # the bucket's entry count (little-endian u32 at its offset)
-        cnt |= a[o + j].astype(np.int64) << (8 * j)
-        assert np.array_equal(a[o + j], b[o + j])
-    rel = d - (o + 4 + kb * cnt)                                           # position inside the bucket's value array
-    assert np.all(rel >= 0) and np.all(rel < 12 * cnt)
-    assert np.all((rel % 12 >= 4) & (rel % 12 < 8))                        # only bytes of the f32 weightedCount differ
-    e = np.unique(o + 4 + kb * cnt + 12 * (rel // 12))                     # the entries concerned
-
-    def field(img, at, width):
-        return np.stack([img[e + at + j] for j in range(width)], axis=1).copy()
-    count = field(a, 0, 2).view(np.uint16).reshape(-1).astype(np.float64)
-    wa, wb = field(a, 4, 4).view(np.float32).reshape(-1), field(b, 4, 4).view(np.float32).reshape(-1)
-    assert np.all(np.abs(wa.astype(np.float64) - wb) <= 1e-5 * count)
-    return int(e.size)
-
-
-@pytest.mark.parametrize("k,quality", [(51, "noisy"), (64, "flat"), (96, "flat"), (96, "noisy"), (127, "flat"), (127, "noisy")])
-def test_multiword_keys_at_scale_modes_agree(k, quality):
-    """two-, three- and four-word keys at 3 M reads x 150 bp of a 30x genome (up to 3e8 k-mers), flat qualities and qualities of
-    their own: the default build against the device-table build -- statistics equal, weak images byte for byte (flat), or byte for
-    byte outside weightedCount and there within 1e-5 * count (noisy: the same weights added in another order)."""
-    import torch
-    import bench
-    n = 3_000_000
-    dev = torch.device("cuda", 0)
-    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 7, 0, dev, quality)
-    torch.cuda.synchronize()
-    res = []
-    for mode in (0, 1):
-        p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode))
-        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
-        p.finalize(2)
-        st = p.stats()
-        assert st["raw_kmers"] == n * (150 - k + 1) and st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
-        res.append((st, p.image(KMR_MAP_WEAK), p.kb))
-        p.close()
-        del p
-    (st0, a, kb), (st1, b, _) = res
-    assert st0 == st1 and st0["weak_entries"] > 100_000
-    if quality == "flat":
-        assert np.array_equal(a, b)
-    else:
-        assert _images_equal_outside_weights(a, b, kb) < st0["weak_entries"]
-
-
-@pytest.mark.parametrize("k,min_depth,sep", [(31, 1, 1), (31, 3, 1), (31, 1, 0), (51, 1, 1)])
-def test_singleton_maps_at_scale_modes_agree(k, min_depth, sep):
-    """3 M reads with the singleton map kept (min-depth 1) or purged below 3, with and without a separate singleton map: the default
-    build against the device-table build -- statistics, weak image and singleton image (1-byte values: the quantised weight)
-    byte for byte.  The small cases of test_singleton_map_and_min_depth_variants go against the oracle; this one is about size."""
-    import torch
-    import bench
-    n = 3_000_000
-    dev = torch.device("cuda", 0)
-    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 5, 0, dev)
-    torch.cuda.synchronize()
-    res = []
-    for mode in (0, 1):
-        p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode, separate_singletons=sep))
-        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
-        p.finalize(min_depth)
-        res.append((p.stats(), _image_digest(p, KMR_MAP_WEAK), _image_digest(p, KMR_MAP_SINGLETON)))
-        p.close()
-        del p
-    assert res[0] == res[1]
-    assert res[0][0]["unique_kmers"] > 1_000_000
-
-
-@pytest.mark.parametrize("world,k", [(2, 31), (4, 31), (2, 51)])
-def test_list_exchange_at_scale_on_one_gpu(world, k):
-    """The N > 1 build of the default mode at a size where a rank packs and adopts millions of chunks (the two-rank tests on one GPU
-    use 6e4 reads): `world` handles on one GPU, 2 M reads each of one shared genome, every rank extracts into the job's lists with
-    global stream ordinals, packs what the others own (kmr_sk_exchange_counts / _pack_dev), the segments are handed over in device
-    memory as the all-to-all would deliver them, every owner adopts and finalizes.  The ranks' maps must partition the spectrum of
-    one handle fed the same reads in rank order: unique / weak / singleton counts and the count histograms add up to the whole's."""
-    import torch
-    import bench
-    n, L = 2_000_000, 150
-    dev = torch.device("cuda", 0)
-    reads = [bench.gen_reads(torch, n, 5 * n * world, 4, r, dev) for r in range(world)]
-    torch.cuda.synchronize()
-    per = L - k + 1
-    hs, packed = [], []
-    for r in range(world):
-        h = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per * world, device=0, rank=r, world_size=world, build_mode=3))
-        b, q, o = reads[r]
-        h.sk_exchange_begin()
-        h.set_stream_origin(r * n * L)
-        h.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr(), n, n * L, r * n)
-        chunks, granules = h.sk_exchange_counts()
-        sc = [int(c) if j != r else 0 for j, c in enumerate(chunks)]
-        sg = [int(g) if j != r else 0 for j, g in enumerate(granules)]
-        goff = [int(x) for x in np.concatenate([[0], np.cumsum(sg)[:-1]])]
-        coff = [int(x) for x in np.concatenate([[0], np.cumsum(sc)[:-1]])]
-        data = torch.empty((max(sum(sg), 1), 4), dtype=torch.int32, device=dev)
-        meta = torch.empty((max(sum(sc), 1), 2), dtype=torch.int32, device=dev)
-        h.sk_exchange_pack(data.data_ptr(), meta.data_ptr(), goff, coff)
-        assert sum(sc) > 100_000                                              # the size this test is about
-        hs.append(h)
-        packed.append((data, meta, sc, sg, goff, coff))
-    for owner in range(world):
-        for r in range(world):
-            if r == owner:
-                continue
-            data, meta, sc, sg, goff, coff = packed[r]
-            if sc[owner]:
-                hs[owner].sk_exchange_adopt(data[goff[owner]:].data_ptr(), meta[coff[owner]:].data_ptr(), sc[owner], sg[owner])
-        hs[owner].sync()
-    tot = {"unique_kmers": 0, "weak_entries": 0, "singleton_kmers": 0}
-    hist = None
-    for h in hs:
-        h.finalize(2)
-        st = h.stats()
-        for key in tot:
-            tot[key] += st[key]
-        hh = h.histogram(1024)[0].astype(np.int64)
-        hist = hh if hist is None else hist + hh
-        h.close()
-    del packed
-    whole = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per * world, device=0))
-    for r in range(world):
-        b, q, o = reads[r]
-        whole.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr(), n, n * L, r * n)
-    whole.finalize(2)
-    st = whole.stats()
-    assert st["raw_kmers"] == world * n * per
-    assert {key: st[key] for key in tot} == tot
-    assert np.array_equal(whole.histogram(1024)[0].astype(np.int64), hist)
-    whole.close()
-
-
-def test_c2_full_size_packed_feed_in_pieces():
-    """The PCIe-inclusive leg of bench.py at full size (configs[1]): the batch handed over 2-bit packed as the reference's Read
-    keeps it (TwoBitSequence::compressSequence, one quality character for all bases), in four calls, staged by the extraction as
-    it lies -- statistics and weak image must equal those of the text feed in one call byte for byte (the same stream ordinals,
-    hence the same first sightings)."""
-    import torch
-    import bench
-    n, rl, pieces = 10_000_000, 150, 4
-    dev = torch.device("cuda", 0)
-    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 1, 0, dev)
-    PB = (rl + 3) // 4
-    db = torch.empty(n * PB + 64, dtype=torch.uint8, device=dev)
-    for lo in range(0, n, 1 << 20):
-        m = min(1 << 20, n - lo)
-        c = bases[lo * rl:(lo + m) * rl].view(m, rl)
-        c = ((c >> 1) & 3) ^ ((c >> 2) & 1)                                # A C G T -> 0 1 2 3
-        c = torch.nn.functional.pad(c, (0, PB * 4 - rl)).view(m, PB, 4)
-        db[lo * PB:(lo + m) * PB] = (c[:, :, 0] << 6 | c[:, :, 1] << 4 | c[:, :, 2] << 2 | c[:, :, 3]).reshape(-1)
-    tb_off = torch.arange(n + 1, device=dev, dtype=torch.int64) * PB
-    torch.cuda.synchronize()
-    p = ka.KmerSpectrum(ka.default_config(31, estimated_raw_kmers=n * 120, device=0))
-    p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * rl, 0)
-    p.finalize(2)
-    st0, dg0 = p.stats(), _image_digest(p)
-    p.reset()
-    per = (n + pieces - 1) // pieces
-    for c in range(pieces):
-        r0, r1 = c * per, min(n, (c + 1) * per)
-        p.buildKmerSpectrumTwoBitDevice(db.data_ptr(), tb_off.data_ptr() + 8 * r0, offsets.data_ptr() + 8 * r0, r1 - r0, (r1 - r0) * rl,
-                                        quals_ptr=None, uniform_quality=33 + 40, first_read_idx=r0)
-    p.finalize(2)
-    assert p.stats() == st0 and st0["raw_kmers"] == n * 120
-    assert _image_digest(p) == dg0
-    p.close()
-
-
-def test_extension_values_at_scale_modes_agree():
-    """MeraculousCounter's settings (BASELINE.json configs[4]: k = 21, extension values, min quality 2, no weight floor) at 5 M
-    synthetic reads = 6.5e8 k-mers: the default build (extension records on the super-k-mer lists) against the device-table build
-    (build_mode 1) -- statistics equal and the weak images, 60-byte values with all twelve tallies, byte for byte."""
-    import torch
-    import bench
-    n, k = 5_000_000, 21
-    dev = torch.device("cuda", 0)
-    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev)
-    torch.cuda.synchronize()
-    res = []
-    for mode in (0, 1):
-        p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * (150 - k + 1), device=0, build_mode=mode, value_kind=KMR_VALUE_EXT,
-                                              min_weight=0.0, min_quality_score=2))
-        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * 150, 0)
-        p.finalize(2)
-        st = p.stats()
-        assert st["raw_kmers"] == n * (150 - k + 1) == st["raw_good_kmers"]
-        assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
-        res.append((st, _image_digest(p)))
-        p.close()
-        del p
-    assert res[0][0] == res[1][0] and res[0][0]["weak_entries"] > 10_000_000
-    assert res[0][1] == res[1][1]
-
-
-def test_c4_full_size_k51():
-    """BASELINE.json configs[3] exactly as SURVEY 8(d) defines it: k = 51 (two-word keys), 50 M synthetic 150 bp reads of a 250 Mbp
-    genome, seed 3 = 5e9 k-mers over 7.5e9 input bases -- more than 2^32, so the stream ordinal that decides which sighting of a k-mer was its first (directionBias, the
-    quantised first weight) has to be wider than 32 bits.  The default build (super-k-mer lists) must conserve the k-mers, be
-    consistent with its own histogram and lookups, and give the weak map of the device-table build (build_mode 1, 40-bit
-    ordinals in the slots) BYTE FOR BYTE -- counts, weights and direction biases; build_mode 2's 16-byte records carry 32
-    ordinal bits and must refuse the input instead of being quietly wrong."""
-    import torch
-    import bench
-    n, rl, k = 50_000_000, 150, 51
-    dev = torch.device("cuda", 0)
-    bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev, read_len=rl)
-    torch.cuda.synchronize()
-    per = rl - k + 1
-    digests, stats = {}, {}
-    for mode in (0, 1):
-        p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per, device=0, build_mode=mode))
-        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * rl, 0)
-        p.finalize(2)
-        st = p.stats()
-        assert st["raw_kmers"] == n * per == st["raw_good_kmers"]
-        assert st["unique_kmers"] == st["weak_entries"] + st["singleton_kmers"]
-        if mode == 0:
-            hist = p.histogram(4096)[0]
-            assert int(hist.sum()) == st["weak_entries"]
-            assert int((hist * np.arange(hist.size, dtype=np.uint64)).sum()) + st["singleton_kmers"] == st["raw_good_kmers"]
-            # lookups of k-mers cut out of the reads
-            host = bases[:200 * rl].cpu().numpy().tobytes()
-            lib = ka.load()
-            import ctypes as C
-            keys = np.zeros((200, p.kb), dtype=np.uint8)
-            for r in range(200):
-                packed = np.zeros(p.kb, dtype=np.uint8)
-                lib.kmr_compress_sequence(host[r * rl + 7:r * rl + 7 + k], k, packed.ctypes.data_as(C.POINTER(C.c_uint8)), None, None, 0)
-                lib.kmr_least_complement(packed.ctypes.data_as(C.POINTER(C.c_uint8)), k, keys[r].ctypes.data_as(C.POINTER(C.c_uint8)))
-            got = p.getCount(keys)
-            assert (got >= 1).sum() > 100 and got.max() < 200      # ~20x coverage of a random genome
-        stats[mode] = st
-        digests[mode] = _image_digest(p)
-        p.close()
-        del p
-    assert stats[0] == stats[1]
-    assert digests[0] == digests[1]
-    p = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per, device=0, build_mode=2))
-    with pytest.raises(ka.KmerSpectrumError, match="32-bit stream ordinal"):
-        p.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n, n * rl, 0)
-    p.close()
-
-
 @pytest.mark.parametrize("k", [31, 51])
 def test_million_noisy_reads_against_the_oracle(k):
     """1 M reads x 100 bp with noisy qualities (the discard path and the divide chain are live) against the SERIAL
@@ -1278,6 +944,41 @@ def test_low_complexity_reads(mode):
         for kw, tune in ((dict(separate_singletons=0), dict()), (dict(), dict(long_list_chunks=8))):
             o2, p2 = run_both(default_config(31, estimated_raw_kmers=24000 * 120, **kw), rb, mode=3, **tune)
             assert compare_weak_images(o2.image(KMR_MAP_WEAK), p2.image(KMR_MAP_WEAK), p2.kb, False) == o2.stats()["weak_entries"]
+
+
+@pytest.mark.parametrize("k,ext,kw,tune", [(31, False, {}, {}), (31, False, dict(separate_singletons=0), {}), (51, False, {}, dict(long_list_chunks=8)),
+                                           (21, True, dict(value_kind=KMR_VALUE_EXT, min_weight=0.0, min_quality_score=2), {})])
+def test_high_count_kmers_keep_the_reference_order(k, ext, kw, tune):
+    """weightedCount of k-mers seen 10^3 ... 6 x 10^4 times (unsaturated), noisy weights: the reference adds the weights one after
+    the other in arrival order into a float (weightedCount += weight, src/KmerTrackingData.h:427-448), which at these counts drifts
+    from the exact sum by far more than 1e-5 * count; the default build redoes every k-mer seen SK_ORDERED_FROM = 256 times or more
+    from its sightings in input order (sat_*_kernel) and must give the SERIAL oracle's value BIT FOR BIT -- with and without a
+    singleton map (the first sighting comes back quantised, or not), with lists counted in pieces, with extension values.
+    Three repeat families (400 bases under 4 000 and 40 000 reads, 150 bases under 60 000 reads of 100 bases) make ~900 keys at
+    counts from several hundred to ~45 000."""
+    rng = np.random.default_rng(1234 + k)
+    L = 100
+    seqs, quals = [], []
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    qv = np.frombuffer(b"I?5+#", dtype=np.uint8)
+    for flen, cov_reads in ((400, 4000), (400, 40000), (150, 60000)):
+        fam = lut[rng.integers(0, 4, flen)]
+        for _ in range(cov_reads):
+            st = int(rng.integers(0, flen - L + 1))
+            r = fam[st:st + L]
+            if rng.random() < 0.5:
+                r = (lut[3 - np.searchsorted(lut, r[::-1])])
+            seqs.append(r.tobytes())
+            quals.append(qv[rng.choice(5, L, p=[0.80, 0.10, 0.05, 0.04, 0.01])].tobytes())
+    order = rng.permutation(len(seqs))
+    rb = ReadBatch([seqs[i] for i in order], [quals[i] for i in order])
+    cfg = default_config(k, estimated_raw_kmers=rb.n * (L - k + 1), **kw)
+    o, p = run_both(cfg, rb, min_depth=2, mode=0, **tune)
+    keys, cnt, _, _, _ = o.entries()
+    assert ((cnt >= 2000) & (cnt < 65535)).sum() >= 100 and (cnt >= 256).sum() >= 500
+    assert cnt.max() > 20000
+    n = compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, ext, exact_from=256)
+    assert n == o.stats()["weak_entries"]
 
 
 @pytest.mark.parametrize("k,chunks", [(31, 2), (51, 3), (27, 16)])

@@ -146,3 +146,58 @@ def test_count_saturation_and_direction():
     assert fwd["raw_good_kmers"] == 6 * n and fwd["unique_kmers"] == 6
     # every occurrence has the same orientation: bias is 0 or count-1 (first sighting lost)
     assert set(int(d) for d in dirb) <= {0, 65534}
+
+
+@pytest.mark.parametrize("gold_name,mrl,both,out_base", [
+    ("1000-Filtered-0.85.fastq", 0.85, False, 64), ("1000-Filtered-0.85.std.fastq", 0.85, False, 33),
+    ("1000-Filtered-readlength.fastq", 1.0, False, 64), ("1000-Filtered-readlength-both.fastq", 1.0, True, 64), ("1000-Filtered.fastq", 25.0, False, 64)])
+@pytest.mark.parametrize("fq,start", [("1000.fastq", 64), ("1000.std.fastq", 33)])
+def test_filterreads_selection_goldens(fq, start, gold_name, mrl, both, out_base):
+    """test/runFilterTests.sh:43-63: the reference's other FilterReads outputs -- `--min-read-length 0.85` (the artifact filter
+    trims where 85 % of the read survive and discards otherwise; the spectrum, hence the scores, are those of the reads so filtered),
+    `--min-read-length 1` (only untrimmed reads pass; a pair is kept when either read passes) and `--min-passing-in-pair 2` (both
+    must) -- reproduced WHOLE FILE, byte for byte (names, labels, trimmed sequences and qualities, the one-base placeholder of an
+    emptied read, the order), from either quality encoding of the input to either encoding of the output: artifact filter ->
+    spectrum of the filtered reads -> scoring / trimming (all the oracle's) -> isPassingRead / isPassingPair / writePicks
+    (tests/refsemantics.py).  (test/ also holds `-readlength.std`, `-readlength-both.std` and `1000-Filtered.std.fastq`: the script
+    uses none of them and they carry no labels at all -- files of an older version, not fixtures.)"""
+    import re
+    from helpers import OracleArtifactFilter, apply_artifact_result, artifact_config, oracle_weighted_kmers
+    from refsemantics import filterreads_output, score_and_trim
+    k = 31
+    rb = read_fastq(os.path.join(GOLDEN, fq))
+    gold = open(os.path.join(GOLDEN, gold_name), "rb").read()
+    f = OracleArtifactFilter(artifact_config(edit_distance=1, fastq_start_char=start, min_read_length=mrl),
+                             open(os.path.join(GOLDEN, "artifact_sequences.fa"), "rb").read())
+    res = f.apply(rb)
+    assert not res["remnant_len"].any()
+    fr = apply_artifact_result(rb, res)
+    cfg = default_config(k, fastq_start_char=start, estimated_raw_kmers=(76 - k + 1) * 1000)
+    s = OracleSpectrum(cfg)
+    s.add_reads(fr)
+    s.finalize(2)
+    labels, to, tl, sc, disc = [], [], [], [], []
+    for i in range(rb.n):
+        d = res["action"][i] == 2
+        disc.append(d)
+        if d:
+            labels.append(b""); to.append(0); tl.append(0); sc.append(0.0)
+            continue
+        seq = fr.seq(i)
+        keys, w, ext = oracle_weighted_kmers(cfg, seq, fr.qual(i))
+        o, l, score, trimmed = score_and_trim(s.lookup(keys) if len(keys) else [], seq, k, 2, "MEDIAN")
+        label = b""
+        if res["action"][i] == 1:
+            label += b"AFTrim:%d+%d " % (res["min_pass"][i], res["max_pass"][i] - res["min_pass"][i])
+        if trimmed:
+            label += b"Trim:%d+%d " % (o, l)
+        label += b"MedianScore:%d" % int(score + 0.5)
+        labels.append(label); to.append(o); tl.append(l); sc.append(score)
+    names = [nm.split(b" ")[0] for nm in rb.names]
+    text = filterreads_output(names, [fr.seq(i) for i in range(rb.n)], [fr.qual(i) for i in range(rb.n)], labels, disc, to, tl, sc,
+                              2, mrl, both, qual_shift=out_base - start, out_base=out_base)
+    text, gold = text.replace(b"\t", b" "), gold.replace(b"\t", b" ")          # the script compares with diff -w
+    if text != gold:
+        a, b = text.split(b"\n"), gold.split(b"\n")
+        first = next((j for j in range(min(len(a), len(b))) if a[j] != b[j]), None)
+        raise AssertionError((len(a), len(b), first, a[first - 1:first + 3] if first is not None else None, b[first - 1:first + 3] if first is not None else None))
