@@ -77,6 +77,7 @@ struct Tuning {
 	uint64_t list_aim = 0;             /* k-mers per list the list count of a single GPU's build aims for (0: the defaults of add_reads_superkmer_t) */
 	bool pow2_lists = false;           /* the list count of build_mode 3 always a power of two (A/B runs, tests of both list functions) */
 	bool no_packed_direct = false;     /* kmr_add_reads_twobit* always unpack to text first (A/B runs, tests of the unpack path) */
+	bool no_uniform_count = false;     /* never take sk_count_kernel<.., UNI> (A/B runs, tests of the general count pass on one-weight builds) */
 	bool no_lean_extract = false;      /* never take sk_extract_lean_kernel (A/B runs, tests of the general kernel on uniform qualities) */
 	bool exchange_fail_once = false;   /* tests: the next kmr_exchange_add_reads_dev of this rank fails locally (the other ranks must come back with an error, not hang) */
 	bool no_coarse_lists = true;       /* exchange: scatter into the job's fine lists (default) or, kmr_tune("coarse_lists", 1), into coarse ones that the owner splits before the count pass (sk_refine_kernel: not yet fast enough to pay) */
@@ -153,6 +154,9 @@ struct kmr_handle {
 	/* build_mode 3 (kmr_superkmer.hpp): list words, minimizer geometry, table of k-fold quality products */
 	unsigned long long *sk_state = nullptr; uint32_t sk_bits = 0, sk_m = 0, sk_off = 0, sk_win = 0; double *dPk = nullptr;
 	double hP[256], hPk[256];              /* host copies of the probability table and of its k-fold products */
+	/* does every record of the lists carry ONE weight (all calls went through the lean extraction with the same quality character)?  The
+	 * host knows for its own calls (sk_uni_w: SK_UNI_NONE before the first; sk_uni_mixed), a device pair collects it for adopted records */
+	uint32_t sk_uni_w = 0xffffffffu; bool sk_uni_mixed = false; uint32_t *d_uni = nullptr;
 	unsigned int *qrange = nullptr; bool qual_mixed = false;      /* sk_qual_range_kernel's answer; a build that has seen two different quality characters stops asking */
 	/* exchange with world_size > 1: sk_bits are the COARSE lists reads are scattered into and that travel; each holds 2^sk_fine_shift
 	 * fine lists, made by sk_refine_kernel before the count pass (fine state: sk_fine_state, 2^(sk_bits + sk_fine_shift) words) */
@@ -521,7 +525,7 @@ template <int W, bool EXT> int finalize_t(kmr_handle *h, uint32_t min_depth) {
 	int rc = sync_state(h);
 	if (rc) return rc;
 	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
-	FinalizeParams f; f.kb = h->hkb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	FinalizeParams f; f.kb = h->hkb; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing; f.uni_wbits = 0;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	uint32_t *wc = nullptr, *sc = nullptr; FinalizeCounters *fc = nullptr;
 	HIPCHK(h, dev_malloc((void **)&wc, 4 * h->nb_weak)); HIPCHK(h, dev_malloc((void **)&sc, 4 * h->nb_sing)); HIPCHK(h, dev_malloc((void **)&fc, sizeof(FinalizeCounters)));
@@ -1061,7 +1065,7 @@ template <int W, bool EXT> int finalize_partition_t(kmr_handle *h, uint32_t min_
 	if (rc) return rc;
 	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
 	const uint64_t G = h->stats.raw_good_kmers;     /* records in the level-1 pool */
-	FinalizeParams f; f.kb = h->hkb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	FinalizeParams f; f.kb = h->hkb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing; f.uni_wbits = 0;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
 	rc = arena_reset(h); if (rc) return rc;
@@ -1533,6 +1537,12 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 	bool lean = false; float wK = 1.0f;
 	if (!filt && !h->ext && !sp_debug_extract(h)) { int rcq = sk_uniform_weight(h, rvAll, lean, wK); if (rcq) return rcq; }      /* (extension values want every neighbour's quality: the general kernel) */
 	if (h->packed_direct && (!lean || h->cfg.size_tracker)) return fail(h, KMR_ERR_STATE, "internal: a packed batch handed to an extraction that wants text");      /* (sk_packed_direct_ok said otherwise) */
+	if (rvAll.n_reads) {      /* one weight for the whole build so far? (the count pass's UNI form) */
+		uint32_t wb; memcpy(&wb, &wK, 4);
+		if (!lean) h->sk_uni_mixed = true;
+		else if (h->sk_uni_w == SK_UNI_NONE) h->sk_uni_w = wb;
+		else if (h->sk_uni_w != wb) h->sk_uni_mixed = true;
+	}
 	if (!h->sk_state) {
 		/* lists: about 1100 k-mers each, as the final lists of the two-level partition */
 		/* the list space is the whole job's (with world_size > 1 a rank owns every world_size-th list): sized from the caller's estimate
@@ -1751,7 +1761,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	if (rc) return rc;
 	hipEvent_t ea, eb; time_begin(h, 1, &ea, &eb);
 	const uint64_t G = h->stats.raw_good_kmers;
-	FinalizeParams f; f.kb = h->hkb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing;
+	FinalizeParams f; f.kb = h->hkb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing; f.uni_wbits = 0;
 	const bool keepSing = f.has_singletons && min_depth <= 1;
 	if (!h->l1.head) { rc = pool_reserve(h, h->l1, 0, false); if (rc) return rc; }
 	rc = arena_reset(h); if (rc) return rc;
@@ -1771,6 +1781,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		if (head > h->l1.cap) head = h->l1.cap;
 		if (h->sk_fine_cap < nlf) {
 			if (h->sk_fine_state) hipFree(h->sk_fine_state);
+	if (h->d_uni) hipFree(h->d_uni);
 			h->sk_fine_state = nullptr; h->sk_fine_cap = 0;
 			HIPCHK(h, dev_malloc((void **)&h->sk_fine_state, 8 * nlf)); h->sk_fine_cap = nlf;
 		}
@@ -1811,6 +1822,19 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	std::vector<unsigned long long> bounds; std::vector<uint64_t> snap_raw, snap_good;
 	SkTrackView tv; tv.bounds = nullptr; tv.n = 0; tv.d_unique = tv.d_single = nullptr;
 	const bool tracking = h->cfg.size_tracker != 0;
+	/* one weight for every record of the lists (own calls: host state; adopted records: the device pair)?  Then the count pass's UNI form */
+	bool uni = false;
+	f.uni_wbits = 0;
+	if (!tracking && !ext && !h->sk_uni_mixed && !h->tune.no_uniform_count) {
+		uint32_t w = h->sk_uni_w; bool mixed = false;
+		if (h->d_uni) {
+			uint32_t dv[2] = {SK_UNI_NONE, 0u};
+			HIPCHK(h, hipMemcpy(dv, h->d_uni, 8, hipMemcpyDeviceToHost));
+			if (dv[1]) mixed = true;
+			else if (dv[0] != SK_UNI_NONE) { if (w == SK_UNI_NONE) w = dv[0]; else if (w != dv[0]) mixed = true; }
+		}
+		if (!mixed && w != SK_UNI_NONE) { uni = true; f.uni_wbits = w; }
+	}
 	if (tracking) {
 		bounds = h->trk_bounds; snap_raw = h->trk_snap_raw; snap_good = h->trk_snap_good;
 		if (bounds.size() > SK_TRACK_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "size tracker: more than 512 elements");
@@ -1867,7 +1891,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		if (ext) { out.wkeys = (uint64_t *)h->uw_keys; out.wvals = (uint32_t *)h->uw_vals; out.wentries = nullptr; out.wcap = h->uw_cap; out.spkt = (uint32_t *)h->us_pkt; out.weakCount = wc; }
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (nl / lgMain.list_stride + SK_LBATCH) / SK_LBATCH);
-		auto kern = ext ? sk_count_kernel<W, COUNT_LOG2S_EXT, false, true> : (tracking ? sk_count_kernel<W, COUNT_LOG2S, true> : sk_count_kernel<W, COUNT_LOG2S, false>);
+		auto kern = ext ? sk_count_kernel<W, COUNT_LOG2S_EXT, false, true> : (tracking ? sk_count_kernel<W, COUNT_LOG2S, true> : (uni ? sk_count_kernel<W, COUNT_LOG2S, false, false, true> : sk_count_kernel<W, COUNT_LOG2S, false>));
 		const size_t smem = ext ? sk_count_smem_bytes<W, COUNT_LOG2S_EXT, false, true>() : (tracking ? sk_count_smem_bytes<W, COUNT_LOG2S, true>() : sk_count_smem_bytes<W, COUNT_LOG2S, false>());
 		if (tracking) HIPCHK(h, hipMemsetAsync(tv.d_unique, 0, 8 * (tv.n + 1), h->stream));
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -2109,6 +2133,8 @@ int kmr_reset(kmr_handle *h) {
 		h->l1.used_ub = 0;
 		h->inserted_records = 0;
 		h->qual_mixed = false;
+		h->sk_uni_w = SK_UNI_NONE; h->sk_uni_mixed = false;
+		if (h->d_uni) { const uint32_t init[2] = {SK_UNI_NONE, 0u}; HIPCHK(h, hipMemcpyAsync(h->d_uni, init, 8, hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
 		if (h->sk_state) hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(sk_list_count(h->sk_bits))), dim3(256), 0, h->stream, h->sk_state, sk_list_count(h->sk_bits));
 		if (h->l1_state) {      /* what an unfinished build kept back is dropped with its pool */
 			hipLaunchKernelGGL(partition_state_init_kernel, dim3(partition_blocks(h)), dim3(256), 0, h->stream, h->l1_state,
@@ -2163,6 +2189,7 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "stream_lookups") h->tune.no_stream_lookups = value == 0;
 	else if (k == "long_list_chunks") h->tune.long_list_chunks = value < 2 ? 2 : (uint64_t)value;
 	else if (k == "lean_extract") h->tune.no_lean_extract = value == 0;
+	else if (k == "uniform_count") h->tune.no_uniform_count = value == 0;
 	else if (k == "packed_direct") h->tune.no_packed_direct = value == 0;
 	else if (k == "pow2_lists") h->tune.pow2_lists = value != 0;
 	else if (k == "list_aim") h->tune.list_aim = value >= 1 ? (uint64_t)value : 0;
@@ -3624,6 +3651,11 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
 	uint64_t *start = (uint64_t *)h->adopt_buf; uint32_t *cnt = (uint32_t *)(h->adopt_buf + 8 * (n_chunks + 1));
 	hipLaunchKernelGGL(sk_meta_counts_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, h->stream, (const uint2 *)dev_meta, n_chunks, cnt);
 	rc = exclusive_scan(h, cnt, n_chunks, start);
+	if (!rc && !h->d_uni) {
+		if (dev_malloc((void **)&h->d_uni, 8) != hipSuccess) rc = fail(h, KMR_ERR_OOM, "uniform-weight flags");
+		else { const uint32_t init[2] = {SK_UNI_NONE, 0u}; if (hipMemcpyAsync(h->d_uni, init, 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = fail(h, KMR_ERR_HIP, "uniform-weight flags"); else hipStreamSynchronize(h->stream); }
+	}
+	if (!rc) hipLaunchKernelGGL(sk_uniform_check_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, h->stream, (const uint4 *)dev_data, start, cnt, n_chunks, h->d_uni);
 	if (!rc) {
 		hipLaunchKernelGGL(sk_adopt_kernel, dim3(grid), dim3(SK_ADOPT_WAVES * 64), 0, h->stream, (const uint4 *)dev_data, (const uint2 *)dev_meta, start, n_chunks, sk_params(h), pool_view(h, h->l1));
 		if (hipGetLastError() != hipSuccess) rc = fail(h, KMR_ERR_HIP, "sk_adopt_kernel launch");

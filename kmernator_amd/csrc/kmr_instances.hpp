@@ -35,7 +35,8 @@ static const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
 #define KMR_SKC(W, TRACK) KMR_SKCX(W, TRACK, false)
 #define KMR_SKCX(W, TRACK, EXT) KMR_T __global__ void sk_count_kernel<W, EXT ? COUNT_LOG2S_EXT : COUNT_LOG2S, TRACK, EXT>(PoolView, const uint64_t *, const uint64_t *, uint64_t, uint32_t, CountOut, FinalizeParams, unsigned int *, uint32_t, SkTrackView, SkLong<W>);
 #define KMR_SKL(W) KMR_T __global__ void sk_lookup_kernel<W>(PoolView, const uint64_t *, const uint64_t *, uint64_t, uint32_t, const uint64_t *, const uint64_t *, const uint32_t *, uint32_t *, uint64_t, unsigned int *, const uint64_t *, const uint64_t *, const uint32_t *, uint64_t, uint64_t);
-#define KMR_SKC_W(W) KMR_SKC(W, false) KMR_SKC(W, true) KMR_SKCX(W, false, true) KMR_SKL(W)
+#define KMR_SKCU(W) KMR_T __global__ void sk_count_kernel<W, COUNT_LOG2S, false, false, true>(PoolView, const uint64_t *, const uint64_t *, uint64_t, uint32_t, CountOut, FinalizeParams, unsigned int *, uint32_t, SkTrackView, SkLong<W>);
+#define KMR_SKC_W(W) KMR_SKC(W, false) KMR_SKCU(W) KMR_SKC(W, true) KMR_SKCX(W, false, true) KMR_SKL(W)
 
 /* build modes 1 and 2, lookups, owner requests: the k-mer extraction with its Ops */
 #define KMR_EX(W, EXT, OP, SUB) KMR_T __global__ void extract_kernel<W, EXT, OP, SUB>(ReadsView, DevParams, OP);

@@ -967,6 +967,7 @@ struct FinalizeParams {
 	uint32_t min_depth;
 	uint32_t has_singletons;      /* cfg.separate_singletons */
 	uint64_t nb_weak, nb_sing;
+	uint32_t uni_wbits;           /* sk_count_kernel<.., UNI>: the one weight of every k-mer of the build */
 };
 struct FinalizeCounters { unsigned long long unique, singletons, weak_kept, sing_kept, saturated, sat_sightings; };      /* saturated: keys seen more than 65 535 times (build_mode 3 counts them and their sightings) */
 

@@ -1384,10 +1384,15 @@ static const unsigned long long SK_KEY_PENDING = ~0ull;
 static const uint32_t SK_ORDERED_FROM = 256;
 static const unsigned long long SK_OSLAB = 2048;      /* entries a wavefront reserves at a time in the count pass's output */
 
-template <int W, int LOG2S, bool TRACK = false, bool EXT = false>
+/* UNI: every record of every list is uniform and carries ONE weight, f.uni_wbits (a build whose calls all went through the lean
+ * extraction with the same quality character, or with none): the weight sum of a slot is its count times that weight -- exact in
+ * f64, count * w needs 24 + 20 bits -- so the table takes no ds_add_f64, no weight is read or converted per k-mer, and the weight
+ * part of the first-sighting word is a constant of the launch (a sixth of the inner loop's vector instructions). */
+template <int W, int LOG2S, bool TRACK = false, bool EXT = false, bool UNI = false>
 __global__ __launch_bounds__(SKC_THREADS, EXT ? (W == 1 ? (LOG2S <= 9 ? SK_EXT_BLOCKS : 2) : 1) : ((W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 3 : 1)))
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
                      CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv, SkLong<W> lg) {
+	static_assert(!UNI || (!TRACK && !EXT), "the one-weight count pass is the plain one's");
 	constexpr int S = 1 << LOG2S;
 	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
 	constexpr int WSLOTS = S / SKC_WAVES;        /* slots a wavefront looks after in the emit phase */
@@ -1426,6 +1431,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	 * any other count below weakMin is dropped */
 	const uint32_t singC = f.has_singletons ? (f.min_depth > 1 ? 0u : 2u) : 3u;
 	const uint32_t weakMin = ((!f.has_singletons || f.min_depth > 2) && f.min_depth != 1) ? f.min_depth : 0u;
+	const uint32_t uniFirst = UNI ? (first_weight_bits(__uint_as_float(f.uni_wbits)) & 0x7fffffu) : 0u;      /* the weight bits of every first-sighting word */
 	const uint4 *poolg = (const uint4 *)pool.base;
 	uint4 pre = make_uint4(0, 0, 0, 0); uint32_t preCount = 0; uint64_t preList = ~0ull;      /* this wavefront's first chunk of the list named */
 	uint32_t gen = 0;                                  /* lists this block has counted: the flag pair in use is gen & 1 */
@@ -1624,7 +1630,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 						 * among its 64 lanes every time (one claim attempt and one LDS round trip per step) */
 						st.step = ((uint32_t)(h >> (64 - 2 * LOG2S)) & (uint32_t)(S - 1)) | 1u;
 						st.mine = ((uint32_t)(h >> 20) & subMask) == val;
-						st.w = uniformW ? hw : ww[j];
+						if constexpr (!UNI) st.w = uniformW ? hw : ww[j];
 						st.ord = ord0 + j;
 						if constexpr (EXT) {
 							/* the two neighbours of k-mer j of the record (Extension left / right of buildWeightedKmers, src/KmerReadUtils.h:224-236):
@@ -1654,7 +1660,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 					auto step_one = [&](KState &cur, KState &nxt) {
 						if (left) {
 							uint32_t s = cur.slot;
-							const float wa = __uint_as_float(cur.w);
+							const float wa = __uint_as_float(UNI ? f.uni_wbits : cur.w);
 							/* (one-word keys: a compare-and-swap against "empty" returns what the slot holds whether it wins or not, so the slot is
 							 * not read first) */
 							unsigned long long old = EMPTY_KEY;
@@ -1746,8 +1752,8 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 								if (!placed) s_overflow[fl] = 1;      /* table full */
 								else {
 									atomicAdd(&tcnt[s], 1ull | ((unsigned long long)(cur.fwd ? 1 : 0) << 32));
-									atomicAdd(&twsum[s], (double)wa);
-									const unsigned long long fp = first_pack(cur.ord, cur.fwd, wa);
+									if constexpr (!UNI) atomicAdd(&twsum[s], (double)wa);
+									const unsigned long long fp = UNI ? (((unsigned long long)cur.ord << FIRST_ORD_SHIFT) | ((unsigned long long)(cur.fwd ? 1u : 0u) << 23) | (unsigned long long)uniFirst) : first_pack(cur.ord, cur.fwd, wa);
 									if (TRACK) {      /* the two smallest: whichever of (old first, this one) is larger is a candidate for second */
 										const unsigned long long was = atomicMin(&tfirst[s], fp);
 										const unsigned long long cand = was > fp ? was : fp;
@@ -1811,7 +1817,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 #pragma unroll
 					for (int q = 0; q < W; q++) key.w[q] = used ? tkeys[(size_t)s * W + q] : 0ull;
 					const unsigned long long fst = used ? tfirst[s] : NO_FIRST;
-					const double wsum = used ? twsum[s] : 0.0;
+					const double wsum = UNI ? (double)count * (double)__uint_as_float(f.uni_wbits) : (used ? twsum[s] : 0.0);
 					if (TRACK && used) {
 						/* the key counts as seen from the first boundary behind its first sighting on, and as a singleton until the
 						 * first boundary behind its second one: index = number of boundaries <= the ordinal */
@@ -2520,6 +2526,27 @@ void sk_pack_kernel(PoolView pool, uint32_t n_chunks, uint32_t world, uint32_t r
 __global__ void sk_state_drop_kernel(unsigned long long *state, uint64_t n, uint32_t world, uint32_t rank) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
 		if (i % world != rank) state[i] = ((unsigned long long)NO_CHUNK << 32) | SK_CHUNK_G;
+}
+#endif
+/* Are the records a rank receives all uniform with one weight (the count pass's UNI form)?  One thread per received chunk follows its
+ * headers; uni[0] collects the one weight (0xffffffff: none seen yet), uni[1] is raised by a record with weights of its own or by a
+ * second weight. */
+static const uint32_t SK_UNI_NONE = 0xffffffffu;
+#ifndef KMR_INSTANCE_TU
+__global__ void sk_uniform_check_kernel(const uint4 *data, const uint64_t *start, const uint32_t *cnt, uint64_t n_chunks, uint32_t *uni) {
+	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4 *g = data + start[c];
+		const uint32_t n = cnt[c];
+		for (uint32_t pos = 0; pos < n; ) {
+			const uint4 hd = g[pos];
+			const uint32_t glen = (hd.y >> 17) & 0x7fu;
+			if (!((hd.y >> 16) & 1u)) { uni[1] = 1; break; }
+			const uint32_t was = atomicCAS(&uni[0], SK_UNI_NONE, hd.w);
+			if (was != SK_UNI_NONE && was != hd.w) { uni[1] = 1; break; }
+			if (glen == 0) break;
+			pos += glen;
+		}
+	}
 }
 #endif
 #ifndef KMR_INSTANCE_TU
