@@ -498,7 +498,11 @@ int kmr_reads_twobit(kmr_handle *h, const kmr_reads *r, uint8_t *twobit, uint64_
  * Results are those of kmr_add_reads on the same reads.  The device form is asynchronous on the handle's stream like kmr_add_reads_dev.
  * A batch without a quality array (one character, or none) that is built on the super-k-mer lists with direction-counting values is
  * extracted from the packed bytes as they are; every other batch is unpacked to text in a scratch of the handle first.  kmr_tune
- * "packed_direct" = 0 forces the unpack (tests, A/B runs). */
+ * "packed_direct" = 0 forces the unpack (tests, A/B runs).
+ * Device form: the packed bytes are fetched 16 bytes at a time from 16-byte aligned addresses, so up to 15 bytes in front of the
+ * first read's first byte and behind the last read's last byte are READ (never used): dev_twobit must lie in an allocation that
+ * holds them -- as hipMalloc'ed buffers do in front (256-byte aligned), and give the buffer 64 spare bytes behind the last read, as
+ * for kmr_add_reads_dev. */
 int kmr_add_reads_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *twobit_offsets, const uint64_t *offsets,
                          const uint64_t *markup_offsets, const uint32_t *markup_pos, const char *markup_char,
                          const char *quals, int uniform_quality, uint64_t n_reads, uint64_t first_global_read_idx, const uint8_t *discarded);
@@ -578,8 +582,14 @@ void *kmr_stream(kmr_handle *h);
  *   "list_aim" (k-mers per list that count aims for; default 1450 when every k-mer weighs the same, 1700 raw k-mers otherwise, 800 with
  *   extension values, just below the table's bound for keys of more than one word), "packed_direct" (0: kmr_add_reads_twobit* always
  *   unpack to text first).
+ *   "uniform_count" (0: never the one-weight form of the count pass), "lean_extract" (0: never the bases-only extraction),
+ *   "superkmer_window" (the widest minimizer window build_mode 3 may take: 32 (k >= 45) / 16 / 8 / 4).
  * Call before the first kmr_add_reads* of a build.  KMR_ERR_INVALID_ARG for an unknown knob. */
 int kmr_tune(kmr_handle *h, const char *knob, double value);
+/* What the current build decided, for tests and measurement tools (the reference logs such figures, LOG_VERBOSE): "lists" = super-k-mer
+ * lists of the build (0 before the first reads, or in another build mode), "uniform_count" = 1 if the last kmr_finalize ran the
+ * count pass's one-weight form, "chunk_pool_chunks" = 1 KB chunks the pool holds, "superkmer_window" = the minimizer window in use.  KMR_ERR_INVALID_ARG for an unknown name. */
+int kmr_build_info(kmr_handle *h, const char *what, double *value);
 
 /* Timing of the hot path measured with HIP events on the handle's stream
  * (used by bench.py for the roofline object).  Returns the accumulated

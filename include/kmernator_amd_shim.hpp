@@ -355,7 +355,9 @@ public:
 			 * failure INSIDE a step comes back on every rank -- the status word of kmr_exchange_add_reads_dev -- so all ranks stop together) */
 			rc = kmr_exchange_add_read_batch(h, batch, first + (sidx < mySteps ? cuts[sidx] : 0));
 			if (batch) kmr_reads_free(batch);
-			if (rc != KMR_OK) { if (failed == KMR_OK) { failed = rc; why = kmr_last_error(h); } break; }
+			/* (no break: an error that is this rank's alone -- a state check in front of the step's first gather -- must not leave the
+			 * others waiting in a collective; the rank keeps taking part with empty batches until all steps are done) */
+			if (rc != KMR_OK && failed == KMR_OK) { failed = rc; why = kmr_last_error(h); }
 		}
 		int anyFailed = failed != KMR_OK ? 1 : 0, jobFailed = 0;
 		MPI_Allreduce(&anyFailed, &jobFailed, 1, MPI_INT, MPI_MAX, _comm);
@@ -393,18 +395,22 @@ private:
 		const int R = self->_worldSize;
 		std::vector<std::vector<char> > out(R), in(R);
 		std::vector<MPI_Request> reqs;
-		for (int r = 0; r < R; r++) {
-			if (sendBytes[r] > ((uint64_t)1 << 30) || recvBytes[r] > ((uint64_t)1 << 30)) return KMR_ERR_CAPACITY;
+		/* every size is looked at before anything is posted, and nothing returns while a request is outstanding (the buffers below
+		 * would go out of scope under it, and the peers would wait for ever): a copy that fails still sends its -- then meaningless --
+		 * bytes, the error is reported once everything has completed */
+		for (int r = 0; r < R; r++) if (sendBytes[r] > ((uint64_t)1 << 30) || recvBytes[r] > ((uint64_t)1 << 30)) return KMR_ERR_CAPACITY;
+		int failed = KMR_OK;
+		for (int r = 0; r < R; r++)
 			if (recvBytes[r]) { in[r].resize((size_t)recvBytes[r]); MPI_Request q; MPI_Irecv(&in[r][0], (int)recvBytes[r], MPI_BYTE, r, 7101, self->_comm, &q); reqs.push_back(q); }
-		}
 		for (int r = 0; r < R; r++) {
 			if (!sendBytes[r]) continue;
 			out[r].resize((size_t)sendBytes[r]);
 			const int rc = kmr_copy_to_host(h, &out[r][0], (const char *)send + sendOff[r], sendBytes[r]);
-			if (rc != KMR_OK) return rc;
+			if (rc != KMR_OK && failed == KMR_OK) failed = rc;
 			MPI_Request q; MPI_Isend(&out[r][0], (int)sendBytes[r], MPI_BYTE, r, 7101, self->_comm, &q); reqs.push_back(q);
 		}
-		if (!reqs.empty() && MPI_Waitall((int)reqs.size(), &reqs[0], MPI_STATUSES_IGNORE) != MPI_SUCCESS) return KMR_ERR_HIP;
+		if (!reqs.empty() && MPI_Waitall((int)reqs.size(), &reqs[0], MPI_STATUSES_IGNORE) != MPI_SUCCESS && failed == KMR_OK) failed = KMR_ERR_HIP;
+		if (failed != KMR_OK) return failed;
 		for (int r = 0; r < R; r++) {
 			if (!recvBytes[r]) continue;
 			const int rc = kmr_copy_to_device(h, (char *)recv + recvOff[r], &in[r][0], recvBytes[r]);

@@ -126,6 +126,7 @@ struct kmr_handle {
 	HostPool l1;                       /* the record pool of every partition level */
 	int bits1 = 0;
 	uint64_t inserted_records = 0;     /* records fed through kmr_insert_records_dev (counted on the host) */
+	uint64_t call_bases_hint = 0;      /* a host batch goes to the device in pieces: the bases of the WHOLE call, for what the first piece sizes (lists, chunk pool) */
 	unsigned int *work_counter = nullptr;
 	uint8_t *l1_state = nullptr; size_t l1_state_bytes = 0; bool l1_state_dirty = false;   /* see PartSource::state */
 	/* temporaries of kmr_finalize (chunk CSRs, work items, counters): one grow-only block handed out by bumping a
@@ -156,7 +157,7 @@ struct kmr_handle {
 	double hP[256], hPk[256];              /* host copies of the probability table and of its k-fold products */
 	/* does every record of the lists carry ONE weight (all calls went through the lean extraction with the same quality character)?  The
 	 * host knows for its own calls (sk_uni_w: SK_UNI_NONE before the first; sk_uni_mixed), a device pair collects it for adopted records */
-	uint32_t sk_uni_w = 0xffffffffu; bool sk_uni_mixed = false; uint32_t *d_uni = nullptr;
+	uint32_t sk_uni_w = 0xffffffffu; bool sk_uni_mixed = false; uint32_t *d_uni = nullptr; bool last_count_uniform = false;
 	unsigned int *qrange = nullptr; bool qual_mixed = false;      /* sk_qual_range_kernel's answer; a build that has seen two different quality characters stops asking */
 	/* exchange with world_size > 1: sk_bits are the COARSE lists reads are scattered into and that travel; each holds 2^sk_fine_shift
 	 * fine lists, made by sk_refine_kernel before the count pass (fine state: sk_fine_state, 2^(sk_bits + sk_fine_shift) words) */
@@ -1449,8 +1450,12 @@ int insert_records_partition(kmr_handle *h, const void *recs, uint64_t n) {
 /* build_mode 3: super-k-mer lists (kmr_superkmer.hpp)                        */
 /* Minimizer geometry for k: the window of WIN m-mer offsets sits in the middle of the k-mer (2 * off + WIN = k - m + 1), m is
  * the largest length <= 16 (one 32-bit word) of the right parity, WIN the largest of 16 / 8 / 4 that leaves m >= 10. */
-bool sk_geometry(uint32_t k, uint32_t m_wish, uint32_t &win, uint32_t &m, uint32_t &off) {
-	for (uint32_t w : {16u, 8u, 4u}) {
+bool sk_geometry(uint32_t k, uint32_t m_wish, uint32_t &win, uint32_t &m, uint32_t &off, uint32_t win_max = 32) {
+	/* (a window of 32 offsets -- runs of 16.5 k-mers, half the records and list appends of a window of 16 -- where it leaves m >= 14: k >= 45,
+	 * keys of two words and more; C4's extraction 8 x 9.7 -> x ms) */
+	for (uint32_t w : {32u, 16u, 8u, 4u}) {
+		if (w > win_max) continue;
+		if (w == 32u && (k < 45u || (m_wish && m_wish < 14u))) continue;
 		if (k < w + 9) continue;
 		uint32_t mm = std::min<uint32_t>(m_wish ? m_wish : 16u, k - w + 1);
 		if (mm > 16) mm = 16;
@@ -1547,7 +1552,7 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		/* lists: about 1100 k-mers each, as the final lists of the two-level partition */
 		/* the list space is the whole job's (with world_size > 1 a rank owns every world_size-th list): sized from the caller's estimate
 		 * of all the k-mers (estimateRawKmers), else from this call's bases times the ranks */
-		const uint64_t est = h->cfg.estimated_raw_kmers ? h->cfg.estimated_raw_kmers : total_bases * std::max<uint32_t>(1, h->cfg.world_size);
+		const uint64_t est = h->cfg.estimated_raw_kmers ? h->cfg.estimated_raw_kmers : std::max<uint64_t>(total_bases, h->call_bases_hint) * std::max<uint32_t>(1, h->cfg.world_size);
 		/* k-mers per list: the list's distinct keys have to fit the 1024-slot table of the count pass (80 %), or the list is redone in
 		 * sub-passes.  At k <= 32 a list of ~1200 k-mers holds ~350 distinct ones in sequencing data; longer k-mers are hit by read
 		 * errors more often (k = 51, 1 % errors: 40 % of the k-mers hold one and are nearly all distinct), so their lists are cut
@@ -1609,13 +1614,13 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		 * of the free memory.  Growing call by call frees the old pool every time, and an allocation right after tens of GB were freed
 		 * waits seconds for the driver to clear them (config 3's whole input in eight calls: 5.1 s for the first build);
 		 * denser input than that still grows the pool as before */
-		if (!h->l1.base && r == 0 && h->cfg.world_size <= 1 && !h->sk_exchange && h->cfg.estimated_raw_kmers) {
-			const double job_bases = (double)h->cfg.estimated_raw_kmers * (double)avg / (double)(avg > h->k ? avg - h->k + 1 : 1);
+		if (!h->l1.base && r == 0 && h->cfg.world_size <= 1 && !h->sk_exchange && (h->cfg.estimated_raw_kmers || h->call_bases_hint > total_bases)) {
+			const double job_bases = h->cfg.estimated_raw_kmers ? (double)h->cfg.estimated_raw_kmers * (double)avg / (double)(avg > h->k ? avg - h->k + 1 : 1) : (double)h->call_bases_hint;
 			const double rest = job_bases - (double)total_bases;
 			size_t fr = 0, tot = 0;
 			if (rest > 0 && hipMemGetInfo(&fr, &tot) == hipSuccess) {
 				const uint64_t want = (uint64_t)(rest * (h->ext ? 2.0 : 1.0) * (lean ? 0.3 : 0.65) / SK_CHUNK_G);
-				h->l1.presize = std::min<uint64_t>(want, (uint64_t)(fr / 2) / ((size_t)CH * rec_bytes(h)));
+				h->l1.presize = std::min<uint64_t>(want, (uint64_t)(fr / 4) / ((size_t)CH * rec_bytes(h)));      /* (an estimate: a quarter of what is free at most, kmr_finalize needs room of its own) */
 			}
 		}
 		/* (inside an exchange the lists of other owners start afresh after every pack: an open chunk per list for every call) */
@@ -1627,9 +1632,10 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
                    (filt ? launch_sk_extract<W, WINv, true>(h, rv, sp) : (lean ? launch_sk_extract_lean<W, WINv>(h, rv, sp, wK) : launch_sk_extract<W, WINv, false>(h, rv, sp))))
 		if (h->packed_direct) {
 			SkPacked pkd = *h->packed_direct; pkd.off += r; if (pkd.mk_off) pkd.mk_off += r;
-			rc = h->sk_win == 16 ? launch_sk_extract_lean<W, 16, true>(h, rv, sp, wK, nullptr, &pkd) : (h->sk_win == 8 ? launch_sk_extract_lean<W, 8, true>(h, rv, sp, wK, nullptr, &pkd) : launch_sk_extract_lean<W, 4, true>(h, rv, sp, wK, nullptr, &pkd));
+			if (W > 1 && h->sk_win == 32) rc = launch_sk_extract_lean<W, (W > 1 ? 32 : 16), true>(h, rv, sp, wK, nullptr, &pkd);
+			else rc = h->sk_win == 16 ? launch_sk_extract_lean<W, 16, true>(h, rv, sp, wK, nullptr, &pkd) : (h->sk_win == 8 ? launch_sk_extract_lean<W, 8, true>(h, rv, sp, wK, nullptr, &pkd) : launch_sk_extract_lean<W, 4, true>(h, rv, sp, wK, nullptr, &pkd));
 		} else
-		rc = h->sk_win == 16 ? SKX(16) : (h->sk_win == 8 ? SKX(8) : SKX(4));
+		rc = (W > 1 && h->sk_win == 32) ? SKX((W > 1 ? 32 : 16)) : (h->sk_win == 16 ? SKX(16) : (h->sk_win == 8 ? SKX(8) : SKX(4)));
 #undef SKX
 		time_end(h, KMR_TIME_EXTRACT, a2, b2); time_end(h, KMR_TIME_BUILD, a, b);
 		if (rc) return rc;
@@ -1835,6 +1841,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		}
 		if (!mixed && w != SK_UNI_NONE) { uni = true; f.uni_wbits = w; }
 	}
+	h->last_count_uniform = uni;
 	if (tracking) {
 		bounds = h->trk_bounds; snap_raw = h->trk_snap_raw; snap_good = h->trk_snap_good;
 		if (bounds.size() > SK_TRACK_MAX) return fail(h, KMR_ERR_UNSUPPORTED, "size tracker: more than 512 elements");
@@ -2199,10 +2206,24 @@ int kmr_tune(kmr_handle *h, const char *knob, double value) {
 	else if (k == "coarse_lists") h->tune.no_coarse_lists = value == 0;
 	else if (k == "narrow_tallies") h->tune.no_narrow = value == 0;
 	else if (k == "keep_level1_state") h->tune.no_l1_state = value == 0;
+	else if (k == "superkmer_window") {      /* largest minimizer window the geometry may take (32 / 16 / 8 / 4): A/B runs, tests of the narrower windows at large k */
+		if (h->superkmer_mode && !h->sk_state) { uint32_t w, m, o; if (!sk_geometry(h->k, 0, w, m, o, (uint32_t)value)) return fail(h, KMR_ERR_INVALID_ARG, "no minimizer geometry under that window"); h->sk_win = w; h->sk_m = m; h->sk_off = o; }
+	}
 	else if (k == "superkmer_minimizer") {
 		if (h->superkmer_mode && !h->sk_state) { uint32_t w, m, o; if (!sk_geometry(h->k, (uint32_t)value, w, m, o)) return fail(h, KMR_ERR_INVALID_ARG, "no minimizer geometry for that length"); h->sk_win = w; h->sk_m = m; h->sk_off = o; }
 	}
 	else return fail(h, KMR_ERR_INVALID_ARG, "unknown tuning knob '" + k + "'");
+	return KMR_OK;
+}
+
+int kmr_build_info(kmr_handle *h, const char *what, double *value) {
+	if (!h || !what || !value) return KMR_ERR_INVALID_ARG;
+	const std::string k(what);
+	if (k == "lists") *value = h->sk_state ? (double)sk_list_count(h->sk_bits) : 0.0;
+	else if (k == "uniform_count") *value = h->last_count_uniform ? 1.0 : 0.0;
+	else if (k == "chunk_pool_chunks") *value = (double)h->l1.cap;
+	else if (k == "superkmer_window") *value = (double)h->sk_win;
+	else return fail(h, KMR_ERR_INVALID_ARG, "unknown build figure '" + k + "'");
 	return KMR_OK;
 }
 
@@ -2260,6 +2281,8 @@ int kmr_add_reads(kmr_handle *h, const char *bases, const char *quals, const uin
 #define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->tb_copy_stream); hipStreamSynchronize(h->stream); h->err = std::string(#call) + ": " + hip_err_text(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
 	const uint64_t piece_bases = h->tune.twobit_piece_bases ? h->tune.twobit_piece_bases : (1ull << 28);
 	int rc = KMR_OK; int set = 0;
+	h->call_bases_hint = n_reads ? offsets[n_reads] - offsets[0] : 0;      /* what the first piece sizes is the whole call's */
+	struct HintReset { kmr_handle *h; ~HintReset() { h->call_bases_hint = 0; } } hint_reset{h};
 	for (uint64_t r0 = 0; r0 < n_reads && rc == KMR_OK; set ^= 1) {
 		uint64_t r1 = r0 + 1;
 		while (r1 < n_reads && offsets[r1 + 1] - offsets[r0] <= piece_bases) r1++;
@@ -2379,6 +2402,8 @@ int kmr_add_reads_twobit(kmr_handle *h, const uint8_t *twobit, const uint64_t *t
 #define TBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipStreamSynchronize(h->tb_copy_stream); hipStreamSynchronize(h->stream); h->err = std::string(#call) + ": " + hip_err_text(e_); return e_ == hipErrorOutOfMemory ? KMR_ERR_OOM : KMR_ERR_HIP; } } while (0)
 	const uint64_t piece_bases = h->tune.twobit_piece_bases ? h->tune.twobit_piece_bases : (1ull << 28);
 	int rc = KMR_OK; int set = 0;
+	h->call_bases_hint = n_reads ? offsets[n_reads] - offsets[0] : 0;      /* what the first piece sizes is the whole call's */
+	struct HintReset { kmr_handle *h; ~HintReset() { h->call_bases_hint = 0; } } hint_reset{h};
 	for (uint64_t r0 = 0; r0 < n_reads && rc == KMR_OK; set ^= 1) {
 		uint64_t r1 = r0 + 1;
 		while (r1 < n_reads && offsets[r1 + 1] - offsets[r0] <= piece_bases) r1++;
@@ -2514,7 +2539,8 @@ template <int W> int lookup_stream_t(kmr_handle *h, const ReadsView &rvAll, uint
 	DevParams dp = dev_params(h);
 	dp.min_weight = 0.5f; dp.subsample = 1; dp.world = 1; dp.num_parts = 1; dp.sub_wnb = 0; dp.sub_snb = 0; dp.stats = h->scratch_stats;
 	SkParams sp = sk_params(h); sp.keep_all_owners = 1; sp.track = nullptr;
-	if (!rv.quals && !h->tune.no_lean_extract) rc = h->sk_win == 16 ? launch_sk_extract_lean<W, 16>(h, rv, sp, 1.0f, &dp) : (h->sk_win == 8 ? launch_sk_extract_lean<W, 8>(h, rv, sp, 1.0f, &dp) : launch_sk_extract_lean<W, 4>(h, rv, sp, 1.0f, &dp));
+	if (W > 1 && h->sk_win == 32) rc = (!rv.quals && !h->tune.no_lean_extract) ? launch_sk_extract_lean<W, (W > 1 ? 32 : 16)>(h, rv, sp, 1.0f, &dp) : launch_sk_extract<W, (W > 1 ? 32 : 16), false>(h, rv, sp, &dp);
+	else if (!rv.quals && !h->tune.no_lean_extract) rc = h->sk_win == 16 ? launch_sk_extract_lean<W, 16>(h, rv, sp, 1.0f, &dp) : (h->sk_win == 8 ? launch_sk_extract_lean<W, 8>(h, rv, sp, 1.0f, &dp) : launch_sk_extract_lean<W, 4>(h, rv, sp, 1.0f, &dp));
 	else rc = h->sk_win == 16 ? launch_sk_extract<W, 16, false>(h, rv, sp, &dp) : (h->sk_win == 8 ? launch_sk_extract<W, 8, false>(h, rv, sp, &dp) : launch_sk_extract<W, 4, false>(h, rv, sp, &dp));
 	if (rc) return rc;
 	hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);

@@ -31,6 +31,8 @@ static const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
 #define KMR_SKXL(W, WIN) KMR_T __global__ void sk_extract_lean_kernel<W, WIN, false>(ReadsView, DevParams, SkParams, PoolView, float, SkPacked); KMR_T __global__ void sk_extract_lean_kernel<W, WIN, true>(ReadsView, DevParams, SkParams, PoolView, float, SkPacked);
 #define KMR_SKX_W(W) KMR_SKX(W, 16, false) KMR_SKX(W, 16, true) KMR_SKX(W, 8, false) KMR_SKX(W, 8, true) KMR_SKX(W, 4, false) KMR_SKX(W, 4, true) KMR_SKXL(W, 16) KMR_SKXL(W, 8) KMR_SKXL(W, 4)
 
+#define KMR_SKX_W32(W) KMR_SKX(W, 32, false) KMR_SKX(W, 32, true) KMR_SKXL(W, 32)      /* k >= 45: keys of two words and more */
+
 /* build_mode 3: count pass and streaming lookups */
 #define KMR_SKC(W, TRACK) KMR_SKCX(W, TRACK, false)
 #define KMR_SKCX(W, TRACK, EXT) KMR_T __global__ void sk_count_kernel<W, EXT ? COUNT_LOG2S_EXT : COUNT_LOG2S, TRACK, EXT>(PoolView, const uint64_t *, const uint64_t *, uint64_t, uint32_t, CountOut, FinalizeParams, unsigned int *, uint32_t, SkTrackView, SkLong<W>);
@@ -58,6 +60,7 @@ static const int PD_THREADS = 1024, PD_RPT = 8, PD_LINE = 4;
 
 #if defined(KMR_INSTANCES_EXTERN)
 KMR_SKX_W(1) KMR_SKX_W(2) KMR_SKX_W(3) KMR_SKX_W(4)
+KMR_SKX_W32(2) KMR_SKX_W32(3) KMR_SKX_W32(4)
 KMR_SKC_W(1) KMR_SKC_W(2) KMR_SKC_W(3) KMR_SKC_W(4)
 KMR_EX_W(1) KMR_EX_W(2) KMR_EX_W(3) KMR_EX_W(4)
 KMR_PART_W(1) KMR_PART_W(2) KMR_PART_W(3) KMR_PART_W(4)
@@ -65,6 +68,9 @@ KMR_CK(1, true, COUNT_LOG2S, true)
 #else
 #ifdef KMR_INST_SKX
 KMR_SKX_W(KMR_INST_W)
+#if KMR_INST_W > 1
+KMR_SKX_W32(KMR_INST_W)
+#endif
 #endif
 #ifdef KMR_INST_SKC
 KMR_SKC_W(KMR_INST_W)

@@ -455,9 +455,15 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 		uint32_t qrun = 0;
 		/* minimizer pipeline: runs sp.off positions behind the k-mer pipeline */
 		uint32_t mf = 0, mr = 0;
-		uint32_t hs[WIN];
+		/* WIN = 32: the minimum over the last 32 hashes is the smaller of the block minimum over the last 16 and the one of 16 positions
+		 * earlier -- the value the same position of the window before produced (mprev) */
+		constexpr int WB = WIN > 16 ? 16 : WIN;
+		static_assert(WIN <= 16 || WIN == 2 * SK_WINDOW, "windows above 16 are two blocks of SK_WINDOW");
+		uint32_t hs[WB], mprev[WIN > 16 ? SK_WINDOW : 1];
 #pragma unroll
-		for (int i = 0; i < WIN; i++) hs[i] = 0xffffffffu;
+		for (int i = 0; i < WB; i++) hs[i] = 0xffffffffu;
+#pragma unroll
+		for (int i = 0; i < (WIN > 16 ? SK_WINDOW : 1); i++) mprev[i] = 0xffffffffu;
 		uint32_t pref = 0xffffffffu;
 		/* the run in progress */
 		bool runOpen = false, runUniform = true, runInWin = false;
@@ -562,15 +568,16 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 				mf = ((mf << 2) | mc) & mmask;
 				mr = (mr >> 2) | ((3u - mc) << mtop);
 				const uint32_t x = sk_mmer_hash(mf < mr ? mf : mr);
-				const int r = t % WIN;
+				const int r = t % WB;
 				pref = r == 0 ? x : (x < pref ? x : pref);
 				hs[r] = x;
 				uint32_t M = pref;
-				if (r < WIN - 1) { const uint32_t sfx = hs[r + 1 < WIN ? r + 1 : 0]; M = sfx < M ? sfx : M; }
+				if (r < WB - 1) { const uint32_t sfx = hs[r + 1 < WB ? r + 1 : 0]; M = sfx < M ? sfx : M; }
 				else {
 #pragma unroll
-					for (int u = WIN - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
+					for (int u = WB - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
 				}
+				if constexpr (WIN > 16) { const uint32_t m16 = M; const uint32_t before = mprev[t]; M = before < M ? before : M; mprev[t] = m16; }
 				return M;
 			};
 			/* Flat window: no lane sees an N or a quality below the floor (in the window or in the k positions before it), and the
@@ -1113,9 +1120,15 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 		constexpr int ZN = W == 1 ? 1 : (W == 2 ? 2 : 3);      /* history of N flags, one bit per position: k + 1 bits */
 		uint64_t zbits[3] = {0, 0, 0};
 		uint32_t mf = 0, mr = 0;
-		uint32_t hs[WIN];
+		/* WIN = 32: the minimum over the last 32 hashes is the smaller of the block minimum over the last 16 and the one of 16 positions
+		 * earlier -- the value the same position of the window before produced (mprev) */
+		constexpr int WB = WIN > 16 ? 16 : WIN;
+		static_assert(WIN <= 16 || WIN == 2 * SK_WINDOW, "windows above 16 are two blocks of SK_WINDOW");
+		uint32_t hs[WB], mprev[WIN > 16 ? SK_WINDOW : 1];
 #pragma unroll
-		for (int i = 0; i < WIN; i++) hs[i] = 0xffffffffu;
+		for (int i = 0; i < WB; i++) hs[i] = 0xffffffffu;
+#pragma unroll
+		for (int i = 0; i < (WIN > 16 ? SK_WINDOW : 1); i++) mprev[i] = 0xffffffffu;
 		uint32_t pref = 0xffffffffu;
 		bool runOpen = false, runInWin = false;
 		uint32_t runStart = 0, runN = 0, runMh = 0;
@@ -1214,15 +1227,16 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 				mf = ((mf << 2) | mc) & mmask;
 				mr = (mr >> 2) | ((3u - mc) << mtop);
 				const uint32_t x = sk_mmer_hash(mf < mr ? mf : mr);
-				const int r = t % WIN;
+				const int r = t % WB;
 				pref = r == 0 ? x : (x < pref ? x : pref);
 				hs[r] = x;
 				uint32_t M = pref;
-				if (r < WIN - 1) { const uint32_t sfx = hs[r + 1 < WIN ? r + 1 : 0]; M = sfx < M ? sfx : M; }
+				if (r < WB - 1) { const uint32_t sfx = hs[r + 1 < WB ? r + 1 : 0]; M = sfx < M ? sfx : M; }
 				else {
 #pragma unroll
-					for (int u = WIN - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
+					for (int u = WB - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
 				}
+				if constexpr (WIN > 16) { const uint32_t m16 = M; const uint32_t before = mprev[t]; M = before < M ? before : M; mprev[t] = m16; }
 				const bool valid = ((Vm >> t) & 1u) != 0;
 				const bool cont = runOpen && M == runMh && runN < SK_MAX_N;
 				const bool nw = valid && !cont;

@@ -77,6 +77,12 @@ class KmerSpectrum:
         return self
 
     # -- build
+    def build_info(self, what):
+        """kmr_build_info: a figure of the current build ("lists", "uniform_count", "chunk_pool_chunks")"""
+        v = C.c_double()
+        self._call("build_info", self.h, what.encode(), C.byref(v))
+        return v.value
+
     def buildKmerSpectrum(self, bases, quals, offsets, first_read_idx=0, discarded=None):
         """KmerSpectrum::buildKmerSpectrum(const ReadSet&) on flat host arrays."""
         bases = _u8(bases)

@@ -647,20 +647,62 @@ def test_uniform_weight_extraction(k, quals):
     batches = _uniform_quality_reads(900 + k, k, quals)
     cfg = default_config(k, estimated_raw_kmers=1_100_000)
     o = OracleSpectrum(cfg)
-    p, g = product(cfg, 3), product(cfg, 3, lean_extract=0)
+    p, g, u = product(cfg, 3), product(cfg, 3, lean_extract=0), product(cfg, 3, uniform_count=0)
     first = 0
     for rb in batches:
         o.add_reads(rb, first_idx=first)
         add(p, rb, first=first)
         add(g, rb, first=first)
+        add(u, rb, first=first)
         first += rb.n
-    for x in (o, p, g):
+    for x in (o, p, g, u):
         x.finalize(1)
-    assert o.stats() == p.stats() == g.stats()
+    # one weight throughout: the count pass's one-weight form (no weight sums in the table) against the general form on the same lists
+    assert (p.build_info("uniform_count"), g.build_info("uniform_count"), u.build_info("uniform_count")) == (1.0, 0.0, 0.0)
+    assert np.array_equal(p.image(KMR_MAP_WEAK), u.image(KMR_MAP_WEAK)) and np.array_equal(p.image(KMR_MAP_SINGLETON), u.image(KMR_MAP_SINGLETON))
+    assert o.stats() == p.stats() == g.stats() == u.stats()
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
     assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
     assert np.array_equal(p.image(KMR_MAP_WEAK), g.image(KMR_MAP_WEAK))
     assert np.array_equal(p.image(KMR_MAP_SINGLETON), g.image(KMR_MAP_SINGLETON))
+
+
+@pytest.mark.parametrize("k,win,quality", [(45, 32, "noisy"), (51, 32, "flat"), (51, 16, "noisy"), (51, 8, "flat"), (127, 32, "noisy"), (127, 16, "flat"), (44, 16, "noisy")])
+def test_minimizer_windows_at_large_k(k, win, quality):
+    """build_mode 3 takes a minimizer window of 32 offsets from k = 45 on (runs of ~16 k-mers: half the records of a window of 16);
+    the narrower windows stay reachable (kmr_tune superkmer_window) and every one of them must give the oracle's spectrum -- reads
+    with N's, both extraction kernels (one quality character: the bases-only one; qualities of their own: the general one)"""
+    rb = synth_reads(5000, read_len=200, genome_len=80000, seed=300 + k + win, quality=quality, n_rate=0.002)
+    cfg = default_config(k, estimated_raw_kmers=5000 * (200 - k + 1))
+    o = OracleSpectrum(cfg)
+    p = product(cfg, 3, superkmer_window=win)
+    assert p.build_info("superkmer_window") == win
+    o.add_reads(rb)
+    add(p, rb)
+    o.finalize(1)
+    p.finalize(1)
+    assert o.stats() == p.stats()
+    compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
+    assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+    # lookups stream over lists of the same geometry
+    keys, cnt, _, _, _ = o.entries()
+    assert np.array_equal(p.getCount(keys[:2000]), cnt[:2000])
+
+
+def test_host_batch_in_pieces_sizes_lists_from_the_whole_call():
+    """kmr_add_reads / kmr_add_reads_twobit send a host batch to the device in pieces; without an estimate of the job's k-mers the first
+    piece must size the lists (and the chunk pool) for the WHOLE call, as one device call does -- not for itself"""
+    rb = synth_reads(60000, read_len=150, genome_len=300000, seed=5, quality="flat")
+    cfg = default_config(31)                       # estimated_raw_kmers = 0
+    one = product(cfg, 3)
+    add(one, rb)
+    pieces = product(cfg, 3, twobit_piece_bases=1 << 20)      # nine pieces
+    add(pieces, rb)
+    assert one.build_info("lists") == pieces.build_info("lists") > 64
+    one.finalize(2)
+    pieces.finalize(2)
+    assert one.stats() == pieces.stats()
+    assert np.array_equal(one.image(KMR_MAP_WEAK), pieces.image(KMR_MAP_WEAK))
 
 
 def test_quality_mix_is_noticed_between_calls():
@@ -678,6 +720,7 @@ def test_quality_mix_is_noticed_between_calls():
             first += rb.n
         o.finalize(2)
         p.finalize(2)
+        assert p.build_info("uniform_count") == 0.0      # two different weights in the lists: the general count pass
         assert o.stats() == p.stats()
         compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
 

@@ -1,5 +1,7 @@
 """development tool: k = 51 (two-word keys) at scale: the default build (super-k-mer lists) and, for the image comparison, the
-device-table build.  usage: tools/c4_check.py [reads] [k] [read_len] [modes e.g. 3,2,1] [knob=value ...]"""
+device-table build.  usage: tools/c4_check.py [reads] [k] [read_len] [modes e.g. 3,2,1] [knob=value ...]
+With 50000000 51 150 the input is BASELINE config 4 (seed 3, 250 Mbp genome) and the result is held to the oracle's
+digest under tests/golden/full_size_digests.json."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +14,7 @@ L = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 modes = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [3, 1]
 tune = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in sys.argv[5:]}
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
-bases, quals, offsets = bench.gen_reads(torch, n, n * L // 30, 3, 0, dev, "flat", read_len=L)
+bases, quals, offsets = bench.gen_reads(torch, n, 5 * n, 3, 0, dev, "flat", read_len=L)
 torch.cuda.synchronize()
 imgs = {}
 for mode in modes:
@@ -23,6 +25,10 @@ for mode in modes:
         sp.sync(); t1 = time.time(); sp.finalize(2); dt = time.time() - t0
         print("  rep", rep, "build %.1f ms finalize %.1f ms" % ((t1 - t0) * 1e3, (time.time() - t1) * 1e3), "kernel groups", [round(sp.kernel_time(g)[0], 1) for g in range(7)], "launches", [sp.kernel_time(g)[1] for g in range(7)], flush=True)
     st = sp.stats(); print("mode", mode, "k", k, "%d x %d bp: %.1f ms" % (n, L, dt * 1e3), "%.2f G kmers/s" % (st["raw_kmers"] / dt / 1e9), st, flush=True)
+    if (n, k, L) == (50_000_000, 51, 150):
+        from helpers import digests_agree, full_size_golden
+        g = full_size_golden("c4_flat")
+        print("  statistics == oracle:", st == g["stats"], " weak digest == oracle:", digests_agree(sp.digest(KMR_MAP_WEAK), g["weak_digest"], 1e-6), flush=True)
     if len(modes) > 1:
         imgs[mode] = sp.image(KMR_MAP_WEAK)
     del sp
