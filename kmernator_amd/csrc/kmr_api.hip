@@ -1450,9 +1450,11 @@ int insert_records_partition(kmr_handle *h, const void *recs, uint64_t n) {
 /* build_mode 3: super-k-mer lists (kmr_superkmer.hpp)                        */
 /* Minimizer geometry for k: the window of WIN m-mer offsets sits in the middle of the k-mer (2 * off + WIN = k - m + 1), m is
  * the largest length <= 16 (one 32-bit word) of the right parity, WIN the largest of 16 / 8 / 4 that leaves m >= 10. */
-bool sk_geometry(uint32_t k, uint32_t m_wish, uint32_t &win, uint32_t &m, uint32_t &off, uint32_t win_max = 32) {
-	/* (a window of 32 offsets -- runs of 16.5 k-mers, half the records and list appends of a window of 16 -- where it leaves m >= 14: k >= 45,
-	 * keys of two words and more; C4's extraction 8 x 9.7 -> x ms) */
+bool sk_geometry(uint32_t k, uint32_t m_wish, uint32_t &win, uint32_t &m, uint32_t &off, uint32_t win_max = 16) {
+	/* (a window of 32 offsets -- runs of 16.5 k-mers, half the records and list appends of a window of 16 -- exists where it leaves
+	 * m >= 14 (k >= 45, keys of two words and more) but is NOT the default: on C4 it takes the extraction from 40.7 to 28.4 ms and the count
+	 * pass from 115 to 257 ms -- one place of the genome then puts 33 x coverage k-mers into ONE list, lists of 700 k-mers hold one or
+	 * three such places, and the long ones overflow the LDS table into sub-passes; kmr_tune "superkmer_window" = 32 asks for it) */
 	for (uint32_t w : {32u, 16u, 8u, 4u}) {
 		if (w > win_max) continue;
 		if (w == 32u && (k < 45u || (m_wish && m_wish < 14u))) continue;
@@ -1612,7 +1614,7 @@ template <int W> int add_reads_superkmer_t(kmr_handle *h, const ReadsView &rvAll
 		/* A job fed in many calls (estimated_raw_kmers says how much is to come) gets its pool in ONE allocation: this call's worst case
 		 * plus what the rest of the job typically takes (flat qualities ~0.25 granules per base, a weight per k-mer ~0.55), at most half
 		 * of the free memory.  Growing call by call frees the old pool every time, and an allocation right after tens of GB were freed
-		 * waits seconds for the driver to clear them (config 3's whole input in eight calls: 5.1 s for the first build);
+		 * waits seconds for the driver to clear them (config 3's whole input in eight calls: 5.1 s for the first build, HISTORY.md section 6);
 		 * denser input than that still grows the pool as before */
 		if (!h->l1.base && r == 0 && h->cfg.world_size <= 1 && !h->sk_exchange && (h->cfg.estimated_raw_kmers || h->call_bases_hint > total_bases)) {
 			const double job_bases = h->cfg.estimated_raw_kmers ? (double)h->cfg.estimated_raw_kmers * (double)avg / (double)(avg > h->k ? avg - h->k + 1 : 1) : (double)h->call_bases_hint;

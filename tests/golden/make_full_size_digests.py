@@ -59,7 +59,7 @@ MIN_DEPTH = 2          # unless the configuration says otherwise
 
 def one_part(args):
     name, part = args
-    from helpers import KMR_MAP_WEAK, OracleSpectrum, default_config, synth_reads_8d
+    from helpers import KMR_MAP_SINGLETON, KMR_MAP_WEAK, OracleSpectrum, default_config, synth_reads_8d
     c = CONFIGS[name]
     per = READ_LEN - c["k"] + 1
     cfg = default_config(c["k"], estimated_raw_kmers=c["reads"] * per, num_parts=c["parts"], part_idx=part, **c.get("cfg", {}))

@@ -669,9 +669,10 @@ def test_uniform_weight_extraction(k, quals):
 
 @pytest.mark.parametrize("k,win,quality", [(45, 32, "noisy"), (51, 32, "flat"), (51, 16, "noisy"), (51, 8, "flat"), (127, 32, "noisy"), (127, 16, "flat"), (44, 16, "noisy")])
 def test_minimizer_windows_at_large_k(k, win, quality):
-    """build_mode 3 takes a minimizer window of 32 offsets from k = 45 on (runs of ~16 k-mers: half the records of a window of 16);
-    the narrower windows stay reachable (kmr_tune superkmer_window) and every one of them must give the oracle's spectrum -- reads
-    with N's, both extraction kernels (one quality character: the bases-only one; qualities of their own: the general one)"""
+    """build_mode 3 can take a minimizer window of 32 offsets from k = 45 on (runs of ~16 k-mers: half the records of a window of 16;
+    kmr_tune superkmer_window, not the default: DESIGN.md) beside the windows of 16 / 8 / 4: every one of them must give the oracle's
+    spectrum -- reads with N's, both extraction kernels (one quality character: the bases-only one; qualities of their own: the
+    general one)"""
     rb = synth_reads(5000, read_len=200, genome_len=80000, seed=300 + k + win, quality=quality, n_rate=0.002)
     cfg = default_config(k, estimated_raw_kmers=5000 * (200 - k + 1))
     o = OracleSpectrum(cfg)

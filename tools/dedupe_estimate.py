@@ -1,5 +1,5 @@
 """development tool: what merging identical super-k-mers inside a list would save on C2-like data (30x coverage, 1 % substitutions, k = 31, m = 16):
-the share of k-mers that lie in unique (minimizer, bases) records.  DESIGN.md section 6, "What was tried and dropped"."""
+the share of k-mers that lie in unique (minimizer, bases) records.  HISTORY.md section 6, "What was tried and dropped"."""
 import numpy as np, sys
 from numpy.lib.stride_tricks import sliding_window_view
 rng = np.random.default_rng(1)

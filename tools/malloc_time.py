@@ -1,5 +1,5 @@
 """development tool: what hipMalloc / hipFree of tens of GB cost on the box (normally 0.3 ms whatever the size; seconds when the driver
-still has freed memory to clear -- the pattern a pool that grows by reallocation produces)"""
+still has freed memory to clear -- the pattern a pool that grows by reallocation produces, HISTORY.md section 6)"""
 import torch, time, ctypes
 hip = ctypes.CDLL("libamdhip64.so")
 torch.cuda.init(); torch.zeros(1, device="cuda"); torch.cuda.synchronize()
