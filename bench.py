@@ -358,7 +358,7 @@ def main():
                 per = [("sk_extract_lean_kernel (bases only: minimizer + runs + list scatter)" if lean else "sk_extract_kernel (extract + weight chain + minimizer + list scatter)", 2,
                         raw_local * (1.0 if lean else 2.0) * READ_LEN / kmers_per_read + sk_bytes,
                         "scattered device atomics: one returning 64-bit add per record, ~1.8e10/s chip-wide" if lean else "vector-instruction issue at 1.5 wavefronts per SIMD (LDS: 24 KB per wavefront)"),
-                       ("sk_count_kernel (expand + count in LDS)", 5, sk_bytes + weak * 16.0,
+                       ("sk_count_kernel (expand + count in LDS%s)" % (", one-weight form" if lean else ""), 5, sk_bytes + weak * 16.0,
                         "vector-instruction issue (VALU busy ~70 % of a SIMD's cycles at 4 wavefronts per SIMD; LDS caps the occupancy)"),
                        ("bb_hist + bb_scatter (x levels) + bb_group_kernel (radix partition by bucket, per-group sort)", 6, weak * (16.0 * 5 + 20.0),
                         "HBM / L2 transactions")]
@@ -378,7 +378,7 @@ def main():
                 kernels.append({"name": name, "ms_per_step": ms_step, "launches_per_step": launches // max(1, args.steps),
                                 "ms_per_launch": ms / launches, "bytes_per_step": nbytes,
                                 "achieved_GBps": nbytes / (ms_step / 1e3) / 1e9, "frac": nbytes / (ms_step / 1e3) / HBM_PEAK, "limiter": limiter})
-            out["roofline"]["limiter_source"] = "profiles/r03_sq_counters.json (SQ / LDS / L2 counters per kernel, tools/sq_counters.sh)"
+            out["roofline"]["limiter_source"] = "profiles/r04_sq_counters.json (SQ / LDS / L2 counters per kernel, tools/sq_counters.sh)"
             out["roofline"]["kernels"] = kernels
             if kernels:
                 dom = max(kernels, key=lambda k: k["ms_per_step"])
@@ -388,7 +388,7 @@ def main():
         if exchange:
             out["exchange"] = {k: (v / max(1, args.steps) if isinstance(v, (int, float)) else v) for k, v in xstats.items()}
         # HBM bytes from the PMC counters: bench.py cannot run rocprofv3 on itself, so the committed summary of the same command
-        # (tools/pmc.sh -> profiles/r03_pmc_traffic.json) is quoted when it describes this workload and build mode
+        # (tools/pmc.sh -> profiles/r04_pmc_traffic_<quality>.json) is quoted when it describes this workload, quality mode and build mode
         # (exactly one file may describe a line: the newest round's summary whose workload, quality mode and build mode are this line's)
         for tf in ("r04_pmc_traffic_%s.json" % args.quality, "r03_pmc_traffic.json" if args.quality == "flat" else "r03_pmc_traffic_noisy.json"):
             try:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_summary.py <tag> [quality] -- turn the two counter passes of tools/pmc.sh (gpurun_out/pmc_<tag>_FETCH_SIZE, ..._WRITE_SIZE)
+"""tools/pmc_summary.py <tag> [quality] [commit] -- turn the two counter passes of tools/pmc.sh (gpurun_out/pmc_<tag>_FETCH_SIZE, ..._WRITE_SIZE)
 into the per-step HBM traffic summary bench.py reads (profiles/rNN_pmc_traffic.json).  FETCH_SIZE is doubled (gfx950 reports half
 the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section), WRITE_SIZE taken as reported, both in KB.  Every build of the
 run handles the same reads, so a kernel's per-step figure is its total over the run divided by the number of builds (= launches of
@@ -40,6 +40,8 @@ out = {
     "corrections": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; both x1024 (KB units)",
     "build_mode": "super-k-mer lists",
     "quality": quality,
+    "reads": 10000000,
+    "commit": sys.argv[3] if len(sys.argv) > 3 else "?",
     "per_step_GB": per,
     "hot_path_total_GB_per_step": round(total, 2),
 }
