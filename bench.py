@@ -238,6 +238,50 @@ def main():
     # ones they receive, so the flat-quality case -- nothing discarded -- is the one that can be checked there)
     assert args.no_check or raw_total == total_kmers or (exchange and mode_num != 3 and args.quality != "flat"), (raw_total, total_kmers)
 
+    # The line checks itself against the ORACLE (outside the timed region): the ranks' statistics and map digests (kmr_map_digest: additive over
+    # owners) must add up to what the serial CPU oracle made of the same job (tests/golden/full_size_digests.json, written by
+    # tests/golden/make_full_size_digests.py in the build container) -- C2 flat / noisy on one GPU, the weak-scaling jobs at N = 2 / 4, and
+    # BASELINE config 3 at N = 8.  Configurations without a committed digest report null.
+    oracle_check = None
+    try:
+        from helpers import add_digests, digests_agree, full_size_golden
+        gname = None
+        if args.build_mode in (0, 3) and not args.tune:
+            if world == 1 and n_reads == 10_000_000:
+                gname = "c2_flat" if args.quality == "flat" else "c2_noisy"
+            elif c3 and args.quality == "flat":
+                gname = "c3_flat"
+            elif world in (2, 4) and n_reads == 10_000_000 and args.quality == "flat":
+                gname = "scale_n%d" % world
+        try:
+            gold = full_size_golden(gname) if gname else None
+        except KeyError:
+            gold = None
+        if gold is not None:
+            dg = sp.digest(0)
+            keys = ("raw_kmers", "raw_good_kmers", "unique_kmers", "singleton_kmers", "discarded", "weak_entries", "reads")
+            ints = [st[k_] for k_ in keys] + [dg[k_] for k_ in ("entries", "count_sum", "dir_sum", "hash_sum", "hash_xor")]
+            if dist is not None:
+                t = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in ints], dtype=torch.int64, device=red_dev)
+                every = [torch.zeros_like(t) for _ in range(world)]
+                dist.all_gather(every, t)
+                w = torch.tensor([dg["weighted_sum"]], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(w)
+                rows = [[int(x) & 0xFFFFFFFFFFFFFFFF for x in e.cpu().tolist()] for e in every]
+                wsum = float(w.item())
+            else:
+                rows, wsum = [ints], dg["weighted_sum"]
+            stats_sum = {k_: sum(r[i] for r in rows) for i, k_ in enumerate(keys)}
+            dsum = None
+            for r in rows:
+                dsum = add_digests(dsum, dict(entries=r[7], count_sum=r[8], dir_sum=r[9], hash_sum=r[10], hash_xor=r[11], weighted_sum=0.0))
+            dsum["weighted_sum"] = wsum
+            oracle_check = {"config": gname, "statistics_equal": all(stats_sum[k_] == gold["stats"][k_] for k_ in keys),
+                            "weak_map_digest_equal": bool(digests_agree(dsum, gold["weak_digest"], 1e-6)),
+                            "what": "sum over ranks of kmr_get_stats and kmr_map_digest against the serial CPU oracle's (keys, counts, direction biases bit for bit; weightedCount sum within 1e-6)"}
+    except Exception as e:      # the check must never cost a bench line
+        oracle_check = {"error": repr(e)}
+
     # PCIe-inclusive legs (t_build from "first byte of in-memory reads available"): the reads start in pinned host memory and
     # go to the device in eight pieces on a copy stream while the library's stream builds the pieces that have arrived.  Twice: as
     # text (kmr_add_reads_dev: a byte per base and per quality), and as the reference's Read keeps them (kmr_add_reads_twobit_dev:
@@ -385,6 +429,7 @@ def main():
                 out["roofline"]["dominant_kernel"] = {"name": dom["name"], "ms_per_launch": dom["ms_per_launch"],
                                                       "bytes_per_launch": dom["bytes_per_step"] / max(1, dom["launches_per_step"]),
                                                       "achieved_GBps": dom["achieved_GBps"], "frac": dom["frac"]}
+        out["oracle_check"] = oracle_check
         if exchange:
             out["exchange"] = {k: (v / max(1, args.steps) if isinstance(v, (int, float)) else v) for k, v in xstats.items()}
         # HBM bytes from the PMC counters: bench.py cannot run rocprofv3 on itself, so the committed summary of the same command

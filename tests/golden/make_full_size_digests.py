@@ -11,7 +11,7 @@ the first sighting of a k-mer and with it the quantised first weight and the flo
 the k-mers.  Statistics add up over the parts; the map digest (include/kmernator_amd.h, kmr_map_digest) is defined so that
 part digests add (hash_sum, count_sum, dir_sum, weighted_sum) or xor (hash_xor) to the whole map's.
 
-Run time here (8 cores): C2 about 5 minutes per quality mode, C4 about 35 minutes.
+Run time here (8 cores): C2 about 6 minutes per quality mode, C4 40 minutes, config 3 (100 M reads) about two hours.
 
     python tests/golden/make_full_size_digests.py [name ...]
 """
@@ -29,6 +29,11 @@ CONFIGS = {
     "c2_flat": dict(k=31, seed=1, reads=10_000_000, genome=50_000_000, noisy=False, parts=8),
     "c2_noisy": dict(k=31, seed=1, reads=10_000_000, genome=50_000_000, noisy=True, parts=8),
     "c4_flat": dict(k=51, seed=3, reads=50_000_000, genome=250_000_000, noisy=False, parts=16),
+    # what `bench.py --gpus N` builds (weak scaling: C2's batch per GPU of one genome at 30x; N = 8 is BASELINE config 3 exactly: seed 2,
+    # 100 M reads, 500 Mbp): the ranks' digests must add up to these -- the bench line of a multi-GPU run checks itself against them
+    "scale_n2": dict(k=31, seed=1, reads=20_000_000, genome=100_000_000, noisy=False, parts=8),
+    "scale_n4": dict(k=31, seed=1, reads=40_000_000, genome=200_000_000, noisy=False, parts=8),
+    "c3_flat": dict(k=31, seed=2, reads=100_000_000, genome=500_000_000, noisy=False, parts=24),
     # small ones: the same code path at sizes any test can rebuild (tests/test_full_size_digests.py does, on the CPU)
     "small_k31_noisy": dict(k=31, seed=11, reads=200_000, genome=1_000_000, noisy=True, parts=2),
     "small_k51_flat": dict(k=51, seed=12, reads=200_000, genome=1_000_000, noisy=False, parts=3),
