@@ -351,6 +351,14 @@ int kmr_sk_exchange_begin(kmr_handle *h);      /* before the first reads of the 
 int kmr_sk_exchange_counts(kmr_handle *h, uint64_t *chunks, uint64_t *granules);
 int kmr_sk_exchange_pack_dev(kmr_handle *h, void *dev_data, void *dev_meta, const uint64_t *granule_offset, const uint64_t *chunk_offset);
 int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *dev_meta, uint64_t n_chunks, uint64_t n_granules);
+/* Do all records of this rank's lists carry ONE weight (every call so far took the bases-only extraction with the same quality
+ * character)?  *state = kind << 32 | weight bits; kind 0: no record yet, 1: one weight, 2: several.  A sender hands its state to the
+ * owners along with its chunk counts, an owner folds it in with kmr_sk_exchange_peer_uniform BEFORE adopting that sender's chunks: if all
+ * agree, kmr_finalize counts with the one-weight form of the count pass.  An owner that is told nothing checks the received records
+ * itself (a pass over every received header).  Nothing in the reference corresponds (its wire records carry a weight per k-mer,
+ * src/DistributedFunctions.h:274-303). */
+int kmr_sk_exchange_uniform(kmr_handle *h, uint64_t *state);
+int kmr_sk_exchange_peer_uniform(kmr_handle *h, uint64_t state);
 
 /* KmerSpectrum::SizeTracker (src/KmerSpectrum.h:812-900): the history of (rawKmers, rawGoodKmers, uniqueKmers, singletonKmers) the
  * apps write as --size-history-file (apps/FilterReads.cpp:141-147) and EstimateSize fits.  The reference calls track() before every

@@ -181,7 +181,7 @@ int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void 
 	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_exchange_add_reads_dev after kmr_finalize (kmr_reset first)");
 	hipSetDevice(h->device);
 	const uint32_t world = h->cfg.world_size, rank = h->cfg.rank;
-	const size_t row = 2 * (size_t)world + 1;      /* numbers of the step, then the status word */
+	const size_t row = 2 * (size_t)world + 2;      /* numbers of the step, the sender's uniform-weight state (lists), then the status word */
 	int rc = 0, lrc = 0;                            /* lrc: what went wrong on THIS rank since the last agreement */
 	if (n_reads && (!dev_bases || !dev_offsets)) { lrc = fail(h, KMR_ERR_INVALID_ARG, "null device buffer"); n_reads = 0; total_bases = 0; }
 	if (h->tune.exchange_fail_once) { h->tune.exchange_fail_once = false; lrc = fail(h, KMR_ERR_OOM, "injected failure (kmr_tune exchange_fail_once: the tests' way to fail one rank of a collective step)"); n_reads = 0; total_bases = 0; }
@@ -213,9 +213,11 @@ int kmr_exchange_add_reads_dev(kmr_handle *h, const void *dev_bases, const void 
 		if (!lrc) lrc = kmr_sk_exchange_pack_dev(h, h->xc_send, h->xc_send2, goff.data(), coff.data());
 		std::fill(mine.begin(), mine.end(), 0);
 		if (!lrc) for (uint32_t r = 0; r < world; r++) { mine[r] = chunks[r]; mine[world + r] = granules[r]; }
+		if (!lrc) { uint64_t ust = 0; kmr_sk_exchange_uniform(h, &ust); mine[2 * world] = ust; }
 		status(lrc);
 		rc = xc_allgather_rows(h, mine, all); if (rc) return rc;
 		rc = xc_agree(h, lrc, all, row); if (rc) return rc;
+		for (uint32_t r = 0; r < world; r++) if (r != rank && all[(size_t)r * row + rank]) { rc = kmr_sk_exchange_peer_uniform(h, all[(size_t)r * row + 2 * world]); if (rc) return rc; }
 		std::vector<uint64_t> rc_c(world, 0), rc_g(world, 0), rgo(world, 0), rco(world, 0), sgb(world), scb(world), sgo(world), sco(world);
 		uint64_t rg = 0, rcn = 0, biggest = 0;
 		for (uint32_t r = 0; r < world; r++) {

@@ -233,7 +233,13 @@ def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx
         data = torch.empty((max(ag, 1), 4), dtype=torch.int32, device=dev)
         meta = torch.empty((max(ac, 1), 2), dtype=torch.int32, device=dev)
         spectrum.sk_exchange_pack(data.data_ptr(), meta.data_ptr(), goff, coff)
-        _, recv_c = _exchange_counts(torch.tensor(send_c, dtype=torch.int64, device=dev), group)
+        # (a sender's uniform-weight state rides in the upper bits of its chunk counts -- chunk counts stay below 2^24 per owner and
+        # batch: the owner can then take the count pass's one-weight form without looking at what it receives)
+        assert max(send_c + [0]) < (1 << 24), "more than 2^24 chunks for one owner in one piece: feed smaller pieces"
+        ust = spectrum.sk_exchange_uniform()
+        _, recv_enc = _exchange_counts(torch.tensor([c | (ust << 24) for c in send_c], dtype=torch.int64, device=dev), group)
+        recv_c = [x & 0xFFFFFF for x in recv_enc]
+        peer_states = [x >> 24 for x in recv_enc]
         _, recv_g = _exchange_counts(torch.tensor(send_g, dtype=torch.int64, device=dev), group)
         timed = None
         if dev.type == "cuda":
@@ -246,7 +252,7 @@ def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx
             stats["chunks"] = stats.get("chunks", 0) + sum(send_c)
             stats["records_sent"] = stats.get("records_sent", 0) + sum(send_g)
             stats["bytes_to_peers"] = stats.get("bytes_to_peers", 0) + 16 * sum(send_g) + 8 * sum(send_c)
-        return dict(meta=got_meta, data=got_data, recv_c=recv_c, recv_g=recv_g, works=works, timed=timed, keep=(data, meta))
+        return dict(meta=got_meta, data=got_data, recv_c=recv_c, recv_g=recv_g, works=works, timed=timed, keep=(data, meta), peer_states=peer_states)
 
     def finish(x):
         """wait for the piece's all-to-alls, append what arrived to this rank's lists"""
@@ -257,6 +263,9 @@ def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx
             torch.cuda.synchronize(dev)
             if stats is not None:
                 stats["alltoall_ms"] = stats.get("alltoall_ms", 0.0) + x["timed"][0].elapsed_time(x["timed"][1])
+        for r, n_c in enumerate(x["recv_c"]):
+            if r != rank and n_c:
+                spectrum.sk_exchange_peer_uniform(x["peer_states"][r])
         if sum(x["recv_c"]):
             spectrum.sk_exchange_adopt(x["data"].data_ptr(), x["meta"].data_ptr(), sum(x["recv_c"]), sum(x["recv_g"]))
 

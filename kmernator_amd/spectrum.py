@@ -241,6 +241,16 @@ class KmerSpectrum:
         co = np.ascontiguousarray(chunk_offset, dtype=np.uint64)
         self._call("sk_exchange_pack_dev", self.h, data_ptr, meta_ptr, go.ctypes.data_as(C.POINTER(C.c_uint64)), co.ctypes.data_as(C.POINTER(C.c_uint64)))
 
+    def sk_exchange_uniform(self):
+        """kmr_sk_exchange_uniform: kind << 32 | weight bits of this rank's records (what a sender tells the owners)"""
+        v = C.c_uint64()
+        self._call("sk_exchange_uniform", self.h, C.byref(v))
+        return v.value
+
+    def sk_exchange_peer_uniform(self, state):
+        """kmr_sk_exchange_peer_uniform: fold a sender's state in, before adopting its chunks"""
+        self._call("sk_exchange_peer_uniform", self.h, int(state))
+
     def sk_exchange_adopt(self, data_ptr, meta_ptr, n_chunks, n_granules):
         self._call("sk_exchange_adopt_dev", self.h, data_ptr, meta_ptr, n_chunks, n_granules)
 

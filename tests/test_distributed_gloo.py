@@ -248,6 +248,7 @@ class _FakeListSpectrum:
 
     def __init__(self, rank, world):
         self.rank, self.world, self.piece, self.pending, self.adopted, self.origin, self.begun = rank, world, -1, None, [], [], False
+        self.peer_states = []
 
     def sk_exchange_begin(self):
         self.begun = True
@@ -281,6 +282,12 @@ class _FakeListSpectrum:
                 g += fill
                 c += 1
         self.pending = None
+
+    def sk_exchange_uniform(self):
+        return (1 << 32) | (0x3f000000 + self.rank)      # "one weight", a different one on every rank, so that the owner can tell whose state it got
+
+    def sk_exchange_peer_uniform(self, state):
+        self.peer_states.append(int(state))
 
     def sk_exchange_adopt(self, data_ptr, meta_ptr, n_chunks, n_granules):
         import ctypes as C
@@ -329,6 +336,9 @@ def _list_worker(rank, world, port, tmp, pieces):
                 for ci, fill in enumerate(fake.pending[rank]):
                     want[(s, p * 100 + ci)] = fill
         assert got == want
+        # every sender that sent something told this owner its uniform-weight state (it rides in the upper bits of the chunk counts)
+        senders = {s_ for (s_, _) in want}
+        assert set(sp.peer_states) == {(1 << 32) | (0x3f000000 + s_) for s_ in senders}
         assert stats["bytes_to_peers"] > 0
         open(os.path.join(tmp, "ok.%d" % rank), "w").write("ok")
     finally:

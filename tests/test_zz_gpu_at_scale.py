@@ -235,12 +235,15 @@ def test_list_exchange_at_scale_on_one_gpu(name, world):
                 continue
             data, meta, sc, sg, goff, coff = packed[r]
             if sc[owner]:
+                if owner == 0:      # one owner is told by the senders (as the drivers do), the others look at what they receive
+                    hs[owner].sk_exchange_peer_uniform(hs[r].sk_exchange_uniform())
                 hs[owner].sk_exchange_adopt(data[goff[owner]:].data_ptr(), meta[coff[owner]:].data_ptr(), sc[owner], sg[owner])
         hs[owner].sync()
     tot = {"unique_kmers": 0, "weak_entries": 0, "singleton_kmers": 0}
     dig = None
     for h in hs:
         h.finalize(2)
+        assert h.build_info("uniform_count") == 1.0      # one weight on every rank: the owners count with the one-weight form, told or not
         st = h.stats()
         for key in tot:
             tot[key] += st[key]
@@ -396,3 +399,27 @@ def test_device_memory_returns_after_destroy():
         torch.cuda.synchronize()
         lost.append(before - torch.cuda.mem_get_info(0)[0])
     assert max(lost) < (64 << 20), lost          # a few MB of runtime bookkeeping at most
+
+
+def test_config3_whole_input_on_one_gpu_against_the_oracle():
+    """BASELINE.json configs[2]'s INPUT -- 100 M synthetic 150 bp reads of a 500 Mbp genome, seed 2, k = 31: 1.2e10 k-mers, what
+    `bench.py --gpus 8` spreads over eight GPUs -- built on ONE MI355X in eight calls of 12.5 M reads (each rank's batch generated, fed
+    and dropped in turn; ~150 GB of lists): statistics and weak-map digest (3.6e9 distinct k-mers) equal the SERIAL ORACLE's.  The
+    8-GPU run itself is the driver's; its bench line checks the ranks' summed digests against this same golden entry.  Runs last."""
+    import torch
+    try:
+        g = full_size_golden("c3_flat")
+    except KeyError:
+        pytest.skip("no oracle digest of config 3 committed (tests/golden/make_full_size_digests.py c3_flat: two hours of the build container)")
+    c = g["config"]
+    world, n, L, k = 8, c["reads"] // 8, c["read_len"], c["k"]
+    dev = torch.device("cuda", 0)
+    sp = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=c["reads"] * (L - k + 1), device=0))
+    for r in range(world):
+        b, q, o = ka.synth_reads_device(torch, c["seed"], r * n, n, L, c["genome"], c["noisy"], dev)
+        sp.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr(), n, n * L, r * n)
+        sp.sync()
+        del b, q, o
+    sp.finalize(c["min_depth"])
+    _assert_oracle(sp, g)
+    sp.close()

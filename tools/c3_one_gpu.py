@@ -33,3 +33,11 @@ for rep in range(2):
         st["raw_kmers"], st["raw_good_kmers"], st["unique_kmers"], st["weak_entries"], cons, int(hist.sum()) - st["weak_entries"], torch.cuda.mem_get_info()[0] / 1e9), flush=True)
     print("   ms per call:", calls, flush=True)
     assert st["raw_kmers"] == n * world * per and cons == 0 and int(hist.sum()) == st["weak_entries"]
+    if world == 8 and n == 12_500_000:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import digests_agree, full_size_golden
+        try:
+            g = full_size_golden("c3_flat")
+            print("   statistics == oracle:", st == g["stats"], " weak digest == oracle:", digests_agree(sp.digest(0), g["weak_digest"], 1e-6), flush=True)
+        except KeyError:
+            print("   (no oracle digest of config 3 under tests/golden yet)")

@@ -44,6 +44,7 @@ for rep in range(2):
     for r in range(1, world):
         x = extract_and_pack(other, r, 1)          # the stand-in is configured as rank 1: what it holds for owner 0 is what rank r would hold
         for part in x["parts"]:
+            me.sk_exchange_peer_uniform(other.sk_exchange_uniform())      # as the drivers do: the sender's state travels with its counts
             torch.cuda.synchronize(); t0 = time.time()
             me.sk_exchange_adopt(part["data"][part["goff"][0]:].data_ptr(), part["meta"][part["coff"][0]:].data_ptr(), part["sc"][0], part["sg"][0]); me.sync()
             adopt += time.time() - t0; got += 16 * part["sg"][0] / 1e9; npieces += part["sc"][0]
