@@ -1457,6 +1457,8 @@ bool sk_geometry(uint32_t k, uint32_t m_wish, uint32_t &win, uint32_t &m, uint32
 	 * m >= 14 (k >= 45, keys of two words and more) but is NOT the default: on C4 it takes the extraction from 40.7 to 28.4 ms and the count
 	 * pass from 115 to 257 ms -- one place of the genome then puts 33 x coverage k-mers into ONE list, lists of 700 k-mers hold one or
 	 * three such places, and the long ones overflow the LDS table into sub-passes; kmr_tune "superkmer_window" = 32 asks for it) */
+	/* (a window of 18 offsets at k = 31 -- minimizers of 14 bases, 10 % fewer records -- was built and measured too: extraction 7.57 -> 6.98 ms,
+	 * count pass 9.56 -> 10.92 ms on C2; its instances are no longer compiled, the kernels still take any window 16 + {1, 2, 4, 8, 16}) */
 	for (uint32_t w : {32u, 16u, 8u, 4u}) {
 		if (w > win_max) continue;
 		if (w == 32u && (k < 45u || (m_wish && m_wish < 14u))) continue;

@@ -455,15 +455,17 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 		uint32_t qrun = 0;
 		/* minimizer pipeline: runs sp.off positions behind the k-mer pipeline */
 		uint32_t mf = 0, mr = 0;
-		/* WIN = 32: the minimum over the last 32 hashes is the smaller of the block minimum over the last 16 and the one of 16 positions
-		 * earlier -- the value the same position of the window before produced (mprev) */
+		/* WIN > 16: the minimum over the last WIN hashes is the smaller of the block minimum over the last 16 and the block minimum of
+		 * WIN - 16 positions earlier -- a delay line of WIN - 16 registers (mprev), indexed by the position modulo its length, which is a
+		 * constant after unrolling as long as that length divides the 16 positions of an iteration: WIN = 17, 18, 20, 24, 32 */
 		constexpr int WB = WIN > 16 ? 16 : WIN;
-		static_assert(WIN <= 16 || WIN == 2 * SK_WINDOW, "windows above 16 are two blocks of SK_WINDOW");
-		uint32_t hs[WB], mprev[WIN > 16 ? SK_WINDOW : 1];
+		constexpr int WD = WIN > 16 ? WIN - 16 : 1;
+		static_assert(WIN <= 16 || SK_WINDOW % WD == 0, "the delay line of a window above 16 has to divide SK_WINDOW");
+		uint32_t hs[WB], mprev[WD];
 #pragma unroll
 		for (int i = 0; i < WB; i++) hs[i] = 0xffffffffu;
 #pragma unroll
-		for (int i = 0; i < (WIN > 16 ? SK_WINDOW : 1); i++) mprev[i] = 0xffffffffu;
+		for (int i = 0; i < WD; i++) mprev[i] = 0xffffffffu;
 		uint32_t pref = 0xffffffffu;
 		/* the run in progress */
 		bool runOpen = false, runUniform = true, runInWin = false;
@@ -577,7 +579,7 @@ void sk_extract_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView pool) {
 #pragma unroll
 					for (int u = WB - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
 				}
-				if constexpr (WIN > 16) { const uint32_t m16 = M; const uint32_t before = mprev[t]; M = before < M ? before : M; mprev[t] = m16; }
+				if constexpr (WIN > 16) { const uint32_t m16 = M; const uint32_t before = mprev[t % WD]; M = before < M ? before : M; mprev[t % WD] = m16; }
 				return M;
 			};
 			/* Flat window: no lane sees an N or a quality below the floor (in the window or in the k positions before it), and the
@@ -1120,15 +1122,17 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 		constexpr int ZN = W == 1 ? 1 : (W == 2 ? 2 : 3);      /* history of N flags, one bit per position: k + 1 bits */
 		uint64_t zbits[3] = {0, 0, 0};
 		uint32_t mf = 0, mr = 0;
-		/* WIN = 32: the minimum over the last 32 hashes is the smaller of the block minimum over the last 16 and the one of 16 positions
-		 * earlier -- the value the same position of the window before produced (mprev) */
+		/* WIN > 16: the minimum over the last WIN hashes is the smaller of the block minimum over the last 16 and the block minimum of
+		 * WIN - 16 positions earlier -- a delay line of WIN - 16 registers (mprev), indexed by the position modulo its length, which is a
+		 * constant after unrolling as long as that length divides the 16 positions of an iteration: WIN = 17, 18, 20, 24, 32 */
 		constexpr int WB = WIN > 16 ? 16 : WIN;
-		static_assert(WIN <= 16 || WIN == 2 * SK_WINDOW, "windows above 16 are two blocks of SK_WINDOW");
-		uint32_t hs[WB], mprev[WIN > 16 ? SK_WINDOW : 1];
+		constexpr int WD = WIN > 16 ? WIN - 16 : 1;
+		static_assert(WIN <= 16 || SK_WINDOW % WD == 0, "the delay line of a window above 16 has to divide SK_WINDOW");
+		uint32_t hs[WB], mprev[WD];
 #pragma unroll
 		for (int i = 0; i < WB; i++) hs[i] = 0xffffffffu;
 #pragma unroll
-		for (int i = 0; i < (WIN > 16 ? SK_WINDOW : 1); i++) mprev[i] = 0xffffffffu;
+		for (int i = 0; i < WD; i++) mprev[i] = 0xffffffffu;
 		uint32_t pref = 0xffffffffu;
 		bool runOpen = false, runInWin = false;
 		uint32_t runStart = 0, runN = 0, runMh = 0;
@@ -1236,7 +1240,7 @@ void sk_extract_lean_kernel(ReadsView rv, DevParams p, SkParams sp, PoolView poo
 #pragma unroll
 					for (int u = WB - 2; u >= 0; u--) hs[u] = hs[u] < hs[u + 1] ? hs[u] : hs[u + 1];
 				}
-				if constexpr (WIN > 16) { const uint32_t m16 = M; const uint32_t before = mprev[t]; M = before < M ? before : M; mprev[t] = m16; }
+				if constexpr (WIN > 16) { const uint32_t m16 = M; const uint32_t before = mprev[t % WD]; M = before < M ? before : M; mprev[t % WD] = m16; }
 				const bool valid = ((Vm >> t) & 1u) != 0;
 				const bool cont = runOpen && M == runMh && runN < SK_MAX_N;
 				const bool nw = valid && !cont;

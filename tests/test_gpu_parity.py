@@ -667,7 +667,8 @@ def test_uniform_weight_extraction(k, quals):
     assert np.array_equal(p.image(KMR_MAP_SINGLETON), g.image(KMR_MAP_SINGLETON))
 
 
-@pytest.mark.parametrize("k,win,quality", [(45, 32, "noisy"), (51, 32, "flat"), (51, 16, "noisy"), (51, 8, "flat"), (127, 32, "noisy"), (127, 16, "flat"), (44, 16, "noisy")])
+@pytest.mark.parametrize("k,win,quality", [(45, 32, "noisy"), (51, 32, "flat"), (51, 16, "noisy"), (51, 8, "flat"), (127, 32, "noisy"), (127, 16, "flat"), (44, 16, "noisy"),
+                                           (31, 16, "flat"), (31, 8, "noisy")])
 def test_minimizer_windows_at_large_k(k, win, quality):
     """build_mode 3 can take a minimizer window of 32 offsets from k = 45 on (runs of ~16 k-mers: half the records of a window of 16;
     kmr_tune superkmer_window, not the default: DESIGN.md) beside the windows of 16 / 8 / 4: every one of them must give the oracle's
