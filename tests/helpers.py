@@ -98,6 +98,8 @@ def default_config(k, **kw):
 
 
 def build_oracle():
+    if os.environ.get("KMR_ORACLE_SO"):      # a build of the oracle made elsewhere (the sanitizer run: oracle compiled with -fsanitize=address,undefined)
+        return os.environ["KMR_ORACLE_SO"]
     if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
             os.path.join(ORACLE_DIR, "kmr_oracle.cpp")):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])

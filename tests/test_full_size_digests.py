@@ -65,3 +65,26 @@ def test_part_digests_add_up_to_the_whole_build(name):
     o.finalize(c["min_depth"])
     assert o.stats() == g["stats"]
     assert digests_agree(o.digest(KMR_MAP_WEAK), g["weak_digest"], rel=1e-12)
+
+
+def test_oracle_merge_add_against_a_joint_build():
+    """orc_merge_add (KmerMapByKmerArrayPair::mergeAdd, src/Kmer.h:3209-3261) of the weak maps of two spectra built WITHOUT a singleton
+    map (so that no first sighting is set aside) == the weak map of one build over both read sets: keys, counts and direction
+    biases exactly, weightedCount up to the float additions' order -- the self-consistency the GPU test of kmr_merge_image leans on"""
+    from helpers import synth_reads
+    a = synth_reads(1500, read_len=120, genome_len=12000, seed=5, quality="noisy", n_rate=0.002)
+    b = synth_reads(1500, read_len=120, genome_len=12000, seed=5, quality="noisy", n_rate=0.002)
+    b.bases[:] = np.roll(b.bases.reshape(1500, 120), 7, axis=0).reshape(-1)          # the same genome, the reads in another order ...
+    b.quals[:] = np.roll(b.quals.reshape(1500, 120), 311, axis=0).reshape(-1)        # ... under other qualities
+    cfg = default_config(27, num_buckets_weak=256, num_buckets_singleton=256, separate_singletons=0)
+    oa, ob, oj = OracleSpectrum(cfg), OracleSpectrum(cfg), OracleSpectrum(cfg)
+    oa.add_reads(a); ob.add_reads(b)
+    oj.add_reads(a); oj.add_reads(b, first_idx=1500)
+    for o in (oa, ob, oj):
+        o.finalize(1)
+    oa.merge_add(ob)
+    ka_, ca, da, wa, _ = oa.entries()
+    kj, cj, dj, wj, _ = oj.entries()
+    assert np.array_equal(ka_, kj) and np.array_equal(ca, cj) and np.array_equal(da, dj)
+    assert np.all(np.abs(wa.astype(np.float64) - wj) <= 1e-5 * cj)
+    assert ob.stats()["weak_entries"] == 0 or ob.entries()[0].shape[0] == 0          # the source map is emptied (src.clear(), :3259)
