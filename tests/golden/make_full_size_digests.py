@@ -33,7 +33,7 @@ CONFIGS = {
     # 100 M reads, 500 Mbp): the ranks' digests must add up to these -- the bench line of a multi-GPU run checks itself against them
     "scale_n2": dict(k=31, seed=1, reads=20_000_000, genome=100_000_000, noisy=False, parts=8),
     "scale_n4": dict(k=31, seed=1, reads=40_000_000, genome=200_000_000, noisy=False, parts=8),
-    "c3_flat": dict(k=31, seed=2, reads=100_000_000, genome=500_000_000, noisy=False, parts=24),
+    "c3_flat": dict(k=31, seed=2, reads=100_000_000, genome=500_000_000, noisy=False, parts=32),
     # small ones: the same code path at sizes any test can rebuild (tests/test_full_size_digests.py does, on the CPU)
     "small_k31_noisy": dict(k=31, seed=11, reads=200_000, genome=1_000_000, noisy=True, parts=2),
     "small_k51_flat": dict(k=51, seed=12, reads=200_000, genome=1_000_000, noisy=False, parts=3),
@@ -62,10 +62,16 @@ CHUNK = 500_000
 MIN_DEPTH = 2          # unless the configuration says otherwise
 
 
+CACHE = os.environ.get("DIGEST_CACHE", "/tmp/kmr_digest_parts")      # finished parts are kept: a run that lost a worker (memory) is simply started again
+
+
 def one_part(args):
     name, part = args
     from helpers import KMR_MAP_SINGLETON, KMR_MAP_WEAK, OracleSpectrum, default_config, synth_reads_8d
     c = CONFIGS[name]
+    cached = os.path.join(CACHE, "%s_%dof%d.json" % (name, part, c["parts"]))
+    if os.path.exists(cached):
+        return tuple(json.load(open(cached)))
     per = READ_LEN - c["k"] + 1
     cfg = default_config(c["k"], estimated_raw_kmers=c["reads"] * per, num_parts=c["parts"], part_idx=part, **c.get("cfg", {}))
     o = OracleSpectrum(cfg)
@@ -78,6 +84,9 @@ def one_part(args):
     st, dg, ds = o.stats(), o.digest(KMR_MAP_WEAK), o.digest(KMR_MAP_SINGLETON)
     o.close()
     sys.stderr.write("%s part %d/%d: %.0f s, %d weak entries\n" % (name, part, c["parts"], time.time() - t0, dg["entries"]))
+    os.makedirs(CACHE, exist_ok=True)
+    json.dump([st, dg, ds], open(cached + ".tmp", "w"))
+    os.replace(cached + ".tmp", cached)
     return st, dg, ds
 
 
