@@ -33,7 +33,7 @@ CONFIGS = {
     # 100 M reads, 500 Mbp): the ranks' digests must add up to these -- the bench line of a multi-GPU run checks itself against them
     "scale_n2": dict(k=31, seed=1, reads=20_000_000, genome=100_000_000, noisy=False, parts=8),
     "scale_n4": dict(k=31, seed=1, reads=40_000_000, genome=200_000_000, noisy=False, parts=8),
-    "c3_flat": dict(k=31, seed=2, reads=100_000_000, genome=500_000_000, noisy=False, parts=32),
+    "c3_flat": dict(k=31, seed=2, reads=100_000_000, genome=500_000_000, noisy=False, parts=24),
     # small ones: the same code path at sizes any test can rebuild (tests/test_full_size_digests.py does, on the CPU)
     "small_k31_noisy": dict(k=31, seed=11, reads=200_000, genome=1_000_000, noisy=True, parts=2),
     "small_k51_flat": dict(k=51, seed=12, reads=200_000, genome=1_000_000, noisy=False, parts=3),
