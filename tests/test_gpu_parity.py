@@ -939,6 +939,29 @@ def test_million_noisy_reads_against_the_oracle(k):
     o.close()
 
 
+@pytest.mark.parametrize("k", [31, 51])
+def test_ragged_reads_at_scale_against_the_oracle(k):
+    """150 000 reads of every length from 0 to 400 bases (empty reads, reads shorter than k, reads that fill several LDS tiles' worth of
+    a wavefront unevenly), noisy qualities, 0.3 % N: the default build against the SERIAL oracle -- statistics, singleton image byte
+    for byte, weak image in keys, counts and direction biases; the fixed-length synthetic reads of the other at-scale tests never
+    put a short read next to a long one inside a tile"""
+    n = 150_000
+    full = synth_reads(n, read_len=400, genome_len=2_000_000, seed=500 + k, quality="noisy", n_rate=0.003)
+    rng = np.random.default_rng(9)
+    lens = rng.integers(0, 401, n)
+    lens[::97] = 0
+    lens[1::89] = k - 1
+    lens[2::83] = k
+    seqs = [full.bases[i * 400:i * 400 + int(lens[i])].tobytes() for i in range(n)]
+    quals = [full.quals[i * 400:i * 400 + int(lens[i])].tobytes() for i in range(n)]
+    rb = ReadBatch(seqs, quals)
+    cfg = default_config(k, estimated_raw_kmers=int(np.maximum(lens - k + 1, 0).sum()))
+    o, p = run_both(cfg, rb, min_depth=1, mode=0)
+    assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False) == o.stats()["weak_entries"] > 100_000
+    assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+    o.close()
+
+
 @pytest.mark.parametrize("k,mode,ext", [(21, 2, False), (31, 3, False), (51, 3, False), (95, 1, False), (127, 3, False), (21, 2, True), (31, 1, True)])
 def test_streaming_lookups_equal_table_probes(k, mode, ext):
     """f1 as a streaming pass (reads -> super-k-mers -> minimizer lists, the weak map's entries grouped by the same lists, answers from
