@@ -1412,7 +1412,10 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
                      CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv, SkLong<W> lg) {
 	static_assert(!UNI || (!TRACK && !EXT), "the one-weight count pass is the plain one's");
 	constexpr int S = 1 << LOG2S;
-	constexpr uint32_t LIMIT = (uint32_t)(S * 0.80);
+#ifndef KMR_SKC_LIMIT_PCT
+#define KMR_SKC_LIMIT_PCT 80      /* share of the table a list may fill before it is redone in sub-passes (C2 count pass at 70 / 80 / 85 / 90: 9.84 / 9.54 / 9.57 / 9.55 ms: overflowing lists are not what the uneven lists cost) */
+#endif
+	constexpr uint32_t LIMIT = (uint32_t)(S * (KMR_SKC_LIMIT_PCT / 100.0));
 	constexpr int WSLOTS = S / SKC_WAVES;        /* slots a wavefront looks after in the emit phase */
 	extern __shared__ __attribute__((aligned(16))) uint8_t csm[];
 	uint64_t *tkeys = (uint64_t *)csm;                                 /* [S][W] */
