@@ -359,6 +359,16 @@ int kmr_sk_exchange_adopt_dev(kmr_handle *h, const void *dev_data, const void *d
  * src/DistributedFunctions.h:274-303). */
 int kmr_sk_exchange_uniform(kmr_handle *h, uint64_t *state);
 int kmr_sk_exchange_peer_uniform(kmr_handle *h, uint64_t state);
+/* An exchange in steps over the list space, so that an owner can count what has arrived while the rest is on the wire:
+ * kmr_sk_exchange_range restricts the next kmr_sk_exchange_counts / kmr_sk_exchange_pack_dev to the lists in [list_lo, list_hi)
+ * (0, ~0: all of them, the default; kmr_reset restores it); kmr_count_lists_prefix runs the count pass over this handle's lists below
+ * list_hi NOW -- asynchronously on the handle's stream, into entry buffers of their own -- once everything those lists will ever get
+ * has been adopted; kmr_finalize (same min_depth) then counts the lists from list_hi on and takes the early entries over.  The
+ * result is that of kmr_finalize alone.  What cannot be counted early (extension values, a kept singleton map, the size tracker,
+ * coarse lists, early buffers that turn out too small) is quietly left to kmr_finalize.  The reference's MPI build has no such
+ * phase: its owners insert k-mers as messages arrive (src/DistributedFunctions.h:323-328) and purge at the end. */
+int kmr_sk_exchange_range(kmr_handle *h, uint64_t list_lo, uint64_t list_hi);
+int kmr_count_lists_prefix(kmr_handle *h, uint32_t min_depth, uint64_t list_hi);
 
 /* KmerSpectrum::SizeTracker (src/KmerSpectrum.h:812-900): the history of (rawKmers, rawGoodKmers, uniqueKmers, singletonKmers) the
  * apps write as --size-history-file (apps/FilterReads.cpp:141-147) and EstimateSize fits.  The reference calls track() before every
@@ -596,7 +606,8 @@ void *kmr_stream(kmr_handle *h);
 int kmr_tune(kmr_handle *h, const char *knob, double value);
 /* What the current build decided, for tests and measurement tools (the reference logs such figures, LOG_VERBOSE): "lists" = super-k-mer
  * lists of the build (0 before the first reads, or in another build mode), "uniform_count" = 1 if the last kmr_finalize ran the
- * count pass's one-weight form, "chunk_pool_chunks" = 1 KB chunks the pool holds, "superkmer_window" = the minimizer window in use.  KMR_ERR_INVALID_ARG for an unknown name. */
+ * count pass's one-weight form, "chunk_pool_chunks" = 1 KB chunks the pool holds, "superkmer_window" = the minimizer window in use, "early_lists" / "early_entries" = the bound below which the last
+ * kmr_finalize took its lists' entries from kmr_count_lists_prefix (0: it counted everything itself) and how many entries those were.  KMR_ERR_INVALID_ARG for an unknown name. */
 int kmr_build_info(kmr_handle *h, const char *what, double *value);
 
 /* Timing of the hot path measured with HIP events on the handle's stream

@@ -73,7 +73,7 @@ EXPORTS = [
     "kmr_artifact_config_init", "kmr_artifact_filter_create", "kmr_artifact_filter_info", "kmr_artifact_filter_entries",
     "kmr_artifact_filter_free", "kmr_artifact_filter_apply",
     "kmr_tune", "kmr_set_stream_origin", "kmr_size_tracker", "kmr_exchange_unique_id", "kmr_exchange_init", "kmr_exchange_init_transport", "kmr_exchange_add_reads_dev", "kmr_exchange_add_read_batch", "kmr_exchange_stats", "kmr_copy_to_host", "kmr_copy_to_device", "kmr_sk_exchange_begin", "kmr_sk_exchange_counts", "kmr_sk_exchange_pack_dev", "kmr_sk_exchange_adopt_dev", "kmr_extract_by_owner_host", "kmr_insert_records", "kmr_reads_from_host", "kmr_reads_from_twobit", "kmr_reads_twobit", "kmr_lookup_requests_dev", "kmr_lookup_keys_dev", "kmr_scatter_counts_dev", "kmr_score_counts_dev",
-    "kmr_map_digest", "kmr_synth_reads_dev", "kmr_build_info", "kmr_sk_exchange_uniform", "kmr_sk_exchange_peer_uniform",
+    "kmr_map_digest", "kmr_synth_reads_dev", "kmr_build_info", "kmr_sk_exchange_uniform", "kmr_sk_exchange_peer_uniform", "kmr_sk_exchange_range", "kmr_count_lists_prefix",
 ]
 
 _lib = None
@@ -180,6 +180,8 @@ def load():
     lib.kmr_build_info.argtypes = [vp, C.c_char_p, f64p]
     lib.kmr_sk_exchange_uniform.argtypes = [vp, u64p]
     lib.kmr_sk_exchange_peer_uniform.argtypes = [vp, C.c_uint64]
+    lib.kmr_sk_exchange_range.argtypes = [vp, C.c_uint64, C.c_uint64]
+    lib.kmr_count_lists_prefix.argtypes = [vp, C.c_uint32, C.c_uint64]
     lib.kmr_synth_reads_dev.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, vp]
     _lib = lib
     return lib

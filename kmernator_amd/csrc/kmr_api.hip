@@ -160,6 +160,11 @@ struct kmr_handle {
 	uint32_t sk_uni_w = 0xffffffffu; bool sk_uni_mixed = false; uint32_t *d_uni = nullptr; bool last_count_uniform = false;
 	/* ... or the senders say so themselves (kmr_sk_exchange_peer_uniform): then nothing is looked at on arrival */
 	uint32_t peer_uni_w = 0xffffffffu; bool peer_uni_mixed = false, peers_declare = false;
+	/* an exchange in steps over the list space (kmr_sk_exchange_range) and the lists below `hi` counted early (kmr_count_lists_prefix):
+	 * their entries wait in buffers of their own until kmr_finalize has counted the rest */
+	uint64_t xr_lo = 0, xr_hi = ~0ull;
+	struct Early { bool active = false; uint64_t hi = 0; uint32_t min_depth = 0; uint64_t *ue = nullptr; uint64_t cap = 0; unsigned long long *cursor = nullptr; void *fc = nullptr; } early;
+	uint64_t last_early_hi = 0, last_early_entries = 0;      /* what the last kmr_finalize took over from an early count (kmr_build_info) */
 	unsigned int *qrange = nullptr; bool qual_mixed = false;      /* sk_qual_range_kernel's answer; a build that has seen two different quality characters stops asking */
 	/* exchange with world_size > 1: sk_bits are the COARSE lists reads are scattered into and that travel; each holds 2^sk_fine_shift
 	 * fine lists, made by sk_refine_kernel before the count pass (fine state: sk_fine_state, 2^(sk_bits + sk_fine_shift) words) */
@@ -1793,7 +1798,6 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		if (head > h->l1.cap) head = h->l1.cap;
 		if (h->sk_fine_cap < nlf) {
 			if (h->sk_fine_state) hipFree(h->sk_fine_state);
-	if (h->d_uni) hipFree(h->d_uni);
 			h->sk_fine_state = nullptr; h->sk_fine_cap = 0;
 			HIPCHK(h, dev_malloc((void **)&h->sk_fine_state, 8 * nlf)); h->sk_fine_cap = nlf;
 		}
@@ -1863,6 +1867,26 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	SkLong<W> lgMain; lgMain.item_c0 = lgMain.item_c1 = nullptr; lgMain.n_items = 0; lgMain.long_threshold = 0; lgMain.merge.slots = nullptr; lgMain.merge.ext = nullptr; lgMain.merge.log2cap = 0; lgMain.merge_used = nullptr;
 	lgMain.list_first = 0; lgMain.list_stride = 1;
 	if (h->sk_exchange && h->cfg.world_size > 1 && !refined) { lgMain.list_first = h->cfg.rank; lgMain.list_stride = h->cfg.world_size; }      /* the other lists went to their owners */
+	/* lists below early.hi were counted by kmr_count_lists_prefix: this pass starts behind them and their entries are taken over below.
+	 * An early count that overflowed its buffers, or was made for another min-depth or map layout, is void: everything is counted here */
+	uint64_t early_slots = 0; FinalizeCounters early_c; memset(&early_c, 0, sizeof(early_c));
+	h->last_early_hi = 0; h->last_early_entries = 0;
+	if (h->early.active) {
+		uint32_t cerr0 = 0;
+		HIPCHK(h, hipMemcpy(&cerr0, h->derr, 4, hipMemcpyDeviceToHost));
+		unsigned long long ecur = 0;
+		HIPCHK(h, hipMemcpy(&ecur, h->early.cursor, 8, hipMemcpyDeviceToHost)); HIPCHK(h, hipMemcpy(&early_c, h->early.fc, sizeof(early_c), hipMemcpyDeviceToHost));
+		const bool ok = !(cerr0 & ERR_ENTRIES_FULL) && ecur <= h->early.cap && h->early.min_depth == min_depth && !tracking && !ext && !keepSing && !refined;
+		if (cerr0 & ERR_ENTRIES_FULL) { cerr0 &= ~(uint32_t)ERR_ENTRIES_FULL; HIPCHK(h, hipMemcpy(h->derr, &cerr0, 4, hipMemcpyHostToDevice)); }
+		if (ok) {
+			early_slots = ecur;
+			h->last_early_hi = h->early.hi; h->last_early_entries = early_c.weak_kept;
+			const uint64_t stride0 = lgMain.list_stride, first0 = lgMain.list_first;
+			uint64_t first = h->early.hi;
+			if (stride0 > 1) first += (first0 + stride0 - first % stride0) % stride0;      /* the first list at or behind hi that is this rank's */
+			lgMain.list_first = first;
+		} else { h->early.active = false; memset(&early_c, 0, sizeof(early_c)); }
+	}
 	SkLong<W> lgItems = lgMain;
 	uint64_t n_items = 0, long_chunks = 0;
 	/* (extension values: the 16-bit tallies of a block's table are exact below 65 536 k-mers, SK_EXT_LONG_CHUNKS) */
@@ -1962,6 +1986,21 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 			h->trk_elems.push_back(uniq * sub); h->trk_elems.push_back(f.has_singletons ? (uint64_t)single * sub : 0);
 		}
 	}
+	if (early_slots) {      /* the early count's entries behind this pass's (the slabs' unused tails are holes in both) */
+		const size_t eb = 8ull * (W + 1);
+		if (cur[0] + early_slots > h->ue_cap) {
+			uint64_t *bigger = nullptr; const uint64_t ncap = cur[0] + early_slots + 4096;
+			HIPCHK(h, dev_malloc((void **)&bigger, eb * ncap));
+			HIPCHK(h, hipMemcpyAsync(bigger, h->ue, eb * cur[0], hipMemcpyDeviceToDevice, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
+			hipFree(h->ue); h->ue = bigger; h->ue_cap = ncap;
+		}
+		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->ue + eb * cur[0], h->early.ue, eb * early_slots, hipMemcpyDeviceToDevice, h->stream));
+		cur[0] += early_slots;
+		c.unique += early_c.unique; c.singletons += early_c.singletons; c.weak_kept += early_c.weak_kept; c.sing_kept += early_c.sing_kept;
+		c.saturated += early_c.saturated; c.sat_sightings += early_c.sat_sightings;
+		h->stats.unique_kmers = c.unique; h->stats.singleton_kmers = f.has_singletons ? c.singletons : 0;
+	}
+	h->early.active = false;
 	hipEvent_t tma, tmb; time_begin(h, KMR_TIME_BUCKETS, &tma, &tmb);
 	rc = finish_maps_from_entries(h, wc, sc, cur[0], cur[1], c.weak_kept, c.sing_kept, keepSing, !ext);
 	time_end(h, KMR_TIME_BUCKETS, tma, tmb);
@@ -1975,6 +2014,80 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	if (!rc && !h->arena_overflow.empty()) rc = arena_reset(h);
 	return rc;
 }
+/* kmr_count_lists_prefix: the count pass over this handle's lists below `hi`, now, into entry buffers of their own -- the lower part of
+ * the list space is counted while the upper part is still on the wire; kmr_finalize counts what is left and takes these entries
+ * over.  Direction-counting values without a singleton map in the result (min_depth >= 2 or no separate singletons), fine lists only;
+ * anything else, or buffers that turn out too small, leaves the lists to kmr_finalize. */
+template <int W> int count_prefix_superkmer_t(kmr_handle *h, uint32_t min_depth, uint64_t hi) {
+	int rc = sync_state(h); if (rc) return rc;
+	FinalizeParams f; f.kb = h->hkb; f.ext_min_q = h->cfg.ext_min_quality; f.min_depth = min_depth; f.has_singletons = h->cfg.separate_singletons ? 1 : 0; f.nb_weak = h->nb_weak; f.nb_sing = h->nb_sing; f.uni_wbits = 0;
+	const bool keepSing = f.has_singletons && min_depth <= 1;
+	h->early.active = false;      /* an earlier early count is replaced */
+	if (h->ext || h->cfg.size_tracker || keepSing || (h->sk_state && h->sk_fine_shift > 0) || !h->sk_state) return KMR_OK;      /* nothing counted early: kmr_finalize does it all */
+	const uint64_t nl = sk_list_count(h->sk_bits);
+	if (hi > nl) hi = nl;
+	if (hi == 0) return KMR_OK;
+	rc = arena_reset(h); if (rc) return rc;
+	hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);
+	HIPCHK(h, hipGetLastError());
+	uint64_t *ls = nullptr, *lc = nullptr; uint32_t nch = 0;
+	rc = build_csr(h, h->l1, nl, 0, &ls, &lc, &nch); if (rc) return rc;
+	/* room: the share of the good k-mers that lies below hi, at the rate kmr_finalize starts with; too little is found out by
+	 * kmr_finalize (ERR_ENTRIES_FULL), which then counts everything itself */
+	const uint64_t G = h->stats.raw_good_kmers;      /* (an owner's lists hold about as many k-mers as its own reads gave: the job's share of one rank) */
+	const uint64_t slack = (uint64_t)num_cus(h) * 4 * 8192 + 16;
+	const uint64_t want = (uint64_t)((double)G * ((double)hi / (double)nl) / (f.has_singletons ? 6.0 : 2.5)) + slack;
+	if (!h->early.ue || h->early.cap < want) {
+		if (h->early.ue) hipFree(h->early.ue); h->early.ue = nullptr; h->early.cap = 0;
+		HIPCHK(h, dev_malloc((void **)&h->early.ue, 8ull * (W + 1) * want)); h->early.cap = want;
+	}
+	if (!h->early.cursor) HIPCHK(h, dev_malloc((void **)&h->early.cursor, 16));
+	if (!h->early.fc) HIPCHK(h, dev_malloc((void **)&h->early.fc, sizeof(FinalizeCounters)));
+	HIPCHK(h, hipMemsetAsync(h->early.cursor, 0, 16, h->stream)); HIPCHK(h, hipMemsetAsync(h->early.fc, 0, sizeof(FinalizeCounters), h->stream));
+	bool uni = false;
+	if (!h->sk_uni_mixed && !h->tune.no_uniform_count && !h->peer_uni_mixed) {
+		uint32_t w = h->sk_uni_w; bool mixed = false;
+		if (h->peer_uni_w != SK_UNI_NONE) { if (w == SK_UNI_NONE) w = h->peer_uni_w; else if (w != h->peer_uni_w) mixed = true; }
+		if (h->d_uni) {
+			uint32_t dv[2] = {SK_UNI_NONE, 0u};
+			HIPCHK(h, hipMemcpy(dv, h->d_uni, 8, hipMemcpyDeviceToHost));
+			if (dv[1]) mixed = true;
+			else if (dv[0] != SK_UNI_NONE) { if (w == SK_UNI_NONE) w = dv[0]; else if (w != dv[0]) mixed = true; }
+		}
+		if (!mixed && w != SK_UNI_NONE) { uni = true; f.uni_wbits = w; }
+	}
+	SkTrackView tv; tv.bounds = nullptr; tv.n = 0; tv.d_unique = tv.d_single = nullptr;
+	SkLong<W> lg; lg.item_c0 = lg.item_c1 = nullptr; lg.n_items = 0; lg.merge.slots = nullptr; lg.merge.ext = nullptr; lg.merge.log2cap = 0; lg.merge_used = nullptr;
+	lg.list_first = 0; lg.list_stride = 1;
+	if (h->sk_exchange && h->cfg.world_size > 1) { lg.list_first = h->cfg.rank; lg.list_stride = h->cfg.world_size; }
+	/* (lists too long for one block are left to kmr_finalize's pass over work items, which covers the whole list space) */
+	lg.long_threshold = h->tune.long_list_chunks ? h->tune.long_list_chunks : 1024;
+	uint32_t *sc = nullptr;
+	rc = arena_get(h, &sc, h->nb_sing); if (rc) return rc;
+	HIPCHK(h, hipMemsetAsync(sc, 0, 4 * h->nb_sing, h->stream));
+	CountOut out; out.wkeys = nullptr; out.wvals = nullptr; out.wentries = h->early.ue; out.wcursor = h->early.cursor; out.wcap = h->early.cap;
+	out.skeys = nullptr; out.sweight = nullptr; out.spkt = nullptr; out.scursor = h->early.cursor + 1; out.scap = 0;
+	out.weakCount = nullptr; out.singCount = sc; out.fc = (FinalizeCounters *)h->early.fc; out.err = h->derr;
+	rc = zero_work_counter(h); if (rc) return rc;
+	const uint64_t n_work = hi > lg.list_first ? (hi - lg.list_first + lg.list_stride - 1) / lg.list_stride : 0;
+	if (n_work) {
+		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (n_work + SK_LBATCH) / SK_LBATCH);
+		auto kern = uni ? sk_count_kernel<W, COUNT_LOG2S, false, false, true> : sk_count_kernel<W, COUNT_LOG2S, false>;
+		const size_t smem = sk_count_smem_bytes<W, COUNT_LOG2S, false>();
+		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+		hipEvent_t a, b; time_begin(h, KMR_TIME_COUNT, &a, &b);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(SKC_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, hi, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lg);
+		time_end(h, KMR_TIME_COUNT, a, b);
+		HIPCHK(h, hipGetLastError());
+	}
+	h->early.active = true; h->early.hi = hi; h->early.min_depth = min_depth;
+	return KMR_OK;      /* asynchronous: the handle's stream carries the pass; kmr_finalize (or kmr_sync) waits for it */
+}
+int count_prefix_superkmer(kmr_handle *h, uint32_t min_depth, uint64_t hi) {
+	switch (h->W) { case 1: return count_prefix_superkmer_t<1>(h, min_depth, hi); case 2: return count_prefix_superkmer_t<2>(h, min_depth, hi);
+	case 3: return count_prefix_superkmer_t<3>(h, min_depth, hi); default: return count_prefix_superkmer_t<4>(h, min_depth, hi); }
+}
+
 int finalize_superkmer(kmr_handle *h, uint32_t min_depth) {
 	switch (h->W) { case 1: return finalize_superkmer_t<1>(h, min_depth); case 2: return finalize_superkmer_t<2>(h, min_depth);
 	case 3: return finalize_superkmer_t<3>(h, min_depth); default: return finalize_superkmer_t<4>(h, min_depth); }
@@ -2121,6 +2234,8 @@ void kmr_destroy(kmr_handle *h) {
 	if (h->trk) hipFree(h->trk);
 	if (h->adopt_buf) hipFree(h->adopt_buf);
 	if (h->sk_fine_state) hipFree(h->sk_fine_state);
+	if (h->d_uni) hipFree(h->d_uni);
+	if (h->early.ue) hipFree(h->early.ue); if (h->early.cursor) hipFree(h->early.cursor); if (h->early.fc) hipFree(h->early.fc);
 	if (h->ix_start) hipFree(h->ix_start); if (h->ix_keys) hipFree(h->ix_keys); if (h->ix_counts) hipFree(h->ix_counts); if (h->scratch_stats) hipFree(h->scratch_stats);
 	exchange_free(h);
 	if (h->stream) hipStreamDestroy(h->stream);
@@ -2149,6 +2264,7 @@ int kmr_reset(kmr_handle *h) {
 		h->inserted_records = 0;
 		h->qual_mixed = false;
 		h->sk_uni_w = SK_UNI_NONE; h->sk_uni_mixed = false; h->peer_uni_w = SK_UNI_NONE; h->peer_uni_mixed = false;
+		h->xr_lo = 0; h->xr_hi = ~0ull; h->early.active = false;
 		if (h->d_uni) { const uint32_t init[2] = {SK_UNI_NONE, 0u}; HIPCHK(h, hipMemcpyAsync(h->d_uni, init, 8, hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
 		if (h->sk_state) hipLaunchKernelGGL(sk_state_init_kernel, dim3(grid_for(sk_list_count(h->sk_bits))), dim3(256), 0, h->stream, h->sk_state, sk_list_count(h->sk_bits));
 		if (h->l1_state) {      /* what an unfinished build kept back is dropped with its pool */
@@ -2231,6 +2347,8 @@ int kmr_build_info(kmr_handle *h, const char *what, double *value) {
 	else if (k == "uniform_count") *value = h->last_count_uniform ? 1.0 : 0.0;
 	else if (k == "chunk_pool_chunks") *value = (double)h->l1.cap;
 	else if (k == "superkmer_window") *value = (double)h->sk_win;
+	else if (k == "early_lists") *value = (double)h->last_early_hi;
+	else if (k == "early_entries") *value = (double)h->last_early_entries;
 	else return fail(h, KMR_ERR_INVALID_ARG, "unknown build figure '" + k + "'");
 	return KMR_OK;
 }
@@ -3633,7 +3751,7 @@ int kmr_sk_exchange_counts(kmr_handle *h, uint64_t *chunks, uint64_t *granules) 
 	unsigned long long *d = nullptr;
 	HIPCHK(h, dev_malloc((void **)&d, 16 * SK_OWNER_MAX)); HIPCHK(h, hipMemsetAsync(d, 0, 16 * SK_OWNER_MAX, h->stream));
 	hipLaunchKernelGGL(sk_close_kernel, dim3(grid_for(nl)), dim3(256), 0, h->stream, h->sk_state, nl, h->l1.chunk_count, h->l1.cap);
-	if (head) hipLaunchKernelGGL(sk_owner_count_kernel, dim3(grid_for(head)), dim3(256), 0, h->stream, h->l1.chunk_list, h->l1.chunk_count, head, world, d, d + SK_OWNER_MAX);
+	if (head) hipLaunchKernelGGL(sk_owner_count_kernel, dim3(grid_for(head)), dim3(256), 0, h->stream, h->l1.chunk_list, h->l1.chunk_count, head, world, d, d + SK_OWNER_MAX, h->xr_lo, h->xr_hi);
 	hipError_t e = hipGetLastError();
 	std::vector<unsigned long long> hv(2 * SK_OWNER_MAX, 0);
 	if (e == hipSuccess) e = hipMemcpyAsync(hv.data(), d, 16 * SK_OWNER_MAX, hipMemcpyDeviceToHost, h->stream);
@@ -3658,14 +3776,27 @@ int kmr_sk_exchange_pack_dev(kmr_handle *h, void *dev_data, void *dev_meta, cons
 	hipError_t e = hipMemcpyAsync(d, hv.data(), 32 * SK_OWNER_MAX, hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess && head) {
 		hipLaunchKernelGGL(sk_pack_kernel, dim3(grid_for((uint64_t)head * 64, 256, num_cus(h) * 8)), dim3(256), 0, h->stream, pool_view(h, h->l1), head, world, h->cfg.rank,
-		                   d, d + SK_OWNER_MAX, d + 2 * SK_OWNER_MAX, d + 3 * SK_OWNER_MAX, (uint4 *)dev_data, (uint2 *)dev_meta);
-		hipLaunchKernelGGL(sk_state_drop_kernel, dim3(grid_for(sk_list_count(h->sk_bits))), dim3(256), 0, h->stream, h->sk_state, sk_list_count(h->sk_bits), world, h->cfg.rank);
+		                   d, d + SK_OWNER_MAX, d + 2 * SK_OWNER_MAX, d + 3 * SK_OWNER_MAX, (uint4 *)dev_data, (uint2 *)dev_meta, h->xr_lo, h->xr_hi);
+		hipLaunchKernelGGL(sk_state_drop_kernel, dim3(grid_for(sk_list_count(h->sk_bits))), dim3(256), 0, h->stream, h->sk_state, sk_list_count(h->sk_bits), world, h->cfg.rank, h->xr_lo, h->xr_hi);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);      /* hv and d go out of scope */
 	hipFree(d);
 	HIPCHK(h, e);
 	return KMR_OK;
+}
+/* the part of the list space the next kmr_sk_exchange_counts / kmr_sk_exchange_pack_dev are about ([0, ~0) = all of it) */
+int kmr_sk_exchange_range(kmr_handle *h, uint64_t list_lo, uint64_t list_hi) {
+	if (!h || list_lo > list_hi) return KMR_ERR_INVALID_ARG;
+	h->xr_lo = list_lo; h->xr_hi = list_hi;
+	return KMR_OK;
+}
+int kmr_count_lists_prefix(kmr_handle *h, uint32_t min_depth, uint64_t list_hi) {
+	if (!h) return KMR_ERR_INVALID_ARG;
+	if (h->finalized) return fail(h, KMR_ERR_STATE, "kmr_count_lists_prefix after kmr_finalize");
+	if (!h->superkmer_mode) return KMR_OK;      /* the other build modes have no lists: kmr_finalize counts */
+	hipSetDevice(h->device);
+	return count_prefix_superkmer(h, min_depth, list_hi);
 }
 /* One weight for every record of this rank's lists so far?  state = kind << 32 | weight bits, kind 0: no record yet, 1: one weight, 2: several
  * (records with weights of their own).  A sender's state travels with its chunk counts; the owner folds it in with

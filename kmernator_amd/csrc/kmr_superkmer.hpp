@@ -2483,13 +2483,14 @@ void sat_reduce_kernel(const unsigned long long *keys, const uint32_t *weights, 
 static const uint32_t SK_OWNER_MAX = 64;
 #ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(256)
-void sk_owner_count_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, uint32_t world, unsigned long long *chunks, unsigned long long *granules) {
+void sk_owner_count_kernel(const uint32_t *chunk_list, const uint32_t *chunk_count, uint32_t n_chunks, uint32_t world, unsigned long long *chunks, unsigned long long *granules,
+                           uint64_t list_lo = 0, uint64_t list_hi = ~0ull) {      /* [list_lo, list_hi): the part of the list space this exchange step is about (kmr_sk_exchange_range) */
 	__shared__ unsigned long long lc[SK_OWNER_MAX], lg[SK_OWNER_MAX];
 	if (threadIdx.x < SK_OWNER_MAX) { lc[threadIdx.x] = 0; lg[threadIdx.x] = 0; }
 	__syncthreads();
 	for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t l = chunk_list[c];
-		if (l == NO_CHUNK || chunk_count[c] == 0) continue;
+		if (l == NO_CHUNK || chunk_count[c] == 0 || l < list_lo || l >= list_hi) continue;
 		atomicAdd(&lc[l % world], 1ull); atomicAdd(&lg[l % world], (unsigned long long)chunk_count[c]);
 	}
 	__syncthreads();
@@ -2506,7 +2507,7 @@ static const int SK_PACK_TILE = 1024;
 #ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(256)
 void sk_pack_kernel(PoolView pool, uint32_t n_chunks, uint32_t world, uint32_t rank, const unsigned long long *granule_base, const unsigned long long *chunk_base,
-                    unsigned long long *granule_cursor, unsigned long long *chunk_cursor, uint4 *out_data, uint2 *out_meta) {
+                    unsigned long long *granule_cursor, unsigned long long *chunk_cursor, uint4 *out_data, uint2 *out_meta, uint64_t list_lo = 0, uint64_t list_hi = ~0ull) {
 	__shared__ unsigned long long s_book[SK_OWNER_MAX], s_base[SK_OWNER_MAX];
 	__shared__ unsigned long long s_at[SK_PACK_TILE];          /* per chunk of the tile: place in the tile's share of its owner (chunks << 40 | granules), ~0 = stays */
 	__shared__ uint32_t s_list[SK_PACK_TILE];
@@ -2522,7 +2523,7 @@ void sk_pack_kernel(PoolView pool, uint32_t n_chunks, uint32_t world, uint32_t r
 			unsigned long long at = ~0ull; uint32_t l = NO_CHUNK, cnt = 0, o = 0;
 			if (c < n_chunks) {
 				l = pool.chunk_list[c]; cnt = pool.chunk_count[c];
-				if (l != NO_CHUNK && cnt != 0 && l % world != rank) { o = l % world; if (cnt > SK_CHUNK_G) cnt = SK_CHUNK_G; at = atomicAdd(&s_book[o], (1ull << 40) | (unsigned long long)cnt); }
+				if (l != NO_CHUNK && cnt != 0 && l % world != rank && l >= list_lo && l < list_hi) { o = l % world; if (cnt > SK_CHUNK_G) cnt = SK_CHUNK_G; at = atomicAdd(&s_book[o], (1ull << 40) | (unsigned long long)cnt); }
 			}
 			s_at[i] = at; s_list[i] = l; s_cnt[i] = (uint8_t)cnt; s_own[i] = (uint8_t)o;
 		}
@@ -2544,9 +2545,9 @@ void sk_pack_kernel(PoolView pool, uint32_t n_chunks, uint32_t world, uint32_t r
 #endif
 /* lists of other owners start afresh (their chunks are gone) */
 #ifndef KMR_INSTANCE_TU
-__global__ void sk_state_drop_kernel(unsigned long long *state, uint64_t n, uint32_t world, uint32_t rank) {
+__global__ void sk_state_drop_kernel(unsigned long long *state, uint64_t n, uint32_t world, uint32_t rank, uint64_t list_lo = 0, uint64_t list_hi = ~0ull) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		if (i % world != rank) state[i] = ((unsigned long long)NO_CHUNK << 32) | SK_CHUNK_G;
+		if (i % world != rank && i >= list_lo && i < list_hi) state[i] = ((unsigned long long)NO_CHUNK << 32) | SK_CHUNK_G;
 }
 #endif
 /* Are the records a rank receives all uniform with one weight (the count pass's UNI form)?  One thread per received chunk follows its

@@ -251,6 +251,14 @@ class KmerSpectrum:
         """kmr_sk_exchange_peer_uniform: fold a sender's state in, before adopting its chunks"""
         self._call("sk_exchange_peer_uniform", self.h, int(state))
 
+    def sk_exchange_range(self, list_lo=0, list_hi=0xFFFFFFFFFFFFFFFF):
+        """kmr_sk_exchange_range: the lists the next sk_exchange_counts / sk_exchange_pack are about"""
+        self._call("sk_exchange_range", self.h, int(list_lo), int(list_hi))
+
+    def count_lists_prefix(self, min_depth, list_hi):
+        """kmr_count_lists_prefix: count this handle's lists below list_hi now (asynchronously); finalize(min_depth) does the rest"""
+        self._call("count_lists_prefix", self.h, int(min_depth), int(list_hi))
+
     def sk_exchange_adopt(self, data_ptr, meta_ptr, n_chunks, n_granules):
         self._call("sk_exchange_adopt_dev", self.h, data_ptr, meta_ptr, n_chunks, n_granules)
 

@@ -691,6 +691,51 @@ def test_minimizer_windows_at_large_k(k, win, quality):
     assert np.array_equal(p.getCount(keys[:2000]), cnt[:2000])
 
 
+@pytest.mark.parametrize("k,quality,share", [(31, "flat", 0.5), (31, "noisy", 0.3), (51, "noisy", 0.5), (31, "flat", 1.0), (31, "noisy", 0.0)])
+def test_lists_counted_early_then_finalize(k, quality, share):
+    """kmr_count_lists_prefix: the lists below a bound are counted ahead of kmr_finalize (what an owner does with the part of the list
+    space that has arrived while the rest is on the wire); kmr_finalize counts the others and takes the early entries over.  Statistics
+    and weak image must be those of kmr_finalize alone, byte for byte -- for a bound in the middle, at the end (everything early) and at
+    zero; a second early count replaces the first; a min-depth that keeps the singleton map leaves everything to kmr_finalize."""
+    rb = synth_reads(40000, read_len=150, genome_len=300000, seed=640 + k, quality=quality, n_rate=0.001)
+    cfg = default_config(k, estimated_raw_kmers=40000 * (150 - k + 1))
+    plain, early = product(cfg, 3), product(cfg, 3)
+    add(plain, rb)
+    add(early, rb)
+    nl = int(early.build_info("lists"))
+    assert nl > 64
+    early.count_lists_prefix(2, nl // 7)                 # replaced by the next one
+    early.count_lists_prefix(2, int(nl * share))
+    plain.finalize(2)
+    early.finalize(2)
+    assert early.build_info("early_lists") == int(nl * share) and plain.build_info("early_lists") == 0
+    if share > 0:
+        assert 0 < early.build_info("early_entries") <= early.stats()["weak_entries"]
+    if share == 1.0:
+        assert early.build_info("early_entries") == early.stats()["weak_entries"]
+    assert plain.stats() == early.stats()
+    assert np.array_equal(plain.image(KMR_MAP_WEAK), early.image(KMR_MAP_WEAK))
+    # with the singleton map kept nothing is counted early; the result is the same all the same
+    for sp in (plain, early):
+        sp.reset()
+        add(sp, rb)
+    early.count_lists_prefix(1, nl // 2)
+    plain.finalize(1)
+    early.finalize(1)
+    assert early.build_info("early_lists") == 0
+    assert plain.stats() == early.stats()
+    assert np.array_equal(plain.image(KMR_MAP_WEAK), early.image(KMR_MAP_WEAK)) and np.array_equal(plain.image(KMR_MAP_SINGLETON), early.image(KMR_MAP_SINGLETON))
+    # an early count made for another min-depth is void
+    for sp in (plain, early):
+        sp.reset()
+        add(sp, rb)
+    early.count_lists_prefix(3, nl // 2)
+    plain.finalize(2)
+    early.finalize(2)
+    assert early.build_info("early_lists") == 0
+    assert plain.stats() == early.stats() and np.array_equal(plain.image(KMR_MAP_WEAK), early.image(KMR_MAP_WEAK))
+
+
 def test_host_batch_in_pieces_sizes_lists_from_the_whole_call():
     """kmr_add_reads / kmr_add_reads_twobit send a host batch to the device in pieces; without an estimate of the job's k-mers the first
     piece must size the lists (and the chunk pool) for the WHOLE call, as one device call does -- not for itself"""

@@ -254,6 +254,72 @@ def test_list_exchange_at_scale_on_one_gpu(name, world):
     assert digests_agree(dig, g["weak_digest"], WEIGHT_REL), (dig, g["weak_digest"])
 
 
+@pytest.mark.parametrize("name,world", [("xchg_k31_4m", 2), ("xchg_k31_8m", 4)])
+def test_list_exchange_in_two_steps_with_an_early_count(name, world):
+    """The exchange in two steps over the list space (kmr_sk_exchange_range): the lower half of the lists travels and is adopted, every
+    owner counts it (kmr_count_lists_prefix) -- on real devices while the upper half is on the wire --, then the upper half travels
+    and kmr_finalize counts it and takes the early entries over.  `world` handles on one GPU, segments handed over in device memory:
+    the owners' statistics and digests must add up to the SERIAL ORACLE's of the whole job, as in the one-step exchange."""
+    import torch
+    g = full_size_golden(name)
+    c = g["config"]
+    k, L = c["k"], c["read_len"]
+    n = c["reads"] // world
+    dev = torch.device("cuda", 0)
+    per = L - k + 1
+    hs = []
+    for r in range(world):
+        h = ka.KmerSpectrum(ka.default_config(k, estimated_raw_kmers=n * per * world, device=0, rank=r, world_size=world, build_mode=3))
+        b, q, o = ka.synth_reads_device(torch, c["seed"], r * n, n, L, c["genome"], c["noisy"], dev)
+        h.sk_exchange_begin()
+        h.set_stream_origin(r * n * L)
+        h.buildKmerSpectrumDevice(b.data_ptr(), q.data_ptr(), o.data_ptr(), n, n * L, r * n)
+        h.sync()
+        del b, q, o
+        hs.append(h)
+    nl = int(hs[0].build_info("lists"))
+    mid = nl // 2
+    for lo, hi in ((0, mid), (mid, nl)):
+        packed = []
+        for r, h in enumerate(hs):
+            h.sk_exchange_range(lo, hi)
+            chunks, granules = h.sk_exchange_counts()
+            sc = [int(x) if j != r else 0 for j, x in enumerate(chunks)]
+            sg = [int(x) if j != r else 0 for j, x in enumerate(granules)]
+            goff = [int(x) for x in np.concatenate([[0], np.cumsum(sg)[:-1]])]
+            coff = [int(x) for x in np.concatenate([[0], np.cumsum(sc)[:-1]])]
+            data = torch.empty((max(sum(sg), 1), 4), dtype=torch.int32, device=dev)
+            meta = torch.empty((max(sum(sc), 1), 2), dtype=torch.int32, device=dev)
+            h.sk_exchange_pack(data.data_ptr(), meta.data_ptr(), goff, coff)
+            assert sum(sc) > 10_000
+            packed.append((data, meta, sc, sg, goff, coff))
+        for owner in range(world):
+            for r in range(world):
+                if r == owner:
+                    continue
+                data, meta, sc, sg, goff, coff = packed[r]
+                if sc[owner]:
+                    hs[owner].sk_exchange_peer_uniform(hs[r].sk_exchange_uniform())
+                    hs[owner].sk_exchange_adopt(data[goff[owner]:].data_ptr(), meta[coff[owner]:].data_ptr(), sc[owner], sg[owner])
+            if hi == mid:
+                hs[owner].count_lists_prefix(2, mid)          # the lower half is complete on this owner
+        for h in hs:
+            h.sync()
+        del packed
+    tot = {"unique_kmers": 0, "weak_entries": 0, "singleton_kmers": 0}
+    dig = None
+    for h in hs:
+        h.finalize(2)
+        assert h.build_info("early_lists") == mid and h.build_info("early_entries") > 100_000      # the lower half's entries came from the early count
+        st = h.stats()
+        for key in tot:
+            tot[key] += st[key]
+        dig = add_digests(dig, h.digest(KMR_MAP_WEAK))
+        h.close()
+    assert {key: g["stats"][key] for key in tot} == tot
+    assert digests_agree(dig, g["weak_digest"], WEIGHT_REL), (dig, g["weak_digest"])
+
+
 def test_c2_full_size_against_the_oracle():
     """BASELINE.json configs[1] at full size (10M reads x 150 bp, k=31, 1.2e9 k-mers; SURVEY 8(d): seed 1, 50 Mbp genome) through
     the device-pointer entry point bench.py times.  Statistics and the weak map's digest equal the SERIAL ORACLE's (keys, counts and
