@@ -50,6 +50,8 @@ def parse_args():
                     "running while the next is extracted.  Default 1: with 10 M reads per rank a rank holds half a chunk for each of the job's "
                     "lists at 8 ranks, so every further piece sends (and the owner adopts) that many more partly filled chunks "
                     "(tools/two_rank_step.py: 43.8 ms of compute per step in one piece, 48.4 in two)")
+    ap.add_argument("--exchange-steps", type=int, default=1, help="N > 1: the exchange goes over the list space in this many steps and every owner counts the lists that "
+                    "have arrived (kmr_count_lists_prefix) while the next step is on the wire.  Default 1: nothing on a one-GPU box can say what it buys")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="kmr_tune knob of the handle (measurement sweeps), e.g. partition_blocks=192")
     ap.add_argument("--no-check", action="store_true", help="development: skip the conservation assert (ablation runs of a debug build)")
     ap.add_argument("--build-mode", type=int, default=0, help="kmr_config.build_mode: 0 auto, 1 device table, 2 two-level k-mer partition, 3 super-k-mer lists")
@@ -203,7 +205,8 @@ def main():
             sp.buildKmerSpectrumDevice(bases.data_ptr(), quals.data_ptr(), offsets.data_ptr(), n_reads, total_bases, 0)
         elif mode_num == 3:
             build_partitioned_superkmers(sp, bases[:total_bases + 64], quals[:total_bases + 64], offsets, first_read_idx=rank * n_reads, stats=xstats,
-                                         stream_origin=rank * total_bases, pieces=args.exchange_pieces if world > 1 else 1)
+                                         stream_origin=rank * total_bases, pieces=args.exchange_pieces if world > 1 else 1,
+                                         list_steps=args.exchange_steps, early_min_depth=2 if args.exchange_steps > 1 else None)
         else:
             build_partitioned(sp, bases, quals, offsets, first_read_idx=rank * n_reads, stats=xstats)
         sp.finalize(2)

@@ -189,7 +189,8 @@ def build_partitioned(spectrum, bases, quals, offsets, first_read_idx=0, chunk_r
     return spectrum
 
 
-def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx=0, group=None, stats=None, stream_origin=None, pieces=1):
+def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx=0, group=None, stats=None, stream_origin=None, pieces=1,
+                                 list_steps=1, early_min_depth=None):
     """The N > 1 build on super-k-mer lists (kmr_config.build_mode = 3, rank / world_size configured): every rank scatters the
     super-k-mers of its own reads into the job's lists on its own GPU (no owner filter), list l belongs to rank l % world, and
     the chunks a rank holds of other ranks' lists travel as they lie -- one all-to-all of (list, granules) pairs and one of the
@@ -202,7 +203,13 @@ def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx
     a k-mer is the first one in the whole input, as in a serial build, whatever the ranks' timing.  pieces > 1 (the same on every
     rank): the reads go through in that many pieces and the all-to-all of piece i runs (RCCL's own stream) while the library's
     stream extracts piece i + 1 -- over xGMI the exchange of a C2 batch takes about as long as its extraction.  stats (a dict,
-    optional) accumulates "bytes_to_peers", "records_sent" (granules), "chunks", "alltoall_ms"."""
+    optional) accumulates "bytes_to_peers", "records_sent" (granules), "chunks", "alltoall_ms".
+
+    list_steps > 1 (with pieces == 1; the same on every rank): the whole batch is extracted first and the exchange then goes over the
+    list space in that many steps (kmr_sk_exchange_range) -- while step s + 1 is on the wire the owner has everything the lists of
+    steps <= s will ever get and, given early_min_depth (the min_depth kmr_finalize will be called with), counts them
+    (kmr_count_lists_prefix): the count pass of the lower part of the list space overlaps the all-to-all of the upper part.  The
+    result is that of the one-step exchange.  Not measured on real devices: off by default."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = bases.device
@@ -246,8 +253,9 @@ def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx
             timed = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             timed[0].record()
         works = []
-        got_meta = _all_to_all_sliced(meta[:ac], send_c, recv_c, group, works=works if pieces > 1 else None)
-        got_data = _all_to_all_sliced(data[:ag], send_g, recv_g, group, works=works if pieces > 1 else None)
+        overlap = pieces > 1 or list_steps > 1
+        got_meta = _all_to_all_sliced(meta[:ac], send_c, recv_c, group, works=works if overlap else None)
+        got_data = _all_to_all_sliced(data[:ag], send_g, recv_g, group, works=works if overlap else None)
         if stats is not None:
             stats["chunks"] = stats.get("chunks", 0) + sum(send_c)
             stats["records_sent"] = stats.get("records_sent", 0) + sum(send_g)
@@ -269,6 +277,27 @@ def build_partitioned_superkmers(spectrum, bases, quals, offsets, first_read_idx
         if sum(x["recv_c"]):
             spectrum.sk_exchange_adopt(x["data"].data_ptr(), x["meta"].data_ptr(), sum(x["recv_c"]), sum(x["recv_g"]))
 
+    list_steps = max(1, int(list_steps))
+    if list_steps > 1:
+        if pieces != 1:
+            raise ValueError("list_steps > 1 goes with pieces == 1")
+        if n:
+            spectrum.set_stream_origin(stream_origin)
+            spectrum.buildKmerSpectrumDevice(bases.data_ptr(), None if quals is None else quals.data_ptr(), offsets.data_ptr(), n, total, first_read_idx)
+        nl = int(spectrum.build_info("lists"))
+        bounds = [nl * s // list_steps for s in range(list_steps)] + [nl]
+        pending, pending_hi = None, 0
+        for s in range(list_steps):
+            spectrum.sk_exchange_range(bounds[s], bounds[s + 1] if s + 1 < list_steps else 0xFFFFFFFFFFFFFFFF)
+            x = start(s)                       # counts, pack, the step's all-to-alls set going (behind the step before on the wire)
+            if pending is not None:
+                finish(pending)                # the step before has arrived: adopt it ...
+                if early_min_depth is not None:
+                    spectrum.count_lists_prefix(early_min_depth, pending_hi)      # ... and count everything below its bound while this step travels
+            pending, pending_hi = x, bounds[s + 1]
+        finish(pending)
+        spectrum.sk_exchange_range()
+        return spectrum
     pending = None
     for i in range(pieces):
         lo, hi = cuts[i], cuts[i + 1]

@@ -249,6 +249,7 @@ class _FakeListSpectrum:
     def __init__(self, rank, world):
         self.rank, self.world, self.piece, self.pending, self.adopted, self.origin, self.begun = rank, world, -1, None, [], [], False
         self.peer_states = []
+        self.calls = []
 
     def sk_exchange_begin(self):
         self.begun = True
@@ -282,6 +283,20 @@ class _FakeListSpectrum:
                 g += fill
                 c += 1
         self.pending = None
+
+    def build_info(self, what):
+        assert what == "lists"
+        return 1000.0
+
+    def sk_exchange_range(self, lo=0, hi=0xFFFFFFFFFFFFFFFF):
+        self.calls.append(("range", int(lo), int(hi)))
+        # a step of the list space: what the fake "holds" for the others is made anew per step, as if the step's lists were packed
+        if (lo, hi) != (0, 0xFFFFFFFFFFFFFFFF) and self.calls.count(("range", int(lo), int(hi))) == 1 and len([c for c in self.calls if c[0] == "range"]) > 1:
+            self.piece += 1
+            self.pending = {r: [((self.rank * 7 + r * 3 + self.piece * 5 + c) % 64) + 1 for c in range((self.rank + 2 * r + self.piece) % 4 + 1)] for r in range(self.world)}
+
+    def count_lists_prefix(self, min_depth, hi):
+        self.calls.append(("count_prefix", int(min_depth), int(hi), len(self.adopted)))
 
     def sk_exchange_uniform(self):
         return (1 << 32) | (0x3f000000 + self.rank)      # "one weight", a different one on every rank, so that the owner can tell whose state it got
@@ -343,6 +358,40 @@ def _list_worker(rank, world, port, tmp, pieces):
         open(os.path.join(tmp, "ok.%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
+
+
+def _steps_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmernator_amd.distributed import build_partitioned_superkmers
+        n = 400 + 100 * rank
+        offsets = torch.arange(n + 1, dtype=torch.int64) * 100
+        bases = torch.zeros(int(offsets[-1]) + 64, dtype=torch.uint8)
+        sp = _FakeListSpectrum(rank, world)
+        build_partitioned_superkmers(sp, bases, bases, offsets, first_read_idx=0, list_steps=2, early_min_depth=2)
+        # one extraction of the whole batch; the list space in two steps; the lower half counted after it was adopted and before the upper
+        # half is; the range restored at the end
+        assert sp.piece == 1                      # build (piece 0) + the second step's pack
+        kinds = [c[0] for c in sp.calls]
+        assert kinds == ["range", "range", "count_prefix", "range"]
+        assert sp.calls[0][1:] == (0, 500) and sp.calls[1][1] == 500 and sp.calls[3][1:] == (0, 0xFFFFFFFFFFFFFFFF)
+        assert sp.calls[2][1:3] == (2, 500) and sp.calls[2][3] == 1      # exactly one adopt (the lower half's) had happened
+        assert len(sp.adopted) == 2
+        open(os.path.join(tmp, "ok.%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_list_exchange_in_steps_driver(world):
+    """build_partitioned_superkmers(list_steps=2, early_min_depth=2): the call sequence an owner sees -- the lower half of the list space
+    adopted, counted early, then the upper half -- over gloo with a stand-in spectrum"""
+    port = 31100 + (os.getpid() % 500) + 10 * world
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_steps_worker, args=(world, port, tmp), nprocs=world, join=True)
+        assert all(os.path.exists(os.path.join(tmp, "ok.%d" % r)) for r in range(world))
 
 
 @pytest.mark.parametrize("world,pieces", [(2, 1), (3, 3), (2, 4)])
