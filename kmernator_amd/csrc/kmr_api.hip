@@ -1841,7 +1841,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 	/* one weight for every record of the lists (own calls: host state; adopted records: the device pair)?  Then the count pass's UNI form */
 	bool uni = false;
 	f.uni_wbits = 0;
-	if (!tracking && !ext && !h->sk_uni_mixed && !h->tune.no_uniform_count) {
+	if (!tracking && !ext && !h->sk_uni_mixed && !h->tune.no_uniform_count && (W == 1 || (h->k & 31u) != 0)) {      /* (multi-word keys: the one-weight pass has no state words, it needs pad bits in the last key word) */
 		uint32_t w = h->sk_uni_w; bool mixed = false;
 		if (h->peer_uni_mixed) mixed = true;
 		else if (h->peer_uni_w != SK_UNI_NONE) { if (w == SK_UNI_NONE) w = h->peer_uni_w; else if (w != h->peer_uni_w) mixed = true; }
@@ -1931,7 +1931,7 @@ template <int W> int finalize_superkmer_t(kmr_handle *h, uint32_t min_depth) {
 		rc = zero_work_counter(h); if (rc) return rc;
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (nl / lgMain.list_stride + SK_LBATCH) / SK_LBATCH);
 		auto kern = ext ? sk_count_kernel<W, COUNT_LOG2S_EXT, false, true> : (tracking ? sk_count_kernel<W, COUNT_LOG2S, true> : (uni ? sk_count_kernel<W, COUNT_LOG2S, false, false, true> : sk_count_kernel<W, COUNT_LOG2S, false>));
-		const size_t smem = ext ? sk_count_smem_bytes<W, COUNT_LOG2S_EXT, false, true>() : (tracking ? sk_count_smem_bytes<W, COUNT_LOG2S, true>() : sk_count_smem_bytes<W, COUNT_LOG2S, false>());
+		const size_t smem = ext ? sk_count_smem_bytes<W, COUNT_LOG2S_EXT, false, true>() : (tracking ? sk_count_smem_bytes<W, COUNT_LOG2S, true>() : (uni ? sk_count_smem_bytes<W, COUNT_LOG2S, false, false, true>() : sk_count_smem_bytes<W, COUNT_LOG2S, false>()));
 		if (tracking) HIPCHK(h, hipMemsetAsync(tv.d_unique, 0, 8 * (tv.n + 1), h->stream));
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 		if (dbg()) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, SKC_THREADS, smem); fprintf(stderr, "sk_count<W=%d>: %d blocks per CU (LDS %zu), %llu lists, %u chunks\n", W, nb, smem, (unsigned long long)nl, nch); }
@@ -2045,7 +2045,7 @@ template <int W> int count_prefix_superkmer_t(kmr_handle *h, uint32_t min_depth,
 	if (!h->early.fc) HIPCHK(h, dev_malloc((void **)&h->early.fc, sizeof(FinalizeCounters)));
 	HIPCHK(h, hipMemsetAsync(h->early.cursor, 0, 16, h->stream)); HIPCHK(h, hipMemsetAsync(h->early.fc, 0, sizeof(FinalizeCounters), h->stream));
 	bool uni = false;
-	if (!h->sk_uni_mixed && !h->tune.no_uniform_count && !h->peer_uni_mixed) {
+	if (!h->sk_uni_mixed && !h->tune.no_uniform_count && !h->peer_uni_mixed && (W == 1 || (h->k & 31u) != 0)) {
 		uint32_t w = h->sk_uni_w; bool mixed = false;
 		if (h->peer_uni_w != SK_UNI_NONE) { if (w == SK_UNI_NONE) w = h->peer_uni_w; else if (w != h->peer_uni_w) mixed = true; }
 		if (h->d_uni) {
@@ -2073,7 +2073,7 @@ template <int W> int count_prefix_superkmer_t(kmr_handle *h, uint32_t min_depth,
 	if (n_work) {
 		const int grid = (int)std::min<uint64_t>((uint64_t)num_cus(h) * 4, (n_work + SK_LBATCH) / SK_LBATCH);
 		auto kern = uni ? sk_count_kernel<W, COUNT_LOG2S, false, false, true> : sk_count_kernel<W, COUNT_LOG2S, false>;
-		const size_t smem = sk_count_smem_bytes<W, COUNT_LOG2S, false>();
+		const size_t smem = uni ? sk_count_smem_bytes<W, COUNT_LOG2S, false, false, true>() : sk_count_smem_bytes<W, COUNT_LOG2S, false>();
 		HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 		hipEvent_t a, b; time_begin(h, KMR_TIME_COUNT, &a, &b);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(SKC_THREADS), smem, h->stream, pool_view(h, h->l1), ls, lc, hi, h->k, out, f, h->work_counter, sk_dbg_flags("KMR_SK_COUNT_DBG"), tv, lg);

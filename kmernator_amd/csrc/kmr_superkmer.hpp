@@ -1369,8 +1369,9 @@ template <int W> struct SkLong {
 /* EXT (extension values): six more words per slot -- the twelve tallies as 16-bit halves, exact while a block's share of a list stays
  * below 65 536 k-mers (the host cuts longer lists into pieces, SK_EXT_LONG_CHUNKS) -- and the packet of one occurrence, read only
  * when the key ends as a singleton: 60 bytes per slot, two blocks per CU */
-template <int W, int LOG2S, bool TRACK = false, bool EXT = false>
-__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) + (TRACK ? 8 : 0) + (EXT ? 28 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
+/* (the one-weight pass over multi-word keys keeps no weight sums and no state words: 32 instead of 44 bytes per slot at W = 2) */
+template <int W, int LOG2S, bool TRACK = false, bool EXT = false, bool UNI = false>
+__host__ __device__ constexpr size_t sk_count_smem_bytes() { return (size_t)(1 << LOG2S) * (8 * W + 24 + (W > 1 ? 4 : 0) - (UNI && W > 1 ? 12 : 0) + (TRACK ? 8 : 0) + (EXT ? 28 : 0)) + (size_t)SK_STAGE_G * 16 + 256 + 64 + (TRACK ? 8 * (SK_TRACK_MAX + 1) : 0); }
 /* a chunk of extension records holds at most ~6.4 k-mers per granule (n = 128: 21 granules): 128 chunks stay below 65 536 k-mers */
 static const uint64_t SK_EXT_LONG_CHUNKS = 128;
 static const int SK_EXT_BLOCKS = 3;      /* blocks per CU of the count pass with extension values (166 registers; four -- 128 registers, 34 dwords spilled -- ran 11 % slower) */
@@ -1407,11 +1408,14 @@ static const unsigned long long SK_OSLAB = 2048;      /* entries a wavefront res
  * f64, count * w needs 24 + 20 bits -- so the table takes no ds_add_f64, no weight is read or converted per k-mer, and the weight
  * part of the first-sighting word is a constant of the launch (a sixth of the inner loop's vector instructions). */
 template <int W, int LOG2S, bool TRACK = false, bool EXT = false, bool UNI = false>
-__global__ __launch_bounds__(SKC_THREADS, EXT ? (W == 1 ? (LOG2S <= 9 ? SK_EXT_BLOCKS : 2) : 1) : ((W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? 3 : 1)))
+__global__ __launch_bounds__(SKC_THREADS, EXT ? (W == 1 ? (LOG2S <= 9 ? SK_EXT_BLOCKS : 2) : 1) : ((W == 1 && LOG2S <= 10 && !TRACK) ? 4 : (W == 2 && LOG2S <= 10 && !TRACK ? (UNI ? 4 : 3) : 1)))
 void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *list_chunks, uint64_t n_lists, uint32_t k,
                      CountOut out, FinalizeParams f, unsigned int *work_counter, uint32_t dbgFlags, SkTrackView tv, SkLong<W> lg) {
 	static_assert(!UNI || (!TRACK && !EXT), "the one-weight count pass is the plain one's");
 	constexpr int S = 1 << LOG2S;
+	/* LEAN: the one-weight pass over multi-word keys keeps neither weight sums (count x weight at emit) nor state words (the host sends only
+	 * k with pad bits in the last key word here: the claim protocol of SK_KEY_PENDING needs none) -- W = 2: 37 KB a block, four to a CU */
+	constexpr bool LEAN = UNI && W > 1;
 #ifndef KMR_SKC_LIMIT_PCT
 #define KMR_SKC_LIMIT_PCT 80      /* share of the table a list may fill before it is redone in sub-passes (C2 count pass at 70 / 80 / 85 / 90: 9.84 / 9.54 / 9.57 / 9.55 ms: overflowing lists are not what the uneven lists cost) */
 #endif
@@ -1421,9 +1425,9 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	uint64_t *tkeys = (uint64_t *)csm;                                 /* [S][W] */
 	unsigned long long *tcnt = (unsigned long long *)(tkeys + (size_t)S * W);
 	double *twsum = (double *)(tcnt + S);
-	unsigned long long *tfirst = (unsigned long long *)(twsum + S);
-	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only */
-	uint32_t *ttally = tstate + (W > 1 ? S : 0);                       /* EXT only: [S][6] tallies (left A C | G T | N X, right A C | G T | N X as 16-bit halves), [S] packets */
+	unsigned long long *tfirst = (unsigned long long *)(twsum + (LEAN ? 0 : S));
+	uint32_t *tstate = (uint32_t *)(tfirst + S);                       /* W > 1 only, and not LEAN */
+	uint32_t *ttally = tstate + (W > 1 && !LEAN ? S : 0);                       /* EXT only: [S][6] tallies (left A C | G T | N X, right A C | G T | N X as 16-bit halves), [S] packets */
 	uint32_t *tpkt = ttally + (EXT ? 6 * S : 0);
 	uint4 *stage = (uint4 *)(tpkt + (EXT ? S : 0));                    /* 16-byte aligned: every table array is a multiple of 16 bytes */
 	uint8_t *recOf = (uint8_t *)(stage + SK_STAGE_G);                  /* [4][64] per wavefront: header lane of the record a lane's first k-mer lies in */
@@ -1445,7 +1449,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 	unsigned long long wpos = 0, wend = 0, spos = 0, send = 0;
 	bool outFull = false;
 	if (t == 0) { s_claimed[0] = s_claimed[1] = 0; s_overflow[0] = s_overflow[1] = 0; s_sp = 0; }
-	for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)i * W + W - 1] = SK_KEY_PENDING; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
+	for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)i * W + W - 1] = SK_KEY_PENDING; tcnt[i] = 0; if constexpr (!LEAN) twsum[i] = 0.0; tfirst[i] = NO_FIRST; if constexpr (W > 1 && !LEAN) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
 	if (EXT) for (int i = t; i < 6 * S; i += SKC_THREADS) ttally[i] = 0;
 	lds_barrier();
 	/* classify() of kmr_kernels.hpp folded into launch-wide scalars: a count of one goes to class singC when singletons are separate,
@@ -1503,7 +1507,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 			 * bits `bits` equal val: sub-passes of a split list) */
 			auto insert_pass = [&](const uint32_t bits, const uint32_t val, const bool firstPass) {
 				const uint32_t subMask = bits ? ((1u << bits) - 1) : 0;
-				const bool padded = W > 1 && (k & 31u) != 0;      /* the last key word ends in pad bits: the claim protocol of SK_KEY_PENDING */
+				const bool padded = W > 1 && (LEAN || (k & 31u) != 0);      /* the last key word ends in pad bits: the claim protocol of SK_KEY_PENDING */
 				uint4 *wstage = stage + wv * SK_CHUNK_G;
 				uint8_t *wrecOf = recOf + wv * 64;
 				uint4 cur = make_uint4(0, 0, 0, 0); uint32_t curCount = 0;
@@ -1749,7 +1753,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 										const unsigned long long o2 = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)cur.key.w[0]);
 										if (o2 == EMPTY_KEY) { claimedHere++; placed = true; break; }
 										if (o2 == cur.key.w[0]) { placed = true; break; }
-									} else {
+									} else if constexpr (!LEAN) {
 										uint32_t st = __hip_atomic_load(&tstate[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 										if (st == 0) {
 											const uint32_t old2 = atomicCAS(&tstate[s], 0u, 1u);
@@ -1951,7 +1955,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				for (int i = 0; i < WSLOTS / 64; i++) {
 					const int s = wv * WSLOTS + i * 64 + lane;
 					if ((usedMask[i] >> lane) & 1ull) {
-						tkeys[(size_t)s * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)s * W + W - 1] = SK_KEY_PENDING; tcnt[s] = 0; twsum[s] = 0.0; tfirst[s] = NO_FIRST; if (W > 1) tstate[s] = 0; if (TRACK) tsecond[s] = NO_FIRST;
+						tkeys[(size_t)s * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)s * W + W - 1] = SK_KEY_PENDING; tcnt[s] = 0; if constexpr (!LEAN) twsum[s] = 0.0; tfirst[s] = NO_FIRST; if constexpr (W > 1 && !LEAN) tstate[s] = 0; if (TRACK) tsecond[s] = NO_FIRST;
 						if constexpr (EXT) {
 #pragma unroll
 							for (int q = 0; q < 6; q++) ttally[(size_t)s * 6 + q] = 0;
@@ -1960,7 +1964,7 @@ void sk_count_kernel(PoolView pool, const uint64_t *list_start, const uint64_t *
 				}
 			};
 			auto clear_table = [&]() {
-				for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)i * W + W - 1] = SK_KEY_PENDING; tcnt[i] = 0; twsum[i] = 0.0; tfirst[i] = NO_FIRST; if (W > 1) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
+				for (int i = t; i < S; i += SKC_THREADS) { tkeys[(size_t)i * W] = EMPTY_KEY; if (W > 1) tkeys[(size_t)i * W + W - 1] = SK_KEY_PENDING; tcnt[i] = 0; if constexpr (!LEAN) twsum[i] = 0.0; tfirst[i] = NO_FIRST; if constexpr (W > 1 && !LEAN) tstate[i] = 0; if (TRACK) tsecond[i] = NO_FIRST; }
 				if (EXT) for (int i = t; i < 6 * S; i += SKC_THREADS) ttally[i] = 0;
 			};
 
