@@ -1321,7 +1321,11 @@ template <int W> int binned_buckets_t(kmr_handle *h, uint64_t wslots, uint64_t w
 		rc2 = reserve_bytes(h, (void **)&wm.vals, wm.c_vals, 12ull * wn); if (rc2) return rc2;
 		auto gk = bb_group_kernel<W>;
 		HIPCHK(h, hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bb_group_smem_bytes<W>()));
-		hipLaunchKernelGGL(gk, dim3((unsigned)std::min<uint64_t>(groups, (uint64_t)num_cus(h) * 8)), dim3(BB_GROUP_THREADS), bb_group_smem_bytes<W>(), h->stream, entries, wm.keys, wm.vals, gs, gc, groups, g, h->hkb, nb, wm.start, wn, h->derr);
+		/* the blocks stride over the groups: as many of them as fit the chip at once, so that they all get the same number of groups */
+		int per_cu = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)gk, BB_GROUP_THREADS, bb_group_smem_bytes<W>()) != hipSuccess || per_cu < 1) per_cu = 4;
+		if (dbg()) fprintf(stderr, "bb_group<W=%d>: %d blocks per CU, %llu groups\n", W, per_cu, (unsigned long long)groups);
+		hipLaunchKernelGGL(gk, dim3((unsigned)std::min<uint64_t>(groups, (uint64_t)num_cus(h) * per_cu)), dim3(BB_GROUP_THREADS), bb_group_smem_bytes<W>(), h->stream, entries, wm.keys, wm.vals, gs, gc, groups, g, h->hkb, nb, wm.start, wn, h->derr);
 		HIPCHK(h, hipGetLastError());
 		return 0;
 	};
@@ -1334,7 +1338,7 @@ template <int W> int binned_buckets_t(kmr_handle *h, uint64_t wslots, uint64_t w
 		hipLaunchKernelGGL(bb_pad_kernel, dim3(grid_for(bins1)), dim3(256), 0, h->stream, (const uint32_t *)hist1, bins1, (uint32_t *)nullptr, dmax);
 		HIPCHK(h, hipMemcpyAsync(&mx, dmax, 4, hipMemcpyDeviceToHost, h->stream));
 		rc = exclusive_scan(h, hist1, bins1, start1); if (rc) return rc;      /* (synchronises) */
-		if (mx > BB_GROUP_CAP) return 0;
+		if (mx > bb_group_cap<W>()) return 0;
 		rc = scratch(wn); if (rc) return rc;
 		hipLaunchKernelGGL(bb_cursor_init_kernel, dim3(grid_for(bins1)), dim3(256), 0, h->stream, (const uint64_t *)start1, bins1, cursor);
 		hipLaunchKernelGGL(bb_scatter_kernel<W>, dim3(scatter_grid(wslots)), dim3(BB_THREADS), 0, h->stream, in1, shift1, bits1, h->hkb, nb, cursor, h->ue2);
@@ -1360,7 +1364,7 @@ template <int W> int binned_buckets_t(kmr_handle *h, uint64_t wslots, uint64_t w
 	rc = exclusive_scan(h, hist2, groups, gstart); if (rc) return rc;
 	/* the packed entries the count pass wrote are about to be overwritten (the second level writes where the first one read): a
 	 * group too large for the LDS arrays sends the build down the other path BEFORE that */
-	if (mx > BB_GROUP_CAP || h->ue_cap < wn) return 0;
+	if (mx > bb_group_cap<W>() || h->ue_cap < wn) return 0;
 	hipLaunchKernelGGL(bb_cursor_init_kernel, dim3(grid_for(groups)), dim3(256), 0, h->stream, (const uint64_t *)gstart, groups, cursor);
 	hipLaunchKernelGGL(bb_scatter_kernel<W>, dim3(scatter_grid(padded_total)), dim3(BB_THREADS), 0, h->stream, in2, shift2, bits2, h->hkb, nb, cursor, h->ue);
 	rc = group_launch(h->ue, gstart, hist2); if (rc) return rc;

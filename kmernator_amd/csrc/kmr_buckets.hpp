@@ -34,7 +34,10 @@ static const int BB_GROUP_THREADS = 256;    /* threads of a bb_group_kernel bloc
 static const int BB_PER_THREAD = BB_TILE / BB_THREADS;
 static const int BB_MAX_BITS = 10;          /* bins per level <= 1024                                                   */
 static const int BB_MAX_GROUP_BITS = 8;     /* buckets per group <= 256                                                 */
-static const uint32_t BB_GROUP_CAP = 1536;  /* entries of a group the LDS arrays take                                   */
+static const uint32_t BB_GROUP_CAP = 1536;  /* entries of a group the LDS arrays take (one-word keys: 30 KB, five blocks per CU) */
+/* multi-word keys: 28 bytes an entry at W = 2 -- 1344 of them (37 KB) let four blocks share a CU where 1536 allowed three; the groups
+ * are sized for 512-1023 entries on average, and one that is larger than the arrays sends the build down the other path */
+template <int W> __host__ __device__ constexpr uint32_t bb_group_cap() { return W == 1 ? BB_GROUP_CAP : 1344u; }
 
 /* the entries a level reads: segments (one at the first level: the count pass's slots with their holes; the bins of the level
  * before afterwards) whose starts are multiples of BB_TILE */
@@ -186,21 +189,22 @@ void bb_scatter_kernel(BbInput in, uint32_t shift, uint32_t bits, uint32_t kb, u
 }
 
 static const int BB_GROUP_PER_THREAD = (BB_GROUP_CAP + BB_GROUP_THREADS - 1) / BB_GROUP_THREADS;
-template <int W> __host__ __device__ constexpr size_t bb_group_smem_bytes() { return (size_t)BB_GROUP_CAP * (8 * W + 8 + 2 + 2); }
+template <int W> __host__ __device__ constexpr size_t bb_group_smem_bytes() { return (size_t)bb_group_cap<W>() * (8 * W + 8 + 2 + 2); }
 
 /* One block per group of 2^gbits neighbouring buckets: its entries lie at [gstart[G], gstart[G] + gcount[G]) of `entries` and go
  * to the same range of the map's key and value arrays, in (bucket, key) order.  A thread keeps its (up to six) entries in
  * registers while the buckets are counted and scanned, then files them into LDS bucket by bucket, so that the rank loop of an
  * entry walks the consecutive keys of its bucket (independent LDS reads, no index in between). */
 template <int W>
-__global__ __launch_bounds__(BB_GROUP_THREADS)
+__global__ __launch_bounds__(BB_GROUP_THREADS, W <= 2 ? 4 : 1)      /* (W = 2: 130 registers without the bound, three blocks per CU) */
 void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, const uint64_t *gstart, const uint32_t *gcount, uint64_t n_groups, uint32_t gbits, uint32_t kb, uint64_t nb,
                      uint64_t *start, uint64_t n_total, uint32_t *err) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t gsm[];
 	uint64_t *skeys = (uint64_t *)gsm;                                   /* [CAP][W] keys, grouped by bucket */
-	uint64_t *svalw = skeys + (size_t)BB_GROUP_CAP * W;                  /* [CAP] value words, same order   */
-	uint16_t *sbucket = (uint16_t *)(svalw + BB_GROUP_CAP);              /* bucket (inside the group) of the entry at a position */
-	uint16_t *final_ = sbucket + BB_GROUP_CAP;                           /* position (in bucket order) of the entry that ends up at a place */
+	constexpr uint32_t CAP = bb_group_cap<W>();
+	uint64_t *svalw = skeys + (size_t)CAP * W;                  /* [CAP] value words, same order   */
+	uint16_t *sbucket = (uint16_t *)(svalw + CAP);              /* bucket (inside the group) of the entry at a position */
+	uint16_t *final_ = sbucket + CAP;                           /* position (in bucket order) of the entry that ends up at a place */
 	__shared__ uint32_t bcnt[1 << BB_MAX_GROUP_BITS], bstart[(1 << BB_MAX_GROUP_BITS) + 1], bscan[BB_GROUP_THREADS / 64];
 	const int t = threadIdx.x;
 	const uint32_t nbk = 1u << gbits;
@@ -209,7 +213,7 @@ void bb_group_kernel(const uint64_t *entries, uint64_t *keys, uint32_t *vals, co
 		const uint32_t n = gcount[G];
 		__syncthreads();
 		if ((uint32_t)t < nbk) bcnt[t] = 0;
-		if (n > BB_GROUP_CAP) { if (t == 0) atomicOr(err, (uint32_t)ERR_ENTRIES_FULL); continue; }      /* (the host looked at the largest group before the launch) */
+		if (n > CAP) { if (t == 0) atomicOr(err, (uint32_t)ERR_ENTRIES_FULL); continue; }      /* (the host looked at the largest group before the launch) */
 		__syncthreads();
 		uint64_t ew[BB_GROUP_PER_THREAD][W + 1]; uint32_t lb[BB_GROUP_PER_THREAD];
 #pragma unroll

@@ -948,11 +948,14 @@ static const int SKL_WAVES = 4, SKL_MIN_BLOCKS = 2;      /* 8 wavefronts per CU 
 static const int SKL_WAVE_LDS = (SK_GROUPS * 4 + SK_GROUPS * 2 + 8 + SK_WINDOW * 64 * 4 + 15) & ~15;
 static const size_t SKL_EXTRACT_SMEM = (size_t)SKL_WAVES * SKL_WAVE_LDS;
 
-/* smallest and largest quality character of the reads offsets[0] .. offsets[n_reads] (min in range[0], max in range[1]) */
+/* Are the quality characters of the reads offsets[0] .. offsets[n_reads] all the same one?  range[0] gets a lower bound of the smallest
+ * and range[1] an upper bound of the largest (the bytes of the AND and of the OR of all dwords: two instructions a dword instead of
+ * a minimum and a maximum per byte), equal -- and then exact -- iff one character fills the range; 255 / 0 are left alone when there is none */
 #ifndef KMR_INSTANCE_TU
 __global__ __launch_bounds__(256)
 void sk_qual_range_kernel(const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads, unsigned int *range) {
 	unsigned int lo = 255, hi = 0;
+	uint32_t all = 0xffffffffu, any = 0u;
 	const uint64_t b0 = offsets[0], b1 = offsets[n_reads];
 	const uintptr_t p0 = (uintptr_t)(quals + b0), p1 = (uintptr_t)(quals + b1);
 	const uintptr_t a0 = (p0 + 15) & ~(uintptr_t)15, a1 = p1 & ~(uintptr_t)15;      /* the 16-byte aligned middle */
@@ -966,20 +969,15 @@ void sk_qual_range_kernel(const uint8_t *quals, const uint64_t *offsets, uint64_
 #pragma unroll
 			for (int u = 0; u < 4; u++) { const uint64_t i = i0 + (uint64_t)u * nthreads; v[u] = q4[i < n16 ? i : i0]; }
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-				for (int j = 0; j < 4; j++) {
-#pragma unroll
-					for (int b = 0; b < 4; b++) { const unsigned int c = (w4[j] >> (8 * b)) & 0xffu; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
-				}
-			}
+			for (int u = 0; u < 4; u++) { all &= v[u].x & v[u].y & v[u].z & v[u].w; any |= v[u].x | v[u].y | v[u].z | v[u].w; }
 		}
 		if (tid < 16) { const uintptr_t q = p0 + tid; if (q < a0) { const unsigned int c = *(const uint8_t *)q; lo = c < lo ? c : lo; hi = c > hi ? c : hi; } }
 		if (tid >= 16 && tid < 32) { const uintptr_t q = a1 + (tid - 16); if (q < p1) { const unsigned int c = *(const uint8_t *)q; lo = c < lo ? c : lo; hi = c > hi ? c : hi; } }
 	} else {
 		for (uintptr_t q = p0 + tid; q < p1; q += nthreads) { const unsigned int c = *(const uint8_t *)q; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
 	}
+#pragma unroll
+	for (int b = 0; b < 4; b++) { const unsigned int c0 = (all >> (8 * b)) & 0xffu, c1 = (any >> (8 * b)) & 0xffu; lo = c0 < lo ? c0 : lo; hi = c1 > hi ? c1 : hi; }
 	for (int o = 32; o > 0; o >>= 1) { const unsigned int a = (unsigned int)__shfl_xor((int)lo, o, 64), b = (unsigned int)__shfl_xor((int)hi, o, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
 	if ((threadIdx.x & 63) == 0) { atomicMin(&range[0], lo); atomicMax(&range[1], hi); }
 }
