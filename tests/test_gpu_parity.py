@@ -639,7 +639,7 @@ def _uniform_quality_reads(seed, k, quals):
 
 
 @pytest.mark.parametrize("quals", ["flat", "ref", "none"])
-@pytest.mark.parametrize("k", [13, 21, 31, 32, 51, 127])
+@pytest.mark.parametrize("k", [13, 21, 31, 32, 51, 64, 127])
 def test_uniform_weight_extraction(k, quals):
     """sk_extract_lean_kernel takes launches whose k-mers all weigh the same (no qualities, or one quality character): the spectrum
     must be the serial oracle's, and byte for byte what the general kernel makes of the same reads (kmr_tune lean_extract = 0) -- with
@@ -658,7 +658,10 @@ def test_uniform_weight_extraction(k, quals):
     for x in (o, p, g, u):
         x.finalize(1)
     # one weight throughout: the count pass's one-weight form (no weight sums in the table) against the general form on the same lists
-    assert (p.build_info("uniform_count"), g.build_info("uniform_count"), u.build_info("uniform_count")) == (1.0, 0.0, 0.0)
+    # (multi-word keys without pad bits in the last word -- k = 64 -- claim slots through state words, which the one-weight table of
+    # multi-word keys does not keep: the general form counts them)
+    one_weight_form = 1.0 if (k <= 32 or k % 32 != 0) else 0.0
+    assert (p.build_info("uniform_count"), g.build_info("uniform_count"), u.build_info("uniform_count")) == (one_weight_form, 0.0, 0.0)
     assert np.array_equal(p.image(KMR_MAP_WEAK), u.image(KMR_MAP_WEAK)) and np.array_equal(p.image(KMR_MAP_SINGLETON), u.image(KMR_MAP_SINGLETON))
     assert o.stats() == p.stats() == g.stats() == u.stats()
     compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False)
