@@ -602,6 +602,30 @@ def test_many_distinct_keys_force_subpass_split():
     assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
 
 
+@pytest.mark.parametrize("k", [31, 51])
+def test_one_weight_count_pass_cold_paths(k):
+    """The one-weight form of the default build's count pass (one quality character; over two-word keys its LDS table keeps neither
+    weight sums nor state words) off its usual path: lists whose distinct k-mers overflow the table and are redone in sub-passes by
+    further hash bits (low coverage, 2 % errors, an estimate a third of the truth), lists so long that they are counted in pieces
+    through the merge table (an estimate of next to nothing; long_list_chunks turned down on an ordinary input)."""
+    sparse = synth_reads(30000, read_len=150, genome_len=40_000_000, seed=78 + k, err=0.02)
+    n_kmers = 30000 * (150 - k + 1)
+    for est in (n_kmers // 3, 1000):
+        cfg = default_config(k, estimated_raw_kmers=est, num_buckets_weak=4096, num_buckets_singleton=16384)
+        o, p = run_both(cfg, sparse, min_depth=1, mode=3)
+        assert p.build_info("uniform_count") == 1.0
+        assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False) == o.stats()["weak_entries"]
+        assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+    covered = synth_reads(20000, read_len=150, genome_len=120000, seed=k)
+    cfg = default_config(k, estimated_raw_kmers=20000 * 40)
+    for min_depth in (2, 1):
+        o, p = run_both(cfg, covered, min_depth=min_depth, mode=3, long_list_chunks=3)
+        assert p.build_info("uniform_count") == 1.0
+        assert compare_weak_images(o.image(KMR_MAP_WEAK), p.image(KMR_MAP_WEAK), p.kb, False) == o.stats()["weak_entries"]
+        if min_depth == 1:
+            assert np.array_equal(o.image(KMR_MAP_SINGLETON), p.image(KMR_MAP_SINGLETON))
+
+
 @pytest.mark.parametrize("k,nbw,reads", [(31, 1 << 10, 4000), (31, 1 << 16, 30000), (31, 1 << 20, 30000), (51, 1 << 19, 20000), (127, 1 << 12, 6000)])
 def test_buckets_by_radix_partition(k, nbw, reads):
     """The weak map of the default build is bucketed by an MSD radix partition over the bucket index (kmr_buckets.hpp) instead of a
