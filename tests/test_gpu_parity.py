@@ -718,13 +718,14 @@ def test_minimizer_windows_at_large_k(k, win, quality):
     assert np.array_equal(p.getCount(keys[:2000]), cnt[:2000])
 
 
-@pytest.mark.parametrize("k,quality,share", [(31, "flat", 0.5), (31, "noisy", 0.3), (51, "noisy", 0.5), (31, "flat", 1.0), (31, "noisy", 0.0)])
-def test_lists_counted_early_then_finalize(k, quality, share):
+@pytest.mark.parametrize("k,quality,share,n_rate", [(31, "flat", 0.5, 0.001), (31, "noisy", 0.3, 0.001), (51, "noisy", 0.5, 0.001), (31, "flat", 1.0, 0.001), (31, "noisy", 0.0, 0.001),
+                                                   (31, "flat", 0.5, 0.0), (51, "flat", 0.4, 0.0)])      # (no N and one quality character: the one-weight count pass, early and late)
+def test_lists_counted_early_then_finalize(k, quality, share, n_rate):
     """kmr_count_lists_prefix: the lists below a bound are counted ahead of kmr_finalize (what an owner does with the part of the list
     space that has arrived while the rest is on the wire); kmr_finalize counts the others and takes the early entries over.  Statistics
     and weak image must be those of kmr_finalize alone, byte for byte -- for a bound in the middle, at the end (everything early) and at
     zero; a second early count replaces the first; a min-depth that keeps the singleton map leaves everything to kmr_finalize."""
-    rb = synth_reads(40000, read_len=150, genome_len=300000, seed=640 + k, quality=quality, n_rate=0.001)
+    rb = synth_reads(40000, read_len=150, genome_len=300000, seed=640 + k, quality=quality, n_rate=n_rate)
     cfg = default_config(k, estimated_raw_kmers=40000 * (150 - k + 1))
     plain, early = product(cfg, 3), product(cfg, 3)
     add(plain, rb)
@@ -742,6 +743,7 @@ def test_lists_counted_early_then_finalize(k, quality, share):
         assert early.build_info("early_entries") == early.stats()["weak_entries"]
     assert plain.stats() == early.stats()
     assert np.array_equal(plain.image(KMR_MAP_WEAK), early.image(KMR_MAP_WEAK))
+    assert plain.build_info("uniform_count") == early.build_info("uniform_count") == (1.0 if (quality == "flat" and n_rate == 0.0) else 0.0)
     # with the singleton map kept nothing is counted early; the result is the same all the same
     for sp in (plain, early):
         sp.reset()
