@@ -6,6 +6,10 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 pass() { # name counters...
   n=$1; shift
+  if [ -n "$SQ_PROGRAM" ]; then      # another tool instead of bench.py: SQ_PROGRAM=tools/c4_check.py tools/sq_counters.sh c4 50000000 51 150 3
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/sq_${tag}_$n -- python3 $R/$SQ_PROGRAM $BENCH_ARGS > $R/gpurun_out/sq_${tag}_$n.log 2>&1 || tail -3 $R/gpurun_out/sq_${tag}_$n.log
+    return
+  fi
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/sq_${tag}_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-h2d $BENCH_ARGS > $R/gpurun_out/sq_${tag}_$n.log 2>&1 || tail -3 $R/gpurun_out/sq_${tag}_$n.log
 }
 BENCH_ARGS="$*"
