@@ -1329,8 +1329,12 @@ template <int W> __device__ __forceinline__ Key<W> key_revcomp(const Key<W> &f, 
 	Key<W> o;
 #pragma unroll
 	for (int i = 0; i < W; i++) {
+		/* words i + ws and i + ws + 1 of r (zero beyond the last one), by selects over the W words: r.w[] indexed with the run-time word
+		 * shift lived in scratch memory -- a store, a load and a wait for the vector-memory counter per k-mer of a multi-word key */
 		const int a = i + (int)ws;
-		const uint64_t hi = a < W ? r.w[a < W ? a : 0] : 0ull, lo = a + 1 < W ? r.w[a + 1 < W ? a + 1 : 0] : 0ull;
+		uint64_t hi = 0ull, lo = 0ull;
+#pragma unroll
+		for (int j = 0; j < W; j++) { if (j == a) hi = r.w[j]; if (j == a + 1) lo = r.w[j]; }
 		o.w[i] = bs ? (hi << bs) | (lo >> (64 - bs)) : hi;
 	}
 	return o;
